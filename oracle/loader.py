@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE: ctypes bindings for oracle/liboracle_fq.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle_fq.so")
+REF_DIR = os.path.join(HERE, "_ref")
+
+FLAG_R, FLAG_S, FLAG_E, FLAG_Q = 1, 2, 4, 8
+ARG2_NONE, ARG2_FILE, ARG2_PE = 0, 1, 2
+
+
+class Job(C.Structure):
+    _fields_ = [
+        ("buf1", C.c_char_p), ("n1", C.c_size_t), ("name1", C.c_char_p),
+        ("buf2", C.c_char_p), ("n2", C.c_size_t), ("name2", C.c_char_p),
+        ("arg2_kind", C.c_int), ("flags", C.c_int),
+    ]
+
+
+class Outcome(C.Structure):
+    _fields_ = [
+        ("code", C.c_int32), ("file", C.c_int32), ("record", C.c_uint64), ("line", C.c_uint64),
+        ("aux0", C.c_uint64), ("aux1", C.c_uint64),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("num_reads", C.c_uint64), ("min_rl", C.c_uint64), ("max_rl", C.c_uint64),
+        ("median_rl", C.c_uint64), ("min_qual", C.c_uint64), ("max_qual", C.c_uint64),
+        ("num_rds_counted", C.c_uint64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("exit_status", C.c_int), ("first", Outcome), ("summary", Summary),
+        ("out", C.c_void_p), ("out_len", C.c_size_t), ("err", C.c_void_p), ("err_len", C.c_size_t),
+    ]
+
+
+_lib = None
+
+
+def build():
+    """(Re)build the restatement; also rebuilds oracle/_ref when the reference is present."""
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.fqo_fastq_info.argtypes = [C.POINTER(Job), C.POINTER(Result)]
+        _lib.fqo_fastq_info.restype = C.c_int
+        _lib.fqo_result_free.argtypes = [C.POINTER(Result)]
+        _lib.fqo_qual_range_to_enc.argtypes = [C.c_uint, C.c_uint]
+        _lib.fqo_qual_range_to_enc.restype = C.c_char_p
+    return _lib
+
+
+def parse_args(args):
+    """Split a fastq_info argv (without argv[0]) the way the reference does
+    (src/fastq_info.c:214-267): flags first, then one or two positionals."""
+    flags, pos = 0, []
+    for a in args:
+        if a.startswith("-") and len(a) > 1 and not pos:
+            for ch in a[1:]:
+                flags |= {"r": FLAG_R, "s": FLAG_S, "e": FLAG_E, "q": FLAG_Q}[ch]
+        else:
+            pos.append(a)
+    return flags, pos
+
+
+def fastq_info(buf1, name1, buf2=None, name2=None, arg2_kind=ARG2_NONE, flags=0):
+    """Run the restated fastq_info on in-memory (decompressed) file images.
+    Returns dict(exit, stdout, stderr, first=dict(...), summary=dict(...))."""
+    L = lib()
+    job = Job(buf1, len(buf1), name1.encode(), buf2, len(buf2) if buf2 is not None else 0,
+              name2.encode() if name2 is not None else None, arg2_kind, flags)
+    res = Result()
+    L.fqo_fastq_info(C.byref(job), C.byref(res))
+    out = C.string_at(res.out, res.out_len)
+    err = C.string_at(res.err, res.err_len)
+    d = {
+        "exit": res.exit_status,
+        "stdout": out.decode("latin-1"),
+        "stderr": err.decode("latin-1"),
+        "first": {k: getattr(res.first, k) for k, _ in Outcome._fields_},
+        "summary": {k: getattr(res.summary, k) for k, _ in Summary._fields_},
+    }
+    L.fqo_result_free(C.byref(res))
+    return d
