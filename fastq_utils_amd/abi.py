@@ -1,0 +1,248 @@
+"""ctypes binding of libfqgpu.so (include/fqg.h).
+
+There is deliberately no fallback: if the library cannot be loaded, or no GPU is present,
+every entry point raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfqgpu.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE = 0, 1, 2, 4
+NAME_DEFAULT, NAME_CASAVA18, NAME_INTEGER, NAME_UNDEF = 0, 1, 2, -1
+SPACE_SEQ, SPACE_COLOUR, SPACE_UNDEF = 0, 1, -1
+
+CODE_NAMES = {
+    0: "OK", 1: "TRUNCATED", 2: "WRONG_HEADER", 3: "DUP_NAME", 4: "HDR1_AT", 5: "HDR1_SHORT",
+    6: "SEQ_CHAR", 7: "SEQ_UT", 8: "LEN_SMALL", 9: "HDR2_PLUS", 10: "HDR2_DIFF", 11: "QLEN",
+    12: "QLEN_CS", 13: "UNPAIRED", 14: "NAME_MISMATCH", 15: "LINE_TOO_LONG", 16: "STOP_NUL",
+}
+
+# every symbol include/fqg.h declares (checked by tests/test_abi_symbols.py against the header)
+EXPORTS = [
+    "fqg_open", "fqg_close", "fqg_last_error", "fqg_abi_version", "fqg_set_stream",
+    "fqg_synchronize", "fqg_host_alloc", "fqg_host_free", "fqg_probe_readname_format",
+    "fqg_probe_space", "fqg_probe_first_record", "fqg_acc_create", "fqg_acc_destroy",
+    "fqg_acc_reset", "fqg_acc_read", "fqg_acc_hist_nonzero", "fqg_acc_median", "fqg_acc_export",
+    "fqg_acc_merge", "fqg_validate", "fqg_frame_records", "fqg_profile_enable",
+    "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
+]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class FileState(C.Structure):
+    _fields_ = [("is_pe", C.c_int32), ("readname_format", C.c_int32), ("space", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class FileStats(C.Structure):
+    _fields_ = [("num_rds", C.c_uint64), ("min_rl", C.c_uint64), ("max_rl", C.c_uint64),
+                ("min_qual", C.c_uint64), ("max_qual", C.c_uint64)]
+
+
+class ValidateResult(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_lines", C.c_uint64), ("consumed", C.c_uint64),
+                ("record", C.c_uint64), ("aux0", C.c_uint64), ("aux1", C.c_uint64),
+                ("code", C.c_int32), ("stopped", C.c_int32), ("path", C.c_int32),
+                ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class Record(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("hdr1_len", C.c_uint32), ("seq_len", C.c_uint32),
+                ("hdr2_len", C.c_uint32), ("qual_len", C.c_uint32), ("read_len", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libfqgpu.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+    L.fqg_open.argtypes = [C.c_int, C.POINTER(vp)]
+    L.fqg_close.argtypes = [vp]
+    L.fqg_close.restype = None
+    L.fqg_last_error.argtypes = [vp]
+    L.fqg_last_error.restype = C.c_char_p
+    L.fqg_set_stream.argtypes = [vp, vp]
+    L.fqg_synchronize.argtypes = [vp]
+    L.fqg_host_alloc.argtypes = [vp, sz]
+    L.fqg_host_alloc.restype = vp
+    L.fqg_host_free.argtypes = [vp, vp]
+    L.fqg_host_free.restype = None
+    L.fqg_probe_readname_format.argtypes = [C.c_char_p]
+    L.fqg_probe_space.argtypes = [C.c_char_p]
+    L.fqg_probe_first_record.argtypes = [vp, u64, C.c_int, C.POINTER(FileState)]
+    L.fqg_acc_create.argtypes = [vp, C.POINTER(vp)]
+    L.fqg_acc_destroy.argtypes = [vp]
+    L.fqg_acc_destroy.restype = None
+    L.fqg_acc_reset.argtypes = [vp]
+    L.fqg_acc_read.argtypes = [vp, C.POINTER(FileStats)]
+    L.fqg_acc_hist_nonzero.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), sz, C.POINTER(sz)]
+    L.fqg_acc_median.argtypes = [vp, vp, C.POINTER(u64)]
+    L.fqg_acc_export.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.fqg_acc_merge.argtypes = [vp, vp, sz]
+    L.fqg_validate.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, C.POINTER(FileState), C.c_uint32,
+                               C.POINTER(ValidateResult)]
+    L.fqg_frame_records.argtypes = [vp, u64, u64, vp, C.c_int]
+    L.fqg_profile_enable.argtypes = [vp, C.c_int]
+    L.fqg_profile_reset.argtypes = [vp]
+    L.fqg_profile_read.argtypes = [vp, C.POINTER(KernelTime), sz, C.POINTER(sz)]
+    L.fqg_synth_record_bytes.argtypes = [C.c_uint32]
+    L.fqg_synth_record_bytes.restype = u64
+    L.fqg_synth_fastq.argtypes = [vp, vp, u64, C.c_uint32, u64, u64, C.c_int]
+    _lib = L
+    return L
+
+
+class FqgError(RuntimeError):
+    pass
+
+
+def probe_first_record(image: bytes, is_pe: bool) -> FileState:
+    st = FileState()
+    st.is_pe = int(is_pe)
+    st.readname_format = NAME_UNDEF
+    st.space = SPACE_UNDEF
+    load().fqg_probe_first_record(image, len(image), int(is_pe), C.byref(st))
+    return st
+
+
+class Accumulator:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(load().fqg_acc_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            load().fqg_acc_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.ctx._check(load().fqg_acc_reset(self.h))
+
+    def read(self):
+        s = FileStats()
+        self.ctx._check(load().fqg_acc_read(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in FileStats._fields_}
+
+    def hist(self):
+        n = C.c_size_t()
+        self.ctx._check(load().fqg_acc_hist_nonzero(self.h, None, None, 0, C.byref(n)))
+        lens = (C.c_uint64 * max(1, n.value))()
+        cnts = (C.c_uint64 * max(1, n.value))()
+        self.ctx._check(load().fqg_acc_hist_nonzero(self.h, lens, cnts, n.value, C.byref(n)))
+        return {int(lens[i]): int(cnts[i]) for i in range(n.value)}
+
+    def median(self, other=None):
+        m = C.c_uint64()
+        self.ctx._check(load().fqg_acc_median(self.h, other.h if other else None, C.byref(m)))
+        return m.value
+
+    def export(self):
+        n = C.c_size_t()
+        self.ctx._check(load().fqg_acc_export(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self.ctx._check(load().fqg_acc_export(self.h, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value]
+
+    def merge(self, blob: bytes):
+        self.ctx._check(load().fqg_acc_merge(self.h, blob, len(blob)))
+
+
+class Context:
+    """One GPU context (fqg_ctx).  Raises if there is no GPU: there is no CPU path."""
+
+    def __init__(self, device=0):
+        L = load()
+        h = C.c_void_p()
+        rc = L.fqg_open(device, C.byref(h))
+        if rc != 0:
+            raise FqgError(f"fqg_open({device}) failed with {rc}: no MI355X visible?")
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FqgError(f"libfqgpu error {rc}: {load().fqg_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            load().fqg_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def accumulator(self):
+        return Accumulator(self)
+
+    def set_stream(self, stream_ptr):
+        self._check(load().fqg_set_stream(self.h, stream_ptr))
+
+    def synchronize(self):
+        self._check(load().fqg_synchronize(self.h))
+
+    def validate(self, image, acc, state, final=True, flags=0, nbytes=None, mem=None):
+        """image: bytes (host) or an int device pointer (then nbytes is required)."""
+        res = ValidateResult()
+        if isinstance(image, (bytes, bytearray)):
+            buf = (C.c_char * len(image)).from_buffer_copy(image) if len(image) else None
+            n = len(image)
+            rc = load().fqg_validate(self.h, acc.h if acc else None, buf, n, MEM_HOST, int(final),
+                                     C.byref(state), flags, C.byref(res))
+        else:
+            rc = load().fqg_validate(self.h, acc.h if acc else None, C.c_void_p(int(image)), nbytes,
+                                     MEM_DEVICE if mem is None else mem, int(final), C.byref(state),
+                                     flags, C.byref(res))
+        self._check(rc)
+        return res.as_dict()
+
+    def frame_records(self, first, count):
+        out = (Record * max(1, count))()
+        self._check(load().fqg_frame_records(self.h, first, count, out, MEM_HOST))
+        return [{k: getattr(out[i], k) for k, _ in Record._fields_ if k != "reserved"}
+                for i in range(count)]
+
+    def profile(self, on=True):
+        self._check(load().fqg_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._check(load().fqg_profile_reset(self.h))
+
+    def profile_read(self):
+        n = C.c_size_t()
+        out = (KernelTime * 64)()
+        self._check(load().fqg_profile_read(self.h, out, 64, C.byref(n)))
+        return {out[i].name.decode(): (int(out[i].launches), float(out[i].total_ms))
+                for i in range(min(64, n.value))}
+
+    def synth_fastq(self, device_ptr, n_records, read_len=150, first_index=0, seed=12345, mate=1):
+        self._check(load().fqg_synth_fastq(self.h, C.c_void_p(int(device_ptr)), n_records, read_len,
+                                           first_index, seed, mate))
+
+
+def synth_record_bytes(read_len=150):
+    return int(load().fqg_synth_record_bytes(read_len))

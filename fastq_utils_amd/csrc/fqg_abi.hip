@@ -1,0 +1,659 @@
+// fqg_abi.hip - the C-ABI of libfqgpu.so (include/fqg.h): contexts, workspaces, launches.
+// Single translation unit: the kernels are included so that launch sites see them directly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fqg_device.h"
+#include "fqg_kernels.hip"
+
+using namespace fqg;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct ProfEvent {
+  int slot;
+  hipEvent_t a, b;
+};
+
+struct ProfSlot {
+  std::string name;
+  uint64_t launches = 0;
+  double ms = 0;
+};
+
+}  // namespace
+
+struct fqg_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int cu_count = 256;
+
+  DevBuf image;       // staging for host images
+  DevBuf tile_counts; // u32 per tile
+  DevBuf tile_local;  // u32 per tile
+  DevBuf span_sums;   // u64 per span
+  DevBuf line_end;    // u64 per line (+1)
+  DevBuf records;     // fqg_record staging for fqg_frame_records
+  CallState* d_cs = nullptr;
+  CallState* h_cs = nullptr;  // pinned
+  uint64_t* h_scalar = nullptr;  // pinned, 8 x u64
+
+  FrameView frame{};
+  bool frame_valid = false;
+
+  bool profiling = false;
+  std::vector<ProfSlot> slots;
+  std::vector<ProfEvent> pending;
+  std::vector<hipEvent_t> free_events;
+};
+
+struct fqg_acc {
+  fqg_ctx* ctx = nullptr;
+  AccState* d_state = nullptr;
+  unsigned long long* d_hist = nullptr;  // FQG_MAX_READ_LENGTH bins
+  std::vector<unsigned long long> h_hist;
+};
+
+namespace {
+
+int fail(fqg_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIP_TRY(c, call)                                              \
+  do {                                                                \
+    hipError_t e__ = (call);                                          \
+    if (e__ != hipSuccess) return fail((c), FQG_ERR_HIP, #call, e__); \
+  } while (0)
+
+int ensure(fqg_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, FQG_ERR_HIP, "hipStreamSynchronize", e);
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&b.p, want);
+  }
+  if (e != hipSuccess) return fail(c, FQG_ERR_NOMEM, "hipMalloc", e);
+  b.cap = want;
+  return 0;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+int prof_slot(fqg_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->slots.size(); ++i)
+    if (c->slots[i].name == name) return (int)i;
+  ProfSlot s;
+  s.name = name;
+  c->slots.push_back(s);
+  return (int)c->slots.size() - 1;
+}
+
+hipEvent_t get_event(fqg_ctx* c) {
+  if (!c->free_events.empty()) {
+    hipEvent_t e = c->free_events.back();
+    c->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+// fold finished event pairs into the per-kernel totals (call after the stream is idle)
+void prof_drain(fqg_ctx* c) {
+  for (auto& p : c->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      c->slots[p.slot].launches++;
+      c->slots[p.slot].ms += ms;
+    }
+    c->free_events.push_back(p.a);
+    c->free_events.push_back(p.b);
+  }
+  c->pending.clear();
+}
+
+struct ProfScope {
+  fqg_ctx* c;
+  ProfEvent ev{};
+  bool on;
+  ProfScope(fqg_ctx* ctx, const char* name) : c(ctx), on(ctx->profiling) {
+    if (!on) return;
+    ev.slot = prof_slot(c, name);
+    ev.a = get_event(c);
+    ev.b = get_event(c);
+    (void)hipEventRecord(ev.a, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, c->stream);
+    c->pending.push_back(ev);
+  }
+};
+
+int grid_for_waves(fqg_ctx* c, uint64_t n_records) {
+  // persistent wave-per-record kernels: enough workgroups to fill every CU 8 deep
+  uint64_t want = (n_records + (kBlock / kWave) - 1) / (kBlock / kWave);
+  uint64_t cap = (uint64_t)c->cu_count * 8;
+  return (int)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+}  // namespace
+
+extern "C" {
+
+int fqg_abi_version(void) { return FQG_ABI_VERSION; }
+
+int fqg_open(int device_ordinal, fqg_ctx** out) {
+  if (!out) return FQG_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FQG_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= n) return FQG_ERR_ARG;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return FQG_ERR_NO_DEVICE;
+  fqg_ctx* c = new fqg_ctx();
+  c->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return FQG_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  if (hipMalloc((void**)&c->d_cs, sizeof(CallState)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_cs, sizeof(CallState), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_scalar, 8 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+    fqg_close(c);
+    return FQG_ERR_NOMEM;
+  }
+  *out = c;
+  return 0;
+}
+
+void fqg_close(fqg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  prof_drain(c);
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  release(c->image);
+  release(c->tile_counts);
+  release(c->tile_local);
+  release(c->span_sums);
+  release(c->line_end);
+  release(c->records);
+  if (c->d_cs) (void)hipFree(c->d_cs);
+  if (c->h_cs) (void)hipHostFree(c->h_cs);
+  if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* fqg_last_error(const fqg_ctx* c) { return c ? c->err.c_str() : "no context"; }
+
+int fqg_set_stream(fqg_ctx* c, void* s) {
+  if (!c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return 0;
+}
+
+int fqg_synchronize(fqg_ctx* c) {
+  if (!c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void* fqg_host_alloc(fqg_ctx* c, size_t bytes) {
+  void* p = nullptr;
+  if (!c || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void fqg_host_free(fqg_ctx* c, void* p) {
+  (void)c;
+  if (p) (void)hipHostFree(p);
+}
+
+// ---- accumulator --------------------------------------------------------------------------
+int fqg_acc_reset(fqg_acc* a) {
+  if (!a) return FQG_ERR_ARG;
+  fqg_ctx* c = a->ctx;
+  AccState init;
+  init.num_rds = 0;
+  init.min_rl = FQG_MAX_READ_LENGTH;
+  init.max_rl = 0;
+  init.min_qbyte = 255;
+  init.max_qbyte = 0;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(a->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemset(a->d_hist, 0, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH));
+  return 0;
+}
+
+int fqg_acc_create(fqg_ctx* c, fqg_acc** out) {
+  if (!c || !out) return FQG_ERR_ARG;
+  fqg_acc* a = new fqg_acc();
+  a->ctx = c;
+  if (hipMalloc((void**)&a->d_state, sizeof(AccState)) != hipSuccess ||
+      hipMalloc((void**)&a->d_hist, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH) != hipSuccess) {
+    fqg_acc_destroy(a);
+    return fail(c, FQG_ERR_NOMEM, "accumulator allocation");
+  }
+  int rc = fqg_acc_reset(a);
+  if (rc) {
+    fqg_acc_destroy(a);
+    return rc;
+  }
+  *out = a;
+  return 0;
+}
+
+void fqg_acc_destroy(fqg_acc* a) {
+  if (!a) return;
+  if (a->d_state) (void)hipFree(a->d_state);
+  if (a->d_hist) (void)hipFree(a->d_hist);
+  delete a;
+}
+
+static int acc_fetch_state(fqg_acc* a, AccState* s) {
+  fqg_ctx* c = a->ctx;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(s, a->d_state, sizeof(AccState), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// the reference widens each quality char through (unsigned int): bytes >= 0x80 sign-extend
+static uint64_t widen_qual(unsigned b) { return b < 128 ? b : (0xFFFFFF00ull | b); }
+
+int fqg_acc_read(fqg_acc* a, fqg_file_stats* out) {
+  if (!a || !out) return FQG_ERR_ARG;
+  AccState s;
+  int rc = acc_fetch_state(a, &s);
+  if (rc) return rc;
+  out->num_rds = s.num_rds;
+  out->min_rl = s.min_rl;
+  out->max_rl = s.max_rl;
+  // FASTQ_FILE starts at min_qual=126, max_qual=0 (src/fastq.c:174-175)
+  if (s.min_qbyte <= s.max_qbyte) {
+    out->min_qual = std::min<uint64_t>(FQG_MAX_PHRED_QUAL, widen_qual(s.min_qbyte));
+    out->max_qual = widen_qual(s.max_qbyte);
+  } else {
+    out->min_qual = FQG_MAX_PHRED_QUAL;
+    out->max_qual = 0;
+  }
+  return 0;
+}
+
+static int acc_fetch_hist(fqg_acc* a) {
+  fqg_ctx* c = a->ctx;
+  a->h_hist.resize(FQG_MAX_READ_LENGTH);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(a->h_hist.data(), a->d_hist, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH,
+                       hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fqg_acc_hist_nonzero(fqg_acc* a, uint64_t* lens, uint64_t* counts, size_t cap, size_t* n) {
+  if (!a || !n) return FQG_ERR_ARG;
+  int rc = acc_fetch_hist(a);
+  if (rc) return rc;
+  size_t k = 0;
+  for (size_t i = 0; i < (size_t)FQG_MAX_READ_LENGTH; ++i)
+    if (a->h_hist[i]) {
+      if (k < cap && lens && counts) {
+        lens[k] = i;
+        counts[k] = a->h_hist[i];
+      }
+      ++k;
+    }
+  *n = k;
+  return 0;
+}
+
+// median_rl(), reference src/fastq_info.c:39-55
+int fqg_acc_median(fqg_acc* a, fqg_acc* b, uint64_t* median) {
+  if (!a || !median) return FQG_ERR_ARG;
+  AccState sa, sb;
+  int rc = acc_fetch_state(a, &sa);
+  if (rc) return rc;
+  if (sa.num_rds == 1 && !b) {
+    *median = sa.min_rl;
+    return 0;
+  }
+  uint64_t nreads = sa.num_rds;
+  if ((rc = acc_fetch_hist(a))) return rc;
+  if (b) {
+    if ((rc = acc_fetch_state(b, &sb))) return rc;
+    if ((rc = acc_fetch_hist(b))) return rc;
+    nreads += sb.num_rds;
+  }
+  unsigned long long ctr = 0;
+  uint64_t crl = 1;
+  while (crl < FQG_MAX_READ_LENGTH) {
+    ctr += a->h_hist[crl];
+    if (b) ctr += b->h_hist[crl];
+    if (sa.num_rds > 1 && ctr > nreads / 2) break;
+    ++crl;
+  }
+  *median = crl;
+  return 0;
+}
+
+// export layout: AccState | u64 n | n x (u64 len, u64 count)
+int fqg_acc_export(fqg_acc* a, void* buf, size_t cap, size_t* used) {
+  if (!a || !used) return FQG_ERR_ARG;
+  AccState s;
+  int rc = acc_fetch_state(a, &s);
+  if (rc) return rc;
+  if ((rc = acc_fetch_hist(a))) return rc;
+  std::vector<uint64_t> pairs;
+  for (size_t i = 0; i < (size_t)FQG_MAX_READ_LENGTH; ++i)
+    if (a->h_hist[i]) {
+      pairs.push_back(i);
+      pairs.push_back(a->h_hist[i]);
+    }
+  const size_t need = sizeof(AccState) + 8 + pairs.size() * 8;
+  *used = need;
+  if (!buf || cap < need) return buf ? FQG_ERR_ARG : 0;
+  char* w = (char*)buf;
+  memcpy(w, &s, sizeof(s));
+  const uint64_t n = pairs.size() / 2;
+  memcpy(w + sizeof(s), &n, 8);
+  if (n) memcpy(w + sizeof(s) + 8, pairs.data(), pairs.size() * 8);
+  return 0;
+}
+
+int fqg_acc_merge(fqg_acc* a, const void* buf, size_t used) {
+  if (!a || !buf || used < sizeof(AccState) + 8) return FQG_ERR_ARG;
+  fqg_ctx* c = a->ctx;
+  AccState mine, other;
+  int rc = acc_fetch_state(a, &mine);
+  if (rc) return rc;
+  const char* r = (const char*)buf;
+  memcpy(&other, r, sizeof(other));
+  uint64_t n;
+  memcpy(&n, r + sizeof(other), 8);
+  if (used < sizeof(AccState) + 8 + n * 16) return FQG_ERR_ARG;
+  mine.num_rds += other.num_rds;
+  mine.min_rl = std::min(mine.min_rl, other.min_rl);
+  mine.max_rl = std::max(mine.max_rl, other.max_rl);
+  mine.min_qbyte = std::min(mine.min_qbyte, other.min_qbyte);
+  mine.max_qbyte = std::max(mine.max_qbyte, other.max_qbyte);
+  HIP_TRY(c, hipMemcpy(a->d_state, &mine, sizeof(mine), hipMemcpyHostToDevice));
+  if (n) {
+    if ((rc = acc_fetch_hist(a))) return rc;
+    const uint64_t* pr = (const uint64_t*)(r + sizeof(other) + 8);
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t len = pr[2 * i], cnt = pr[2 * i + 1];
+      if (len >= (uint64_t)FQG_MAX_READ_LENGTH) return FQG_ERR_ARG;
+      a->h_hist[len] += cnt;
+      HIP_TRY(c, hipMemcpy(a->d_hist + len, &a->h_hist[len], 8, hipMemcpyHostToDevice));
+    }
+  }
+  return 0;
+}
+
+// ---- framing + validation -------------------------------------------------------------------
+int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, int mem, int final,
+                 const fqg_file_state* st, uint32_t flags, fqg_validate_result* out) {
+  if (!c || !out || !st || (nbytes && !image)) return FQG_ERR_ARG;
+  if (!(flags & FQG_VALIDATE_NO_STATS) && !acc) return fail(c, FQG_ERR_ARG, "fqg_validate: acc is NULL");
+  if (mem != FQG_MEM_HOST && mem != FQG_MEM_DEVICE) return FQG_ERR_ARG;
+  if (flags & FQG_VALIDATE_NO_STATS) acc = nullptr;
+  memset(out, 0, sizeof(*out));
+  c->frame_valid = false;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (nbytes == 0) return 0;
+  if (nbytes >= (1ull << 46)) return fail(c, FQG_ERR_ARG, "image too large");
+
+  int rc;
+  const uint8_t* d_img;
+  if (mem == FQG_MEM_HOST) {
+    if ((rc = ensure(c, c->image, nbytes + 64))) return rc;
+    ProfScope ps(c, "h2d_image");
+    HIP_TRY(c, hipMemcpyAsync(c->image.p, image, nbytes, hipMemcpyHostToDevice, c->stream));
+    d_img = (const uint8_t*)c->image.p;
+  } else {
+    if (((uintptr_t)image & 15u) != 0) return fail(c, FQG_ERR_ARG, "device image must be 16-byte aligned");
+    d_img = (const uint8_t*)image;
+  }
+
+  const uint64_t n_tiles64 = (nbytes + kTileBytes - 1) / kTileBytes;
+  const uint32_t n_tiles = (uint32_t)n_tiles64;
+  const uint32_t n_spans = (n_tiles + kScanSpan - 1) / kScanSpan;
+  if ((rc = ensure(c, c->tile_counts, (size_t)n_tiles * 4))) return rc;
+  if ((rc = ensure(c, c->tile_local, (size_t)n_tiles * 4))) return rc;
+  if ((rc = ensure(c, c->span_sums, (size_t)n_spans * 8))) return rc;
+
+  CallState init;
+  memset(&init, 0, sizeof(init));
+  init.first_key = ~0ull;
+  init.stop_record = ~0ull;
+  *c->h_cs = init;
+  HIP_TRY(c, hipMemcpyAsync(c->d_cs, c->h_cs, sizeof(CallState), hipMemcpyHostToDevice, c->stream));
+
+  {
+    ProfScope ps(c, "k_count_nl");
+    hipLaunchKernelGGL(k_count_nl, dim3(n_tiles), dim3(kBlock), 0, c->stream, d_img, nbytes,
+                       (uint32_t*)c->tile_counts.p, c->d_cs);
+  }
+  {
+    ProfScope ps(c, "k_scan");
+    hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
+                       n_tiles, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p);
+    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
+                       n_spans, d_img, nbytes, c->d_cs);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint64_t n_newlines = c->h_cs->n_newlines;
+  const bool last_nl = c->h_cs->last_byte_is_nl != 0;
+  const uint32_t img_flags = c->h_cs->flags;
+  const uint64_t n_lines_all = n_newlines + (last_nl ? 0 : 1);
+  // an unterminated last line is only a line when nothing more can follow
+  const uint64_t usable = (final || last_nl) ? n_lines_all : n_newlines;
+  uint64_t n_records = usable / 4;
+  const uint64_t leftover = usable % 4;
+
+  if ((rc = ensure(c, c->line_end, (size_t)(n_lines_all + 1) * 8))) return rc;
+  {
+    ProfScope ps(c, "k_lines");
+    hipLaunchKernelGGL(k_lines, dim3(n_tiles), dim3(kBlock), 0, c->stream, d_img, nbytes,
+                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
+                       (uint64_t*)c->line_end.p, c->d_cs);
+  }
+  FrameView fv;
+  fv.img = d_img;
+  fv.nbytes = nbytes;
+  fv.line_end = (const uint64_t*)c->line_end.p;
+  fv.n_lines = n_lines_all;
+  fv.n_records = n_records;
+
+  // a record that starts with NUL ends the file silently (src/fastq.c:250)
+  bool tail_is_stop = false;
+  if (img_flags & kFlagNul) {
+    if (n_records) {
+      ProfScope ps(c, "k_find_stop");
+      hipLaunchKernelGGL(k_find_stop, dim3((unsigned)((n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                         c->stream, fv, c->d_cs);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+    if (leftover && final) {
+      // first byte of the incomplete trailing group
+      const uint64_t* le = (const uint64_t*)c->line_end.p;
+      if (n_records) {
+        HIP_TRY(c, hipMemcpyAsync(&c->h_scalar[0], le + 4 * n_records - 1, 8, hipMemcpyDeviceToHost, c->stream));
+      } else c->h_scalar[0] = ~0ull;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      const uint64_t at = c->h_scalar[0] + 1;
+      uint8_t b = 1;
+      HIP_TRY(c, hipMemcpy(&b, d_img + at, 1, hipMemcpyDeviceToHost));
+      tail_is_stop = (b == 0);
+    } else {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->h_cs->stop_record < n_records) {
+      n_records = c->h_cs->stop_record;
+      out->stopped = 1;
+    }
+    fv.n_records = n_records;
+  }
+
+  if (n_records) {
+    ProfScope ps(c, "k_validate_exact");
+    hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
+                       st->is_pe, st->readname_format, st->space, (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u,
+                       acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr, c->d_cs, kNoRecord);
+    out->path = 1;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+  if (n_records) {
+    HIP_TRY(c, hipMemcpyAsync(&c->h_scalar[1], (const uint64_t*)c->line_end.p + 4 * n_records - 1, 8,
+                              hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out->n_records = n_records;
+  out->n_lines = n_lines_all;
+  out->consumed = n_records ? c->h_scalar[1] + 1 : 0;
+  if (out->consumed > nbytes) out->consumed = nbytes;  // unterminated last line
+
+  if (c->h_cs->first_key != ~0ull) {
+    out->record = c->h_cs->first_key >> 8;
+    out->code = (int32_t)(c->h_cs->first_key & 0xFF);
+    hipLaunchKernelGGL(k_validate_exact, dim3(1), dim3(kBlock), 0, c->stream, fv, st->is_pe,
+                       st->readname_format, st->space, 1u, (AccState*)nullptr, (unsigned long long*)nullptr,
+                       c->d_cs, out->record);
+    HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->aux0 = c->h_cs->aux0;
+    out->aux1 = c->h_cs->aux1;
+  } else if (final && leftover && !out->stopped && !tail_is_stop) {
+    // src/fastq.c:254-257: fewer than four lines left
+    out->code = FQG_E_TRUNCATED;
+    out->record = n_records;
+  } else if (tail_is_stop && !out->stopped) {
+    out->stopped = 1;
+  }
+  c->frame = fv;
+  c->frame_valid = true;
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
+int fqg_frame_records(fqg_ctx* c, uint64_t first, uint64_t count, fqg_record* out, int mem) {
+  if (!c || (!out && count)) return FQG_ERR_ARG;
+  if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  if (first + count > c->frame.n_records) return fail(c, FQG_ERR_ARG, "record range outside the frame");
+  if (!count) return 0;
+  int rc;
+  fqg_record* d_out = out;
+  if (mem == FQG_MEM_HOST) {
+    if ((rc = ensure(c, c->records, count * sizeof(fqg_record)))) return rc;
+    d_out = (fqg_record*)c->records.p;
+  }
+  {
+    ProfScope ps(c, "k_records");
+    hipLaunchKernelGGL(k_records, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                       c->frame, first, count, d_out);
+  }
+  if (mem == FQG_MEM_HOST) {
+    HIP_TRY(c, hipMemcpyAsync(out, d_out, count * sizeof(fqg_record), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+int fqg_profile_enable(fqg_ctx* c, int on) {
+  if (!c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  c->profiling = on != 0;
+  return 0;
+}
+int fqg_profile_reset(fqg_ctx* c) {
+  if (!c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  for (auto& s : c->slots) {
+    s.launches = 0;
+    s.ms = 0;
+  }
+  return 0;
+}
+int fqg_profile_read(fqg_ctx* c, fqg_kernel_time* out, size_t cap, size_t* n) {
+  if (!c || !n) return FQG_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  size_t k = 0;
+  for (auto& s : c->slots) {
+    if (k < cap && out) {
+      memset(&out[k], 0, sizeof(out[k]));
+      strncpy(out[k].name, s.name.c_str(), sizeof(out[k].name) - 1);
+      out[k].launches = s.launches;
+      out[k].total_ms = s.ms;
+    }
+    ++k;
+  }
+  *n = k;
+  return 0;
+}
+
+// ---- synthetic data -------------------------------------------------------------------------
+uint64_t fqg_synth_record_bytes(uint32_t read_len) { return (uint64_t)kSynthHdr + 2ull * (read_len + 1) + 2; }
+
+int fqg_synth_fastq(fqg_ctx* c, void* device_out, uint64_t n_records, uint32_t read_len, uint64_t first_index,
+                    uint64_t seed, int mate) {
+  if (!c || !device_out || read_len == 0 || read_len >= FQG_MAX_READ_LENGTH - 2) return FQG_ERR_ARG;
+  if (((uintptr_t)device_out & 15u) != 0) return fail(c, FQG_ERR_ARG, "output must be 16-byte aligned");
+  if (first_index + n_records > 9999999999ull) return fail(c, FQG_ERR_ARG, "index does not fit 10 digits");
+  if (!n_records) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t total = n_records * fqg_synth_record_bytes(read_len);
+  const uint64_t threads = (total + 15) / 16;
+  const uint64_t blocks = std::min<uint64_t>((threads + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 32);
+  ProfScope ps(c, "k_synth");
+  hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, (uint8_t*)device_out, n_records,
+                     read_len, first_index, seed, mate == 2 ? 2 : 1);
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

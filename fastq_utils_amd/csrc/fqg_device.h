@@ -1,0 +1,50 @@
+// fqg_device.h - device-side data structures shared by the kernels and the C-ABI host code.
+// gfx950 only (64-lane wavefronts are assumed throughout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fqg.h"
+
+namespace fqg {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;                 // 4 waves
+constexpr int kTileBytes = 16384;           // bytes framed by one workgroup
+constexpr int kPieces = kTileBytes / (kBlock * 16);  // 16-byte pieces per thread per tile
+constexpr int kScanSpan = 4096;             // tile counts scanned by one workgroup
+constexpr uint64_t kNoRecord = ~0ull;
+
+// image-level flags raised by the framing pass
+constexpr uint32_t kFlagNul = 1u;       // a NUL byte somewhere in the image
+constexpr uint32_t kFlagCr = 2u;        // a '\r' somewhere in the image
+constexpr uint32_t kFlagSuspect = 4u;   // the tiled validator saw a record it cannot vouch for
+
+// Scalars of one fqg_validate() call.  Lives in device memory; the host copies it back once.
+struct CallState {
+  unsigned long long first_key;   // min over failing records of (record << 8 | code)
+  unsigned long long stop_record; // min record whose first line starts with NUL
+  unsigned long long n_newlines;  // total '\n' in the image
+  unsigned long long aux0, aux1;  // filled by the explain launch for first_key's record
+  unsigned int flags;
+  unsigned int last_byte_is_nl;
+};
+
+// Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).
+struct AccState {
+  unsigned long long num_rds;
+  unsigned long long min_rl;   // init FQG_MAX_READ_LENGTH
+  unsigned long long max_rl;   // init 0
+  unsigned int min_qbyte;      // init 255 (unsigned-byte domain; mapped at read-out)
+  unsigned int max_qbyte;      // init 0
+};
+
+struct FrameView {
+  const uint8_t* img;
+  uint64_t nbytes;
+  const uint64_t* line_end;  // per line: offset of its '\n', or nbytes for an unterminated last line
+  uint64_t n_lines;
+  uint64_t n_records;
+};
+
+}  // namespace fqg

@@ -1,0 +1,638 @@
+// fqg_kernels.hip - HIP kernels for gfx950 (MI355X): FASTQ framing and record validation.
+//
+// Pipeline of one fqg_validate() call:
+//   k_count_nl   one workgroup per 16 KiB tile: count '\n', raise NUL / CR flags
+//   k_scan_a/b   exclusive prefix over the tile counts (two small launches)
+//   k_lines      one workgroup per tile: write the offset of every '\n' into line_end[]
+//   k_validate_exact  one wavefront per record: the complete check sequence of
+//                fastq_validate_entry (reference src/fastq.c:300-392) with ballots over 64-byte
+//                slices of each line; statistics kept in registers and flushed once per wave
+//
+// Everything here is byte / integer work bounded by HBM bandwidth; there is no MFMA use.
+#include "fqg_device.h"
+
+namespace fqg {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// 0x80 in every byte of w that equals the corresponding byte of pat (exact, no borrow leaks)
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t pat) {
+  const uint32_t x = w ^ pat;
+  const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+// gather the four 0x80 marks of a word into bits 0..3
+__device__ __forceinline__ uint32_t mark_bits(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;  // valid in lane 0
+}
+// inclusive scan across the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+// the alphabet of reference src/fastq.c:319-322: ACGTUacgtu0123nN.
+__device__ __forceinline__ bool is_base(uint32_t c) {
+  // bits for '.'(46) '0'..'3'(48..51) in the low word; letters in the high word (c-64)
+  constexpr uint64_t lo = (1ull << 46) | (0xFull << 48);
+  constexpr uint64_t hi = (1ull << ('A' - 64)) | (1ull << ('C' - 64)) | (1ull << ('G' - 64)) |
+                          (1ull << ('T' - 64)) | (1ull << ('U' - 64)) | (1ull << ('N' - 64)) |
+                          (1ull << ('a' - 64)) | (1ull << ('c' - 64)) | (1ull << ('g' - 64)) |
+                          (1ull << ('t' - 64)) | (1ull << ('u' - 64)) | (1ull << ('n' - 64));
+  const uint64_t w = (c & 64u) ? hi : lo;
+  return c < 128u && ((w >> (c & 63u)) & 1ull);
+}
+
+// ------------------------------------------------------------------------------------------
+// framing: newline census per tile
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_count_nl(const uint8_t* __restrict__ img, uint64_t n,
+                                                     uint32_t* __restrict__ tile_counts,
+                                                     CallState* __restrict__ cs) {
+  __shared__ uint32_t s_cnt[kBlock / kWave];
+  __shared__ uint32_t s_flag[kBlock / kWave];
+  const uint64_t base = (uint64_t)blockIdx.x * kTileBytes;
+  uint32_t cnt = 0, nul = 0, cr = 0;
+#pragma unroll
+  for (int u = 0; u < kPieces; ++u) {
+    const uint64_t off = base + ((uint64_t)u * kBlock + threadIdx.x) * 16;
+    if (off + 16 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(img + off);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cnt += __popc(eq_bytes(w[k], 0x0A0A0A0Au));
+        nul |= eq_bytes(w[k], 0u);
+        cr |= eq_bytes(w[k], 0x0D0D0D0Du);
+      }
+    } else if (off < n) {
+      for (uint64_t i = off; i < n; ++i) {
+        const uint32_t c = img[i];
+        cnt += (c == '\n');
+        nul |= (c == 0);
+        cr |= (c == '\r');
+      }
+    }
+  }
+  uint32_t fl = (nul ? kFlagNul : 0u) | (cr ? kFlagCr : 0u);
+  cnt = wave_sum(cnt);
+  const uint64_t anyn = __ballot(fl & kFlagNul), anyc = __ballot(fl & kFlagCr);
+  if (lane_id() == 0) {
+    s_cnt[threadIdx.x >> 6] = cnt;
+    s_flag[threadIdx.x >> 6] = (anyn ? kFlagNul : 0u) | (anyc ? kFlagCr : 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0, f = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      t += s_cnt[w];
+      f |= s_flag[w];
+    }
+    tile_counts[blockIdx.x] = t;
+    if (f) atomicOr(&cs->flags, f);
+  }
+}
+
+// block-wide exclusive scan of one value per thread (kBlock threads); returns the exclusive
+// prefix, *total gets the block sum.  Uses 2 barriers.
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_wave /*[4]*/,
+                                                    uint32_t* total) {
+  const uint32_t incl = wave_scan_incl(v);
+  if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    const uint32_t t = s_wave[w];
+    if (w < (int)(threadIdx.x >> 6)) before += t;
+    all += t;
+  }
+  __syncthreads();
+  *total = all;
+  return before + incl - v;
+}
+
+// phase A: each workgroup scans kScanSpan tile counts (16 per thread)
+__global__ __launch_bounds__(kBlock) void k_scan_a(const uint32_t* __restrict__ counts,
+                                                   uint32_t n_tiles,
+                                                   uint32_t* __restrict__ local_excl,
+                                                   unsigned long long* __restrict__ block_sums) {
+  __shared__ uint32_t s_wave[kBlock / kWave];
+  const uint32_t first = blockIdx.x * kScanSpan + threadIdx.x * 16;
+  uint32_t v[16];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    v[k] = (first + k < n_tiles) ? counts[first + k] : 0u;
+    sum += v[k];
+  }
+  uint32_t total;
+  uint32_t run = block_scan_excl(sum, s_wave, &total);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (first + k < n_tiles) local_excl[first + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// phase B: one workgroup turns the span sums into exclusive prefixes in place
+__global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restrict__ block_sums,
+                                                   uint32_t n_blocks, const uint8_t* __restrict__ img,
+                                                   uint64_t n, CallState* __restrict__ cs) {
+  __shared__ unsigned long long s_part[kBlock];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += kBlock) {
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = (i < n_blocks) ? block_sums[i] : 0ull;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    // Hillis-Steele over 256 entries; cheap, runs once per call
+    for (int d = 1; d < kBlock; d <<= 1) {
+      unsigned long long o = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0ull;
+      __syncthreads();
+      s_part[threadIdx.x] += o;
+      __syncthreads();
+    }
+    const unsigned long long carry = s_carry;
+    if (i < n_blocks) block_sums[i] = carry + s_part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) s_carry = carry + s_part[kBlock - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    cs->n_newlines = s_carry;
+    cs->last_byte_is_nl = (n > 0 && img[n - 1] == '\n') ? 1u : 0u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// framing: line index
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_lines(const uint8_t* __restrict__ img, uint64_t n,
+                                                  const uint32_t* __restrict__ tile_local,
+                                                  const unsigned long long* __restrict__ span_excl,
+                                                  uint64_t* __restrict__ line_end,
+                                                  const CallState* __restrict__ cs) {
+  __shared__ uint32_t s_wave[kBlock / kWave];
+  const uint32_t tile = blockIdx.x;
+  uint64_t rank0 = span_excl[tile / kScanSpan] + tile_local[tile];
+  const uint64_t base = (uint64_t)tile * kTileBytes;
+#pragma unroll
+  for (int u = 0; u < kPieces; ++u) {
+    const uint64_t off = base + ((uint64_t)u * kBlock + threadIdx.x) * 16;
+    uint32_t m = 0;  // bit j: byte off+j is '\n'
+    if (off + 16 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(img + off);
+      m = mark_bits(eq_bytes(v.x, 0x0A0A0A0Au)) | (mark_bits(eq_bytes(v.y, 0x0A0A0A0Au)) << 4) |
+          (mark_bits(eq_bytes(v.z, 0x0A0A0A0Au)) << 8) | (mark_bits(eq_bytes(v.w, 0x0A0A0A0Au)) << 12);
+    } else if (off < n) {
+      for (uint64_t i = off; i < n; ++i) m |= (img[i] == '\n') ? (1u << (i - off)) : 0u;
+    }
+    uint32_t total;
+    uint32_t r = block_scan_excl(__popc(m), s_wave, &total);
+    while (m) {
+      const int j = __builtin_ctz(m);
+      m &= m - 1;
+      line_end[rank0 + r++] = off + j;
+    }
+    rank0 += total;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl)
+    line_end[cs->n_newlines] = n;  // an unterminated last line ends at the end of the image
+}
+
+// ------------------------------------------------------------------------------------------
+// exact validator: one wavefront per record
+// ------------------------------------------------------------------------------------------
+template <class Pred>
+__device__ __forceinline__ uint32_t wave_find(const uint8_t* __restrict__ p, uint32_t from,
+                                              uint32_t to, Pred pred) {
+  for (uint32_t b = from; b < to; b += kWave) {
+    const uint32_t i = b + lane_id();
+    const bool hit = (i < to) && pred((uint32_t)p[i]);
+    const uint64_t m = __ballot(hit);
+    if (m) return b + (uint32_t)__builtin_ctzll(m);
+  }
+  return to;
+}
+
+struct Line {
+  const uint8_t* p;  // first byte
+  uint32_t len;      // bytes before the '\n' (or before the end of the image)
+  uint32_t nl;       // 1 if terminated by '\n'
+};
+
+// Length and start (relative to p) of the canonical read name of a header line, following
+// fastq_get_readname (reference src/fastq.c:488-512).  cstr = C-string length of the line.
+__device__ __forceinline__ uint32_t canonical_name_len(const Line& h, uint32_t cstr, int fmt, int is_pe) {
+  // S = line[1 .. cstr): what strncpy(rn, &hdr[1], ...) copies
+  const uint32_t L = cstr > 0 ? cstr - 1 : 0;
+  if (fmt == FQG_NAME_CASAVA18) {
+    const uint32_t sp = wave_find(h.p + 1, 0, L, [](uint32_t c) { return c == ' '; });
+    if (sp >= 2 && h.p[1 + sp - 2] == '/') return sp - 2;
+    return sp;
+  }
+  long len = (long)L;
+  if (fmt == FQG_NAME_DEFAULT && is_pe) len--;
+  return len >= 1 ? (uint32_t)(len - 1) : L;  // rn[len-1]='\0' lands outside the string when len<1
+}
+
+// compare_headers (reference src/fastq.c:543-566) on two NUL-free byte ranges
+__device__ __forceinline__ bool same_names(const uint8_t* a, uint32_t na, const uint8_t* b, uint32_t nb) {
+  if (nb == 0) return true;
+  const uint32_t b0 = b[0];
+  if (b0 == '\n' || b0 == '\r') return true;
+  const uint32_t m = na < nb ? na : nb;
+  uint32_t cp = m;
+  for (uint32_t base = 0; base < m; base += kWave) {
+    const uint32_t i = base + lane_id();
+    const bool diff = (i < m) && (a[i] != b[i]);
+    const uint64_t mm = __ballot(diff);
+    if (mm) {
+      cp = base + (uint32_t)__builtin_ctzll(mm);
+      break;
+    }
+  }
+  auto not_eol = [](uint32_t c) { return c != '\r' && c != '\n'; };
+  if (wave_find(a, cp, na, not_eol) != na) return false;
+  if (wave_find(b, cp, nb, not_eol) != nb) return false;
+  return true;
+}
+
+struct RecOut {
+  uint32_t code;
+  uint64_t aux0, aux1;
+  uint32_t read_len;  // strlen(seq)
+  uint32_t qmin, qmax;
+};
+
+__device__ __forceinline__ void load_lines(const FrameView& f, uint64_t r, Line ln[4]) {
+  // lanes 0..4 fetch line_end[4r-1 .. 4r+3]
+  const int l = lane_id();
+  uint64_t e = 0;
+  if (l < 5) {
+    const uint64_t idx = 4 * r + (uint64_t)l;
+    e = (idx == 0) ? ~0ull : f.line_end[idx - 1];
+  }
+  uint64_t ends[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) ends[k] = __shfl(e, k, 64);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t s = ends[k] + 1;  // ~0ull + 1 == 0 for the very first line
+    ln[k].p = f.img + s;
+    ln[k].len = (uint32_t)(ends[k + 1] - s);
+    ln[k].nl = ends[k + 1] < f.nbytes ? 1u : 0u;
+  }
+}
+
+// The whole check sequence for one record, executed by one wavefront (all lanes take the same
+// path).  Order of checks = reference src/fastq.c:245-261 then :300-392.
+__device__ __forceinline__ RecOut validate_record(const FrameView& f, uint64_t r, int is_pe, int fmt,
+                                                  int space) {
+  RecOut o;
+  o.code = FQG_OK;
+  o.aux0 = o.aux1 = 0;
+  o.read_len = 0;
+  o.qmin = 255;
+  o.qmax = 0;
+  Line ln[4];
+  load_lines(f, r, ln);
+  const Line &h1 = ln[0], &sq = ln[1], &h2 = ln[2], &ql = ln[3];
+
+  // gzgets limits (src/fastq.c:249-253): a longer line would have been split by the reference
+  if (h1.len + h1.nl > FQG_MAX_LABEL_LENGTH - 1 || h2.len + h2.nl > FQG_MAX_LABEL_LENGTH - 1 ||
+      sq.len + sq.nl > FQG_MAX_READ_LENGTH - 1 || ql.len + ql.nl > FQG_MAX_READ_LENGTH - 1) {
+    o.code = FQG_E_LINE_TOO_LONG;
+    return o;
+  }
+  const uint32_t b0 = h1.p[0];
+  // src/fastq.c:254: a 2nd/3rd/4th line that starts with NUL reads as missing
+  if (sq.p[0] == 0 || h2.p[0] == 0 || ql.p[0] == 0) {
+    o.code = FQG_E_TRUNCATED;
+    return o;
+  }
+  if (b0 != '@') {
+    o.code = FQG_E_HDR1_AT;
+    return o;
+  }
+  const uint32_t h1_total = h1.len + h1.nl;
+  const uint32_t b1 = h1_total > 1 ? (uint32_t)h1.p[1] : 0u;
+  if (b1 == 0 || b1 == '\n' || b1 == '\r') {
+    o.code = FQG_E_HDR1_SHORT;
+    return o;
+  }
+
+  // ---- sequence line ----
+  uint32_t slen = sq.len;
+  uint32_t term = 256;  // byte that stopped the scan, 256 = the line end
+  uint32_t p_inv = ~0u, p_t = ~0u, p_u = ~0u, inv_char = 0;
+  for (uint32_t base = 0; base < sq.len; base += kWave) {
+    const uint32_t i = base + lane_id();
+    const bool in = i < sq.len;
+    const uint32_t c = in ? (uint32_t)sq.p[i] : (uint32_t)'A';
+    const uint64_t m_term = __ballot(in && (c == 0 || c == '\r'));
+    const uint64_t below = m_term ? ((1ull << __builtin_ctzll(m_term)) - 1ull) : ~0ull;
+    const uint64_t m_inv = __ballot(in && !is_base(c)) & below;
+    const uint64_t m_t = __ballot(in && (c == 'T' || c == 't')) & below;
+    const uint64_t m_u = __ballot(in && (c == 'U' || c == 'u')) & below;
+    if (m_inv && p_inv == ~0u) {
+      const int k = __builtin_ctzll(m_inv);
+      p_inv = base + k;
+      inv_char = __shfl(c, k, 64);
+    }
+    if (m_t && p_t == ~0u) p_t = base + __builtin_ctzll(m_t);
+    if (m_u && p_u == ~0u) p_u = base + __builtin_ctzll(m_u);
+    if (m_term) {
+      const int k = __builtin_ctzll(m_term);
+      slen = base + k;
+      term = __shfl(c, k, 64);
+      break;
+    }
+    if (p_inv != ~0u || (p_t != ~0u && p_u != ~0u)) break;  // outcome already decided
+  }
+  {
+    const uint32_t p_ut = (p_t != ~0u && p_u != ~0u) ? (p_t > p_u ? p_t : p_u) : ~0u;
+    if (p_inv < p_ut) {
+      o.code = FQG_E_SEQ_CHAR;
+      o.aux0 = inv_char;
+      return o;
+    }
+    if (p_ut != ~0u) {
+      o.code = FQG_E_SEQ_UT;
+      return o;
+    }
+  }
+  // FASTQ_ENTRY.read_len = strlen(seq) (src/fastq.c:259): up to the first NUL, '\n' included
+  if (term == 0) o.read_len = slen;
+  else if (term == '\r') {
+    const uint32_t z = wave_find(sq.p, slen + 1, sq.len, [](uint32_t c) { return c == 0; });
+    o.read_len = z < sq.len ? z : sq.len + sq.nl;
+  } else o.read_len = sq.len + sq.nl;
+
+  if (slen < 1) {
+    o.code = FQG_E_LEN_SMALL;
+    o.aux0 = slen;
+    return o;
+  }
+  if (h2.p[0] != '+') {
+    o.code = FQG_E_HDR2_PLUS;
+    return o;
+  }
+  // ---- header 2 against header 1 (src/fastq.c:363-370) ----
+  {
+    const uint32_t h2_total = h2.len + h2.nl;
+    const uint32_t c1 = h2_total > 1 ? (uint32_t)h2.p[1] : 0u;
+    if (!(c1 == 0 || c1 == '\n' || c1 == '\r')) {
+      auto is_nul = [](uint32_t c) { return c == 0; };
+      const uint32_t z1 = wave_find(h1.p, 0, h1.len, is_nul);
+      const uint32_t z2 = wave_find(h2.p, 0, h2.len, is_nul);
+      const uint32_t cs1 = z1 < h1.len ? z1 : h1_total;
+      const uint32_t cs2 = z2 < h2.len ? z2 : h2_total;
+      const uint32_t n1 = canonical_name_len(h1, cs1, fmt, is_pe);
+      const uint32_t n2 = canonical_name_len(h2, cs2, fmt, is_pe);
+      if (!same_names(h1.p + 1, n1, h2.p + 1, n2)) {
+        o.code = FQG_E_HDR2_DIFF;
+        return o;
+      }
+    }
+  }
+  // ---- quality line ----
+  uint32_t qlen = ql.len;
+  uint32_t qmin = 255, qmax = 0;
+  for (uint32_t base = 0; base < ql.len; base += kWave) {
+    const uint32_t i = base + lane_id();
+    const bool in = i < ql.len;
+    const uint32_t c = in ? (uint32_t)ql.p[i] : 0xFFu;
+    const uint64_t m_term = __ballot(in && (c == 0 || c == '\r'));
+    const uint32_t stop = m_term ? (uint32_t)__builtin_ctzll(m_term) : 64u;
+    const bool use = in && (uint32_t)lane_id() < stop;
+    qmin = use && c < qmin ? c : qmin;
+    qmax = use && c > qmax ? c : qmax;
+    if (m_term) {
+      qlen = base + stop;
+      break;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
+    qmin = a < qmin ? a : qmin;
+    qmax = b > qmax ? b : qmax;
+  }
+  o.qmin = qmin;
+  o.qmax = qmax;
+  if (space == FQG_SPACE_SEQ && qlen != slen) {
+    o.code = FQG_E_QLEN;
+    o.aux0 = slen;
+    o.aux1 = qlen;
+    return o;
+  }
+  if (space == FQG_SPACE_COLOUR && !(qlen == slen - 1 || qlen == slen)) {
+    o.code = FQG_E_QLEN_CS;
+    o.aux0 = slen;
+    o.aux1 = qlen;
+    return o;
+  }
+  return o;
+}
+
+// Persistent wavefronts: wave w handles records w, w + W, w + 2W, ...  Statistics stay in
+// registers (min/max, and a run-length cache for the length histogram) until the wave is done.
+__global__ __launch_bounds__(kBlock) void k_validate_exact(FrameView f, int is_pe, int fmt, int space,
+                                                           uint32_t weight, AccState* __restrict__ acc,
+                                                           unsigned long long* __restrict__ hist,
+                                                           CallState* __restrict__ cs,
+                                                           uint64_t explain_record) {
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (explain_record != kNoRecord) {
+    if (wave != 0) return;
+    const RecOut o = validate_record(f, explain_record, is_pe, fmt, space);
+    if (lane_id() == 0) {
+      cs->aux0 = o.aux0;
+      cs->aux1 = o.aux1;
+    }
+    return;
+  }
+  uint64_t n_ok = 0, min_rl = ~0ull, max_rl = 0;
+  uint32_t qmin = 255, qmax = 0;
+  uint32_t run_len = 0;
+  uint64_t run_cnt = 0;
+  unsigned long long key = ~0ull;
+  for (uint64_t r = wave; r < f.n_records; r += n_waves) {
+    const RecOut o = validate_record(f, r, is_pe, fmt, space);
+    if (o.code != FQG_OK) {
+      const unsigned long long k = (r << 8) | o.code;
+      key = k < key ? k : key;
+      continue;
+    }
+    ++n_ok;
+    min_rl = o.read_len < min_rl ? o.read_len : min_rl;
+    max_rl = o.read_len > max_rl ? o.read_len : max_rl;
+    qmin = o.qmin < qmin ? o.qmin : qmin;
+    qmax = o.qmax > qmax ? o.qmax : qmax;
+    if (o.read_len == run_len) ++run_cnt;
+    else {
+      if (run_cnt && acc && lane_id() == 0) atomicAdd(&hist[run_len], run_cnt * weight);
+      run_len = o.read_len;
+      run_cnt = 1;
+    }
+  }
+  if (lane_id() == 0) {
+    if (key != ~0ull) atomicMin(&cs->first_key, key);
+    if (acc && n_ok) {
+      if (run_cnt) atomicAdd(&hist[run_len], run_cnt * weight);
+      atomicAdd(&acc->num_rds, n_ok * weight);
+      atomicMin(&acc->min_rl, min_rl);
+      atomicMax(&acc->max_rl, max_rl);
+      if (qmin <= qmax) {
+        atomicMin(&acc->min_qbyte, qmin);
+        atomicMax(&acc->max_qbyte, qmax);
+      }
+    }
+  }
+}
+
+// first record whose first line starts with a NUL byte (src/fastq.c:250): only launched for
+// images that contain NUL bytes at all
+__global__ __launch_bounds__(kBlock) void k_find_stop(FrameView f, CallState* __restrict__ cs) {
+  const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= f.n_records) return;
+  const uint64_t s = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+  if (f.img[s] == 0) atomicMin(&cs->stop_record, (unsigned long long)r);
+}
+
+// record descriptors (FASTQ_ENTRY geometry) for a range of records
+__global__ __launch_bounds__(kBlock) void k_records(FrameView f, uint64_t first, uint64_t count,
+                                                    fqg_record* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t r = first + i;
+  uint64_t e[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const uint64_t idx = 4 * r + k;
+    e[k] = idx == 0 ? ~0ull : f.line_end[idx - 1];
+  }
+  fqg_record d;
+  d.offset = e[0] + 1;
+  uint32_t len[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t s = e[k] + 1;
+    len[k] = (uint32_t)(e[k + 1] - s) + (e[k + 1] < f.nbytes ? 1u : 0u);
+  }
+  d.hdr1_len = len[0];
+  d.seq_len = len[1];
+  d.hdr2_len = len[2];
+  d.qual_len = len[3];
+  // strlen(seq): stop at the first NUL inside the line
+  uint32_t rl = len[1];
+  const uint8_t* p = f.img + e[1] + 1;
+  for (uint32_t k = 0; k < len[1]; ++k)
+    if (p[k] == 0) {
+      rl = k;
+      break;
+    }
+  d.read_len = rl;
+  d.reserved = 0;
+  out[i] = d;
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic FASTQ (bench / tests): fixed-geometry records, every byte a pure function of
+// (seed, record index, offset in record)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+// header: "@SYN001:1:FC1:<lane>:<tile 4d>:<x 1d>:<index 10d> <mate>:N:0:ACGT\n" = 45 bytes
+constexpr int kSynthHdr = 45;
+__device__ __forceinline__ uint8_t synth_header_byte(uint64_t idx, uint32_t o, int mate) {
+  const char* a = "@SYN001:1:FC1:";  // 14
+  if (o < 14) return (uint8_t)a[o];
+  if (o == 14) return (uint8_t)('1' + (idx / 40000000ull) % 8);
+  if (o == 15 || o == 20 || o == 22) return ':';
+  if (o >= 16 && o < 20) {
+    uint32_t t = (uint32_t)((idx / 10000ull) % 10000ull);
+    const uint32_t d[4] = {t / 1000, (t / 100) % 10, (t / 10) % 10, t % 10};
+    return (uint8_t)('0' + d[o - 16]);
+  }
+  if (o == 21) return (uint8_t)('0' + idx % 10);
+  if (o >= 23 && o < 33) {
+    uint64_t v = idx;
+    for (uint32_t k = 32; k > o; --k) v /= 10;
+    return (uint8_t)('0' + v % 10);
+  }
+  const char* z = " 1:N:0:ACGT\n";  // 12: offsets 33..44
+  if (o == 34) return (uint8_t)('0' + mate);
+  return (uint8_t)z[o - 33];
+}
+
+__global__ __launch_bounds__(kBlock) void k_synth(uint8_t* __restrict__ out, uint64_t n_records,
+                                                  uint32_t read_len, uint64_t first_index,
+                                                  uint64_t seed, int mate) {
+  const uint64_t R = (uint64_t)kSynthHdr + 2ull * (read_len + 1) + 2;
+  const uint64_t total = n_records * R;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock * 16;
+  for (uint64_t p0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 16; p0 < total; p0 += stride) {
+    uint8_t b[16];
+    uint64_t rec = p0 / R;
+    uint32_t o = (uint32_t)(p0 - rec * R);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t idx = first_index + rec;
+      uint8_t c;
+      if (o < (uint32_t)kSynthHdr) c = synth_header_byte(idx, o, mate);
+      else if (o < kSynthHdr + read_len) {
+        const uint64_t h = mix64(seed ^ (idx * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(o - kSynthHdr) << 1));
+        c = ((h >> 8) & 1023u) == 0 ? 'N' : (uint8_t)"ACGT"[h & 3u];
+      } else if (o == kSynthHdr + read_len) c = '\n';
+      else if (o == kSynthHdr + read_len + 1) c = '+';
+      else if (o == kSynthHdr + read_len + 2) c = '\n';
+      else if (o < kSynthHdr + 2 * read_len + 3) {
+        const uint64_t h = mix64(seed ^ (idx * 0xD1B54A32D192ED03ull) ^ (((uint64_t)(o - kSynthHdr - read_len - 3) << 1) | 1ull));
+        c = (uint8_t)(33 + 2 + (uint32_t)((h >> 11) % 39u));
+      } else c = '\n';
+      b[j] = c;
+      if (++o == R) {
+        o = 0;
+        ++rec;
+      }
+    }
+    if (p0 + 16 <= total) {
+      uint4 v;
+      v.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+      v.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+      v.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
+      v.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((uint32_t)b[15] << 24);
+      *reinterpret_cast<uint4*>(out + p0) = v;
+    } else {
+      for (uint64_t i = p0; i < total; ++i) out[i] = b[i - p0];
+    }
+  }
+}
+
+}  // namespace fqg

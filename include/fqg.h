@@ -1,0 +1,183 @@
+/*
+ * fqg.h - bulk C-ABI of libfqgpu.so: the MI355X (gfx950) implementation of fastq_utils'
+ * per-read hot path.
+ *
+ * The reference (nunofonseca/fastq_utils 0.25.3) has no FFI layer: its programs call a
+ * per-record C API (src/fastq.h:133-158, src/hash.h:64-78) in a serial loop.  A per-record
+ * call cannot feed a GPU, so the boundary is one level up: each entry point below replaces one
+ * whole *loop* of the reference and works on a block of records ("image": the decompressed
+ * bytes of a FASTQ file or of a record-aligned piece of one).  The reference interface every
+ * entry point stands in for is cited next to it.  INTEGRATION.md shows how the reference's own
+ * programs would bind these.
+ *
+ * Conventions: plain C, no torch / HIP types in any signature; every function returns 0 on
+ * success or a negative FQG_ERR_* value and never calls exit(); record-level findings (format
+ * errors in the data) are *results*, not failures.  Buffers tagged FQG_MEM_DEVICE are device
+ * pointers owned by the caller (e.g. a torch tensor's data_ptr()); FQG_MEM_HOST buffers are
+ * copied to the GPU by the library (pinned memory from fqg_host_alloc() copies fastest).
+ * One fqg_ctx per process and GPU; a context is not thread-safe.
+ */
+#ifndef FQG_H
+#define FQG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fqg_codes.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQG_ABI_VERSION 1
+
+/* library-level failures (negative); record-level outcomes are enum fqg_code */
+#define FQG_ERR_NO_DEVICE (-1)   /* no usable gfx950 device / HIP runtime failure at open */
+#define FQG_ERR_HIP (-2)         /* a HIP call failed; see fqg_last_error() */
+#define FQG_ERR_ARG (-3)         /* invalid argument */
+#define FQG_ERR_NOMEM (-4)       /* device or pinned allocation failed */
+#define FQG_ERR_STATE (-5)       /* call sequence violated (e.g. no frame to index) */
+
+#define FQG_MEM_HOST 0
+#define FQG_MEM_DEVICE 1
+
+typedef struct fqg_ctx fqg_ctx;
+typedef struct fqg_acc fqg_acc;
+
+/* ---- context -------------------------------------------------------------------------- */
+int fqg_open(int device_ordinal, fqg_ctx **ctx);
+void fqg_close(fqg_ctx *ctx);
+const char *fqg_last_error(const fqg_ctx *ctx);
+int fqg_abi_version(void);
+/* launch on a caller-provided hipStream_t (passed as void*); NULL restores the context's own */
+int fqg_set_stream(fqg_ctx *ctx, void *hip_stream);
+int fqg_synchronize(fqg_ctx *ctx);
+/* pinned host memory for staging file contents */
+void *fqg_host_alloc(fqg_ctx *ctx, size_t bytes);
+void fqg_host_free(fqg_ctx *ctx, void *p);
+
+/* ---- per-file state decided from the first record --------------------------------------
+ * Mirrors the FASTQ_FILE fields that steer validation (src/fastq.h:125-130): the read-name
+ * format and the colour-space flag are fixed by the first record of a file
+ * (src/fastq.c:459-485) and is_pe by the program (src/fastq.c:88-90).  The host decides them
+ * (fqg_probe_first_record) and passes them to every bulk call on that file. */
+typedef struct {
+  int32_t is_pe;           /* FASTQ_FILE.is_pe */
+  int32_t readname_format; /* FQG_NAME_* */
+  int32_t space;           /* FQG_SPACE_* */
+  int32_t reserved;
+} fqg_file_state;
+
+/* Host-side, no GPU: src/fastq.c:459-485 + :666-754 on one header line (without the leading
+ * '@', NUL-terminated) and one sequence line.  Returns the format / the space. */
+int fqg_probe_readname_format(const char *hdr_after_at);
+int fqg_probe_space(const char *seq_line);
+/* Both probes on the first record of a host-resident image (first two lines, read with the
+ * reference's gzgets limits, src/fastq.c:249-251).  Fills readname_format and space; is_pe is
+ * copied through.  Returns 0, or FQG_ERR_ARG when the image has no complete first two lines. */
+int fqg_probe_first_record(const void *host_image, uint64_t nbytes, int is_pe, fqg_file_state *out);
+
+/* ---- statistics accumulator -------------------------------------------------------------
+ * Device-resident counterpart of FASTQ_FILE's counters (src/fastq.h:116-122): min/max/last
+ * read length, min/max quality byte, number of reads, and the rdlen_ctr[] histogram.
+ * Replaces fastq_new_entry_stats() (src/fastq.c:97-110) and the quality-range update in
+ * fastq_validate_entry() (src/fastq.c:372-378). */
+typedef struct {
+  uint64_t num_rds;  /* records counted */
+  uint64_t min_rl;   /* FASTQ_FILE.min_rl: strlen(seq) units, i.e. including the '\n' */
+  uint64_t max_rl;
+  uint64_t min_qual; /* as the reference's unsigned long: bytes >= 0x80 read 0xFFFFFF80.. */
+  uint64_t max_qual;
+} fqg_file_stats;
+
+int fqg_acc_create(fqg_ctx *ctx, fqg_acc **acc);
+void fqg_acc_destroy(fqg_acc *acc);
+int fqg_acc_reset(fqg_acc *acc);
+int fqg_acc_read(fqg_acc *acc, fqg_file_stats *out);
+/* count of reads whose length (strlen(seq) units) is `len`, i.e. FASTQ_FILE.rdlen_ctr[len] */
+int fqg_acc_hist_nonzero(fqg_acc *acc, uint64_t *lens, uint64_t *counts, size_t cap, size_t *n);
+/* median_rl(), src/fastq_info.c:39-55, over one or two accumulators (b may be NULL).
+ * `weight` multiplies every count and num_rds (index mode counts each record twice, F7). */
+int fqg_acc_median(fqg_acc *a, fqg_acc *b, uint64_t *median);
+/* multi-GPU: element-wise merge of another accumulator's host-exported state */
+int fqg_acc_export(fqg_acc *acc, void *buf, size_t cap, size_t *used);
+int fqg_acc_merge(fqg_acc *acc, const void *buf, size_t used);
+
+/* ---- framing + validation ---------------------------------------------------------------
+ * Replaces the read/validate loop: fastq_read_entry() (src/fastq.c:245-261) for every record
+ * of the image followed by fastq_validate_entry() (src/fastq.c:300-392), as driven by
+ * validate_single_fastq_file() (src/fastq_info.c:155-176) and the other fastq_info loops.
+ *
+ * `image` must start at a record boundary.  With final != 0 the image ends the file: a last
+ * line without '\n' is a line, and an incomplete last record is FQG_E_TRUNCATED.  With
+ * final == 0 an incomplete tail is not an error: `consumed` tells how many bytes were used and
+ * the caller prepends the rest to its next image.
+ *
+ * The outcome reported is the FIRST one in file order, exactly as the serial loop would hit
+ * it (record index, then the check order inside fastq_validate_entry).  Statistics are added
+ * to `acc` for every record of the image; they are only meaningful when code == FQG_OK (the
+ * reference exits at the first error and never prints them otherwise). */
+typedef struct {
+  uint64_t n_records; /* complete records framed (and validated) */
+  uint64_t n_lines;   /* lines seen */
+  uint64_t consumed;  /* bytes covered by the n_records records */
+  uint64_t record;    /* 0-based index (within the image) of the first failing record */
+  uint64_t aux0;      /* code-specific: offending byte / slen */
+  uint64_t aux1;      /*                qlen */
+  int32_t code;       /* enum fqg_code; FQG_OK if every record passed */
+  int32_t stopped;    /* 1: a record starting with a NUL byte ended the file early (src/fastq.c:250) */
+  int32_t path;       /* which device path ran: 1 = exact wave-per-record, 2 = tiled fast path */
+  int32_t reserved;
+} fqg_validate_result;
+
+/* checks bitmask */
+#define FQG_VALIDATE_DEFAULT 0u
+#define FQG_VALIDATE_FORCE_EXACT 1u /* always use the wave-per-record kernel */
+#define FQG_VALIDATE_NO_STATS 2u    /* do not touch acc (acc may be NULL) */
+#define FQG_VALIDATE_COUNT_TWICE 4u /* every record counts twice in acc: the index loop runs
+                                       fastq_new_entry_stats in both fastq_read_next_entry and
+                                       fastq_validate_entry (src/fastq.c:415,432) */
+
+int fqg_validate(fqg_ctx *ctx, fqg_acc *acc, const void *image, uint64_t nbytes, int mem,
+                 int final, const fqg_file_state *state, uint32_t flags,
+                 fqg_validate_result *out);
+
+/* Record descriptors of the image framed by the last fqg_validate() call on this context.
+ * One per record, 32 bytes: what FASTQ_ENTRY (src/fastq.h:97-108) holds besides the bytes. */
+typedef struct {
+  uint64_t offset;   /* FASTQ_ENTRY.offset: byte offset of the '@' line in the image */
+  uint32_t hdr1_len; /* bytes in each of the four lines, '\n' included when present */
+  uint32_t seq_len;
+  uint32_t hdr2_len;
+  uint32_t qual_len;
+  uint32_t read_len; /* FASTQ_ENTRY.read_len = strlen(seq) */
+  uint32_t reserved;
+} fqg_record;
+
+int fqg_frame_records(fqg_ctx *ctx, uint64_t first, uint64_t count, fqg_record *out, int mem);
+
+/* ---- measurement ------------------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */
+typedef struct {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} fqg_kernel_time;
+
+int fqg_profile_enable(fqg_ctx *ctx, int on);
+int fqg_profile_reset(fqg_ctx *ctx);
+int fqg_profile_read(fqg_ctx *ctx, fqg_kernel_time *out, size_t cap, size_t *n);
+
+/* ---- synthetic data (bench / tests) -----------------------------------------------------
+ * Fills a device buffer with `n_records` seeded FASTQ records of fixed geometry
+ * (CASAVA-1.8 names unique by index, `read_len` bases uniform over ACGT with
+ * 0.1% N, Phred 2..40 +33).  Every record has exactly fqg_synth_record_bytes(read_len) bytes.
+ * Deterministic in (seed, first_index, i). */
+uint64_t fqg_synth_record_bytes(uint32_t read_len);
+int fqg_synth_fastq(fqg_ctx *ctx, void *device_out, uint64_t n_records, uint32_t read_len,
+                    uint64_t first_index, uint64_t seed, int mate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

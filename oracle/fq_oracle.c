@@ -714,6 +714,17 @@ static void run_fastq_info(run_t *r, const fqo_job *job, fqo_summary *sum) {
     if (f2->min_qual < min_qual) min_qual = f2->min_qual;
     if (f2->max_qual > max_qual) max_qual = f2->max_qual;
   }
+  /* structured copy of the statistics, taken before the encoding verdict can end the run */
+  unsigned int med = median_rl(f1, f2);
+  if (sum) {
+    sum->num_reads = num_reads1;
+    sum->min_rl = min_rl;
+    sum->max_rl = max_rl;
+    sum->median_rl = med;
+    sum->min_qual = min_qual;
+    sum->max_qual = max_qual;
+    sum->num_rds_counted = f1->num_rds;
+  }
   eprintf(r, "------------------------------------\n");
   if (num_reads2 > 0) eprintf(r, "Number of reads: %lu %lu\n", num_reads1, num_reads2);
   else eprintf(r, "Number of reads: %lu\n", num_reads1);
@@ -732,18 +743,8 @@ static void run_fastq_info(run_t *r, const fqo_job *job, fqo_summary *sum) {
   eprintf(r, "Quality encoding range: %lu %lu\n", min_qual, max_qual);
   if (enc == NULL) eprintf(r, "Quality encoding: NA\n");
   else eprintf(r, "Quality encoding: %s\n", enc);
-  unsigned int med = median_rl(f1, f2);
   eprintf(r, "Read length: %lu %lu %u\n", min_rl - 1, max_rl - 1, med - 1);
   eprintf(r, "OK\n");
-  if (sum) {
-    sum->num_reads = num_reads1;
-    sum->min_rl = min_rl;
-    sum->max_rl = max_rl;
-    sum->median_rl = med;
-    sum->min_qual = min_qual;
-    sum->max_qual = max_qual;
-    sum->num_rds_counted = f1->num_rds;
-  }
   leave(r, 0);
 }
 
