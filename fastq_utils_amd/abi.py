@@ -68,6 +68,21 @@ class KernelTime(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  The PyTorch wheel bundles its own libamdhip64.so
+    (same SONAME, libamdhip64.so.7, as /opt/rocm's).  If libfqgpu.so pulled in the system copy
+    first, a later `import torch` would load a second runtime that sees no GPU.  Loading the
+    wheel's copy first makes both sides resolve to it; without torch the system copy is used."""
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libfqgpu.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
@@ -75,6 +90,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
     L.fqg_open.argtypes = [C.c_int, C.POINTER(vp)]
