@@ -50,6 +50,8 @@ struct fqg_ctx {
   DevBuf span_sums;   // u64 per span
   DevBuf line_end;    // u64 per line (+1)
   DevBuf records;     // fqg_record staging for fqg_frame_records
+  DevBuf suspect;     // 1 bit per record: the fast path could not vouch for it
+  DevBuf list;        // u64 record indices queued for the exact validator
   CallState* d_cs = nullptr;
   CallState* h_cs = nullptr;  // pinned
   uint64_t* h_scalar = nullptr;  // pinned, 8 x u64
@@ -218,6 +220,8 @@ void fqg_close(fqg_ctx* c) {
   release(c->span_sums);
   release(c->line_end);
   release(c->records);
+  release(c->suspect);
+  release(c->list);
   if (c->d_cs) (void)hipFree(c->d_cs);
   if (c->h_cs) (void)hipHostFree(c->h_cs);
   if (c->h_scalar) (void)hipHostFree(c->h_scalar);
@@ -493,12 +497,6 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   const uint64_t leftover = usable % 4;
 
   if ((rc = ensure(c, c->line_end, (size_t)(n_lines_all + 1) * 8))) return rc;
-  {
-    ProfScope ps(c, "k_lines");
-    hipLaunchKernelGGL(k_lines, dim3(n_tiles), dim3(kBlock), 0, c->stream, d_img, nbytes,
-                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
-                       (uint64_t*)c->line_end.p, c->d_cs);
-  }
   FrameView fv;
   fv.img = d_img;
   fv.nbytes = nbytes;
@@ -506,6 +504,14 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   fv.n_lines = n_lines_all;
   fv.n_records = n_records;
 
+  // images with NUL / CR bytes (or on request) take the exact path: plain line index first
+  const bool want_fast = !(flags & FQG_VALIDATE_FORCE_EXACT) && !(img_flags & (kFlagNul | kFlagCr));
+  if (!want_fast) {
+    ProfScope ps(c, "k_lines");
+    hipLaunchKernelGGL(k_lines, dim3(n_tiles), dim3(kBlock), 0, c->stream, d_img, nbytes,
+                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
+                       (uint64_t*)c->line_end.p, c->d_cs);
+  }
   // a record that starts with NUL ends the file silently (src/fastq.c:250)
   bool tail_is_stop = false;
   if (img_flags & kFlagNul) {
@@ -536,11 +542,50 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
     fv.n_records = n_records;
   }
 
-  if (n_records) {
+  const uint32_t weight = (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u;
+  // The tiled path needs an image without NUL / CR bytes (then every line is terminated by
+  // its '\n' alone and statistics follow from the line index); anything else goes through the
+  // exact wave-per-record validator as a whole.
+  const bool fast = !(flags & FQG_VALIDATE_FORCE_EXACT) && !(img_flags & (kFlagNul | kFlagCr));
+  uint64_t list_cap = 0;
+  if (fast) {
+    list_cap = std::max<uint64_t>(1u << 20, n_records / 16);
+    if (list_cap > n_records) list_cap = std::max<uint64_t>(n_records, 1);
+    if ((rc = ensure(c, c->suspect, (size_t)(n_records / 32 + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->list, (size_t)list_cap * 8))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(n_records / 32 + 2) * 4, c->stream));
+    const unsigned grid_t = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->cu_count * 8);
+    {
+      ProfScope ps(c, "k_frame_fast");
+      hipLaunchKernelGGL(k_frame_fast, dim3(grid_t), dim3(kBlock), 0, c->stream, d_img, nbytes, n_tiles,
+                         (const uint32_t*)c->tile_counts.p, (const uint32_t*)c->tile_local.p,
+                         (const unsigned long long*)c->span_sums.p, (uint64_t*)c->line_end.p, 4 * n_records,
+                         (uint32_t*)c->suspect.p, acc ? acc->d_state : nullptr, c->d_cs);
+    }
+    if (n_records) {
+      const unsigned grid_r =
+          (unsigned)std::min<uint64_t>((n_records + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 8);
+      {
+        ProfScope ps(c, "k_records_fast");
+        hipLaunchKernelGGL(k_records_fast, dim3(grid_r), dim3(kBlock), 0, c->stream, fv, st->space, weight,
+                           (const uint32_t*)c->suspect.p, (unsigned long long*)c->list.p, list_cap,
+                           &c->d_cs->list_count, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr);
+      }
+      {
+        ProfScope ps(c, "k_validate_exact");
+        hipLaunchKernelGGL(k_validate_exact, dim3(c->cu_count * 2), dim3(kBlock), 0, c->stream, fv, st->is_pe,
+                           st->readname_format, st->space, weight, (AccState*)nullptr,
+                           (unsigned long long*)nullptr, c->d_cs, kNoRecord,
+                           (const unsigned long long*)c->list.p, (const unsigned long long*)&c->d_cs->list_count);
+      }
+    }
+    out->path = 2;
+  } else if (n_records) {
     ProfScope ps(c, "k_validate_exact");
     hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
-                       st->is_pe, st->readname_format, st->space, (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u,
-                       acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr, c->d_cs, kNoRecord);
+                       st->is_pe, st->readname_format, st->space, weight, acc ? acc->d_state : nullptr,
+                       acc ? acc->d_hist : nullptr, c->d_cs, kNoRecord, (const unsigned long long*)nullptr,
+                       (const unsigned long long*)nullptr);
     out->path = 1;
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
@@ -554,12 +599,24 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   out->consumed = n_records ? c->h_scalar[1] + 1 : 0;
   if (out->consumed > nbytes) out->consumed = nbytes;  // unterminated last line
 
+  if (fast && c->h_cs->list_count > list_cap) {
+    // more suspects than the queue holds (e.g. every record carries its name on line 3): let the
+    // exact validator look at every record; the statistics of the tiled pass stand
+    ProfScope ps(c, "k_validate_exact");
+    hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
+                       st->is_pe, st->readname_format, st->space, weight, (AccState*)nullptr,
+                       (unsigned long long*)nullptr, c->d_cs, kNoRecord, (const unsigned long long*)nullptr,
+                       (const unsigned long long*)nullptr);
+    HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   if (c->h_cs->first_key != ~0ull) {
     out->record = c->h_cs->first_key >> 8;
     out->code = (int32_t)(c->h_cs->first_key & 0xFF);
     hipLaunchKernelGGL(k_validate_exact, dim3(1), dim3(kBlock), 0, c->stream, fv, st->is_pe,
                        st->readname_format, st->space, 1u, (AccState*)nullptr, (unsigned long long*)nullptr,
-                       c->d_cs, out->record);
+                       c->d_cs, out->record, (const unsigned long long*)nullptr,
+                       (const unsigned long long*)nullptr);
     HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->aux0 = c->h_cs->aux0;

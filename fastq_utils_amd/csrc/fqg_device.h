@@ -26,6 +26,7 @@ struct CallState {
   unsigned long long stop_record; // min record whose first line starts with NUL
   unsigned long long n_newlines;  // total '\n' in the image
   unsigned long long aux0, aux1;  // filled by the explain launch for first_key's record
+  unsigned long long list_count;  // records queued by the fast path for the exact validator
   unsigned int flags;
   unsigned int last_byte_is_nl;
 };

@@ -458,7 +458,9 @@ __global__ __launch_bounds__(kBlock) void k_validate_exact(FrameView f, int is_p
                                                            uint32_t weight, AccState* __restrict__ acc,
                                                            unsigned long long* __restrict__ hist,
                                                            CallState* __restrict__ cs,
-                                                           uint64_t explain_record) {
+                                                           uint64_t explain_record,
+                                                           const unsigned long long* __restrict__ list,
+                                                           const unsigned long long* __restrict__ list_count) {
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   if (explain_record != kNoRecord) {
@@ -475,7 +477,10 @@ __global__ __launch_bounds__(kBlock) void k_validate_exact(FrameView f, int is_p
   uint32_t run_len = 0;
   uint64_t run_cnt = 0;
   unsigned long long key = ~0ull;
-  for (uint64_t r = wave; r < f.n_records; r += n_waves) {
+  // (an overflowing queue is noticed by the host, which then re-runs over every record)
+  const uint64_t n_todo = list ? (uint64_t)*list_count : f.n_records;
+  for (uint64_t i = wave; i < n_todo; i += n_waves) {
+    const uint64_t r = list ? (uint64_t)list[i] : i;
     const RecOut o = validate_record(f, r, is_pe, fmt, space);
     if (o.code != FQG_OK) {
       const unsigned long long k = (r << 8) | o.code;
@@ -506,6 +511,307 @@ __global__ __launch_bounds__(kBlock) void k_validate_exact(FrameView f, int is_p
         atomicMax(&acc->max_qbyte, qmax);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// tiled fast path
+//
+// For images without NUL / CR bytes the statistics do not need per-record work on the bytes:
+//   - read lengths come from the newline positions alone (k_records_fast),
+//   - the quality range is the min/max over every byte of every 4th line,
+// and a record is certainly valid when its header starts with '@' and is longer than 1, its
+// bases are all in "ACGTN", its third line is exactly "+\n" and the 2nd and 4th line have the
+// same non-zero length.  k_frame_fast checks the byte-level conditions while it builds the line
+// index, 16 bytes per lane with SWAR compares, and marks every record it cannot vouch for in a
+// bitmap; k_records_fast checks the lengths and queues marked records for the exact
+// wave-per-record validator, which alone decides error codes.  Over-marking is harmless.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t prefix_xor16(uint32_t x) {
+  x ^= x << 1;
+  x ^= x << 2;
+  x ^= x << 4;
+  x ^= x << 8;
+  return x & 0xFFFFu;
+}
+
+// 0x80 in every byte of w that is NOT one of A C G T N.  The five letters have distinct low
+// three bits (1,3,7,4,6), so an 8-entry byte table indexed by (c & 7) names the only letter each
+// byte could be; entries 0,2,5 hold 0xFF which no byte with those low bits can equal.
+__device__ __forceinline__ uint32_t not_acgtn(uint32_t w) {
+  // table bytes, index 0..7: FF 'A' FF 'C' 'T' FF 'N' 'G'
+  const uint32_t lut_lo = 0x43FF41FFu;  // idx 3..0
+  const uint32_t lut_hi = 0x474EFF54u;  // idx 7..4
+  const uint32_t want = __builtin_amdgcn_perm(lut_hi, lut_lo, w & 0x07070707u);
+  const uint32_t x = want ^ w;
+  return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+
+// spread the low 4 bits of m into four 0x00/0xFF bytes
+__device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t m) {
+  return (((m & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+__device__ __forceinline__ void mark_suspect(uint32_t* __restrict__ suspect, uint64_t record) {
+  atomicOr(&suspect[record >> 5], 1u << (record & 31u));
+}
+
+// Generic byte-at-a-time version of the per-piece work, used for the one or two tiles at the
+// end of the image where look-ahead bytes or lines beyond the last complete record exist.
+__device__ __forceinline__ void piece_generic(const uint8_t* __restrict__ img, uint64_t n, uint64_t off,
+                                              uint64_t line, uint64_t limit, uint32_t* __restrict__ suspect,
+                                              uint32_t& qmin, uint32_t& qmax) {
+  for (int j = 0; j < 16 && off + j < n; ++j) {
+    const uint64_t pos = off + j;
+    const uint32_t c = img[pos];
+    if (line < limit) {
+      const uint32_t t = (uint32_t)line & 3u;
+      const bool start = pos == 0 || img[pos - 1] == '\n';
+      const bool second = !start && (pos == 1 || img[pos - 2] == '\n');
+      bool bad = false;
+      if (t == 0) bad = (start && c != '@') || (second && c == '\n');
+      else if (t == 2) bad = (start && c != '+') || (second && c != '\n');
+      else if (t == 1) bad = c != '\n' && !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N');
+      else if (c != '\n') {
+        qmin = c < qmin ? c : qmin;
+        qmax = c > qmax ? c : qmax;
+      }
+      if (bad) mark_suspect(suspect, line >> 2);
+    }
+    if (c == '\n') ++line;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_frame_fast(const uint8_t* __restrict__ img, uint64_t n,
+                                                       uint32_t n_tiles,
+                                                       const uint32_t* __restrict__ tile_counts,
+                                                       const uint32_t* __restrict__ tile_local,
+                                                       const unsigned long long* __restrict__ span_excl,
+                                                       uint64_t* __restrict__ line_end, uint64_t limit,
+                                                       uint32_t* __restrict__ suspect,
+                                                       AccState* __restrict__ acc,
+                                                       const CallState* __restrict__ cs) {
+  __shared__ uint32_t s_wave[kBlock / kWave];
+  __shared__ uint32_t s_q[2][kBlock / kWave];
+  // packed u16 pairs: even bytes / odd bytes
+  uint32_t mn_e = 0x00FF00FFu, mn_o = 0x00FF00FFu, mx_e = 0, mx_o = 0;
+  uint32_t gq_min = 255, gq_max = 0;  // from the generic tail path
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint64_t rank0 = span_excl[tile / kScanSpan] + tile_local[tile];
+    const uint64_t base = (uint64_t)tile * kTileBytes;
+    const bool interior = base + kTileBytes + 4 <= n && rank0 + tile_counts[tile] + 1 <= limit;
+#pragma unroll 1
+    for (int u = 0; u < kPieces; ++u) {
+      const uint64_t off = base + ((uint64_t)u * kBlock + threadIdx.x) * 16;
+      uint32_t nl = 0;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (off + 16 <= n) {
+        v = *reinterpret_cast<const uint4*>(img + off);
+        nl = mark_bits(eq_bytes(v.x, 0x0A0A0A0Au)) | (mark_bits(eq_bytes(v.y, 0x0A0A0A0Au)) << 4) |
+             (mark_bits(eq_bytes(v.z, 0x0A0A0A0Au)) << 8) | (mark_bits(eq_bytes(v.w, 0x0A0A0A0Au)) << 12);
+      } else if (off < n) {
+        for (uint64_t i = off; i < n; ++i) nl |= (img[i] == '\n') ? (1u << (i - off)) : 0u;
+      }
+      uint32_t total;
+      const uint32_t r = block_scan_excl(__popc(nl), s_wave, &total);
+      const uint64_t line0 = rank0 + r;  // index of the line the first byte of this piece is in
+      // ---- line index ----
+      {
+        uint32_t m = nl;
+        uint64_t k = line0;
+        while (m) {
+          const int j = __builtin_ctz(m);
+          m &= m - 1;
+          line_end[k++] = off + j;
+        }
+      }
+      if (interior) {
+        // type (line index mod 4) of every byte: 2-bit running count of the newlines before it
+        const uint32_t e = (nl << 1) & 0xFFFFu;
+        const uint32_t P = prefix_xor16(e);            // count bit 0
+        const uint32_t Q = prefix_xor16(e & ~P);       // count bit 1 (carry when bit 0 wraps)
+        const uint32_t t0 = (uint32_t)line0 & 3u;
+        const uint32_t a0 = (t0 & 1u) ? 0xFFFFu : 0u, a1 = (t0 & 2u) ? 0xFFFFu : 0u;
+        const uint32_t L = P ^ a0;
+        const uint32_t H = Q ^ a1 ^ (P & a0);
+        const uint32_t M1 = ~H & L & 0xFFFFu, M3 = H & L;
+        // ---- bases: anything outside ACGTN on a sequence line ----
+        const uint32_t inv = mark_bits(not_acgtn(v.x)) | (mark_bits(not_acgtn(v.y)) << 4) |
+                             (mark_bits(not_acgtn(v.z)) << 8) | (mark_bits(not_acgtn(v.w)) << 12);
+        uint32_t bad = inv & M1 & ~nl;
+        // ---- first two bytes of header lines, anchored at the newline in front of them ----
+        uint32_t cand = nl & (M1 | M3);  // newline ends a sequence / quality line
+        const uint32_t nxt_own = v.x;
+        uint32_t nxt = __shfl_down(nxt_own, 1, 64);
+        if (lane_id() == 63) nxt = *reinterpret_cast<const uint32_t*>(img + off + 16);
+        uint32_t badstart = 0;  // bit j: the line after the newline at j is not provably fine
+        if (cand) {
+          const uint64_t q0 = (uint64_t)v.x | ((uint64_t)v.y << 32), q1 = (uint64_t)v.z | ((uint64_t)v.w << 32),
+                         q2 = nxt;
+          uint32_t m = cand;
+          while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            const int p = j + 1;
+            const uint64_t lo = p < 8 ? q0 : (p < 16 ? q1 : q2), hi = p < 8 ? q1 : q2;
+            const int sh = (p & 7) * 8;
+            uint64_t x = lo >> sh;
+            if ((p & 7) == 7) x |= hi << 8;
+            const uint32_t c1 = (uint32_t)x & 0xFFu, c2 = ((uint32_t)x >> 8) & 0xFFu;
+            const bool after_qual = (M3 >> j) & 1u;  // next line is a header 1, else a header 2
+            const bool ok = after_qual ? (c1 == '@' && c2 != '\n') : (c1 == '+' && c2 == '\n');
+            if (!ok) badstart |= 1u << j;
+          }
+        }
+        if (off == 0 && ((v.x & 0xFFu) != '@' || ((v.x >> 8) & 0xFFu) == '\n')) mark_suspect(suspect, 0);
+        if (bad | badstart) {
+          uint32_t m = bad;
+          while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u))) >> 2);
+          }
+          m = badstart;
+          while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u)) + 1) >> 2);
+          }
+        }
+        // ---- quality range: bytes of 4th lines, newline excluded ----
+        const uint32_t qm = M3 & ~nl;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t bm = nibble_to_bytes(qm >> (4 * k));
+          const uint32_t lo = w[k] | ~bm, hi = w[k] & bm;
+          mn_e = pk_min_u16(mn_e, __builtin_amdgcn_perm(0u, lo, 0x0C020C00u));
+          mn_o = pk_min_u16(mn_o, __builtin_amdgcn_perm(0u, lo, 0x0C030C01u));
+          mx_e = pk_max_u16(mx_e, __builtin_amdgcn_perm(0u, hi, 0x0C020C00u));
+          mx_o = pk_max_u16(mx_o, __builtin_amdgcn_perm(0u, hi, 0x0C030C01u));
+        }
+      } else if (off < n) {
+        piece_generic(img, n, off, line0, limit, suspect, gq_min, gq_max);
+      }
+      rank0 += total;
+    }
+  }
+  if (tile_counts && blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl)
+    line_end[cs->n_newlines] = n;
+  // ---- fold the quality range: lanes -> wave -> block -> device ----
+  uint32_t qmin = pk_min_u16(mn_e, mn_o), qmax = pk_max_u16(mx_e, mx_o);
+  qmin = (qmin & 0xFFFFu) < (qmin >> 16) ? (qmin & 0xFFFFu) : (qmin >> 16);
+  qmax = (qmax & 0xFFFFu) > (qmax >> 16) ? (qmax & 0xFFFFu) : (qmax >> 16);
+  qmin = gq_min < qmin ? gq_min : qmin;
+  qmax = gq_max > qmax ? gq_max : qmax;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
+    qmin = a < qmin ? a : qmin;
+    qmax = b > qmax ? b : qmax;
+  }
+  if (lane_id() == 0) {
+    s_q[0][threadIdx.x >> 6] = qmin;
+    s_q[1][threadIdx.x >> 6] = qmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && acc) {
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      qmin = s_q[0][w] < qmin ? s_q[0][w] : qmin;
+      qmax = s_q[1][w] > qmax ? s_q[1][w] : qmax;
+    }
+    if (qmin <= qmax) {
+      // plain reads first: after the first few workgroups nobody improves the range any more
+      if (qmin < acc->min_qbyte) atomicMin(&acc->min_qbyte, qmin);
+      if (qmax > acc->max_qbyte) atomicMax(&acc->max_qbyte, qmax);
+    }
+  }
+}
+
+// One thread per record: lengths from the line index, statistics, and the list of records the
+// exact validator has to look at.
+constexpr int kHistLds = 4096;
+__global__ __launch_bounds__(kBlock) void k_records_fast(FrameView f, int space, uint32_t weight,
+                                                         const uint32_t* __restrict__ suspect,
+                                                         unsigned long long* __restrict__ list,
+                                                         unsigned long long list_cap,
+                                                         unsigned long long* __restrict__ list_count,
+                                                         AccState* __restrict__ acc,
+                                                         unsigned long long* __restrict__ hist) {
+  __shared__ uint32_t s_hist[kHistLds];
+  __shared__ unsigned long long s_red[3][kBlock / kWave];
+  for (int i = threadIdx.x; i < kHistLds; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  unsigned long long n_ok = 0, min_rl = ~0ull, max_rl = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t r0 = (uint64_t)blockIdx.x * kBlock; r0 < f.n_records; r0 += stride) {
+    const uint64_t r = r0 + threadIdx.x;
+    if (r < f.n_records) {
+      uint64_t e[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const uint64_t idx = 4 * r + k;
+        e[k] = idx == 0 ? ~0ull : f.line_end[idx - 1];
+      }
+      const uint64_t l0 = e[1] - e[0] - 1, l1 = e[2] - e[1] - 1, l2 = e[3] - e[2] - 1, l3 = e[4] - e[3] - 1;
+      const uint32_t has_nl = e[4] < f.nbytes ? 1u : 0u;  // only the very last line can lack it
+      bool sus = (suspect[r >> 5] >> (r & 31u)) & 1u;
+      sus |= l1 < 1 || l1 != l3 || space != FQG_SPACE_SEQ;
+      sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
+             l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + has_nl > FQG_MAX_READ_LENGTH - 1;
+      if (sus) {
+        const unsigned long long at = atomicAdd(list_count, 1ull);
+        if (at < list_cap) list[at] = r;
+      }
+      if (acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1) {
+        const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line always ends in '\n' here
+        ++n_ok;
+        min_rl = rl < min_rl ? rl : min_rl;
+        max_rl = rl > max_rl ? rl : max_rl;
+        if (rl < (uint64_t)kHistLds) atomicAdd(&s_hist[rl], 1u);
+        else atomicAdd(&hist[rl], (unsigned long long)weight);
+      }
+    }
+  }
+  if (!acc) return;
+  // block reduction of the scalars
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    n_ok += __shfl_down(n_ok, d, 64);
+    const unsigned long long a = __shfl_down(min_rl, d, 64), b = __shfl_down(max_rl, d, 64);
+    min_rl = a < min_rl ? a : min_rl;
+    max_rl = b > max_rl ? b : max_rl;
+  }
+  if (lane_id() == 0) {
+    s_red[0][threadIdx.x >> 6] = n_ok;
+    s_red[1][threadIdx.x >> 6] = min_rl;
+    s_red[2][threadIdx.x >> 6] = max_rl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      n_ok += s_red[0][w];
+      min_rl = s_red[1][w] < min_rl ? s_red[1][w] : min_rl;
+      max_rl = s_red[2][w] > max_rl ? s_red[2][w] : max_rl;
+    }
+    if (n_ok) {
+      atomicAdd(&acc->num_rds, n_ok * weight);
+      if (min_rl < acc->min_rl) atomicMin(&acc->min_rl, min_rl);
+      if (max_rl > acc->max_rl) atomicMax(&acc->max_rl, max_rl);
+    }
+  }
+  for (int i = threadIdx.x; i < kHistLds; i += kBlock) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&hist[i], (unsigned long long)c * weight);
   }
 }
 

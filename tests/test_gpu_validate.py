@@ -189,3 +189,62 @@ def test_synthetic_generator_is_valid_and_deterministic(ctx):
     got_d = ctx.validate(a.data_ptr(), acc, st, nbytes=n * R)
     assert got_d["code"] == 0 and got_d["n_records"] == n
     acc.close()
+
+
+FAST_KINDS = ["flip_seq", "del_byte", "drop_line", "dup_line", "bad_plus", "bad_at", "short_qual", "mix_ut",
+              "empty_seq", "high_qual", "hdr2_name", "empty_hdr", "strip_last_nl", "truncate"]
+
+
+@pytest.mark.parametrize("kind", FAST_KINDS)
+def test_tiled_path_on_multi_tile_images(ctx, kind):
+    """Images of many 16 KiB tiles with ONE defect somewhere: the tiled path (path == 2) must
+    find exactly what the serial oracle finds, including defects on tile seams."""
+    rng = np.random.default_rng(abs(hash("big" + kind)) % 100000)
+    for trial in range(6):
+        style = ["casava", "slash", "int", "nosuffix"][trial % 4]
+        img = fuzz.make_fastq(rng, 6000, 20, 200, style)
+        img = fuzz.mutate(rng, img, kind)
+        got = check_image(ctx, img)
+        assert got["path"] == 2
+        check_image(ctx, img, force_exact=True)
+
+
+def test_tiled_path_defects_on_every_seam_offset(ctx):
+    """Slide one bad base / one bad '+' / one bad '@' across a tile boundary byte by byte."""
+    rng = np.random.default_rng(3)
+    base = bytearray(fuzz.make_fastq(rng, 400, 100, 100, "casava"))
+    lines = bytes(base).split(b"\n")
+    # record geometry is fixed (names differ in length a little): find records around 16 KiB
+    offs, p = [], 0
+    for ln in lines[:-1]:
+        offs.append(p)
+        p += len(ln) + 1
+    seam = 16384
+    near = [i for i, o in enumerate(offs) if seam - 400 < o < seam + 400]
+    for li in near:
+        for delta, repl in ((0, b"X"), (1, b"\n")):
+            img = bytearray(base)
+            pos = offs[li] + delta
+            if pos < len(img) and img[pos:pos + 1] != b"\n":
+                img[pos:pos + 1] = repl
+                check_image(ctx, bytes(img))
+
+
+def test_tiled_path_many_suspects_overflow_queue(ctx):
+    """Every record repeats its name on line 3: each one is queued for the exact validator."""
+    rng = np.random.default_rng(21)
+    img = fuzz.make_fastq(rng, 30000, 30, 60, "slash", hdr2_names=True)
+    got = check_image(ctx, img)
+    assert got["path"] == 2 and got["code"] == 0
+    bad = img.replace(b"\n+read.29000/1\n", b"\n+read.29000/2x\n")
+    got = check_image(ctx, bad)
+    assert got["code"] == 10 and got["record"] == 29000
+
+
+def test_lowercase_and_rna_take_the_exact_checks(ctx):
+    rng = np.random.default_rng(8)
+    img = fuzz.make_fastq(rng, 5000, 50, 120, "casava", rna=True)
+    got = check_image(ctx, img)
+    assert got["code"] == 0
+    img2 = fuzz.make_fastq(rng, 5000, 50, 120, "casava").lower().replace(b"syn:", b"SYN:")
+    check_image(ctx, img2)
