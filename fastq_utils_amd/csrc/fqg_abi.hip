@@ -435,6 +435,73 @@ int fqg_acc_merge(fqg_acc* a, const void* buf, size_t used) {
 }
 
 // ---- framing + validation -------------------------------------------------------------------
+namespace {
+
+struct Framed {
+  uint64_t n_newlines = 0;
+  bool last_nl = false;
+  uint32_t img_flags = 0;
+  bool checks_done = false;  // the byte-class checks of the tiled path ran over the image
+};
+
+void init_call_state(fqg_ctx* c) {
+  CallState init;
+  memset(&init, 0, sizeof(init));
+  init.first_key = ~0ull;
+  init.stop_record = ~0ull;
+  init.qmin_byte = 255;
+  *c->h_cs = init;
+}
+
+// Two passes over the image: newline census per chunk, prefix over the counts, then the line
+// index (with or without the byte-class checks).  Sizes every buffer exactly.
+int frame_two_pass(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_chunks, bool final,
+                   bool want_checks, SuspectMap sm, Framed* out) {
+  int rc;
+  const uint32_t n_spans = (n_chunks + kScanSpan - 1) / kScanSpan;
+  if ((rc = ensure(c, c->tile_counts, (size_t)n_chunks * 4))) return rc;
+  if ((rc = ensure(c, c->tile_local, (size_t)n_chunks * 4))) return rc;
+  if ((rc = ensure(c, c->span_sums, (size_t)n_spans * 8))) return rc;
+  init_call_state(c);
+  HIP_TRY(c, hipMemcpyAsync(c->d_cs, c->h_cs, sizeof(CallState), hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, "k_count_nl");
+    hipLaunchKernelGGL(k_count_nl, dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
+                       (uint32_t*)c->tile_counts.p, c->d_cs);
+  }
+  {
+    ProfScope ps(c, "k_scan");
+    hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
+                       n_chunks, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p);
+    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
+                       n_spans, d_img, nbytes, c->d_cs);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out->n_newlines = c->h_cs->n_newlines;
+  out->last_nl = c->h_cs->last_byte_is_nl != 0;
+  out->img_flags = c->h_cs->flags;
+  const uint64_t n_lines_all = out->n_newlines + (out->last_nl ? 0 : 1);
+  const uint64_t usable = (final || out->last_nl) ? n_lines_all : out->n_newlines;
+  const uint64_t line_cap = n_lines_all + 17;
+  if ((rc = ensure(c, c->line_end, (size_t)line_cap * 8))) return rc;
+  const bool checks = want_checks && !(out->img_flags & (kFlagNul | kFlagCr));
+  const unsigned grid = (unsigned)std::min<uint64_t>((n_chunks + 3) / 4, (uint64_t)c->cu_count * 8);
+  ProfScope ps(c, checks ? "k_frame_fast" : "k_lines");
+  if (checks)
+    hipLaunchKernelGGL(k_frame_fast_t<0u>, dim3(grid), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
+                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
+                       (uint64_t*)c->line_end.p, line_cap, 4 * (usable / 4), sm, c->d_cs);
+  else
+    hipLaunchKernelGGL(k_frame_fast_t<7u>, dim3(grid), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
+                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
+                       (uint64_t*)c->line_end.p, line_cap, (uint64_t)0, sm, c->d_cs);
+  out->checks_done = checks;
+  return 0;
+}
+
+}  // namespace
+
 int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, int mem, int final,
                  const fqg_file_state* st, uint32_t flags, fqg_validate_result* out) {
   if (!c || !out || !st || (nbytes && !image)) return FQG_ERR_ARG;
@@ -445,7 +512,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   c->frame_valid = false;
   HIP_TRY(c, hipSetDevice(c->device));
   if (nbytes == 0) return 0;
-  if (nbytes >= (1ull << 46)) return fail(c, FQG_ERR_ARG, "image too large");
+  if (nbytes >= (1ull << 44)) return fail(c, FQG_ERR_ARG, "image too large");
 
   int rc;
   const uint8_t* d_img;
@@ -458,45 +525,33 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
     if (((uintptr_t)image & 15u) != 0) return fail(c, FQG_ERR_ARG, "device image must be 16-byte aligned");
     d_img = (const uint8_t*)image;
   }
+  const uint32_t n_chunks = (uint32_t)((nbytes + kChunkBytes - 1) / kChunkBytes);
+  const bool want_checks = !(flags & FQG_VALIDATE_FORCE_EXACT);
+  const uint32_t weight = (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u;
 
-  const uint64_t n_tiles64 = (nbytes + kTileBytes - 1) / kTileBytes;
-  const uint32_t n_tiles = (uint32_t)n_tiles64;
-  const uint32_t n_spans = (n_tiles + kScanSpan - 1) / kScanSpan;
-  if ((rc = ensure(c, c->tile_counts, (size_t)n_tiles * 4))) return rc;
-  if ((rc = ensure(c, c->tile_local, (size_t)n_tiles * 4))) return rc;
-  if ((rc = ensure(c, c->span_sums, (size_t)n_spans * 8))) return rc;
-
-  CallState init;
-  memset(&init, 0, sizeof(init));
-  init.first_key = ~0ull;
-  init.stop_record = ~0ull;
-  *c->h_cs = init;
-  HIP_TRY(c, hipMemcpyAsync(c->d_cs, c->h_cs, sizeof(CallState), hipMemcpyHostToDevice, c->stream));
-
-  {
-    ProfScope ps(c, "k_count_nl");
-    hipLaunchKernelGGL(k_count_nl, dim3(n_tiles), dim3(kBlock), 0, c->stream, d_img, nbytes,
-                       (uint32_t*)c->tile_counts.p, c->d_cs);
+  // suspect bitmap, sized from the image (>= 16 bytes per record assumed; denser images overflow
+  // it, which sends every record to the exact validator)
+  SuspectMap sm;
+  sm.cap = std::max<uint64_t>(nbytes / 16, 1024);
+  sm.flags = &c->d_cs->flags;
+  sm.bits = nullptr;
+  if (want_checks) {
+    if ((rc = ensure(c, c->suspect, (size_t)(sm.cap / 32 + 2) * 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(sm.cap / 32 + 2) * 4, c->stream));
+    sm.bits = (uint32_t*)c->suspect.p;
   }
-  {
-    ProfScope ps(c, "k_scan");
-    hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
-                       n_tiles, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p);
-    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
-                       n_spans, d_img, nbytes, c->d_cs);
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  const uint64_t n_newlines = c->h_cs->n_newlines;
-  const bool last_nl = c->h_cs->last_byte_is_nl != 0;
-  const uint32_t img_flags = c->h_cs->flags;
+
+  Framed fr;
+  if ((rc = frame_two_pass(c, d_img, nbytes, n_chunks, final != 0, want_checks, sm, &fr))) return rc;
+  const uint64_t n_newlines = fr.n_newlines;
+  const bool last_nl = fr.last_nl;
+  const uint32_t img_flags = fr.img_flags;
   const uint64_t n_lines_all = n_newlines + (last_nl ? 0 : 1);
   // an unterminated last line is only a line when nothing more can follow
   const uint64_t usable = (final || last_nl) ? n_lines_all : n_newlines;
   uint64_t n_records = usable / 4;
   const uint64_t leftover = usable % 4;
 
-  if ((rc = ensure(c, c->line_end, (size_t)(n_lines_all + 1) * 8))) return rc;
   FrameView fv;
   fv.img = d_img;
   fv.nbytes = nbytes;
@@ -504,14 +559,6 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   fv.n_lines = n_lines_all;
   fv.n_records = n_records;
 
-  // images with NUL / CR bytes (or on request) take the exact path: plain line index first
-  const bool want_fast = !(flags & FQG_VALIDATE_FORCE_EXACT) && !(img_flags & (kFlagNul | kFlagCr));
-  if (!want_fast) {
-    ProfScope ps(c, "k_lines");
-    hipLaunchKernelGGL(k_lines, dim3(n_tiles), dim3(kBlock), 0, c->stream, d_img, nbytes,
-                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
-                       (uint64_t*)c->line_end.p, c->d_cs);
-  }
   // a record that starts with NUL ends the file silently (src/fastq.c:250)
   bool tail_is_stop = false;
   if (img_flags & kFlagNul) {
@@ -542,34 +589,24 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
     fv.n_records = n_records;
   }
 
-  const uint32_t weight = (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u;
-  // The tiled path needs an image without NUL / CR bytes (then every line is terminated by
-  // its '\n' alone and statistics follow from the line index); anything else goes through the
+  // The tiled path needs an image without NUL / CR bytes (then every line is terminated by its
+  // '\n' alone and the statistics follow from the line index); anything else goes through the
   // exact wave-per-record validator as a whole.
-  const bool fast = !(flags & FQG_VALIDATE_FORCE_EXACT) && !(img_flags & (kFlagNul | kFlagCr));
+  const bool fast = fr.checks_done;
   uint64_t list_cap = 0;
   if (fast) {
-    list_cap = std::max<uint64_t>(1u << 20, n_records / 16);
-    if (list_cap > n_records) list_cap = std::max<uint64_t>(n_records, 1);
-    if ((rc = ensure(c, c->suspect, (size_t)(n_records / 32 + 2) * 4))) return rc;
-    if ((rc = ensure(c, c->list, (size_t)list_cap * 8))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(n_records / 32 + 2) * 4, c->stream));
-    const unsigned grid_t = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->cu_count * 8);
-    {
-      ProfScope ps(c, "k_frame_fast");
-      hipLaunchKernelGGL(k_frame_fast, dim3(grid_t), dim3(kBlock), 0, c->stream, d_img, nbytes, n_tiles,
-                         (const uint32_t*)c->tile_counts.p, (const uint32_t*)c->tile_local.p,
-                         (const unsigned long long*)c->span_sums.p, (uint64_t*)c->line_end.p, 4 * n_records,
-                         (uint32_t*)c->suspect.p, acc ? acc->d_state : nullptr, c->d_cs);
-    }
+    out->path = 2;
     if (n_records) {
+      list_cap = std::max<uint64_t>(1u << 20, n_records / 16);
+      if (list_cap > n_records) list_cap = n_records;
+      if ((rc = ensure(c, c->list, (size_t)list_cap * 8))) return rc;
       const unsigned grid_r =
           (unsigned)std::min<uint64_t>((n_records + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 8);
       {
         ProfScope ps(c, "k_records_fast");
-        hipLaunchKernelGGL(k_records_fast, dim3(grid_r), dim3(kBlock), 0, c->stream, fv, st->space, weight,
-                           (const uint32_t*)c->suspect.p, (unsigned long long*)c->list.p, list_cap,
-                           &c->d_cs->list_count, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr);
+        hipLaunchKernelGGL(k_records_fast, dim3(grid_r), dim3(kBlock), 0, c->stream, fv, st->space, weight, sm,
+                           (unsigned long long*)c->list.p, list_cap, &c->d_cs->list_count,
+                           acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr, c->d_cs);
       }
       {
         ProfScope ps(c, "k_validate_exact");
@@ -579,7 +616,6 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
                            (const unsigned long long*)c->list.p, (const unsigned long long*)&c->d_cs->list_count);
       }
     }
-    out->path = 2;
   } else if (n_records) {
     ProfScope ps(c, "k_validate_exact");
     hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
@@ -599,9 +635,9 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   out->consumed = n_records ? c->h_scalar[1] + 1 : 0;
   if (out->consumed > nbytes) out->consumed = nbytes;  // unterminated last line
 
-  if (fast && c->h_cs->list_count > list_cap) {
-    // more suspects than the queue holds (e.g. every record carries its name on line 3): let the
-    // exact validator look at every record; the statistics of the tiled pass stand
+  if (fast && n_records && (c->h_cs->list_count > list_cap || (c->h_cs->flags & kFlagSuspectOverflow))) {
+    // more suspects than the queue / bitmap holds (e.g. every record carries its name on line 3):
+    // let the exact validator look at every record; the statistics of the tiled pass stand
     ProfScope ps(c, "k_validate_exact");
     hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
                        st->is_pe, st->readname_format, st->space, weight, (AccState*)nullptr,

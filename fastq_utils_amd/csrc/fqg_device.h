@@ -10,15 +10,15 @@ namespace fqg {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;                 // 4 waves
-constexpr int kTileBytes = 16384;           // bytes framed by one workgroup
-constexpr int kPieces = kTileBytes / (kBlock * 16);  // 16-byte pieces per thread per tile
-constexpr int kScanSpan = 4096;             // tile counts scanned by one workgroup
+constexpr int kChunkBytes = 4096;           // bytes framed by one wavefront per step
+constexpr int kSlices = kChunkBytes / (kWave * 16);  // 1 KiB slices (64 lanes x 16 B) per chunk
+constexpr int kScanSpan = 4096;             // chunk counts scanned by one workgroup
 constexpr uint64_t kNoRecord = ~0ull;
 
 // image-level flags raised by the framing pass
 constexpr uint32_t kFlagNul = 1u;       // a NUL byte somewhere in the image
 constexpr uint32_t kFlagCr = 2u;        // a '\r' somewhere in the image
-constexpr uint32_t kFlagSuspect = 4u;   // the tiled validator saw a record it cannot vouch for
+constexpr uint32_t kFlagSuspectOverflow = 16u;  // a suspect record lies beyond the bitmap
 
 // Scalars of one fqg_validate() call.  Lives in device memory; the host copies it back once.
 struct CallState {
@@ -29,6 +29,7 @@ struct CallState {
   unsigned long long list_count;  // records queued by the fast path for the exact validator
   unsigned int flags;
   unsigned int last_byte_is_nl;
+  unsigned int qmin_byte, qmax_byte;  // quality range seen by the tiled pass (255 / 0 when none)
 };
 
 // Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).
@@ -38,6 +39,13 @@ struct AccState {
   unsigned long long max_rl;   // init 0
   unsigned int min_qbyte;      // init 255 (unsigned-byte domain; mapped at read-out)
   unsigned int max_qbyte;      // init 0
+};
+
+// 1 bit per record: the tiled pass could not vouch for it.
+struct SuspectMap {
+  uint32_t* bits;
+  unsigned long long cap;  // records covered
+  unsigned int* flags;     // &CallState::flags
 };
 
 struct FrameView {

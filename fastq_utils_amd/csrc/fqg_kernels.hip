@@ -1,9 +1,11 @@
 // fqg_kernels.hip - HIP kernels for gfx950 (MI355X): FASTQ framing and record validation.
 //
 // Pipeline of one fqg_validate() call:
-//   k_count_nl   one workgroup per 16 KiB tile: count '\n', raise NUL / CR flags
-//   k_scan_a/b   exclusive prefix over the tile counts (two small launches)
-//   k_lines      one workgroup per tile: write the offset of every '\n' into line_end[]
+//   k_count_nl   one wavefront per 4 KiB chunk: count '\n', raise NUL / CR flags
+//   k_scan_a/b   exclusive prefix over the chunk counts (two small launches)
+//   k_frame_fast_t  one wavefront per chunk: offsets of every '\n' into line_end[], and (tiled
+//                path) the byte-class checks + quality range; <7> builds the line index only
+//   k_records_fast  one thread per record: lengths, statistics, queue of suspect records
 //   k_validate_exact  one wavefront per record: the complete check sequence of
 //                fastq_validate_entry (reference src/fastq.c:300-392) with ballots over 64-byte
 //                slices of each line; statistics kept in registers and flushed once per wave
@@ -58,25 +60,21 @@ __device__ __forceinline__ bool is_base(uint32_t c) {
 // framing: newline census per tile
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_count_nl(const uint8_t* __restrict__ img, uint64_t n,
-                                                     uint32_t* __restrict__ tile_counts,
+                                                     uint32_t n_chunks,
+                                                     uint32_t* __restrict__ chunk_counts,
                                                      CallState* __restrict__ cs) {
-  __shared__ uint32_t s_cnt[kBlock / kWave];
-  __shared__ uint32_t s_flag[kBlock / kWave];
-  const uint64_t base = (uint64_t)blockIdx.x * kTileBytes;
+  // one wavefront per 4 KiB chunk, no workgroup-level cooperation
+  const uint32_t chunk = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (chunk >= n_chunks) return;
+  const uint64_t base = (uint64_t)chunk * kChunkBytes + (uint64_t)lane_id() * 16;
   uint32_t cnt = 0, nul = 0, cr = 0;
+  uint4 v[kSlices];
 #pragma unroll
-  for (int u = 0; u < kPieces; ++u) {
-    const uint64_t off = base + ((uint64_t)u * kBlock + threadIdx.x) * 16;
-    if (off + 16 <= n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(img + off);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        cnt += __popc(eq_bytes(w[k], 0x0A0A0A0Au));
-        nul |= eq_bytes(w[k], 0u);
-        cr |= eq_bytes(w[k], 0x0D0D0D0Du);
-      }
-    } else if (off < n) {
+  for (int k = 0; k < kSlices; ++k) {
+    const uint64_t off = base + (uint64_t)k * (kWave * 16);
+    v[k] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+    if (off + 16 <= n) v[k] = *reinterpret_cast<const uint4*>(img + off);
+    else if (off < n) {
       for (uint64_t i = off; i < n; ++i) {
         const uint32_t c = img[i];
         cnt += (c == '\n');
@@ -85,22 +83,21 @@ __global__ __launch_bounds__(kBlock) void k_count_nl(const uint8_t* __restrict__
       }
     }
   }
-  uint32_t fl = (nul ? kFlagNul : 0u) | (cr ? kFlagCr : 0u);
-  cnt = wave_sum(cnt);
-  const uint64_t anyn = __ballot(fl & kFlagNul), anyc = __ballot(fl & kFlagCr);
-  if (lane_id() == 0) {
-    s_cnt[threadIdx.x >> 6] = cnt;
-    s_flag[threadIdx.x >> 6] = (anyn ? kFlagNul : 0u) | (anyc ? kFlagCr : 0u);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0, f = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) {
-      t += s_cnt[w];
-      f |= s_flag[w];
+  for (int k = 0; k < kSlices; ++k) {
+    const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cnt += __popc(eq_bytes(w[j], 0x0A0A0A0Au));
+      nul |= eq_bytes(w[j], 0u);
+      cr |= eq_bytes(w[j], 0x0D0D0D0Du);
     }
-    tile_counts[blockIdx.x] = t;
+  }
+  cnt = wave_sum(cnt);
+  const uint64_t anyn = __ballot(nul != 0), anyc = __ballot(cr != 0);
+  if (lane_id() == 0) {
+    chunk_counts[chunk] = cnt;
+    const uint32_t f = (anyn ? kFlagNul : 0u) | (anyc ? kFlagCr : 0u);
     if (f) atomicOr(&cs->flags, f);
   }
 }
@@ -178,42 +175,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restric
     cs->n_newlines = s_carry;
     cs->last_byte_is_nl = (n > 0 && img[n - 1] == '\n') ? 1u : 0u;
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// framing: line index
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_lines(const uint8_t* __restrict__ img, uint64_t n,
-                                                  const uint32_t* __restrict__ tile_local,
-                                                  const unsigned long long* __restrict__ span_excl,
-                                                  uint64_t* __restrict__ line_end,
-                                                  const CallState* __restrict__ cs) {
-  __shared__ uint32_t s_wave[kBlock / kWave];
-  const uint32_t tile = blockIdx.x;
-  uint64_t rank0 = span_excl[tile / kScanSpan] + tile_local[tile];
-  const uint64_t base = (uint64_t)tile * kTileBytes;
-#pragma unroll
-  for (int u = 0; u < kPieces; ++u) {
-    const uint64_t off = base + ((uint64_t)u * kBlock + threadIdx.x) * 16;
-    uint32_t m = 0;  // bit j: byte off+j is '\n'
-    if (off + 16 <= n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(img + off);
-      m = mark_bits(eq_bytes(v.x, 0x0A0A0A0Au)) | (mark_bits(eq_bytes(v.y, 0x0A0A0A0Au)) << 4) |
-          (mark_bits(eq_bytes(v.z, 0x0A0A0A0Au)) << 8) | (mark_bits(eq_bytes(v.w, 0x0A0A0A0Au)) << 12);
-    } else if (off < n) {
-      for (uint64_t i = off; i < n; ++i) m |= (img[i] == '\n') ? (1u << (i - off)) : 0u;
-    }
-    uint32_t total;
-    uint32_t r = block_scan_excl(__popc(m), s_wave, &total);
-    while (m) {
-      const int j = __builtin_ctz(m);
-      m &= m - 1;
-      line_end[rank0 + r++] = off + j;
-    }
-    rank0 += total;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl)
-    line_end[cs->n_newlines] = n;  // an unterminated last line ends at the end of the image
 }
 
 // ------------------------------------------------------------------------------------------
@@ -560,14 +521,15 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
-__device__ __forceinline__ void mark_suspect(uint32_t* __restrict__ suspect, uint64_t record) {
-  atomicOr(&suspect[record >> 5], 1u << (record & 31u));
+__device__ __forceinline__ void mark_suspect(const SuspectMap& sm, uint64_t record) {
+  if (record < sm.cap) atomicOr(&sm.bits[record >> 5], 1u << (record & 31u));
+  else atomicOr(sm.flags, kFlagSuspectOverflow);
 }
 
 // Generic byte-at-a-time version of the per-piece work, used for the one or two tiles at the
 // end of the image where look-ahead bytes or lines beyond the last complete record exist.
 __device__ __forceinline__ void piece_generic(const uint8_t* __restrict__ img, uint64_t n, uint64_t off,
-                                              uint64_t line, uint64_t limit, uint32_t* __restrict__ suspect,
+                                              uint64_t line, uint64_t limit, const SuspectMap& suspect,
                                               uint32_t& qmin, uint32_t& qmax) {
   for (int j = 0; j < 16 && off + j < n; ++j) {
     const uint64_t pos = off + j;
@@ -590,124 +552,201 @@ __device__ __forceinline__ void piece_generic(const uint8_t* __restrict__ img, u
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_frame_fast(const uint8_t* __restrict__ img, uint64_t n,
-                                                       uint32_t n_tiles,
-                                                       const uint32_t* __restrict__ tile_counts,
-                                                       const uint32_t* __restrict__ tile_local,
-                                                       const unsigned long long* __restrict__ span_excl,
-                                                       uint64_t* __restrict__ line_end, uint64_t limit,
-                                                       uint32_t* __restrict__ suspect,
-                                                       AccState* __restrict__ acc,
-                                                       const CallState* __restrict__ cs) {
-  __shared__ uint32_t s_wave[kBlock / kWave];
-  __shared__ uint32_t s_q[2][kBlock / kWave];
-  // packed u16 pairs: even bytes / odd bytes
-  uint32_t mn_e = 0x00FF00FFu, mn_o = 0x00FF00FFu, mx_e = 0, mx_o = 0;
-  uint32_t gq_min = 255, gq_max = 0;  // from the generic tail path
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    uint64_t rank0 = span_excl[tile / kScanSpan] + tile_local[tile];
-    const uint64_t base = (uint64_t)tile * kTileBytes;
-    const bool interior = base + kTileBytes + 4 <= n && rank0 + tile_counts[tile] + 1 <= limit;
-#pragma unroll 1
-    for (int u = 0; u < kPieces; ++u) {
-      const uint64_t off = base + ((uint64_t)u * kBlock + threadIdx.x) * 16;
-      uint32_t nl = 0;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (off + 16 <= n) {
-        v = *reinterpret_cast<const uint4*>(img + off);
-        nl = mark_bits(eq_bytes(v.x, 0x0A0A0A0Au)) | (mark_bits(eq_bytes(v.y, 0x0A0A0A0Au)) << 4) |
-             (mark_bits(eq_bytes(v.z, 0x0A0A0A0Au)) << 8) | (mark_bits(eq_bytes(v.w, 0x0A0A0A0Au)) << 12);
-      } else if (off < n) {
-        for (uint64_t i = off; i < n; ++i) nl |= (img[i] == '\n') ? (1u << (i - off)) : 0u;
-      }
-      uint32_t total;
-      const uint32_t r = block_scan_excl(__popc(nl), s_wave, &total);
-      const uint64_t line0 = rank0 + r;  // index of the line the first byte of this piece is in
-      // ---- line index ----
-      {
-        uint32_t m = nl;
-        uint64_t k = line0;
-        while (m) {
-          const int j = __builtin_ctz(m);
-          m &= m - 1;
-          line_end[k++] = off + j;
-        }
-      }
-      if (interior) {
-        // type (line index mod 4) of every byte: 2-bit running count of the newlines before it
-        const uint32_t e = (nl << 1) & 0xFFFFu;
-        const uint32_t P = prefix_xor16(e);            // count bit 0
-        const uint32_t Q = prefix_xor16(e & ~P);       // count bit 1 (carry when bit 0 wraps)
-        const uint32_t t0 = (uint32_t)line0 & 3u;
-        const uint32_t a0 = (t0 & 1u) ? 0xFFFFu : 0u, a1 = (t0 & 2u) ? 0xFFFFu : 0u;
-        const uint32_t L = P ^ a0;
-        const uint32_t H = Q ^ a1 ^ (P & a0);
-        const uint32_t M1 = ~H & L & 0xFFFFu, M3 = H & L;
-        // ---- bases: anything outside ACGTN on a sequence line ----
-        const uint32_t inv = mark_bits(not_acgtn(v.x)) | (mark_bits(not_acgtn(v.y)) << 4) |
-                             (mark_bits(not_acgtn(v.z)) << 8) | (mark_bits(not_acgtn(v.w)) << 12);
-        uint32_t bad = inv & M1 & ~nl;
-        // ---- first two bytes of header lines, anchored at the newline in front of them ----
-        uint32_t cand = nl & (M1 | M3);  // newline ends a sequence / quality line
-        const uint32_t nxt_own = v.x;
-        uint32_t nxt = __shfl_down(nxt_own, 1, 64);
-        if (lane_id() == 63) nxt = *reinterpret_cast<const uint32_t*>(img + off + 16);
-        uint32_t badstart = 0;  // bit j: the line after the newline at j is not provably fine
-        if (cand) {
-          const uint64_t q0 = (uint64_t)v.x | ((uint64_t)v.y << 32), q1 = (uint64_t)v.z | ((uint64_t)v.w << 32),
-                         q2 = nxt;
-          uint32_t m = cand;
-          while (m) {
-            const int j = __builtin_ctz(m);
-            m &= m - 1;
-            const int p = j + 1;
-            const uint64_t lo = p < 8 ? q0 : (p < 16 ? q1 : q2), hi = p < 8 ? q1 : q2;
-            const int sh = (p & 7) * 8;
-            uint64_t x = lo >> sh;
-            if ((p & 7) == 7) x |= hi << 8;
-            const uint32_t c1 = (uint32_t)x & 0xFFu, c2 = ((uint32_t)x >> 8) & 0xFFu;
-            const bool after_qual = (M3 >> j) & 1u;  // next line is a header 1, else a header 2
-            const bool ok = after_qual ? (c1 == '@' && c2 != '\n') : (c1 == '+' && c2 == '\n');
-            if (!ok) badstart |= 1u << j;
-          }
-        }
-        if (off == 0 && ((v.x & 0xFFu) != '@' || ((v.x >> 8) & 0xFFu) == '\n')) mark_suspect(suspect, 0);
-        if (bad | badstart) {
-          uint32_t m = bad;
-          while (m) {
-            const int j = __builtin_ctz(m);
-            m &= m - 1;
-            mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u))) >> 2);
-          }
-          m = badstart;
-          while (m) {
-            const int j = __builtin_ctz(m);
-            m &= m - 1;
-            mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u)) + 1) >> 2);
-          }
-        }
-        // ---- quality range: bytes of 4th lines, newline excluded ----
-        const uint32_t qm = M3 & ~nl;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+// DPP lane permutes (gfx9 family): row_shr:n = 0x110+n, row_bcast15 = 0x142, row_bcast31 = 0x143,
+// wave_shl1 = 0x130.  Masked-off or out-of-range lanes contribute 0.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+// inclusive scan over the 64 lanes in 7 DPP adds (no LDS traffic)
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v) {
+  uint32_t x = v + dpp0<0x111, 0xf, 0xf>(v);
+  x += dpp0<0x112, 0xf, 0xf>(v);
+  x += dpp0<0x113, 0xf, 0xf>(v);
+  x += dpp0<0x114, 0xf, 0xe>(x);
+  x += dpp0<0x118, 0xf, 0xc>(x);
+  x += dpp0<0x142, 0xa, 0xf>(x);
+  x += dpp0<0x143, 0xc, 0xf>(x);
+  return x;
+}
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint4& v) {
+  return mark_bits(eq_bytes(v.x, 0x0A0A0A0Au)) | (mark_bits(eq_bytes(v.y, 0x0A0A0A0Au)) << 4) |
+         (mark_bits(eq_bytes(v.z, 0x0A0A0A0Au)) << 8) | (mark_bits(eq_bytes(v.w, 0x0A0A0A0Au)) << 12);
+}
+
+struct QRange {
+  uint32_t mn_e, mn_o, mx_e, mx_o;  // packed u16 pairs: even / odd bytes
+};
+
+// The SWAR checks on one 16-byte piece whose bytes, two look-ahead bytes and lines all exist.
+// ABL is an ablation mask for tools/kbench (product code instantiates 0).
+template <uint32_t ABL>
+__device__ __forceinline__ void piece_fast(const uint4& v, uint32_t nl, uint64_t line0, uint64_t off,
+                                           uint32_t nxt, const SuspectMap& suspect, QRange& q) {
+  // type (line index mod 4) of every byte: 2-bit running count of the newlines before it
+  const uint32_t e = (nl << 1) & 0xFFFFu;
+  const uint32_t P = prefix_xor16(e);       // count bit 0
+  const uint32_t Q = prefix_xor16(e & ~P);  // count bit 1 (carry when bit 0 wraps)
+  const uint32_t t0 = (uint32_t)line0 & 3u;
+  const uint32_t a0 = (t0 & 1u) ? 0xFFFFu : 0u, a1 = (t0 & 2u) ? 0xFFFFu : 0u;
+  const uint32_t L = P ^ a0;
+  const uint32_t H = Q ^ a1 ^ (P & a0);
+  const uint32_t M1 = ~H & L & 0xFFFFu, M3 = H & L;
+  uint32_t bad = 0, badstart = 0;
+  if (!(ABL & 2u)) {
+    // bases: anything outside ACGTN on a sequence line
+    const uint32_t inv = mark_bits(not_acgtn(v.x)) | (mark_bits(not_acgtn(v.y)) << 4) |
+                         (mark_bits(not_acgtn(v.z)) << 8) | (mark_bits(not_acgtn(v.w)) << 12);
+    bad = inv & M1 & ~nl;
+  }
+  if (!(ABL & 4u)) {
+    // first two bytes of header lines, anchored at the newline in front of them
+    uint32_t cand = nl & (M1 | M3);  // newline ends a sequence / quality line
+    if (cand) {
+      const uint64_t q0 = (uint64_t)v.x | ((uint64_t)v.y << 32), q1 = (uint64_t)v.z | ((uint64_t)v.w << 32),
+                     q2 = nxt;
+      // newline bits of this piece followed by those of the next 2 bytes
+      const uint32_t nl18 = nl | ((mark_bits(eq_bytes(nxt, 0x0A0A0A0Au)) & 3u) << 16);
+      do {  // one trip for ordinary data: a 16-byte piece rarely holds two such newlines
+        const int j = __builtin_ctz(cand);
+        cand &= cand - 1;
+        const int p = j + 1;
+        const uint64_t lo = p < 8 ? q0 : (p < 16 ? q1 : q2);
+        const uint32_t c1 = (uint32_t)(lo >> ((p & 7) * 8)) & 0xFFu;
+        const bool c2_nl = (nl18 >> (p + 1)) & 1u;
+        const bool after_qual = (M3 >> j) & 1u;  // next line is a header 1, else a header 2
+        const bool ok = after_qual ? (c1 == '@' && !c2_nl) : (c1 == '+' && c2_nl);
+        badstart |= ok ? 0u : (1u << j);
+      } while (cand);
+    }
+    if (off == 0 && ((v.x & 0xFFu) != '@' || ((v.x >> 8) & 0xFFu) == '\n')) mark_suspect(suspect, 0);
+  }
+  if (bad | badstart) {
+    uint32_t m = bad;
+    while (m) {
+      const int j = __builtin_ctz(m);
+      m &= m - 1;
+      mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u))) >> 2);
+    }
+    m = badstart;
+    while (m) {
+      const int j = __builtin_ctz(m);
+      m &= m - 1;
+      mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u)) + 1) >> 2);
+    }
+  }
+  if (!(ABL & 1u)) {
+    // quality range: bytes of 4th lines, newline excluded
+    const uint32_t qm = M3 & ~nl;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t bm = nibble_to_bytes(qm >> (4 * k));
-          const uint32_t lo = w[k] | ~bm, hi = w[k] & bm;
-          mn_e = pk_min_u16(mn_e, __builtin_amdgcn_perm(0u, lo, 0x0C020C00u));
-          mn_o = pk_min_u16(mn_o, __builtin_amdgcn_perm(0u, lo, 0x0C030C01u));
-          mx_e = pk_max_u16(mx_e, __builtin_amdgcn_perm(0u, hi, 0x0C020C00u));
-          mx_o = pk_max_u16(mx_o, __builtin_amdgcn_perm(0u, hi, 0x0C030C01u));
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t bm = nibble_to_bytes(qm >> (4 * k));
+      const uint32_t lo = w[k] | ~bm, hi = w[k] & bm;
+      q.mn_e = pk_min_u16(q.mn_e, __builtin_amdgcn_perm(0u, lo, 0x0C020C00u));
+      q.mn_o = pk_min_u16(q.mn_o, __builtin_amdgcn_perm(0u, lo, 0x0C030C01u));
+      q.mx_e = pk_max_u16(q.mx_e, __builtin_amdgcn_perm(0u, hi, 0x0C020C00u));
+      q.mx_o = pk_max_u16(q.mx_o, __builtin_amdgcn_perm(0u, hi, 0x0C030C01u));
+    }
+  }
+}
+
+// Work decomposition: ONE WAVEFRONT owns a contiguous 4 KiB chunk per step and walks it as 4
+// slices of 1 KiB (64 lanes x 16 B, fully coalesced).  There is no workgroup-level cooperation
+// at all - no LDS, no barriers: the newline ranks inside a chunk come from two packed DPP scans,
+// the rank of the chunk itself from the prefix over the per-chunk counts.  Wavefronts are
+// persistent (chunk = wave, wave + W, ...), and the loads of the next chunk are issued before
+// the current one is processed.
+template <uint32_t ABL>
+__global__ __launch_bounds__(kBlock) void k_frame_fast_t(const uint8_t* __restrict__ img, uint64_t n,
+                                                         uint32_t n_chunks,
+                                                         const uint32_t* __restrict__ chunk_local,
+                                                         const unsigned long long* __restrict__ span_excl,
+                                                         uint64_t* __restrict__ line_end, uint64_t line_cap,
+                                                         uint64_t limit, SuspectMap suspect,
+                                                         CallState* __restrict__ cs) {
+  static_assert(kSlices == 4, "packed scans below assume 4 slices per chunk");
+  const int lane = lane_id();
+  const uint32_t n_waves = gridDim.x * (kBlock / kWave);
+  const uint32_t wave0 = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
+  uint32_t gq_min = 255, gq_max = 0;  // from the generic tail path
+  uint4 vn[kSlices];
+  auto load_chunk = [&](uint32_t c, uint4 (&dst)[kSlices]) {
+    const uint64_t wb = (uint64_t)c * kChunkBytes + (uint64_t)lane * 16;
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) {
+      const uint64_t off = wb + (uint64_t)k * (kWave * 16);
+      dst[k] = make_uint4(0, 0, 0, 0);
+      if (off + 16 <= n) dst[k] = *reinterpret_cast<const uint4*>(img + off);
+    }
+  };
+  if (wave0 < n_chunks) load_chunk(wave0, vn);
+  for (uint32_t chunk = wave0; chunk < n_chunks; chunk += n_waves) {
+    const uint64_t rank0 = span_excl[chunk / kScanSpan] + chunk_local[chunk];
+    const uint64_t cbase = (uint64_t)chunk * kChunkBytes;
+    const uint64_t wbase = cbase + (uint64_t)lane * 16;
+    uint4 v[kSlices];
+    uint32_t nl[kSlices];
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) v[k] = vn[k];
+    if (chunk + n_waves < n_chunks) load_chunk(chunk + n_waves, vn);
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) {
+      const uint64_t off = wbase + (uint64_t)k * (kWave * 16);
+      nl[k] = nl_mask16(v[k]);
+      if (off + 16 > n) {
+        nl[k] = 0;
+        for (uint64_t i = off; i < n; ++i) nl[k] |= (img[i] == '\n') ? (1u << (i - off)) : 0u;
+      }
+    }
+    const uint32_t c01 = __popc(nl[0]) | (__popc(nl[1]) << 16), c23 = __popc(nl[2]) | (__popc(nl[3]) << 16);
+    const uint32_t s01 = wave_scan_incl_dpp(c01), s23 = wave_scan_incl_dpp(c23);
+    const uint32_t t01 = __builtin_amdgcn_readlane(s01, 63), t23 = __builtin_amdgcn_readlane(s23, 63);
+    const uint32_t total = (t01 & 0xFFFFu) + (t01 >> 16) + (t23 & 0xFFFFu) + (t23 >> 16);
+    const bool interior = cbase + kChunkBytes + 4 <= n && rank0 + total + 1 <= limit;
+    // exclusive rank of this lane's slice k inside the chunk
+    uint32_t ex[kSlices];
+    ex[0] = (s01 & 0xFFFFu) - (c01 & 0xFFFFu);
+    ex[1] = (t01 & 0xFFFFu) + (s01 >> 16) - (c01 >> 16);
+    ex[2] = (t01 & 0xFFFFu) + (t01 >> 16) + (s23 & 0xFFFFu) - (c23 & 0xFFFFu);
+    ex[3] = (t01 & 0xFFFFu) + (t01 >> 16) + (t23 & 0xFFFFu) + (s23 >> 16) - (c23 >> 16);
+    uint32_t tail4 = 0;  // the 4 bytes after this chunk, for lane 63 of the last slice
+    if (interior && lane == 63) tail4 = *reinterpret_cast<const uint32_t*>(img + cbase + kChunkBytes);
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) {
+      const uint64_t off = wbase + (uint64_t)k * (kWave * 16);
+      const uint64_t line0 = rank0 + ex[k];
+      if (!(ABL & 8u)) {
+        uint32_t m = nl[k];
+        if (m && line0 + 16 <= line_cap) {  // (the host notices an undersized index by the line count)
+          uint64_t* dst = line_end + line0;
+          dst[0] = off + __builtin_ctz(m);
+          m &= m - 1;
+          if (m) {
+            dst[1] = off + __builtin_ctz(m);
+            m &= m - 1;
+            for (int r = 2; m; ++r, m &= m - 1) dst[r] = off + __builtin_ctz(m);
+          }
         }
+      }
+      if ((ABL & 7u) == 7u) continue;  // line index only (exact path)
+      if (interior) {
+        uint32_t nxt = dpp0<0x130, 0xf, 0xf>(v[k].x);  // lane i <- lane i+1
+        const uint32_t first_next = (uint32_t)__builtin_amdgcn_readlane(v[k + 1 < kSlices ? k + 1 : k].x, 0);
+        if (lane == 63) nxt = k + 1 < kSlices ? first_next : tail4;
+        piece_fast<ABL>(v[k], nl[k], line0, off, nxt, suspect, q);
       } else if (off < n) {
         piece_generic(img, n, off, line0, limit, suspect, gq_min, gq_max);
       }
-      rank0 += total;
     }
   }
-  if (tile_counts && blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl && cs->n_newlines < line_cap)
     line_end[cs->n_newlines] = n;
-  // ---- fold the quality range: lanes -> wave -> block -> device ----
-  uint32_t qmin = pk_min_u16(mn_e, mn_o), qmax = pk_max_u16(mx_e, mx_o);
+  if ((ABL & 7u) == 7u) return;
+  // ---- fold the quality range: lanes -> wave -> device ----
+  uint32_t qmin = pk_min_u16(q.mn_e, q.mn_o), qmax = pk_max_u16(q.mx_e, q.mx_o);
   qmin = (qmin & 0xFFFFu) < (qmin >> 16) ? (qmin & 0xFFFFu) : (qmin >> 16);
   qmax = (qmax & 0xFFFFu) > (qmax >> 16) ? (qmax & 0xFFFFu) : (qmax >> 16);
   qmin = gq_min < qmin ? gq_min : qmin;
@@ -718,22 +757,10 @@ __global__ __launch_bounds__(kBlock) void k_frame_fast(const uint8_t* __restrict
     qmin = a < qmin ? a : qmin;
     qmax = b > qmax ? b : qmax;
   }
-  if (lane_id() == 0) {
-    s_q[0][threadIdx.x >> 6] = qmin;
-    s_q[1][threadIdx.x >> 6] = qmax;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && acc) {
-#pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) {
-      qmin = s_q[0][w] < qmin ? s_q[0][w] : qmin;
-      qmax = s_q[1][w] > qmax ? s_q[1][w] : qmax;
-    }
-    if (qmin <= qmax) {
-      // plain reads first: after the first few workgroups nobody improves the range any more
-      if (qmin < acc->min_qbyte) atomicMin(&acc->min_qbyte, qmin);
-      if (qmax > acc->max_qbyte) atomicMax(&acc->max_qbyte, qmax);
-    }
+  if (lane == 0 && qmin <= qmax) {
+    // plain reads first: after the first few wavefronts nobody improves the range any more
+    if (qmin < cs->qmin_byte) atomicMin(&cs->qmin_byte, qmin);
+    if (qmax > cs->qmax_byte) atomicMax(&cs->qmax_byte, qmax);
   }
 }
 
@@ -741,12 +768,13 @@ __global__ __launch_bounds__(kBlock) void k_frame_fast(const uint8_t* __restrict
 // exact validator has to look at.
 constexpr int kHistLds = 4096;
 __global__ __launch_bounds__(kBlock) void k_records_fast(FrameView f, int space, uint32_t weight,
-                                                         const uint32_t* __restrict__ suspect,
+                                                         SuspectMap suspect,
                                                          unsigned long long* __restrict__ list,
                                                          unsigned long long list_cap,
                                                          unsigned long long* __restrict__ list_count,
                                                          AccState* __restrict__ acc,
-                                                         unsigned long long* __restrict__ hist) {
+                                                         unsigned long long* __restrict__ hist,
+                                                         const CallState* __restrict__ cs) {
   __shared__ uint32_t s_hist[kHistLds];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
   for (int i = threadIdx.x; i < kHistLds; i += kBlock) s_hist[i] = 0;
@@ -764,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_records_fast(FrameView f, int space,
       }
       const uint64_t l0 = e[1] - e[0] - 1, l1 = e[2] - e[1] - 1, l2 = e[3] - e[2] - 1, l3 = e[4] - e[3] - 1;
       const uint32_t has_nl = e[4] < f.nbytes ? 1u : 0u;  // only the very last line can lack it
-      bool sus = (suspect[r >> 5] >> (r & 31u)) & 1u;
+      bool sus = r < suspect.cap ? ((suspect.bits[r >> 5] >> (r & 31u)) & 1u) : true;
       sus |= l1 < 1 || l1 != l3 || space != FQG_SPACE_SEQ;
       sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
              l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + has_nl > FQG_MAX_READ_LENGTH - 1;
@@ -783,6 +811,11 @@ __global__ __launch_bounds__(kBlock) void k_records_fast(FrameView f, int space,
     }
   }
   if (!acc) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && cs->qmin_byte <= cs->qmax_byte) {
+    // quality range found by k_frame_fast for this image
+    atomicMin(&acc->min_qbyte, cs->qmin_byte);
+    atomicMax(&acc->max_qbyte, cs->qmax_byte);
+  }
   // block reduction of the scalars
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {

@@ -1,0 +1,68 @@
+// kbench.hip - developer micro-benchmark: times the framing/validation kernels on a synthetic
+// HBM-resident batch, with ablation variants, using hipEvents.  Not part of the product.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o kbench kbench.hip && ./kbench [reads] [reps]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+#include <functional>
+#include "../../fastq_utils_amd/csrc/fqg_device.h"
+#include "../../fastq_utils_amd/csrc/fqg_kernels.hip"
+#ifdef KBENCH_EXTRA
+#include KBENCH_EXTRA
+#endif
+using namespace fqg;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+static double time_ms(int reps, const std::function<void()>& f) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) f();
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const uint64_t reads = argc > 1 ? strtoull(argv[1], 0, 10) : 20000000ull;
+  const int reps = argc > 2 ? atoi(argv[2]) : 5;
+  const uint32_t L = 150;
+  const uint64_t R = 45 + 2ull * (L + 1) + 2, n = reads * R;
+  uint8_t* img; CK(hipMalloc(&img, n + 64));
+  hipLaunchKernelGGL(k_synth, dim3(256 * 32), dim3(kBlock), 0, 0, img, reads, L, 0ull, 12345ull, 1);
+  CK(hipDeviceSynchronize());
+  const uint32_t n_tiles = (uint32_t)((n + kChunkBytes - 1) / kChunkBytes), n_spans = (n_tiles + kScanSpan - 1) / kScanSpan;
+  uint32_t *counts, *local, *suspect; unsigned long long *spans, *list; uint64_t* line_end; CallState* cs; AccState* acc; unsigned long long* hist;
+  CK(hipMalloc(&counts, n_tiles * 4ull)); CK(hipMalloc(&local, n_tiles * 4ull)); CK(hipMalloc(&spans, n_spans * 8ull));
+  CK(hipMalloc(&line_end, (reads * 4 + 2) * 8)); CK(hipMalloc(&cs, sizeof(CallState))); CK(hipMalloc(&acc, sizeof(AccState)));
+  CK(hipMalloc(&hist, 8ull * FQG_MAX_READ_LENGTH)); CK(hipMalloc(&suspect, (reads / 32 + 2) * 4)); CK(hipMalloc(&list, 8ull << 20));
+  { CallState init{}; init.first_key = ~0ull; init.stop_record = ~0ull; init.qmin_byte = 255; CK(hipMemcpy(cs, &init, sizeof(init), hipMemcpyHostToDevice)); } CK(hipMemset(hist, 0, 8ull * FQG_MAX_READ_LENGTH)); CK(hipMemset(suspect, 0, (reads / 32 + 2) * 4));
+  AccState init{0, FQG_MAX_READ_LENGTH, 0, 255, 0}; CK(hipMemcpy(acc, &init, sizeof(init), hipMemcpyHostToDevice));
+  const double gb = n / 1e9;
+  auto report = [&](const char* name, double ms) { printf("%-28s %8.3f ms  %8.1f GB/s (input bytes)\n", name, ms, gb / (ms * 1e-3)); };
+  report("k_count_nl", time_ms(reps, [&] { hipLaunchKernelGGL(k_count_nl, dim3((n_tiles + 3) / 4), dim3(kBlock), 0, 0, img, n, n_tiles, counts, cs); }));
+  hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, 0, counts, n_tiles, local, spans);
+  hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, 0, spans, n_spans, img, n, cs);
+  CK(hipDeviceSynchronize());
+  const unsigned grid_t = 256 * 8;
+  SuspectMap sm{suspect, reads, &cs->flags};
+#define FF(ABL, label) report(label, time_ms(reps, [&] { hipLaunchKernelGGL(k_frame_fast_t<ABL>, dim3(grid_t), dim3(kBlock), 0, 0, img, n, n_tiles, local, spans, line_end, 4 * reads + 32, 4 * reads, sm, cs); }))
+  { CallState init{}; init.first_key = ~0ull; init.stop_record = ~0ull; init.qmin_byte = 255; init.n_newlines = 4 * reads; init.last_byte_is_nl = 1; CK(hipMemcpy(cs, &init, sizeof(init), hipMemcpyHostToDevice)); }
+  FF(0u, "k_frame_fast (full)");
+  FF(1u, "  - no qual range");
+  FF(2u, "  - no base check");
+  FF(4u, "  - no line-start check");
+  FF(8u, "  - no line_end stores");
+  FF(7u, "  line index only (exact path)");
+#ifdef KBENCH_EXTRA
+  kbench_extra(img, n, reads, n_tiles, counts, local, spans, line_end, suspect, acc, cs, hist, list, reps, report);
+#endif
+  FrameView fv{img, n, line_end, reads * 4, reads};
+  report("k_records_fast", time_ms(reps, [&] { hipLaunchKernelGGL(k_records_fast, dim3(256 * 8), dim3(kBlock), 0, 0, fv, 0, 1u, sm, list, 1ull << 20, &cs->list_count, acc, hist, cs); }));
+  CallState h; CK(hipMemcpy(&h, cs, sizeof(h), hipMemcpyDeviceToHost));
+  AccState ha; CK(hipMemcpy(&ha, acc, sizeof(ha), hipMemcpyDeviceToHost));
+  printf("check: newlines=%llu (want %llu) suspects=%llu q=[%u,%u] acc q=[%u,%u] rl=[%llu,%llu]\n", h.n_newlines, (unsigned long long)reads * 4, h.list_count, h.qmin_byte, h.qmax_byte, ha.min_qbyte, ha.max_qbyte, ha.min_rl, ha.max_rl);
+  return 0;
+}
