@@ -28,6 +28,8 @@ EXPORTS = [
     "fqg_acc_reset", "fqg_acc_read", "fqg_acc_hist_nonzero", "fqg_acc_median", "fqg_acc_export",
     "fqg_acc_merge", "fqg_validate", "fqg_frame_records", "fqg_profile_enable",
     "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
+    "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_index_create",
+    "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_names_compare",
 ]
 
 
@@ -49,7 +51,7 @@ class ValidateResult(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_lines", C.c_uint64), ("consumed", C.c_uint64),
                 ("record", C.c_uint64), ("aux0", C.c_uint64), ("aux1", C.c_uint64),
                 ("code", C.c_int32), ("stopped", C.c_int32), ("path", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("tail_lines", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -59,6 +61,14 @@ class Record(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("hdr1_len", C.c_uint32), ("seq_len", C.c_uint32),
                 ("hdr2_len", C.c_uint32), ("qual_len", C.c_uint32), ("read_len", C.c_uint32),
                 ("reserved", C.c_uint32)]
+
+
+class IndexResult(C.Structure):
+    _fields_ = [("n_entries", C.c_uint64), ("index_mem", C.c_uint64), ("record", C.c_uint64),
+                ("code", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 class KernelTime(C.Structure):
@@ -125,6 +135,17 @@ def load():
     L.fqg_synth_record_bytes.argtypes = [C.c_uint32]
     L.fqg_synth_record_bytes.restype = u64
     L.fqg_synth_fastq.argtypes = [vp, vp, u64, C.c_uint32, u64, u64, C.c_int]
+    L.fqg_frame_retain.argtypes = [vp, C.POINTER(vp)]
+    L.fqg_frame_release.argtypes = [vp]
+    L.fqg_frame_release.restype = None
+    L.fqg_frame_n_records.argtypes = [vp]
+    L.fqg_frame_n_records.restype = u64
+    L.fqg_index_create.argtypes = [vp, u64, C.POINTER(vp)]
+    L.fqg_index_destroy.argtypes = [vp]
+    L.fqg_index_destroy.restype = None
+    L.fqg_index_insert_unique.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
+    L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
+    L.fqg_names_compare.argtypes = [vp, vp, C.POINTER(FileState), vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     _lib = L
     return L
 
@@ -186,6 +207,50 @@ class Accumulator:
         self.ctx._check(load().fqg_acc_merge(self.h, blob, len(blob)))
 
 
+class Frame:
+    """A retained frame (fqg_frame): image + line index that outlive later validate calls."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(load().fqg_frame_retain(ctx.h, C.byref(h)))
+        self.h = h
+
+    @property
+    def n_records(self):
+        return int(load().fqg_frame_n_records(self.h))
+
+    def release(self):
+        if self.h:
+            load().fqg_frame_release(self.h)
+            self.h = None
+
+
+class NameIndex:
+    """Device read-name index (fqg_index)."""
+
+    def __init__(self, ctx, expected_names=0):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(load().fqg_index_create(ctx.h, expected_names, C.byref(h)))
+        self.h = h
+
+    def insert_unique(self, state):
+        r = IndexResult()
+        self.ctx._check(load().fqg_index_insert_unique(self.ctx.h, self.h, C.byref(state), C.byref(r)))
+        return r.as_dict()
+
+    def match_delete(self, state):
+        r = IndexResult()
+        self.ctx._check(load().fqg_index_match_delete(self.ctx.h, self.h, C.byref(state), C.byref(r)))
+        return r.as_dict()
+
+    def close(self):
+        if self.h:
+            load().fqg_index_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """One GPU context (fqg_ctx).  Raises if there is no GPU: there is no CPU path."""
 
@@ -235,6 +300,18 @@ class Context:
                                      flags, C.byref(res))
         self._check(rc)
         return res.as_dict()
+
+    def retain_frame(self):
+        return Frame(self)
+
+    def name_index(self, expected_names=0):
+        return NameIndex(self, expected_names)
+
+    def names_compare(self, frame_a, state_a, frame_b=None, state_b=None):
+        r = IndexResult()
+        self._check(load().fqg_names_compare(self.h, frame_a.h, C.byref(state_a), frame_b.h if frame_b else None,
+                                             C.byref(state_b) if state_b is not None else None, C.byref(r)))
+        return r.as_dict()
 
     def frame_records(self, first, count):
         out = (Record * max(1, count))()

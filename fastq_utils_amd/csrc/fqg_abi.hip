@@ -11,6 +11,7 @@
 
 #include "fqg_device.h"
 #include "fqg_kernels.hip"
+#include "fqg_index_kernels.hip"
 
 using namespace fqg;
 
@@ -58,6 +59,10 @@ struct fqg_ctx {
 
   FrameView frame{};
   bool frame_valid = false;
+  bool frame_img_owned = false;  // the frame's image lives in `image` (host input), not with the caller
+  uint32_t frame_flags = 0;      // kFlagNul / kFlagCr of the framed image
+  IndexCall* d_icall = nullptr;
+  IndexCall* h_icall = nullptr;  // pinned
 
   bool profiling = false;
   std::vector<ProfSlot> slots;
@@ -198,7 +203,9 @@ int fqg_open(int device_ordinal, fqg_ctx** out) {
     return FQG_ERR_HIP;
   }
   c->stream = c->own_stream;
-  if (hipMalloc((void**)&c->d_cs, sizeof(CallState)) != hipSuccess ||
+  if (hipMalloc((void**)&c->d_icall, sizeof(IndexCall)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_icall, sizeof(IndexCall), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&c->d_cs, sizeof(CallState)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_cs, sizeof(CallState), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->h_scalar, 8 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     fqg_close(c);
@@ -222,6 +229,8 @@ void fqg_close(fqg_ctx* c) {
   release(c->records);
   release(c->suspect);
   release(c->list);
+  if (c->d_icall) (void)hipFree(c->d_icall);
+  if (c->h_icall) (void)hipHostFree(c->h_icall);
   if (c->d_cs) (void)hipFree(c->d_cs);
   if (c->h_cs) (void)hipHostFree(c->h_cs);
   if (c->h_scalar) (void)hipHostFree(c->h_scalar);
@@ -632,6 +641,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   out->n_records = n_records;
   out->n_lines = n_lines_all;
+  out->tail_lines = (final && leftover && !out->stopped && !tail_is_stop) ? (int32_t)leftover : 0;
   out->consumed = n_records ? c->h_scalar[1] + 1 : 0;
   if (out->consumed > nbytes) out->consumed = nbytes;  // unterminated last line
 
@@ -666,6 +676,8 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   }
   c->frame = fv;
   c->frame_valid = true;
+  c->frame_img_owned = (mem == FQG_MEM_HOST);
+  c->frame_flags = img_flags;
   HIP_TRY(c, hipGetLastError());
   return 0;
 }
@@ -690,6 +702,281 @@ int fqg_frame_records(fqg_ctx* c, uint64_t first, uint64_t count, fqg_record* ou
     HIP_TRY(c, hipMemcpyAsync(out, d_out, count * sizeof(fqg_record), hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- frames ---------------------------------------------------------------------------------
+struct fqg_frame {
+  fqg_ctx* ctx = nullptr;
+  FrameView fv{};
+  DevBuf image;     // owned copy of a host image (empty for caller-owned device images)
+  DevBuf line_end;  // owned line index
+  uint32_t flags = 0;
+};
+
+int fqg_frame_retain(fqg_ctx* c, fqg_frame** out) {
+  if (!c || !out) return FQG_ERR_ARG;
+  if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  fqg_frame* f = new fqg_frame();
+  f->ctx = c;
+  f->fv = c->frame;
+  f->flags = c->frame_flags;
+  f->line_end = c->line_end;  // the context allocates fresh buffers on its next call
+  c->line_end = DevBuf();
+  if (c->frame_img_owned) {
+    f->image = c->image;
+    c->image = DevBuf();
+  }
+  c->frame_valid = false;
+  *out = f;
+  return 0;
+}
+
+void fqg_frame_release(fqg_frame* f) {
+  if (!f) return;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  release(f->image);
+  release(f->line_end);
+  delete f;
+}
+
+uint64_t fqg_frame_n_records(const fqg_frame* f) { return f ? f->fv.n_records : 0; }
+
+// ---- read-name index ------------------------------------------------------------------------
+struct fqg_index {
+  fqg_ctx* ctx = nullptr;
+  DevBuf slots, claims, segs_dev;
+  uint64_t capacity = 0;
+  bool claims_ready = false;
+  std::vector<fqg_frame*> frames;
+  std::vector<IndexSeg> segs;
+  uint64_t n_records_total = 0;  // records fed so far = global index of the next frame's first record
+  uint64_t inserted = 0, matched = 0, name_bytes = 0;
+  int fmt = FQG_NAME_UNDEF, is_pe = 0;
+  uint32_t flags = 0;
+};
+
+namespace {
+
+int index_alloc_table(fqg_index* ix, uint64_t capacity) {
+  fqg_ctx* c = ix->ctx;
+  int rc;
+  if ((rc = ensure(c, ix->slots, (size_t)capacity * 8))) return rc;
+  HIP_TRY(c, hipMemsetAsync(ix->slots.p, 0xFF, (size_t)capacity * 8, c->stream));
+  ix->capacity = capacity;
+  ix->claims_ready = false;
+  return 0;
+}
+
+IndexView index_view(fqg_index* ix) {
+  IndexView v;
+  v.slots = (unsigned long long*)ix->slots.p;
+  v.claims = (unsigned long long*)ix->claims.p;
+  v.mask = ix->capacity - 1;
+  v.segs = (const IndexSeg*)ix->segs_dev.p;
+  v.n_segs = (int)ix->segs.size();
+  v.fmt = ix->fmt;
+  v.is_pe = ix->is_pe;
+  v.may_have_nul = (ix->flags & kFlagNul) ? 1 : 0;
+  return v;
+}
+
+int index_upload_segs(fqg_index* ix) {
+  fqg_ctx* c = ix->ctx;
+  int rc;
+  if ((rc = ensure(c, ix->segs_dev, std::max<size_t>(1, ix->segs.size()) * sizeof(IndexSeg)))) return rc;
+  if (!ix->segs.empty())
+    HIP_TRY(c, hipMemcpyAsync(ix->segs_dev.p, ix->segs.data(), ix->segs.size() * sizeof(IndexSeg),
+                              hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int index_reset_call(fqg_ctx* c) {
+  IndexCall z;
+  memset(&z, 0, sizeof(z));
+  z.first_dup = z.first_wrong = z.first_missing = kNoRecord;
+  *c->h_icall = z;
+  HIP_TRY(c, hipMemcpyAsync(c->d_icall, c->h_icall, sizeof(IndexCall), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int index_fetch_call(fqg_ctx* c) {
+  HIP_TRY(c, hipMemcpyAsync(c->h_icall, c->d_icall, sizeof(IndexCall), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+unsigned index_grid(fqg_ctx* c, uint64_t n) {
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 16));
+}
+
+// rebuild the table at a larger capacity from the retained segments
+int index_grow(fqg_index* ix, uint64_t need_names) {
+  fqg_ctx* c = ix->ctx;
+  uint64_t cap = ix->capacity ? ix->capacity : 1024;
+  while (cap < 2 * need_names) cap <<= 1;
+  if (cap == ix->capacity) return 0;
+  int rc;
+  if ((rc = index_alloc_table(ix, cap))) return rc;
+  if ((rc = index_upload_segs(ix))) return rc;
+  for (size_t s = 0; s < ix->segs.size(); ++s) {
+    if ((rc = index_reset_call(c))) return rc;
+    FrameView fv = ix->frames[s]->fv;
+    ProfScope ps(c, "k_index_insert(regrow)");
+    hipLaunchKernelGGL(k_index_insert, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv,
+                       index_view(ix), ix->segs[s].record_base, c->d_icall);
+  }
+  return 0;
+}
+
+}  // namespace
+
+int fqg_index_create(fqg_ctx* c, uint64_t expected_names, fqg_index** out) {
+  if (!c || !out) return FQG_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  fqg_index* ix = new fqg_index();
+  ix->ctx = c;
+  uint64_t cap = 1024;
+  while (cap < 2 * expected_names) cap <<= 1;
+  int rc = index_alloc_table(ix, cap);
+  if (rc) {
+    fqg_index_destroy(ix);
+    return rc;
+  }
+  *out = ix;
+  return 0;
+}
+
+void fqg_index_destroy(fqg_index* ix) {
+  if (!ix) return;
+  (void)hipStreamSynchronize(ix->ctx->stream);
+  for (auto* f : ix->frames) fqg_frame_release(f);
+  release(ix->slots);
+  release(ix->claims);
+  release(ix->segs_dev);
+  delete ix;
+}
+
+int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, fqg_index_result* out) {
+  if (!c || !ix || !st || !out || ix->ctx != c) return FQG_ERR_ARG;
+  if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  memset(out, 0, sizeof(*out));
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  fqg_frame* fr = nullptr;
+  if ((rc = fqg_frame_retain(c, &fr))) return rc;
+  if (ix->frames.empty()) {
+    ix->fmt = st->readname_format;
+    ix->is_pe = st->is_pe;
+  }
+  ix->flags |= fr->flags;
+  IndexSeg sg;
+  sg.img = fr->fv.img;
+  sg.line_end = fr->fv.line_end;
+  sg.nbytes = fr->fv.nbytes;
+  sg.n_records = fr->fv.n_records;
+  sg.record_base = ix->n_records_total;
+  ix->frames.push_back(fr);
+  ix->segs.push_back(sg);
+  if (2 * (ix->inserted + sg.n_records) > ix->capacity) {
+    // grow first (re-inserting the earlier segments), then insert this one
+    ix->segs.pop_back();
+    ix->frames.pop_back();
+    if ((rc = index_grow(ix, ix->inserted + sg.n_records))) return rc;
+    ix->frames.push_back(fr);
+    ix->segs.push_back(sg);
+  }
+  if ((rc = index_upload_segs(ix))) return rc;
+  if ((rc = index_reset_call(c))) return rc;
+  if (sg.n_records) {
+    ProfScope ps(c, "k_index_insert");
+    hipLaunchKernelGGL(k_index_insert, dim3(index_grid(c, sg.n_records)), dim3(kBlock), 0, c->stream, fr->fv,
+                       index_view(ix), sg.record_base, c->d_icall);
+  }
+  if ((rc = index_fetch_call(c))) return rc;
+  HIP_TRY(c, hipGetLastError());
+  if (c->h_icall->table_full) return fail(c, FQG_ERR_STATE, "name index full");
+  ix->n_records_total += sg.n_records;
+  ix->inserted += c->h_icall->inserted;
+  ix->name_bytes += c->h_icall->name_bytes;
+  const uint64_t w = c->h_icall->first_wrong;
+  const uint64_t d = c->h_icall->first_dup == kNoRecord ? kNoRecord : c->h_icall->first_dup - sg.record_base;
+  if (w != kNoRecord && w < d) {
+    out->code = FQG_E_WRONG_HEADER;
+    out->record = w;
+  } else if (d != kNoRecord) {
+    out->code = FQG_E_DUP_NAME;
+    out->record = d;
+  }
+  out->n_entries = ix->inserted;
+  // sizeof(hashtable) + per entry sizeof(INDEX_ENTRY) + len + 1 + sizeof(hashnode)
+  out->index_mem = 8 + ix->inserted * (16 + 1 + 24) + ix->name_bytes;
+  return 0;
+}
+
+int fqg_index_match_delete(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, fqg_index_result* out) {
+  if (!c || !ix || !st || !out || ix->ctx != c) return FQG_ERR_ARG;
+  if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  memset(out, 0, sizeof(*out));
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if (!ix->claims_ready) {
+    if ((rc = ensure(c, ix->claims, (size_t)ix->capacity * 8))) return rc;
+    HIP_TRY(c, hipMemsetAsync(ix->claims.p, 0xFF, (size_t)ix->capacity * 8, c->stream));
+    ix->claims_ready = true;
+  }
+  if ((rc = index_upload_segs(ix))) return rc;
+  if ((rc = index_reset_call(c))) return rc;
+  const FrameView fv = c->frame;
+  if (fv.n_records) {
+    ProfScope ps(c, "k_index_match_delete");
+    hipLaunchKernelGGL(k_index_match_delete, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv,
+                       index_view(ix), st->readname_format, st->is_pe, (c->frame_flags & kFlagNul) ? 1 : 0,
+                       c->d_icall);
+  }
+  if ((rc = index_fetch_call(c))) return rc;
+  HIP_TRY(c, hipGetLastError());
+  ix->matched += c->h_icall->matched;
+  const uint64_t w = c->h_icall->first_wrong, m = c->h_icall->first_missing;
+  if (w != kNoRecord && w < m) {
+    out->code = FQG_E_WRONG_HEADER;
+    out->record = w;
+  } else if (m != kNoRecord) {
+    out->code = FQG_E_UNPAIRED;
+    out->record = m;
+  }
+  out->n_entries = ix->inserted - ix->matched;
+  out->index_mem = 8 + ix->inserted * (16 + 1 + 24) + ix->name_bytes;
+  return 0;
+}
+
+int fqg_names_compare(fqg_ctx* c, const fqg_frame* a, const fqg_file_state* sa, const fqg_frame* b,
+                      const fqg_file_state* sb, fqg_index_result* out) {
+  if (!c || !a || !sa || !out || (b && !sb)) return FQG_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = index_reset_call(c))) return rc;
+  const int interleaved = b ? 0 : 1;
+  const uint64_t n_pairs = interleaved ? a->fv.n_records / 2 : std::min(a->fv.n_records, b->fv.n_records);
+  if (n_pairs) {
+    ProfScope ps(c, "k_names_compare");
+    const uint32_t fl = a->flags | (b ? b->flags : 0u);
+    hipLaunchKernelGGL(k_names_compare, dim3(index_grid(c, n_pairs)), dim3(kBlock), 0, c->stream, a->fv,
+                       sa->readname_format, sa->is_pe, b ? b->fv : a->fv, b ? sb->readname_format : sa->readname_format,
+                       b ? sb->is_pe : sa->is_pe, interleaved, (fl & kFlagNul) ? 1 : 0, n_pairs, c->d_icall);
+  }
+  if ((rc = index_fetch_call(c))) return rc;
+  HIP_TRY(c, hipGetLastError());
+  const uint64_t w = c->h_icall->first_wrong, m = c->h_icall->first_missing;
+  if (w != kNoRecord && w <= m) {
+    out->code = FQG_E_WRONG_HEADER;
+    out->record = interleaved ? 2 * w : w;
+  } else if (m != kNoRecord) {
+    out->code = interleaved ? FQG_E_UNPAIRED : FQG_E_NAME_MISMATCH;
+    out->record = interleaved ? 2 * m : m;
+  }
   return 0;
 }
 

@@ -1,0 +1,271 @@
+// fqg_index_kernels.hip - the GPU read-name index: replaces hash.c as used by
+// fastq_index_readnames (reference src/fastq.c:396-439, :577-611) and by the file-2 pairing
+// loop of fastq_info (reference src/fastq_info.c:333-356).
+//
+// Table: open addressing, linear probing, ONE 8-byte word per slot
+//     { tag : 24 | record : 40 }          (all ones = empty)
+// `record` is the global index of the record that owns the name, `tag` 24 further bits of the
+// name's 64-bit hash.  Names themselves are not copied: the index keeps references to the framed
+// images it was fed (segments), and a slot's record index leads back to the header bytes.
+// Equality is decided on the name BYTES (a tag match only nominates a candidate), so hash
+// collisions can neither fake nor hide a duplicate.
+//
+// Serial semantics in a parallel insert: the reference stops at the first record (file order)
+// whose name is already present.  Every thread that meets its own name in the table does
+// atomicMin(slot, tag|me) and reports max(previous owner, me); the minimum over all reports is
+// exactly the second-smallest index of the earliest repeated name, i.e. the record the serial
+// loop would have stopped at.  The same argument gives the first unpaired record in the
+// match-and-delete pass (claims[] holds the smallest file-2 record that asked for the slot).
+#include "fqg_device.h"
+
+namespace fqg {
+
+constexpr unsigned long long kSlotEmpty = ~0ull;
+constexpr unsigned long long kIdxMask = (1ull << 40) - 1;
+
+struct IndexSeg {
+  const uint8_t* img;
+  const uint64_t* line_end;
+  uint64_t nbytes;
+  uint64_t n_records;
+  uint64_t record_base;  // global index of the segment's first record
+};
+
+struct IndexView {
+  unsigned long long* slots;
+  unsigned long long* claims;  // per slot, match-and-delete only (may be null)
+  uint64_t mask;               // capacity - 1 (capacity is a power of two)
+  const IndexSeg* segs;
+  int n_segs;
+  int fmt, is_pe;  // read-name format / is_pe of the file the index was built from
+  int may_have_nul;
+};
+
+struct IndexCall {
+  unsigned long long first_dup;     // min over reports, kNoRecord if none (global record index)
+  unsigned long long first_wrong;   // first record whose header does not start with '@' (frame-local)
+  unsigned long long first_missing; // match-delete: first record without a partner (frame-local)
+  unsigned long long inserted;      // names added
+  unsigned long long matched;       // slots claimed for the first time
+  unsigned long long name_bytes;    // sum of the `len` the reference accounts per name (src/fastq.c:609)
+  unsigned int table_full;
+  unsigned int pad;
+};
+
+__device__ __forceinline__ uint64_t mix_hash(uint64_t h, uint64_t w) {
+  h ^= w;
+  h *= 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  return h;
+}
+
+// Canonical read name of the header line [line, line+len) (+'\n' when has_nl), after
+// fastq_get_readname (reference src/fastq.c:488-512).  Returns its length; the name starts at
+// line+1.  *acct is the `len` value the reference hands to new_indexentry (index_mem accounting).
+__device__ inline uint32_t canon_name(const uint8_t* __restrict__ line, uint32_t len, uint32_t has_nl, int fmt,
+                                      int is_pe, int may_have_nul, uint32_t* acct) {
+  uint32_t cstr = len + has_nl;  // C-string length of the line
+  if (may_have_nul)
+    for (uint32_t i = 0; i < len; ++i)
+      if (line[i] == 0) {
+        cstr = i;
+        break;
+      }
+  const uint32_t L = cstr > 0 ? cstr - 1 : 0;  // strlen(&hdr[1])
+  if (fmt == FQG_NAME_CASAVA18) {
+    uint32_t sp = L;
+    for (uint32_t i = 0; i < L; ++i)
+      if (line[1 + i] == ' ') {
+        sp = i;
+        break;
+      }
+    if (sp >= 2 && line[1 + sp - 2] == '/') sp -= 2;
+    *acct = sp;
+    return sp;
+  }
+  long l = (long)L;
+  if (fmt == FQG_NAME_DEFAULT && is_pe) l--;
+  *acct = (uint32_t)(l < 0 ? 0 : l);
+  return l >= 1 ? (uint32_t)(l - 1) : L;
+}
+
+__device__ __forceinline__ uint64_t hash_name(const uint8_t* __restrict__ p, uint32_t n) {
+  uint64_t h = 0x2545F4914F6CDD1Dull ^ n;
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    __builtin_memcpy(&w, p + i, 8);
+    h = mix_hash(h, w);
+  }
+  uint64_t w = 0;
+  for (uint32_t k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
+  h = mix_hash(h, w);
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  h ^= h >> 32;
+  return h;
+}
+
+__device__ __forceinline__ bool same_bytes(const uint8_t* a, const uint8_t* b, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i)
+    if (a[i] != b[i]) return false;
+  return true;
+}
+
+// header line of the record with global index g, as kept by the index
+__device__ inline bool stored_name(const IndexView& ix, uint64_t g, const uint8_t** name, uint32_t* n) {
+  for (int s = 0; s < ix.n_segs; ++s) {
+    const IndexSeg& sg = ix.segs[s];
+    if (g >= sg.record_base && g < sg.record_base + sg.n_records) {
+      const uint64_t r = g - sg.record_base;
+      const uint64_t b = r == 0 ? 0 : sg.line_end[4 * r - 1] + 1;
+      const uint64_t e = sg.line_end[4 * r];
+      uint32_t acct;
+      *n = canon_name(sg.img + b, (uint32_t)(e - b), e < sg.nbytes ? 1u : 0u, ix.fmt, ix.is_pe, ix.may_have_nul,
+                      &acct);
+      *name = sg.img + b + 1;
+      return true;
+    }
+  }
+  return false;
+}
+
+// One thread per record of the frame: insert its canonical name, report repeats.
+__global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView ix, uint64_t record_base,
+                                                         IndexCall* __restrict__ call) {
+  unsigned long long my_first_dup = kNoRecord, my_first_wrong = kNoRecord, inserted = 0, name_bytes = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
+    const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+    const uint64_t e = f.line_end[4 * r];
+    const uint8_t* line = f.img + b;
+    if (line[0] != '@') {  // fastq_get_readname refuses it (src/fastq.c:448)
+      my_first_wrong = r < my_first_wrong ? r : my_first_wrong;
+      continue;
+    }
+    uint32_t acct;
+    const uint32_t n = canon_name(line, (uint32_t)(e - b), e < f.nbytes ? 1u : 0u, ix.fmt, ix.is_pe,
+                                  ix.may_have_nul, &acct);
+    const uint8_t* name = line + 1;
+    const uint64_t h = hash_name(name, n);
+    const unsigned long long g = record_base + r;
+    const unsigned long long mine = ((h >> 40) << 40) | g;
+    uint64_t at = h & ix.mask;
+    bool done = false;
+    for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
+      unsigned long long cur = __hip_atomic_load(&ix.slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == kSlotEmpty) {
+        cur = atomicCAS(&ix.slots[at], kSlotEmpty, mine);
+        if (cur == kSlotEmpty) {
+          ++inserted;
+          name_bytes += acct;
+          done = true;
+          break;
+        }
+      }
+      if ((cur >> 40) == (mine >> 40)) {
+        const uint8_t* other;
+        uint32_t on;
+        if (stored_name(ix, cur & kIdxMask, &other, &on) && on == n && same_bytes(other, name, n)) {
+          const unsigned long long prev = atomicMin(&ix.slots[at], mine);
+          const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
+          my_first_dup = late < my_first_dup ? late : my_first_dup;
+          done = true;
+          break;
+        }
+      }
+    }
+    if (!done) atomicOr(&call->table_full, 1u);
+  }
+  if (my_first_dup != kNoRecord) atomicMin(&call->first_dup, my_first_dup);
+  if (my_first_wrong != kNoRecord) atomicMin(&call->first_wrong, my_first_wrong);
+  // wave-level sums before touching the global counters
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    inserted += __shfl_down(inserted, d, 64);
+    name_bytes += __shfl_down(name_bytes, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && inserted) {
+    atomicAdd(&call->inserted, inserted);
+    atomicAdd(&call->name_bytes, name_bytes);
+  }
+}
+
+// One thread per record of the (file-2) frame: find the name, claim its slot.
+__global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, IndexView ix, int fmt2, int is_pe2,
+                                                               int may_have_nul2, IndexCall* __restrict__ call) {
+  unsigned long long my_missing = kNoRecord, my_wrong = kNoRecord, matched = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
+    const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+    const uint64_t e = f.line_end[4 * r];
+    const uint8_t* line = f.img + b;
+    if (line[0] != '@') {
+      my_wrong = r < my_wrong ? r : my_wrong;
+      continue;
+    }
+    uint32_t acct;
+    const uint32_t n = canon_name(line, (uint32_t)(e - b), e < f.nbytes ? 1u : 0u, fmt2, is_pe2, may_have_nul2, &acct);
+    const uint8_t* name = line + 1;
+    const uint64_t h = hash_name(name, n);
+    uint64_t at = h & ix.mask;
+    bool found = false;
+    for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
+      const unsigned long long cur = ix.slots[at];
+      if (cur == kSlotEmpty) break;
+      if ((cur >> 40) == (h >> 40)) {
+        const uint8_t* other;
+        uint32_t on;
+        if (stored_name(ix, cur & kIdxMask, &other, &on) && on == n && same_bytes(other, name, n)) {
+          // the smallest asker gets the entry; every other asker is what the serial loop would
+          // have found missing after the delete
+          const unsigned long long prev = atomicMin(&ix.claims[at], (unsigned long long)r);
+          if (prev == kSlotEmpty) ++matched;
+          else {
+            const unsigned long long late = prev > r ? prev : r;
+            my_missing = late < my_missing ? late : my_missing;
+          }
+          found = true;
+          break;
+        }
+      }
+    }
+    if (!found) my_missing = r < my_missing ? r : my_missing;
+  }
+  if (my_missing != kNoRecord) atomicMin(&call->first_missing, my_missing);
+  if (my_wrong != kNoRecord) atomicMin(&call->first_wrong, my_wrong);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) matched += __shfl_down(matched, d, 64);
+  if ((threadIdx.x & 63) == 0 && matched) atomicAdd(&call->matched, matched);
+}
+
+// Names of paired records must be equal: record 2k against 2k+1 of one frame (interleaved
+// input, src/fastq_info.c:81-91) or record k of frame A against record k of frame B (files with
+// the same ordering, src/fastq_info.c:133-138).  Reports the first pair that differs.
+__global__ __launch_bounds__(kBlock) void k_names_compare(FrameView a, int fmt_a, int pe_a, FrameView b2, int fmt_b,
+                                                          int pe_b, int interleaved, int may_have_nul,
+                                                          uint64_t n_pairs, IndexCall* __restrict__ call) {
+  unsigned long long my_bad = kNoRecord, my_wrong = kNoRecord;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_pairs; k += stride) {
+    const uint64_t ra = interleaved ? 2 * k : k, rb = interleaved ? 2 * k + 1 : k;
+    const FrameView& fb = interleaved ? a : b2;
+    const uint64_t ba = ra == 0 ? 0 : a.line_end[4 * ra - 1] + 1, ea = a.line_end[4 * ra];
+    const uint64_t bb = rb == 0 ? 0 : fb.line_end[4 * rb - 1] + 1, eb = fb.line_end[4 * rb];
+    const uint8_t *la = a.img + ba, *lb = fb.img + bb;
+    if (la[0] != '@' || lb[0] != '@') {
+      // src/fastq.c:448; for interleaved input both names are taken before anything else,
+      // for same-order files each record has already passed validation at this point
+      my_wrong = k < my_wrong ? k : my_wrong;
+      continue;
+    }
+    uint32_t acct;
+    const uint32_t na = canon_name(la, (uint32_t)(ea - ba), ea < a.nbytes ? 1u : 0u, fmt_a, pe_a, may_have_nul, &acct);
+    const uint32_t nb = canon_name(lb, (uint32_t)(eb - bb), eb < fb.nbytes ? 1u : 0u, fmt_b, pe_b, may_have_nul, &acct);
+    if (na != nb || !same_bytes(la + 1, lb + 1, na)) my_bad = k < my_bad ? k : my_bad;
+  }
+  if (my_bad != kNoRecord) atomicMin(&call->first_missing, my_bad);
+  if (my_wrong != kNoRecord) atomicMin(&call->first_wrong, my_wrong);
+}
+
+}  // namespace fqg

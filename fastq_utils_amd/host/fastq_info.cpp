@@ -1,0 +1,689 @@
+// fastq_info - drop-in for the reference program of the same name (reference src/fastq_info.c),
+// with the per-record loops replaced by bulk calls into libfqgpu.so (include/fqg.h).
+//
+// Same command line, same stdout/stderr text, same exit status.  What runs where:
+//   host   option parsing, (gz) reading into pinned pieces, the once-per-file probes, the order in
+//          which findings of different kinds win, message text, the final summary
+//   GPU    framing, validation, statistics, read-name index / pairing / name comparison
+// There is no CPU path for the record work: without a GPU the program fails at start-up.
+#include <getopt.h>
+#include <regex.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "fq_input.h"
+
+using namespace fqhost;
+
+namespace {
+
+fqg_ctx* g_ctx = nullptr;
+
+[[noreturn]] void die_lib(const char* what, int rc) {
+  FQ_PRINT_ERROR("GPU library failure in %s (%d): %s", what, rc, g_ctx ? fqg_last_error(g_ctx) : "no context");
+  exit(kExitSys);
+}
+#define LIB(call)                   \
+  do {                              \
+    int rc__ = (call);              \
+    if (rc__ != 0) die_lib(#call, rc__); \
+  } while (0)
+
+size_t piece_bytes() {
+  const char* e = getenv("FQGPU_CHUNK_MB");
+  size_t mb = e ? strtoull(e, nullptr, 10) : 1024;
+  if (mb < 1) mb = 1;
+  return mb << 20;
+}
+
+// ---- the four lines of one record, as the reference's buffers would hold them ---------------
+struct RecordText {
+  std::string l[4];  // with '\n' when present; c_str() cuts at an embedded NUL like the C strings do
+};
+
+// record `r` of a piece that starts at a record boundary
+RecordText locate_record(const char* buf, size_t n, uint64_t r) {
+  RecordText t;
+  const char* p = buf;
+  const char* end = buf + n;
+  uint64_t line = 0;
+  while (p < end && line < 4 * r) {
+    const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+    if (!nl) return t;
+    p = nl + 1;
+    ++line;
+  }
+  for (int k = 0; k < 4 && p < end; ++k) {
+    const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+    const char* stop = nl ? nl + 1 : end;
+    t.l[k].assign(p, stop);
+    p = stop;
+  }
+  return t;
+}
+
+// fastq_get_readname's result for a header line (src/fastq.c:442-516), for messages
+std::string canonical_name(const std::string& hdr_line, const fqg_file_state& st) {
+  std::string rn = hdr_line.c_str() + (hdr_line.empty() ? 0 : 1);  // strncpy(rn, &hdr[1], ...)
+  long len;
+  switch (st.readname_format) {
+    case FQG_NAME_DEFAULT:
+      len = (long)rn.size();
+      if (st.is_pe) len--;
+      if (len >= 1) rn.resize((size_t)len - 1);
+      break;
+    case FQG_NAME_INTEGER:
+      len = (long)rn.size();
+      if (len >= 1) rn.resize((size_t)len - 1);
+      break;
+    case FQG_NAME_CASAVA18: {
+      size_t sp = rn.find(' ');
+      if (sp == std::string::npos) sp = rn.size();
+      rn.resize(sp);
+      if (sp >= 2 && rn[sp - 2] == '/') rn.resize(sp - 2);
+      break;
+    }
+  }
+  return rn;
+}
+
+// fastq_qualRange2enc, src/fastq.c:274-297
+const char* qual_range_to_enc(unsigned long min_qual, unsigned long max_qual) {
+  static const char* names[] = {"33", "64", "solexa", "33 *", "sanger"};
+  int enc;
+  const unsigned int mn = (unsigned int)min_qual, mx = (unsigned int)max_qual;
+  if (mn >= 33 && mn < 59 && mx >= 90) enc = 4;
+  else if (mn >= 33 && mx <= 73) enc = 0;
+  else if (mn < 59) enc = 0;
+  else if (mn >= 64 && mx > 74) enc = 1;
+  else if (mn >= 59 && mx > 74) enc = 2;
+  else enc = 3;
+  if (mx > FQG_MAX_PHRED_QUAL) return nullptr;
+  if (enc != 4 && mx > mn + 60) return nullptr;
+  return names[enc];
+}
+
+struct Probe {
+  fqg_file_state st{};
+  bool done = false;
+  std::string format_line;  // text printed with the format decision
+};
+
+void probe_piece(Probe& pr, const char* buf, size_t n, int is_pe) {
+  if (pr.done) return;
+  pr.st.is_pe = is_pe;
+  pr.st.readname_format = FQG_NAME_UNDEF;
+  pr.st.space = FQG_SPACE_UNDEF;
+  if (n == 0) return;
+  if (fqg_probe_first_record(buf, n, is_pe, &pr.st) != 0) return;
+  pr.done = true;
+  // which of the two formats with value 2 it is decides the text (src/fastq.c:465-474)
+  if (pr.st.readname_format == FQG_NAME_CASAVA18) pr.format_line = "CASAVA=1.8\n";
+  else if (pr.st.readname_format == FQG_NAME_INTEGER) {
+    const RecordText t = locate_record(buf, std::min<size_t>(n, 4096), 0);
+    const std::string s = t.l[0].size() > 1 ? std::string(t.l[0].c_str() + 1) : std::string();
+    regex_t rx;
+    bool all_digits = false;
+    if (regcomp(&rx, "^[0-9]+[\n\r]?$", REG_EXTENDED) == 0) {  // src/fastq.c:694
+      all_digits = regexec(&rx, s.c_str(), 0, nullptr, 0) == 0;
+      regfree(&rx);
+    }
+    pr.format_line = all_digits ? "Read name provided as an integer\n" : "Read name provided with no suffix\n";
+  }
+}
+
+void print_probe(const Probe& pr) {
+  fputs(pr.format_line.c_str(), stderr);
+  if (pr.st.space == FQG_SPACE_COLOUR) fputs("Color space\n", stderr);
+}
+
+// PRINT_READS_PROCESSED (src/fastq.h:82) for the counts first..last
+void ticker(uint64_t first, uint64_t last, uint64_t every, uint64_t scale = 1) {
+  for (uint64_t c = (first + every - 1) / every * every; c <= last; c += every) {
+    if (c == 0) continue;
+    fprintf(stderr, "\b\b\b\b\b\b\b\b\b\b\b\b\b\b\b%lu", (unsigned long)(c * scale));
+    fflush(stderr);
+  }
+}
+
+bool is_early_code(int code) {
+  return code == FQG_E_TRUNCATED || code == FQG_E_HDR1_AT || code == FQG_E_HDR1_SHORT || code == FQG_E_SEQ_CHAR ||
+         code == FQG_E_SEQ_UT || code == FQG_E_LEN_SMALL || code == FQG_E_HDR2_PLUS || code == FQG_E_LINE_TOO_LONG;
+}
+
+// One validation finding as text (src/fastq.c:300-392).  `cline` is FASTQ_FILE.cline at the time.
+void print_validation_error(const char* fname, unsigned long cline, const fqg_validate_result& r,
+                            const RecordText& t) {
+  switch (r.code) {
+    case FQG_E_HDR1_AT:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: sequence identifier should start with an @ - %s", fname, cline,
+                     t.l[0].c_str());
+      break;
+    case FQG_E_HDR1_SHORT:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: sequence identifier should be longer than 1", fname, cline);
+      break;
+    case FQG_E_SEQ_CHAR:
+      FQ_PRINT_ERROR(
+          "Error in file %s: line %lu: invalid character '%c' (hex. code:'%x'), expected ACGTUacgtu0123nN.", fname,
+          cline + 1, (char)r.aux0, (int)(char)r.aux0);
+      break;
+    case FQG_E_SEQ_UT:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: read contains both U and T bases", fname, cline - 2);
+      break;
+    case FQG_E_LEN_SMALL:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: read length too small - %lu", fname, cline + 1,
+                     (unsigned long)r.aux0);
+      break;
+    case FQG_E_HDR2_PLUS:
+      FQ_PRINT_ERROR(
+          "Error in file %s: line %lu:  header2 wrong. The line should contain only '+' followed by a newline or "
+          "read name (header1).",
+          fname, cline + 2);
+      break;
+    case FQG_E_HDR2_DIFF:
+      FQ_PRINT_ERROR("Error in file %s: line %lu:  header2 differs from header1\nheader 1 \"%s\"\nheader 2 \"%s\"",
+                     fname, cline, t.l[0].c_str(), t.l[2].c_str());
+      break;
+    case FQG_E_QLEN:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: sequence and quality don't have the same length %lu!=%lu", fname,
+                     cline, (unsigned long)r.aux0, (unsigned long)r.aux1);
+      break;
+    case FQG_E_QLEN_CS:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: sequence and quality length don't match %lu!=%lu", fname, cline,
+                     (unsigned long)r.aux0, (unsigned long)r.aux1);
+      break;
+    default:
+      FQ_PRINT_ERROR("Error in file %s: line %lu: unexpected outcome %d", fname, cline, r.code);
+  }
+}
+
+[[noreturn]] void fail_truncated(const char* fname, unsigned long cline) {
+  FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", fname, cline);  // src/fastq.c:255
+  exit(1);
+}
+[[noreturn]] void fail_too_long(const char* fname, uint64_t rec) {
+  FQ_PRINT_ERROR(
+      "Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes); the "
+      "reference splits such lines silently, this program refuses them",
+      fname, (unsigned long)(rec + 1), FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
+  exit(kExitSys);
+}
+[[noreturn]] void fail_wrong_header(const char* fname, unsigned long cline, const std::string& hdr) {
+  FQ_PRINT_ERROR("Error in file %s: line %lu: wrong header %s", fname, cline, hdr.c_str());  // src/fastq.c:449
+  exit(kExitFormat);
+}
+
+struct Stats {
+  unsigned long num_reads1 = 0;
+  fqg_acc* acc1 = nullptr;
+  fqg_acc* acc2 = nullptr;  // non-null when the reference would pass fd2 to median_rl()
+};
+
+void print_usage(int verbose) {
+  printf("Usage: fastq_info [-r -e -s -q -h] fastq1 [fastq2 file|pe]\n");
+  if (verbose) {
+    printf(" -h  : print this help message\n");
+    printf(" -s  : the reads in the two fastq files have the same ordering\n");
+    printf(" -e  : do not fail with empty files\n");
+    printf(" -q  : do not fail if quality encoding cannot be determined\n");
+    printf(" -r  : skip check for duplicated readnames\n");
+  }
+}
+
+// ---- -r, one file: validate_single_fastq_file (src/fastq_info.c:155-176) ------------------
+void run_single_noindex(const char* path, Stats& S) {
+  Input in(g_ctx, path, piece_bytes());
+  Probe pr;
+  uint64_t base = 0;
+  bool info_pending = true;
+  while (in.next()) {
+    probe_piece(pr, in.data(), in.size(), 1);
+    fqg_validate_result r;
+    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st, 0, &r));
+    if (info_pending && base == 0 && r.n_records > 0) {
+      if (!(r.code && r.record == 0 && is_early_code(r.code))) print_probe(pr);
+      info_pending = false;
+    }
+    if (r.code) {
+      const uint64_t R = base + r.record;
+      ticker(base + 1, R, 100000);
+      if (r.code == FQG_E_TRUNCATED) fail_truncated(path, 4 * R);
+      if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, R);
+      print_validation_error(path, 4 * (R + 1), r, locate_record(in.data(), in.size(), r.record));
+      exit(kExitFormat);
+    }
+    ticker(base + 1, base + r.n_records, 100000);
+    base += r.n_records;
+    if (r.stopped) break;
+    if (!in.final()) in.carry_from(r.consumed);
+  }
+  printf("\n");
+  fqg_file_stats fs;
+  LIB(fqg_acc_read(S.acc1, &fs));
+  S.num_reads1 = fs.num_rds;
+}
+
+// ---- default: fastq_index_readnames (src/fastq.c:396-439) ---------------------------------
+struct IndexedFile {
+  fqg_index* index = nullptr;
+  fqg_file_state st{};
+  uint64_t n_records = 0;
+  uint64_t entries = 0, index_mem = 0;
+};
+
+void run_index_file(const char* path, int is_pe, Stats& S, IndexedFile& F) {
+  Input in(g_ctx, path, piece_bytes());
+  Probe pr;
+  uint64_t base = 0;
+  bool info_pending = true;
+  LIB(fqg_index_create(g_ctx, 1 << 20, &F.index));
+  F.index_mem = 8;
+  while (in.next()) {
+    probe_piece(pr, in.data(), in.size(), is_pe);
+    fqg_validate_result r;
+    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st,
+                     FQG_VALIDATE_COUNT_TWICE, &r));
+    fqg_index_result ir{};
+    if (r.n_records > 0) LIB(fqg_index_insert_unique(g_ctx, F.index, &pr.st, &ir));
+    // which finding does the serial loop hit first?  per record: read (truncation), name
+    // (wrong header), duplicate, validation
+    uint64_t best_rec = ~0ull;
+    int best_stage = 9;
+    auto offer = [&](uint64_t rec, int stage) {
+      if (rec < best_rec || (rec == best_rec && stage < best_stage)) {
+        best_rec = rec;
+        best_stage = stage;
+      }
+    };
+    if (r.code == FQG_E_TRUNCATED || r.code == FQG_E_LINE_TOO_LONG) offer(r.record, 0);
+    else if (r.code == FQG_E_HDR1_AT) offer(r.record, 1);
+    else if (r.code) offer(r.record, 3);
+    if (ir.code == FQG_E_WRONG_HEADER) offer(ir.record, 1);
+    if (ir.code == FQG_E_DUP_NAME) offer(ir.record, 2);
+    if (info_pending && base == 0 && r.n_records > 0) {
+      if (!(best_rec == 0 && best_stage <= 1)) print_probe(pr);
+      info_pending = false;
+    }
+    if (best_rec != ~0ull) {
+      const uint64_t R = base + best_rec;
+      ticker(base + 1, R, 100000);
+      const RecordText t = locate_record(in.data(), in.size(), best_rec);
+      if (best_stage == 0) {
+        if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, R);
+        fail_truncated(path, 4 * R);
+      }
+      if (best_stage == 1) fail_wrong_header(path, 4 * (R + 1), t.l[0]);
+      if (best_stage == 2) {
+        FQ_PRINT_ERROR("Error in file %s: line %lu: duplicated sequence %s", path, (unsigned long)(4 * (R + 1)),
+                       canonical_name(t.l[0], pr.st).c_str());
+        exit(kExitFormat);
+      }
+      print_validation_error(path, 4 * (R + 1), r, t);
+      exit(kExitFormat);
+    }
+    ticker(base + 1, base + r.n_records, 100000);
+    base += r.n_records;
+    if (r.n_records > 0) {
+      F.entries = ir.n_entries;
+      F.index_mem = ir.index_mem;
+    }
+    if (r.stopped) break;
+    if (!in.final()) in.carry_from(r.consumed);
+  }
+  F.st = pr.st;
+  F.n_records = base;
+}
+
+// ---- second file of a pair: src/fastq_info.c:322-362 ----------------------------------------
+void run_pair_second_file(const char* path1, const char* path2, Stats& S, IndexedFile& F) {
+  Input in(g_ctx, path2, piece_bytes());
+  Probe pr2;
+  uint64_t base = 0;
+  bool info_pending = true;
+  const unsigned long cline1 = 4 * F.n_records;  // fd1->cline stays where indexing left it
+  while (in.next()) {
+    probe_piece(pr2, in.data(), in.size(), 1);
+    fqg_validate_result r;
+    // file-2 records are validated against file 1's state and counters (src/fastq_info.c:345)
+    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &F.st, 0, &r));
+    fqg_index_result ir{};
+    ir.n_entries = F.entries;
+    if (r.n_records > 0) LIB(fqg_index_match_delete(g_ctx, F.index, &pr2.st, &ir));
+    uint64_t best_rec = ~0ull;
+    int best_stage = 9;
+    auto offer = [&](uint64_t rec, int stage) {
+      if (rec < best_rec || (rec == best_rec && stage < best_stage)) {
+        best_rec = rec;
+        best_stage = stage;
+      }
+    };
+    if (r.code == FQG_E_TRUNCATED || r.code == FQG_E_LINE_TOO_LONG) offer(r.record, 0);
+    else if (r.code == FQG_E_HDR1_AT) offer(r.record, 1);
+    else if (r.code) offer(r.record, 3);
+    if (ir.code == FQG_E_WRONG_HEADER) offer(ir.record, 1);
+    if (ir.code == FQG_E_UNPAIRED) offer(ir.record, 2);
+    if (info_pending && base == 0 && r.n_records > 0) {
+      if (!(best_rec == 0 && best_stage <= 1)) print_probe(pr2);
+      info_pending = false;
+    }
+    if (best_rec != ~0ull) {
+      const uint64_t R = base + best_rec;
+      ticker(base + 1, R, 100000);
+      const RecordText t = locate_record(in.data(), in.size(), best_rec);
+      if (best_stage == 0) {
+        if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path2, R);
+        fail_truncated(path2, 4 * R);
+      }
+      if (best_stage == 1) fail_wrong_header(path2, 4 * (R + 1), t.l[0]);
+      if (best_stage == 2) {
+        FQ_PRINT_ERROR("Error in file %s: line %lu: unpaired read - %s", path2, (unsigned long)(4 * (R + 1)),
+                       canonical_name(t.l[0], pr2.st).c_str());
+        exit(kExitFormat);
+      }
+      print_validation_error(path1, cline1, r, t);  // named after file 1, like the reference
+      exit(kExitFormat);
+    }
+    ticker(base + 1, base + r.n_records, 100000);
+    base += r.n_records;
+    if (r.n_records > 0) F.entries = ir.n_entries;
+    if (r.stopped) break;
+    if (!in.final()) in.carry_from(r.consumed);
+  }
+  printf("\n");
+  if (F.entries > 0) {
+    FQ_PRINT_ERROR("Error in file %s: found %llu unpaired reads", path1, (unsigned long long)F.entries);
+    exit(kExitFormat);
+  }
+}
+
+// ---- "pe": validate_interleaved (src/fastq_info.c:57-106) ------------------------------------
+void run_interleaved(const char* path, Stats& S) {
+  fprintf(stderr, "Paired-end interleaved\n");
+  Input in(g_ctx, path, piece_bytes());
+  in.next(true);  // pairs are compared inside one frame: the whole file is one image
+  Probe pr;
+  probe_piece(pr, in.data(), in.size(), 1);
+  fqg_validate_result r;
+  LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, 1, &pr.st, 0, &r));
+  const uint64_t n = r.n_records;
+  fqg_index_result cr{};
+  if (n >= 2) {
+    fqg_frame* fr = nullptr;
+    LIB(fqg_frame_retain(g_ctx, &fr));
+    LIB(fqg_names_compare(g_ctx, fr, &pr.st, nullptr, nullptr, &cr));
+    fqg_frame_release(fr);
+  }
+  // order inside pair k: read m1, read m2, name m1, name m2, names equal, validate m1, validate m2
+  uint64_t best_pair = ~0ull;
+  int best_stage = 99;
+  auto offer = [&](uint64_t pair, int stage) {
+    if (pair < best_pair || (pair == best_pair && stage < best_stage)) {
+      best_pair = pair;
+      best_stage = stage;
+    }
+  };
+  const bool trunc = r.code == FQG_E_TRUNCATED || r.code == FQG_E_LINE_TOO_LONG;
+  uint64_t trunc_rec = trunc ? r.record : ~0ull;
+  if (trunc) offer(r.record / 2, r.record % 2 == 0 ? 0 : 2);
+  else if (r.code == FQG_E_HDR1_AT) offer(r.record / 2, r.record % 2 == 0 ? 3 : 4);
+  else if (r.code) offer(r.record / 2, r.record % 2 == 0 ? 6 : 7);
+  if (r.tail_lines > 0) {  // an incomplete last record, even when an earlier record has a finding
+    offer(n / 2, n % 2 == 0 ? 0 : 2);
+    if (trunc_rec == ~0ull) trunc_rec = n;
+  } else if (n % 2 == 1) {
+    offer(n / 2, 1);  // a first mate without a second one
+  }
+  if (cr.code == FQG_E_WRONG_HEADER) {
+    const RecordText t = locate_record(in.data(), in.size(), cr.record);
+    offer(cr.record / 2, (!t.l[0].empty() && t.l[0][0] != '@') ? 3 : 4);
+  }
+  if (cr.code == FQG_E_UNPAIRED) offer(cr.record / 2, 5);
+  // format lines: printed by the first fastq_get_readname call, i.e. for mate 1 of pair 0
+  if (n >= 2 && !(best_pair == 0 && best_stage <= 3)) print_probe(pr);
+  if (best_pair != ~0ull) {
+    ticker(1, best_pair, 50000, 2);
+    const uint64_t k = best_pair;
+    const unsigned long cline_pair = 4 * (2 * k + 2);
+    switch (best_stage) {
+      case 0:
+      case 2:
+        if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, r.record);
+        fail_truncated(path, 4 * (best_pair * 2 + (best_stage == 2 ? 1 : 0)));
+      case 1:
+        FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated?", path, (unsigned long)(4 * n));
+        exit(kExitFormat);
+      case 3:
+        fail_wrong_header(path, cline_pair, locate_record(in.data(), in.size(), 2 * k).l[0]);
+      case 4:
+        fail_wrong_header(path, cline_pair, locate_record(in.data(), in.size(), 2 * k + 1).l[0]);
+      case 5:
+        FQ_PRINT_ERROR("Error in file %s: line %lu: unpaired read - %s", path, cline_pair,
+                       canonical_name(locate_record(in.data(), in.size(), 2 * k).l[0], pr.st).c_str());
+        exit(kExitFormat);
+      default:
+        print_validation_error(path, cline_pair, r, locate_record(in.data(), in.size(), r.record));
+        exit(kExitFormat);
+    }
+  }
+  ticker(1, n / 2, 50000, 2);
+  printf("\n");
+  fqg_file_stats fs;
+  LIB(fqg_acc_read(S.acc1, &fs));
+  S.num_reads1 = fs.num_rds;
+}
+
+// ---- -r -s, two files: validate_paired_sorted_fastq_file (src/fastq_info.c:108-152) ---------
+void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
+  Input in1(g_ctx, p1, piece_bytes()), in2(g_ctx, p2, piece_bytes());
+  in1.next(true);
+  in2.next(true);
+  Probe pr1, pr2;
+  probe_piece(pr1, in1.data(), in1.size(), 1);
+  probe_piece(pr2, in2.data(), in2.size(), 1);
+  fqg_validate_result r1, r2;
+  LIB(fqg_validate(g_ctx, S.acc1, in1.data(), in1.size(), FQG_MEM_HOST, 1, &pr1.st, 0, &r1));
+  fqg_frame *f1 = nullptr, *f2 = nullptr;
+  if (r1.n_records) LIB(fqg_frame_retain(g_ctx, &f1));
+  LIB(fqg_validate(g_ctx, S.acc2, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st, 0, &r2));
+  if (r2.n_records) LIB(fqg_frame_retain(g_ctx, &f2));
+  fqg_index_result cr{};
+  if (f1 && f2) LIB(fqg_names_compare(g_ctx, f1, &pr1.st, f2, &pr2.st, &cr));
+  const uint64_t n1 = r1.stopped ? r1.n_records : r1.n_records, n2 = r2.n_records;
+  // read failures: a NUL-started line inside the file (reported as the first finding), or an
+  // incomplete last record (always known through tail_lines)
+  const bool t1 = r1.code == FQG_E_TRUNCATED || r1.code == FQG_E_LINE_TOO_LONG;
+  const bool t2 = r2.code == FQG_E_TRUNCATED || r2.code == FQG_E_LINE_TOO_LONG;
+  const bool tail1 = r1.tail_lines > 0, tail2 = r2.tail_lines > 0;
+  // per index k: read 1, validate 1, read 2, validate 2, names
+  enum { READ1 = 0, VAL1 = 1, READ2 = 2, VAL2 = 3, NAMES = 4, END1 = 5, END2 = 6 };
+  uint64_t best_k = ~0ull;
+  int best_stage = 99, best_kind = -1;
+  auto offer = [&](uint64_t k, int stage, int kind) {
+    if (k < best_k || (k == best_k && stage < best_stage)) {
+      best_k = k;
+      best_stage = stage;
+      best_kind = kind;
+    }
+  };
+  if (t1) offer(r1.record, 0, READ1);
+  else if (r1.code) offer(r1.record, 1, VAL1);
+  if (t2) offer(r2.record, 2, READ2);
+  else if (r2.code) offer(r2.record, 3, VAL2);
+  if (cr.code == FQG_E_NAME_MISMATCH) offer(cr.record, 4, NAMES);
+  if (tail1) offer(n1, 0, READ1);
+  else offer(n1, 0, END1);  // clean end of file 1: the loop ends before reading file 2
+  if (tail2) offer(n2, 2, READ2);
+  else offer(n2, 2, END2);  // clean end of file 2, after record n2 of file 1 was handled
+  // format lines come from inside validation (src/fastq.c:364) of each file's first record
+  const bool reach1 = n1 > 0 && !(r1.code && r1.record == 0 && is_early_code(r1.code));
+  if (reach1) print_probe(pr1);
+  const bool reach2 = n1 > 0 && !(r1.code && r1.record == 0) && n2 > 0 &&
+                      !(r2.code && r2.record == 0 && is_early_code(r2.code));
+  if (reach2) print_probe(pr2);
+  auto finish_frames = [&]() {
+    if (f1) fqg_frame_release(f1);
+    if (f2) fqg_frame_release(f2);
+  };
+  const uint64_t k = best_k;
+  switch (best_kind) {
+    case READ1:
+      if (r1.code == FQG_E_LINE_TOO_LONG) fail_too_long(p1, k);
+      fail_truncated(p1, 4 * k);
+    case VAL1:
+      print_validation_error(p1, 4 * (k + 1), r1, locate_record(in1.data(), in1.size(), k));
+      exit(kExitFormat);
+    case READ2:
+      if (r2.code == FQG_E_LINE_TOO_LONG) fail_too_long(p2, k);
+      fail_truncated(p2, 4 * k);
+    case VAL2:
+      print_validation_error(p2, 4 * (k + 1), r2, locate_record(in2.data(), in2.size(), k));
+      exit(kExitFormat);
+    case NAMES:
+      FQ_PRINT_ERROR("Readnames do not match across files (read #%ld)", (long)(k + 1 + 1));
+      exit(kExitFormat);
+    case END1:
+      // file 1 is exhausted at record n1; anything left in file 2?
+      if (n2 > n1) {
+        FQ_PRINT_ERROR("Premature end of file1");
+        exit(kExitFormat);
+      }
+      if (tail2 && n2 == n1) fail_truncated(p2, 4 * n1);
+      break;
+    case END2:
+      // file 2 is exhausted at record n2 (record n2 of file 1 has been read and validated)
+      if (n1 >= n2 + 2) {
+        FQ_PRINT_ERROR("Premature end of file2");
+        exit(kExitFormat);
+      }
+      if (tail1 && n1 == n2 + 1) fail_truncated(p1, 4 * (n2 + 1));
+      break;
+  }
+  finish_frames();
+  printf("\n");
+  fqg_file_stats fs;
+  LIB(fqg_acc_read(S.acc1, &fs));
+  S.num_reads1 = fs.num_rds;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  int is_paired_data = 0, is_interleaved = 0, is_sorted = 0, empty_ok = 0, no_encoding_ok = 0, skip_readname_check = 0;
+  int nopt = 0, c;
+  opterr = 0;
+  fprintf(stderr, "fastq_utils %s\n", "0.25.3");  // fastq_print_version
+  // option handling as in src/fastq_info.c:214-255 (nopt counts option letters)
+  while ((c = getopt(argc, argv, "esfrhq")) != -1) switch (c) {
+      case 'q': no_encoding_ok = 1; ++nopt; break;
+      case 'e': empty_ok = 1; ++nopt; break;
+      case 's': is_sorted = 1; ++nopt; break;
+      case 'r': skip_readname_check = 1; ++nopt; break;
+      case 'h': print_usage(1); exit(0);
+      case 'f':
+        fprintf(stderr, "Fixing (-f) enabled: Replacing . by N (creating .fix.gz files)\n");
+        FQ_PRINT_ERROR("-f option is no longer valid.");
+        exit(kExitParams);
+      default:
+        ++nopt;
+        FQ_PRINT_ERROR("Option -%c invalid", optopt);
+        exit(kExitParams);
+    }
+  if (argc - nopt < 2 || argc - nopt > 3) {
+    FQ_PRINT_ERROR("Invalid number of arguments");
+    print_usage(0);
+    exit(kExitParams);
+  }
+  if (argc - nopt == 3) {
+    is_paired_data = 1;
+    is_interleaved = strncmp(argv[2 + nopt], "pe", 2) == 0;
+  }
+  const char* file1 = argv[1 + nopt];
+  const char* file2 = is_paired_data ? argv[2 + nopt] : nullptr;
+
+  const char* dev = getenv("FQGPU_DEVICE");
+  int rc = fqg_open(dev ? atoi(dev) : 0, &g_ctx);
+  if (rc != 0) {
+    FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
+    exit(kExitSys);
+  }
+  Stats S;
+  LIB(fqg_acc_create(g_ctx, &S.acc1));
+  IndexedFile F;
+  bool merged_second_file = false;
+
+  if (is_interleaved) {
+    run_interleaved(file1, S);
+  } else if (is_paired_data && is_sorted && skip_readname_check) {
+    fprintf(stderr, "-s option used: assuming that reads have the same ordering in both files\n");
+    LIB(fqg_acc_create(g_ctx, &S.acc2));
+    run_paired_sorted(file1, file2, S);
+    fqg_acc_destroy(S.acc2);
+    S.acc2 = nullptr;  // the summary only looks at file 1 (src/fastq_info.c:316-319)
+  } else if (!is_paired_data && skip_readname_check) {
+    fprintf(stderr, "Skipping check for duplicated read names\n");
+    run_single_noindex(file1, S);
+  } else {
+    fprintf(stderr, "DEFAULT_HASHSIZE=%lu\n", 39000001ul);
+    fprintf(stderr, "Scanning and indexing all reads from %s\n", file1);
+    run_index_file(file1, is_paired_data, S, F);
+    fprintf(stderr, "Scanning complete.\n");
+    S.num_reads1 = F.entries;
+    fprintf(stderr, "\n");
+    fprintf(stderr, "Reads processed: %llu\n", (unsigned long long)F.entries);
+    fprintf(stderr, "Memory used in indexing: ~%ld MB\n", (long)(F.index_mem / 1024 / 1024));
+  }
+  if (S.num_reads1 == 0) {
+    if (empty_ok) {
+      fprintf(stdout, "Number of reads: %lu\n", 0L);
+      fprintf(stdout, "Quality encoding range: %lu %lu\n", 0L, 0L);
+      fprintf(stdout, "Quality encoding: %s\n", "");
+      fprintf(stdout, "Read length: %lu %lu %u\n", 0L, 0L, 0);
+      exit(0);
+    }
+    FQ_PRINT_ERROR("No reads found in %s.", file1);
+    exit(kExitFormat);
+  }
+  // min/max lengths and qualities are taken BEFORE the second file goes through fd1
+  // (src/fastq_info.c:316-319); only the length histogram keeps growing
+  fqg_file_stats fs;
+  LIB(fqg_acc_read(S.acc1, &fs));
+  if (is_paired_data && !is_interleaved && !is_sorted) {
+    fprintf(stderr, "File %s processed\n", file1);
+    fprintf(stderr, "Next file %s\n", file2);
+    run_pair_second_file(file1, file2, S, F);
+    // fd2's own counters are never touched (file-2 records went through fd1): an untouched
+    // accumulator stands in for it in min/max and in median_rl()
+    LIB(fqg_acc_create(g_ctx, &S.acc2));
+    merged_second_file = true;
+  }
+  unsigned long min_rl = fs.min_rl, max_rl = fs.max_rl, min_qual = fs.min_qual, max_qual = fs.max_qual;
+  if (merged_second_file) {
+    fqg_file_stats f2s;
+    LIB(fqg_acc_read(S.acc2, &f2s));
+    min_rl = std::min<unsigned long>(f2s.min_rl, min_rl);
+    max_rl = std::max<unsigned long>(f2s.max_rl, max_rl);
+    min_qual = std::min<unsigned long>(f2s.min_qual, min_qual);
+    max_qual = std::max<unsigned long>(f2s.max_qual, max_qual);
+  }
+  fprintf(stderr, "------------------------------------\n");
+  fprintf(stderr, "Number of reads: %lu\n", S.num_reads1);
+  const char* enc = qual_range_to_enc(min_qual, max_qual);
+  if (!enc && !no_encoding_ok) {
+    if (max_qual > FQG_MAX_PHRED_QUAL)
+      FQ_PRINT_ERROR("Unable to determine quality encoding - unknown range [%lu,>%u]", min_qual, FQG_MAX_PHRED_QUAL);
+    else
+      FQ_PRINT_ERROR("Unable to determine quality encoding - unknown range [%lu,%lu]", min_qual, max_qual);
+    exit(kExitFormat);
+  }
+  fprintf(stderr, "Quality encoding range: %lu %lu\n", min_qual, max_qual);
+  if (!enc) fprintf(stderr, "Quality encoding: NA\n");
+  else fprintf(stderr, "Quality encoding: %s\n", enc);
+  uint64_t med = 0;
+  LIB(fqg_acc_median(S.acc1, S.acc2, &med));
+  fprintf(stderr, "Read length: %lu %lu %u\n", min_rl - 1, max_rl - 1, (unsigned)(med - 1));
+  fprintf(stderr, "OK\n");
+  exit(0);
+}

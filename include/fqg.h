@@ -127,7 +127,8 @@ typedef struct {
   int32_t code;       /* enum fqg_code; FQG_OK if every record passed */
   int32_t stopped;    /* 1: a record starting with a NUL byte ended the file early (src/fastq.c:250) */
   int32_t path;       /* which device path ran: 1 = exact wave-per-record, 2 = tiled fast path */
-  int32_t reserved;
+  int32_t tail_lines; /* final images: lines (1..3) of an incomplete last record, whether or not an
+                         earlier record already failed; 0 if the image ends at a record boundary */
 } fqg_validate_result;
 
 /* checks bitmask */
@@ -155,6 +156,49 @@ typedef struct {
 } fqg_record;
 
 int fqg_frame_records(fqg_ctx *ctx, uint64_t first, uint64_t count, fqg_record *out, int mem);
+
+/* ---- frames ------------------------------------------------------------------------------
+ * fqg_validate() leaves a "frame" in the context: the image on the device plus its line index.
+ * The next fqg_validate() call overwrites it.  fqg_frame_retain() moves the frame's buffers into
+ * an object of its own so that it outlives later calls (images the caller passed as
+ * FQG_MEM_DEVICE stay the caller's and must stay alive as long as the frame is used). */
+typedef struct fqg_frame fqg_frame;
+int fqg_frame_retain(fqg_ctx *ctx, fqg_frame **out);
+void fqg_frame_release(fqg_frame *frame);
+uint64_t fqg_frame_n_records(const fqg_frame *frame);
+
+/* ---- read-name index --------------------------------------------------------------------
+ * Replaces hash.c as fastq.c uses it: new_hashtable() + the fastq_index_readnames() loop
+ * (src/fastq.c:396-439: fastq_get_readname, fastq_index_lookup_header, new_indexentry) and the
+ * lookup / fastq_index_delete loop over the second file (src/fastq_info.c:333-356).
+ * Names are the canonical read names of fastq_get_readname() (src/fastq.c:488-512) under the
+ * given file state; equality is decided on the name bytes. */
+typedef struct fqg_index fqg_index;
+typedef struct {
+  uint64_t n_entries; /* hashtable.n_entries after the call */
+  uint64_t index_mem; /* what the reference adds up in index_mem (src/fastq.c:609, src/fastq_info.c:293) */
+  uint64_t record;    /* index, within the frame, of the first record with a finding */
+  int32_t code;       /* FQG_OK, FQG_E_WRONG_HEADER, FQG_E_DUP_NAME, FQG_E_UNPAIRED, FQG_E_NAME_MISMATCH */
+  int32_t reserved;
+} fqg_index_result;
+
+int fqg_index_create(fqg_ctx *ctx, uint64_t expected_names, fqg_index **out);
+void fqg_index_destroy(fqg_index *index);
+/* Insert the name of every record of the context's current frame (the frame is retained by the
+ * index).  Finding: the first record whose header does not start with '@' (FQG_E_WRONG_HEADER,
+ * src/fastq.c:448) or whose name is already in the index (FQG_E_DUP_NAME, src/fastq.c:422),
+ * whichever record comes first. */
+int fqg_index_insert_unique(fqg_ctx *ctx, fqg_index *index, const fqg_file_state *state,
+                            fqg_index_result *out);
+/* For every record of the current frame: look its name up and delete the entry.  Finding: the
+ * first record with a wrong header or without a partner (FQG_E_UNPAIRED, src/fastq_info.c:338). */
+int fqg_index_match_delete(fqg_ctx *ctx, fqg_index *index, const fqg_file_state *state,
+                           fqg_index_result *out);
+/* Pairwise name agreement without an index.  b == NULL: records 2k and 2k+1 of frame a
+ * (interleaved input, src/fastq_info.c:81-91, finding FQG_E_UNPAIRED at pair k -> record 2k);
+ * otherwise record k of a against record k of b (src/fastq_info.c:133-138, FQG_E_NAME_MISMATCH). */
+int fqg_names_compare(fqg_ctx *ctx, const fqg_frame *a, const fqg_file_state *state_a, const fqg_frame *b,
+                      const fqg_file_state *state_b, fqg_index_result *out);
 
 /* ---- measurement ------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */

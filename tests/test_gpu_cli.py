@@ -1,0 +1,124 @@
+"""End-to-end parity of the drop-in program bin/fastq_info (C++ host + libfqgpu.so) with the
+reference program: every golden invocation (tests/golden/fastq_info.json, captured from the
+reference binary) must give the same exit status, stdout and stderr; seeded mutated inputs are
+checked against the oracle in all four modes."""
+import os
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from oracle import loader as orc
+from tests import fuzz
+from tests.util import GOLD, REPO, load_fastq_info_golden, strip_progress
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(REPO, "bin", "fastq_info")
+GOLDEN = load_fastq_info_golden()
+
+
+def run_cli(args, cwd, env_extra=None):
+    env = dict(os.environ)
+    if env_extra:
+        env.update(env_extra)
+    p = subprocess.run([BIN] + args, cwd=cwd, capture_output=True, timeout=300, env=env)
+    return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1")
+
+
+def test_binary_exists():
+    assert os.path.exists(BIN), "run __graft_entry__.build() first"
+
+
+def test_all_golden_invocations():
+    def one(case):
+        rc, out, err = run_cli(case["args"], GOLD)
+        ok = (rc == case["exit"] and out == case["stdout"]
+              and strip_progress(err) == strip_progress(case["stderr"]))
+        return None if ok else (case["args"], rc, case["exit"], err[-400:], case["stderr"][-400:])
+
+    with ThreadPoolExecutor(8) as ex:
+        bad = [b for b in ex.map(one, GOLDEN) if b]
+    assert not bad, f"{len(bad)} of {len(GOLDEN)} differ; first: {bad[:3]}"
+
+
+def oracle_run(args, files):
+    flags, pos = orc.parse_args(args)
+    if len(pos) == 1:
+        return orc.fastq_info(files[pos[0]], pos[0], flags=flags)
+    if pos[1].startswith("pe"):
+        return orc.fastq_info(files[pos[0]], pos[0], None, pos[1], orc.ARG2_PE, flags)
+    return orc.fastq_info(files[pos[0]], pos[0], files[pos[1]], pos[1], orc.ARG2_FILE, flags)
+
+
+def compare_with_oracle(tmp, args, files, env=None):
+    rc, out, err = run_cli(args, tmp, env)
+    want = oracle_run(args, files)
+    ctx = (args, err[-500:], want["stderr"][-500:])
+    assert rc == want["exit"], ctx
+    assert out == want["stdout"], ctx
+    assert strip_progress(err) == strip_progress(want["stderr"]), ctx
+
+
+@pytest.mark.parametrize("kind", fuzz.MUTATIONS)
+def test_mutated_single_files(kind):
+    rng = np.random.default_rng(abs(hash("cli" + kind)) % 100000)
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(4):
+            style = ["casava", "slash", "int", "nosuffix"][trial % 4]
+            img = fuzz.make_fastq(rng, int(rng.integers(1, 300)), 1, 100, style, hdr2_names=bool(trial & 1),
+                                  crlf=(trial == 3), rna=(trial == 2))
+            img = fuzz.mutate(rng, img, kind)
+            with open(os.path.join(tmp, "f.fastq"), "wb") as f:
+                f.write(img)
+            for args in (["-r", "f.fastq"], ["f.fastq"], ["f.fastq", "pe"]):
+                compare_with_oracle(tmp, args, {"f.fastq": img})
+
+
+def test_duplicates_and_pairs():
+    rng = np.random.default_rng(5)
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(10):
+            style = ["casava", "slash"][trial % 2]
+            n = int(rng.integers(2, 400))
+            a = fuzz.make_fastq(np.random.default_rng(trial), n, 1, 60, style, mate=1)
+            b = fuzz.make_fastq(np.random.default_rng(trial), n, 1, 60, style, mate=2)
+            la, lb = a.split(b"\n"), b.split(b"\n")
+            if trial % 5 == 1:  # duplicate a record of file 1 (twice, to test "earliest repeat")
+                k = int(rng.integers(0, n))
+                la = la[:-1] + la[4 * k:4 * k + 4] + la[4 * k:4 * k + 4] + [b""]
+            if trial % 5 == 2:  # drop a record from file 2
+                k = int(rng.integers(0, n))
+                lb = lb[:4 * k] + lb[4 * k + 4:]
+            if trial % 5 == 3:  # shuffle file 2 (still paired)
+                recs = [lb[4 * i:4 * i + 4] for i in range(n)]
+                order = rng.permutation(n)
+                lb = [x for i in order for x in recs[i]] + [b""]
+            if trial % 5 == 4:  # duplicate in file 2
+                k = int(rng.integers(0, n))
+                lb = lb[:-1] + lb[4 * k:4 * k + 4] + [b""]
+            a, b = b"\n".join(la), b"\n".join(lb)
+            files = {"a.fastq": a, "b.fastq": b}
+            for name, img in files.items():
+                with open(os.path.join(tmp, name), "wb") as f:
+                    f.write(img)
+            for args in (["a.fastq"], ["a.fastq", "b.fastq"], ["b.fastq", "a.fastq"], ["-r", "-s", "a.fastq", "b.fastq"],
+                         ["-s", "a.fastq", "b.fastq"]):
+                compare_with_oracle(tmp, args, files)
+
+
+def test_small_pieces_exercise_the_carry():
+    """1 MiB pieces: records straddle piece boundaries, the index spans many segments."""
+    rng = np.random.default_rng(17)
+    with tempfile.TemporaryDirectory() as tmp:
+        a = fuzz.make_fastq(np.random.default_rng(1), 30000, 50, 150, "casava", mate=1)
+        b = fuzz.make_fastq(np.random.default_rng(1), 30000, 50, 150, "casava", mate=2)
+        dup = a + b"\n".join(a.split(b"\n")[4 * 123:4 * 123 + 4]) + b"\n"
+        files = {"a.fastq": a, "b.fastq": b, "d.fastq": dup}
+        for name, img in files.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(img)
+        env = {"FQGPU_CHUNK_MB": "1"}
+        for args in (["-r", "a.fastq"], ["a.fastq"], ["a.fastq", "b.fastq"], ["d.fastq"]):
+            compare_with_oracle(tmp, args, files, env)
