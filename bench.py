@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exact", action="store_true", help="use only the wave-per-record validator")
+    ap.add_argument("--no-index-extra", action="store_true",
+                    help="skip the untimed extra: fastq_info default mode (validate + unique read-name index)")
     return ap.parse_args()
 
 
@@ -68,6 +70,23 @@ def cpu_baseline(image_prefix_bytes, n_reads):
     dt = time.perf_counter() - t0
     return {"value": n_reads / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
             "sample": sample + "; oracle/fq_oracle.c restatement", "seconds": dt, "ok": r["exit"] == 0}
+
+
+def committed_traffic(kernel, n_reads, read_len, record_bytes):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes, by
+    tools/pmc_traffic.py).  Only valid for the exact workload it was measured on; otherwise None."""
+    path = os.path.join(REPO, "profiles", f"r01_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    if int(t["image_bytes"]) != n_reads * record_bytes:
+        return None, None
+    for k, v in t["kernels"].items():
+        if k.split("<")[0] == {"k_frame_fast": "k_frame_fast_t"}.get(kernel, kernel):
+            return v["total"] / 1e9, os.path.relpath(path, REPO)
+    return None, None
 
 
 def main():
@@ -145,6 +164,7 @@ def main():
         algo_bytes = n * (R + ALGO_BYTES_PER_READ_EXTRA)  # per launch: one batch
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         all_ms = sum(v[1] for v in kernels.values()) / a.steps
+        traffic, traffic_src = committed_traffic(dom, n, a.read_len, R)
         out = {
             "metric": "Mreads/s validated (fastq_info, 150bp)",
             "value": n * a.steps * world / dt / 1e6,
@@ -165,13 +185,38 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms,
                 "all_kernels_ms_per_step": all_ms,
                 "pipeline_achieved": algo_bytes / (all_ms * 1e-3) / 1e9,
                 "kernels_ms_per_step": {k: v[1] / a.steps for k, v in kernels.items()},
             },
         }
+        if world == 1 and not a.no_index_extra:
+            # untimed extra: fastq_info's default mode = the same pass + the unique read-name index
+            acc2 = ctx.accumulator()
+            ctx.profile(True)
+            ctx.profile_reset()
+            t1 = time.perf_counter()
+            r2 = ctx.validate(image.data_ptr(), acc2, st, final=True, flags=fq.abi.VALIDATE_COUNT_TWICE, nbytes=n * R)
+            idx = ctx.name_index(n)
+            ir = idx.insert_unique(st)
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            p2 = ctx.profile_read()
+            ctx.profile(False)
+            assert r2["code"] == 0 and ir["code"] == 0 and ir["n_entries"] == n, (r2, ir)
+            ki = p2.get("k_index_insert", (1, 0.0))
+            out["default_mode_extra"] = {
+                "what": "fastq_info default mode: validate + insert every read name into the GPU index (all unique)",
+                "wall_ms_one_pass_incl_allocations": (t2 - t1) * 1e3,
+                "k_index_insert_ms": ki[1] / max(1, ki[0]),
+                "index_entries": ir["n_entries"],
+                "Mreads_per_s_kernels_only": n / ((all_ms + ki[1] / max(1, ki[0])) * 1e-3) / 1e6,
+            }
+            idx.close()
+            acc2.close()
         if world == 1 and not a.no_cpu_baseline:
             m = min(n, a.cpu_sample_reads)
             out["cpu_baseline"] = cpu_baseline(bytes(image[: m * R].cpu().numpy()), m)

@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: two gloo ranks shard a record range, exchange statistics blobs with
+all_gather_object and agree on the merged summary and on the first finding in file order."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fastq_utils_amd import dist as fdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = fdist.shard_records(1001, world)[rank]
+    # synthetic per-rank statistics: record i has read length 100 + i % 7 (+1 for the newline)
+    hist = {}
+    for i in range(first, first + count):
+        rl = 101 + i % 7
+        hist[rl] = hist.get(rl, 0) + 1
+    blob = fdist.make_acc_blob(count, min(hist), max(hist), 35 + rank, 70 + rank, hist)
+    finding = (first + 5, 3, 11) if rank == 1 else None  # rank 1 saw a QLEN error at its 6th record
+    blobs, finds = [None] * world, [None] * world
+    dist.all_gather_object(blobs, blob)
+    dist.all_gather_object(finds, finding)
+    merged = fdist.merge_acc_blobs(blobs)
+    q.put((rank, merged["num_rds"], merged["min_rl"], merged["max_rl"], merged["min_qbyte"], merged["max_qbyte"],
+           fdist.median_rl(merged), fdist.first_finding(finds)))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_merge_statistics_and_findings():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shards = fdist.shard_records(1001, world)
+    assert shards == [(0, 501), (501, 500)]
+    lens = sorted(101 + i % 7 for i in range(1001))
+    for rank, num, mn, mx, qmn, qmx, med, first in out:
+        assert (num, mn, mx, qmn, qmx) == (1001, 101, 107, 35, 71)
+        # median_rl: first length whose cumulative count exceeds n/2
+        assert med == lens[1001 // 2]
+        assert first == (506, 3, 11)
+
+
+def test_blob_roundtrip_matches_library_layout():
+    blob = fdist.make_acc_blob(10, 50, 151, 35, 73, {151: 9, 50: 1})
+    p = fdist.parse_acc_blob(blob)
+    assert p["num_rds"] == 10 and p["hist"] == {50: 1, 151: 9}
+    assert len(blob) == 32 + 8 + 4 * 8
