@@ -100,5 +100,107 @@ def main():
     print("fastq_info invocations:", len(out), "by exit status:", by)
 
 
+PB_BIN = os.path.join(REPO, "oracle", "_ref", "fastq_pre_barcodes")
+
+
+def pre_barcodes_jobs():
+    """argv lists for fastq_pre_barcodes; OUT1/OUT2 stand for output files in a scratch directory.
+    Taken from run_tests.sh:383-449 and sh/fastq2bam:116-273 (the 10x / drop-seq flag sets)."""
+    d = "data/"
+    b1, b2 = d + "barcode_test2_1.fastq.gz", d + "barcode_test2_2.fastq.gz"
+    common = ["--phred_encoding", "33", "--umi_read", "index1", "--umi_offset", "0", "--umi_size", "16",
+              "--read1_offset", "0", "--read1_size", "-1"]
+    jobs = []
+    jobs.append(["--index1", d + "barcode_test_1.fastq.gz", "--min_qual", "10"] + common +
+                ["--read1", d + "barcode_test_2.fastq.gz", "--outfile1", "OUT1"])
+    jobs.append(jobs[-1] + ["-X"])
+    jobs.append(["--index1", b1, "--min_qual", "10"] + common + ["--read1", b2, "--outfile1", "OUT1"])  # pre1
+    cell = ["--cell_read", "index1", "--cell_offset", "0", "--cell_size", "8"]
+    jobs.append(["--index1", b1, "--min_qual", "10"] + common + cell + ["--read1", b2, "--outfile1", "OUT1"])  # pre2
+    samp = ["--sample_read", "read1", "--sample_offset", "0", "--sample_size", "4"]
+    jobs.append(["--index1", b1, "--min_qual", "1"] + common + cell + samp + ["--read1", b2, "--outfile1", "OUT1"])  # pre3
+    three = ["--index1", b1, "--index2", b1, "--index3", b1, "--min_qual", "1"] + common + [
+        "--cell_read", "index2", "--cell_offset", "0", "--cell_size", "8", "--sample_read", "index3",
+        "--sample_offset", "0", "--sample_size", "4", "--read1", b2]
+    jobs.append(three + ["--outfile1", "OUT1"])
+    jobs.append(three + ["--read2", b2, "--outfile1", "OUT1", "--outfile2", "OUT2"])
+    jobs.append(three + ["--read2", b2, "--outfile1", "OUT1", "--outfile2", "OUT2", "--sam"])
+    jobs.append(three + ["--outfile1", "OUT1", "--sam"])
+    jobs.append(["--index1", b1, "--min_qual", "10"] + common + cell + ["--read1", b2, "--outfile1", "OUT1", "--sam"])
+    jobs.append(["--index1", b1, "--min_qual", "10"] + common + cell + ["--read1", b2, "--outfile1", "OUT1", "--sam", "--10x"])
+    umi16 = ["--umi_read", "index1", "--umi_offset", "0", "--umi_size", "16"]
+    inter, cas = d + "inter.fastq.gz", d + "casava.1.8i.fastq.gz"
+    jobs.append(["--interleaved", "read1", "--read1", inter, "--index1", inter, "--outfile1", "OUT1"] + umi16 + ["--sam"])
+    jobs.append(["--interleaved", "read1,read2,index1", "--read1", inter, "--index1", inter, "--outfile1", "OUT1"] + umi16 + ["--sam"])
+    for order in ("index1,read1", "read1,index1"):
+        for f in (cas, inter):
+            jobs.append(["--interleaved", order, "--read1", f, "--index1", f, "--outfile1", "OUT1"] + umi16)
+            jobs.append(["--interleaved", order, "--read1", f, "--index1", f, "--outfile1", "OUT1"] + umi16 + ["--sam"])
+    # slicing variants
+    for off, size in (("0", "10"), ("5", "10"), ("5", "-1"), ("0", "0"), ("3", "200"), ("0", "98"), ("0", "97"), ("1", "97")):
+        jobs.append(["--index1", b1, "--min_qual", "1", "--phred_encoding", "33"] + umi16 + cell +
+                    ["--read1_offset", off, "--read1_size", size, "--read1", b2, "--outfile1", "OUT1"])
+        if (off, size) != ("5", "-1"):  # the reference itself crashes (SIGSEGV) on this one in SAM mode
+            jobs.append(jobs[-1] + ["--sam"])
+    # 10x v2 flag set (sh/fastq2bam:125-130) on the pbmc8k fixtures, and the tx (10x v1) set
+    r1, r2 = d + "pbmc8k_S1_L007_R1_001.fastq.gz", d + "pbmc8k_S1_L007_R2_001.fastq.gz"
+    v2 = ["--read1", r2, "--index1", r1, "--umi_read", "index1", "--umi_offset", "16", "--umi_size", "10",
+          "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16"]
+    jobs.append(v2 + ["--outfile1", "OUT1"])
+    jobs.append(v2 + ["--outfile1", "OUT1", "--sam"])
+    jobs.append(v2 + ["--outfile1", "OUT1", "--sam", "--10x", "--phred_encoding", "33", "--min_qual", "10"])
+    jobs.append(v2 + ["--outfile1", "OUT1", "--phred_encoding", "33", "--min_qual", "30"])
+    tx = ["--read1", d + "tx.RA.fastq.gz", "--index3", d + "tx.RA.fastq.gz", "--index1", d + "tx.I1.fastq.gz",
+          "--umi_read", "index3", "--umi_offset", "0", "--umi_size", "10", "--cell_read", "index1",
+          "--cell_offset", "0", "--cell_size", "14", "--interleaved", "read1,index3",
+          "--index2", d + "tx.I2.fastq.gz", "--sample_read", "index2", "--sample_offset", "0", "--sample_size", "8"]
+    jobs.append(tx + ["--sam", "--outfile1", "-"])
+    jobs.append(tx + ["--outfile1", "OUT1"])
+    # failures
+    jobs.append([])
+    jobs.append(["--index1", d + "test_1.fastq.gz", "--min_qual", "1"] + common + cell + samp + ["--read1", b2, "--outfile1", "OUT1"])
+    jobs.append(["--index1", b1, "--min_qual", "1"] + common + cell + samp + ["--read1", b2])
+    jobs.append(["--index1", b1, "--min_qual", "1"] + common + ["--umi_read", "index5", "--read1", b2, "--outfile1", "OUT1"])
+    jobs.append(["--index1", b1, "--min_qual", "1"] + common + ["--read1", d + "test_e5.fastq.gz", "--outfile1", "OUT1"])
+    jobs.append(["--help"])
+    return jobs
+
+
+def gen_pre_barcodes():
+    import gzip
+    import tempfile
+
+    if not os.path.exists(PB_BIN):
+        sys.exit("build the reference first: make -C oracle ref")
+    out = []
+    for args in pre_barcodes_jobs():
+        with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+            rel = os.path.relpath(tmp, GOLD)
+            real = [a.replace("OUT1", rel + "/o1.fastq.gz").replace("OUT2", rel + "/o2.fastq.gz") for a in args]
+            p = subprocess.run(["fastq_pre_barcodes"] + real, executable=PB_BIN, cwd=GOLD, capture_output=True, timeout=120)
+            files = {}
+            for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
+                path = os.path.join(tmp, fn)
+                if os.path.exists(path):
+                    raw = open(path, "rb").read()
+                    try:
+                        files[tag] = gzip.decompress(raw).decode("latin-1") if raw else ""
+                    except Exception:
+                        files[tag] = None  # unfinished gzip stream (the reference exited mid-way)
+            out.append({"args": args, "exit": p.returncode,
+                        "stdout": p.stdout.decode("latin-1").replace(rel + "/", "SCRATCH/"),
+                        "stderr": p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"), "files": files})
+    with open(os.path.join(GOLD, "pre_barcodes.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    by = {}
+    for o in out:
+        by[o["exit"]] = by.get(o["exit"], 0) + 1
+    print("fastq_pre_barcodes invocations:", len(out), "by exit status:", by)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pre_barcodes":
+        gen_pre_barcodes()
+    else:
+        main()
+        gen_pre_barcodes()
