@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfqgpu.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE = 0, 1, 2, 4
+VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE, VALIDATE_FRAME_ONLY = 0, 1, 2, 4, 8
 NAME_DEFAULT, NAME_CASAVA18, NAME_INTEGER, NAME_UNDEF = 0, 1, 2, -1
 SPACE_SEQ, SPACE_COLOUR, SPACE_UNDEF = 0, 1, -1
 
@@ -30,6 +30,7 @@ EXPORTS = [
     "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
     "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_index_create",
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_names_compare",
+    "fqg_barcodes_transform", "fqg_barcodes_output",
 ]
 
 

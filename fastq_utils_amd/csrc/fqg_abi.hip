@@ -12,6 +12,7 @@
 #include "fqg_device.h"
 #include "fqg_kernels.hip"
 #include "fqg_index_kernels.hip"
+#include "fqg_barcode_kernels.hip"
 
 using namespace fqg;
 
@@ -61,6 +62,10 @@ struct fqg_ctx {
   bool frame_valid = false;
   bool frame_img_owned = false;  // the frame's image lives in `image` (host input), not with the caller
   uint32_t frame_flags = 0;      // kFlagNul / kFlagCr of the framed image
+  DevBuf bc_status, bc_len[3], bc_off[3], bc_sum[3], bc_out[3];
+  BcCall* d_bcall = nullptr;
+  BcCall* h_bcall = nullptr;  // pinned
+  uint64_t bc_out_bytes[3] = {0, 0, 0};
   IndexCall* d_icall = nullptr;
   IndexCall* h_icall = nullptr;  // pinned
 
@@ -203,7 +208,9 @@ int fqg_open(int device_ordinal, fqg_ctx** out) {
     return FQG_ERR_HIP;
   }
   c->stream = c->own_stream;
-  if (hipMalloc((void**)&c->d_icall, sizeof(IndexCall)) != hipSuccess ||
+  if (hipMalloc((void**)&c->d_bcall, sizeof(BcCall) + 64) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_bcall, sizeof(BcCall) + 64, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&c->d_icall, sizeof(IndexCall)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_icall, sizeof(IndexCall), hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void**)&c->d_cs, sizeof(CallState)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_cs, sizeof(CallState), hipHostMallocDefault) != hipSuccess ||
@@ -229,6 +236,15 @@ void fqg_close(fqg_ctx* c) {
   release(c->records);
   release(c->suspect);
   release(c->list);
+  release(c->bc_status);
+  for (int i = 0; i < 3; ++i) {
+    release(c->bc_len[i]);
+    release(c->bc_off[i]);
+    release(c->bc_sum[i]);
+    release(c->bc_out[i]);
+  }
+  if (c->d_bcall) (void)hipFree(c->d_bcall);
+  if (c->h_bcall) (void)hipHostFree(c->h_bcall);
   if (c->d_icall) (void)hipFree(c->d_icall);
   if (c->h_icall) (void)hipHostFree(c->h_icall);
   if (c->d_cs) (void)hipFree(c->d_cs);
@@ -514,7 +530,8 @@ int frame_two_pass(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n
 int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, int mem, int final,
                  const fqg_file_state* st, uint32_t flags, fqg_validate_result* out) {
   if (!c || !out || !st || (nbytes && !image)) return FQG_ERR_ARG;
-  if (!(flags & FQG_VALIDATE_NO_STATS) && !acc) return fail(c, FQG_ERR_ARG, "fqg_validate: acc is NULL");
+  if (!(flags & (FQG_VALIDATE_NO_STATS | FQG_VALIDATE_FRAME_ONLY)) && !acc)
+    return fail(c, FQG_ERR_ARG, "fqg_validate: acc is NULL");
   if (mem != FQG_MEM_HOST && mem != FQG_MEM_DEVICE) return FQG_ERR_ARG;
   if (flags & FQG_VALIDATE_NO_STATS) acc = nullptr;
   memset(out, 0, sizeof(*out));
@@ -535,7 +552,9 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
     d_img = (const uint8_t*)image;
   }
   const uint32_t n_chunks = (uint32_t)((nbytes + kChunkBytes - 1) / kChunkBytes);
-  const bool want_checks = !(flags & FQG_VALIDATE_FORCE_EXACT);
+  const bool frame_only = (flags & FQG_VALIDATE_FRAME_ONLY) != 0;
+  if (frame_only) acc = nullptr;
+  const bool want_checks = !(flags & FQG_VALIDATE_FORCE_EXACT) && !frame_only;
   const uint32_t weight = (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u;
 
   // suspect bitmap, sized from the image (>= 16 bytes per record assumed; denser images overflow
@@ -625,7 +644,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
                            (const unsigned long long*)c->list.p, (const unsigned long long*)&c->d_cs->list_count);
       }
     }
-  } else if (n_records) {
+  } else if (n_records && !frame_only) {
     ProfScope ps(c, "k_validate_exact");
     hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
                        st->is_pe, st->readname_format, st->space, weight, acc ? acc->d_state : nullptr,
@@ -977,6 +996,149 @@ int fqg_names_compare(fqg_ctx* c, const fqg_frame* a, const fqg_file_state* sa, 
     out->code = interleaved ? FQG_E_UNPAIRED : FQG_E_NAME_MISMATCH;
     out->record = interleaved ? 2 * m : m;
   }
+  return 0;
+}
+
+// ---- barcode extraction ----------------------------------------------------------------------
+int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const fqg_file_state states[6],
+                           const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_iter,
+                           uint64_t first_read_number, fqg_barcode_result* out) {
+  if (!c || !frames || !states || !first_record || !bp || !out) return FQG_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  BcParams P;
+  memset(&P, 0, sizeof(P));
+  const bool inter = bp->interleaved[0] != 0 || bp->interleaved[1] != 0;
+  for (int x = 1; x < kBcFiles; ++x) {
+    if (!bp->present[x]) continue;
+    if (!frames[x]) return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: missing frame");
+    if (frames[x]->flags & kFlagNul) return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: input holds NUL bytes");
+    BcFile& f = P.f[x];
+    f.fv = frames[x]->fv;
+    f.first = first_record[x];
+    f.present = 1;
+    f.fmt = states[x].readname_format;
+    f.step = 1;
+    f.add = 0;
+    if (inter && (x == bp->interleaved[0] || x == bp->interleaved[1])) {
+      f.step = 2;
+      f.add = x == bp->interleaved[1] ? 1 : 0;
+    }
+    // every record the batch touches must exist
+    if (n_iter && f.first + (n_iter - 1) * f.step + f.add >= f.fv.n_records)
+      return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: iterations beyond a frame");
+    P.n_inputs++;
+  }
+  if (!P.f[1].present) return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: read1 is required");
+  for (int x = 1; x <= 2; ++x)
+    if (((bp->out_sam && x == 1) || (!bp->out_sam && bp->emit[x])) && !P.f[x].present)
+      return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: output requested for an absent input");
+  const int64_t sizes[3] = {bp->umi_size, bp->cell_size, bp->sample_size};
+  for (int i = 0; i < 3; ++i)
+    if (sizes[i] < 0 || sizes[i] >= 50) return fail(c, FQG_ERR_ARG, "barcode sizes must be 0..49 (MAX_BARCODE_LENGTH)");
+  P.umi_read = bp->umi_read;
+  P.cell_read = bp->cell_read;
+  P.sample_read = bp->sample_read;
+  P.phred = bp->phred_encoding;
+  P.min_qual = bp->min_qual;
+  P.out_sam = bp->out_sam;
+  P.tenx = bp->tenx;
+  P.umi_off = bp->umi_offset;
+  P.umi_size = bp->umi_size;
+  P.cell_off = bp->cell_offset;
+  P.cell_size = bp->cell_size;
+  P.sample_off = bp->sample_offset;
+  P.sample_size = bp->sample_size;
+  for (int x = 0; x < 3; ++x) {
+    P.emit[x] = bp->emit[x];
+    P.read_off[x] = bp->read_offset[x];
+    P.read_size[x] = bp->read_size[x];
+  }
+  P.first_read_number = first_read_number;
+  if (!n_iter) return 0;
+
+  int rc;
+  if ((rc = ensure(c, c->bc_status, n_iter))) return rc;
+  const uint64_t nb = (n_iter + kScan64Span - 1) / kScan64Span;
+  for (int i = 0; i < 3; ++i) {
+    if ((rc = ensure(c, c->bc_len[i], n_iter * 4))) return rc;
+    if ((rc = ensure(c, c->bc_off[i], n_iter * 8))) return rc;
+    if ((rc = ensure(c, c->bc_sum[i], nb * 8))) return rc;
+  }
+  BcCall z;
+  memset(&z, 0, sizeof(z));
+  z.first_finding = z.first_discard = ~0ull;
+  *c->h_bcall = z;
+  HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
+  const unsigned grid = (unsigned)((n_iter + kBlock - 1) / kBlock);
+  {
+    ProfScope ps(c, "k_bc_plan");
+    hipLaunchKernelGGL(k_bc_plan, dim3(grid), dim3(kBlock), 0, c->stream, P, n_iter, (uint8_t*)c->bc_status.p,
+                       (uint32_t*)c->bc_len[0].p, (uint32_t*)c->bc_len[1].p, (uint32_t*)c->bc_len[2].p, c->d_bcall);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t n_done = n_iter;
+  if (c->h_bcall->first_finding != ~0ull) {
+    const uint64_t k = c->h_bcall->first_finding >> 8;
+    n_done = k;
+    out->iteration = k;
+    out->code = (int32_t)((c->h_bcall->first_finding & 0xFF) >> 3);
+    out->file = (int32_t)(c->h_bcall->first_finding & 7);
+  }
+  if (inter && c->h_bcall->first_discard < n_done) {
+    n_done = c->h_bcall->first_discard + 1;
+    out->code = FQG_OK;  // a finding beyond the re-synchronisation point is not reached in this batch
+    out->file = 0;
+    out->iteration = 0;
+  }
+  out->n_done = n_done;
+  if (!n_done) return 0;
+  unsigned long long* d_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_bcall) + sizeof(BcCall));
+  unsigned long long* h_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_bcall) + sizeof(BcCall));
+  const uint64_t nb_done = (n_done + kScan64Span - 1) / kScan64Span;
+  {
+    ProfScope ps(c, "k_bc_scan");
+    hipLaunchKernelGGL(k_bc_count, dim3((unsigned)((n_done + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                       (const uint8_t*)c->bc_status.p, n_done, c->d_bcall);
+    for (int i = 0; i < 3; ++i) {
+      hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb_done), dim3(kBlock), 0, c->stream, (const uint32_t*)c->bc_len[i].p,
+                         n_done, (unsigned long long*)c->bc_off[i].p, (unsigned long long*)c->bc_sum[i].p);
+      hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->bc_sum[i].p, nb_done,
+                         d_tot + i);
+    }
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall) + 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out->n_discarded = c->h_bcall->discarded;
+  out->n_short = c->h_bcall->short_warnings;
+  for (int i = 0; i < 3; ++i) {
+    out->out_bytes[i] = h_tot[i];
+    c->bc_out_bytes[i] = h_tot[i];
+    if ((rc = ensure(c, c->bc_out[i], std::max<uint64_t>(h_tot[i], 16)))) return rc;
+  }
+  {
+    ProfScope ps(c, "k_bc_emit");
+    const unsigned grid_e =
+        (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));
+    hipLaunchKernelGGL(k_bc_emit, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done, (const uint8_t*)c->bc_status.p,
+                       (const unsigned long long*)c->bc_off[0].p, (const unsigned long long*)c->bc_sum[0].p,
+                       (const unsigned long long*)c->bc_off[1].p, (const unsigned long long*)c->bc_sum[1].p,
+                       (const unsigned long long*)c->bc_off[2].p, (const unsigned long long*)c->bc_sum[2].p,
+                       (uint8_t*)c->bc_out[0].p, (uint8_t*)c->bc_out[1].p, (uint8_t*)c->bc_out[2].p);
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
+int fqg_barcodes_output(fqg_ctx* c, int which, void* host_dst, uint64_t nbytes) {
+  if (!c || which < 0 || which > 2 || (!host_dst && nbytes)) return FQG_ERR_ARG;
+  if (nbytes > c->bc_out_bytes[which]) return fail(c, FQG_ERR_ARG, "fqg_barcodes_output: more than was produced");
+  if (!nbytes) return 0;
+  HIP_TRY(c, hipMemcpyAsync(host_dst, c->bc_out[which].p, nbytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -1,0 +1,473 @@
+// fastq_pre_barcodes - drop-in for the reference program of the same name
+// (reference src/fastq_pre_barcodes.c): same options, same stderr / stdout text, same output bytes.
+//
+//   host   option parsing, (gz) reading of up to five inputs into pinned pieces, lock-step
+//          bookkeeping across pieces, gzip / stdout writing of what the GPU produced
+//   GPU    framing of every input, read-name agreement, barcode extraction with the quality
+//          filter, header tagging, slicing, and the assembly of the output text (FASTQ or SAM)
+// There is no CPU path for the per-read work.
+#include <getopt.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "fq_input.h"
+
+using namespace fqhost;
+
+namespace {
+
+fqg_ctx* g_ctx = nullptr;
+[[noreturn]] void die_lib(const char* what, int rc) {
+  FQ_PRINT_ERROR("GPU library failure in %s (%d): %s", what, rc, g_ctx ? fqg_last_error(g_ctx) : "no context");
+  exit(kExitSys);
+}
+#define LIB(call)                        \
+  do {                                   \
+    int rc__ = (call);                   \
+    if (rc__ != 0) die_lib(#call, rc__); \
+  } while (0)
+#define FQ_PRINT_INFO(...)        \
+  do {                            \
+    fprintf(stderr, "INFO:");     \
+    fprintf(stderr, __VA_ARGS__); \
+    fprintf(stderr, "\n");        \
+  } while (0)
+
+size_t piece_bytes() {
+  const char* e = getenv("FQGPU_CHUNK_MB");
+  size_t mb = e ? strtoull(e, nullptr, 10) : 512;
+  if (mb < 1) mb = 1;
+  return mb << 20;
+}
+
+enum { READ1 = 1, READ2 = 2, INDEX1 = 3, INDEX2 = 4, INDEX3 = 5 };
+
+int read_index2read_idx(const char* s) {  // src/fastq_pre_barcodes.c:79-89
+  if (!strcmp(s, "read1")) return READ1;
+  if (!strcmp(s, "read2")) return READ2;
+  if (!strcmp(s, "index1")) return INDEX1;
+  if (!strcmp(s, "index2")) return INDEX2;
+  if (!strcmp(s, "index3")) return INDEX3;
+  FQ_PRINT_ERROR("invalid file reference %s (valid values are read1,read2, index1,index2,index3)\n", s);
+  exit(1);
+}
+
+void print_usage() {  // src/fastq_pre_barcodes.c:311-346
+  const char msg[] =
+      "  --verbose    :increase level of messages printed to stderr\n"
+      "  --brief      :decrease level of messages printed to stderr\n"
+      "  --help       :print the usage\n"
+      "  --read1 <filename> :fastq (optional gzipped) file name \n"
+      "  --read2 <filename> :fastq (optional gzipped) file name \n"
+      "  --index1 <filename> :fastq (optional gzipped) file name \n"
+      "  --index2 <filename> :fastq (optional gzipped) file name \n"
+      "  --index3 <filename> :fastq (optional gzipped) file name \n"
+      "  --phred_encoding (33|64) :phred encoding used in the input files\n"
+      "  --min_qual [0-40]        :defines the minimum quality that all bases in the UMI, CELL or Sample should "
+      "have (reads that do not pass the criteria are discarded). 0 disables the filter. \n"
+      "  --outfile1 <filename>    :file name for ouputing the reads from file1\n"
+      "  --outfile2 <filename>    :file name for ouputing the reads from file2\n"
+      "  --outfile3 <filename>    :file name for ouputing the reads from file3\n"
+      "  --interleaved (read1|read2|index1|index2|index3),(read1|read2|index1|index2|index3)    :interleaved data\n"
+      "  --umi_read (read1|read2|index1|index2|index3)       :in which input file can the UMI be found\n"
+      "  --umi_offset integer     :offset \n"
+      "  --umi_size               :number of bases after the offset\n"
+      "  --cell_read (read1|read2|index1|index2|index3)      :in which input file can the cell be found\n"
+      "  --cell_offset integer    :offset \n"
+      "  --cell_size integer      :number of bases after the offset\n"
+      "  --sample_read (read1|read2|index1|index2|index3)    :in which input file can the sample barcode be found\n"
+      "  --sample_offset integer  :offset \n"
+      "  --sample_size integer    :number of bases after the offset\n"
+      "  --read1_offset integer   :\n"
+      "  --read1_size integer     :\n"
+      "  --read2_offset integer   :\n"
+      "  --read2_size integer     :\n"
+      "  --10x     : use 10X UMI tags (UB and UY) instead of the default tags defined in the SAM specification\n";
+  fprintf(stderr, "usage: fastq_pre_barcodes --read1 fastq_file --outfile1 out_file [optional parameters]\n");
+  fprintf(stderr, "%s\n", msg);
+}
+
+// one input: pieces, frames, and where the next iteration reads
+struct Source {
+  const char* path = nullptr;
+  Input* in = nullptr;
+  fqg_frame* frame = nullptr;
+  fqg_file_state st{};
+  bool probed = false;
+  std::string format_line;
+  uint64_t avail = 0;       // complete records in the current frame
+  long use = 0;             // local index of the record the next iteration uses (may exceed avail)
+  uint64_t records_before = 0;  // records in earlier frames
+  bool final_piece = false;
+  int tail_lines = 0;
+  bool exhausted = false;   // no more data will come
+  bool carry_pending = false;
+  size_t carry_at = 0;      // bytes of the current piece covered by complete records
+};
+
+void probe(Source& s) {
+  if (s.probed || s.in->size() == 0) return;
+  s.st.is_pe = 1;
+  if (fqg_probe_first_record(s.in->data(), s.in->size(), 1, &s.st) != 0) return;
+  s.probed = true;
+  if (s.st.readname_format == FQG_NAME_CASAVA18) s.format_line = "CASAVA=1.8\n";
+  else if (s.st.readname_format == FQG_NAME_INTEGER) {
+    // INTEGERNAME and NOP share a value; the text differs (src/fastq.c:465-474)
+    const char* b = s.in->data();
+    const char* nl = static_cast<const char*>(memchr(b, '\n', s.in->size()));
+    std::string h(b + 1, nl ? (size_t)(nl - b) : s.in->size() - 1);
+    const std::string name = h.c_str();
+    size_t i = 0;
+    while (i < name.size() && name[i] >= '0' && name[i] <= '9') ++i;
+    const std::string rest = name.substr(i);
+    const bool all_digits = i > 0 && (rest.empty() || rest == "\n" || rest == "\r");
+    s.format_line = all_digits ? "Read name provided as an integer\n" : "Read name provided with no suffix\n";
+  }
+}
+
+// frame the next piece of `s`; false when the input is used up
+bool refill(Source& s) {
+  if (s.frame) {
+    fqg_frame_release(s.frame);
+    s.frame = nullptr;
+    s.records_before += s.avail;
+    s.use -= (long)s.avail;
+    s.avail = 0;
+  }
+  if (s.exhausted) return false;
+  if (s.carry_pending) {  // only now: the piece's bytes stay readable for messages until it is replaced
+    s.in->carry_from(s.carry_at);
+    s.carry_pending = false;
+  }
+  if (!s.in->next()) {
+    s.exhausted = true;
+    return false;
+  }
+  probe(s);
+  fqg_validate_result r;
+  LIB(fqg_validate(g_ctx, nullptr, s.in->data(), s.in->size(), FQG_MEM_HOST, s.in->final() ? 1 : 0, &s.st,
+                   FQG_VALIDATE_FRAME_ONLY, &r));
+  s.final_piece = s.in->final();
+  s.tail_lines = r.tail_lines;
+  s.avail = r.n_records;
+  if (r.n_records) LIB(fqg_frame_retain(g_ctx, &s.frame));
+  if (!s.in->final()) {
+    s.carry_pending = true;
+    s.carry_at = r.consumed;
+  } else s.exhausted = true;
+  return r.n_records > 0 || !s.exhausted;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  static int verbose = 0, paired = 0, help = 0, out_sam = 0, tenx = 0;
+  fqg_barcode_params P;
+  memset(&P, 0, sizeof(P));
+  const char* file[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const char* outfile[3] = {nullptr, nullptr, nullptr};
+  P.phred_encoding = 64;
+  P.umi_read = P.cell_read = P.sample_read = -1;
+  P.umi_offset = P.cell_offset = P.sample_offset = -1;
+  P.read_offset[1] = P.read_offset[2] = -1;
+  int num_input_files = 0;
+  bool has_interleaved = false;
+  opterr = 0;
+  fprintf(stderr, "fastq_utils %s\n", "0.25.3");
+
+  static struct option long_options[] = {{"verbose", no_argument, &verbose, 1},
+                                         {"brief", no_argument, &verbose, 0},
+                                         {"paired_end", no_argument, &paired, 1},
+                                         {"single_end", no_argument, &paired, 0},
+                                         {"sam", no_argument, &out_sam, 1},
+                                         {"fastq", no_argument, &out_sam, 0},
+                                         {"help", no_argument, &help, 1},
+                                         {"umi_read", required_argument, 0, 'a'},
+                                         {"umi_offset", required_argument, 0, 'b'},
+                                         {"umi_size", required_argument, 0, 'c'},
+                                         {"read1_offset", required_argument, 0, 'd'},
+                                         {"read1_size", required_argument, 0, 'e'},
+                                         {"read2_offset", required_argument, 0, 'f'},
+                                         {"read2_size", required_argument, 0, 'g'},
+                                         {"min_qual", required_argument, 0, 'h'},
+                                         {"cell_read", required_argument, 0, 'i'},
+                                         {"cell_offset", required_argument, 0, 'j'},
+                                         {"cell_size", required_argument, 0, 'k'},
+                                         {"read1", required_argument, 0, 'l'},
+                                         {"read2", required_argument, 0, 'm'},
+                                         {"index1", required_argument, 0, 't'},
+                                         {"index2", required_argument, 0, 'v'},
+                                         {"index3", required_argument, 0, 'u'},
+                                         {"outfile1", required_argument, 0, 'n'},
+                                         {"outfile2", required_argument, 0, 'o'},
+                                         {"interleaved", required_argument, 0, 'z'},
+                                         {"sample_read", required_argument, 0, 'p'},
+                                         {"sample_offset", required_argument, 0, 'q'},
+                                         {"sample_size", required_argument, 0, 'r'},
+                                         {"phred_encoding", required_argument, 0, 's'},
+                                         {"10x", no_argument, &tenx, 1},
+                                         {0, 0, 0, 0}};
+  auto set_input = [&](const char* name, int idx) {
+    if (name && !file[idx]) num_input_files++;
+    file[idx] = name;
+  };
+  for (;;) {
+    int option_index = 0;
+    const int c = getopt_long(argc, argv, "a:b:c:d:e:f:g:h:i:j:k:l:m:n:o:p:q:r:s:t:u:z:X", long_options, &option_index);
+    if (c == -1) break;
+    switch (c) {
+      case 'X': tenx = 1; break;
+      case 'z': {
+        char tmps[1025];
+        strncpy(tmps, optarg, 1024);
+        tmps[1024] = 0;
+        int xx = 0;
+        char* token = strtok(tmps, ",");
+        int refs[3] = {0, 0, 0};
+        while (token != nullptr) {
+          refs[xx] = read_index2read_idx(token);
+          token = xx == 2 ? nullptr : strtok(nullptr, ",");
+          ++xx;
+        }
+        if (xx != 2) {
+          FQ_PRINT_ERROR("two file references should be passed to --interleaved");
+          exit(1);
+        }
+        P.interleaved[0] = refs[0];
+        P.interleaved[1] = refs[1];
+        has_interleaved = true;
+        break;
+      }
+      case 'a': P.umi_read = read_index2read_idx(optarg); break;
+      case 'b': P.umi_offset = atol(optarg); break;
+      case 'c': P.umi_size = atol(optarg); break;
+      case 'd': P.read_offset[READ1] = atol(optarg); break;
+      case 'e': P.read_size[READ1] = atol(optarg); break;
+      case 'f': P.read_offset[READ2] = atol(optarg); break;
+      case 'g': P.read_size[READ2] = atol(optarg); break;
+      case 'h': P.min_qual = atoi(optarg); break;
+      case 'i': P.cell_read = read_index2read_idx(optarg); break;
+      case 'j': P.cell_offset = atol(optarg); break;
+      case 'k': P.cell_size = atol(optarg); break;
+      case 'l': set_input(optarg, READ1); break;
+      case 'm': set_input(optarg, READ2); break;
+      case 't': set_input(optarg, INDEX1); break;
+      case 'v': set_input(optarg, INDEX2); break;
+      case 'u': set_input(optarg, INDEX3); break;
+      case 'n': outfile[READ1] = optarg; break;
+      case 'o': outfile[READ2] = optarg; break;
+      case 'p': P.sample_read = read_index2read_idx(optarg); break;
+      case 'q': P.sample_offset = atol(optarg); break;
+      case 'r': P.sample_size = atol(optarg); break;
+      case 's': P.phred_encoding = atoi(optarg); break;
+      default: break;
+    }
+  }
+  if (help) {
+    print_usage();
+    exit(0);
+  }
+  FQ_PRINT_INFO("Validating options...");
+  if (!file[READ1]) {  // validate_options, src/fastq_pre_barcodes.c:91-107
+    FQ_PRINT_ERROR("missing input file (-read1)");
+    exit(1);
+  }
+  if (paired && !file[READ2]) {
+    FQ_PRINT_ERROR("if paired_end is used then two fastq files should be provided - missing input file (-read2)");
+    exit(kExitParams);
+  }
+  if (!outfile[READ1]) {
+    FQ_PRINT_ERROR("if single_end then -outfile1 should be provided");
+    exit(kExitParams);
+  }
+  FQ_PRINT_INFO("Options OK.");
+  FQ_PRINT_INFO("input files %d", num_input_files);
+
+  const char* dev = getenv("FQGPU_DEVICE");
+  int rc = fqg_open(dev ? atoi(dev) : 0, &g_ctx);
+  if (rc != 0) {
+    FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
+    exit(kExitSys);
+  }
+  P.out_sam = out_sam;
+  P.tenx = tenx;
+  Source src[6];
+  for (int x = READ1; x <= INDEX3; ++x)
+    if (file[x]) {
+      P.present[x] = 1;
+      src[x].path = file[x];
+      src[x].in = new Input(g_ctx, file[x], piece_bytes());
+    }
+  if (has_interleaved && (!file[P.interleaved[0]] || !file[P.interleaved[1]])) {
+    FQ_PRINT_ERROR("--interleaved refers to an input that was not given");
+    exit(kExitParams);
+  }
+  gzFile outgz[3] = {nullptr, nullptr, nullptr};
+  if (!out_sam) {
+    for (int x = READ1; x <= READ2; ++x)
+      if (outfile[x]) {
+        if (!file[x]) {
+          FQ_PRINT_ERROR("--outfile%d needs --read%d", x, x);
+          exit(kExitParams);
+        }
+        P.emit[x] = 1;
+        outgz[x] = (outfile[x][0] == '-' && outfile[x][1] == 0) ? gzdopen(fileno(stdout), "wb") : gzopen(outfile[x], "w4");
+        if (!outgz[x]) {
+          FQ_PRINT_ERROR("Unable to open %s", outfile[x]);
+          exit(kExitParams);
+        }
+        gzbuffer(outgz[x], 1 << 20);
+      }
+  } else {
+    printf("@HD\tVN:1.0 SO:unknown\n");
+    printf("@PG\tID:1 PN:fastq_pre_barcodes CL:%s", argv[0]);
+    for (int c = 1; c < argc - 1; c++) printf(" %s", argv[c]);  // (the reference drops the last word)
+    printf("\n");
+  }
+
+  unsigned long processed = 0, discarded = 0;
+  bool first_batch = true;
+  std::vector<char> hostbuf;
+  auto step_of = [&](int x) { return (has_interleaved && (x == P.interleaved[0] || x == P.interleaved[1])) ? 2L : 1L; };
+  for (int x = READ1; x <= INDEX3; ++x)
+    if (file[x]) src[x].use = (has_interleaved && x == P.interleaved[1]) ? 1 : 0;
+
+  for (;;) {
+    // every input needs a frame that holds the record its next iteration uses
+    bool out_of_data = false;
+    for (int x = READ1; x <= INDEX3 && !out_of_data; ++x)
+      if (file[x]) {
+        Source& s = src[x];
+        while (!s.frame || s.use >= (long)s.avail) {
+          if (!refill(s) && !s.frame) {
+            out_of_data = true;
+            break;
+          }
+          if (s.frame && s.use < (long)s.avail) break;
+          if (s.exhausted && (!s.frame || s.use >= (long)s.avail)) {
+            out_of_data = true;
+            break;
+          }
+        }
+      }
+    if (out_of_data) break;
+    uint64_t n = ~0ull;
+    for (int x = READ1; x <= INDEX3; ++x)
+      if (file[x]) {
+        const Source& s = src[x];
+        const uint64_t left = s.avail - (uint64_t)s.use;
+        const long st = step_of(x);
+        n = std::min<uint64_t>(n, (left + st - 1) / st);
+      }
+    if (n == 0 || n == ~0ull) break;
+    const fqg_frame* frames[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fqg_file_state states[6];
+    uint64_t first[6] = {0, 0, 0, 0, 0, 0};
+    memset(states, 0, sizeof(states));
+    fqg_barcode_params Pb = P;
+    for (int x = READ1; x <= INDEX3; ++x)
+      if (file[x]) {
+        frames[x] = src[x].frame;
+        states[x] = src[x].st;
+        // the library adds +1 for the second interleaved reference itself
+        first[x] = (uint64_t)src[x].use - ((has_interleaved && x == P.interleaved[1]) ? 1 : 0);
+      }
+    fqg_barcode_result r;
+    LIB(fqg_barcodes_transform(g_ctx, frames, states, first, &Pb, n, processed, &r));
+    if (first_batch && num_input_files > 1) {
+      // format lines of the first fastq_get_readname call per file, in file order (src/fastq.c:459-485)
+      for (int x = READ1; x <= INDEX3; ++x)
+        if (file[x]) {
+          if (r.code == FQG_E_WRONG_HEADER && r.iteration == 0 && r.file == x) break;
+          fputs(src[x].format_line.c_str(), stderr);
+          if (src[x].st.space == FQG_SPACE_COLOUR) fputs("Color space\n", stderr);
+        }
+    }
+    first_batch = false;
+    for (uint64_t w = 0; w < r.n_short; ++w) fputs("Warning: Read too short - barcode not found\n", stderr);
+    // hand the text to stdout / gzip
+    for (int which = 0; which < 3; ++which)
+      if (r.out_bytes[which]) {
+        if (hostbuf.size() < r.out_bytes[which]) hostbuf.resize(r.out_bytes[which]);
+        LIB(fqg_barcodes_output(g_ctx, which, hostbuf.data(), r.out_bytes[which]));
+        if (which == 0) fwrite(hostbuf.data(), 1, r.out_bytes[0], stdout);
+        else {
+          size_t off = 0;
+          while (off < r.out_bytes[which]) {
+            const unsigned chunk = (unsigned)std::min<uint64_t>(r.out_bytes[which] - off, 1u << 30);
+            if (gzwrite(outgz[which], hostbuf.data() + off, chunk) <= 0) {
+              int en = 0;
+              FQ_PRINT_ERROR("%s.\n", gzerror(outgz[which], &en));
+              exit(kExitSys);
+            }
+            off += chunk;
+          }
+        }
+      }
+    const unsigned long before = processed;
+    processed += r.n_done;
+    discarded += r.n_discarded;
+    for (unsigned long c = (before / 100000 + 1) * 100000; c <= processed; c += 100000) {
+      fprintf(stderr, "\b\b\b\b\b\b\b\b\b\b\b\b\b\b\b%lu", c * (has_interleaved ? 2 : 1));
+      fflush(stderr);
+    }
+    if (r.code != FQG_OK) {
+      if (r.code == FQG_E_WRONG_HEADER) {
+        // src/fastq.c:448-451, with the file's own line counter
+        Source& s = src[r.file];
+        const uint64_t rec = s.records_before + (uint64_t)s.use + r.n_done * step_of(r.file);
+        const char* b = s.in->data();
+        // the header text: first line of that record in the current piece
+        const char* p = b;
+        const char* end = b + s.in->size();
+        const uint64_t local = (uint64_t)s.use + r.n_done * step_of(r.file);
+        for (uint64_t line = 0; p < end && line < 4 * local; ++line) {
+          const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+          p = nl ? nl + 1 : end;
+        }
+        const char* nl = p < end ? static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))) : nullptr;
+        const std::string hdr(p, nl ? nl + 1 : end);
+        const uint64_t reads_of_file = rec + 1;  // records this file has handed out so far
+        FQ_PRINT_ERROR("Error in file %s: line %lu: wrong header %s", s.path, (unsigned long)(4 * reads_of_file),
+                       hdr.c_str());
+        exit(kExitFormat);
+      }
+      FQ_PRINT_ERROR("Readnames do not match across files (read #%ld)", (long)(processed + 1));
+      exit(kExitFormat);
+    }
+    const bool ended_on_discard = has_interleaved && r.n_done < n;
+    for (int x = READ1; x <= INDEX3; ++x)
+      if (file[x]) {
+        src[x].use += (long)r.n_done * step_of(x);
+        if (ended_on_discard && x == P.interleaved[0]) src[x].use -= 1;  // no re-synchronising read after a discard
+      }
+  }
+  // an incomplete record where the next read would have happened is a truncated file
+  // (src/fastq.c:254-257); a clean end of any input just ends the loop
+  for (int x = READ1; x <= INDEX3; ++x)
+    if (file[x]) {
+      Source& s = src[x];
+      const bool drained = s.exhausted && (!s.frame || s.use >= (long)s.avail);
+      if (!drained) continue;
+      if (s.tail_lines > 0 && (!s.frame || s.use == (long)s.avail ||
+                               (has_interleaved && x == P.interleaved[1] && s.use == (long)s.avail + 1))) {
+        FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", s.path,
+                       (unsigned long)(4 * (s.records_before + s.avail)));
+        exit(1);
+      }
+      break;
+    }
+  FQ_PRINT_INFO("Reads processed: %ld", (long)processed);
+  FQ_PRINT_INFO("Reads discarded: %ld", (long)discarded);
+  if (!out_sam)
+    for (int x = READ1; x <= READ2; ++x)
+      if (outgz[x] && gzclose(outgz[x]) != Z_OK) {
+        FQ_PRINT_ERROR("unable to close file descriptor");
+        exit(kExitSys);
+      }
+  fflush(stdout);
+  exit(0);
+}

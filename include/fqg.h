@@ -135,6 +135,8 @@ typedef struct {
 #define FQG_VALIDATE_DEFAULT 0u
 #define FQG_VALIDATE_FORCE_EXACT 1u /* always use the wave-per-record kernel */
 #define FQG_VALIDATE_NO_STATS 2u    /* do not touch acc (acc may be NULL) */
+#define FQG_VALIDATE_FRAME_ONLY 8u  /* build the line index only: no checks, no statistics (inputs that the
+                                       caller vouches for, src/fastq_pre_barcodes.c:541-543) */
 #define FQG_VALIDATE_COUNT_TWICE 4u /* every record counts twice in acc: the index loop runs
                                        fastq_new_entry_stats in both fastq_read_next_entry and
                                        fastq_validate_entry (src/fastq.c:415,432) */
@@ -199,6 +201,43 @@ int fqg_index_match_delete(fqg_ctx *ctx, fqg_index *index, const fqg_file_state 
  * otherwise record k of a against record k of b (src/fastq_info.c:133-138, FQG_E_NAME_MISMATCH). */
 int fqg_names_compare(fqg_ctx *ctx, const fqg_frame *a, const fqg_file_state *state_a, const fqg_frame *b,
                       const fqg_file_state *state_b, fqg_index_result *out);
+
+/* ---- barcode extraction (fastq_pre_barcodes) ----------------------------------------------
+ * Replaces the body of the main loop of fastq_pre_barcodes (src/fastq_pre_barcodes.c:594-727):
+ * for iteration k, record first_record[x] + k*step (+1) of every input x must carry the same
+ * read name (src/fastq_pre_barcodes.c:606-635); UMI / cell / sample are cut out (get_barcode,
+ * :218-259) - a read too short or with a base below min_qual is discarded -; kept reads are written
+ * with the tags in the read name (add_tags2readname :192-216, slice_read :160-190) as FASTQ text, or
+ * as SAM lines (:657-710).  Inputs are retained frames; index 1..5 = read1, read2, index1..3 as in
+ * the reference's READ_IDX.  The two references of --interleaved advance two records per iteration. */
+typedef struct {
+  int32_t present[6];
+  int32_t interleaved[2];      /* {0,0}: none; else the two file references of --interleaved */
+  int32_t umi_read, cell_read, sample_read; /* 1..5, -1 = not set */
+  int32_t phred_encoding, min_qual;
+  int32_t out_sam, tenx;       /* --sam, --10x */
+  int32_t emit[3];             /* FASTQ mode: outfile1 / outfile2 wanted */
+  int64_t umi_offset, umi_size, cell_offset, cell_size, sample_offset, sample_size; /* offset -1 = not set */
+  int64_t read_offset[3], read_size[3];
+} fqg_barcode_params;
+
+typedef struct {
+  uint64_t n_done;        /* iterations consumed: all of them, or up to a finding, or (interleaved input)
+                             up to and including the first discarded read, after which the reference's
+                             file pointers are out of step (src/fastq_pre_barcodes.c:653 vs :722) */
+  uint64_t n_discarded;   /* among the n_done */
+  uint64_t n_short;       /* of those, "Warning: Read too short - barcode not found" cases */
+  uint64_t out_bytes[3];  /* [0] SAM text, [1] / [2] FASTQ text of outfile1 / outfile2 */
+  uint64_t iteration;     /* finding: iteration (== n_done) */
+  int32_t code;           /* FQG_OK, FQG_E_NAME_MISMATCH, FQG_E_WRONG_HEADER */
+  int32_t file;           /* finding: which input (1..5) */
+} fqg_barcode_result;
+
+int fqg_barcodes_transform(fqg_ctx *ctx, const fqg_frame *const frames[6], const fqg_file_state states[6],
+                           const uint64_t first_record[6], const fqg_barcode_params *params,
+                           uint64_t n_iterations, uint64_t first_read_number, fqg_barcode_result *out);
+/* copy output `which` (0 SAM, 1, 2) of the last transform to host memory */
+int fqg_barcodes_output(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
 
 /* ---- measurement ------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */

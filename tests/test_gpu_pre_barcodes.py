@@ -1,0 +1,113 @@
+"""GPU parity for fastq_pre_barcodes: bin/fastq_pre_barcodes (C++ host + HIP kernels) against
+the golden invocations captured from the reference binary, and against the reference binary itself
+(oracle/_ref) / the Python oracle on seeded 10x-style inputs."""
+import gzip
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import pre_barcodes_oracle as pbo
+from tests.util import GOLD, REPO, read_image, strip_progress
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(REPO, "bin", "fastq_pre_barcodes")
+REF = os.path.join(REPO, "oracle", "_ref", "fastq_pre_barcodes")
+GOLDEN = json.load(open(os.path.join(GOLD, "pre_barcodes.json")))
+
+
+def run(binary, args, cwd, env=None):
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    p = subprocess.run(["fastq_pre_barcodes"] + args, executable=binary, cwd=cwd, capture_output=True, timeout=600, env=e)
+    return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1")
+
+
+def gunzip_file(path):
+    if not os.path.exists(path):
+        return None
+    raw = open(path, "rb").read()
+    return gzip.decompress(raw).decode("latin-1") if raw else ""
+
+
+@pytest.mark.parametrize("case", GOLDEN, ids=[str(i) + ":" + " ".join(c["args"])[:60] for i, c in enumerate(GOLDEN)])
+def test_golden_invocations(case):
+    with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+        rel = os.path.relpath(tmp, GOLD)
+        args = [a.replace("OUT1", rel + "/o1.fastq.gz").replace("OUT2", rel + "/o2.fastq.gz") for a in case["args"]]
+        rc, out, err = run(BIN, args, GOLD)
+        out, err = out.replace(rel + "/", "SCRATCH/"), err.replace(rel + "/", "SCRATCH/")
+        assert rc == case["exit"], err
+        assert out == case["stdout"]
+        assert strip_progress(err) == strip_progress(case["stderr"])
+        if case["exit"] == 0:
+            for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
+                if tag in case["files"]:
+                    assert gunzip_file(os.path.join(tmp, fn)) == case["files"][tag]
+
+
+def make_10x(rng, n, umi_q_low=0.05, short=0.01):
+    """R1 = 16 bp cell + 10 bp UMI, R2 = 40..150 bp cDNA; same names before the blank."""
+    bases = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    r1, r2 = [], []
+    for i in range(n):
+        name = b"SYN:1:FC:%d:%d:%d:%d" % (i % 8 + 1, i % 97, i % 1013, i)
+        l1 = 26 if rng.random() > short else int(rng.integers(5, 26))
+        s1 = bases[rng.integers(0, 4, l1)].tobytes()
+        q1 = (rng.integers(12, 41, l1) + 33).astype(np.uint8)
+        if rng.random() < umi_q_low and l1:
+            q1[int(rng.integers(0, l1))] = 33 + int(rng.integers(0, 10))
+        l2 = int(rng.integers(40, 151))
+        s2 = bases[rng.integers(0, 5, l2)].tobytes()
+        q2 = (rng.integers(2, 41, l2) + 33).astype(np.uint8).tobytes()
+        r1.append(b"@" + name + b" 1:N:0:ACGT\n" + s1 + b"\n+\n" + q1.tobytes() + b"\n")
+        r2.append(b"@" + name + b" 2:N:0:ACGT\n" + s2 + b"\n+\n" + q2 + b"\n")
+    return b"".join(r1), b"".join(r2)
+
+
+V2 = ["--read1", "r2.fastq", "--index1", "r1.fastq", "--umi_read", "index1", "--umi_offset", "16", "--umi_size", "10",
+      "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16", "--phred_encoding", "33", "--min_qual", "10"]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
+@pytest.mark.parametrize("extra", [["--outfile1", "o.fastq.gz"], ["--sam", "--outfile1", "-"], ["--sam", "--10x", "--outfile1", "-"],
+                                   ["--outfile1", "o.fastq.gz", "--read1_offset", "3", "--read1_size", "50"]])
+def test_10x_v2_against_reference_binary(extra):
+    rng = np.random.default_rng(len(extra) * 7 + 1)
+    r1, r2 = make_10x(rng, 20000)
+    with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+        res = []
+        for d, binary, env in ((a, REF, None), (b, BIN, {"FQGPU_CHUNK_MB": "1"})):
+            for name, img in (("r1.fastq", r1), ("r2.fastq", r2)):
+                with open(os.path.join(d, name), "wb") as f:
+                    f.write(img)
+            rc, out, err = run(binary, V2 + extra, d, env)
+            res.append((rc, out, strip_progress(err), gunzip_file(os.path.join(d, "o.fastq.gz"))))
+        assert res[0][0] == res[1][0] == 0
+        assert res[0][1] == res[1][1]
+        assert res[0][2] == res[1][2]
+        assert res[0][3] == res[1][3]
+
+
+def test_name_mismatch_and_oracle_agreement():
+    rng = np.random.default_rng(3)
+    r1, r2 = make_10x(rng, 3000, 0.0, 0.0)
+    lines = r2.split(b"\n")
+    lines[4 * 1234] = lines[4 * 1234].replace(b"SYN:", b"SYX:")
+    r2bad = b"\n".join(lines)
+    with tempfile.TemporaryDirectory() as d:
+        files = {"r1.fastq": r1, "r2.fastq": r2bad}
+        for name, img in files.items():
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img)
+        args = V2 + ["--sam", "--outfile1", "-"]
+        rc, out, err = run(BIN, args, d)
+        want = pbo.run_pre_barcodes(args, lambda n: files[n])
+        assert rc == want["exit"] == 3
+        assert "Readnames do not match across files (read #1235)" in err
+        assert out == want["stdout"]
+        assert strip_progress(err) == strip_progress(want["stderr"])
