@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libfqgpu.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE, VALIDATE_FRAME_ONLY = 0, 1, 2, 4, 8
+VALIDATE_TWO_PASS = 16
 NAME_DEFAULT, NAME_CASAVA18, NAME_INTEGER, NAME_UNDEF = 0, 1, 2, -1
 SPACE_SEQ, SPACE_COLOUR, SPACE_UNDEF = 0, 1, -1
 

@@ -11,6 +11,7 @@
 
 #include "fqg_device.h"
 #include "fqg_kernels.hip"
+#include "fqg_stream_kernels.hip"
 #include "fqg_index_kernels.hip"
 #include "fqg_barcode_kernels.hip"
 
@@ -45,6 +46,7 @@ struct fqg_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   int cu_count = 256;
+  uint64_t stream_min = 1ull << 20;  // images at least this large take the single-pass framing path (FQGPU_STREAM_MIN)
 
   DevBuf image;       // staging for host images
   DevBuf tile_counts; // u32 per tile
@@ -54,6 +56,10 @@ struct fqg_ctx {
   DevBuf records;     // fqg_record staging for fqg_frame_records
   DevBuf suspect;     // 1 bit per record: the fast path could not vouch for it
   DevBuf list;        // u64 record indices queued for the exact validator
+  DevBuf stage;       // streaming path: u16 staged newline entries, kStageCap per chunk
+  DevBuf cinfo;       // streaming path: u32 info word per chunk
+  DevBuf queue;       // streaming path: u64 suspect byte positions
+  DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
   CallState* d_cs = nullptr;
   CallState* h_cs = nullptr;  // pinned
   uint64_t* h_scalar = nullptr;  // pinned, 8 x u64
@@ -208,6 +214,7 @@ int fqg_open(int device_ordinal, fqg_ctx** out) {
     return FQG_ERR_HIP;
   }
   c->stream = c->own_stream;
+  if (const char* e = getenv("FQGPU_STREAM_MIN")) c->stream_min = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
   if (hipMalloc((void**)&c->d_bcall, sizeof(BcCall) + 64) != hipSuccess ||
       hipHostMalloc((void**)&c->h_bcall, sizeof(BcCall) + 64, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void**)&c->d_icall, sizeof(IndexCall)) != hipSuccess ||
@@ -236,6 +243,10 @@ void fqg_close(fqg_ctx* c) {
   release(c->records);
   release(c->suspect);
   release(c->list);
+  release(c->stage);
+  release(c->cinfo);
+  release(c->queue);
+  release(c->redo);
   release(c->bc_status);
   for (int i = 0; i < 3; ++i) {
     release(c->bc_len[i]);
@@ -475,6 +486,7 @@ void init_call_state(fqg_ctx* c) {
   init.first_key = ~0ull;
   init.stop_record = ~0ull;
   init.qmin_byte = 255;
+  init.boot_qmin = 255;
   *c->h_cs = init;
 }
 
@@ -516,12 +528,96 @@ int frame_two_pass(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n
   if (checks)
     hipLaunchKernelGGL(k_frame_fast_t<0u>, dim3(grid), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
                        (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
-                       (uint64_t*)c->line_end.p, line_cap, 4 * (usable / 4), sm, c->d_cs);
+                       (uint64_t*)c->line_end.p, line_cap, 4 * (usable / 4), sm, c->d_cs, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr);
   else
     hipLaunchKernelGGL(k_frame_fast_t<7u>, dim3(grid), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
                        (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
-                       (uint64_t*)c->line_end.p, line_cap, (uint64_t)0, sm, c->d_cs);
+                       (uint64_t*)c->line_end.p, line_cap, (uint64_t)0, sm, c->d_cs, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr);
   out->checks_done = checks;
+  return 0;
+}
+
+
+constexpr uint32_t kStreamBootBytes = 64u << 10;   // prefix whose quality range seeds the range test
+constexpr uint64_t kStreamQueueCap = 1ull << 20;
+
+// One pass over the image (see fqg_stream_kernels.hip).  Returns 1 when the image is not eligible
+// (NUL / CR bytes, bytes >= 0x80, more newlines per chunk than the staging area holds): the caller
+// then runs frame_two_pass, which also decides about the exact path.
+int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_chunks, bool final, SuspectMap sm,
+                 Framed* out) {
+  int rc;
+  const uint32_t n_spans = (n_chunks + kScanSpan - 1) / kScanSpan;
+  if ((rc = ensure(c, c->tile_counts, (size_t)n_chunks * 4))) return rc;
+  if ((rc = ensure(c, c->tile_local, (size_t)n_chunks * 4))) return rc;
+  if ((rc = ensure(c, c->span_sums, (size_t)n_spans * 8))) return rc;
+  if ((rc = ensure(c, c->cinfo, (size_t)n_chunks * 4))) return rc;
+  if ((rc = ensure(c, c->redo, (size_t)n_chunks * 4))) return rc;
+  if ((rc = ensure(c, c->stage, (size_t)n_chunks * kStageCap * 2))) return rc;
+  if ((rc = ensure(c, c->queue, (size_t)kStreamQueueCap * 8))) return rc;
+  init_call_state(c);
+  HIP_TRY(c, hipMemcpyAsync(c->d_cs, c->h_cs, sizeof(CallState), hipMemcpyHostToDevice, c->stream));
+  StreamOut so;
+  so.counts = (uint32_t*)c->tile_counts.p;
+  so.cinfo = (uint32_t*)c->cinfo.p;
+  so.stage = (uint16_t*)c->stage.p;
+  so.queue = (unsigned long long*)c->queue.p;
+  so.queue_cap = kStreamQueueCap;
+  {
+    ProfScope ps(c, "k_stream_boot");
+    const uint32_t span = (uint32_t)std::min<uint64_t>(kStreamBootBytes, nbytes & ~255ull);
+    hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBlock), 0, c->stream, d_img, span, c->d_cs);
+  }
+  {
+    ProfScope ps(c, "k_stream_pass1");
+    hipLaunchKernelGGL(k_stream_pass1<0u>, dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
+                       so, c->d_cs);
+  }
+  {
+    ProfScope ps(c, "k_scan");
+    hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
+                       n_chunks, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p);
+    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
+                       n_spans, d_img, nbytes, c->d_cs);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->h_cs->flags & (kFlagNul | kFlagCr | kFlagHigh | kFlagStageOverflow)) return 1;
+  out->n_newlines = c->h_cs->n_newlines;
+  out->last_nl = c->h_cs->last_byte_is_nl != 0;
+  out->img_flags = 0;
+  const uint64_t n_lines_all = out->n_newlines + (out->last_nl ? 0 : 1);
+  const uint64_t usable = (final || out->last_nl) ? n_lines_all : out->n_newlines;
+  const uint64_t line_cap = n_lines_all + 17;
+  const uint64_t limit = 4 * (usable / 4);
+  if ((rc = ensure(c, c->line_end, (size_t)line_cap * 8))) return rc;
+  {
+    ProfScope ps(c, "k_stream_pass2");
+    const unsigned per_wg = (kBlock / kWave) * kP2Batch;
+    hipLaunchKernelGGL(k_stream_pass2, dim3((n_chunks + per_wg - 1) / per_wg), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
+                       (const uint32_t*)c->tile_counts.p, (const uint32_t*)c->cinfo.p, (const uint16_t*)c->stage.p,
+                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
+                       (uint64_t*)c->line_end.p, line_cap, limit, sm, (uint32_t*)c->redo.p, c->d_cs);
+  }
+  {
+    ProfScope ps(c, "k_stream_queue");
+    hipLaunchKernelGGL(k_stream_queue, dim3(64), dim3(kBlock), 0, c->stream, (const unsigned long long*)c->queue.p,
+                       (unsigned long long)kStreamQueueCap, (const uint64_t*)c->line_end.p, n_lines_all, limit / 4, sm,
+                       c->d_cs);
+  }
+  {
+    // chunks whose speculated line type was wrong or missing: the two-pass kernel repeats the checks
+    // with the true rank (no line-index stores)
+    ProfScope ps(c, "k_stream_redo");
+    const unsigned grid = (unsigned)std::min<uint64_t>((n_chunks + 3) / 4, (uint64_t)c->cu_count * 8);
+    hipLaunchKernelGGL(k_frame_fast_t<8u>, dim3(grid), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
+                       (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
+                       (uint64_t*)c->line_end.p, line_cap, limit, sm, c->d_cs, (const uint32_t*)c->redo.p,
+                       (const uint32_t*)&c->d_cs->redo_count);
+  }
+  out->checks_done = true;
   return 0;
 }
 
@@ -570,7 +666,14 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   }
 
   Framed fr;
-  if ((rc = frame_two_pass(c, d_img, nbytes, n_chunks, final != 0, want_checks, sm, &fr))) return rc;
+  bool streamed = false;
+  if (want_checks && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS)) {
+    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, &fr);
+    if (rc < 0) return rc;
+    streamed = rc == 0;
+    if (!streamed) HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(sm.cap / 32 + 2) * 4, c->stream));
+  }
+  if (!streamed && (rc = frame_two_pass(c, d_img, nbytes, n_chunks, final != 0, want_checks, sm, &fr))) return rc;
   const uint64_t n_newlines = fr.n_newlines;
   const bool last_nl = fr.last_nl;
   const uint32_t img_flags = fr.img_flags;
@@ -623,7 +726,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   const bool fast = fr.checks_done;
   uint64_t list_cap = 0;
   if (fast) {
-    out->path = 2;
+    out->path = streamed ? 3 : 2;
     if (n_records) {
       list_cap = std::max<uint64_t>(1u << 20, n_records / 16);
       if (list_cap > n_records) list_cap = n_records;
@@ -664,7 +767,8 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   out->consumed = n_records ? c->h_scalar[1] + 1 : 0;
   if (out->consumed > nbytes) out->consumed = nbytes;  // unterminated last line
 
-  if (fast && n_records && (c->h_cs->list_count > list_cap || (c->h_cs->flags & kFlagSuspectOverflow))) {
+  if (fast && n_records &&
+      (c->h_cs->list_count > list_cap || (c->h_cs->flags & (kFlagSuspectOverflow | kFlagQueueOverflow)))) {
     // more suspects than the queue / bitmap holds (e.g. every record carries its name on line 3):
     // let the exact validator look at every record; the statistics of the tiled pass stand
     ProfScope ps(c, "k_validate_exact");

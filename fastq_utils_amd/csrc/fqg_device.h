@@ -18,7 +18,19 @@ constexpr uint64_t kNoRecord = ~0ull;
 // image-level flags raised by the framing pass
 constexpr uint32_t kFlagNul = 1u;       // a NUL byte somewhere in the image
 constexpr uint32_t kFlagCr = 2u;        // a '\r' somewhere in the image
+constexpr uint32_t kFlagHigh = 8u;      // a byte >= 0x80 (streaming pass: its SWAR tests need 7-bit bytes)
 constexpr uint32_t kFlagSuspectOverflow = 16u;  // a suspect record lies beyond the bitmap
+constexpr uint32_t kFlagStageOverflow = 32u;    // a chunk with more newlines than the staging area holds
+constexpr uint32_t kFlagQueueOverflow = 64u;    // more suspect positions than the queue holds
+
+// streaming (single-pass) framing: per 4 KiB chunk, newline offsets are staged as 16-bit entries
+constexpr int kStageCap = 256;  // entries per chunk; denser images take the two-pass path
+// staged entry: bits 0..11 offset of the '\n' inside the chunk; 12..13 class of the byte after it
+// (1 = '@', 2 = '+', 0 = other); bit 14: the byte after that one is a '\n'
+constexpr uint32_t kClsAt = 1u, kClsPlus = 2u;
+// chunk info word: bits 0..1 speculated line type of the chunk's first byte; bit 2: no speculation
+// (the chunk must be re-checked once its true rank is known); bit 3: qmin/qmax valid (bits 8..15, 16..23)
+constexpr uint32_t kInfoUnknown = 4u, kInfoRange = 8u;
 
 // Scalars of one fqg_validate() call.  Lives in device memory; the host copies it back once.
 struct CallState {
@@ -30,6 +42,10 @@ struct CallState {
   unsigned int flags;
   unsigned int last_byte_is_nl;
   unsigned int qmin_byte, qmax_byte;  // quality range seen by the tiled pass (255 / 0 when none)
+  unsigned long long queue_count;     // streaming pass: suspect byte positions queued
+  unsigned int redo_count;            // streaming pass: chunks whose checks must be repeated
+  unsigned int boot_qmin, boot_qmax;  // streaming pass: quality range of the image's first records
+  unsigned int pad0;
 };
 
 // Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).

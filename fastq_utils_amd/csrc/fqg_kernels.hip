@@ -579,6 +579,20 @@ struct QRange {
   uint32_t mn_e, mn_o, mx_e, mx_o;  // packed u16 pairs: even / odd bytes
 };
 
+// exact min / max over the bytes of a 16-byte piece selected by the 16-bit mask qm
+__device__ __forceinline__ void qrange_accum(const uint4& v, uint32_t qm, QRange& q) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t bm = nibble_to_bytes(qm >> (4 * k));
+    const uint32_t lo = w[k] | ~bm, hi = w[k] & bm;
+    q.mn_e = pk_min_u16(q.mn_e, __builtin_amdgcn_perm(0u, lo, 0x0C020C00u));
+    q.mn_o = pk_min_u16(q.mn_o, __builtin_amdgcn_perm(0u, lo, 0x0C030C01u));
+    q.mx_e = pk_max_u16(q.mx_e, __builtin_amdgcn_perm(0u, hi, 0x0C020C00u));
+    q.mx_o = pk_max_u16(q.mx_o, __builtin_amdgcn_perm(0u, hi, 0x0C030C01u));
+  }
+}
+
 // The SWAR checks on one 16-byte piece whose bytes, two look-ahead bytes and lines all exist.
 // ABL is an ablation mask for tools/kbench (product code instantiates 0).
 template <uint32_t ABL>
@@ -636,20 +650,7 @@ __device__ __forceinline__ void piece_fast(const uint4& v, uint32_t nl, uint64_t
       mark_suspect(suspect, (line0 + __popc(nl & ((1u << j) - 1u)) + 1) >> 2);
     }
   }
-  if (!(ABL & 1u)) {
-    // quality range: bytes of 4th lines, newline excluded
-    const uint32_t qm = M3 & ~nl;
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t bm = nibble_to_bytes(qm >> (4 * k));
-      const uint32_t lo = w[k] | ~bm, hi = w[k] & bm;
-      q.mn_e = pk_min_u16(q.mn_e, __builtin_amdgcn_perm(0u, lo, 0x0C020C00u));
-      q.mn_o = pk_min_u16(q.mn_o, __builtin_amdgcn_perm(0u, lo, 0x0C030C01u));
-      q.mx_e = pk_max_u16(q.mx_e, __builtin_amdgcn_perm(0u, hi, 0x0C020C00u));
-      q.mx_o = pk_max_u16(q.mx_o, __builtin_amdgcn_perm(0u, hi, 0x0C030C01u));
-    }
-  }
+  if (!(ABL & 1u)) qrange_accum(v, M3 & ~nl, q);  // quality range: bytes of 4th lines, newline excluded
 }
 
 // Work decomposition: ONE WAVEFRONT owns a contiguous 4 KiB chunk per step and walks it as 4
@@ -665,11 +666,15 @@ __global__ __launch_bounds__(kBlock) void k_frame_fast_t(const uint8_t* __restri
                                                          const unsigned long long* __restrict__ span_excl,
                                                          uint64_t* __restrict__ line_end, uint64_t line_cap,
                                                          uint64_t limit, SuspectMap suspect,
-                                                         CallState* __restrict__ cs) {
+                                                         CallState* __restrict__ cs,
+                                                         const uint32_t* __restrict__ todo,
+                                                         const uint32_t* __restrict__ todo_count) {
   static_assert(kSlices == 4, "packed scans below assume 4 slices per chunk");
   const int lane = lane_id();
   const uint32_t n_waves = gridDim.x * (kBlock / kWave);
   const uint32_t wave0 = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  // todo != null: only the listed chunks (the streaming path's redo list), in any order
+  const uint32_t n_items = todo ? *todo_count : n_chunks;
   QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
   uint32_t gq_min = 255, gq_max = 0;  // from the generic tail path
   uint4 vn[kSlices];
@@ -682,8 +687,9 @@ __global__ __launch_bounds__(kBlock) void k_frame_fast_t(const uint8_t* __restri
       if (off + 16 <= n) dst[k] = *reinterpret_cast<const uint4*>(img + off);
     }
   };
-  if (wave0 < n_chunks) load_chunk(wave0, vn);
-  for (uint32_t chunk = wave0; chunk < n_chunks; chunk += n_waves) {
+  if (wave0 < n_items) load_chunk(todo ? todo[wave0] : wave0, vn);
+  for (uint32_t item = wave0; item < n_items; item += n_waves) {
+    const uint32_t chunk = todo ? todo[item] : item;
     const uint64_t rank0 = span_excl[chunk / kScanSpan] + chunk_local[chunk];
     const uint64_t cbase = (uint64_t)chunk * kChunkBytes;
     const uint64_t wbase = cbase + (uint64_t)lane * 16;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_fast_t(const uint8_t* __restri
     uint32_t nl[kSlices];
 #pragma unroll
     for (int k = 0; k < kSlices; ++k) v[k] = vn[k];
-    if (chunk + n_waves < n_chunks) load_chunk(chunk + n_waves, vn);
+    if (item + n_waves < n_items) load_chunk(todo ? todo[item + n_waves] : item + n_waves, vn);
 #pragma unroll
     for (int k = 0; k < kSlices; ++k) {
       const uint64_t off = wbase + (uint64_t)k * (kWave * 16);
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_fast_t(const uint8_t* __restri
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl && cs->n_newlines < line_cap)
+  if (!(ABL & 8u) && blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !cs->last_byte_is_nl && cs->n_newlines < line_cap)
     line_end[cs->n_newlines] = n;
   if ((ABL & 7u) == 7u) return;
   // ---- fold the quality range: lanes -> wave -> device ----

@@ -1,0 +1,501 @@
+// fqg_stream_kernels.hip - single-pass ("streaming") framing + byte-class checks for gfx950.
+//
+// The two-pass path of fqg_kernels.hip reads the image twice: a newline census gives every 4 KiB
+// chunk its global line rank, then k_frame_fast_t uses the rank for the line index and for the
+// line type (index mod 4) that the byte-class checks depend on.  Here the image is read ONCE:
+//
+//   k_stream_boot   quality range of the first records (line types are known at the image start)
+//   k_stream_pass1  one wavefront per 4 KiB chunk, no dependence on any other chunk:
+//                     - newline mask, NUL / CR / high-byte detection (SWAR on bytes < 0x80, byte
+//                       marks compacted to bit masks with v_dot4_u32_u8)
+//                     - the line type of the chunk's first byte is SPECULATED from the first
+//                       one-character line of the chunk (in FASTQ that is the "+" line, type 2)
+//                     - with that type: bases outside ACGTN on sequence lines -> suspect byte
+//                       positions are queued; quality bytes are only tested against the boot
+//                       range, and a chunk with bytes outside it computes its exact min / max
+//                     - every '\n' is staged as a 16-bit entry (offset in chunk, class of the byte
+//                       after it, "the byte after that is '\n'") through a per-wave LDS table, so
+//                       that the global stores are contiguous
+//   k_scan_a/b      prefix over the per-chunk newline counts (fqg_kernels.hip)
+//   k_stream_pass2  one wavefront per chunk, now with the true rank: staged entries -> line_end[],
+//                   header-start checks ('@', not empty; "+\n") by line type, verification of the
+//                   speculation (a wrong or missing one sends the chunk to the redo list, where
+//                   k_frame_fast_t repeats the checks with the true type), quality range merge
+//   k_stream_queue  queued suspect positions -> record bits (binary search in line_end[])
+//
+// Nothing here decides an error code: as in the two-pass path, records the checks cannot vouch for
+// are marked in the suspect bitmap and k_validate_exact alone decides.  Over-marking is harmless;
+// what must be exact are the line index, the quality range (hull of the boot range, of verified
+// per-chunk ranges and of redone chunks) and the image flags that force the two-pass / exact path.
+#include "fqg_device.h"
+
+namespace fqg {
+
+constexpr uint32_t kH = 0x80808080u;
+
+// four words of 0x80-per-byte marks -> 16-bit mask (bit i = byte i of the 16)
+__device__ __forceinline__ uint32_t pack_marks16(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3) {
+  uint32_t lo = __builtin_amdgcn_udot4(m0, 0x08040201u, 0u, false);
+  lo = __builtin_amdgcn_udot4(m1, 0x80402010u, lo, false);
+  uint32_t hi = __builtin_amdgcn_udot4(m2, 0x08040201u, 0u, false);
+  hi = __builtin_amdgcn_udot4(m3, 0x80402010u, hi, false);
+  return (lo >> 7) | (hi << 1);
+}
+
+// newline marks of a word whose bytes are all < 0x80; okacc keeps bit 7 of a byte only while
+// every byte seen there was a '\n' or >= 0x20
+__device__ __forceinline__ uint32_t nl_marks7(uint32_t w, uint32_t& okacc) {
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  const uint32_t t = kH - x;            // bit 7 of a byte: x == 0
+  const uint32_t y = x + 0x60606060u;   // bit 7 of a byte: x >= 0x20, i.e. the byte itself is >= 0x20
+  okacc &= (t | y);
+  return t & kH;
+}
+
+// 0x80 in every byte (< 0x80) that is not one of A C G T N
+__device__ __forceinline__ uint32_t not_acgtn7(uint32_t w) {
+  // byte table indexed by (c & 7): 7F 'A' 7F 'C' 'T' 7F 'N' 'G'; 0x7F never matches (its low bits are 7)
+  const uint32_t want = __builtin_amdgcn_perm(0x474E7F54u, 0x437F417Fu, w & 0x07070707u);
+  return ((w ^ want) + 0x7F7F7F7Fu) & kH;
+}
+
+// 0x80 in every byte (< 0x80) inside [lo, hi]; lob = lo * 0x01010101, hihb = (hi | 0x80) * 0x01010101
+__device__ __forceinline__ uint32_t in_range7(uint32_t w, uint32_t lob, uint32_t hihb) {
+  return ((w | kH) - lob) & (hihb - w) & kH;
+}
+
+// ------------------------------------------------------------------------------------------
+// quality range of the complete records inside the first `span` bytes (span: multiple of 256,
+// span <= image size).  One workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_stream_boot(const uint8_t* __restrict__ img, uint32_t span,
+                                                        CallState* __restrict__ cs) {
+  __shared__ uint32_t s_cnt[kBlock / kWave];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const uint32_t part = span / (kBlock / kWave);
+  const uint8_t* p = img + (uint64_t)wv * part;
+  uint32_t cnt = 0;
+  for (uint32_t o = lane; o < part; o += kWave) cnt += (p[o] == '\n');
+  cnt = wave_sum(cnt);
+  if (lane == 0) s_cnt[wv] = cnt;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    if (w < wv) before += s_cnt[w];
+    total += s_cnt[w];
+  }
+  const uint32_t limit = total & ~3u;
+  uint32_t line = before, qmin = 255, qmax = 0;
+  for (uint32_t o = 0; o < part; o += kWave) {
+    const uint32_t c = p[o + lane];
+    const uint64_t bal = __ballot(c == '\n');
+    const uint32_t mine = line + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if ((mine & 3u) == 3u && mine < limit && c != '\n') {
+      qmin = c < qmin ? c : qmin;
+      qmax = c > qmax ? c : qmax;
+    }
+    line += (uint32_t)__builtin_popcountll(bal);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
+    qmin = a < qmin ? a : qmin;
+    qmax = b > qmax ? b : qmax;
+  }
+  if (lane == 0 && qmin <= qmax) {
+    atomicMin(&cs->boot_qmin, qmin);
+    atomicMax(&cs->boot_qmax, qmax);
+    atomicMin(&cs->qmin_byte, qmin);
+    atomicMax(&cs->qmax_byte, qmax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 1
+// ------------------------------------------------------------------------------------------
+struct StreamOut {
+  uint32_t* counts;            // newlines per chunk
+  uint32_t* cinfo;             // chunk info word
+  uint16_t* stage;             // kStageCap entries per chunk
+  unsigned long long* queue;   // suspect byte positions
+  unsigned long long queue_cap;
+};
+
+__device__ __forceinline__ void queue_suspect(const StreamOut& o, CallState* cs, uint64_t pos) {
+  if (__hip_atomic_load(&cs->queue_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > o.queue_cap) return;
+  const unsigned long long at = atomicAdd(&cs->queue_count, 1ull);
+  if (at < o.queue_cap) o.queue[at] = pos;
+}
+
+// Work decomposition of pass 1: ONE WAVEFRONT per 4 KiB chunk, walked as kHalves = 2 slices of
+// 2 KiB; inside a slice every lane owns 32 CONTIGUOUS bytes (two 16-byte loads at a 32-byte lane
+// stride - measured as fast as the fully interleaved pattern), so that all per-lane masks are
+// 32 bits wide and the cross-lane work (scan, look-ahead) is paid once per 32 bytes.
+constexpr int kHalves = 2;
+constexpr int kLaneBytes = 32;
+constexpr int kHalfBytes = kWave * kLaneBytes;  // 2 KiB
+
+__device__ __forceinline__ uint32_t prefix_xor32(uint32_t x) {
+  x ^= x << 1;
+  x ^= x << 2;
+  x ^= x << 4;
+  x ^= x << 8;
+  x ^= x << 16;
+  return x;
+}
+
+// masks of the bytes on sequence (M1) and quality (M3) lines; t0 = type of the first byte
+__device__ __forceinline__ void type_masks32(uint32_t nl, uint32_t t0, uint32_t& M1, uint32_t& M3) {
+  const uint32_t e = nl << 1;
+  const uint32_t P = prefix_xor32(e);        // bit 0 of the running newline count
+  const uint32_t Q = prefix_xor32(e & ~P);   // bit 1 (carry when bit 0 wraps)
+  const uint32_t a0 = 0u - (t0 & 1u), a1 = 0u - ((t0 >> 1) & 1u);
+  const uint32_t L = P ^ a0;
+  const uint32_t Hh = Q ^ a1 ^ (P & a0);
+  M1 = ~Hh & L;
+  M3 = Hh & L;
+}
+
+struct Piece32 {
+  uint4 a, b;  // bytes 0..15, 16..31
+};
+
+// Staging of the newlines of one chunk, in two steps so that the fetch of the bytes that follow
+// the newlines is in flight while the byte-class checks run:
+//   stage_begin  every lane writes (offset | "second next byte is a newline") of its newlines to the
+//                wave's LDS table at their rank; lane i then picks entry i and starts the load of the
+//                byte after that newline
+//   stage_end    class of that byte -> entry; contiguous 2-byte stores
+struct StagePending {
+  uint32_t ent;  // entry of newline `lane` (valid if lane < tot)
+  uint32_t c1;   // the byte after it
+};
+
+template <uint32_t ABL>
+__device__ __forceinline__ StagePending stage_begin(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb,
+                                                    const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
+                                                    const uint32_t (&ex)[kHalves], uint32_t tot,
+                                                    uint16_t* __restrict__ slots, bool bounded) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < kHalves; ++k) {
+    uint32_t m = nl[k], r = ex[k];
+    const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
+    while (m) {
+      const uint32_t j = (uint32_t)__builtin_ctz(m);
+      m &= m - 1;
+      if (r < (uint32_t)kStageCap) slots[r] = (uint16_t)((at + j) | (((nl2[k] >> j) & 1u) << 14));
+      ++r;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  StagePending sp{0u, 0u};
+  if ((uint32_t)lane < tot) {
+    sp.ent = slots[lane];
+    const uint64_t p = cb + (sp.ent & 0xFFFu) + 1;
+    if (!(ABL & 4u)) sp.c1 = (!bounded || p < n) ? img[p] : 0u;
+  }
+  return sp;
+}
+
+__device__ __forceinline__ uint32_t stage_entry(uint32_t ent, uint32_t c1) {
+  return ent | ((c1 == '@' ? kClsAt : (c1 == '+' ? kClsPlus : 0u)) << 12);
+}
+
+template <uint32_t ABL>
+__device__ __forceinline__ void stage_end(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
+                                          const StagePending& sp, uint32_t tot, const uint16_t* __restrict__ slots,
+                                          uint16_t* __restrict__ stage, bool bounded) {
+  const int lane = lane_id();
+  uint16_t* dst = stage + (uint64_t)chunk * kStageCap;
+  if ((uint32_t)lane < tot) dst[lane] = (uint16_t)stage_entry(sp.ent, sp.c1);
+  for (uint32_t i = kWave + lane; i < tot; i += kWave) {  // more than 64 newlines in 4 KiB: rare
+    const uint32_t ent = slots[i];
+    const uint64_t p = cb + (ent & 0xFFFu) + 1;
+    uint32_t c1 = 0;
+    if (!(ABL & 4u)) c1 = (!bounded || p < n) ? img[p] : 0u;
+    dst[i] = (uint16_t)stage_entry(ent, c1);
+  }
+}
+
+// ABL: ablation mask for tools/kbench (product code instantiates 0): 1 = no byte-class checks,
+// 2 = no staging, 4 = no fetch of the byte after a newline, 8 = no base check, 16 = no quality test
+template <uint32_t ABL>
+__global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restrict__ img, uint64_t n,
+                                                         uint32_t n_chunks, StreamOut o,
+                                                         CallState* __restrict__ cs) {
+  static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
+  __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const uint32_t chunk = blockIdx.x * (kBlock / kWave) + wv;
+  if (chunk >= n_chunks) return;
+  const uint64_t cb = (uint64_t)chunk * kChunkBytes;
+  const uint64_t wb = cb + (uint64_t)lane * kLaneBytes;
+  const bool interior = cb + kChunkBytes + 4 <= n;
+  uint32_t nl[kHalves], ex[kHalves];
+  Piece32 v[kHalves];
+  uint32_t flags = 0;
+
+  uint32_t tail = 0;  // the 4 bytes after the chunk (look-ahead of the last lane)
+  const uint32_t boot_lo = cs->boot_qmin, boot_hi = cs->boot_qmax;
+  if (interior) {
+    tail = *reinterpret_cast<const uint32_t*>(img + cb + kChunkBytes);
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) {
+      v[k].a = *reinterpret_cast<const uint4*>(img + wb + (uint64_t)k * kHalfBytes);
+      v[k].b = *reinterpret_cast<const uint4*>(img + wb + (uint64_t)k * kHalfBytes + 16);
+    }
+    uint32_t okacc = kH, hiacc = 0;
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) {
+      hiacc |= v[k].a.x | v[k].a.y | v[k].a.z | v[k].a.w | v[k].b.x | v[k].b.y | v[k].b.z | v[k].b.w;
+      const uint32_t lo = pack_marks16(nl_marks7(v[k].a.x, okacc), nl_marks7(v[k].a.y, okacc),
+                                       nl_marks7(v[k].a.z, okacc), nl_marks7(v[k].a.w, okacc));
+      const uint32_t hi = pack_marks16(nl_marks7(v[k].b.x, okacc), nl_marks7(v[k].b.y, okacc),
+                                       nl_marks7(v[k].b.z, okacc), nl_marks7(v[k].b.w, okacc));
+      nl[k] = lo | (hi << 16);
+    }
+    const bool high = __ballot((hiacc & kH) != 0) != 0;
+    const bool ctrl = __ballot((okacc & kH) != kH) != 0;
+    if (high) flags |= kFlagHigh;  // (the masks above are meaningless then; the host drops this pass)
+    if (ctrl && !high) {
+      // rare: a control byte other than '\n'.  Only NUL and CR change what a line is (C strings,
+      // src/fastq.c:250,317); anything else (a tab in a header ...) is just a byte.
+      uint32_t nul = 0, cr = 0;
+#pragma unroll
+      for (int k = 0; k < kHalves; ++k) {
+        const uint32_t w[8] = {v[k].a.x, v[k].a.y, v[k].a.z, v[k].a.w, v[k].b.x, v[k].b.y, v[k].b.z, v[k].b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          nul |= eq_bytes(w[j], 0u);
+          cr |= eq_bytes(w[j], 0x0D0D0D0Du);
+        }
+      }
+      if (__ballot(nul != 0)) flags |= kFlagNul;
+      if (__ballot(cr != 0)) flags |= kFlagCr;
+    }
+  } else {
+    // the last one or two chunks: bytes may be missing, look-ahead may cross the end of the image
+    uint32_t bad = 0;
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) {
+      const uint64_t off = wb + (uint64_t)k * kHalfBytes;
+      nl[k] = 0;
+      v[k].a = v[k].b = make_uint4(0, 0, 0, 0);
+      for (uint64_t i = off; i < n && i < off + kLaneBytes; ++i) {
+        const uint32_t c = img[i];
+        if (c == '\n') nl[k] |= 1u << (i - off);
+        else if (c == 0u) bad |= kFlagNul;
+        else if (c == '\r') bad |= kFlagCr;
+        else if (c >= 0x80u) bad |= kFlagHigh;
+      }
+    }
+    if (__ballot((bad & kFlagNul) != 0)) flags |= kFlagNul;
+    if (__ballot((bad & kFlagCr) != 0)) flags |= kFlagCr;
+    if (__ballot((bad & kFlagHigh) != 0)) flags |= kFlagHigh;
+  }
+
+  // ranks of the newlines inside the chunk: one packed scan for both slices
+  const uint32_t c01 = __popc(nl[0]) | (__popc(nl[1]) << 16);
+  const uint32_t s01 = wave_scan_incl_dpp(c01);
+  const uint32_t t01 = __builtin_amdgcn_readlane(s01, 63);
+  const uint32_t total = (t01 & 0xFFFFu) + (t01 >> 16);
+  ex[0] = (s01 & 0xFFFFu) - (c01 & 0xFFFFu);
+  ex[1] = (t01 & 0xFFFFu) + (s01 >> 16) - (c01 >> 16);
+  if (total > (uint32_t)kStageCap) flags |= kFlagStageOverflow;
+
+  // newline bits of the bytes 1 and 2 further on (funnel shifts over {next lane, this lane})
+  uint32_t tail_nl = 0;
+  if (interior) {
+    tail_nl = ((tail & 0xFFu) == '\n' ? 1u : 0u) | (((tail >> 8) & 0xFFu) == '\n' ? 2u : 0u);
+  } else {
+    for (uint64_t i = 0; i < 2; ++i)
+      if (cb + kChunkBytes + i < n && img[cb + kChunkBytes + i] == '\n') tail_nl |= 1u << i;
+  }
+  uint32_t nl2[kHalves], cand[kHalves];
+#pragma unroll
+  for (int k = 0; k < kHalves; ++k) {
+    uint32_t nxt = dpp0<0x130, 0xf, 0xf>(nl[k]);  // lane i <- lane i+1
+    const uint32_t first_next = (uint32_t)__builtin_amdgcn_readlane(nl[k + 1 < kHalves ? k + 1 : k], 0);
+    if (lane == 63) nxt = k + 1 < kHalves ? first_next : tail_nl;
+    const uint32_t n1 = __builtin_amdgcn_alignbit(nxt, nl[k], 1);
+    nl2[k] = __builtin_amdgcn_alignbit(nxt, nl[k], 2);
+    cand[k] = nl[k] & nl2[k] & ~n1;  // a '\n' followed by exactly one byte and another '\n'
+  }
+
+  const uint32_t tot = total < (uint32_t)kStageCap ? total : (uint32_t)kStageCap;
+  StagePending sp{0u, 0u};
+  if (!(ABL & 2u)) sp = stage_begin<ABL>(img, n, cb, nl, nl2, ex, tot, s_slots[wv], !interior);
+
+  uint32_t info = kInfoUnknown;
+  if (!(ABL & 1u) && interior && !(flags & kFlagHigh)) {
+    // ---- speculation: the first line of exactly one byte is taken for a "+" line (type 2) ----
+    bool found = false;
+    uint32_t t0 = 0;
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) {
+      const uint64_t bal = __ballot(cand[k] != 0);
+      if (!found && bal) {
+        const int l = __builtin_ctzll(bal);
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane(cand[k], l);
+        const uint32_t nll = (uint32_t)__builtin_amdgcn_readlane(nl[k], l);
+        const uint32_t exl = (uint32_t)__builtin_amdgcn_readlane(ex[k], l);
+        const uint32_t j = (uint32_t)__builtin_ctz(cl);
+        const uint32_t a = exl + __popc(nll & ((1u << j) - 1u));  // rank in the chunk of the '\n' in front of the "+"
+        t0 = (1u - a) & 3u;  // the next '\n' (rank a + 1) ends a type-2 line
+        found = true;
+      }
+    }
+    if (found) {
+      info = t0;
+      uint32_t lo = boot_lo, hi = boot_hi;
+      if (lo > hi || lo > 127u) {
+        lo = 127u;
+        hi = 0u;
+      }
+      const uint32_t lob = lo * 0x01010101u, hihb = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
+      QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
+      bool any_viol = false;
+#pragma unroll
+      for (int k = 0; k < kHalves; ++k) {
+        uint32_t M1, M3;
+        type_masks32(nl[k], t0 + ex[k], M1, M3);
+        const uint4 &a = v[k].a, &b = v[k].b;
+        const uint32_t inv = pack_marks16(not_acgtn7(a.x), not_acgtn7(a.y), not_acgtn7(a.z), not_acgtn7(a.w)) |
+                             (pack_marks16(not_acgtn7(b.x), not_acgtn7(b.y), not_acgtn7(b.z), not_acgtn7(b.w)) << 16);
+        const uint32_t bad = (ABL & 8u) ? 0u : inv & M1 & ~nl[k];
+        if (bad) queue_suspect(o, cs, wb + (uint64_t)k * kHalfBytes + (uint32_t)__builtin_ctz(bad));
+        const uint32_t okq =
+            pack_marks16(in_range7(a.x, lob, hihb), in_range7(a.y, lob, hihb), in_range7(a.z, lob, hihb),
+                         in_range7(a.w, lob, hihb)) |
+            (pack_marks16(in_range7(b.x, lob, hihb), in_range7(b.y, lob, hihb), in_range7(b.z, lob, hihb),
+                          in_range7(b.w, lob, hihb)) << 16);
+        const uint32_t qm = (ABL & 16u) ? 0u : M3 & ~nl[k];
+        if (__ballot((qm & ~okq) != 0)) {  // rare: exact range of this slice's quality bytes
+          any_viol = true;
+          qrange_accum(a, qm & 0xFFFFu, q);
+          qrange_accum(b, qm >> 16, q);
+        }
+      }
+      if (any_viol) {
+        uint32_t qmin = pk_min_u16(q.mn_e, q.mn_o), qmax = pk_max_u16(q.mx_e, q.mx_o);
+        qmin = (qmin & 0xFFFFu) < (qmin >> 16) ? (qmin & 0xFFFFu) : (qmin >> 16);
+        qmax = (qmax & 0xFFFFu) > (qmax >> 16) ? (qmax & 0xFFFFu) : (qmax >> 16);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          const uint32_t x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
+          qmin = x < qmin ? x : qmin;
+          qmax = y > qmax ? y : qmax;
+        }
+        if (qmin <= qmax) info |= kInfoRange | ((qmin & 0xFFu) << 8) | ((qmax & 0xFFu) << 16);
+      }
+    }
+  }
+
+  if (!(ABL & 2u)) stage_end<ABL>(img, n, cb, chunk, sp, tot, s_slots[wv], o.stage, !interior);
+  if (lane == 0) {
+    o.counts[chunk] = total;
+    o.cinfo[chunk] = info;
+    if (flags) atomicOr(&cs->flags, flags);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2: staged entries -> line index, header-start checks, verification of the speculation
+// ------------------------------------------------------------------------------------------
+constexpr int kP2Batch = 8;  // chunks per wavefront (their loads are issued together)
+
+__global__ __launch_bounds__(kBlock) void k_stream_pass2(const uint8_t* __restrict__ img, uint64_t n,
+                                                         uint32_t n_chunks, const uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ cinfo,
+                                                         const uint16_t* __restrict__ stage,
+                                                         const uint32_t* __restrict__ chunk_local,
+                                                         const unsigned long long* __restrict__ span_excl,
+                                                         uint64_t* __restrict__ line_end, uint64_t line_cap,
+                                                         uint64_t limit, SuspectMap suspect,
+                                                         uint32_t* __restrict__ redo, CallState* __restrict__ cs) {
+  const int lane = lane_id();
+  const uint32_t c0 = (blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kP2Batch;
+  if (c0 >= n_chunks) return;
+  // lane b < kP2Batch holds the scalars of chunk c0 + b
+  uint32_t cnt = 0, info = 0;
+  uint64_t rank0 = 0;
+  const uint32_t mine = c0 + (uint32_t)lane;
+  if (lane < kP2Batch && mine < n_chunks) {
+    cnt = counts[mine];
+    info = cinfo[mine];
+    rank0 = span_excl[mine / kScanSpan] + chunk_local[mine];
+  }
+  uint32_t e[kP2Batch], tot[kP2Batch];
+  uint64_t r0[kP2Batch];
+#pragma unroll
+  for (int b = 0; b < kP2Batch; ++b) {
+    const uint32_t cb_cnt = (uint32_t)__builtin_amdgcn_readlane(cnt, b);
+    tot[b] = cb_cnt < (uint32_t)kStageCap ? cb_cnt : (uint32_t)kStageCap;
+    r0[b] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)rank0, b) |
+            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(rank0 >> 32), b) << 32);
+    e[b] = (uint32_t)lane < tot[b] ? stage[(uint64_t)(c0 + b) * kStageCap + lane] : 0u;
+  }
+  auto entry = [&](uint32_t chunk, uint64_t rank, uint32_t i, uint32_t ent) {
+    const uint64_t L = rank + i;
+    if (L < line_cap) line_end[L] = (uint64_t)chunk * kChunkBytes + (ent & 0xFFFu);
+    const uint64_t nx = L + 1;  // the line that starts after this '\n'
+    if (nx < limit) {
+      const uint32_t cls = (ent >> 12) & 3u, nl2 = (ent >> 14) & 1u;
+      const uint32_t t = (uint32_t)nx & 3u;
+      const bool bad = t == 0 ? !(cls == kClsAt && !nl2) : (t == 2 ? !(cls == kClsPlus && nl2) : false);
+      if (bad) mark_suspect(suspect, nx >> 2);
+    }
+  };
+#pragma unroll
+  for (int b = 0; b < kP2Batch; ++b) {
+    if ((uint32_t)lane < tot[b]) entry(c0 + b, r0[b], (uint32_t)lane, e[b]);
+    for (uint32_t i = kWave + lane; i < tot[b]; i += kWave)  // more than 64 newlines in 4 KiB: rare
+      entry(c0 + b, r0[b], i, stage[(uint64_t)(c0 + b) * kStageCap + i]);
+  }
+  if (lane < kP2Batch && mine < n_chunks) {
+    if (mine == 0 && limit > 0 && (img[0] != '@' || (n > 1 && img[1] == '\n'))) mark_suspect(suspect, 0);
+    // only chunks that hold bytes of complete records need their byte checks to stand
+    if (rank0 < limit) {
+      // (a chunk that reaches beyond the last complete record is repeated too: its quality range may
+      // include bytes of an incomplete record)
+      if ((info & kInfoUnknown) || (info & 3u) != ((uint32_t)rank0 & 3u) || rank0 + cnt >= limit) {
+        const uint32_t at = atomicAdd(&cs->redo_count, 1u);
+        if (at < n_chunks) redo[at] = mine;
+      } else if (info & kInfoRange) {
+        atomicMin(&cs->qmin_byte, (info >> 8) & 0xFFu);
+        atomicMax(&cs->qmax_byte, (info >> 16) & 0xFFu);
+      }
+    }
+    if (mine == n_chunks - 1 && n > 0 && !cs->last_byte_is_nl && cs->n_newlines < line_cap)
+      line_end[cs->n_newlines] = n;
+  }
+}
+
+// queued suspect byte positions -> records
+__global__ __launch_bounds__(kBlock) void k_stream_queue(const unsigned long long* __restrict__ queue,
+                                                         unsigned long long queue_cap,
+                                                         const uint64_t* __restrict__ line_end, uint64_t n_lines,
+                                                         uint64_t n_records, SuspectMap suspect,
+                                                         CallState* __restrict__ cs) {
+  unsigned long long cnt = cs->queue_count;
+  if (cnt > queue_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cs->flags, kFlagQueueOverflow);
+    cnt = queue_cap;
+  }
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += stride) {
+    const uint64_t pos = queue[i];
+    // first line whose end is >= pos
+    uint64_t lo = 0, hi = n_lines;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (line_end[mid] < pos) lo = mid + 1;
+      else hi = mid;
+    }
+    const uint64_t rec = lo >> 2;
+    if (rec < n_records) mark_suspect(suspect, rec);
+  }
+}
+
+}  // namespace fqg

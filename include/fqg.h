@@ -126,7 +126,8 @@ typedef struct {
   uint64_t aux1;      /*                qlen */
   int32_t code;       /* enum fqg_code; FQG_OK if every record passed */
   int32_t stopped;    /* 1: a record starting with a NUL byte ended the file early (src/fastq.c:250) */
-  int32_t path;       /* which device path ran: 1 = exact wave-per-record, 2 = tiled fast path */
+  int32_t path;       /* which device path ran: 1 = exact wave-per-record, 2 = tiled two-pass path,
+                         3 = single-pass (streaming) path */
   int32_t tail_lines; /* final images: lines (1..3) of an incomplete last record, whether or not an
                          earlier record already failed; 0 if the image ends at a record boundary */
 } fqg_validate_result;
@@ -137,6 +138,7 @@ typedef struct {
 #define FQG_VALIDATE_NO_STATS 2u    /* do not touch acc (acc may be NULL) */
 #define FQG_VALIDATE_FRAME_ONLY 8u  /* build the line index only: no checks, no statistics (inputs that the
                                        caller vouches for, src/fastq_pre_barcodes.c:541-543) */
+#define FQG_VALIDATE_TWO_PASS 16u    /* never take the single-pass (streaming) framing path */
 #define FQG_VALIDATE_COUNT_TWICE 4u /* every record counts twice in acc: the index loop runs
                                        fastq_new_entry_stats in both fastq_read_next_entry and
                                        fastq_validate_entry (src/fastq.c:415,432) */

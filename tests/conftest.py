@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+# PyTorch (used by a few GPU tests and by bench.py for device buffers) must be imported BEFORE
+# libfqgpu.so initialises the HIP runtime: registering the wheel's thousands of code objects with an
+# already running runtime takes minutes.  Collection happens before any test touches the GPU.
+try:  # pragma: no cover - plumbing
+    import torch  # noqa: F401
+except Exception:  # torch is optional for the CPU suite
+    torch = None

@@ -9,10 +9,25 @@
 #include <functional>
 #include "../../fastq_utils_amd/csrc/fqg_device.h"
 #include "../../fastq_utils_amd/csrc/fqg_kernels.hip"
+#include "../../fastq_utils_amd/csrc/fqg_stream_kernels.hip"
 #ifdef KBENCH_EXTRA
 #include KBENCH_EXTRA
 #endif
 using namespace fqg;
+// census with each lane reading 32 contiguous bytes (two 16-byte loads at a 32-byte lane stride)
+__global__ __launch_bounds__(kBlock) void k_count_nl_s32(const uint8_t* __restrict__ img, uint64_t n, uint32_t n_chunks, uint32_t* __restrict__ out) {
+  const uint32_t chunk = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (chunk >= n_chunks || (uint64_t)(chunk + 1) * kChunkBytes > n) return;
+  const uint8_t* p = img + (uint64_t)chunk * kChunkBytes + (threadIdx.x & 63) * 32;
+  uint32_t cnt = 0;
+  uint4 v[4];
+  v[0] = *reinterpret_cast<const uint4*>(p); v[1] = *reinterpret_cast<const uint4*>(p + 16);
+  v[2] = *reinterpret_cast<const uint4*>(p + 2048); v[3] = *reinterpret_cast<const uint4*>(p + 2048 + 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cnt += __popc(eq_bytes(v[k].x, 0x0A0A0A0Au)) + __popc(eq_bytes(v[k].y, 0x0A0A0A0Au)) + __popc(eq_bytes(v[k].z, 0x0A0A0A0Au)) + __popc(eq_bytes(v[k].w, 0x0A0A0A0Au));
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) out[chunk] = cnt;
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 static double time_ms(int reps, const std::function<void()>& f) {
@@ -48,14 +63,36 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   const unsigned grid_t = 256 * 8;
   SuspectMap sm{suspect, reads, &cs->flags};
-#define FF(ABL, label) report(label, time_ms(reps, [&] { hipLaunchKernelGGL(k_frame_fast_t<ABL>, dim3(grid_t), dim3(kBlock), 0, 0, img, n, n_tiles, local, spans, line_end, 4 * reads + 32, 4 * reads, sm, cs); }))
-  { CallState init{}; init.first_key = ~0ull; init.stop_record = ~0ull; init.qmin_byte = 255; init.n_newlines = 4 * reads; init.last_byte_is_nl = 1; CK(hipMemcpy(cs, &init, sizeof(init), hipMemcpyHostToDevice)); }
+#define FF(ABL, label) report(label, time_ms(reps, [&] { hipLaunchKernelGGL(k_frame_fast_t<ABL>, dim3(grid_t), dim3(kBlock), 0, 0, img, n, n_tiles, local, spans, line_end, 4 * reads + 32, 4 * reads, sm, cs, (const uint32_t*)nullptr, (const uint32_t*)nullptr); }))
+  { CallState init{}; init.first_key = ~0ull; init.stop_record = ~0ull; init.qmin_byte = 255; init.boot_qmin = 255; init.n_newlines = 4 * reads; init.last_byte_is_nl = 1; CK(hipMemcpy(cs, &init, sizeof(init), hipMemcpyHostToDevice)); }
   FF(0u, "k_frame_fast (full)");
   FF(1u, "  - no qual range");
   FF(2u, "  - no base check");
   FF(4u, "  - no line-start check");
   FF(8u, "  - no line_end stores");
   FF(7u, "  line index only (exact path)");
+  {
+    // streaming (single-pass) path
+    uint32_t *cinfo, *redo; uint16_t* stage; unsigned long long* queue;
+    CK(hipMalloc(&cinfo, n_tiles * 4ull)); CK(hipMalloc(&redo, n_tiles * 4ull)); CK(hipMalloc(&stage, (size_t)n_tiles * kStageCap * 2)); CK(hipMalloc(&queue, 8ull << 20));
+    StreamOut so{counts, cinfo, stage, queue, 1ull << 20};
+    report("k_stream_boot", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBlock), 0, 0, img, 65536u, cs); }));
+#define P1(ABL, label) report(label, time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_pass1<ABL>, dim3((n_tiles + 3) / 4), dim3(kBlock), 0, 0, img, n, n_tiles, so, cs); }))
+    P1(1u, "  pass1 - no checks");
+    P1(2u, "  pass1 - no staging");
+    P1(3u, "  pass1 - masks+scan only");
+    report("  census, 32B-stride loads", time_ms(reps, [&] { hipLaunchKernelGGL(k_count_nl_s32, dim3((n_tiles + 3) / 4), dim3(kBlock), 0, 0, img, n, n_tiles, cinfo); }));
+    P1(4u, "  pass1 - no next-byte fetch");
+    P1(8u, "  pass1 - no base check");
+    P1(16u, "  pass1 - no quality test");
+    P1(24u, "  pass1 - types only");
+    P1(0u, "k_stream_pass1");
+    hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, 0, counts, n_tiles, local, spans);
+    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, 0, spans, n_spans, img, n, cs);
+    report("k_stream_pass2", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_pass2, dim3((n_tiles + 31) / 32), dim3(kBlock), 0, 0, img, n, n_tiles, counts, cinfo, stage, local, spans, line_end, 4 * reads + 32, 4 * reads, sm, redo, cs); }));
+    CallState h; CK(hipMemcpy(&h, cs, sizeof(h), hipMemcpyDeviceToHost));
+    printf("stream: flags=%u queue=%llu redo=%u (of %u x %d launches) boot q=[%u,%u]\n", h.flags, h.queue_count, h.redo_count, n_tiles, reps + 1, h.boot_qmin, h.boot_qmax);
+  }
 #ifdef KBENCH_EXTRA
   kbench_extra(img, n, reads, n_tiles, counts, local, spans, line_end, suspect, acc, cs, hist, list, reps, report);
 #endif
