@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exact", action="store_true", help="use only the wave-per-record validator")
+    ap.add_argument("--two-pass", action="store_true", help="census + framing passes instead of the single-pass path")
     ap.add_argument("--no-index-extra", action="store_true",
                     help="skip the untimed extra: fastq_info default mode (validate + unique read-name index)")
     return ap.parse_args()
@@ -76,7 +77,7 @@ def committed_traffic(kernel, n_reads, read_len, record_bytes):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes, by
     tools/pmc_traffic.py).  Only valid for the exact workload it was measured on; otherwise None."""
-    path = os.path.join(REPO, "profiles", f"r01_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")
+    path = os.path.join(REPO, "profiles", f"r01c_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -84,7 +85,7 @@ def committed_traffic(kernel, n_reads, read_len, record_bytes):
     if int(t["image_bytes"]) != n_reads * record_bytes:
         return None, None
     for k, v in t["kernels"].items():
-        if k.split("<")[0] == {"k_frame_fast": "k_frame_fast_t"}.get(kernel, kernel):
+        if k.split("<")[0] == {"k_frame_fast": "k_frame_fast_t", "k_stream_redo": "k_frame_fast_t"}.get(kernel, kernel):
             return v["total"] / 1e9, os.path.relpath(path, REPO)
     return None, None
 
@@ -117,6 +118,8 @@ def main():
     st = fq.abi.probe_first_record(head, True)  # fastq_info -r sets is_pe (src/fastq_info.c:158)
     acc = ctx.accumulator()
     flags = fq.abi.VALIDATE_FORCE_EXACT if a.force_exact else 0
+    if a.two_pass:
+        flags |= fq.abi.VALIDATE_TWO_PASS
 
     def step():
         return ctx.validate(image.data_ptr(), acc, st, final=True, flags=flags, nbytes=n * R)

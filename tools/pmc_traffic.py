@@ -6,7 +6,7 @@ read stream.  The factor is checked here on k_count_nl, which reads every byte o
 exactly once with 16-byte-per-lane loads (calibration on a known byte count, as the guide asks).
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> \
-           <image_bytes> > profiles/rNN_traffic.json
+           <image_bytes> [<fetch csv of a run that contains k_count_nl>] > profiles/rNN_traffic.json
 """
 import collections
 import csv
@@ -26,7 +26,8 @@ def per_kernel(path, counter):
 def main():
     fetch, write, image_bytes = sys.argv[1], sys.argv[2], float(sys.argv[3])
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-    calib = image_bytes / (f["k_count_nl"] * 1024.0)
+    fc = per_kernel(sys.argv[4], "FETCH_SIZE") if len(sys.argv) > 4 else f
+    calib = image_bytes / (fc["k_count_nl"] * 1024.0)
     out = {"image_bytes": image_bytes, "fetch_correction_measured_on_k_count_nl": calib,
            "fetch_correction_applied": 2.0, "unit": "bytes per launch", "kernels": {}}
     for k in sorted(set(f) | set(w)):
