@@ -160,22 +160,26 @@ struct Piece32 {
   uint4 a, b;  // bytes 0..15, 16..31
 };
 
-// Staging of the newlines of one chunk, in two steps so that the fetch of the bytes that follow
-// the newlines is in flight while the byte-class checks run:
-//   stage_begin  every lane writes (offset | "second next byte is a newline") of its newlines to the
-//                wave's LDS table at their rank; lane i then picks entry i and starts the load of the
-//                byte after that newline
-//   stage_end    class of that byte -> entry; contiguous 2-byte stores
-struct StagePending {
-  uint32_t ent;  // entry of newline `lane` (valid if lane < tot)
-  uint32_t c1;   // the byte after it
-};
+// Staging of the newlines of one chunk.  Every lane writes (offset | "second next byte is a newline")
+// of its newlines to the wave's LDS table at their rank; lane i then takes entry i, adds the class
+// of the byte after that newline and stores the 16-bit entry (contiguous 2-byte stores).  The byte
+// after a newline comes from an LDS copy of the chunk (interior chunks; written with conflict-free
+// 16-byte stores: the low halves of all lanes of a slice first, then the high halves) - a gather
+// from global memory would miss the L2 often enough to cost 10 % more HBM reads.
+__device__ __forceinline__ uint32_t lds_chunk_addr(uint32_t o) {  // byte o of the chunk -> its place in the copy
+  return (o & 0x800u) | ((o & 0x10u) << 6) | ((o >> 1) & 0x3F0u) | (o & 0xFu);
+}
+
+__device__ __forceinline__ uint32_t stage_entry(uint32_t ent, uint32_t c1) {
+  return ent | ((c1 == '@' ? kClsAt : (c1 == '+' ? kClsPlus : 0u)) << 12);
+}
 
 template <uint32_t ABL>
-__device__ __forceinline__ StagePending stage_begin(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb,
-                                                    const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
-                                                    const uint32_t (&ex)[kHalves], uint32_t tot,
-                                                    uint16_t* __restrict__ slots, bool bounded) {
+__device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
+                                            const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
+                                            const uint32_t (&ex)[kHalves], uint32_t tot,
+                                            uint16_t* __restrict__ slots, const uint8_t* __restrict__ copy,
+                                            uint32_t tail, uint16_t* __restrict__ stage, bool interior) {
   const int lane = lane_id();
 #pragma unroll
   for (int k = 0; k < kHalves; ++k) {
@@ -189,31 +193,15 @@ __device__ __forceinline__ StagePending stage_begin(const uint8_t* __restrict__ 
     }
   }
   __builtin_amdgcn_wave_barrier();
-  StagePending sp{0u, 0u};
-  if ((uint32_t)lane < tot) {
-    sp.ent = slots[lane];
-    const uint64_t p = cb + (sp.ent & 0xFFFu) + 1;
-    if (!(ABL & 4u)) sp.c1 = (!bounded || p < n) ? img[p] : 0u;
-  }
-  return sp;
-}
-
-__device__ __forceinline__ uint32_t stage_entry(uint32_t ent, uint32_t c1) {
-  return ent | ((c1 == '@' ? kClsAt : (c1 == '+' ? kClsPlus : 0u)) << 12);
-}
-
-template <uint32_t ABL>
-__device__ __forceinline__ void stage_end(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
-                                          const StagePending& sp, uint32_t tot, const uint16_t* __restrict__ slots,
-                                          uint16_t* __restrict__ stage, bool bounded) {
-  const int lane = lane_id();
   uint16_t* dst = stage + (uint64_t)chunk * kStageCap;
-  if ((uint32_t)lane < tot) dst[lane] = (uint16_t)stage_entry(sp.ent, sp.c1);
-  for (uint32_t i = kWave + lane; i < tot; i += kWave) {  // more than 64 newlines in 4 KiB: rare
+  for (uint32_t i = lane; i < tot; i += kWave) {
     const uint32_t ent = slots[i];
-    const uint64_t p = cb + (ent & 0xFFFu) + 1;
+    const uint32_t o = (ent & 0xFFFu) + 1;  // the byte after the '\n'
     uint32_t c1 = 0;
-    if (!(ABL & 4u)) c1 = (!bounded || p < n) ? img[p] : 0u;
+    if (!(ABL & 4u)) {
+      if (interior) c1 = o < (uint32_t)kChunkBytes ? (uint32_t)copy[lds_chunk_addr(o)] : (tail & 0xFFu);
+      else c1 = cb + o < n ? (uint32_t)img[cb + o] : 0u;
+    }
     dst[i] = (uint16_t)stage_entry(ent, c1);
   }
 }
@@ -226,6 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
                                                          CallState* __restrict__ cs) {
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
   __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
+  __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][kChunkBytes];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const uint32_t chunk = blockIdx.x * (kBlock / kWave) + wv;
   if (chunk >= n_chunks) return;
@@ -244,6 +233,13 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     for (int k = 0; k < kHalves; ++k) {
       v[k].a = *reinterpret_cast<const uint4*>(img + wb + (uint64_t)k * kHalfBytes);
       v[k].b = *reinterpret_cast<const uint4*>(img + wb + (uint64_t)k * kHalfBytes + 16);
+    }
+    if (!(ABL & 6u)) {
+#pragma unroll
+      for (int k = 0; k < kHalves; ++k) {
+        *reinterpret_cast<uint4*>(&s_copy[wv][k * kHalfBytes + lane * 16]) = v[k].a;
+        *reinterpret_cast<uint4*>(&s_copy[wv][k * kHalfBytes + kHalfBytes / 2 + lane * 16]) = v[k].b;
+      }
     }
     uint32_t okacc = kH, hiacc = 0;
 #pragma unroll
@@ -324,8 +320,6 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
   }
 
   const uint32_t tot = total < (uint32_t)kStageCap ? total : (uint32_t)kStageCap;
-  StagePending sp{0u, 0u};
-  if (!(ABL & 2u)) sp = stage_begin<ABL>(img, n, cb, nl, nl2, ex, tot, s_slots[wv], !interior);
 
   uint32_t info = kInfoUnknown;
   if (!(ABL & 1u) && interior && !(flags & kFlagHigh)) {
@@ -392,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     }
   }
 
-  if (!(ABL & 2u)) stage_end<ABL>(img, n, cb, chunk, sp, tot, s_slots[wv], o.stage, !interior);
+  if (!(ABL & 2u)) stage_chunk<ABL>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], s_copy[wv], tail, o.stage, interior);
   if (lane == 0) {
     o.counts[chunk] = total;
     o.cinfo[chunk] = info;
