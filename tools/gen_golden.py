@@ -198,9 +198,165 @@ def gen_pre_barcodes():
     print("fastq_pre_barcodes invocations:", len(out), "by exit status:", by)
 
 
+UMI_BIN = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
+UMI_DATA = os.path.join(GOLD, "data_umi")
+
+
+def umi_synthetic_bams():
+    """Seeded BAMs from tests/bamgen.py (committed under tests/golden/data_umi/ so that the GPU box
+    needs no generator run): name -> bytes"""
+    import numpy as np
+
+    sys.path.insert(0, REPO)
+    from tests import bamgen
+
+    out = {}
+    rng = np.random.default_rng(20251002)
+    # fresh_umis: UMI ids only grow, the regime in which the reference's RL_Tree is a set (DESIGN.md)
+    out["syn_plain.bam"] = bamgen.tagged_bam(rng, n_cells=30, genes=60, fresh_umis=True)[0]
+    out["syn_nh.bam"] = bamgen.tagged_bam(rng, n_cells=20, genes=50, nh=True, fresh_umis=True)[0]
+    out["syn_multi.bam"] = bamgen.tagged_bam(rng, n_cells=20, genes=50, nh=True, multi_gx=True, noise=True,
+                                             fresh_umis=True)[0]
+    out["syn_few_umis.bam"] = bamgen.tagged_bam(rng, n_cells=25, genes=300, reads_per_cell=(1, 6), noise=True,
+                                                fresh_umis=True)[0]
+    # UMIs re-used across cells and genes, as in real data: the reference's RL_Tree loses / invents
+    # members here (test_oracle_umi.py::test_reference_rl_tree_defect)
+    out["syn_reuse.bam"] = bamgen.tagged_bam(rng, n_cells=30, genes=60)[0]
+    # the smallest input that shows it: one cell; 40 UMIs on gene A (ids 1..40); gene B sees UMI 40,
+    # UMI 20, UMI 40 again.  A set holds {20, 40} for B; the reference counts 3 (inserting 20 drops 40:
+    # shift_right() in src/range_list.c:287-301 moves nothing when one node follows the new one)
+    umis = []
+    while len(umis) < 40:
+        u = bamgen.barcode(rng, 10)
+        if u not in umis:
+            umis.append(u)
+    recs = [bamgen.record(b"a%d" % i, bamgen.aux_z(b"CR", b"ACGTACGTACGT") + bamgen.aux_z(b"GX", b"A") +
+                          bamgen.aux_z(b"RX", u)) for i, u in enumerate(umis)]
+    for i, k in enumerate((39, 19, 39)):
+        recs.append(bamgen.record(b"b%d" % i, bamgen.aux_z(b"CR", b"ACGTACGTACGT") + bamgen.aux_z(b"GX", b"B") +
+                                  bamgen.aux_z(b"RX", umis[k])))
+    out["rl_defect.bam"] = bamgen.bgzf(bamgen.header() + b"".join(recs))
+    out["syn_unsorted.bam"] = bamgen.tagged_bam(rng, n_cells=10, genes=30, sort_cells=False, nh=True)[0]
+    out["syn_long_gene.bam"] = bamgen.tagged_bam(rng, n_cells=3, genes=5, gene_prefix=b"ENSG0000000000000000000")[0]
+    return out
+
+
+def umi_jobs():
+    """argv lists for bam_umi_count; OUTU / OUTR stand for output files in a scratch directory.  The
+    first block follows the reference's own suite (run_tests.sh:96-177)."""
+    d = lambda n: "data_umi/" + n
+    ns = "--not_sorted_by_cell"
+    jobs = [
+        ["--min_reads", "1", "--bam", d("test_annot.bam"), "--ucounts", "OUTU", "-x", "TX", ns],
+        ["--min_reads", "1", "--bam", d("test_annot.bam"), "--ucounts", "OUTU", "-x", "GX", ns],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "-x", "TX", ns],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "-x", "GX", ns],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "-x", "TX", ns, "--10x"],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "-x", "GX", ns, "--10x"],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--multi_mapped", "--ucounts", "OUTU", ns],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "--ignore_sample", ns,
+         "--cell_suffix", "-123456789"],
+        [ns, "--min_reads", "1", "--bam", d("test_annot5.bam"), "--known_cells", d("known_cells.txt"), "--ucounts", "OUTU"],
+        ["--min_reads", "1"],
+        ["--bam", d("test_annot.bam")],
+        ["--bam", d("test_annot.bam"), "-x"],
+        ["--bam", d("test_annot.bam_missing")],
+        ["--bam", d("test_annot.bam_missing"), "--ucounts", "OUTU"],
+        ["--min_reads", "1", "--bam", d("test_annot.bam"), "--known_umi", d("known_umis.txt_missing"), "--ucounts", "OUTU"],
+        ["--min_reads", "1", "--bam", d("test_annot.bam"), "--known_cells", d("known_cells.txt_missing"), "--ucounts", "OUTU"],
+        ["--sorted_by_cell", "--min_reads", "1", "--bam", d("test_annot.bam"), "--known_cells",
+         d("known_cells.txt_missing"), "--ucounts", "OUTU"],
+        ["--min_reads", "1", "--bam", d("test_annot.bam"), "--known_umi", d("known_umis.txt"), ns, "--ucounts", "OUTU",
+         "--rcounts", "OUTR"],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--known_umi", d("known_umis.txt"), ns, "--ucounts", "OUTU"],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "-x", "TX", "--max_cells", "10",
+         "--max_feat", "2", "--feat_cell", "2", ns],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "--max_cells", "100", ns],
+        ["--min_reads", "4", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "--rcounts", "OUTR", ns],
+        ["--min_reads", "1", "--bam", d("test_annot5.bam"), "--ucounts", "OUTU", "--uniq_mapped", ns],
+        # default (sorted-by-cell) mode
+        ["--bam", d("test_one_cell.bam"), "--ucounts", "OUTU"],
+        ["--bam", d("test_one_cell.bam"), "--ucounts", "OUTU", "--rcounts", "OUTR", "--min_reads", "2"],
+        ["--bam", d("test_one_cell.bam"), "--ucounts", "OUTU", "--uniq_mapped", "--min_umis", "3"],
+        ["--bam", d("test_one_cell.bam"), "--ucounts", "OUTU", "-x", "TX", "--cell_suffix", "-1"],
+        ["--bam", d("test_annot5.bam"), "--ucounts", "OUTU"],
+        ["--bam", d("test_annot.bam"), "--ucounts", "OUTU"],
+        ["--help"],
+    ]
+    for name in ("syn_plain.bam", "syn_nh.bam", "syn_multi.bam", "syn_few_umis.bam", "syn_long_gene.bam"):
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU"])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", "--rcounts", "OUTR"])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", "--rcounts", "OUTR", "--min_reads", "2", "--min_umis", "2"])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", "--uniq_mapped"])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", "--10x", "-x", "TX"])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", ns, "--rcounts", "OUTR"])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", "--known_cells", d("syn_cells.txt")])
+        jobs.append(["--bam", d(name), "--ucounts", "OUTU", "--known_umi", d("known_umis.txt")])
+    jobs.append(["--bam", d("rl_defect.bam"), "--ucounts", "OUTU"])
+    jobs.append(["--bam", d("syn_reuse.bam"), "--ucounts", "OUTU", "--rcounts", "OUTR"])
+    jobs.append(["--bam", d("syn_reuse.bam"), "--ucounts", "OUTU", "--rcounts", "OUTR", ns])
+    jobs.append(["--bam", d("syn_unsorted.bam"), "--ucounts", "OUTU"])
+    jobs.append(["--bam", d("syn_unsorted.bam"), "--ucounts", "OUTU", ns])
+    jobs.append(["--bam", d("syn_unsorted.bam"), "--ucounts", "OUTU", ns, "--max_cells", "5"])
+    jobs.append(["--bam", d("syn_plain.bam"), "--ucounts", "OUTU", "--max_feat", "20"])
+    jobs.append(["--bam", d("syn_plain.bam"), "--ucounts", "OUTU", "-X", "RX"])
+    return jobs
+
+
+def gen_umi():
+    import tempfile
+
+    if not os.path.exists(UMI_BIN):
+        sys.exit("build the reference first: make -C oracle ref")
+    os.makedirs(UMI_DATA, exist_ok=True)
+    for n in ("test_annot.bam", "test_annot5.bam", "test_one_cell.bam", "known_cells.txt", "known_umis.txt"):
+        shutil.copyfile(os.path.join(REF, "tests", n), os.path.join(UMI_DATA, n))
+        os.chmod(os.path.join(UMI_DATA, n), 0o644)
+    syn = umi_synthetic_bams()
+    for n, b in syn.items():
+        with open(os.path.join(UMI_DATA, n), "wb") as f:
+            f.write(b)
+    # a cell whitelist that keeps about half of the cells of the synthetic BAMs
+    sys.path.insert(0, REPO)
+    from oracle import umi_oracle as uo
+    keep = []
+    for n in sorted(syn):
+        seen = []
+        for tid, flag, aux in uo.bam_records(uo.bgzf_inflate(syn[n])):
+            c = uo.get_tag(aux, b"CR")
+            if c and c not in seen:
+                seen.append(c)
+        keep += seen[::2]
+    with open(os.path.join(UMI_DATA, "syn_cells.txt"), "wb") as f:
+        f.write(b"".join(c + b"\n" for c in keep))
+    out = []
+    for args in umi_jobs():
+        with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+            rel = os.path.relpath(tmp, GOLD)
+            real = [a.replace("OUTU", rel + "/u.mtx").replace("OUTR", rel + "/r.mtx") for a in args]
+            p = subprocess.run(["bam_umi_count"] + real, executable=UMI_BIN, cwd=GOLD, capture_output=True, timeout=300)
+            files = {}
+            for tag, fn in (("OUTU", "u.mtx"), ("OUTR", "r.mtx")):
+                for ext in ("", "_rows", "_cols"):
+                    path = os.path.join(tmp, fn + ext)
+                    if os.path.exists(path):
+                        files[tag + ext] = open(path, "rb").read().decode("latin-1")
+            out.append({"args": args, "exit": p.returncode,
+                        "stdout": p.stdout.decode("latin-1").replace(rel + "/", "SCRATCH/"),
+                        "stderr": p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"), "files": files})
+    with open(os.path.join(GOLD, "umi_count.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    by = {}
+    for o in out:
+        by[o["exit"]] = by.get(o["exit"], 0) + 1
+    print("bam_umi_count invocations:", len(out), "by exit status:", by)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "pre_barcodes":
-        gen_pre_barcodes()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "fastq_info"):
         main()
+    if which in ("all", "pre_barcodes"):
         gen_pre_barcodes()
+    if which in ("all", "umi"):
+        gen_umi()
