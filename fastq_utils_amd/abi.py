@@ -32,6 +32,8 @@ EXPORTS = [
     "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_index_create",
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output",
+    "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
+    "fqg_umi_cells", "fqg_umi_entries",
 ]
 
 
@@ -47,6 +49,26 @@ class FileState(C.Structure):
 class FileStats(C.Structure):
     _fields_ = [("num_rds", C.c_uint64), ("min_rl", C.c_uint64), ("max_rl", C.c_uint64),
                 ("min_qual", C.c_uint64), ("max_qual", C.c_uint64)]
+
+
+class UmiParams(C.Structure):
+    _fields_ = [("feat_tag", C.c_char * 2), ("cell_tag", C.c_char * 2), ("umi_tag", C.c_char * 2),
+                ("reserved", C.c_char * 2), ("sorted_by_cell", C.c_int32), ("uniq_mapped_only", C.c_int32),
+                ("max_cells", C.c_uint32), ("max_features", C.c_uint32), ("min_reads", C.c_uint32),
+                ("min_umis", C.c_uint32), ("known_umis", C.POINTER(C.c_uint64)),
+                ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64)]
+
+
+class UmiResult(C.Structure):
+    _fields_ = [("n_alignments", C.c_uint64), ("n_tags_found", C.c_uint64), ("n_umis_discarded", C.c_uint64),
+                ("n_cells_discarded", C.c_uint64), ("n_features", C.c_uint64), ("n_cells", C.c_uint64),
+                ("n_entries", C.c_uint64 * 2), ("total", C.c_uint64 * 2), ("tot_reads", C.c_float),
+                ("tot_umi", C.c_float), ("code", C.c_int32), ("reserved", C.c_int32), ("record", C.c_uint64),
+                ("aux", C.c_uint64)]
+
+
+class UmiEntry(C.Structure):
+    _fields_ = [("row", C.c_uint32), ("col", C.c_uint32), ("value", C.c_uint32)]
 
 
 class ValidateResult(C.Structure):
@@ -148,6 +170,15 @@ def load():
     L.fqg_index_insert_unique.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_names_compare.argtypes = [vp, vp, C.POINTER(FileState), vp, C.POINTER(FileState), C.POINTER(IndexResult)]
+    L.fqg_pack_barcode.argtypes = [C.c_char_p]
+    L.fqg_pack_barcode.restype = u64
+    L.fqg_unpack_barcode.argtypes = [u64, C.c_char_p]
+    L.fqg_unpack_barcode.restype = None
+    L.fqg_bam_index_records.argtypes = [vp, u64, C.POINTER(u64), u64, C.POINTER(u64), C.POINTER(u64)]
+    L.fqg_umi_count.argtypes = [vp, vp, u64, C.c_int, C.POINTER(u64), u64, C.POINTER(UmiParams), C.POINTER(UmiResult)]
+    L.fqg_umi_features.argtypes = [vp, vp, u64]
+    L.fqg_umi_cells.argtypes = [vp, C.POINTER(u64), u64]
+    L.fqg_umi_entries.argtypes = [vp, C.c_int, C.POINTER(UmiEntry), u64]
     _lib = L
     return L
 
@@ -333,6 +364,57 @@ class Context:
         self._check(load().fqg_profile_read(self.h, out, 64, C.byref(n)))
         return {out[i].name.decode(): (int(out[i].launches), float(out[i].total_ms))
                 for i in range(min(64, n.value))}
+
+    def umi_count(self, stream, offsets=None, sorted_by_cell=True, uniq_mapped_only=False, feat_tag=b"GX",
+                  cell_tag=b"CR", umi_tag=b"RX", max_cells=None, max_features=100000, min_reads=0, min_umis=0,
+                  known_umis=None, known_cells=None, nbytes=None, want_entries=True):
+        """bam_umi_count's alignment loop on an inflated BAM stream: bytes (host) or an int device pointer
+        (then `nbytes` and `offsets` are required).  Returns the result fields plus, when the call
+        succeeded, feature names / packed cells in id order and the (row, col, value) lines."""
+        L = load()
+        host = isinstance(stream, (bytes, bytearray))
+        if host:
+            buf = (C.c_char * len(stream)).from_buffer_copy(stream)
+            nbytes = len(stream)
+        if offsets is None:
+            n, used = C.c_uint64(), C.c_uint64()
+            self._check(L.fqg_bam_index_records(buf, nbytes, None, 0, C.byref(n), C.byref(used)))
+            offs = (C.c_uint64 * max(1, n.value))()
+            self._check(L.fqg_bam_index_records(buf, nbytes, offs, n.value, C.byref(n), C.byref(used)))
+            n_rec = n.value
+        else:
+            n_rec = len(offsets)
+            offs = (C.c_uint64 * max(1, n_rec))(*offsets) if not isinstance(offsets, C.Array) else offsets
+        p = UmiParams()
+        p.feat_tag, p.cell_tag, p.umi_tag = feat_tag[:2], cell_tag[:2], umi_tag[:2]
+        p.sorted_by_cell, p.uniq_mapped_only = int(sorted_by_cell), int(uniq_mapped_only)
+        p.max_cells = (1 if sorted_by_cell else 1000000) if max_cells is None else max_cells
+        p.max_features, p.min_reads, p.min_umis = max_features, min_reads, min_umis
+        keep = []
+        for name, vals in (("known_umis", known_umis), ("known_cells", known_cells)):
+            if vals is not None:
+                arr = (C.c_uint64 * max(1, len(vals)))(*vals)
+                keep.append(arr)
+                setattr(p, name, arr)
+                setattr(p, "n_" + name, len(vals))
+        r = UmiResult()
+        self._check(L.fqg_umi_count(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
+                                    MEM_HOST if host else MEM_DEVICE, offs, n_rec, C.byref(p), C.byref(r)))
+        out = {k: getattr(r, k) for k, _ in UmiResult._fields_ if k not in ("reserved", "n_entries", "total")}
+        out["n_entries"], out["total"] = list(r.n_entries), list(r.total)
+        if r.code == 0 and want_entries:
+            names = C.create_string_buffer(max(1, r.n_features * 25))
+            self._check(L.fqg_umi_features(self.h, names, r.n_features))
+            out["features"] = [names.raw[i * 25:(i + 1) * 25].split(b"\0")[0] for i in range(r.n_features)]
+            cells = (C.c_uint64 * max(1, r.n_cells))()
+            self._check(L.fqg_umi_cells(self.h, cells, r.n_cells))
+            out["cells"] = [int(cells[i]) for i in range(r.n_cells)]
+            out["entries"] = []
+            for w in range(2):
+                e = (UmiEntry * max(1, r.n_entries[w]))()
+                self._check(L.fqg_umi_entries(self.h, w, e, r.n_entries[w]))
+                out["entries"].append([(e[i].row, e[i].col, e[i].value) for i in range(r.n_entries[w])])
+        return out
 
     def synth_fastq(self, device_ptr, n_records, read_len=150, first_index=0, seed=12345, mate=1):
         self._check(load().fqg_synth_fastq(self.h, C.c_void_p(int(device_ptr)), n_records, read_len,

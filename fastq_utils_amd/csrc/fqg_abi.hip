@@ -2,6 +2,9 @@
 // Single translation unit: the kernels are included so that launch sites see them directly.
 #include <hip/hip_runtime.h>
 
+#include <cstring>  // (before rocPRIM, whose texture iterator calls memset unqualified)
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +17,7 @@
 #include "fqg_stream_kernels.hip"
 #include "fqg_index_kernels.hip"
 #include "fqg_barcode_kernels.hip"
+#include "fqg_umi_kernels.hip"
 
 using namespace fqg;
 
@@ -60,6 +64,8 @@ struct fqg_ctx {
   DevBuf cinfo;       // streaming path: u32 info word per chunk
   DevBuf queue;       // streaming path: u64 suspect byte positions
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
+  DevBuf umi_names, umi_cells, umi_entries[2];  // results of the last fqg_umi_count
+  uint64_t umi_n_features = 0, umi_n_cells = 0, umi_n_entries[2] = {0, 0};
   CallState* d_cs = nullptr;
   CallState* h_cs = nullptr;  // pinned
   uint64_t* h_scalar = nullptr;  // pinned, 8 x u64
@@ -247,6 +253,10 @@ void fqg_close(fqg_ctx* c) {
   release(c->cinfo);
   release(c->queue);
   release(c->redo);
+  release(c->umi_names);
+  release(c->umi_cells);
+  release(c->umi_entries[0]);
+  release(c->umi_entries[1]);
   release(c->bc_status);
   for (int i = 0; i < 3; ++i) {
     release(c->bc_len[i]);
@@ -1301,5 +1311,7 @@ int fqg_synth_fastq(fqg_ctx* c, void* device_out, uint64_t n_records, uint32_t r
   HIP_TRY(c, hipGetLastError());
   return 0;
 }
+
+#include "fqg_umi_abi.inc"
 
 }  // extern "C"

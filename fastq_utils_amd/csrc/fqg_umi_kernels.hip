@@ -1,0 +1,764 @@
+// fqg_umi_kernels.hip - the alignment loop of bam_umi_count (reference src/bam_umi_count.c:942-1060)
+// and its per-cell output decisions (cell2MM :666-705, write2MM :584-663) on gfx950.
+//
+// Input: the inflated alignment records of a BAM file (the host inflates BGZF and walks the
+// block_size chain to get one offset per record).  One pass of kernels over N records:
+//
+//   k_umi_parse     1 thread / record: BAM core fields, aux scan with libbam's rules (bam_aux_get,
+//                   bam_aux2Z, bam_aux2i), filters (:950-970), barcode packing (char2uint_64
+//                   :364-382), first GX token + n_feat with strtok's rules (:1031-1058)
+//   k_umi_insert    whitelists (:981-999), then every key goes into an open-addressing table that
+//                   keeps the SMALLEST record index per key (atomicMin): UMIs, cells (packed u64)
+//                   and feature names (32-bit tag + byte compare against the claimant's bytes)
+//   k_umi_flag + scans   dense ids in order of first appearance (label_str2id :143, blabel2id :225)
+//                   = 1 + number of keys whose first record comes earlier: a flag per first record
+//                   and an exclusive prefix sum over the record axis
+//   k_umi_assign    ids per record, the "sorted by cell" test (:1002-1008), the limits of
+//                   process_entry (:447-462); the first finding in record order wins
+//   k_umi_count     (cell, feature, UMI) triples into a hash SET with the smallest record index: the
+//                   record that holds it is the one process_entry sees as a new UMI (:495-502);
+//                   (cell, feature) pairs get a slot with read / new-UMI counters
+//   k_umi_sums_*    the float32 counters of the reference.  When every increment is 1.0 (no NH > 1,
+//                   one GX per read) they are exact integers = the atomic counters; otherwise the
+//                   records are sorted by pair / cell (stable radix sort, rocPRIM) and summed
+//                   sequentially in record order, which reproduces the float32 rounding
+//   k_umi_rank / k_umi_emit   pairs grouped by cell; one workgroup per cell ranks its features
+//                   through an LDS bitmap (no sort), applies the early-break rule of cell2MM
+//                   (:697) / write2MM (:643), the thresholds and the UMI / reads fallback, and
+//                   writes (row, column, value) triples in file order
+//
+// The UMI container is a set, as src/range_list.h:150-162 documents it; the reference's RL_Tree
+// implementation loses and invents members when ids arrive out of order.
+#include "fqg_device.h"
+
+namespace fqg {
+
+constexpr unsigned long long kKeyEmpty = ~0ull;
+constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
+constexpr uint32_t kUmisFeature = 1048576u;  // src/bam_umi_count.c:48
+constexpr int kFeatIdMaxLen = 25;            // :40
+
+// stages a record reaches (what the counters of main() need)
+constexpr uint8_t kStSkipped = 0;    // filtered, or no feature tag
+constexpr uint8_t kStNoUmi = 1;      // feature tag found (num_tags_found), no UMI
+constexpr uint8_t kStUmi = 2;        // UMI present (intermediate)
+constexpr uint8_t kStUmiDiscarded = 3;
+constexpr uint8_t kStCellDiscarded = 4;
+constexpr uint8_t kStCounted = 5;    // reached the cell id (and process_entry when it has a token)
+
+struct UmiParams {
+  uint8_t feat_tag[2], cell_tag[2], umi_tag[2];
+  int sorted_by_cell, uniq_mapped_only;
+  uint32_t max_cells, max_features, min_reads, min_umis;
+  const unsigned long long* known_umis;  // distinct packed values in whitelist order (id = index + 1)
+  uint32_t n_known_umis;
+  const unsigned long long* known_umis_sorted;  // the same, sorted, with ...
+  const uint32_t* known_umis_order;             // ... their whitelist order
+  const unsigned long long* known_cells_sorted;
+  uint32_t n_known_cells;
+  int have_known_umis, have_known_cells;
+};
+
+struct UmiRec {            // per record, after parsing
+  unsigned long long umi_i, cell_i;
+  unsigned long long tok_off;  // first GX token: offset in the record buffer
+  uint32_t tok_len;
+  float incr;
+};
+
+struct UmiCall {
+  unsigned long long first_key;  // min (record << 8 | code)
+  unsigned long long aux;        // id that broke a limit (for the message)
+  unsigned long long n_tags, n_umis_disc, n_cells_disc;
+  unsigned long long n_counted, n_new;     // records that reached process_entry / that brought a new UMI
+  unsigned long long n_lines[2], tot[2];  // matrix lines / sum of truncated counts: [0] ucounts, [1] rcounts
+  unsigned int all_unit;         // 1 while every increment seen is exactly 1.0f
+  unsigned int table_full;
+  float db_reads, db_umi;
+};
+
+__device__ __forceinline__ uint64_t umi_mix(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+// ---- libbam 0.1.19 aux access (bam_aux.c, bam.h:772-778) ----------------------------------------
+__device__ __forceinline__ int aux_type2size(int x) {
+  if (x == 'C' || x == 'c' || x == 'A') return 1;
+  if (x == 'S' || x == 's') return 2;
+  if (x == 'I' || x == 'i' || x == 'f' || x == 'F') return 4;
+  return 0;
+}
+__device__ __forceinline__ int c_toupper(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+
+// bam_aux_get: pointer to the type byte of the first field named tag, or null.  [s, end) is the aux
+// area; `lim` bounds every read (a malformed field may run past `end`, as in libbam).
+__device__ const uint8_t* aux_get(const uint8_t* s, const uint8_t* end, const uint8_t* lim, const uint8_t tag[2]) {
+  while (s < end) {
+    if (s + 2 > lim) return nullptr;
+    const int x0 = s[0], x1 = s[1];
+    s += 2;
+    if (x0 == tag[0] && x1 == tag[1]) return s < lim ? s : nullptr;
+    if (s >= lim) return nullptr;
+    const int type = c_toupper(*s);
+    ++s;
+    if (type == 'Z' || type == 'H') {
+      while (s < lim && *s) ++s;
+      ++s;
+    } else if (type == 'B') {
+      if (s + 5 > lim) return nullptr;
+      const int sub = *s;
+      const int32_t cnt = (int32_t)((uint32_t)s[1] | ((uint32_t)s[2] << 8) | ((uint32_t)s[3] << 16) | ((uint32_t)s[4] << 24));
+      s += 5 + (long)aux_type2size(sub) * cnt;
+    } else {
+      s += aux_type2size(type);
+    }
+  }
+  return nullptr;
+}
+
+// bam_aux2Z + get_tag (src/bam_umi_count.c:513-522): string bytes and length (0 = EMPTY_STRING)
+__device__ __forceinline__ uint32_t aux_string(const uint8_t* t, const uint8_t* lim, const uint8_t** str) {
+  *str = nullptr;
+  if (!t) return 0;
+  if (*t != 'Z' && *t != 'H') return 0;
+  const uint8_t* p = t + 1;
+  uint32_t n = 0;
+  while (p + n < lim && p[n]) ++n;
+  *str = p;
+  return n;
+}
+
+__device__ __forceinline__ int32_t aux_int(const uint8_t* t, const uint8_t* lim) {  // bam_aux2i
+  if (!t || t + 2 > lim) return 0;
+  const int type = *t;
+  const uint8_t* s = t + 1;
+  if (((type == 's' || type == 'S') && t + 3 > lim) || ((type == 'i' || type == 'I') && t + 5 > lim)) return 0;
+  if (type == 'c') return (int32_t)(int8_t)s[0];
+  if (type == 'C') return (int32_t)s[0];
+  if (type == 's') return (int32_t)(int16_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8));
+  if (type == 'S') return (int32_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8));
+  if (type == 'i' || type == 'I') return (int32_t)((uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24));
+  return 0;
+}
+
+// char2uint_64 (src/bam_umi_count.c:364-382): base 10, A C G T N -> 1..5, parsed from the end, stops
+// at the first other character
+__device__ __forceinline__ unsigned long long pack_barcode(const uint8_t* s, uint32_t n) {
+  uint32_t pos = 0;
+  while (pos < n && s[pos] != '\n') ++pos;
+  unsigned long long v = 0;
+  while (pos > 0) {
+    int b;
+    switch (s[pos - 1]) {  // base2int :321-337
+      case 'A': case 'a': b = 1; break;
+      case 'C': case 'c': b = 2; break;
+      case 'G': case 'g': b = 3; break;
+      case 'T': case 't': b = 4; break;
+      case 'N': case 'n': b = 5; break;
+      default: b = 0;
+    }
+    if (!b) break;
+    v = v * 10ull + (unsigned long long)b;
+    --pos;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict__ buf, uint64_t nbytes,
+                                                      const unsigned long long* __restrict__ offs, uint32_t n,
+                                                      UmiParams P, UmiRec* __restrict__ rec,
+                                                      uint8_t* __restrict__ stage, UmiCall* __restrict__ call) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* lim = buf + nbytes;
+  const uint8_t* r = buf + offs[i];
+  uint8_t st = kStSkipped;
+  UmiRec out;
+  out.umi_i = out.cell_i = 0;
+  out.tok_off = 0;
+  out.tok_len = 0;
+  out.incr = 1.0f;
+  do {
+    if (r + 36 > lim) break;
+    auto rd32 = [&](int o) { return (uint32_t)r[o] | ((uint32_t)r[o + 1] << 8) | ((uint32_t)r[o + 2] << 16) | ((uint32_t)r[o + 3] << 24); };
+    const int32_t block_len = (int32_t)rd32(0);
+    const int32_t tid = (int32_t)rd32(4);
+    const uint32_t l_qname = rd32(12) & 0xFFu;
+    const uint32_t flag_nc = rd32(16);
+    const uint32_t flag = flag_nc >> 16, n_cigar = flag_nc & 0xFFFFu;
+    const uint32_t l_qseq = rd32(20);
+    if (tid < 0) break;          // :950
+    if (flag & 4u) break;        // BAM_FUNMAP :951
+    const uint8_t* end = r + 4 + (long)block_len;
+    if (end > lim) end = lim;
+    const uint8_t* aux = r + 36 + l_qname + 4ull * n_cigar + (l_qseq + 1) / 2 + l_qseq;
+    if (aux > end) aux = end;
+    int nh_i = 1;
+    const uint8_t nh_tag[2] = {'N', 'H'};
+    const uint8_t* t = aux_get(aux, end, lim, nh_tag);
+    if (t) {
+      nh_i = aux_int(t, lim);
+      if (nh_i > 1 && P.uniq_mapped_only) break;
+    }
+    const uint8_t *feat, *umi, *cell;
+    const uint32_t lf = aux_string(aux_get(aux, end, lim, P.feat_tag), lim, &feat);
+    if (!lf) break;
+    st = kStNoUmi;
+    const uint32_t lu = aux_string(aux_get(aux, end, lim, P.umi_tag), lim, &umi);
+    if (!lu) break;
+    st = kStUmi;
+    const uint32_t lc = aux_string(aux_get(aux, end, lim, P.cell_tag), lim, &cell);
+    out.umi_i = pack_barcode(umi, lu);
+    out.cell_i = lc ? pack_barcode(cell, lc) : 0ull;
+    // strtok(feat, ","): tokens are the maximal runs of non-comma bytes.  n_feat counts the first
+    // token and every token equal to its predecessor; only the first token is processed (the first
+    // pass replaced the commas by NULs)
+    uint32_t p = 0, n_feat = 0, t0 = 0, l0 = 0, prev_s = 0, prev_l = 0;
+    bool have_prev = false;
+    while (p < lf) {
+      while (p < lf && feat[p] == ',') ++p;
+      if (p >= lf) break;
+      const uint32_t s0 = p;
+      while (p < lf && feat[p] != ',') ++p;
+      const uint32_t len = p - s0;
+      bool same = have_prev && len == prev_l;
+      if (same)
+        for (uint32_t k = 0; k < len; ++k)
+          if (feat[s0 + k] != feat[prev_s + k]) {
+            same = false;
+            break;
+          }
+      if (!have_prev) {
+        t0 = s0;
+        l0 = len;
+      }
+      if (!have_prev || same) ++n_feat;
+      have_prev = true;
+      prev_s = s0;
+      prev_l = len;
+    }
+    out.tok_off = (unsigned long long)(feat - buf) + t0;
+    out.tok_len = l0;
+    out.incr = (float)(1.0 / (double)((int)n_feat * nh_i));  // float incr=1.0/(n_feat*nh_i) :1044
+  } while (false);
+  rec[i] = out;
+  stage[i] = st;
+  const unsigned long long tags = __ballot(st >= kStNoUmi);
+  if ((threadIdx.x & 63) == 0 && tags) atomicAdd(&call->n_tags, (unsigned long long)__builtin_popcountll(tags));
+}
+
+// ---- hash tables --------------------------------------------------------------------------------
+struct KeyTable {          // u64 key -> smallest record index
+  unsigned long long* keys;
+  uint32_t* first;
+  uint64_t mask;
+};
+struct NameTable {         // feature names: slot = tag32 << 32 | claimant record
+  unsigned long long* slots;
+  uint32_t* first;
+  uint64_t mask;
+};
+
+__device__ __forceinline__ uint32_t table_insert(const KeyTable& T, unsigned long long key, uint32_t idx,
+                                                 UmiCall* call) {
+  uint64_t h = umi_mix(key) & T.mask;
+  for (uint64_t probes = 0; probes <= T.mask; ++probes) {
+    unsigned long long k = T.keys[h];
+    if (k == kKeyEmpty) {
+      k = atomicCAS(&T.keys[h], kKeyEmpty, key);
+      if (k == kKeyEmpty) k = key;
+    }
+    if (k == key) {
+      atomicMin(&T.first[h], idx);
+      return (uint32_t)h;
+    }
+    h = (h + 1) & T.mask;
+  }
+  atomicOr(&call->table_full, 1u);
+  return kNoIdx;
+}
+
+__device__ __forceinline__ uint32_t table_find(const KeyTable& T, unsigned long long key) {
+  uint64_t h = umi_mix(key) & T.mask;
+  for (uint64_t probes = 0; probes <= T.mask; ++probes) {
+    const unsigned long long k = T.keys[h];
+    if (k == key) return (uint32_t)h;
+    if (k == kKeyEmpty) return kNoIdx;
+    h = (h + 1) & T.mask;
+  }
+  return kNoIdx;
+}
+
+__device__ __forceinline__ bool sorted_contains(const unsigned long long* a, uint32_t n, unsigned long long v,
+                                                uint32_t* at) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  if (at) *at = lo;
+  return lo < n && a[lo] == v;
+}
+
+// whitelists, then the three key tables.  slot arrays: table slot of the record's key, or
+// kNoIdx | (whitelist order) for UMIs that the whitelist already numbered.
+constexpr uint32_t kWhiteBit = 0x80000000u;
+
+__global__ __launch_bounds__(kBlock) void k_umi_insert(const uint8_t* __restrict__ buf, uint32_t n, UmiParams P,
+                                                       const UmiRec* __restrict__ rec, uint8_t* __restrict__ stage,
+                                                       KeyTable U, KeyTable C, NameTable F,
+                                                       uint32_t* __restrict__ uslot, uint32_t* __restrict__ cslot,
+                                                       uint32_t* __restrict__ fslot, UmiCall* __restrict__ call) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  uint8_t st = i < n ? stage[i] : kStSkipped;
+  uint32_t us = kNoIdx, cs = kNoIdx, fs = kNoIdx;
+  if (st == kStUmi) {
+    const UmiRec r = rec[i];
+    // valid_barcode() looks the PACKED umi up among the whitelist's dense IDS (src/bam_umi_count.c:559-571,
+    // 984): true iff 1 <= packed <= number of distinct whitelist entries
+    if (P.have_known_umis && !(r.umi_i >= 1 && r.umi_i <= (unsigned long long)P.n_known_umis)) st = kStUmiDiscarded;
+    else {
+      uint32_t at;
+      if (P.have_known_umis && sorted_contains(P.known_umis_sorted, P.n_known_umis, r.umi_i, &at))
+        us = kWhiteBit | P.known_umis_order[at];
+      else
+        us = table_insert(U, r.umi_i, i, call);
+      if (P.have_known_cells && !sorted_contains(P.known_cells_sorted, P.n_known_cells, r.cell_i, nullptr))
+        st = kStCellDiscarded;
+      else {
+        st = kStCounted;
+        cs = table_insert(C, r.cell_i, i, call);
+        if (r.tok_len > 0 && r.tok_len + 1 < (uint32_t)kFeatIdMaxLen) {
+          const uint8_t* s = buf + r.tok_off;
+          uint64_t hsh = 0x9E3779B97F4A7C15ull;
+          for (uint32_t k = 0; k < r.tok_len; ++k) hsh = umi_mix(hsh ^ s[k]);
+          const unsigned long long tag = (hsh >> 32) << 32;
+          uint64_t h = hsh & F.mask;
+          for (uint64_t probes = 0; probes <= F.mask; ++probes) {
+            unsigned long long v = F.slots[h];
+            if (v == kKeyEmpty) {
+              v = atomicCAS(&F.slots[h], kKeyEmpty, tag | i);
+              if (v == kKeyEmpty) v = tag | i;
+            }
+            if ((v >> 32) == (tag >> 32)) {
+              const UmiRec o = rec[(uint32_t)v];
+              bool same = o.tok_len == r.tok_len;
+              if (same) {
+                const uint8_t* q = buf + o.tok_off;
+                for (uint32_t k = 0; k < r.tok_len; ++k)
+                  if (q[k] != s[k]) {
+                    same = false;
+                    break;
+                  }
+              }
+              if (same) {
+                atomicMin(&F.first[h], i);
+                fs = (uint32_t)h;
+                break;
+              }
+            }
+            h = (h + 1) & F.mask;
+          }
+          if (fs == kNoIdx) atomicOr(&call->table_full, 1u);
+        }
+      }
+    }
+  }
+  if (i < n) {
+    stage[i] = st;
+    uslot[i] = us;
+    cslot[i] = cs;
+    fslot[i] = fs;
+  }
+  const unsigned long long du = __ballot(st == kStUmiDiscarded), dc = __ballot(st == kStCellDiscarded);
+  if ((threadIdx.x & 63) == 0) {
+    if (du) atomicAdd(&call->n_umis_disc, (unsigned long long)__builtin_popcountll(du));
+    if (dc) atomicAdd(&call->n_cells_disc, (unsigned long long)__builtin_popcountll(dc));
+  }
+}
+
+// flag[first record of every key] = 1 (the flag arrays are zeroed by the host)
+__global__ __launch_bounds__(kBlock) void k_umi_flag(const uint32_t* __restrict__ first, uint64_t n_slots,
+                                                     uint32_t* __restrict__ flag) {
+  const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (h >= n_slots) return;
+  const uint32_t f = first[h];
+  if (f != kNoIdx) flag[f] = 1u;
+}
+
+// exclusive prefix over u32 flags: local (per span of kUmiSpan) + span sums (scanned by k_scan64_b)
+constexpr int kUmiSpan = kBlock * 8;
+struct Prefix {
+  const unsigned long long* local;
+  const unsigned long long* spans;
+  __device__ __forceinline__ uint32_t at(uint32_t i) const { return (uint32_t)(local[i] + spans[i / kUmiSpan]); }
+};
+
+struct UmiIds {
+  uint32_t *umi, *cell, *feat;
+};
+
+__global__ __launch_bounds__(kBlock) void k_umi_assign(uint32_t n, UmiParams P, const UmiRec* __restrict__ rec,
+                                                       const uint8_t* __restrict__ stage, KeyTable U, KeyTable C,
+                                                       NameTable F, const uint32_t* __restrict__ uslot,
+                                                       const uint32_t* __restrict__ cslot,
+                                                       const uint32_t* __restrict__ fslot, Prefix pu, Prefix pc,
+                                                       Prefix pf, const uint32_t* __restrict__ cflag, UmiIds ids,
+                                                       UmiCall* __restrict__ call) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t uid = 0, cid = 0, fid = 0;
+  const uint8_t st = stage[i];
+  if (st == kStCounted) {
+    const UmiRec r = rec[i];
+    const uint32_t us = uslot[i];
+    if (us != kNoIdx) uid = (us & kWhiteBit) ? (us & ~kWhiteBit) + 1u : P.n_known_umis + pu.at(U.first[us]) + 1u;
+    const uint32_t cs = cslot[i];
+    if (cs != kNoIdx) cid = pc.at(C.first[cs]) + 1u;
+    unsigned long long key = kKeyEmpty;
+    auto finding = [&](uint32_t code, unsigned long long) {  // (the host reads the offending id from ids[])
+      const unsigned long long k = ((unsigned long long)i << 8) | code;
+      if (k < key) {
+        key = k;
+        atomicMin(&call->first_key, k);
+      }
+    };
+    // :1002-1008 - ids are dense in first-appearance order, so the largest id so far is the number
+    // of cells first seen up to here
+    if (P.sorted_by_cell && cid != pc.at(i) + cflag[i]) finding(FQG_E_UMI_NOT_SORTED, cid);
+    if (r.tok_len > 0 && key == kKeyEmpty) {
+      if (r.tok_len + 1 >= (uint32_t)kFeatIdMaxLen) finding(FQG_E_UMI_FEATURE_NAME, r.tok_len);
+      else {
+        const uint32_t fs = fslot[i];
+        if (fs != kNoIdx) fid = pf.at(F.first[fs]) + 1u;
+        // process_entry :447-462
+        if (uid > kUmisFeature) finding(FQG_E_UMI_TOO_MANY_UMIS, uid);
+        else if (!P.sorted_by_cell && cid > P.max_cells && P.max_cells > 1) finding(FQG_E_UMI_TOO_MANY_CELLS, cid);
+        else if (fid > P.max_features) finding(FQG_E_UMI_TOO_MANY_FEATURES, fid);
+      }
+    }
+    if (r.incr != 1.0f && fid) atomicAnd(&call->all_unit, 0u);
+  }
+  ids.umi[i] = uid;
+  ids.cell[i] = cid;
+  ids.feat[i] = fid;
+}
+
+// ---- counting -------------------------------------------------------------------------------------
+struct PairTable {
+  KeyTable t;            // key = cell << 32 | feature
+  uint32_t* reads;       // records of the pair
+  uint32_t* umis;        // records that brought a new UMI
+};
+
+__device__ __forceinline__ unsigned long long pair_key(uint32_t cell, uint32_t feat) {
+  return ((unsigned long long)cell << 32) | feat;
+}
+
+// (cell, feature, UMI) set: key = slot of the (cell, feature) pair << 32 | umi id - exact and unbounded
+__global__ __launch_bounds__(kBlock) void k_umi_count(uint32_t n, uint32_t limit, UmiIds ids, KeyTable T,
+                                                      PairTable Pt, uint32_t* __restrict__ pslot,
+                                                      uint32_t* __restrict__ tslot, UmiCall* __restrict__ call) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t ps = kNoIdx, ts = kNoIdx;
+  const uint32_t fid = ids.feat[i];
+  if (fid && i < limit) {
+    ps = table_insert(Pt.t, pair_key(ids.cell[i], fid), i, call);
+    if (ps != kNoIdx) {
+      atomicAdd(&Pt.reads[ps], 1u);
+      ts = table_insert(T, ((unsigned long long)ps << 32) | ids.umi[i], i, call);
+    }
+  }
+  pslot[i] = ps;
+  tslot[i] = ts;
+}
+
+// is_new[i]: record i is the first one of its (cell, feature, UMI); unit-increment counters
+__global__ __launch_bounds__(kBlock) void k_umi_new(uint32_t n, const uint32_t* __restrict__ tslot,
+                                                    const uint32_t* __restrict__ pslot, KeyTable T, PairTable Pt,
+                                                    UmiIds ids, uint8_t* __restrict__ is_new,
+                                                    uint32_t* __restrict__ cell_reads, uint32_t* __restrict__ cell_umis,
+                                                    UmiCall* __restrict__ call) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t ts = tslot[i];
+  uint8_t nw = 0;
+  if (ts != kNoIdx) {
+    nw = T.first[ts] == i;
+    const uint32_t cid = ids.cell[i];
+    atomicAdd(&cell_reads[cid], 1u);
+    if (nw) {
+      atomicAdd(&Pt.umis[pslot[i]], 1u);
+      atomicAdd(&cell_umis[cid], 1u);
+    }
+  }
+  is_new[i] = nw;
+  const unsigned long long cnt = __ballot(ts != kNoIdx), nws = __ballot(nw != 0);
+  if ((threadIdx.x & 63) == 0) {
+    if (cnt) atomicAdd(&call->n_counted, (unsigned long long)__builtin_popcountll(cnt));
+    if (nws) atomicAdd(&call->n_new, (unsigned long long)__builtin_popcountll(nws));
+  }
+}
+
+// float32 value of `count` additions of 1.0f starting from 0 (saturates at 2^24)
+__device__ __forceinline__ float unit_sum(uint32_t count) { return count > 16777216u ? 16777216.0f : (float)count; }
+
+// General increments: records sorted by group (stable, so record order inside a group); one thread
+// walks a group and adds in float32 exactly as process_entry does.
+__global__ __launch_bounds__(kBlock) void k_umi_sums_sorted(uint32_t m, const uint32_t* __restrict__ group,
+                                                            const uint32_t* __restrict__ order,
+                                                            const UmiRec* __restrict__ rec,
+                                                            const uint8_t* __restrict__ is_new,
+                                                            float* __restrict__ sum_reads, float* __restrict__ sum_umis) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t g = group[j];
+  if (g == kNoIdx || (j > 0 && group[j - 1] == g)) return;  // excluded, or not the first record of its group
+  float r = 0.0f, u = 0.0f;
+  for (uint32_t k = j; k < m && group[k] == g; ++k) {
+    const uint32_t i = order[k];
+    const float incr = rec[i].incr;
+    if (is_new[i]) u += incr;
+    r += incr;
+  }
+  sum_reads[g] = r;
+  sum_umis[g] = u;
+}
+
+// unit increments: counters -> the float32 values the reference would hold
+__global__ __launch_bounds__(kBlock) void k_umi_unit_sums(uint64_t n, const uint32_t* __restrict__ reads,
+                                                          const uint32_t* __restrict__ umis,
+                                                          float* __restrict__ f_reads, float* __restrict__ f_umis) {
+  const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n) return;
+  f_reads[j] = unit_sum(reads[j]);
+  f_umis[j] = unit_sum(umis[j]);
+}
+
+// sort keys of the general path: the record's group (pair slot / cell id), kNoIdx when not counted
+__global__ __launch_bounds__(kBlock) void k_umi_sort_keys(uint32_t n, const uint32_t* __restrict__ tslot,
+                                                          const uint32_t* __restrict__ pslot,
+                                                          const uint32_t* __restrict__ cell,
+                                                          uint32_t* __restrict__ key_pair, uint32_t* __restrict__ key_cell,
+                                                          uint32_t* __restrict__ idx) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const bool counted = tslot[i] != kNoIdx;
+  key_pair[i] = counted ? pslot[i] : kNoIdx;
+  key_cell[i] = counted ? cell[i] : kNoIdx;
+  idx[i] = i;
+}
+
+// db->tot_reads_obs / tot_umi_obs: one float32 chain over all records in order
+__global__ void k_umi_db_totals(uint32_t n, uint32_t limit, const UmiRec* __restrict__ rec,
+                                const uint32_t* __restrict__ tslot, const uint8_t* __restrict__ is_new,
+                                UmiCall* __restrict__ call) {
+  if (blockIdx.x || threadIdx.x) return;
+  float r = 0.0f, u = 0.0f;
+  for (uint32_t i = 0; i < n && i < limit; ++i) {
+    if (tslot[i] == kNoIdx) continue;
+    const float incr = rec[i].incr;
+    if (is_new[i]) u += incr;
+    r += incr;
+  }
+  call->db_reads = r;
+  call->db_umi = u;
+}
+
+// ---- output ---------------------------------------------------------------------------------------
+// pairs grouped by cell: cell_count[c] pairs, cell_start = exclusive prefix; pair_of[] filled by atomics
+__global__ __launch_bounds__(kBlock) void k_umi_pairs_count(uint64_t n_slots, PairTable Pt,
+                                                            uint32_t* __restrict__ cell_pairs) {
+  const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (h >= n_slots) return;
+  const unsigned long long k = Pt.t.keys[h];
+  if (k != kKeyEmpty) atomicAdd(&cell_pairs[(uint32_t)(k >> 32)], 1u);
+}
+__global__ __launch_bounds__(kBlock) void k_umi_pairs_fill(uint64_t n_slots, PairTable Pt, Prefix start,
+                                                           uint32_t* __restrict__ cursor,
+                                                           uint32_t* __restrict__ pair_of) {
+  const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (h >= n_slots) return;
+  const unsigned long long k = Pt.t.keys[h];
+  if (k == kKeyEmpty) return;
+  const uint32_t c = (uint32_t)(k >> 32);
+  pair_of[start.at(c) + atomicAdd(&cursor[c], 1u)] = (uint32_t)h;
+}
+
+struct UmiEntry {
+  uint32_t row, col, val;
+};
+
+// One workgroup per cell: rank the cell's features with a bitmap, apply the output rules and write
+// every printed line at (first pair of the cell + rank of the feature) into a scratch that has one
+// entry per pair and was filled with 0xFF: file order with gaps, closed by k_umi_compact.
+constexpr int kUmiBitmapWords = 4096;  // 131072 feature ids per sweep; more features loop over sweeps
+
+struct EmitArgs {
+  PairTable Pt;
+  Prefix start;                 // first pair of a cell in pair_of[]
+  const uint32_t* cell_pairs;
+  const uint32_t* pair_of;
+  const float* pair_reads;      // float32 counters per pair slot
+  const float* pair_umis;
+  const float* cell_umis;       // cells[c].tot_umi_obs
+  UmiParams P;
+  uint32_t n_cells;
+  UmiEntry* out_u;              // scratch, one entry per pair
+  UmiEntry* out_r;
+};
+
+__global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __restrict__ call) {
+  __shared__ uint32_t s_bits[kUmiBitmapWords];
+  __shared__ uint32_t s_pre[kUmiBitmapWords];
+  __shared__ uint32_t s_wave[kBlock / kWave];
+  __shared__ uint32_t s_base;
+  const uint32_t c = blockIdx.x + 1;  // cell id
+  if (c > A.n_cells) return;
+  const uint32_t np = A.cell_pairs[c];
+  const uint32_t p0 = A.start.at(c);
+  const float tot = A.cell_umis[c];
+  if (threadIdx.x == 0) s_base = 0;
+  // unsorted mode never prints cell ids >= max_cells (write2MM loops while cell_id < max_cells, :612)
+  const bool cell_printed = A.P.sorted_by_cell || c < A.P.max_cells;
+  unsigned long long tu = 0, tr = 0;
+  // sweeps over the feature id space, 131072 ids at a time (one sweep unless --max_feat is huge)
+  uint32_t max_f = 0;
+  for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
+    const uint32_t f = (uint32_t)A.Pt.t.keys[A.pair_of[p0 + k]];
+    max_f = f > max_f ? f : max_f;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t o = __shfl_xor(max_f, d, 64);
+    max_f = o > max_f ? o : max_f;
+  }
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = max_f;
+  __syncthreads();
+  max_f = 0;
+  for (int w = 0; w < kBlock / kWave; ++w) max_f = s_wave[w] > max_f ? s_wave[w] : max_f;
+  __syncthreads();
+  for (uint32_t sweep0 = 0; sweep0 <= max_f; sweep0 += kUmiBitmapWords * 32) {
+    for (int w = threadIdx.x; w < kUmiBitmapWords; w += kBlock) s_bits[w] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
+      const uint32_t f = (uint32_t)A.Pt.t.keys[A.pair_of[p0 + k]] - sweep0;
+      if (f < (uint32_t)kUmiBitmapWords * 32) atomicOr(&s_bits[f >> 5], 1u << (f & 31));
+    }
+    __syncthreads();
+    // exclusive prefix of the word popcounts: 16 words per thread
+    uint32_t local[kUmiBitmapWords / kBlock], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kUmiBitmapWords / kBlock; ++q) {
+      local[q] = sum;
+      sum += __popc(s_bits[threadIdx.x * (kUmiBitmapWords / kBlock) + q]);
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      if (w < (int)(threadIdx.x >> 6)) before += s_wave[w];
+      all += s_wave[w];
+    }
+    const uint32_t base = s_base;  // features of earlier sweeps
+#pragma unroll
+    for (int q = 0; q < kUmiBitmapWords / kBlock; ++q)
+      s_pre[threadIdx.x * (kUmiBitmapWords / kBlock) + q] = base + before + incl - sum + local[q];
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
+      const uint32_t slot = A.pair_of[p0 + k];
+      const uint32_t feat = (uint32_t)A.Pt.t.keys[slot];
+      const uint32_t f = feat - sweep0;
+      if (f >= (uint32_t)kUmiBitmapWords * 32) continue;
+      const uint32_t rank = s_pre[f >> 5] + __popc(s_bits[f >> 5] & ((1u << (f & 31)) - 1u));  // among the cell's features
+      // the walk over cf stops once `pr >= tot_umi_obs` (:697 / :643).  Sorted mode counts every feature
+      // seen so far in the file (ids 1..feat-1 precede this one), unsorted mode the cell's own.
+      const uint32_t pr_before = A.P.sorted_by_cell ? feat - 1u : rank;
+      if (!cell_printed || feat >= A.P.max_features || (float)pr_before >= tot) continue;
+      const float u = A.pair_umis[slot], r = A.pair_reads[slot];
+      if (!(r >= (float)A.P.min_reads && u >= (float)A.P.min_umis)) continue;
+      // ucounts: UMIs, or the reads when the UMI count truncates to 0 (:685-695)
+      uint32_t val_u = 0, val_r = 0;
+      bool pu = false, prd = false;
+      if ((uint32_t)u >= 1u) {
+        pu = true;
+        val_u = (uint32_t)roundf(u);
+        tu += (uint32_t)u;
+      } else if ((uint32_t)r >= 1u) {
+        pu = true;
+        val_u = (uint32_t)roundf(r);
+        tu += (uint32_t)r;
+      }
+      if ((uint32_t)r >= 1u) {
+        prd = true;
+        val_r = (uint32_t)roundf(r);
+        tr += (uint32_t)r;
+      }
+      if (pu) A.out_u[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c, val_u};
+      if (prd) A.out_r[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c, val_r};
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = base + all;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    tu += __shfl_down(tu, d, 64);
+    tr += __shfl_down(tr, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (tu) atomicAdd(&call->tot[0], tu);
+    if (tr) atomicAdd(&call->tot[1], tr);
+  }
+}
+
+// close the gaps of the rank-indexed scratch: flag -> prefix -> scatter
+__global__ __launch_bounds__(kBlock) void k_umi_entry_flags(uint32_t n, const UmiEntry* __restrict__ in,
+                                                            uint32_t* __restrict__ flag) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < n) flag[j] = in[j].col != 0xFFFFFFFFu ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_umi_compact(uint32_t n, const UmiEntry* __restrict__ in,
+                                                        const uint32_t* __restrict__ flag, Prefix pos,
+                                                        UmiEntry* __restrict__ out) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < n && flag[j]) out[pos.at(j)] = in[j];
+}
+
+// names / packed barcodes in id order
+__global__ __launch_bounds__(kBlock) void k_umi_export_features(const uint8_t* __restrict__ buf, uint64_t n_slots,
+                                                                NameTable F, Prefix pf,
+                                                                const UmiRec* __restrict__ rec,
+                                                                char* __restrict__ names /* 25 bytes each */) {
+  const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (h >= n_slots) return;
+  const uint32_t f = F.first[h];
+  if (f == kNoIdx) return;
+  const uint32_t id = pf.at(f);  // 0-based
+  const UmiRec r = rec[f];
+  char* dst = names + (uint64_t)id * kFeatIdMaxLen;
+  for (uint32_t k = 0; k < (uint32_t)kFeatIdMaxLen; ++k) dst[k] = k < r.tok_len ? (char)buf[r.tok_off + k] : 0;
+}
+__global__ __launch_bounds__(kBlock) void k_umi_export_cells(uint64_t n_slots, KeyTable C, Prefix pc,
+                                                             unsigned long long* __restrict__ out) {
+  const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (h >= n_slots) return;
+  const uint32_t f = C.first[h];
+  if (f == kNoIdx) return;
+  out[pc.at(f)] = C.keys[h];
+}
+
+}  // namespace fqg

@@ -241,6 +241,54 @@ int fqg_barcodes_transform(fqg_ctx *ctx, const fqg_frame *const frames[6], const
 /* copy output `which` (0 SAM, 1, 2) of the last transform to host memory */
 int fqg_barcodes_output(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
 
+/* ---- UMI counting (bam_umi_count) ---------------------------------------------------------------
+ * Replaces the alignment loop of bam_umi_count (src/bam_umi_count.c:942-1060: filters, aux tags,
+ * char2uint_64 :364-382, the label maps :143-260, process_entry :444-509) and the output decisions
+ * of cell2MM (:666-705) / write2MM (:584-663).  Input: the inflated BAM stream of a file (the host
+ * inflates BGZF; libbam does that inside bam_read1) and the offset of every alignment record in
+ * it (fqg_bam_index_records).  The UMIs of a (cell, feature) form a set (src/range_list.h:150-162);
+ * counters are float32 and are added in record order, as the reference's `float` fields are. */
+typedef struct {
+  char feat_tag[2], cell_tag[2], umi_tag[2];      /* -x / -X / RX or UB (--10x) */
+  char reserved[2];
+  int32_t sorted_by_cell, uniq_mapped_only;       /* --not_sorted_by_cell clears the first, --uniq_mapped sets the second */
+  uint32_t max_cells, max_features, min_reads, min_umis;
+  const uint64_t *known_umis, *known_cells;       /* packed (fqg_pack_barcode) whitelist lines in file order, or NULL */
+  uint64_t n_known_umis, n_known_cells;
+} fqg_umi_params;
+
+typedef struct {
+  uint64_t n_alignments, n_tags_found, n_umis_discarded, n_cells_discarded;
+  uint64_t n_features, n_cells;
+  uint64_t n_entries[2];  /* lines of the UMI-count / read-count matrix */
+  uint64_t total[2];      /* sum of the truncated counts of those lines (third header field in sorted mode) */
+  float tot_reads, tot_umi; /* db->tot_reads_obs / tot_umi_obs (:1086-1087) */
+  int32_t code;           /* FQG_OK or FQG_E_UMI_*: the first finding in record order; nothing else is valid then */
+  int32_t reserved;
+  uint64_t record, aux;   /* alignment index of the finding, offending id */
+} fqg_umi_result;
+
+typedef struct {
+  uint32_t row, col, value; /* feature id (0 in unsorted mode, as the reference prints), cell id, rounded count */
+} fqg_umi_entry;
+
+/* char2uint_64 (:364-382) on a NUL- or newline-terminated string; host side, no GPU */
+uint64_t fqg_pack_barcode(const char *s);
+/* uint_642char (:342-360); out needs 20 bytes */
+void fqg_unpack_barcode(uint64_t v, char *out);
+/* Host side, no GPU: walk an inflated BAM stream (magic, header text, references, then records).
+ * Writes the offset of every alignment record (of its block_size field) to offsets[0..*n) and the
+ * end of the last complete record to *used.  Returns 0, FQG_ERR_ARG for a stream that is not BAM or a
+ * too small `cap` (*n then holds the number needed). */
+int fqg_bam_index_records(const void *stream, uint64_t nbytes, uint64_t *offsets, uint64_t cap, uint64_t *n,
+                          uint64_t *used);
+int fqg_umi_count(fqg_ctx *ctx, const void *stream, uint64_t nbytes, int mem, const uint64_t *offsets,
+                  uint64_t n_records, const fqg_umi_params *params, fqg_umi_result *out);
+/* results of the last fqg_umi_count on this context */
+int fqg_umi_features(fqg_ctx *ctx, char *names, uint64_t cap);       /* n_features x 25 bytes, NUL padded, id order */
+int fqg_umi_cells(fqg_ctx *ctx, uint64_t *packed, uint64_t cap);     /* n_cells packed barcodes, id order */
+int fqg_umi_entries(fqg_ctx *ctx, int which, fqg_umi_entry *out, uint64_t cap); /* which: 0 UMI counts, 1 read counts */
+
 /* ---- measurement ------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */
 typedef struct {

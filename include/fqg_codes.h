@@ -49,7 +49,16 @@ enum fqg_code {
   /* src/fastq.c:249-250  a record whose first line starts with a NUL byte ends the file
    * silently (fastq_read_entry returns 0).  Reported so that the caller can re-run on the
    * prefix that precedes it. */
-  FQG_STOP_NUL = 16
+  FQG_STOP_NUL = 16,
+  /* bam_umi_count, src/bam_umi_count.c:1004-1007  a cell seen again after another one in sorted mode:
+   * "The BAM file does not seem to be sorted by CR", exit 1 */
+  FQG_E_UMI_NOT_SORTED = 17,
+  /* :1047  assert(len1+1 < FEAT_ID_MAX_LEN): a feature name of 24 characters or more aborts */
+  FQG_E_UMI_FEATURE_NAME = 18,
+  /* process_entry :451-453, :455-457, :459-461  "Too many umi barcodes / cells / features"; aux = the id */
+  FQG_E_UMI_TOO_MANY_UMIS = 19,
+  FQG_E_UMI_TOO_MANY_CELLS = 20,
+  FQG_E_UMI_TOO_MANY_FEATURES = 21
 };
 
 /* read-name formats, src/fastq.h:25-28 (INTEGERNAME and NOP share the value 2) */

@@ -1,0 +1,134 @@
+"""GPU parity tests for the bam_umi_count path: bin/bam_umi_count (C++ host + libfqgpu.so) against
+every comparable golden invocation of the reference binary (tests/golden/umi_count.json), and
+fqg_umi_count through the C-ABI against the oracle (oracle/umi_oracle.py) on seeded BAMs with
+re-used UMIs, NH weights, multi-gene tags, whitelists, in both output modes.  Integer / byte work
+and float32 counters added in record order: the bar is bit-exact."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import umi_oracle as uo
+from tests import bamgen
+from tests.test_oracle_umi import GOLDEN, comparable, golden_files, want_exit
+from tests.util import GOLD, REPO
+
+pytestmark = pytest.mark.gpu
+fq = pytest.importorskip("fastq_utils_amd")
+BIN = os.path.join(REPO, "bin", "bam_umi_count")
+
+
+def run_cli(args, cwd):
+    # argv[0] as in the golden runs: getopt's own messages start with it
+    p = subprocess.run(["bam_umi_count"] + args, executable=BIN, cwd=cwd, capture_output=True, timeout=300)
+    return p.returncode, p.stderr.decode("latin-1")
+
+
+@pytest.mark.parametrize("case", [c for c in GOLDEN if comparable(c)], ids=lambda c: " ".join(c["args"])[:80])
+def test_cli_matches_reference_binary(case):
+    with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+        rel = os.path.relpath(tmp, GOLD)
+        real = [a.replace("OUTU", rel + "/u.mtx").replace("OUTR", rel + "/r.mtx") for a in case["args"]]
+        rc, err = run_cli(real, GOLD)
+        err = err.replace(rel + "/", "SCRATCH/")
+        assert (rc if rc >= 0 else 128 - rc) == want_exit(case), err[-400:]
+        if case["exit"] == -6:
+            assert "Assertion `len1+1 < FEAT_ID_MAX_LEN' failed" in err
+            return
+        assert err == case["stderr"]
+        if case["exit"] == 0:
+            got = {}
+            for base in ("u.mtx", "r.mtx"):
+                for ext in ("", "_rows", "_cols"):
+                    path = os.path.join(tmp, base + ext)
+                    if os.path.exists(path):
+                        got["SCRATCH/" + base + ext] = open(path, "rb").read().decode("latin-1")
+            assert got == golden_files(case)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = fq.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_files(bam, extra):
+    files = {"in.bam": bam}
+    got = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"] + extra, lambda p: files.get(p))
+    return got
+
+
+def lines_of(text):
+    return [tuple(int(x) for x in ln.split()) for ln in text.splitlines()[2:]]
+
+
+@pytest.mark.parametrize("variant", ["plain", "nh", "multi", "noise", "unsorted", "whitelist", "uniq", "thresholds"])
+def test_abi_matches_oracle_on_reused_umis(ctx, variant):
+    """UMIs re-used across genes and cells (the regime where the reference's own RL_Tree breaks,
+    tests/test_oracle_umi.py::test_reference_rl_tree_defect): the oracle's set semantics are the bar."""
+    rng = np.random.default_rng(abs(hash(variant)) % 9999)
+    for trial in range(3):
+        kw = dict(n_cells=int(rng.integers(3, 60)), genes=int(rng.integers(5, 400)), umi_len=int(rng.integers(2, 9)),
+                  reads_per_cell=(1, int(rng.integers(2, 300))))
+        if variant in ("nh", "multi", "noise", "uniq"):
+            kw["nh"] = True
+        if variant in ("multi", "noise"):
+            kw["multi_gx"] = True
+        if variant == "noise":
+            kw["noise"] = True
+        sorted_mode = variant != "unsorted"
+        if not sorted_mode:
+            kw["sort_cells"] = False
+        bam, stream = bamgen.tagged_bam(rng, **kw)
+        extra, args = [], {}
+        if not sorted_mode:
+            extra.append("--not_sorted_by_cell")
+        if variant == "uniq":
+            extra.append("--uniq_mapped")
+            args["uniq_mapped_only"] = True
+        if variant == "thresholds":
+            extra += ["--min_reads", "2", "--min_umis", "2"]
+            args.update(min_reads=2, min_umis=2)
+        files = {"in.bam": bam}
+        if variant == "whitelist":
+            cells = []
+            for tid, flag, aux in uo.bam_records(stream):
+                c = uo.get_tag(aux, b"CR")
+                if c and c not in cells:
+                    cells.append(c)
+            keep = cells[::2]
+            files["wl.txt"] = b"".join(c + b"\n" for c in keep)
+            extra += ["--known_cells", "wl.txt"]
+            args["known_cells"] = [uo.char2uint_64(c) for c in keep]
+        want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"] + extra, files.get)
+        got = ctx.umi_count(stream, sorted_by_cell=sorted_mode, **args)
+        assert want["exit"] == 0 and got["code"] == 0
+        assert got["entries"][0] == lines_of(want["files"]["u"])
+        assert got["entries"][1] == lines_of(want["files"]["r"])
+        rows = [ln.split("\t")[1] for ln in want["files"]["u_rows"].splitlines()]
+        assert [f.decode() for f in got["features"]] == rows
+        cols = [ln.split("\t")[1] for ln in want["files"]["u_cols"].splitlines()]
+        assert [uo.uint_642char(c).decode() for c in got["cells"]] == cols
+        tail = want["stderr"].splitlines()
+        assert "%f total reads" % got["tot_reads"] in tail and "%f total UMI" % got["tot_umi"] in tail
+        if sorted_mode:
+            hdr = want["files"]["u"].splitlines()[1].split()
+            assert [got["n_features"], got["n_cells"], got["total"][0]] == [int(x) for x in hdr]
+
+
+def test_abi_findings(ctx):
+    rng = np.random.default_rng(77)
+    bam, stream = bamgen.tagged_bam(rng, n_cells=8, genes=20, sort_cells=False)
+    got = ctx.umi_count(stream)
+    want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u"], {"in.bam": bam}.get)
+    assert want["exit"] == 1 and got["code"] == 17  # FQG_E_UMI_NOT_SORTED
+    bam, stream = bamgen.tagged_bam(rng, n_cells=3, genes=5, gene_prefix=b"ENSG0000000000000000000")
+    assert ctx.umi_count(stream)["code"] == 18      # FQG_E_UMI_FEATURE_NAME
+    bam, stream = bamgen.tagged_bam(rng, n_cells=8, genes=20, sort_cells=False)
+    got = ctx.umi_count(stream, sorted_by_cell=False, max_cells=5)
+    want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--not_sorted_by_cell", "--max_cells", "5"],
+                                {"in.bam": bam}.get)
+    assert want["exit"] == 1 and got["code"] == 20 and ("Too many cells %d " % got["aux"]) in want["stderr"]
