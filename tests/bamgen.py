@@ -127,3 +127,99 @@ def tagged_bam(rng, n_cells=12, genes=40, reads_per_cell=(5, 120), umi_len=8, ce
         recs = [recs[i] for i in perm]
     stream = header() + b"".join(recs)
     return bgzf(stream), stream
+
+
+# ---- large, vectorised: fixed-geometry records (BASELINE.json configs[3]) --------------------------
+REC_BYTES = 124
+
+
+def _digits(a, width):
+    out = np.empty((a.size, width), dtype=np.uint8)
+    for k in range(width):
+        out[:, width - 1 - k] = (a % 10) + 48
+        a = a // 10
+    return out
+
+
+def _bases(codes, width):
+    """codes: uint64 array, 2 bits per base, most significant base first"""
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = np.empty((codes.size, width), dtype=np.uint8)
+    for k in range(width):
+        out[:, k] = lut[(codes >> np.uint64(2 * (width - 1 - k))) & np.uint64(3)]
+    return out
+
+
+def fixed_records(cell_code, gene, umi_code):
+    """One 124-byte alignment record per element: CR:Z:<16 bases> GX:Z:G<5 digits> RX:Z:<10 bases>.
+    Returns a uint8 array of shape (n, 124)."""
+    n = cell_code.size
+    rec = np.zeros((n, REC_BYTES), dtype=np.uint8)
+    core = struct.pack("<iiiIIiiii", REC_BYTES - 4, 0, 100, (4680 << 16) | (255 << 8) | 10, (0 << 16) | 1, 20, -1, -1, 0)
+    rec[:, :36] = np.frombuffer(core, dtype=np.uint8)
+    rec[:, 36] = ord("r")
+    rec[:, 37:45] = _digits(np.arange(n, dtype=np.int64) % 100000000, 8)
+    rec[:, 46:50] = np.frombuffer(struct.pack("<I", 20 << 4), dtype=np.uint8)
+    rec[:, 50:60] = 0x12
+    rec[:, 60:80] = 30
+    rec[:, 80:83] = np.frombuffer(b"CRZ", dtype=np.uint8)
+    rec[:, 83:99] = _bases(cell_code, 16)
+    rec[:, 100:103] = np.frombuffer(b"GXZ", dtype=np.uint8)
+    rec[:, 103] = ord("G")
+    rec[:, 104:109] = _digits(gene.astype(np.int64), 5)
+    rec[:, 110:113] = np.frombuffer(b"RXZ", dtype=np.uint8)
+    rec[:, 113:123] = _bases(umi_code, 10)
+    return rec
+
+
+def config4(rng, n_cells=10000, n_genes=20000, n_triples=5000000, dup=0.3, fresh_umis=False):
+    """CR-sorted synthetic alignments: `n_triples` distinct (cell, gene, UMI) plus `dup` duplicate reads.
+    fresh_umis: every distinct triple gets a UMI string of its own, in increasing order of first use
+    (needs n_triples <= 4**10): the regime in which the reference's RL_Tree behaves as a set.
+    Returns (records uint8 [n, 124], cell index, gene, umi code) in file order."""
+    cells_code = rng.choice(np.uint64(1) << np.uint64(32), size=n_cells, replace=False).astype(np.uint64)
+    cell = np.sort(rng.integers(0, n_cells, n_triples))
+    gene = rng.zipf(1.3, n_triples) % n_genes
+    if fresh_umis:
+        assert n_triples <= 4 ** 10
+        umi = rng.permutation(4 ** 10)[:n_triples].astype(np.uint64)
+    else:
+        umi = rng.integers(0, 4 ** 10, n_triples).astype(np.uint64)
+        key = (cell.astype(np.uint64) << np.uint64(40)) | (gene.astype(np.uint64) << np.uint64(20)) | umi
+        _, first = np.unique(key, return_index=True)
+        first.sort()
+        cell, gene, umi = cell[first], gene[first], umi[first]
+    n_dup = int(cell.size * dup)
+    src = rng.integers(0, cell.size, n_dup)
+    cell_all = np.concatenate([cell, cell[src]])
+    gene_all = np.concatenate([gene, gene[src]])
+    umi_all = np.concatenate([umi, umi[src]])
+    # file order: by cell, and inside a cell the originals first in their order (so that with fresh_umis
+    # the first use of every UMI happens in increasing order), then the duplicates
+    order = np.lexsort((np.arange(cell_all.size), cell_all))
+    cell_all, gene_all, umi_all = cell_all[order], gene_all[order], umi_all[order]
+    rec = fixed_records(cells_code[cell_all], gene_all, umi_all)
+    return rec, cell_all, gene_all, umi_all
+
+
+def expected_matrix(cell, gene, umi):
+    """(cell id, gene id, distinct UMIs, reads) per printed (cell, gene), sorted by cell then gene - the
+    answer the counting must give in sorted mode when every increment is 1.0 (numpy, independent of the
+    oracle).  Includes the early break of cell2MM (src/bam_umi_count.c:697): a cell prints only the
+    features whose id - 1 is smaller than the cell's UMI total."""
+    def first_ids(x):
+        u, first, inv = np.unique(x, return_index=True, return_inverse=True)
+        rank = np.empty(u.size, dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(1, u.size + 1)
+        return rank[inv], u.size
+    cid, n_cells = first_ids(cell)
+    gid, n_genes = first_ids(gene)
+    pair = cid.astype(np.int64) * (n_genes + 1) + gid
+    trip = pair * (4 ** 10) + umi.astype(np.int64)
+    up, reads = np.unique(pair, return_counts=True)
+    ut = np.unique(trip)
+    _, umis = np.unique(ut // (4 ** 10), return_counts=True)
+    c, g = up // (n_genes + 1), up % (n_genes + 1)
+    tot = np.bincount(c, weights=umis, minlength=n_cells + 1)
+    keep = (g - 1) < tot[c]
+    return c[keep], g[keep], umis[keep], reads[keep], n_cells, n_genes

@@ -132,3 +132,46 @@ def test_abi_findings(ctx):
     want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--not_sorted_by_cell", "--max_cells", "5"],
                                 {"in.bam": bam}.get)
     assert want["exit"] == 1 and got["code"] == 20 and ("Too many cells %d " % got["aux"]) in want["stderr"]
+
+
+def test_fixed_geometry_batch_against_numpy(ctx):
+    """BASELINE.json configs[3] geometry at 1/10 size: the printed matrix must equal the one numpy
+    derives from the generated (cell, gene, UMI) columns (distinct counts, first-appearance ids,
+    early break), for UMI and read counts."""
+    rng = np.random.default_rng(2024)
+    rec, cell, gene, umi = bamgen.config4(rng, n_cells=1500, n_genes=20000, n_triples=500000)
+    stream = bamgen.header() + rec.tobytes()
+    got = ctx.umi_count(stream)
+    c, g, u, r, n_cells, n_genes = bamgen.expected_matrix(cell, gene, umi)
+    assert got["code"] == 0 and (got["n_cells"], got["n_features"]) == (n_cells, n_genes)
+    assert got["entries"][0] == list(zip(g.tolist(), c.tolist(), u.tolist()))
+    assert got["entries"][1] == list(zip(g.tolist(), c.tolist(), r.tolist()))
+    assert got["total"] == [int(u.sum()), int(r.sum())]
+    assert got["tot_reads"] == float(len(cell)) and got["n_alignments"] == len(cell)
+
+
+def test_reference_binary_differential_on_fresh_umis():
+    """The reference program itself (oracle/_ref, built from the reference's sources) on a CR-sorted
+    BAM of 300 k alignments whose UMI ids only grow (the regime in which its RL_Tree is a set): all
+    three output files of both programs must be byte-identical."""
+    ref = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/bam_umi_count not built")
+    rng = np.random.default_rng(31)
+    rec, *_ = bamgen.config4(rng, n_cells=800, n_genes=5000, n_triples=230000, fresh_umis=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "in.bam"), "wb") as f:
+            f.write(bamgen.bgzf(bamgen.header() + rec.tobytes(), level=1))
+        outs = {}
+        for tag, exe in (("ref", ref), ("gpu", BIN)):
+            p = subprocess.run(["bam_umi_count", "--bam", "in.bam", "--ucounts", tag + "_u", "--rcounts", tag + "_r"],
+                               executable=exe, cwd=tmp, capture_output=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-300:]
+            outs[tag] = p.stderr.decode("latin-1").replace(tag + "_", "X_")
+            for base in ("_u", "_r"):
+                for ext in ("", "_rows", "_cols"):
+                    outs[tag + base + ext] = open(os.path.join(tmp, tag + base + ext), "rb").read()
+        assert outs["ref"] == outs["gpu"]
+        for base in ("_u", "_r"):
+            for ext in ("", "_rows", "_cols"):
+                assert outs["ref" + base + ext] == outs["gpu" + base + ext], base + ext
