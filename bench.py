@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--two-pass", action="store_true", help="census + framing passes instead of the single-pass path")
     ap.add_argument("--no-index-extra", action="store_true",
                     help="skip the untimed extra: fastq_info default mode (validate + unique read-name index)")
+    ap.add_argument("--no-umi-extra", action="store_true",
+                    help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
+    ap.add_argument("--umi-triples", type=int, default=5_000_000)
     return ap.parse_args()
 
 
@@ -71,6 +74,98 @@ def cpu_baseline(image_prefix_bytes, n_reads):
     dt = time.perf_counter() - t0
     return {"value": n_reads / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
             "sample": sample + "; oracle/fq_oracle.c restatement", "seconds": dt, "ok": r["exit"] == 0}
+
+
+def umi_extra(ctx, torch, dev, n_triples):
+    """bam_umi_count's alignment loop (fqg_umi_count) on BASELINE.json configs[3]: CR-sorted synthetic
+    alignments, 10 k cells x 20 k genes, `n_triples` distinct (cell, gene, UMI) + 30 % duplicate reads,
+    inflated records resident in HBM.  Checked at full size against the matrix numpy derives from the
+    generated columns; the reference program is timed on a sample whose UMI ids only grow (the regime in
+    which its RL_Tree is a set) and must produce byte-identical files."""
+    import numpy as np
+
+    from tests import bamgen  # generator only (no oracle code)
+
+    rng = np.random.default_rng(4242)
+    t0 = time.perf_counter()
+    rec, cell, gene, umi = bamgen.config4(rng, n_cells=10000, n_genes=20000, n_triples=n_triples)
+    hdr = bamgen.header()
+    n = rec.shape[0]
+    gen_s = time.perf_counter() - t0
+    stream = torch.empty(len(hdr) + rec.size + 64, dtype=torch.uint8, device=dev)
+    stream[: len(hdr)] = torch.frombuffer(bytearray(hdr), dtype=torch.uint8).to(dev)
+    stream[len(hdr): len(hdr) + rec.size] = torch.from_numpy(rec.reshape(-1)).to(dev)
+    torch.cuda.synchronize()
+    offs = (np.arange(n, dtype=np.uint64) * np.uint64(bamgen.REC_BYTES) + np.uint64(len(hdr)))
+
+    def run(want_entries):
+        return ctx.umi_count(stream.data_ptr(), offsets=_OffsetArray(offs), nbytes=len(hdr) + rec.size,
+                             want_entries=want_entries)
+
+    run(False)  # warm-up
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    r = run(False)
+    ctx.synchronize()
+    wall = time.perf_counter() - t1
+    prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_umi")}
+    ctx.profile(False)
+    got = run(True)
+    c, g, u, rd, n_cells, n_genes = bamgen.expected_matrix(cell, gene, umi)
+    exact = (got["code"] == 0 and (got["n_cells"], got["n_features"]) == (n_cells, n_genes)
+             and got["entries"][0] == list(zip(g.tolist(), c.tolist(), u.tolist()))
+             and got["entries"][1] == list(zip(g.tolist(), c.tolist(), rd.tolist())))
+    kernels_ms = sum(prof.values())
+    out = {
+        "what": "bam_umi_count alignment loop + output decisions (fqg_umi_count), BASELINE.json configs[3]",
+        "alignments": n, "distinct_triples": int(len(np.unique((cell.astype(np.int64) * 20000 + gene) * 4 ** 10 + umi.astype(np.int64)))),
+        "cells": n_cells, "genes": n_genes, "matrix_lines": len(got["entries"][0]) if got["code"] == 0 else None,
+        "record_bytes": bamgen.REC_BYTES, "wall_ms_one_call_incl_allocations": wall * 1e3,
+        "kernels_ms": kernels_ms, "Malignments_per_s_wall": n / wall / 1e6,
+        "Malignments_per_s_kernels_only": n / (kernels_ms * 1e-3) / 1e6 if kernels_ms else None,
+        "kernels_ms_breakdown": prof, "matrix_identical_to_numpy_expectation": bool(exact),
+        "host_generation_s": gen_s,
+    }
+    # the reference program on a sample it can count correctly
+    ref = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
+    mine = os.path.join(REPO, "bin", "bam_umi_count")
+    if os.path.exists(ref) and os.path.exists(mine):
+        m = min(n_triples, 1_000_000)
+        rec2, *_ = bamgen.config4(np.random.default_rng(7), n_cells=2000, n_genes=20000, n_triples=m, fresh_umis=True)
+        with tempfile.TemporaryDirectory() as tmp:
+            with open(os.path.join(tmp, "in.bam"), "wb") as f:
+                f.write(bamgen.bgzf(hdr + rec2.tobytes(), level=1))
+            files, secs = {}, {}
+            for tag, exe in (("ref", ref), ("gpu", mine)):
+                t2 = time.perf_counter()
+                p = subprocess.run(["bam_umi_count", "--bam", "in.bam", "--ucounts", tag + "_u", "--rcounts", tag + "_r"],
+                                   executable=exe, cwd=tmp, capture_output=True)
+                secs[tag] = time.perf_counter() - t2
+                files[tag] = [open(os.path.join(tmp, tag + b + e), "rb").read() if p.returncode == 0 else None
+                              for b in ("_u", "_r") for e in ("", "_rows", "_cols")]
+        out["cpu_baseline"] = {
+            "value": rec2.shape[0] / secs["ref"] / 1e6, "unit": "Malignments/s", "cores": 1, "kind": "reference",
+            "sample": f"{rec2.shape[0]} alignments, 2000 cells, {m} distinct triples with increasing UMI ids, BGZF level 1; "
+                      "reference bam_umi_count (single-threaded), whole program incl. BGZF inflate",
+            "seconds": secs["ref"], "drop_in_program_seconds_same_input": secs["gpu"],
+            "files_byte_identical_to_reference": files["ref"] == files["gpu"] and files["ref"][0] is not None,
+        }
+    return out
+
+
+class _OffsetArray:
+    """numpy uint64 offsets presented the way Context.umi_count takes precomputed offsets"""
+
+    def __init__(self, a):
+        import ctypes as C
+        self.a = a
+        self.n = int(a.size)
+        self.c = (C.c_uint64 * max(1, self.n)).from_buffer(a)
+
+    def __len__(self):
+        return self.n
 
 
 def committed_traffic(kernel, n_reads, read_len, record_bytes):
@@ -223,6 +318,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             m = min(n, a.cpu_sample_reads)
             out["cpu_baseline"] = cpu_baseline(bytes(image[: m * R].cpu().numpy()), m)
+        if world == 1 and not a.no_umi_extra:
+            del image
+            torch.cuda.empty_cache()
+            out["umi_count_extra"] = umi_extra(ctx, torch, dev, a.umi_triples)
         print(json.dumps(out), flush=True)
     acc.close()
     ctx.close()

@@ -384,7 +384,10 @@ class Context:
             n_rec = n.value
         else:
             n_rec = len(offsets)
-            offs = (C.c_uint64 * max(1, n_rec))(*offsets) if not isinstance(offsets, C.Array) else offsets
+            if hasattr(offsets, "c"):       # a wrapper that already holds a ctypes array (bench.py)
+                offs = offsets.c
+            else:
+                offs = offsets if isinstance(offsets, C.Array) else (C.c_uint64 * max(1, n_rec))(*offsets)
         p = UmiParams()
         p.feat_tag, p.cell_tag, p.umi_tag = feat_tag[:2], cell_tag[:2], umi_tag[:2]
         p.sorted_by_cell, p.uniq_mapped_only = int(sorted_by_cell), int(uniq_mapped_only)
