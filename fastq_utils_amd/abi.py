@@ -34,6 +34,8 @@ EXPORTS = [
     "fqg_barcodes_transform", "fqg_barcodes_output",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
     "fqg_umi_cells", "fqg_umi_entries",
+    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
+    "fqg_fpset_candidates", "fqg_frame_name",
 ]
 
 
@@ -170,6 +172,16 @@ def load():
     L.fqg_index_insert_unique.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_names_compare.argtypes = [vp, vp, C.POINTER(FileState), vp, C.POINTER(FileState), C.POINTER(IndexResult)]
+    L.fqg_fp_owner.argtypes = [u64, C.c_uint32]
+    L.fqg_fp_owner.restype = C.c_uint32
+    L.fqg_names_fingerprints.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, C.POINTER(u64)]
+    L.fqg_fpset_create.argtypes = [vp, u64, C.POINTER(vp)]
+    L.fqg_fpset_destroy.argtypes = [vp]
+    L.fqg_fpset_destroy.restype = None
+    L.fqg_fpset_insert.argtypes = [vp, vp, vp, u64]
+    L.fqg_fpset_candidates.argtypes = [vp, vp, vp, u64, C.POINTER(u64), u64, C.POINTER(u64)]
+    L.fqg_frame_name.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_char_p, u64]
+    L.fqg_frame_name.restype = C.c_int64
     L.fqg_pack_barcode.argtypes = [C.c_char_p]
     L.fqg_pack_barcode.restype = u64
     L.fqg_unpack_barcode.argtypes = [u64, C.c_char_p]
@@ -259,6 +271,32 @@ class Frame:
             self.h = None
 
 
+class FingerprintSet:
+    """Owner-side set of read-name fingerprints (fqg_fpset): smallest global record index per value."""
+
+    def __init__(self, ctx, expected):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(load().fqg_fpset_create(ctx.h, expected, C.byref(h)))
+        self.h = h
+
+    def insert(self, device_ptr, n):
+        self.ctx._check(load().fqg_fpset_insert(self.ctx.h, self.h, C.c_void_p(int(device_ptr)), n))
+
+    def candidates(self, device_ptr, n, cap=1 << 16):
+        pairs = (C.c_uint64 * (2 * cap))()
+        found = C.c_uint64()
+        self.ctx._check(load().fqg_fpset_candidates(self.ctx.h, self.h, C.c_void_p(int(device_ptr)), n, pairs, cap,
+                                                    C.byref(found)))
+        k = min(found.value, cap)
+        return [(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(k)], int(found.value)
+
+    def close(self):
+        if self.h:
+            load().fqg_fpset_destroy(self.h)
+            self.h = None
+
+
 class NameIndex:
     """Device read-name index (fqg_index)."""
 
@@ -336,6 +374,24 @@ class Context:
 
     def retain_frame(self):
         return Frame(self)
+
+    def names_fingerprints(self, frame, state, record_base, n_owners, out_device_ptr):
+        """(fingerprint, global index) pairs of a retained frame (None: the current one) into device
+        memory, bucketed by owner; returns the bucket sizes."""
+        counts = (C.c_uint64 * n_owners)()
+        self._check(load().fqg_names_fingerprints(self.h, frame.h if frame is not None else None, C.byref(state),
+                                                  record_base, n_owners, C.c_void_p(int(out_device_ptr)), counts))
+        return [int(x) for x in counts]
+
+    def fingerprint_set(self, expected):
+        return FingerprintSet(self, expected)
+
+    def frame_name(self, frame, state, record):
+        buf = C.create_string_buffer(1024)
+        n = load().fqg_frame_name(self.h, frame.h, C.byref(state), record, buf, 1024)
+        if n < 0:
+            self._check(int(n))
+        return buf.raw[:n]
 
     def name_index(self, expected_names=0):
         return NameIndex(self, expected_names)

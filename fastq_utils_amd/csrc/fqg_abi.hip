@@ -1313,5 +1313,6 @@ int fqg_synth_fastq(fqg_ctx* c, void* device_out, uint64_t n_records, uint32_t r
 }
 
 #include "fqg_umi_abi.inc"
+#include "fqg_fp_abi.inc"
 
 }  // extern "C"

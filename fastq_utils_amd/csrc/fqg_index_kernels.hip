@@ -268,4 +268,110 @@ __global__ __launch_bounds__(kBlock) void k_names_compare(FrameView a, int fmt_a
   if (my_wrong != kNoRecord) atomicMin(&call->first_wrong, my_wrong);
 }
 
+// ------------------------------------------------------------------------------------------
+// read names across GPUs: every record's canonical name becomes a 64-bit fingerprint
+// + its GLOBAL record index (16 bytes); fingerprints travel to an owner rank (all-to-all over
+// RCCL), whose set keeps the smallest index per fingerprint.  A record that is not the earliest
+// holder of its fingerprint is a CANDIDATE duplicate; candidates are confirmed on the name bytes
+// by their home ranks, so a hash collision can neither fake nor hide a duplicate.
+// ------------------------------------------------------------------------------------------
+struct FpRec {
+  unsigned long long fp, idx;
+};
+constexpr int kMaxOwners = 64;
+
+__device__ __forceinline__ uint32_t fp_owner(unsigned long long fp, uint32_t n_owners) {
+  return (uint32_t)(((fp >> 32) * (unsigned long long)n_owners) >> 32);  // high bits: the table uses the low ones
+}
+
+// pass 0: count per owner; pass 1: write into the owner's bucket (cursor[] starts at the bucket offsets)
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int fmt, int is_pe, int may_have_nul,
+                                                              uint64_t record_base, uint32_t n_owners,
+                                                              unsigned long long* __restrict__ cursor,
+                                                              FpRec* __restrict__ out) {
+  __shared__ unsigned int s_cnt[kMaxOwners];
+  __shared__ unsigned long long s_base[kMaxOwners];
+  const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (threadIdx.x < kMaxOwners) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  bool have = false;
+  FpRec me{0, 0};
+  uint32_t owner = 0, slot = 0;
+  if (r < f.n_records) {
+    const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+    const uint64_t e = f.line_end[4 * r];
+    const uint8_t* line = f.img + b;
+    if (line[0] == '@') {  // (a wrong header is the local pass's finding, src/fastq.c:448)
+      uint32_t acct;
+      const uint32_t n = canon_name(line, (uint32_t)(e - b), e < f.nbytes ? 1u : 0u, fmt, is_pe, may_have_nul, &acct);
+      unsigned long long h = hash_name(line + 1, n);
+      if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
+      me.fp = h;
+      me.idx = record_base + r;
+      owner = fp_owner(h, n_owners);
+      slot = atomicAdd(&s_cnt[owner], 1u);
+      have = true;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < n_owners && s_cnt[threadIdx.x])
+    s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+  if (PASS == 0) return;
+  __syncthreads();
+  if (have) out[s_base[owner] + slot] = me;
+}
+
+struct FpSetView {
+  unsigned long long* fp;       // kSlotEmpty = free
+  unsigned long long* min_idx;
+  uint64_t mask;
+};
+
+__global__ __launch_bounds__(kBlock) void k_fpset_insert(const FpRec* __restrict__ in, uint64_t n, FpSetView S,
+                                                         unsigned int* __restrict__ full) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const FpRec me = in[i];
+  uint64_t at = me.fp & S.mask;
+  for (uint64_t probes = 0; probes <= S.mask; ++probes, at = (at + 1) & S.mask) {
+    unsigned long long cur = S.fp[at];
+    if (cur == kSlotEmpty) {
+      cur = atomicCAS(&S.fp[at], kSlotEmpty, me.fp);
+      if (cur == kSlotEmpty) cur = me.fp;
+    }
+    if (cur == me.fp) {
+      atomicMin(&S.min_idx[at], me.idx);
+      return;
+    }
+  }
+  atomicOr(full, 1u);
+}
+
+// every received fingerprint that is not the earliest holder of its value -> (earliest, this)
+__global__ __launch_bounds__(kBlock) void k_fpset_candidates(const FpRec* __restrict__ in, uint64_t n, FpSetView S,
+                                                             unsigned long long* __restrict__ pairs,
+                                                             unsigned long long cap,
+                                                             unsigned long long* __restrict__ count) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const FpRec me = in[i];
+  uint64_t at = me.fp & S.mask;
+  for (uint64_t probes = 0; probes <= S.mask; ++probes, at = (at + 1) & S.mask) {
+    const unsigned long long cur = S.fp[at];
+    if (cur == kSlotEmpty) return;
+    if (cur == me.fp) {
+      const unsigned long long first = S.min_idx[at];
+      if (first != me.idx) {
+        const unsigned long long k = atomicAdd(count, 1ull);
+        if (k < cap) {
+          pairs[2 * k] = first;
+          pairs[2 * k + 1] = me.idx;
+        }
+      }
+      return;
+    }
+  }
+}
+
 }  // namespace fqg

@@ -2,8 +2,13 @@
 
 Validation shards trivially: every rank frames and validates its own record-aligned shard; no
 data-path collective is needed.  What has to be combined at the end is tiny: per-rank statistics
-blobs (fqg_acc_export) and the first finding in file order.  These helpers are pure Python so that
-they can be exercised with the gloo backend on CPU.
+blobs (fqg_acc_export) and the first finding in file order.
+
+The unique-name test of the index mode is the one step with a real exchange:
+`exchange_fingerprints` is ONE all-to-all (RCCL over xGMI with the nccl backend) of 16-byte
+(fingerprint, global record index) pairs bucketed by owner rank, `global_first_duplicate` runs the
+whole protocol.  The helpers take the process group as an argument so that the exchange itself can
+be exercised with the gloo backend on CPU tensors.
 """
 import struct
 
@@ -73,3 +78,107 @@ def median_rl(merged, second=None):
             break
         crl += 1
     return crl
+
+
+# ---- read names across ranks ---------------------------------------------------------------------
+FP_BYTES = 16  # fqg_fp: u64 fingerprint, u64 global record index
+
+
+def exchange_fingerprints(send, send_counts, group=None):
+    """One all-to-all of fingerprint buckets.  `send`: uint8 tensor holding this rank's buckets back to
+    back (bucket o = send_counts[o] pairs of FP_BYTES bytes, for owner o); returns (received uint8
+    tensor, counts received from every rank).  Works on device tensors with nccl (= RCCL) and on CPU
+    tensors with gloo."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    assert len(send_counts) == world
+    cnt_in = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+    cnt_out = torch.empty(world, dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(cnt_out, cnt_in, group=group)
+    recv_counts = [int(x) for x in cnt_out.tolist()]
+    recv = torch.empty(sum(recv_counts) * FP_BYTES, dtype=torch.uint8, device=send.device)
+    dist.all_to_all_single(recv, send[: sum(send_counts) * FP_BYTES],
+                           output_split_sizes=[c * FP_BYTES for c in recv_counts],
+                           input_split_sizes=[c * FP_BYTES for c in send_counts], group=group)
+    return recv, recv_counts
+
+
+def resolve_candidates(candidates, name_of):
+    """candidates: (earlier, later) global record indices with equal fingerprints; name_of(idx) ->
+    bytes.  Returns the smallest `later` whose name really equals the earlier one's, or None: the
+    record at which the serial loop over the concatenated shards reports "duplicated sequence"."""
+    best = None
+    for first, later in sorted(candidates, key=lambda p: p[1]):
+        if best is not None and later >= best:
+            break
+        if name_of(first) == name_of(later):
+            best = later
+    return best
+
+
+def global_first_duplicate(ctx, frames, state, record_base, group=None, device=None):
+    """Every rank calls this with its retained frames [(frame, n_records)] of ONE file (in file order;
+    the frames' records are record_base, record_base + 1, ... globally).  Returns (global index of the
+    first record whose name already occurred at a smaller global index, its name), or None - the same
+    on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    n_local = sum(n for _, n in frames)
+    send = torch.empty(max(1, n_local) * FP_BYTES, dtype=torch.uint8, device=dev)
+    # one bucketed export per frame, then regroup by owner (frames are few: one per piece of the file)
+    per_frame, base = [], record_base
+    off = 0
+    for fr, n in frames:
+        counts = ctx.names_fingerprints(fr, state, base, world, send.data_ptr() + off * FP_BYTES)
+        per_frame.append((off, counts))
+        off += sum(counts)
+        base += n
+    if len(per_frame) > 1:
+        parts = [[] for _ in range(world)]
+        for o0, counts in per_frame:
+            p = o0
+            for o, c in enumerate(counts):
+                parts[o].append(send[p * FP_BYTES:(p + c) * FP_BYTES])
+                p += c
+        send_counts = [sum(c[o] for _, c in per_frame) for o in range(world)]
+        send = torch.cat([t for o in range(world) for t in parts[o]]) if off else send
+    else:
+        send_counts = per_frame[0][1] if per_frame else [0] * world
+    recv, recv_counts = exchange_fingerprints(send, send_counts, group)
+    n_recv = sum(recv_counts)
+    fps = ctx.fingerprint_set(max(1024, n_recv))
+    try:
+        fps.insert(recv.data_ptr(), n_recv)
+        cand, found = fps.candidates(recv.data_ptr(), n_recv)
+    finally:
+        fps.close()
+    if found > len(cand):
+        raise RuntimeError(f"{found} candidate duplicates exceed the buffer: the input repeats names massively")
+    all_cand = [None] * world
+    dist.all_gather_object(all_cand, cand, group=group)
+    flat = [p for c in all_cand for p in c]
+    if not flat:
+        return None
+    # every rank names the candidates it holds; then everybody can resolve
+    mine = {}
+    bases, b = [], record_base
+    for fr, n in frames:
+        bases.append((b, n, fr))
+        b += n
+    for pair in flat:
+        for g in pair:
+            for b0, n, fr in bases:
+                if b0 <= g < b0 + n and g not in mine:
+                    mine[g] = ctx.frame_name(fr, state, g - b0)
+    names = [None] * world
+    dist.all_gather_object(names, mine, group=group)
+    table = {}
+    for d in names:
+        table.update(d)
+    hit = resolve_candidates(flat, table.__getitem__)
+    return None if hit is None else (hit, table[hit])

@@ -66,3 +66,48 @@ def test_blob_roundtrip_matches_library_layout():
     p = fdist.parse_acc_blob(blob)
     assert p["num_rds"] == 10 and p["hist"] == {50: 1, 151: 9}
     assert len(blob) == 32 + 8 + 4 * 8
+
+
+def _fp_worker(rank, world, port, q):
+    import torch
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank r sends (10 * r + o + 1) pairs to owner o; pair k of that bucket = (fp, idx) = (r * 1000 + o, k)
+    counts = [10 * rank + o + 1 for o in range(world)]
+    vals = []
+    for o, c in enumerate(counts):
+        for k in range(c):
+            vals += [rank * 1000 + o, k]
+    send = torch.tensor(vals, dtype=torch.int64).view(torch.uint8)
+    recv, recv_counts = fdist.exchange_fingerprints(send, counts)
+    got = recv.view(torch.int64).view(-1, 2).tolist()
+    q.put((rank, recv_counts, got))
+    dist.destroy_process_group()
+
+
+def test_fingerprint_exchange_is_one_all_to_all_of_buckets():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {r: (c, g) for r, c, g in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for owner in range(world):
+        counts, got = out[owner]
+        assert counts == [10 * r + owner + 1 for r in range(world)]
+        want = [[r * 1000 + owner, k] for r in range(world) for k in range(10 * r + owner + 1)]
+        assert got == want
+
+
+def test_candidates_are_confirmed_on_names_and_the_earliest_repeat_wins():
+    names = {5: b"a", 9: b"a", 3: b"x", 7: b"y", 2: b"q", 11: b"q", 20: b"z", 21: b"z"}
+    # (3, 7): equal fingerprints, different names - a collision, not a duplicate
+    assert fdist.resolve_candidates([(3, 7), (5, 9), (2, 11), (20, 21)], names.__getitem__) == 9
+    assert fdist.resolve_candidates([(3, 7)], names.__getitem__) is None
+    assert fdist.resolve_candidates([], names.__getitem__) is None
