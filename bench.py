@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--two-pass", action="store_true", help="census + framing passes instead of the single-pass path")
     ap.add_argument("--no-index-extra", action="store_true",
                     help="skip the untimed extra: fastq_info default mode (validate + unique read-name index)")
+    ap.add_argument("--no-dedup-extra", action="store_true",
+                    help="skip the extra: unique read names across ALL ranks (fingerprint all-to-all over RCCL)")
+    ap.add_argument("--dedup-extra", action="store_true",
+                    help="run that extra at --gpus 1 too (a 1-rank RCCL group; off by default: RCCL prints a banner)")
     ap.add_argument("--no-umi-extra", action="store_true",
                     help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
     ap.add_argument("--umi-triples", type=int, default=5_000_000)
@@ -254,6 +258,48 @@ def main():
                 acc.merge(b)
             assert acc.read()["num_rds"] == n * a.steps * world
 
+    dedup = None
+    if not a.no_dedup_extra and (world > 1 or a.dedup_extra):
+        # untimed extra on every rank: the unique-name test of fastq_info's index mode over the names of
+        # ALL ranks: 16-byte (fingerprint, global index) pairs, one all-to-all over RCCL, owner
+        # sets, candidates confirmed on the name bytes.  Names are unique by construction -> no finding.
+        try:
+            from fastq_utils_amd import dist as fdist
+
+            own_group = False
+            if world == 1 and not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29655")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                own_group = True
+            rv = ctx.validate(image.data_ptr(), None, st, final=True, flags=fq.abi.VALIDATE_NO_STATS, nbytes=n * R)
+            frame = ctx.retain_frame()
+            barrier()
+            ctx.profile(True)
+            ctx.profile_reset()
+            t1 = time.perf_counter()
+            hit = fdist.global_first_duplicate(ctx, [(frame, rv["n_records"])], st, rank * n, device=dev)
+            barrier()
+            dt_dedup = time.perf_counter() - t1
+            pd = ctx.profile_read()
+            ctx.profile(False)
+            frame.release()
+            tt = torch.tensor([dt_dedup], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dedup = {
+                "what": "unique read names over all ranks: fingerprint export + all-to-all (RCCL) + owner sets + candidate check",
+                "names_total": n * world, "finding": None if hit is None else [int(hit[0]), hit[1].decode("latin-1")],
+                "wall_ms_max_over_ranks": float(tt.item()) * 1e3,
+                "Mnames_per_s_whole_job": n * world / float(tt.item()) / 1e6,
+                "bytes_exchanged_per_rank": n * 16,
+                "kernels_ms_rank0": {k: v[1] for k, v in pd.items() if k.startswith("k_") and v[0] > 0},
+            }
+            if own_group:
+                dist.destroy_process_group()
+        except Exception as e:  # the headline line must survive a failure of an extra
+            dedup = {"error": repr(e)[:300]}
+
     if rank == 0:
         kernels = {k: v for k, v in prof.items() if k.startswith("k_") and v[0] > 0}
         dom = max(kernels, key=lambda k: kernels[k][1])
@@ -291,6 +337,8 @@ def main():
                 "kernels_ms_per_step": {k: v[1] / a.steps for k, v in kernels.items()},
             },
         }
+        if dedup is not None:
+            out["dedup_extra"] = dedup
         if world == 1 and not a.no_index_extra:
             # untimed extra: fastq_info's default mode = the same pass + the unique read-name index
             acc2 = ctx.accumulator()

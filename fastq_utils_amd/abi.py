@@ -179,7 +179,7 @@ def load():
     L.fqg_fpset_destroy.argtypes = [vp]
     L.fqg_fpset_destroy.restype = None
     L.fqg_fpset_insert.argtypes = [vp, vp, vp, u64]
-    L.fqg_fpset_candidates.argtypes = [vp, vp, vp, u64, C.POINTER(u64), u64, C.POINTER(u64)]
+    L.fqg_fpset_candidates.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
     L.fqg_frame_name.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_char_p, u64]
     L.fqg_frame_name.restype = C.c_int64
     L.fqg_pack_barcode.argtypes = [C.c_char_p]
@@ -272,7 +272,7 @@ class Frame:
 
 
 class FingerprintSet:
-    """Owner-side set of read-name fingerprints (fqg_fpset): smallest global record index per value."""
+    """Owner-side collection of read-name fingerprints (fqg_fpset)."""
 
     def __init__(self, ctx, expected):
         self.ctx = ctx
@@ -283,11 +283,10 @@ class FingerprintSet:
     def insert(self, device_ptr, n):
         self.ctx._check(load().fqg_fpset_insert(self.ctx.h, self.h, C.c_void_p(int(device_ptr)), n))
 
-    def candidates(self, device_ptr, n, cap=1 << 16):
+    def candidates(self, cap=1 << 16):
         pairs = (C.c_uint64 * (2 * cap))()
         found = C.c_uint64()
-        self.ctx._check(load().fqg_fpset_candidates(self.ctx.h, self.h, C.c_void_p(int(device_ptr)), n, pairs, cap,
-                                                    C.byref(found)))
+        self.ctx._check(load().fqg_fpset_candidates(self.ctx.h, self.h, pairs, cap, C.byref(found)))
         k = min(found.value, cap)
         return [(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(k)], int(found.value)
 

@@ -84,37 +84,78 @@ def median_rl(merged, second=None):
 FP_BYTES = 16  # fqg_fp: u64 fingerprint, u64 global record index
 
 
-def exchange_fingerprints(send, send_counts, group=None):
-    """One all-to-all of fingerprint buckets.  `send`: uint8 tensor holding this rank's buckets back to
+ROUND_PAIRS = 1 << 24  # pairs per (sender, owner) and round: 256 MiB messages
+
+
+def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
+    """The all-to-all of fingerprint buckets.  `send`: uint8 tensor holding this rank's buckets back to
     back (bucket o = send_counts[o] pairs of FP_BYTES bytes, for owner o); returns (received uint8
-    tensor, counts received from every rank).  Works on device tensors with nccl (= RCCL) and on CPU
-    tensors with gloo."""
+    tensor with the pairs grouped by sender, counts received from every rank).  Works on device
+    tensors with nccl (= RCCL) and on CPU tensors with gloo.  Buckets larger than `round_pairs` go in
+    several rounds of at most 256 MiB per peer (a single 1.6 GB all_to_all_single was observed to
+    deliver wrong data with RCCL 2.26 / torch 2.10)."""
     import torch
     import torch.distributed as dist
 
+    rp = round_pairs or ROUND_PAIRS
     world = dist.get_world_size(group)
     assert len(send_counts) == world
     cnt_in = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
     cnt_out = torch.empty(world, dtype=torch.int64, device=send.device)
     dist.all_to_all_single(cnt_out, cnt_in, group=group)
     recv_counts = [int(x) for x in cnt_out.tolist()]
-    recv = torch.empty(sum(recv_counts) * FP_BYTES, dtype=torch.uint8, device=send.device)
-    dist.all_to_all_single(recv, send[: sum(send_counts) * FP_BYTES],
-                           output_split_sizes=[c * FP_BYTES for c in recv_counts],
-                           input_split_sizes=[c * FP_BYTES for c in send_counts], group=group)
+    biggest = torch.tensor([max(send_counts + [0])], dtype=torch.int64, device=send.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(biggest.item()) // rp))
+    recv = torch.empty(max(1, sum(recv_counts)) * FP_BYTES, dtype=torch.uint8, device=send.device)
+    send_start = [sum(send_counts[:o]) for o in range(world)]
+    recv_start = [sum(recv_counts[:r]) for r in range(world)]
+    for k in range(rounds):
+        s_lo = [min(c, k * rp) for c in send_counts]
+        s_n = [min(c, (k + 1) * rp) - lo for c, lo in zip(send_counts, s_lo)]
+        r_lo = [min(c, k * rp) for c in recv_counts]
+        r_n = [min(c, (k + 1) * rp) - lo for c, lo in zip(recv_counts, r_lo)]
+        if rounds == 1:
+            src, dst = send[: sum(send_counts) * FP_BYTES], recv[: sum(recv_counts) * FP_BYTES]
+        else:
+            parts = [send[(send_start[o] + s_lo[o]) * FP_BYTES:(send_start[o] + s_lo[o] + s_n[o]) * FP_BYTES]
+                     for o in range(world)]
+            src = torch.cat(parts) if sum(s_n) else send[:0]
+            dst = torch.empty(sum(r_n) * FP_BYTES, dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(dst, src, output_split_sizes=[c * FP_BYTES for c in r_n],
+                               input_split_sizes=[c * FP_BYTES for c in s_n], group=group)
+        if rounds > 1:
+            p = 0
+            for r in range(world):
+                recv[(recv_start[r] + r_lo[r]) * FP_BYTES:(recv_start[r] + r_lo[r] + r_n[r]) * FP_BYTES] = \
+                    dst[p * FP_BYTES:(p + r_n[r]) * FP_BYTES]
+                p += r_n[r]
+    recv = recv[: sum(recv_counts) * FP_BYTES]
+    if recv.is_cuda:
+        torch.cuda.synchronize(recv.device)  # the library launches on its own stream: the data must have landed
     return recv, recv_counts
 
 
 def resolve_candidates(candidates, name_of):
-    """candidates: (earlier, later) global record indices with equal fingerprints; name_of(idx) ->
-    bytes.  Returns the smallest `later` whose name really equals the earlier one's, or None: the
-    record at which the serial loop over the concatenated shards reports "duplicated sequence"."""
+    """candidates: (earliest holder, later holder) global record indices with equal fingerprints;
+    name_of(idx) -> bytes.  Returns the smallest index whose name really equals the name of an earlier
+    holder of the same fingerprint, or None: the record at which the serial loop over the concatenated
+    shards reports "duplicated sequence".  All holders of one fingerprint are compared with each
+    other, so a collision of two different names cannot hide a repeat of the second one."""
+    groups = {}
+    for first, later in candidates:
+        groups.setdefault(first, set()).add(later)
     best = None
-    for first, later in sorted(candidates, key=lambda p: p[1]):
-        if best is not None and later >= best:
-            break
-        if name_of(first) == name_of(later):
-            best = later
+    for first, laters in groups.items():
+        seen = {name_of(first)}
+        for g in sorted(laters):
+            if best is not None and g >= best:
+                break
+            nm = name_of(g)
+            if nm in seen:
+                best = g
+                break
+            seen.add(nm)
     return best
 
 
@@ -154,7 +195,7 @@ def global_first_duplicate(ctx, frames, state, record_base, group=None, device=N
     fps = ctx.fingerprint_set(max(1024, n_recv))
     try:
         fps.insert(recv.data_ptr(), n_recv)
-        cand, found = fps.candidates(recv.data_ptr(), n_recv)
+        cand, found = fps.candidates()
     finally:
         fps.close()
     if found > len(cand):

@@ -208,8 +208,8 @@ int fqg_names_compare(fqg_ctx *ctx, const fqg_frame *a, const fqg_file_state *st
  * The unique-name test of fastq_index_readnames() (src/fastq.c:422-425) when the records of a file
  * are sharded over several GPUs.  Every rank turns the canonical names of its frames
  * into (64-bit fingerprint, GLOBAL record index) pairs bucketed by owner rank; the buckets travel
- * with one all-to-all (RCCL, done by the caller: fastq_utils_amd/dist.py); the owner's set keeps the
- * smallest index per fingerprint and lists every later holder as a CANDIDATE duplicate; candidates are
+ * with one all-to-all (RCCL, done by the caller: fastq_utils_amd/dist.py); the owner sorts what
+ * it received by fingerprint and lists, per value held more than once, its holders as CANDIDATE duplicates; candidates are
  * confirmed on the name bytes (fqg_frame_name on their home ranks), so equality is still decided on
  * the bytes and the finding is the one the serial loop would make over the concatenated shards. */
 typedef struct {
@@ -229,10 +229,9 @@ int fqg_fpset_create(fqg_ctx *ctx, uint64_t expected, fqg_fpset **out);
 void fqg_fpset_destroy(fqg_fpset *set);
 /* fps: DEVICE memory, n fqg_fp */
 int fqg_fpset_insert(fqg_ctx *ctx, fqg_fpset *set, const void *fps_device, uint64_t n);
-/* After every insert: pairs[2k], pairs[2k+1] (host) = (earliest holder, later holder) for the received
- * fingerprints that are not the earliest holder of their value; *n_found may exceed cap. */
-int fqg_fpset_candidates(fqg_ctx *ctx, fqg_fpset *set, const void *fps_device, uint64_t n, uint64_t *pairs,
-                         uint64_t cap, uint64_t *n_found);
+/* After every insert: pairs[2k], pairs[2k+1] (host) = (earliest holder, another holder) for every
+ * fingerprint value held by more than one of the inserted records; *n_found may exceed cap. */
+int fqg_fpset_candidates(fqg_ctx *ctx, fqg_fpset *set, uint64_t *pairs, uint64_t cap, uint64_t *n_found);
 /* canonical read name (fastq_get_readname, src/fastq.c:488-512) of record `record` of a retained frame,
  * NUL-terminated into out[cap]; returns its length or a negative FQG_ERR_* */
 int64_t fqg_frame_name(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t record, char *out,

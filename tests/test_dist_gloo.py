@@ -83,6 +83,9 @@ def _fp_worker(rank, world, port, q):
     send = torch.tensor(vals, dtype=torch.int64).view(torch.uint8)
     recv, recv_counts = fdist.exchange_fingerprints(send, counts)
     got = recv.view(torch.int64).view(-1, 2).tolist()
+    # the same exchange in rounds of 4 pairs per peer must deliver the same bytes
+    recv2, recv_counts2 = fdist.exchange_fingerprints(send, counts, round_pairs=4)
+    assert recv_counts2 == recv_counts and recv2.view(torch.int64).view(-1, 2).tolist() == got
     q.put((rank, recv_counts, got))
     dist.destroy_process_group()
 
@@ -110,4 +113,7 @@ def test_candidates_are_confirmed_on_names_and_the_earliest_repeat_wins():
     # (3, 7): equal fingerprints, different names - a collision, not a duplicate
     assert fdist.resolve_candidates([(3, 7), (5, 9), (2, 11), (20, 21)], names.__getitem__) == 9
     assert fdist.resolve_candidates([(3, 7)], names.__getitem__) is None
+    # a collision (30 vs 31) must not hide the repeat of the second name (31 == 33)
+    coll = {30: b"u", 31: b"v", 33: b"v"}
+    assert fdist.resolve_candidates([(30, 31), (30, 33)], coll.__getitem__) == 33
     assert fdist.resolve_candidates([], names.__getitem__) is None

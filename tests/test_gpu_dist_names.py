@@ -60,9 +60,10 @@ def virtual_first_duplicate(ctx, img, n_shards):
             parts.append(bufs[r][start:start + counts[r][owner] * fdist.FP_BYTES])
         recv = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device="cuda")
         n_recv = recv.numel() // fdist.FP_BYTES
+        torch.cuda.synchronize()  # torch.cat ran on torch's stream, the library launches on its own
         s = ctx.fingerprint_set(max(1024, n_recv))
         s.insert(recv.data_ptr(), n_recv)
-        c, found = s.candidates(recv.data_ptr(), n_recv)
+        c, found = s.candidates()
         assert found == len(c)
         cands += c
         s.close()
