@@ -44,6 +44,9 @@ def parse():
                     help="skip the extra: unique read names across ALL ranks (fingerprint all-to-all over RCCL)")
     ap.add_argument("--dedup-extra", action="store_true",
                     help="run that extra at --gpus 1 too (a 1-rank RCCL group; off by default: RCCL prints a banner)")
+    ap.add_argument("--no-barcodes-extra", action="store_true",
+                    help="skip the extra: fastq_pre_barcodes 10x v2 layout (BASELINE.json configs[2])")
+    ap.add_argument("--barcode-pairs", type=int, default=200_000_000, help="read pairs of that extra (BASELINE: 200 M)")
     ap.add_argument("--no-umi-extra", action="store_true",
                     help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
     ap.add_argument("--umi-triples", type=int, default=5_000_000)
@@ -78,6 +81,102 @@ def cpu_baseline(image_prefix_bytes, n_reads):
     dt = time.perf_counter() - t0
     return {"value": n_reads / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
             "sample": sample + "; oracle/fq_oracle.c restatement", "seconds": dt, "ok": r["exit"] == 0}
+
+
+def barcodes_extra(ctx, fq, torch, dev, n_pairs):
+    """fastq_pre_barcodes' main loop (fqg_barcodes_transform) on BASELINE.json configs[2]: 10x v2 layout,
+    index1 = 16 bp cell barcode + 10 bp UMI, read1 = 150 bp cDNA, flags as sh/fastq2bam:125-130 builds
+    them plus --min_qual 10, SAM output.  Both files are synthetic and resident in HBM; checked through
+    size-independent properties (discard count recomputed with torch from the quality bytes, output
+    size) and against the oracle on the first 2 000 pairs."""
+    A = fq.abi
+    R1, R2 = A.synth_record_bytes(26), A.synth_record_bytes(150)
+    img1 = torch.empty(n_pairs * R1, dtype=torch.uint8, device=dev)
+    img2 = torch.empty(n_pairs * R2, dtype=torch.uint8, device=dev)
+    ctx.synth_fastq(img1.data_ptr(), n_pairs, 26, first_index=0, seed=777, mate=1)
+    ctx.synth_fastq(img2.data_ptr(), n_pairs, 150, first_index=0, seed=778, mate=2)
+    ctx.synchronize()
+    # barcode qualities as SURVEY 8d(3) asks: Phred 12..40, and one base below Phred 10 in about 5 % of the reads
+    q = img1.view(n_pairs, R1)[:, 45 + 26 + 3: 45 + 26 + 3 + 26]
+    q.clamp_(min=33 + 12)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    low = torch.rand(n_pairs, generator=g, device=dev) < 0.05
+    pos = torch.randint(0, 26, (n_pairs,), generator=g, device=dev)
+    rows = torch.nonzero(low).squeeze(1)
+    q[rows, pos[rows]] = 33 + 5
+    torch.cuda.synchronize()
+    st1 = A.probe_first_record(bytes(img1[: 4 * R1].cpu().numpy()), True)
+    st2 = A.probe_first_record(bytes(img2[: 4 * R2].cpu().numpy()), True)
+    frames, states = {}, {A.READ1: st2, A.INDEX1: st1}
+    t0 = time.perf_counter()
+    for key, img, st, R in ((A.READ1, img2, st2, R2), (A.INDEX1, img1, st1, R1)):
+        r = ctx.validate(img.data_ptr(), None, st, final=True, flags=A.VALIDATE_FRAME_ONLY, nbytes=n_pairs * R)
+        assert r["n_records"] == n_pairs, r
+        frames[key] = ctx.retain_frame()
+    ctx.synchronize()
+    frame_s = time.perf_counter() - t0
+
+    def run():
+        return ctx.barcodes_transform(frames, states, n_pairs, umi=(A.INDEX1, 16, 10), cell=(A.INDEX1, 0, 16),
+                                      phred=33, min_qual=10, sam=True)
+
+    run()
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    r = run()
+    ctx.synchronize()
+    wall = time.perf_counter() - t1
+    prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_bc") and v[0] > 0}
+    ctx.profile(False)
+    # every base of the barcode range must reach Phred 10: recount the discards from the quality bytes
+    want_disc = int((q < 33 + 10).any(dim=1).sum().item())
+    kept = n_pairs - r["n_discarded"]
+    ok = r["code"] == 0 and r["n_done"] == n_pairs and r["n_discarded"] == want_disc and r["n_short"] == 0
+    # the first 2 000 pairs against the oracle
+    from oracle import pre_barcodes_oracle as pbo
+
+    m = min(2000, n_pairs)
+    files = {"i1.fastq": bytes(img1[: m * R1].cpu().numpy()), "r1.fastq": bytes(img2[: m * R2].cpu().numpy())}
+    want = pbo.run_pre_barcodes(["--read1", "r1.fastq", "--index1", "i1.fastq", "--umi_read", "index1", "--umi_offset", "16",
+                                 "--umi_size", "10", "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16",
+                                 "--phred_encoding", "33", "--min_qual", "10", "--sam", "--outfile1", "-"], files.get)
+    body = "".join(ln + "\n" for ln in want["stdout"].splitlines() if not ln.startswith("@"))
+    got = ctx.barcodes_output(0, len(body)).decode("latin-1")
+    kernels_ms = sum(prof.values())
+    algo_bytes = n_pairs * (R1 + R2) + r["out_bytes"][0]
+    out = {
+        "what": "fastq_pre_barcodes main loop (fqg_barcodes_transform), 10x v2 layout, SAM output, BASELINE.json configs[2]",
+        "pairs": n_pairs, "baseline_pairs": 200_000_000, "discarded": r["n_discarded"], "sam_bytes": r["out_bytes"][0],
+        "wall_ms_one_call": wall * 1e3, "Mpairs_per_s_wall": n_pairs / wall / 1e6, "kernels_ms": kernels_ms,
+        "kernels_ms_breakdown": prof, "framing_both_files_s": frame_s,
+        "algorithmic_GB": algo_bytes / 1e9,
+        "achieved_GBps_kernels": algo_bytes / (kernels_ms * 1e-3) / 1e9 if kernels_ms else None,
+        "properties_hold": bool(ok), "expected_discarded": want_disc, "sam_bytes_per_kept_pair": r["out_bytes"][0] / max(1, kept),
+        "first_2000_pairs_identical_to_oracle": got == body and want["exit"] == 0,
+    }
+    for f in frames.values():
+        f.release()
+    ref = os.path.join(REPO, "oracle", "_ref", "fastq_pre_barcodes")
+    if os.path.exists(ref):
+        ms = min(n_pairs, 1_000_000)
+        with tempfile.TemporaryDirectory() as tmp:
+            for name, img, R in (("i1.fastq", img1, R1), ("r1.fastq", img2, R2)):
+                with open(os.path.join(tmp, name), "wb") as f:
+                    f.write(bytes(img[: ms * R].cpu().numpy()))
+            t2 = time.perf_counter()
+            p = subprocess.run(["fastq_pre_barcodes", "--read1", "r1.fastq", "--index1", "i1.fastq", "--umi_read", "index1",
+                                "--umi_offset", "16", "--umi_size", "10", "--cell_read", "index1", "--cell_offset", "0",
+                                "--cell_size", "16", "--phred_encoding", "33", "--min_qual", "10", "--sam", "--outfile1", "-"],
+                               executable=ref, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            secs = time.perf_counter() - t2
+        out["cpu_baseline"] = {"value": ms / secs / 1e6, "unit": "Mpairs/s", "cores": 1, "kind": "reference",
+                               "sample": f"first {ms} pairs of the same batch, uncompressed files, SAM to /dev/null; "
+                                         "reference fastq_pre_barcodes (single-threaded)",
+                               "seconds": secs, "ok": p.returncode == 0}
+    return out
 
 
 def umi_extra(ctx, torch, dev, n_triples):
@@ -366,10 +465,20 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             m = min(n, a.cpu_sample_reads)
             out["cpu_baseline"] = cpu_baseline(bytes(image[: m * R].cpu().numpy()), m)
-        if world == 1 and not a.no_umi_extra:
+        if world == 1 and not (a.no_umi_extra and a.no_barcodes_extra):
             del image
             torch.cuda.empty_cache()
-            out["umi_count_extra"] = umi_extra(ctx, torch, dev, a.umi_triples)
+        if world == 1 and not a.no_barcodes_extra:
+            try:
+                out["pre_barcodes_extra"] = barcodes_extra(ctx, fq, torch, dev, a.barcode_pairs)
+            except Exception as e:
+                out["pre_barcodes_extra"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+        if world == 1 and not a.no_umi_extra:
+            try:
+                out["umi_count_extra"] = umi_extra(ctx, torch, dev, a.umi_triples)
+            except Exception as e:
+                out["umi_count_extra"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     acc.close()
     ctx.close()

@@ -53,6 +53,23 @@ class FileStats(C.Structure):
                 ("min_qual", C.c_uint64), ("max_qual", C.c_uint64)]
 
 
+class BarcodeParams(C.Structure):
+    _fields_ = [("present", C.c_int32 * 6), ("interleaved", C.c_int32 * 2), ("umi_read", C.c_int32),
+                ("cell_read", C.c_int32), ("sample_read", C.c_int32), ("phred_encoding", C.c_int32),
+                ("min_qual", C.c_int32), ("out_sam", C.c_int32), ("tenx", C.c_int32), ("emit", C.c_int32 * 3),
+                ("umi_offset", C.c_int64), ("umi_size", C.c_int64), ("cell_offset", C.c_int64),
+                ("cell_size", C.c_int64), ("sample_offset", C.c_int64), ("sample_size", C.c_int64),
+                ("read_offset", C.c_int64 * 3), ("read_size", C.c_int64 * 3)]
+
+
+class BarcodeResult(C.Structure):
+    _fields_ = [("n_done", C.c_uint64), ("n_discarded", C.c_uint64), ("n_short", C.c_uint64),
+                ("out_bytes", C.c_uint64 * 3), ("iteration", C.c_uint64), ("code", C.c_int32), ("file", C.c_int32)]
+
+
+READ1, READ2, INDEX1, INDEX2, INDEX3 = 1, 2, 3, 4, 5
+
+
 class UmiParams(C.Structure):
     _fields_ = [("feat_tag", C.c_char * 2), ("cell_tag", C.c_char * 2), ("umi_tag", C.c_char * 2),
                 ("reserved", C.c_char * 2), ("sorted_by_cell", C.c_int32), ("uniq_mapped_only", C.c_int32),
@@ -172,6 +189,9 @@ def load():
     L.fqg_index_insert_unique.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_names_compare.argtypes = [vp, vp, C.POINTER(FileState), vp, C.POINTER(FileState), C.POINTER(IndexResult)]
+    L.fqg_barcodes_transform.argtypes = [vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64),
+                                         C.POINTER(BarcodeParams), u64, u64, C.POINTER(BarcodeResult)]
+    L.fqg_barcodes_output.argtypes = [vp, C.c_int, vp, u64]
     L.fqg_fp_owner.argtypes = [u64, C.c_uint32]
     L.fqg_fp_owner.restype = C.c_uint32
     L.fqg_names_fingerprints.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, C.POINTER(u64)]
@@ -373,6 +393,43 @@ class Context:
 
     def retain_frame(self):
         return Frame(self)
+
+    def barcodes_transform(self, frames, states, n_iterations, umi=None, cell=None, sample=None, phred=33,
+                           min_qual=0, sam=True, tenx=False, first_read_number=0):
+        """fastq_pre_barcodes' main loop on retained frames.  frames / states: {READ1..INDEX3: Frame / FileState};
+        umi / cell / sample: (file reference, offset, size) or None.  Output stays on the device
+        (barcodes_output copies it)."""
+        p = BarcodeParams()
+        fr = (C.c_void_p * 6)()
+        stt = (FileState * 6)()
+        first = (C.c_uint64 * 6)()
+        for x, f in frames.items():
+            p.present[x] = 1
+            fr[x] = f.h
+            stt[x] = states[x]
+        p.umi_read = p.cell_read = p.sample_read = -1
+        p.umi_offset = p.cell_offset = p.sample_offset = -1
+        p.read_offset[1] = p.read_offset[2] = -1
+        for name, spec in (("umi", umi), ("cell", cell), ("sample", sample)):
+            if spec:
+                setattr(p, name + "_read", spec[0])
+                setattr(p, name + "_offset", spec[1])
+                setattr(p, name + "_size", spec[2])
+        p.phred_encoding, p.min_qual, p.out_sam, p.tenx = phred, min_qual, int(sam), int(tenx)
+        if not sam:
+            p.emit[1] = 1
+            p.emit[2] = 1 if READ2 in frames else 0
+        r = BarcodeResult()
+        self._check(load().fqg_barcodes_transform(self.h, fr, stt, first, C.byref(p), n_iterations, first_read_number,
+                                                  C.byref(r)))
+        out = {k: getattr(r, k) for k, _ in BarcodeResult._fields_ if k != "out_bytes"}
+        out["out_bytes"] = list(r.out_bytes)
+        return out
+
+    def barcodes_output(self, which, nbytes):
+        buf = C.create_string_buffer(max(1, nbytes))
+        self._check(load().fqg_barcodes_output(self.h, which, buf, nbytes))
+        return buf.raw[:nbytes]
 
     def names_fingerprints(self, frame, state, record_base, n_owners, out_device_ptr):
         """(fingerprint, global index) pairs of a retained frame (None: the current one) into device

@@ -1237,10 +1237,12 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
     const unsigned grid_e =
         (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));
     hipLaunchKernelGGL(k_bc_emit, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done, (const uint8_t*)c->bc_status.p,
-                       (const unsigned long long*)c->bc_off[0].p, (const unsigned long long*)c->bc_sum[0].p,
+                       (const uint32_t*)c->bc_len[0].p, (const unsigned long long*)c->bc_off[0].p,
+                       (const unsigned long long*)c->bc_sum[0].p, (const uint32_t*)c->bc_len[1].p,
                        (const unsigned long long*)c->bc_off[1].p, (const unsigned long long*)c->bc_sum[1].p,
-                       (const unsigned long long*)c->bc_off[2].p, (const unsigned long long*)c->bc_sum[2].p,
-                       (uint8_t*)c->bc_out[0].p, (uint8_t*)c->bc_out[1].p, (uint8_t*)c->bc_out[2].p);
+                       (const uint32_t*)c->bc_len[2].p, (const unsigned long long*)c->bc_off[2].p,
+                       (const unsigned long long*)c->bc_sum[2].p, (uint8_t*)c->bc_out[0].p, (uint8_t*)c->bc_out[1].p,
+                       (uint8_t*)c->bc_out[2].p);
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());

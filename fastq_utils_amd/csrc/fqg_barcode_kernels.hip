@@ -184,6 +184,27 @@ __device__ inline uint8_t bc_decide(const BcParams& P, uint64_t k, BcTags* tags,
   return kBcKeep;
 }
 
+// tags of an iteration that bc_decide has already found to be kept: geometry only, none of the
+// byte-by-byte checks (the emit kernel runs one wavefront per iteration: a serial scan there costs
+// a memory round trip per byte)
+__device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine (&lines)[kBcFiles][4], BcTags* tags) {
+  tags->n[0] = tags->n[1] = tags->n[2] = 0;
+#pragma unroll
+  for (int x = 1; x < kBcFiles; ++x)
+    if (P.f[x].present && (P.umi_read == x || P.sample_read == x || P.cell_read == x)) {
+      const BcLine(&ln)[4] = lines[x];
+      auto take = [&](int slot, long off, long size) {
+        if (off == -1 || size == 0) return;
+        tags->n[slot] = (uint32_t)size;
+        tags->s[slot] = ln[1].p + off;
+        tags->q[slot] = ln[3].p + off;
+      };
+      if (P.umi_read == x) take(0, P.umi_off, P.umi_size);
+      if (P.sample_read == x) take(2, P.sample_off, P.sample_size);
+      if (P.cell_read == x) take(1, P.cell_off, P.cell_size);
+    }
+}
+
 // byte counts of the FASTQ record written for file x (src/fastq_pre_barcodes.c:713-718)
 __device__ inline uint32_t bc_fastq_len(const BcParams& P, int x, uint64_t k, const BcTags& t) {
   BcLine ln[4];
@@ -383,9 +404,7 @@ struct Writer {
   }
 };
 
-__device__ inline void bc_emit_fastq(const BcParams& P, int x, uint64_t k, const BcTags& t, Writer& w) {
-  BcLine ln[4];
-  bc_lines(P.f[x], k, ln);
+__device__ __forceinline__ void bc_emit_fastq(const BcParams& P, int x, const BcLine (&ln)[4], const BcTags& t, Writer& w) {
   const bool tagged = (t.n[0] | t.n[1] | t.n[2]) != 0;
   const bool sliced = bc_slices(P, x);
   if (tagged) {  // add_tags2readname, src/fastq_pre_barcodes.c:192-216
@@ -413,11 +432,13 @@ __device__ inline void bc_emit_fastq(const BcParams& P, int x, uint64_t k, const
   else w.bytes(ln[3].p, ln[3].len + ln[3].nl);
 }
 
-__device__ inline void bc_emit_sam(const BcParams& P, uint64_t k, const BcTags& t, Writer& w) {
+__device__ __forceinline__ void bc_emit_sam(const BcParams& P, uint64_t k, const BcLine (&lines)[kBcFiles][4], const BcTags& t,
+                                   Writer& w) {
   const bool se = !P.f[2].present;
-  for (int x = 1; x <= (se ? 1 : 2); ++x) {
-    BcLine ln[4];
-    bc_lines(P.f[x], k, ln);
+#pragma unroll
+  for (int x = 1; x <= 2; ++x) {
+    if (x == 2 && se) break;
+    const BcLine(&ln)[4] = lines[x];
     const SamGeom g = bc_sam_geom(P, x, ln);
     const unsigned flag = se ? 4u : (x == 1 ? 77u : 141u);  // BAM_FUNMAP | FMUNMAP | FPAIRED | FREAD1/2
     w.dec(P.first_read_number + k + 1);
@@ -455,35 +476,120 @@ __device__ inline void bc_emit_sam(const BcParams& P, uint64_t k, const BcTags& 
   }
 }
 
+// One wavefront per kept iteration.
+//   1. The records of the iteration (the four lines are contiguous in the image) are copied into an
+//      LDS staging area with all loads in flight at once - the ~25 pieces of a SAM line would otherwise
+//      cost one memory round trip each.
+//   2. The output text is assembled piece by piece in a second LDS buffer (LDS -> LDS byte copies).
+//   3. The text goes to its place in the output image with 16-byte stores: the buffer starts at the
+//      same residue mod 16 as the global address, so aligned 16-byte units of LDS and of the output
+//      coincide.
+// Records or texts larger than the buffers (long reads) take the direct path from / to global memory.
+constexpr int kEmitBuf = 2048;   // output text per wavefront
+constexpr int kEmitSrc = 2560;   // staged input records per wavefront
+constexpr int kEmitChunks = 10;  // kEmitSrc / 64 / 4: byte loads in flight per lane and round
+
+__device__ __forceinline__ void emit_flush(const uint8_t* __restrict__ buf, uint32_t skew, uint32_t len,
+                                           uint8_t* __restrict__ dst, int lane) {
+  // buf[skew .. skew+len) -> dst[0 .. len), with (dst - skew) 16-byte aligned
+  uint8_t* g0 = dst - skew;
+  const uint32_t end = skew + len;
+  const uint32_t first_full = (skew + 15u) & ~15u, last_full = end & ~15u;
+  for (uint32_t i = skew + lane; i < (first_full < end ? first_full : end); i += kWave) g0[i] = buf[i];
+  for (uint32_t u = first_full + 16u * lane; u + 16u <= last_full; u += 16u * kWave)
+    *reinterpret_cast<uint4*>(g0 + u) = *reinterpret_cast<const uint4*>(buf + u);
+  if (last_full >= first_full)
+    for (uint32_t i = last_full + lane; i < end; i += kWave) g0[i] = buf[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_bc_emit(BcParams P, uint64_t n_done, const uint8_t* __restrict__ status,
+                                                    const uint32_t* __restrict__ len0,
                                                     const unsigned long long* __restrict__ off0,
                                                     const unsigned long long* __restrict__ sum0,
+                                                    const uint32_t* __restrict__ len1,
                                                     const unsigned long long* __restrict__ off1,
                                                     const unsigned long long* __restrict__ sum1,
+                                                    const uint32_t* __restrict__ len2,
                                                     const unsigned long long* __restrict__ off2,
                                                     const unsigned long long* __restrict__ sum2,
                                                     uint8_t* __restrict__ out0, uint8_t* __restrict__ out1,
                                                     uint8_t* __restrict__ out2) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_buf[kBlock / kWave][kEmitBuf + 16];
+  __shared__ uint8_t s_src[kBlock / kWave][kEmitSrc];
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
-  const int lane = (int)(threadIdx.x & 63);
-  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); k < n_done; k += n_waves) {
+  // the wave index is uniform: say so, and everything derived from k (line index loads, pointers,
+  // lengths) lives in scalar registers instead of 64 copies
+  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* buf = s_buf[wv];
+  uint8_t* src = s_src[wv];
+  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_done; k += n_waves) {
     if (status[k] != kBcKeep) continue;
-    BcTags t;
-    uint32_t finding;
-    bc_decide(P, k, &t, &finding);
-    if (P.out_sam) {
-      Writer w{out0 + off0[k] + sum0[k / kScan64Span], lane};
-      bc_emit_sam(P, k, t, w);
-    } else {
-      if (P.emit[1]) {
-        Writer w{out1 + off1[k] + sum1[k / kScan64Span], lane};
-        bc_emit_fastq(P, 1, k, t, w);
+    BcLine lines[kBcFiles][4];
+    uint32_t rec_len[kBcFiles], total = 0;
+#pragma unroll
+    for (int x = 1; x < kBcFiles; ++x) {
+      rec_len[x] = 0;
+      if (!P.f[x].present) continue;
+      bc_lines(P.f[x], k, lines[x]);
+      rec_len[x] = (uint32_t)((lines[x][3].p + lines[x][3].len + lines[x][3].nl) - lines[x][0].p);
+      total += rec_len[x];
+    }
+    if (total <= (uint32_t)kEmitSrc) {
+      // stage: every lane issues its byte loads of all files before the first one is consumed
+      uint32_t at = 0;
+#pragma unroll
+      for (int x = 1; x < kBcFiles; ++x) {
+        if (!rec_len[x]) continue;
+        const uint8_t* g = lines[x][0].p;
+        const uint32_t n = rec_len[x];
+        for (uint32_t base = 0; base < n; base += kEmitChunks * kWave) {
+          uint8_t v[kEmitChunks];
+#pragma unroll
+          for (int c = 0; c < kEmitChunks; ++c) {
+            const uint32_t i = base + c * kWave + lane;
+            v[c] = i < n ? g[i] : (uint8_t)0;
+          }
+#pragma unroll
+          for (int c = 0; c < kEmitChunks; ++c) {
+            const uint32_t i = base + c * kWave + lane;
+            if (i < n) src[at + i] = v[c];
+          }
+        }
+        // re-point the four lines at the copy
+        const uint8_t* g0 = lines[x][0].p;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) lines[x][l].p = src + at + (uint32_t)(lines[x][l].p - g0);
+        at += n;
       }
-      if (P.emit[2]) {
-        Writer w{out2 + off2[k] + sum2[k / kScan64Span], lane};
-        bc_emit_fastq(P, 2, k, t, w);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    BcTags t;
+    bc_tags_of_kept(P, lines, &t);
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+      if (which == 0 ? !P.out_sam : (P.out_sam || !P.emit[which])) continue;
+      const uint32_t* lens = which == 0 ? len0 : (which == 1 ? len1 : len2);
+      const unsigned long long* off = which == 0 ? off0 : (which == 1 ? off1 : off2);
+      const unsigned long long* sum = which == 0 ? sum0 : (which == 1 ? sum1 : sum2);
+      uint8_t* dst = (which == 0 ? out0 : (which == 1 ? out1 : out2)) + off[k] + sum[k / kScan64Span];
+      const uint32_t len = lens[k];
+      if (len <= (uint32_t)kEmitBuf) {
+        const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
+        Writer w{buf + skew, lane};
+        if (which == 0) bc_emit_sam(P, k, lines, t, w);
+        else bc_emit_fastq(P, which, lines[which], t, w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        emit_flush(buf, skew, len, dst, lane);
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        Writer w{dst, lane};
+        if (which == 0) bc_emit_sam(P, k, lines, t, w);
+        else bc_emit_fastq(P, which, lines[which], t, w);
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
