@@ -275,7 +275,7 @@ def committed_traffic(kernel, n_reads, read_len, record_bytes):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes, by
     tools/pmc_traffic.py).  Only valid for the exact workload it was measured on; otherwise None."""
-    path = os.path.join(REPO, "profiles", f"r01c_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")
+    path = os.path.join(REPO, "profiles", f"r01d_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
