@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
   __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
   __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][kChunkBytes];
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  // (the wave index is uniform: telling the compiler keeps chunk-level values in scalar registers)
+  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t chunk = blockIdx.x * (kBlock / kWave) + wv;
   if (chunk >= n_chunks) return;
   const uint64_t cb = (uint64_t)chunk * kChunkBytes;
