@@ -33,7 +33,7 @@ EXPORTS = [
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
-    "fqg_umi_cells", "fqg_umi_entries",
+    "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
     "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
     "fqg_fpset_candidates", "fqg_frame_name",
 ]
@@ -75,7 +75,8 @@ class UmiParams(C.Structure):
                 ("reserved", C.c_char * 2), ("sorted_by_cell", C.c_int32), ("uniq_mapped_only", C.c_int32),
                 ("max_cells", C.c_uint32), ("max_features", C.c_uint32), ("min_reads", C.c_uint32),
                 ("min_umis", C.c_uint32), ("known_umis", C.POINTER(C.c_uint64)),
-                ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64)]
+                ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64),
+                ("defer_output", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class UmiResult(C.Structure):
@@ -83,7 +84,8 @@ class UmiResult(C.Structure):
                 ("n_cells_discarded", C.c_uint64), ("n_features", C.c_uint64), ("n_cells", C.c_uint64),
                 ("n_entries", C.c_uint64 * 2), ("total", C.c_uint64 * 2), ("tot_reads", C.c_float),
                 ("tot_umi", C.c_float), ("code", C.c_int32), ("reserved", C.c_int32), ("record", C.c_uint64),
-                ("aux", C.c_uint64)]
+                ("aux", C.c_uint64), ("n_counted", C.c_uint64), ("n_new", C.c_uint64),
+                ("unit_increments", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class UmiEntry(C.Structure):
@@ -208,6 +210,7 @@ def load():
     L.fqg_unpack_barcode.restype = None
     L.fqg_bam_index_records.argtypes = [vp, u64, C.POINTER(u64), u64, C.POINTER(u64), C.POINTER(u64)]
     L.fqg_umi_count.argtypes = [vp, vp, u64, C.c_int, C.POINTER(u64), u64, C.POINTER(UmiParams), C.POINTER(UmiResult)]
+    L.fqg_umi_emit.argtypes = [vp, C.POINTER(C.c_uint32), u64, C.c_uint32, C.POINTER(UmiResult)]
     L.fqg_umi_features.argtypes = [vp, vp, u64]
     L.fqg_umi_cells.argtypes = [vp, C.POINTER(u64), u64]
     L.fqg_umi_entries.argtypes = [vp, C.c_int, C.POINTER(UmiEntry), u64]
@@ -479,7 +482,7 @@ class Context:
 
     def umi_count(self, stream, offsets=None, sorted_by_cell=True, uniq_mapped_only=False, feat_tag=b"GX",
                   cell_tag=b"CR", umi_tag=b"RX", max_cells=None, max_features=100000, min_reads=0, min_umis=0,
-                  known_umis=None, known_cells=None, nbytes=None, want_entries=True):
+                  known_umis=None, known_cells=None, nbytes=None, want_entries=True, defer_output=False):
         """bam_umi_count's alignment loop on an inflated BAM stream: bytes (host) or an int device pointer
         (then `nbytes` and `offsets` are required).  Returns the result fields plus, when the call
         succeeded, feature names / packed cells in id order and the (row, col, value) lines."""
@@ -505,6 +508,7 @@ class Context:
         p.sorted_by_cell, p.uniq_mapped_only = int(sorted_by_cell), int(uniq_mapped_only)
         p.max_cells = (1 if sorted_by_cell else 1000000) if max_cells is None else max_cells
         p.max_features, p.min_reads, p.min_umis = max_features, min_reads, min_umis
+        p.defer_output = int(defer_output)
         keep = []
         for name, vals in (("known_umis", known_umis), ("known_cells", known_cells)):
             if vals is not None:
@@ -515,8 +519,7 @@ class Context:
         r = UmiResult()
         self._check(L.fqg_umi_count(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
                                     MEM_HOST if host else MEM_DEVICE, offs, n_rec, C.byref(p), C.byref(r)))
-        out = {k: getattr(r, k) for k, _ in UmiResult._fields_ if k not in ("reserved", "n_entries", "total")}
-        out["n_entries"], out["total"] = list(r.n_entries), list(r.total)
+        out = self._umi_result(r)
         if r.code == 0 and want_entries:
             names = C.create_string_buffer(max(1, r.n_features * 25))
             self._check(L.fqg_umi_features(self.h, names, r.n_features))
@@ -524,11 +527,35 @@ class Context:
             cells = (C.c_uint64 * max(1, r.n_cells))()
             self._check(L.fqg_umi_cells(self.h, cells, r.n_cells))
             out["cells"] = [int(cells[i]) for i in range(r.n_cells)]
-            out["entries"] = []
-            for w in range(2):
-                e = (UmiEntry * max(1, r.n_entries[w]))()
-                self._check(L.fqg_umi_entries(self.h, w, e, r.n_entries[w]))
-                out["entries"].append([(e[i].row, e[i].col, e[i].value) for i in range(r.n_entries[w])])
+            if not defer_output:
+                out["entries"] = self._umi_entries(r)
+        return out
+
+    @staticmethod
+    def _umi_result(r):
+        out = {k: getattr(r, k) for k, _ in UmiResult._fields_ if not k.startswith("reserved") and k not in ("n_entries", "total")}
+        out["n_entries"], out["total"] = list(r.n_entries), list(r.total)
+        return out
+
+    def _umi_entries(self, r):
+        both = []
+        for w in range(2):
+            e = (UmiEntry * max(1, r.n_entries[w]))()
+            self._check(load().fqg_umi_entries(self.h, w, e, r.n_entries[w]))
+            both.append([(e[i].row, e[i].col, e[i].value) for i in range(r.n_entries[w])])
+        return both
+
+    def umi_emit(self, feat_remap=None, cell_offset=0, want_entries=True):
+        """The output step after umi_count(defer_output=True): feat_remap[local id] = id to use (index 0 unused)."""
+        r = UmiResult()
+        if feat_remap is not None:
+            arr = (C.c_uint32 * len(feat_remap))(*feat_remap)
+            self._check(load().fqg_umi_emit(self.h, arr, len(feat_remap), cell_offset, C.byref(r)))
+        else:
+            self._check(load().fqg_umi_emit(self.h, None, 0, cell_offset, C.byref(r)))
+        out = {"n_entries": list(r.n_entries), "total": list(r.total)}
+        if want_entries:
+            out["entries"] = self._umi_entries(r)
         return out
 
     def synth_fastq(self, device_ptr, n_records, read_len=150, first_index=0, seed=12345, mate=1):

@@ -6,6 +6,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -66,6 +67,7 @@ struct fqg_ctx {
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
   DevBuf umi_names, umi_cells, umi_entries[2];  // results of the last fqg_umi_count
   uint64_t umi_n_features = 0, umi_n_cells = 0, umi_n_entries[2] = {0, 0};
+  void* umi_state = nullptr;  // UmiState of a deferred fqg_umi_count (fqg_umi_abi.inc)
   CallState* d_cs = nullptr;
   CallState* h_cs = nullptr;  // pinned
   uint64_t* h_scalar = nullptr;  // pinned, 8 x u64
@@ -191,6 +193,8 @@ struct ProfScope {
   }
 };
 
+void umi_drop_state(fqg_ctx* c);  // fqg_umi_abi.inc
+
 int grid_for_waves(fqg_ctx* c, uint64_t n_records) {
   // persistent wave-per-record kernels: enough workgroups to fill every CU 8 deep
   uint64_t want = (n_records + (kBlock / kWave) - 1) / (kBlock / kWave);
@@ -240,6 +244,7 @@ void fqg_close(fqg_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   prof_drain(c);
+  umi_drop_state(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   release(c->image);
   release(c->tile_counts);

@@ -611,6 +611,9 @@ struct EmitArgs {
   const float* cell_umis;       // cells[c].tot_umi_obs
   UmiParams P;
   uint32_t n_cells;
+  const uint32_t* remap;        // feature id -> id used for the output rules and printed (null: identity);
+                                // sharded runs pass the global first-appearance ids here
+  uint32_t cell_offset;         // added to the printed cell id (cells of earlier shards)
   UmiEntry* out_u;              // scratch, one entry per pair
   UmiEntry* out_r;
 };
@@ -627,12 +630,16 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
   const float tot = A.cell_umis[c];
   if (threadIdx.x == 0) s_base = 0;
   // unsorted mode never prints cell ids >= max_cells (write2MM loops while cell_id < max_cells, :612)
-  const bool cell_printed = A.P.sorted_by_cell || c < A.P.max_cells;
+  const bool cell_printed = A.P.sorted_by_cell || c + A.cell_offset < A.P.max_cells;
   unsigned long long tu = 0, tr = 0;
   // sweeps over the feature id space, 131072 ids at a time (one sweep unless --max_feat is huge)
   uint32_t max_f = 0;
+  auto feat_of = [&](uint32_t slot) {
+    const uint32_t f = (uint32_t)A.Pt.t.keys[slot];
+    return A.remap ? A.remap[f] : f;
+  };
   for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
-    const uint32_t f = (uint32_t)A.Pt.t.keys[A.pair_of[p0 + k]];
+    const uint32_t f = feat_of(A.pair_of[p0 + k]);
     max_f = f > max_f ? f : max_f;
   }
 #pragma unroll
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
     for (int w = threadIdx.x; w < kUmiBitmapWords; w += kBlock) s_bits[w] = 0;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
-      const uint32_t f = (uint32_t)A.Pt.t.keys[A.pair_of[p0 + k]] - sweep0;
+      const uint32_t f = feat_of(A.pair_of[p0 + k]) - sweep0;
       if (f < (uint32_t)kUmiBitmapWords * 32) atomicOr(&s_bits[f >> 5], 1u << (f & 31));
     }
     __syncthreads();
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
       const uint32_t slot = A.pair_of[p0 + k];
-      const uint32_t feat = (uint32_t)A.Pt.t.keys[slot];
+      const uint32_t feat = feat_of(slot);
       const uint32_t f = feat - sweep0;
       if (f >= (uint32_t)kUmiBitmapWords * 32) continue;
       const uint32_t rank = s_pre[f >> 5] + __popc(s_bits[f >> 5] & ((1u << (f & 31)) - 1u));  // among the cell's features
@@ -707,8 +714,8 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
         val_r = (uint32_t)roundf(r);
         tr += (uint32_t)r;
       }
-      if (pu) A.out_u[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c, val_u};
-      if (prd) A.out_r[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c, val_r};
+      if (pu) A.out_u[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c + A.cell_offset, val_u};
+      if (prd) A.out_r[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c + A.cell_offset, val_r};
     }
     __syncthreads();
     if (threadIdx.x == 0) s_base = base + all;

@@ -223,3 +223,71 @@ def global_first_duplicate(ctx, frames, state, record_base, group=None, device=N
         table.update(d)
     hit = resolve_candidates(flat, table.__getitem__)
     return None if hit is None else (hit, table[hit])
+
+
+# ---- bam_umi_count over shards ---------------------------------------------------------------------
+def merge_umi_shards(infos):
+    """infos: per rank, in rank order, the dict umi_count(defer_output=True) returned (code, record,
+    features, cells, n_alignments, ...).  A CR-sorted file cut at cell boundaries: rank r holds the cells
+    that follow those of rank r - 1.  Returns {"finding": (rank, code, record, aux) or None, "remap": per
+    rank the local-id -> global-id table of features (index 0 unused), "cell_offset": per rank,
+    "features": global names in first-appearance order, "cells": global packed barcodes}.
+    Dense ids in order of first appearance (label_str2id / blabel2id, src/bam_umi_count.c:143-260) over
+    the whole file = over the ranks in order."""
+    for r, info in enumerate(infos):
+        if info["code"] != 0:
+            return {"finding": (r, info["code"], info["record"], info["aux"])}
+    gid, features, remaps = {}, [], []
+    for info in infos:
+        remap = [0]
+        for name in info["features"]:
+            if name not in gid:
+                features.append(name)
+                gid[name] = len(features)
+            remap.append(gid[name])
+        remaps.append(remap)
+    seen, cells, offsets = set(), [], []
+    for r, info in enumerate(infos):
+        offsets.append(len(cells))
+        for c in info["cells"]:
+            if c in seen:  # a cell of an earlier shard again: the file is not sorted by cell (:1004-1007)
+                return {"finding": (r, 17, None, None)}
+            seen.add(c)
+            cells.append(c)
+    return {"finding": None, "remap": remaps, "cell_offset": offsets, "features": features, "cells": cells}
+
+
+def unit_float(count):
+    """float32 value of `count` additions of 1.0f (saturates at 2**24)"""
+    return float(min(count, 1 << 24))
+
+
+def umi_count_sharded(ctx, stream, group=None, **kw):
+    """Every rank calls this with ITS shard (an inflated BAM stream holding whole cells, in file order
+    over the ranks).  Counts locally, agrees on global feature / cell ids (one all_gather_object of the
+    name lists - kilobytes), applies the output rules with the global ids.  Returns this rank's lines
+    plus the merged header fields; concatenating the lines of the ranks in order gives the file."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    local = ctx.umi_count(stream, defer_output=True, **kw)
+    infos = [None] * world
+    dist.all_gather_object(infos, {k: local.get(k) for k in ("code", "record", "aux", "features", "cells", "n_alignments",
+                                                           "n_tags_found", "n_umis_discarded", "n_cells_discarded",
+                                                           "n_counted", "n_new", "unit_increments")}, group=group)
+    m = merge_umi_shards(infos)
+    if m["finding"] is not None:
+        return {"finding": m["finding"]}
+    if not all(i["unit_increments"] for i in infos):
+        raise NotImplementedError("fractional increments (NH > 1, several genes) add up in file order in float32: "
+                                  "count such files on one GPU")
+    mine = ctx.umi_emit(m["remap"][rank], m["cell_offset"][rank])
+    sums = [None] * world
+    dist.all_gather_object(sums, (mine["n_entries"], mine["total"]), group=group)
+    return {"finding": None, "entries": mine["entries"], "features": m["features"], "cells": m["cells"],
+            "n_entries": [sum(s[0][w] for s in sums) for w in range(2)],
+            "total": [sum(s[1][w] for s in sums) for w in range(2)],
+            "tot_reads": unit_float(sum(i["n_counted"] for i in infos)),
+            "tot_umi": unit_float(sum(i["n_new"] for i in infos)),
+            "n_alignments": sum(i["n_alignments"] for i in infos),
+            "n_tags_found": sum(i["n_tags_found"] for i in infos)}

@@ -288,6 +288,9 @@ typedef struct {
   uint32_t max_cells, max_features, min_reads, min_umis;
   const uint64_t *known_umis, *known_cells;       /* packed (fqg_pack_barcode) whitelist lines in file order, or NULL */
   uint64_t n_known_umis, n_known_cells;
+  int32_t defer_output;   /* 1: count only; the lines are made by fqg_umi_emit (shards of one file: the output
+                             rules need the GLOBAL feature ids, known only after every shard has counted) */
+  int32_t reserved2;
 } fqg_umi_params;
 
 typedef struct {
@@ -299,6 +302,9 @@ typedef struct {
   int32_t code;           /* FQG_OK or FQG_E_UMI_*: the first finding in record order; nothing else is valid then */
   int32_t reserved;
   uint64_t record, aux;   /* alignment index of the finding, offending id */
+  uint64_t n_counted, n_new; /* alignments that reached process_entry / that brought a new UMI */
+  int32_t unit_increments;   /* 1: every increment was 1.0 (then tot_reads = min(n_counted, 2^24) as a float) */
+  int32_t reserved3;
 } fqg_umi_result;
 
 typedef struct {
@@ -317,6 +323,11 @@ int fqg_bam_index_records(const void *stream, uint64_t nbytes, uint64_t *offsets
                           uint64_t *used);
 int fqg_umi_count(fqg_ctx *ctx, const void *stream, uint64_t nbytes, int mem, const uint64_t *offsets,
                   uint64_t n_records, const fqg_umi_params *params, fqg_umi_result *out);
+/* After fqg_umi_count(defer_output = 1): apply the output rules with feature ids mapped through
+ * feat_remap[0..n_remap) (local id -> printed id; NULL: identity) and cell ids shifted by cell_offset.
+ * Fills n_entries / total of *out; the lines are read with fqg_umi_entries as usual. */
+int fqg_umi_emit(fqg_ctx *ctx, const uint32_t *feat_remap, uint64_t n_remap, uint32_t cell_offset,
+                 fqg_umi_result *out);
 /* results of the last fqg_umi_count on this context */
 int fqg_umi_features(fqg_ctx *ctx, char *names, uint64_t cap);       /* n_features x 25 bytes, NUL padded, id order */
 int fqg_umi_cells(fqg_ctx *ctx, uint64_t *packed, uint64_t cap);     /* n_cells packed barcodes, id order */

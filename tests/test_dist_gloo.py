@@ -117,3 +117,23 @@ def test_candidates_are_confirmed_on_names_and_the_earliest_repeat_wins():
     coll = {30: b"u", 31: b"v", 33: b"v"}
     assert fdist.resolve_candidates([(30, 31), (30, 33)], coll.__getitem__) == 33
     assert fdist.resolve_candidates([], names.__getitem__) is None
+
+
+def test_umi_shard_merge_gives_first_appearance_ids_over_the_ranks():
+    infos = [
+        {"code": 0, "features": [b"G3", b"G1"], "cells": [11, 12]},
+        {"code": 0, "features": [b"G1", b"G7", b"G3"], "cells": [13]},
+        {"code": 0, "features": [], "cells": []},
+        {"code": 0, "features": [b"G9"], "cells": [14, 15]},
+    ]
+    m = fdist.merge_umi_shards(infos)
+    assert m["finding"] is None
+    assert m["features"] == [b"G3", b"G1", b"G7", b"G9"]
+    assert m["remap"] == [[0, 1, 2], [0, 2, 3, 1], [0], [0, 4]]
+    assert m["cell_offset"] == [0, 2, 3, 3] and m["cells"] == [11, 12, 13, 14, 15]
+    # a cell of an earlier shard again = "not sorted by CR"; a local finding wins by rank order
+    infos[3]["cells"] = [14, 12]
+    assert fdist.merge_umi_shards(infos)["finding"] == (3, 17, None, None)
+    infos[1].update(code=18, record=5, aux=30)
+    assert fdist.merge_umi_shards(infos)["finding"] == (1, 18, 5, 30)
+    assert fdist.unit_float(5) == 5.0 and fdist.unit_float(1 << 30) == float(1 << 24)

@@ -175,3 +175,84 @@ def test_reference_binary_differential_on_fresh_umis():
         for base in ("_u", "_r"):
             for ext in ("", "_rows", "_cols"):
                 assert outs["ref" + base + ext] == outs["gpu" + base + ext], base + ext
+
+
+def split_at_cell_boundaries(stream, n_shards):
+    """shards of an inflated CR-sorted BAM stream, each a BAM stream of its own holding whole cells"""
+    hdr_len = None
+    recs, cells = [], []
+    raw = stream
+    # header length: the generator's header
+    hdr = bamgen.header()
+    assert raw.startswith(hdr)
+    p = len(hdr)
+    import struct
+    while p < len(raw):
+        (block,) = struct.unpack_from("<i", raw, p)
+        recs.append(raw[p:p + 4 + block])
+        p += 4 + block
+    for tid, flag, aux in uo.bam_records(stream):
+        cells.append(uo.get_tag(aux, b"CR"))
+    bounds = [0]
+    for i in range(1, len(recs)):
+        if cells[i] != cells[i - 1]:
+            bounds.append(i)
+    bounds.append(len(recs))
+    n_cells = len(bounds) - 1
+    cuts = [bounds[(n_cells * k) // n_shards] for k in range(n_shards)] + [len(recs)]
+    return [hdr + b"".join(recs[cuts[k]:cuts[k + 1]]) for k in range(n_shards)]
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 7])
+def test_shards_at_cell_boundaries_give_the_file(ctx, n_shards):
+    """bam_umi_count over several GPUs: shards count on their own, agree on the global
+    first-appearance ids, and apply the output rules with them.  The concatenated lines of the
+    shards must be the single-GPU result = the oracle's file."""
+    from fastq_utils_amd import dist as fdist
+
+    rng = np.random.default_rng(100 + n_shards)
+    bam, stream = bamgen.tagged_bam(rng, n_cells=40, genes=150, reads_per_cell=(1, 200), umi_len=5)
+    want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"], {"in.bam": bam}.get)
+    assert want["exit"] == 0
+    whole = ctx.umi_count(stream)
+    assert whole["entries"][0] == lines_of(want["files"]["u"])
+    infos = []
+    shards = split_at_cell_boundaries(stream, n_shards)
+    for s in shards:
+        infos.append(ctx.umi_count(s, defer_output=True))
+    m = fdist.merge_umi_shards(infos)
+    assert m["finding"] is None
+    assert [f.decode() for f in m["features"]] == [ln.split("\t")[1] for ln in want["files"]["u_rows"].splitlines()]
+    assert [uo.uint_642char(c).decode() for c in m["cells"]] == [ln.split("\t")[1] for ln in want["files"]["u_cols"].splitlines()]
+    lines_u, lines_r, tot = [], [], [0, 0]
+    for k, s in enumerate(shards):
+        ctx.umi_count(s, defer_output=True)          # (one context: count again, then emit with the global ids)
+        e = ctx.umi_emit(m["remap"][k], m["cell_offset"][k])
+        lines_u += e["entries"][0]
+        lines_r += e["entries"][1]
+        tot = [tot[0] + e["total"][0], tot[1] + e["total"][1]]
+    assert lines_u == whole["entries"][0] and lines_r == whole["entries"][1]
+    assert tot == whole["total"]
+    assert fdist.unit_float(sum(i["n_counted"] for i in infos)) == whole["tot_reads"]
+    assert fdist.unit_float(sum(i["n_new"] for i in infos)) == whole["tot_umi"]
+
+
+def test_sharded_protocol_through_a_one_rank_group(ctx):
+    import torch
+    import torch.distributed as dist
+    from fastq_utils_amd import dist as fdist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29641"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(5)
+        bam, stream = bamgen.tagged_bam(rng, n_cells=25, genes=80)
+        whole = ctx.umi_count(stream)
+        got = fdist.umi_count_sharded(ctx, stream)
+        assert got["finding"] is None and got["entries"] == whole["entries"]
+        assert (got["n_entries"], got["total"], got["tot_reads"], got["tot_umi"]) == (
+            whole["n_entries"], whole["total"], whole["tot_reads"], whole["tot_umi"])
+    finally:
+        dist.destroy_process_group()
