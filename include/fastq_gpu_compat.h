@@ -1,0 +1,117 @@
+/*
+ * fastq_gpu_compat.h - the per-record C API of fastq_utils (reference src/fastq.h:84-158 and
+ * src/hash.h:40-78) as exported by libfastq_gpu.so.
+ *
+ * Same names, signatures and struct layouts as the reference, so that a program written against the
+ * reference's headers links against this library unchanged (oracle/Makefile builds the reference's own
+ * fastq_info.c that way; tests/test_gpu_compat.py runs it).  Behind the API nothing works per record:
+ * the first fastq_read_entry() of a file reads the whole file and frames it on the GPU
+ * (fqg_validate, include/fqg.h); fastq_validate_entry() answers from ONE bulk validation of that
+ * file; fastq_index_readnames() and the lookup / delete calls of the pairing loop answer from the GPU
+ * read-name index.  What is done per call on the host is bookkeeping on values that are already
+ * known (copying the four lines into the caller's FASTQ_ENTRY, counters, message text).
+ */
+#ifndef FASTQ_GPU_COMPAT_H
+#define FASTQ_GPU_COMPAT_H
+
+#include <sys/types.h>
+#include <zlib.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- hash.h ---- */
+typedef unsigned long long fq_ulong;
+struct bucket {
+  struct bucket *next;
+  fq_ulong value; /* key */
+  void *obj;
+};
+typedef struct bucket hashnode;
+struct hashtable_s {
+  hashnode **buckets;
+  hashnode **buckets_last;
+  fq_ulong size;
+  fq_ulong last_bucket;
+  fq_ulong n_entries;
+  hashnode *last_node;
+};
+typedef struct hashtable_s *hashtable;
+
+hashtable new_hashtable(fq_ulong hashsize);
+void *get_next_object(hashtable, fq_ulong);
+#ifndef __cplusplus
+void *delete(hashtable, fq_ulong, void *);
+#endif
+void *get_object(hashtable, fq_ulong);
+int insere(hashtable, fq_ulong, void *);
+void free_hashtable(hashtable);
+void reset_hashtable(hashtable);
+void init_hash_traversal(hashtable table);
+void *next_hash_object(hashtable table);
+void *next_hashnode(hashtable table);
+void hashtable_stats(hashtable table);
+
+/* ---- fastq.h ---- */
+#define FQC_MAX_READ_LENGTH 2500000
+#define FQC_MAX_LABEL_LENGTH 1000
+#define FQC_MAX_FILENAME_LENGTH 5000
+
+extern unsigned long index_mem;
+extern char *encodings[];
+
+struct index_entry {
+  char *hdr;
+  off_t entry_start;
+};
+typedef struct index_entry INDEX_ENTRY;
+
+struct fastq_entry {
+  char hdr1[FQC_MAX_LABEL_LENGTH];
+  char hdr2[FQC_MAX_LABEL_LENGTH];
+  char seq[FQC_MAX_READ_LENGTH];
+  char qual[FQC_MAX_READ_LENGTH];
+  unsigned long read_len;
+  long long offset;
+};
+typedef struct fastq_entry FASTQ_ENTRY;
+
+struct fastq_file {
+  gzFile fd;
+  long long cur_offset;
+  unsigned long cline;
+  char filename[FQC_MAX_FILENAME_LENGTH];
+  unsigned long max_rl, last_rl, min_rl;
+  unsigned long min_qual, max_qual;
+  unsigned long num_rds;
+  unsigned long rdlen_ctr[FQC_MAX_READ_LENGTH];
+  int fix_dot, fixed_dot, is_pe, readname_format, is_casava_18;
+  int space; /* READ_SPACE: COLORSPACE = 1, SEQSPACE = 0, UNDEFSPACE = -1 */
+};
+typedef struct fastq_file FASTQ_FILE;
+
+void fastq_print_version(void);
+FASTQ_ENTRY *fastq_new_entry(void);
+void fastq_write_entry(FASTQ_FILE *fd, FASTQ_ENTRY *e);
+unsigned long get_elength(FASTQ_ENTRY *);
+void fastq_index_delete(char *rname, hashtable index);
+INDEX_ENTRY *fastq_index_lookup_header(hashtable sn_index, char *hdr);
+char *fastq_get_readname(FASTQ_FILE *, FASTQ_ENTRY *, char *rn, unsigned long *, int is_header1);
+int fastq_read_entry(FASTQ_FILE *fd, FASTQ_ENTRY *e);
+void fastq_new_entry_stats(FASTQ_FILE *, FASTQ_ENTRY *);
+int fastq_validate_entry(FASTQ_FILE *fd, FASTQ_ENTRY *e);
+int fastq_read_next_entry(FASTQ_FILE *fd, FASTQ_ENTRY *e);
+FASTQ_FILE *fastq_new(const char *filename, const int fix_dot, const char *mode);
+void fastq_destroy(FASTQ_FILE *);
+void fastq_is_pe(FASTQ_FILE *fd);
+void fastq_index_readnames(FASTQ_FILE *, hashtable, long long, int);
+void fastq_write_entry2stdout(FASTQ_ENTRY *e);
+char *fastq_qualRange2enc(unsigned int min_qual, unsigned int max_qual);
+gzFile fastq_open(const char *filename, const char *mode);
+void GZ_WRITE(gzFile fd, char *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

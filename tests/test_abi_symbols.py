@@ -53,3 +53,63 @@ def test_no_gpu_means_no_context():
         pytest.skip("a GPU is present")
     with pytest.raises(fq.abi.FqgError):
         fq.Context(0)
+
+
+COMPAT_EXPORTS = [
+    "fastq_print_version", "fastq_new_entry", "fastq_write_entry", "get_elength", "fastq_index_delete",
+    "fastq_index_lookup_header", "fastq_get_readname", "fastq_read_entry", "fastq_new_entry_stats",
+    "fastq_validate_entry", "fastq_read_next_entry", "fastq_new", "fastq_destroy", "fastq_is_pe",
+    "fastq_index_readnames", "fastq_write_entry2stdout", "fastq_qualRange2enc", "fastq_open", "GZ_WRITE",
+    "index_mem", "encodings", "new_hashtable", "get_next_object", "delete", "get_object", "insere",
+    "free_hashtable", "reset_hashtable", "init_hash_traversal", "next_hash_object", "next_hashnode",
+    "hashtable_stats",
+]
+
+
+def test_compat_library_exports_the_reference_api():
+    """libfastq_gpu.so carries the names of src/fastq.h:84-158 and src/hash.h:64-78 (no compute call here)."""
+    import ctypes
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastq_utils_amd", "libfastq_gpu.so")
+    assert os.path.exists(path), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(path)
+    for name in COMPAT_EXPORTS:
+        assert hasattr(lib, name), name
+
+
+def test_compat_header_layouts_match_the_reference_headers(tmp_path):
+    """Same struct layouts as the reference's own headers (only where the reference checkout exists: the
+    build container).  Two tiny programs print sizeof / offsetof under each header set."""
+    import os
+    import subprocess
+
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        import pytest
+        pytest.skip("no reference checkout here")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = r'''
+#include <stdio.h>
+#include <stddef.h>
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(FASTQ_ENTRY), offsetof(FASTQ_ENTRY, hdr2), offsetof(FASTQ_ENTRY, seq),
+         offsetof(FASTQ_ENTRY, qual), offsetof(FASTQ_ENTRY, read_len), offsetof(FASTQ_ENTRY, offset));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(FASTQ_FILE), offsetof(FASTQ_FILE, cline),
+         offsetof(FASTQ_FILE, filename), offsetof(FASTQ_FILE, max_rl), offsetof(FASTQ_FILE, min_qual),
+         offsetof(FASTQ_FILE, num_rds), offsetof(FASTQ_FILE, rdlen_ctr), offsetof(FASTQ_FILE, is_pe),
+         offsetof(FASTQ_FILE, space));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(struct hashtable_s), offsetof(struct hashtable_s, size),
+         offsetof(struct hashtable_s, n_entries), sizeof(hashnode), sizeof(INDEX_ENTRY));
+  return 0;
+}
+'''
+    outs = []
+    for tag, inc, hdr in (("ours", os.path.join(repo, "include"), '#include "fastq_gpu_compat.h"'),
+                          ("ref", ref, '#include "fastq.h"')):
+        src = tmp_path / (tag + ".c")
+        src.write_text(hdr + body)
+        exe = tmp_path / tag
+        subprocess.run(["gcc", "-w", "-I", inc, "-o", str(exe), str(src)], check=True)
+        outs.append(subprocess.run([str(exe)], capture_output=True, check=True).stdout)
+    assert outs[0] == outs[1]
