@@ -169,14 +169,43 @@ __device__ __forceinline__ unsigned long long pack_barcode(const uint8_t* s, uin
   return v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict__ buf, uint64_t nbytes,
+// The 64 records of a wavefront are contiguous in the stream: they are staged in LDS with coalesced
+// 16-byte loads, and every thread then walks ITS record there (a thread-per-record walk over global
+// memory touches 64 different cache lines per instruction).  Spans larger than the buffer (long
+// records) are walked in global memory.
+constexpr int kParseStage = 16 * 1024;  // bytes per wavefront
+
+__global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict__ gbuf, uint64_t nbytes,
                                                       const unsigned long long* __restrict__ offs, uint32_t n,
                                                       UmiParams P, UmiRec* __restrict__ rec,
                                                       uint8_t* __restrict__ stage, UmiCall* __restrict__ call) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kBlock / kWave][kParseStage + 32];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t i0 = blockIdx.x * kBlock + (uint32_t)wv * kWave;
+  if (i0 >= n) return;
+  const uint32_t i_last = i0 + kWave - 1 < n - 1 ? i0 + kWave - 1 : n - 1;
+  const uint64_t span0 = offs[i0] & ~15ull;  // aligned down: 16-byte loads
+  const uint64_t span1 = i_last + 1 < n ? offs[i_last + 1] : nbytes;
+  const bool staged = span1 - span0 <= (uint64_t)kParseStage;
+  if (staged) {
+    uint8_t* dstb = s_stage[wv];
+    for (uint64_t o = (uint64_t)lane * 16; o < span1 - span0; o += 16 * kWave) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (span0 + o + 16 <= nbytes) v = *reinterpret_cast<const uint4*>(gbuf + span0 + o);
+      else
+        for (uint64_t b = 0; span0 + o + b < nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&v)[b] = gbuf[span0 + o + b];
+      *reinterpret_cast<uint4*>(dstb + o) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   if (i >= n) return;
-  const uint8_t* lim = buf + nbytes;
-  const uint8_t* r = buf + offs[i];
+  // `base` is byte span0 of the stream either way (every pointer stays inside its buffer); offsets
+  // written out are stream offsets
+  const uint8_t* base = staged ? s_stage[wv] : gbuf + span0;
+  const uint8_t* lim = base + ((staged ? span1 : nbytes) - span0);
+  const uint8_t* r = base + (offs[i] - span0);
   uint8_t st = kStSkipped;
   UmiRec out;
   out.umi_i = out.cell_i = 0;
@@ -242,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict_
       prev_s = s0;
       prev_l = len;
     }
-    out.tok_off = (unsigned long long)(feat - buf) + t0;
+    out.tok_off = span0 + (unsigned long long)(feat - base) + t0;
     out.tok_len = l0;
     out.incr = (float)(1.0 / (double)((int)n_feat * nh_i));  // float incr=1.0/(n_feat*nh_i) :1044
   } while (false);
@@ -274,7 +303,9 @@ __device__ __forceinline__ uint32_t table_insert(const KeyTable& T, unsigned lon
       if (k == kKeyEmpty) k = key;
     }
     if (k == key) {
-      atomicMin(&T.first[h], idx);
+      // hot keys (a cell's run of records, a highly expressed gene) are hit by thousands of threads:
+      // look first - the value only ever decreases, so a stale larger one costs an atomic, never a miss
+      if (T.first[h] > idx) atomicMin(&T.first[h], idx);
       return (uint32_t)h;
     }
     h = (h + 1) & T.mask;
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_insert(const uint8_t* __restrict
                   }
               }
               if (same) {
-                atomicMin(&F.first[h], i);
+                if (F.first[h] > i) atomicMin(&F.first[h], i);
                 fs = (uint32_t)h;
                 break;
               }
