@@ -1199,6 +1199,7 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   uint64_t n_done = n_iter;
+  const uint64_t n_big = c->h_bcall->big;
   if (c->h_bcall->first_finding != ~0ull) {
     const uint64_t k = c->h_bcall->first_finding >> 8;
     n_done = k;
@@ -1241,13 +1242,19 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
     ProfScope ps(c, "k_bc_emit");
     const unsigned grid_e =
         (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));
-    hipLaunchKernelGGL(k_bc_emit, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done, (const uint8_t*)c->bc_status.p,
-                       (const uint32_t*)c->bc_len[0].p, (const unsigned long long*)c->bc_off[0].p,
-                       (const unsigned long long*)c->bc_sum[0].p, (const uint32_t*)c->bc_len[1].p,
-                       (const unsigned long long*)c->bc_off[1].p, (const unsigned long long*)c->bc_sum[1].p,
-                       (const uint32_t*)c->bc_len[2].p, (const unsigned long long*)c->bc_off[2].p,
-                       (const unsigned long long*)c->bc_sum[2].p, (uint8_t*)c->bc_out[0].p, (uint8_t*)c->bc_out[1].p,
-                       (uint8_t*)c->bc_out[2].p);
+    EmitOut eo[3];
+    for (int i = 0; i < 3; ++i)
+      eo[i] = EmitOut{(const uint32_t*)c->bc_len[i].p, (const unsigned long long*)c->bc_off[i].p,
+                      (const unsigned long long*)c->bc_sum[i].p, (uint8_t*)c->bc_out[i].p};
+    if (P.out_sam)
+      hipLaunchKernelGGL(k_bc_emit<true>, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done,
+                         (const uint8_t*)c->bc_status.p, eo[0], eo[1], eo[2]);
+    else
+      hipLaunchKernelGGL(k_bc_emit<false>, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done,
+                         (const uint8_t*)c->bc_status.p, eo[0], eo[1], eo[2]);
+    if (n_big)
+      hipLaunchKernelGGL(k_bc_emit_direct, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done,
+                         (const uint8_t*)c->bc_status.p, eo[0], eo[1], eo[2]);
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());

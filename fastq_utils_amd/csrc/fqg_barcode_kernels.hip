@@ -15,7 +15,10 @@
 namespace fqg {
 
 constexpr int kBcFiles = 6;  // index 1..5 as in the reference (READ1, READ2, INDEX1..3)
-enum : uint8_t { kBcKeep = 0, kBcDiscardShort = 1, kBcDiscardQual = 2, kBcFinding = 3 };
+enum : uint8_t { kBcKeep = 0, kBcDiscardShort = 1, kBcDiscardQual = 2, kBcFinding = 3,
+                 kBcKeepBig = 4 };  // kept, but records / text exceed the LDS buffers of k_bc_emit
+constexpr int kEmitBuf = 2048;   // output text per wavefront (k_bc_emit)
+constexpr int kEmitSrc = 2560;   // staged input records per wavefront
 
 struct BcFile {
   FrameView fv;
@@ -42,6 +45,7 @@ struct BcCall {
   unsigned long long first_finding;  // min over iterations of (iteration << 8 | code << 3 | file)
   unsigned long long first_discard;  // first discarded iteration (interleaved input re-syncs there)
   unsigned long long discarded, short_warnings;
+  unsigned long long big;  // kBcKeepBig iterations
 };
 
 struct BcLine {
@@ -276,8 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_bc_plan(BcParams P, uint64_t n_iter,
   if (k >= n_iter) return;
   BcTags t;
   uint32_t finding;
-  const uint8_t st = bc_decide(P, k, &t, &finding);
-  status[k] = st;
+  uint8_t st = bc_decide(P, k, &t, &finding);
   uint32_t a = 0, b = 0, c = 0;
   if (st == kBcKeep) {
     if (P.out_sam) a = bc_sam_len(P, k, t);
@@ -285,11 +288,24 @@ __global__ __launch_bounds__(kBlock) void k_bc_plan(BcParams P, uint64_t n_iter,
       if (P.emit[1]) b = bc_fastq_len(P, 1, k, t);
       if (P.emit[2]) c = bc_fastq_len(P, 2, k, t);
     }
+    // do the records and the text fit the LDS buffers of the emit kernel?
+    uint64_t in_bytes = 0;
+    for (int x = 1; x < kBcFiles; ++x)
+      if (P.f[x].present) {
+        BcLine ln[4];
+        bc_lines(P.f[x], k, ln);
+        in_bytes += (uint64_t)((ln[3].p + ln[3].len + ln[3].nl) - ln[0].p);
+      }
+    if (in_bytes > (uint64_t)kEmitSrc || a > (uint32_t)kEmitBuf || b > (uint32_t)kEmitBuf || c > (uint32_t)kEmitBuf) {
+      st = kBcKeepBig;
+      atomicAdd(&call->big, 1ull);
+    }
   } else if (st == kBcFinding) {
     atomicMin(&call->first_finding, (unsigned long long)((k << 8) | finding));
   } else {
     atomicMin(&call->first_discard, (unsigned long long)k);
   }
+  status[k] = st;
   len0[k] = a;
   len1[k] = b;
   len2[k] = c;
@@ -371,9 +387,21 @@ __global__ __launch_bounds__(kBlock) void k_scan64_b(unsigned long long* __restr
 }
 
 // ---- emit -----------------------------------------------------------------------------------
+// up to 16 characters of a literal as two 64-bit immediates (no memory access when written)
+constexpr uint64_t lit_pack(const char* s, int n, int from) {
+  uint64_t v = 0;
+  for (int i = 0; i < 8 && from + i < n; ++i) v |= (uint64_t)(uint8_t)s[from + i] << (8 * i);
+  return v;
+}
+#define BC_LIT(w, str) (w).lit_imm(lit_pack(str, (int)sizeof(str) - 1, 0), lit_pack(str, (int)sizeof(str) - 1, 8), (uint32_t)sizeof(str) - 1)
+
 struct Writer {
   uint8_t* p;
   int lane;
+  __device__ __forceinline__ void lit_imm(uint64_t lo, uint64_t hi, uint32_t n) {
+    if ((uint32_t)lane < n) p[lane] = (uint8_t)((lane < 8 ? lo >> (8 * lane) : hi >> (8 * (lane - 8))) & 0xFFu);
+    p += n;
+  }
   __device__ __forceinline__ void bytes(const uint8_t* s, uint32_t n) {
     for (uint32_t i = lane; i < n; i += kWave) p[i] = s[i];
     p += n;
@@ -409,13 +437,13 @@ __device__ __forceinline__ void bc_emit_fastq(const BcParams& P, int x, const Bc
   const bool sliced = bc_slices(P, x);
   if (tagged) {  // add_tags2readname, src/fastq_pre_barcodes.c:192-216
     w.ch((char)ln[0].p[0]);
-    w.lit("STAGS_CELL=", 11);
+    BC_LIT(w, "STAGS_CELL=");
     w.bytes(t.s[1], t.n[1]);
-    w.lit("_UMI=", 5);
+    BC_LIT(w, "_UMI=");
     w.bytes(t.s[0], t.n[0]);
-    w.lit("_SAMPLE=", 8);
+    BC_LIT(w, "_SAMPLE=");
     w.bytes(t.s[2], t.n[2]);
-    w.lit("_ETAGS_", 7);
+    BC_LIT(w, "_ETAGS_");
     w.bytes(ln[0].p + 1, ln[0].len + ln[0].nl - 1);
   } else {
     w.bytes(ln[0].p, ln[0].len + ln[0].nl);
@@ -444,49 +472,48 @@ __device__ __forceinline__ void bc_emit_sam(const BcParams& P, uint64_t k, const
     w.dec(P.first_read_number + k + 1);
     w.ch('\t');
     w.dec(flag);
-    w.lit("\t*\t0\t255\t*\t*\t0\t", 15);
+    BC_LIT(w, "\t*\t0\t255\t*\t*\t0\t");
     w.dec(g.shown);
     w.ch('\t');
     w.bytes(ln[1].p + g.cs.from, g.seq_n);
     w.ch('\t');
     w.bytes(ln[3].p + g.cq.from, g.qual_n);
-    w.lit("\ton:Z:", 6);
+    BC_LIT(w, "\ton:Z:");
     w.name(ln[0].p + 1, g.name_n);
-    w.lit("\top:Z:", 6);
+    BC_LIT(w, "\top:Z:");
     w.bytes(ln[3].p + g.cq.from, g.qual_n);
     if (t.n[0]) {
-      w.lit(P.tenx ? "\tUB:Z:" : "\tRX:Z:", 6);
+      if (P.tenx) BC_LIT(w, "\tUB:Z:"); else BC_LIT(w, "\tRX:Z:");
       w.bytes(t.s[0], t.n[0]);
-      w.lit(P.tenx ? "\tUY:Z:" : "\tQX:Z:", 6);
+      if (P.tenx) BC_LIT(w, "\tUY:Z:"); else BC_LIT(w, "\tQX:Z:");
       w.bytes(t.q[0], t.n[0]);
     }
     if (t.n[1]) {
-      w.lit(x == 1 ? "\tCR:Z:" : " CR:Z:", 6);  // the second mate gets a blank (src/fastq_pre_barcodes.c:705)
+      if (x == 1) BC_LIT(w, "\tCR:Z:"); else BC_LIT(w, " CR:Z:");  // the second mate gets a blank (src/fastq_pre_barcodes.c:705)
       w.bytes(t.s[1], t.n[1]);
-      w.lit("\tCY:Z:", 6);
+      BC_LIT(w, "\tCY:Z:");
       w.bytes(t.q[1], t.n[1]);
     }
     if (t.n[2]) {
-      w.lit("\tBC:Z:", 6);
+      BC_LIT(w, "\tBC:Z:");
       w.bytes(t.s[2], t.n[2]);
-      w.lit("\tQT:Z:", 6);
+      BC_LIT(w, "\tQT:Z:");
       w.bytes(t.q[2], t.n[2]);
     }
     w.ch('\n');
   }
 }
 
-// One wavefront per kept iteration.
+// k_bc_emit<SAM>: one wavefront per kept iteration whose records and text fit the LDS buffers (all
+// but long reads; the others are kBcKeepBig and go through k_bc_emit_direct).
 //   1. The records of the iteration (the four lines are contiguous in the image) are copied into an
 //      LDS staging area with all loads in flight at once - the ~25 pieces of a SAM line would otherwise
 //      cost one memory round trip each.
-//   2. The output text is assembled piece by piece in a second LDS buffer (LDS -> LDS byte copies).
+//   2. The output text is assembled piece by piece in a second LDS buffer (LDS -> LDS byte copies,
+//      literals as immediates).
 //   3. The text goes to its place in the output image with 16-byte stores: the buffer starts at the
 //      same residue mod 16 as the global address, so aligned 16-byte units of LDS and of the output
 //      coincide.
-// Records or texts larger than the buffers (long reads) take the direct path from / to global memory.
-constexpr int kEmitBuf = 2048;   // output text per wavefront
-constexpr int kEmitSrc = 2560;   // staged input records per wavefront
 constexpr int kEmitChunks = 10;  // kEmitSrc / 64 / 4: byte loads in flight per lane and round
 
 __device__ __forceinline__ void emit_flush(const uint8_t* __restrict__ buf, uint32_t skew, uint32_t len,
@@ -502,18 +529,16 @@ __device__ __forceinline__ void emit_flush(const uint8_t* __restrict__ buf, uint
     for (uint32_t i = last_full + lane; i < end; i += kWave) g0[i] = buf[i];
 }
 
+struct EmitOut {
+  const uint32_t* len;
+  const unsigned long long* off;
+  const unsigned long long* sum;
+  uint8_t* out;
+};
+
+template <bool SAM>
 __global__ __launch_bounds__(kBlock) void k_bc_emit(BcParams P, uint64_t n_done, const uint8_t* __restrict__ status,
-                                                    const uint32_t* __restrict__ len0,
-                                                    const unsigned long long* __restrict__ off0,
-                                                    const unsigned long long* __restrict__ sum0,
-                                                    const uint32_t* __restrict__ len1,
-                                                    const unsigned long long* __restrict__ off1,
-                                                    const unsigned long long* __restrict__ sum1,
-                                                    const uint32_t* __restrict__ len2,
-                                                    const unsigned long long* __restrict__ off2,
-                                                    const unsigned long long* __restrict__ sum2,
-                                                    uint8_t* __restrict__ out0, uint8_t* __restrict__ out1,
-                                                    uint8_t* __restrict__ out2) {
+                                                    EmitOut o0, EmitOut o1, EmitOut o2) {
   __shared__ __attribute__((aligned(16))) uint8_t s_buf[kBlock / kWave][kEmitBuf + 16];
   __shared__ uint8_t s_src[kBlock / kWave][kEmitSrc];
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
@@ -525,71 +550,76 @@ __global__ __launch_bounds__(kBlock) void k_bc_emit(BcParams P, uint64_t n_done,
   for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_done; k += n_waves) {
     if (status[k] != kBcKeep) continue;
     BcLine lines[kBcFiles][4];
-    uint32_t rec_len[kBcFiles], total = 0;
+    uint32_t at = 0;
 #pragma unroll
     for (int x = 1; x < kBcFiles; ++x) {
-      rec_len[x] = 0;
       if (!P.f[x].present) continue;
+      if (SAM && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) continue;  // not printed, no tag
       bc_lines(P.f[x], k, lines[x]);
-      rec_len[x] = (uint32_t)((lines[x][3].p + lines[x][3].len + lines[x][3].nl) - lines[x][0].p);
-      total += rec_len[x];
-    }
-    if (total <= (uint32_t)kEmitSrc) {
-      // stage: every lane issues its byte loads of all files before the first one is consumed
-      uint32_t at = 0;
+      const uint8_t* g = lines[x][0].p;
+      const uint32_t n = (uint32_t)((lines[x][3].p + lines[x][3].len + lines[x][3].nl) - g);
+      // stage: every lane issues its byte loads before the first one is consumed
+      for (uint32_t base = 0; base < n; base += kEmitChunks * kWave) {
+        uint8_t v[kEmitChunks];
 #pragma unroll
-      for (int x = 1; x < kBcFiles; ++x) {
-        if (!rec_len[x]) continue;
-        const uint8_t* g = lines[x][0].p;
-        const uint32_t n = rec_len[x];
-        for (uint32_t base = 0; base < n; base += kEmitChunks * kWave) {
-          uint8_t v[kEmitChunks];
-#pragma unroll
-          for (int c = 0; c < kEmitChunks; ++c) {
-            const uint32_t i = base + c * kWave + lane;
-            v[c] = i < n ? g[i] : (uint8_t)0;
-          }
-#pragma unroll
-          for (int c = 0; c < kEmitChunks; ++c) {
-            const uint32_t i = base + c * kWave + lane;
-            if (i < n) src[at + i] = v[c];
-          }
+        for (int c = 0; c < kEmitChunks; ++c) {
+          const uint32_t i = base + c * kWave + lane;
+          v[c] = i < n ? g[i] : (uint8_t)0;
         }
-        // re-point the four lines at the copy
-        const uint8_t* g0 = lines[x][0].p;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) lines[x][l].p = src + at + (uint32_t)(lines[x][l].p - g0);
-        at += n;
+        for (int c = 0; c < kEmitChunks; ++c) {
+          const uint32_t i = base + c * kWave + lane;
+          if (i < n) src[at + i] = v[c];
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < 4; ++l) lines[x][l].p = src + at + (uint32_t)(lines[x][l].p - g);  // now in LDS
+      at += n;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     BcTags t;
     bc_tags_of_kept(P, lines, &t);
 #pragma unroll
+    for (int which = SAM ? 0 : 1; which < (SAM ? 1 : 3); ++which) {
+      if (!SAM && !P.emit[which]) continue;
+      const EmitOut& o = which == 0 ? o0 : (which == 1 ? o1 : o2);
+      uint8_t* dst = o.out + o.off[k] + o.sum[k / kScan64Span];
+      const uint32_t len = o.len[k];
+      const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
+      Writer w{buf + skew, lane};
+      if (SAM) bc_emit_sam(P, k, lines, t, w);
+      else bc_emit_fastq(P, which, lines[which], t, w);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      emit_flush(buf, skew, len, dst, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// kBcKeepBig iterations (long reads): the text is written straight to the output image
+__global__ __launch_bounds__(kBlock) void k_bc_emit_direct(BcParams P, uint64_t n_done,
+                                                           const uint8_t* __restrict__ status, EmitOut o0, EmitOut o1,
+                                                           EmitOut o2) {
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_done; k += n_waves) {
+    if (status[k] != kBcKeepBig) continue;
+    BcLine lines[kBcFiles][4];
+#pragma unroll
+    for (int x = 1; x < kBcFiles; ++x)
+      if (P.f[x].present) bc_lines(P.f[x], k, lines[x]);
+    BcTags t;
+    bc_tags_of_kept(P, lines, &t);
     for (int which = 0; which < 3; ++which) {
       if (which == 0 ? !P.out_sam : (P.out_sam || !P.emit[which])) continue;
-      const uint32_t* lens = which == 0 ? len0 : (which == 1 ? len1 : len2);
-      const unsigned long long* off = which == 0 ? off0 : (which == 1 ? off1 : off2);
-      const unsigned long long* sum = which == 0 ? sum0 : (which == 1 ? sum1 : sum2);
-      uint8_t* dst = (which == 0 ? out0 : (which == 1 ? out1 : out2)) + off[k] + sum[k / kScan64Span];
-      const uint32_t len = lens[k];
-      if (len <= (uint32_t)kEmitBuf) {
-        const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
-        Writer w{buf + skew, lane};
-        if (which == 0) bc_emit_sam(P, k, lines, t, w);
-        else bc_emit_fastq(P, which, lines[which], t, w);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        emit_flush(buf, skew, len, dst, lane);
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        Writer w{dst, lane};
-        if (which == 0) bc_emit_sam(P, k, lines, t, w);
-        else bc_emit_fastq(P, which, lines[which], t, w);
-      }
+      const EmitOut& o = which == 0 ? o0 : (which == 1 ? o1 : o2);
+      Writer w{o.out + o.off[k] + o.sum[k / kScan64Span], lane};
+      if (which == 0) bc_emit_sam(P, k, lines, t, w);
+      else if (which == 1) bc_emit_fastq(P, 1, lines[1], t, w);
+      else bc_emit_fastq(P, 2, lines[2], t, w);
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
