@@ -76,7 +76,7 @@ struct fqg_ctx {
   bool frame_valid = false;
   bool frame_img_owned = false;  // the frame's image lives in `image` (host input), not with the caller
   uint32_t frame_flags = 0;      // kFlagNul / kFlagCr of the framed image
-  DevBuf bc_status, bc_len[3], bc_off[3], bc_sum[3], bc_out[3];
+  DevBuf bc_status, bc_len[3], bc_off[3], bc_sum[3], bc_out[3], bc_tile_big;
   BcCall* d_bcall = nullptr;
   BcCall* h_bcall = nullptr;  // pinned
   uint64_t bc_out_bytes[3] = {0, 0, 0};
@@ -263,6 +263,7 @@ void fqg_close(fqg_ctx* c) {
   release(c->umi_entries[0]);
   release(c->umi_entries[1]);
   release(c->bc_status);
+  release(c->bc_tile_big);
   for (int i = 0; i < 3; ++i) {
     release(c->bc_len[i]);
     release(c->bc_off[i]);
@@ -1119,6 +1120,41 @@ int fqg_names_compare(fqg_ctx* c, const fqg_frame* a, const fqg_file_state* sa, 
 }
 
 // ---- barcode extraction ----------------------------------------------------------------------
+// Tile geometry for one call: T iterations whose records and output text fit `budget` bytes of LDS
+// per wavefront, from the mean record sizes (a tile that does not fit anyway takes the direct path).
+// FQGPU_BC_LDS overrides the budget (bytes, 4096..65536).
+static BcTile bc_tile_for(const BcParams& P) {
+  static const unsigned budget = [] {
+    const char* e = getenv("FQGPU_BC_LDS");
+    const long v = e ? atol(e) : 0;
+    return (unsigned)(v >= 4096 && v <= 65536 ? v : 32768);
+  }();
+  double in = 0, out_sam = 0, out_fq = 0;
+  int files = 0;
+  for (int x = 1; x < kBcFiles; ++x) {
+    if (!P.f[x].present) continue;
+    const double rec = P.f[x].fv.n_records ? (double)P.f[x].fv.nbytes / (double)P.f[x].fv.n_records : 0.0;
+    in += rec * P.f[x].step;
+    ++files;
+    if (x <= 2) {
+      out_sam += 1.35 * rec + 130;
+      if (P.emit[x]) out_fq = std::max(out_fq, rec + 100);
+    }
+  }
+  const double out = P.out_sam ? out_sam : out_fq;
+  const unsigned lanes_per_iter = P.out_sam && P.f[2].present ? 2 : 1;
+  const double fixed = 48.0 * files + 96.0;
+  double t = ((double)budget - fixed) / (1.06 * (in + out) + 1.0);
+  unsigned T = (unsigned)std::max(1.0, std::min(t, 64.0 / lanes_per_iter));
+  BcTile tc;
+  tc.T = T;
+  tc.in_cap = ((unsigned)(1.06 * in * T + 48.0 * files + 48.0) + 15u) & ~15u;
+  if (tc.in_cap + 1024u > budget) tc.in_cap = (budget / 2) & ~15u;
+  tc.out_cap = (budget - tc.in_cap) & ~15u;
+  tc.pad = 0;
+  return tc;
+}
+
 int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const fqg_file_state states[6],
                            const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_iter,
                            uint64_t first_read_number, fqg_barcode_result* out) {
@@ -1190,11 +1226,17 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   z.first_finding = z.first_discard = ~0ull;
   *c->h_bcall = z;
   HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
-  const unsigned grid = (unsigned)((n_iter + kBlock - 1) / kBlock);
+  const BcTile tc = bc_tile_for(P);
+  const uint64_t n_tiles = (n_iter + tc.T - 1) / tc.T;
+  if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
+  const unsigned tile_waves = std::max(1u, (160u * 1024u) / (tc.in_cap + tc.out_cap));  // per CU, emit (LDS-bound)
   {
     ProfScope ps(c, "k_bc_plan");
-    hipLaunchKernelGGL(k_bc_plan, dim3(grid), dim3(kBlock), 0, c->stream, P, n_iter, (uint8_t*)c->bc_status.p,
-                       (uint32_t*)c->bc_len[0].p, (uint32_t*)c->bc_len[1].p, (uint32_t*)c->bc_len[2].p, c->d_bcall);
+    const unsigned per_cu = std::min(16u, std::max(1u, (160u * 1024u) / tc.in_cap));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->cu_count * per_cu);
+    hipLaunchKernelGGL(k_bc_plan_tile, dim3(grid), dim3(kWave), tc.in_cap, c->stream, P, tc, n_iter,
+                       (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[0].p, (uint32_t*)c->bc_len[1].p,
+                       (uint32_t*)c->bc_len[2].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1220,9 +1262,11 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   const uint64_t nb_done = (n_done + kScan64Span - 1) / kScan64Span;
   {
     ProfScope ps(c, "k_bc_scan");
-    hipLaunchKernelGGL(k_bc_count, dim3((unsigned)((n_done + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                       (const uint8_t*)c->bc_status.p, n_done, c->d_bcall);
+    hipLaunchKernelGGL(k_bc_count, dim3((unsigned)std::min<uint64_t>((n_done + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0,
+                       c->stream, (const uint8_t*)c->bc_status.p, n_done, c->d_bcall);
+    HIP_TRY(c, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < 3; ++i) {
+      if (P.out_sam ? i != 0 : !P.emit[i]) continue;  // outputs that are not produced have no lengths
       hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb_done), dim3(kBlock), 0, c->stream, (const uint32_t*)c->bc_len[i].p,
                          n_done, (unsigned long long*)c->bc_off[i].p, (unsigned long long*)c->bc_sum[i].p);
       hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->bc_sum[i].p, nb_done,
@@ -1240,21 +1284,25 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   }
   {
     ProfScope ps(c, "k_bc_emit");
-    const unsigned grid_e =
-        (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));
     EmitOut eo[3];
     for (int i = 0; i < 3; ++i)
       eo[i] = EmitOut{(const uint32_t*)c->bc_len[i].p, (const unsigned long long*)c->bc_off[i].p,
                       (const unsigned long long*)c->bc_sum[i].p, (uint8_t*)c->bc_out[i].p};
+    const uint64_t n_tiles_done = (n_done + tc.T - 1) / tc.T;
+    const unsigned grid_t = (unsigned)std::min<uint64_t>(n_tiles_done, (uint64_t)c->cu_count * tile_waves);
+    const unsigned lds = tc.in_cap + tc.out_cap;
     if (P.out_sam)
-      hipLaunchKernelGGL(k_bc_emit<true>, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done,
-                         (const uint8_t*)c->bc_status.p, eo[0], eo[1], eo[2]);
+      hipLaunchKernelGGL(k_bc_emit_tile<true>, dim3(grid_t), dim3(kWave), lds, c->stream, P, tc, n_done,
+                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);
     else
-      hipLaunchKernelGGL(k_bc_emit<false>, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done,
-                         (const uint8_t*)c->bc_status.p, eo[0], eo[1], eo[2]);
-    if (n_big)
-      hipLaunchKernelGGL(k_bc_emit_direct, dim3(grid_e), dim3(kBlock), 0, c->stream, P, n_done,
-                         (const uint8_t*)c->bc_status.p, eo[0], eo[1], eo[2]);
+      hipLaunchKernelGGL(k_bc_emit_tile<false>, dim3(grid_t), dim3(kWave), lds, c->stream, P, tc, n_done,
+                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);
+    if (n_big) {
+      const unsigned grid_e =
+          (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));
+      hipLaunchKernelGGL(k_bc_emit_direct, dim3(grid_e), dim3(kBlock), 0, c->stream, P, tc, n_done,
+                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);
+    }
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());

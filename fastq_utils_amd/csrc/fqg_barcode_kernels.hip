@@ -4,21 +4,32 @@
 // quality), the header gets the STAGS_..._ETAGS_ prefix, reads are optionally sliced, and the
 // result is emitted as FASTQ text (one or two outputs) or as SAM lines.
 //
-// Three launches per batch of iterations:
-//   k_bc_plan   one thread per iteration: status (keep / discarded / finding) and the exact
-//               number of output bytes of every output
-//   scan        64-bit exclusive prefix of the byte counts -> where each iteration writes
-//   k_bc_emit   one wavefront per kept iteration: cooperative byte copies into the output image
+// Three launches per batch of iterations; plan and emit work on TILES of T consecutive iterations,
+// one wavefront per tile, whose records (contiguous in every input image) are first copied into LDS
+// with 16-byte loads:
+//   k_bc_plan_tile  one lane per iteration, reading its records from LDS: status (keep / discarded /
+//                   finding) and the exact number of output bytes of every output
+//   scan            64-bit exclusive prefix of the byte counts -> where each iteration writes
+//   k_bc_emit_tile  one lane per output line (SAM) or record (FASTQ): the lane writes its text into the
+//                   tile's LDS output area, which then goes to the output image with 16-byte stores
+// T is chosen by the host from the mean record sizes so that a tile fits its LDS areas; a tile that
+// does not fit (long reads) is flagged by the plan and handled by the slower direct paths (records read
+// from the images, one wavefront per iteration in k_bc_emit_direct).
 // Inputs are framed images (line index from fqg_validate); nothing is re-parsed on the host.
 #include "fqg_device.h"
 
 namespace fqg {
 
 constexpr int kBcFiles = 6;  // index 1..5 as in the reference (READ1, READ2, INDEX1..3)
-enum : uint8_t { kBcKeep = 0, kBcDiscardShort = 1, kBcDiscardQual = 2, kBcFinding = 3,
-                 kBcKeepBig = 4 };  // kept, but records / text exceed the LDS buffers of k_bc_emit
-constexpr int kEmitBuf = 2048;   // output text per wavefront (k_bc_emit)
-constexpr int kEmitSrc = 2560;   // staged input records per wavefront
+enum : uint8_t { kBcKeep = 0, kBcDiscardShort = 1, kBcDiscardQual = 2, kBcFinding = 3 };
+
+// tile geometry of one call (host: bc_tile_for)
+struct BcTile {
+  uint32_t T;        // iterations per tile (<= 64 / lines per iteration)
+  uint32_t in_cap;   // LDS bytes for the staged records
+  uint32_t out_cap;  // LDS bytes for the output text (emit only)
+  uint32_t pad;
+};
 
 struct BcFile {
   FrameView fv;
@@ -45,7 +56,7 @@ struct BcCall {
   unsigned long long first_finding;  // min over iterations of (iteration << 8 | code << 3 | file)
   unsigned long long first_discard;  // first discarded iteration (interleaved input re-syncs there)
   unsigned long long discarded, short_warnings;
-  unsigned long long big;  // kBcKeepBig iterations
+  unsigned long long big;  // tiles that do not fit LDS
 };
 
 struct BcLine {
@@ -67,22 +78,55 @@ __device__ __forceinline__ void bc_lines(const BcFile& f, uint64_t k, BcLine ln[
   }
 }
 
-// canonical read name with is_pe set (every input of fastq_pre_barcodes has it, :570)
-__device__ inline uint32_t bc_name_len(const BcLine& h, int fmt) {
+// 8 bytes at any alignment (LDS: one ds_read_b64; gfx950 has unaligned DS access)
+__device__ __forceinline__ uint64_t ld8(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+// 0x80 in every byte of x that equals c
+__device__ __forceinline__ uint64_t bytes_eq(uint64_t x, uint8_t c) {
+  const uint64_t y = x ^ (0x0101010101010101ull * c);
+  const uint64_t t = ((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y;
+  return ~(t | 0x7F7F7F7F7F7F7F7Full);
+}
+
+// canonical read name with is_pe set (every input of fastq_pre_barcodes has it, :570).
+// WIDE: the line is in LDS with slack behind it - scan 8 bytes per step.
+template <bool WIDE>
+__device__ __forceinline__ uint32_t bc_name_len(const BcLine& h, int fmt) {
   const uint32_t L = h.len + h.nl - 1;  // strlen(&hdr[1]); images with NUL bytes are refused earlier
   if (fmt == FQG_NAME_CASAVA18) {
     uint32_t sp = L;
-    for (uint32_t i = 0; i < L; ++i)
-      if (h.p[1 + i] == ' ') {
-        sp = i;
-        break;
+    if (WIDE) {
+      for (uint32_t i = 0; i < L; i += 8) {
+        const uint64_t m = bytes_eq(ld8(h.p + 1 + i), (uint8_t)' ');
+        if (m) {
+          const uint32_t at = i + ((uint32_t)__builtin_ctzll(m) >> 3);
+          if (at < L) sp = at;
+          break;
+        }
       }
+    } else {
+      for (uint32_t i = 0; i < L; ++i)
+        if (h.p[1 + i] == ' ') {
+          sp = i;
+          break;
+        }
+    }
     if (sp >= 2 && h.p[1 + sp - 2] == '/') sp -= 2;
     return sp;
   }
   long l = (long)L;
   if (fmt == FQG_NAME_DEFAULT) l--;
   return l >= 1 ? (uint32_t)(l - 1) : L;
+}
+__device__ __forceinline__ bool bc_same_bytes_wide(const uint8_t* a, const uint8_t* b, uint32_t n) {
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    if (ld8(a + i) != ld8(b + i)) return false;
+  if (i < n) return ((ld8(a + i) ^ ld8(b + i)) & ((1ull << (8 * (n - i))) - 1ull)) == 0;
+  return true;
 }
 
 // slice_read's effect on one line (src/fastq_pre_barcodes.c:168-189): the result is
@@ -91,7 +135,6 @@ struct Cut {
   uint32_t from, n, add_nl;
 };
 __device__ __forceinline__ Cut bc_cut(uint32_t L, long off, long size) {
-  Cut c{0, L, 0};
   if (size == 0) return Cut{0, 0, 1};
   if (off > 0 && size == -1) return Cut{0, 0, 0};  // seq[-1]='\n'; seq[0]='\0'
   uint32_t from = 0, Lt = L;
@@ -112,6 +155,11 @@ __device__ __forceinline__ bool bc_slices(const BcParams& P, int x) {
 }
 
 __device__ __forceinline__ uint32_t dec_digits(unsigned long v) {
+  if (!(v >> 32)) {  // compare chain: no division
+    const uint32_t x = (uint32_t)v;
+    return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) +
+           (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
+  }
   uint32_t d = 1;
   while (v >= 10) {
     v /= 10;
@@ -127,46 +175,60 @@ struct BcTags {
 };
 
 // get_barcode for one tag (src/fastq_pre_barcodes.c:218-259).  0 ok, 1 short, 2 low quality
-__device__ inline int bc_get(const BcLine ln[4], long off, long size, int phred, int min_qual, uint32_t* n,
-                             const uint8_t** s, const uint8_t** q) {
+template <bool WIDE>
+__device__ __forceinline__ int bc_get(const BcLine (&ln)[4], long off, long size, int phred, int min_qual, uint32_t* n,
+                                      const uint8_t** s, const uint8_t** q) {
   *n = 0;
   if (off == -1 || size == 0) return 0;
   const unsigned long rl1 = (unsigned long)(ln[1].len + ln[1].nl) - 1ul;
   if ((unsigned long)off > rl1 || (unsigned long)(off + size) > rl1) return 1;
-  if (min_qual > 0)
-    for (long x = off; x < off + size; ++x) {
-      const int c = (int)(signed char)(x < (long)(ln[3].len + ln[3].nl) ? ln[3].p[x] : 0);
-      if (c - phred < min_qual) return 2;
+  if (min_qual > 0) {
+    const long Lq = (long)(ln[3].len + ln[3].nl);
+    if (WIDE && off + size <= Lq) {  // 8 quality characters per LDS access
+      for (long x = off; x < off + size; x += 8) {
+        const uint64_t v = ld8(ln[3].p + x);
+        const int left = (int)(off + size - x);
+        bool low = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) low |= j < left && (int)(signed char)(v >> (8 * j)) - phred < min_qual;
+        if (low) return 2;
+      }
+    } else {
+      for (long x = off; x < off + size; ++x) {
+        const int c = (int)(signed char)(x < Lq ? ln[3].p[x] : 0);
+        if (c - phred < min_qual) return 2;
+      }
     }
+  }
   *n = (uint32_t)size;
   *s = ln[1].p + off;
   *q = ln[3].p + off;
   return 0;
 }
 
-// status + tags of one iteration; shared by plan and emit so that both see the same thing
-__device__ inline uint8_t bc_decide(const BcParams& P, uint64_t k, BcTags* tags, uint32_t* finding) {
+// status + tags of one iteration from the lines of its records (in an image or in LDS)
+template <bool WIDE>
+__device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLine (&L)[kBcFiles][4], BcTags* tags,
+                                                   uint32_t* finding) {
   *finding = 0;
   tags->n[0] = tags->n[1] = tags->n[2] = 0;
-  BcLine ln[4], l1[4];
   if (P.n_inputs > 1) {
     // names: every file against READ1 (src/fastq_pre_barcodes.c:606-635); '@' first (src/fastq.c:448)
+#pragma unroll
     for (int x = 1; x < kBcFiles; ++x)
-      if (P.f[x].present) {
-        bc_lines(P.f[x], k, ln);
-        if (ln[0].p[0] != '@') {
-          *finding = (FQG_E_WRONG_HEADER << 3) | x;
-          return kBcFinding;
-        }
+      if (P.f[x].present && L[x][0].p[0] != '@') {
+        *finding = (FQG_E_WRONG_HEADER << 3) | x;
+        return kBcFinding;
       }
-    bc_lines(P.f[1], k, l1);
-    const uint32_t n1 = bc_name_len(l1[0], P.f[1].fmt);
+    const uint32_t n1 = bc_name_len<WIDE>(L[1][0], P.f[1].fmt);
+#pragma unroll
     for (int x = 2; x < kBcFiles; ++x)
       if (P.f[x].present) {
-        bc_lines(P.f[x], k, ln);
-        const uint32_t nx = bc_name_len(ln[0], P.f[x].fmt);
+        const uint32_t nx = bc_name_len<WIDE>(L[x][0], P.f[x].fmt);
         bool same = nx == n1;
-        for (uint32_t i = 0; same && i < n1; ++i) same = l1[0].p[1 + i] == ln[0].p[1 + i];
+        if (WIDE) same = same && bc_same_bytes_wide(L[1][0].p + 1, L[x][0].p + 1, n1);
+        else
+          for (uint32_t i = 0; same && i < n1; ++i) same = L[1][0].p[1 + i] == L[x][0].p[1 + i];
         if (!same) {
           *finding = (FQG_E_NAME_MISMATCH << 3) | x;
           return kBcFinding;
@@ -174,23 +236,22 @@ __device__ inline uint8_t bc_decide(const BcParams& P, uint64_t k, BcTags* tags,
       }
   }
   // extract_info for each file in order: umi, sample, cell (src/fastq_pre_barcodes.c:262-285)
+#pragma unroll
   for (int x = 1; x < kBcFiles; ++x)
     if (P.f[x].present) {
-      bc_lines(P.f[x], k, ln);
       int rc = 0;
-      if (P.umi_read == x) rc = bc_get(ln, P.umi_off, P.umi_size, P.phred, P.min_qual, &tags->n[0], &tags->s[0], &tags->q[0]);
+      if (P.umi_read == x) rc = bc_get<WIDE>(L[x], P.umi_off, P.umi_size, P.phred, P.min_qual, &tags->n[0], &tags->s[0], &tags->q[0]);
       if (!rc && P.sample_read == x)
-        rc = bc_get(ln, P.sample_off, P.sample_size, P.phred, P.min_qual, &tags->n[2], &tags->s[2], &tags->q[2]);
+        rc = bc_get<WIDE>(L[x], P.sample_off, P.sample_size, P.phred, P.min_qual, &tags->n[2], &tags->s[2], &tags->q[2]);
       if (!rc && P.cell_read == x)
-        rc = bc_get(ln, P.cell_off, P.cell_size, P.phred, P.min_qual, &tags->n[1], &tags->s[1], &tags->q[1]);
+        rc = bc_get<WIDE>(L[x], P.cell_off, P.cell_size, P.phred, P.min_qual, &tags->n[1], &tags->s[1], &tags->q[1]);
       if (rc) return rc == 1 ? kBcDiscardShort : kBcDiscardQual;
     }
   return kBcKeep;
 }
 
-// tags of an iteration that bc_decide has already found to be kept: geometry only, none of the
-// byte-by-byte checks (the emit kernel runs one wavefront per iteration: a serial scan there costs
-// a memory round trip per byte)
+// tags of an iteration that bc_decide_lines has already found to be kept: geometry only, none of
+// the byte-by-byte checks
 __device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine (&lines)[kBcFiles][4], BcTags* tags) {
   tags->n[0] = tags->n[1] = tags->n[2] = 0;
 #pragma unroll
@@ -209,17 +270,15 @@ __device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine 
     }
 }
 
-// byte counts of the FASTQ record written for file x (src/fastq_pre_barcodes.c:713-718)
-__device__ inline uint32_t bc_fastq_len(const BcParams& P, int x, uint64_t k, const BcTags& t) {
-  BcLine ln[4];
-  bc_lines(P.f[x], k, ln);
+// byte count of the FASTQ record written for a file (src/fastq_pre_barcodes.c:713-718);
+// sliced / off / size: bc_slices(P, x), P.read_off[x], P.read_size[x]
+__device__ __forceinline__ uint32_t bc_fastq_len(bool sliced, long off, long size, const BcLine (&ln)[4], const BcTags& t) {
   const bool tagged = (t.n[0] | t.n[1] | t.n[2]) != 0;
-  const bool sliced = bc_slices(P, x);
   uint32_t n = ln[0].len + ln[0].nl + (tagged ? 31u + t.n[0] + t.n[1] + t.n[2] : 0u);
   n += (tagged || sliced) ? 2u : ln[2].len + ln[2].nl;
   if (sliced) {
-    const Cut cs = bc_cut(ln[1].len + ln[1].nl, P.read_off[x], P.read_size[x]);
-    const Cut cq = bc_cut(ln[3].len + ln[3].nl, P.read_off[x], P.read_size[x]);
+    const Cut cs = bc_cut(ln[1].len + ln[1].nl, off, size);
+    const Cut cq = bc_cut(ln[3].len + ln[3].nl, off, size);
     n += cs.n + cs.add_nl + cq.n + cq.add_nl;
   } else {
     n += ln[1].len + ln[1].nl + ln[3].len + ln[3].nl;
@@ -227,7 +286,7 @@ __device__ inline uint32_t bc_fastq_len(const BcParams& P, int x, uint64_t k, co
   return n;
 }
 
-// what the SAM line prints for mate x: sequence / quality without their last character
+// what the SAM line prints for a mate: sequence / quality without their last character
 // (src/fastq_pre_barcodes.c:666-700)
 struct SamGeom {
   Cut cs, cq;
@@ -235,12 +294,12 @@ struct SamGeom {
   uint32_t shown;          // the number in column 9
   uint32_t name_n;         // characters of the on:Z: value
 };
-__device__ inline SamGeom bc_sam_geom(const BcParams& P, int x, const BcLine ln[4]) {
+__device__ __forceinline__ SamGeom bc_sam_geom(bool sliced, long off, long size, bool mate1, const BcLine (&ln)[4]) {
   SamGeom g;
   const uint32_t Ls = ln[1].len + ln[1].nl, Lq = ln[3].len + ln[3].nl;
-  if (bc_slices(P, x)) {
-    g.cs = bc_cut(Ls, P.read_off[x], P.read_size[x]);
-    g.cq = bc_cut(Lq, P.read_off[x], P.read_size[x]);
+  if (sliced) {
+    g.cs = bc_cut(Ls, off, size);
+    g.cq = bc_cut(Lq, off, size);
   } else {
     g.cs = Cut{0, Ls, 0};
     g.cq = Cut{0, Lq, 0};
@@ -248,79 +307,213 @@ __device__ inline SamGeom bc_sam_geom(const BcParams& P, int x, const BcLine ln[
   const uint32_t ls = g.cs.n + g.cs.add_nl, lq = g.cq.n + g.cq.add_nl;  // strlen after slicing
   g.seq_n = ls ? ls - 1 : 0;
   g.qual_n = lq ? lq - 1 : 0;
-  g.shown = x == 1 ? ls - 1u : ls;  // unsigned arithmetic as in the reference (len-1 for mate 1, len for mate 2)
+  g.shown = mate1 ? ls - 1u : ls;  // unsigned arithmetic as in the reference (len-1 for mate 1, len for mate 2)
   // format_read_name: up to the first '\n' of the header, without the '@'
   g.name_n = ln[0].len ? ln[0].len - 1 : 0;
   return g;
 }
 
-__device__ inline uint32_t bc_sam_len(const BcParams& P, uint64_t k, const BcTags& t) {
-  uint32_t total = 0;
-  const bool se = !P.f[2].present;
-  for (int x = 1; x <= (se ? 1 : 2); ++x) {
-    BcLine ln[4];
-    bc_lines(P.f[x], k, ln);
-    const SamGeom g = bc_sam_geom(P, x, ln);
-    const unsigned flag = se ? 4u : (x == 1 ? 77u : 141u);
-    uint32_t n = dec_digits(P.first_read_number + k + 1) + 1 + dec_digits(flag);
-    n += 15;  // "\t*\t0\t255\t*\t*\t0\t"
-    n += dec_digits(g.shown) + 1 + g.seq_n + 1 + g.qual_n + 6 + g.name_n + 6 + g.qual_n;
-    if (t.n[0]) n += 12 + 2 * t.n[0];
-    if (t.n[1]) n += 12 + 2 * t.n[1];
-    if (t.n[2]) n += 12 + 2 * t.n[2];
-    total += n + 1;
-  }
-  return total;
+// one SAM line: number = the read number printed in column 1
+__device__ __forceinline__ uint32_t bc_sam_line_len(unsigned long number, unsigned flag, const SamGeom& g, const BcTags& t) {
+  uint32_t n = dec_digits(number) + 1 + dec_digits(flag);
+  n += 15;  // "\t*\t0\t255\t*\t*\t0\t"
+  n += dec_digits(g.shown) + 1 + g.seq_n + 1 + g.qual_n + 6 + g.name_n + 6 + g.qual_n;
+  if (t.n[0]) n += 12 + 2 * t.n[0];
+  if (t.n[1]) n += 12 + 2 * t.n[1];
+  if (t.n[2]) n += 12 + 2 * t.n[2];
+  return n + 1;
+}
+__device__ __forceinline__ unsigned bc_sam_flag(bool se, bool mate1) {
+  return se ? 4u : (mate1 ? 77u : 141u);  // BAM_FUNMAP | FMUNMAP | FPAIRED | FREAD1/2
 }
 
-__global__ __launch_bounds__(kBlock) void k_bc_plan(BcParams P, uint64_t n_iter, uint8_t* __restrict__ status,
-                                                    uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
-                                                    uint32_t* __restrict__ len2, BcCall* __restrict__ call) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n_iter) return;
-  BcTags t;
-  uint32_t finding;
-  uint8_t st = bc_decide(P, k, &t, &finding);
-  uint32_t a = 0, b = 0, c = 0;
-  if (st == kBcKeep) {
-    if (P.out_sam) a = bc_sam_len(P, k, t);
-    else {
-      if (P.emit[1]) b = bc_fastq_len(P, 1, k, t);
-      if (P.emit[2]) c = bc_fastq_len(P, 2, k, t);
-    }
-    // do the records and the text fit the LDS buffers of the emit kernel?
-    uint64_t in_bytes = 0;
-    for (int x = 1; x < kBcFiles; ++x)
-      if (P.f[x].present) {
-        BcLine ln[4];
-        bc_lines(P.f[x], k, ln);
-        in_bytes += (uint64_t)((ln[3].p + ln[3].len + ln[3].nl) - ln[0].p);
-      }
-    if (in_bytes > (uint64_t)kEmitSrc || a > (uint32_t)kEmitBuf || b > (uint32_t)kEmitBuf || c > (uint32_t)kEmitBuf) {
-      st = kBcKeepBig;
-      atomicAdd(&call->big, 1ull);
-    }
-  } else if (st == kBcFinding) {
-    atomicMin(&call->first_finding, (unsigned long long)((k << 8) | finding));
+// byte counts of the outputs of a kept iteration
+__device__ __forceinline__ void bc_out_lens(const BcParams& P, uint64_t k, const BcLine (&L)[kBcFiles][4], const BcTags& t,
+                                            uint32_t* a, uint32_t* b, uint32_t* c) {
+  *a = *b = *c = 0;
+  if (P.out_sam) {
+    const bool se = !P.f[2].present;
+    *a = bc_sam_line_len(P.first_read_number + k + 1, bc_sam_flag(se, true),
+                         bc_sam_geom(bc_slices(P, 1), P.read_off[1], P.read_size[1], true, L[1]), t);
+    if (!se)
+      *a += bc_sam_line_len(P.first_read_number + k + 1, bc_sam_flag(se, false),
+                            bc_sam_geom(bc_slices(P, 2), P.read_off[2], P.read_size[2], false, L[2]), t);
   } else {
-    atomicMin(&call->first_discard, (unsigned long long)k);
+    if (P.emit[1]) *b = bc_fastq_len(bc_slices(P, 1), P.read_off[1], P.read_size[1], L[1], t);
+    if (P.emit[2]) *c = bc_fastq_len(bc_slices(P, 2), P.read_off[2], P.read_size[2], L[2], t);
   }
-  status[k] = st;
-  len0[k] = a;
-  len1[k] = b;
-  len2[k] = c;
 }
 
-// discards / warnings among the first n_done iterations (counted after the host has decided
-// where the batch ends)
+// ---- wavefront helpers --------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(v, d, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(v, d, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// ---- tiles: the records of T consecutive iterations of one file, copied into LDS -----------------
+// Lane `lane` is given the lines of iteration k0 + it (it already clamped below the tile's size;
+// last_lane holds the tile's last iteration).  The span is copied in 16-byte units aligned on the
+// image ADDRESS, so a unit always holds at least one byte of the image and never leaves its page.
+// Returns false (uniformly) when the span does not fit what is left of the LDS area.
+__device__ __forceinline__ bool bc_stage_file(const BcFile& f, uint64_t k0, uint32_t it, int last_lane, int lane,
+                                              uint8_t* s_in, uint32_t in_cap, uint32_t& at, BcLine (&ln)[4]) {
+  const uint64_t r = f.first + (k0 + it) * f.step + f.add;
+  const uint64_t* __restrict__ le = f.fv.line_end + 4 * r;
+  const uint64_t prev = r == 0 ? ~0ull : le[-1];
+  const uint64_t e0 = le[0], e1 = le[1], e2 = le[2], e3 = le[3];
+  const uint64_t s0 = rfl64(prev + 1);
+  const uint64_t e3l = rl64(e3, last_lane);
+  const uint64_t s1 = e3l < f.fv.nbytes ? e3l + 1 : e3l;
+  const uint64_t n = s1 - s0;
+  const uint32_t skew = (uint32_t)((uintptr_t)(f.fv.img + s0) & 15u);
+  if (n > (uint64_t)in_cap || (uint64_t)at + skew + n + 32 > (uint64_t)in_cap) return false;
+  const uint8_t* __restrict__ g0 = f.fv.img + s0 - skew;
+  uint8_t* d0 = s_in + at;
+  const uint32_t units = (skew + (uint32_t)n + 15u) >> 4;
+  for (uint32_t u0 = 0; u0 < units; u0 += 4 * kWave) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = u0 + j * kWave + lane;
+      v[j] = *reinterpret_cast<const uint4*>(g0 + 16ull * (u < units ? u : units - 1));  // clamped: no branch, 4 in flight
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = u0 + j * kWave + lane;
+      if (u < units) *reinterpret_cast<uint4*>(d0 + 16u * u) = v[j];
+    }
+  }
+  const uint32_t b = at + skew;
+  ln[0] = BcLine{s_in + b + (uint32_t)(prev + 1 - s0), (uint32_t)(e0 - prev - 1), e0 < f.fv.nbytes ? 1u : 0u};
+  ln[1] = BcLine{s_in + b + (uint32_t)(e0 + 1 - s0), (uint32_t)(e1 - e0 - 1), e1 < f.fv.nbytes ? 1u : 0u};
+  ln[2] = BcLine{s_in + b + (uint32_t)(e1 + 1 - s0), (uint32_t)(e2 - e1 - 1), e2 < f.fv.nbytes ? 1u : 0u};
+  ln[3] = BcLine{s_in + b + (uint32_t)(e2 + 1 - s0), (uint32_t)(e3 - e2 - 1), e3 < f.fv.nbytes ? 1u : 0u};
+  at += (skew + (uint32_t)n + 15u) & ~15u;
+  return true;
+}
+
+__device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLine (&L)[kBcFiles][4]) {
+#pragma unroll
+  for (int x = 1; x < kBcFiles; ++x)
+    if (P.f[x].present) bc_lines(P.f[x], k, L[x]);
+}
+
+// One wavefront per tile, one lane per iteration.
+__global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
+                                                        uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
+                                                        uint32_t* __restrict__ len2, uint8_t* __restrict__ tile_big,
+                                                        BcCall* __restrict__ call) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+  const int lane = (int)threadIdx.x;
+  const uint64_t n_tiles = (n_iter + tc.T - 1) / tc.T;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t k0 = tile * tc.T;
+    const uint32_t Tn = (uint32_t)(n_iter - k0 < (uint64_t)tc.T ? n_iter - k0 : (uint64_t)tc.T);
+    const bool valid = (uint32_t)lane < Tn;
+    const uint32_t it = valid ? (uint32_t)lane : Tn - 1;
+    const uint64_t k = k0 + it;
+    BcLine L[kBcFiles][4];
+    uint32_t at = 0;
+    bool fit = true;
+#pragma unroll
+    for (int x = 1; x < kBcFiles; ++x)
+      if (fit && P.f[x].present) fit = bc_stage_file(P.f[x], k0, it, (int)Tn - 1, lane, s_lds, tc.in_cap, at, L[x]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    BcTags t;
+    uint32_t finding = 0, a = 0, b = 0, c = 0;
+    uint8_t st;
+    if (fit) {
+      st = bc_decide_lines<true>(P, L, &t, &finding);
+      if (st == kBcKeep) bc_out_lens(P, k, L, t, &a, &b, &c);
+    } else {  // long reads: from the images
+      BcLine G[kBcFiles][4];
+      bc_lines_all(P, k, G);
+      st = bc_decide_lines<false>(P, G, &t, &finding);
+      if (st == kBcKeep) bc_out_lens(P, k, G, t, &a, &b, &c);
+    }
+    if (valid) {
+      status[k] = st;
+      if (P.out_sam) len0[k] = a;
+      else {
+        if (P.emit[1]) len1[k] = b;
+        if (P.emit[2]) len2[k] = c;
+      }
+    } else {
+      a = b = c = 0;
+    }
+    const unsigned long long none = ~0ull;
+    const unsigned long long fnd = wave_min64(valid && st == kBcFinding ? (unsigned long long)((k << 8) | finding) : none);
+    const unsigned long long dsc =
+        wave_min64(valid && (st == kBcDiscardShort || st == kBcDiscardQual) ? (unsigned long long)k : none);
+    const uint32_t sa = wave_sum32(a), sb = wave_sum32(b), sc = wave_sum32(c);
+    if (lane == 0) {
+      const bool big = !fit || sa + 32 > tc.out_cap || sb + 32 > tc.out_cap || sc + 32 > tc.out_cap;
+      tile_big[tile] = big ? 1 : 0;
+      if (big) atomicAdd(&call->big, 1ull);
+      // tiles run roughly in order: look before the atomic, almost every later tile has nothing to add
+      if (fnd != none && fnd < __atomic_load_n(&call->first_finding, __ATOMIC_RELAXED)) atomicMin(&call->first_finding, fnd);
+      if (dsc != none && dsc < __atomic_load_n(&call->first_discard, __ATOMIC_RELAXED)) atomicMin(&call->first_discard, dsc);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// discarded iterations among the first n_done: one atomic per workgroup
 __global__ __launch_bounds__(kBlock) void k_bc_count(const uint8_t* __restrict__ status, uint64_t n_done,
                                                      BcCall* __restrict__ call) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint8_t st = k < n_done ? status[k] : kBcKeep;
-  const uint64_t d = __ballot(st == kBcDiscardShort || st == kBcDiscardQual), s = __ballot(st == kBcDiscardShort);
-  if ((threadIdx.x & 63) == 0 && d) {
-    atomicAdd(&call->discarded, (unsigned long long)__popcll(d));
-    if (s) atomicAdd(&call->short_warnings, (unsigned long long)__popcll(s));
+  __shared__ unsigned long long s_d[kBlock / kWave], s_s[kBlock / kWave];
+  unsigned long long d = 0, sh = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_done; k += (uint64_t)gridDim.x * kBlock) {
+    const uint8_t st = status[k];
+    d += (st == kBcDiscardShort || st == kBcDiscardQual) ? 1u : 0u;
+    sh += st == kBcDiscardShort ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    d += __shfl_xor(d, o, 64);
+    sh += __shfl_xor(sh, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_d[threadIdx.x >> 6] = d;
+    s_s[threadIdx.x >> 6] = sh;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long td = 0, ts = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      td += s_d[w];
+      ts += s_s[w];
+    }
+    if (td) atomicAdd(&call->discarded, td);
+    if (ts) atomicAdd(&call->short_warnings, ts);
   }
 }
 
@@ -395,6 +588,7 @@ constexpr uint64_t lit_pack(const char* s, int n, int from) {
 }
 #define BC_LIT(w, str) (w).lit_imm(lit_pack(str, (int)sizeof(str) - 1, 0), lit_pack(str, (int)sizeof(str) - 1, 8), (uint32_t)sizeof(str) - 1)
 
+// the whole wavefront writes one text: lane i copies byte i of every piece (k_bc_emit_direct)
 struct Writer {
   uint8_t* p;
   int lane;
@@ -406,7 +600,6 @@ struct Writer {
     for (uint32_t i = lane; i < n; i += kWave) p[i] = s[i];
     p += n;
   }
-  __device__ __forceinline__ void lit(const char* s, uint32_t n) { bytes(reinterpret_cast<const uint8_t*>(s), n); }
   __device__ __forceinline__ void ch(char c) {
     if (lane == 0) p[0] = (uint8_t)c;
     p += 1;
@@ -426,15 +619,130 @@ struct Writer {
     for (uint32_t i = lane; i < n; i += kWave) p[i] = s[i] == ' ' ? (uint8_t)'@' : s[i];
     p += n;
   }
-  __device__ __forceinline__ void cut(const uint8_t* s, const Cut& c) {
-    bytes(s + c.from, c.n);
-    if (c.add_nl) ch('\n');
+};
+
+// one lane writes one text (k_bc_emit_tile: sources and destination are LDS, at any alignment).
+// Copies move 8 bytes per LDS access; the last access of a piece overlaps the one before it, or
+// is split 4/2/1 for pieces shorter than 8.
+struct LaneWriter {
+  uint8_t* p;
+  template <int N>
+  __device__ __forceinline__ void put(uint64_t v) {  // the low N bytes of v
+    if (N == 8) __builtin_memcpy(p, &v, 8);
+    else {
+      uint32_t done = 0;
+      if (N & 4) {
+        const uint32_t w = (uint32_t)v;
+        __builtin_memcpy(p, &w, 4);
+        done = 4;
+      }
+      if (N & 2) {
+        const uint16_t w = (uint16_t)(v >> (8 * done));
+        __builtin_memcpy(p + done, &w, 2);
+        done += 2;
+      }
+      if (N & 1) p[done] = (uint8_t)(v >> (8 * done));
+    }
+  }
+  __device__ __forceinline__ void lit_imm(uint64_t lo, uint64_t hi, uint32_t n) {
+    // n is a literal's length: the branches fold
+    if (n >= 8) {
+      put<8>(lo);
+      p += 8;
+      lo = hi;
+      n -= 8;
+    }
+    switch (n) {
+      case 8: put<8>(lo); break;
+      case 7: put<7>(lo); break;
+      case 6: put<6>(lo); break;
+      case 5: put<5>(lo); break;
+      case 4: put<4>(lo); break;
+      case 3: put<3>(lo); break;
+      case 2: put<2>(lo); break;
+      case 1: put<1>(lo); break;
+      default: break;
+    }
+    p += n;
+  }
+  static __device__ __forceinline__ uint64_t at_for_blank(uint64_t x) {
+    const uint64_t z = bytes_eq(x, (uint8_t)' ');  // ' ' 0x20 -> '@' 0x40
+    return x ^ ((z >> 1) | (z >> 2));
+  }
+  template <bool NAME>
+  __device__ __forceinline__ void copy(const uint8_t* s, uint32_t n) {
+    if (n >= 8) {
+      uint32_t i = 0;
+      for (; i + 16 <= n; i += 16) {
+        uint64_t a = ld8(s + i), b = ld8(s + i + 8);
+        if (NAME) a = at_for_blank(a), b = at_for_blank(b);
+        __builtin_memcpy(p + i, &a, 8);
+        __builtin_memcpy(p + i + 8, &b, 8);
+      }
+      if (i + 8 <= n) {
+        uint64_t a = ld8(s + i);
+        if (NAME) a = at_for_blank(a);
+        __builtin_memcpy(p + i, &a, 8);
+        i += 8;
+      }
+      if (i < n) {  // the last 8 bytes again: they overlap what is already there with the same values
+        uint64_t a = ld8(s + n - 8);
+        if (NAME) a = at_for_blank(a);
+        __builtin_memcpy(p + n - 8, &a, 8);
+      }
+    } else if (n) {
+      uint64_t a = ld8(s);  // the sources have 8 bytes of slack
+      if (NAME) a = at_for_blank(a);
+      uint32_t done = 0;
+      if (n & 4) {
+        const uint32_t w = (uint32_t)a;
+        __builtin_memcpy(p, &w, 4);
+        done = 4;
+      }
+      if (n & 2) {
+        const uint16_t w = (uint16_t)(a >> (8 * done));
+        __builtin_memcpy(p + done, &w, 2);
+        done += 2;
+      }
+      if (n & 1) p[done] = (uint8_t)(a >> (8 * done));
+    }
+    p += n;
+  }
+  __device__ __forceinline__ void bytes(const uint8_t* s, uint32_t n) { copy<false>(s, n); }
+  __device__ __forceinline__ void name(const uint8_t* s, uint32_t n) { copy<true>(s, n); }
+  __device__ __forceinline__ void ch(char c) {
+    p[0] = (uint8_t)c;
+    p += 1;
+  }
+  __device__ __forceinline__ void dec(unsigned long v) {
+    const uint32_t d = dec_digits(v);
+    if (!(v >> 32)) {
+      uint32_t x = (uint32_t)v;
+      for (uint32_t i = 0; i < d; ++i) {
+        const uint32_t q = x / 10u;
+        p[d - 1 - i] = (uint8_t)('0' + (x - q * 10u));
+        x = q;
+      }
+    } else {
+      for (uint32_t i = 0; i < d; ++i) {
+        p[d - 1 - i] = (uint8_t)('0' + v % 10);
+        v /= 10;
+      }
+    }
+    p += d;
   }
 };
 
-__device__ __forceinline__ void bc_emit_fastq(const BcParams& P, int x, const BcLine (&ln)[4], const BcTags& t, Writer& w) {
+template <class W>
+__device__ __forceinline__ void bc_put_cut(W& w, const uint8_t* s, const Cut& c) {
+  w.bytes(s + c.from, c.n);
+  if (c.add_nl) w.ch('\n');
+}
+
+// the FASTQ record of one file (src/fastq_pre_barcodes.c:713-718)
+template <class W>
+__device__ __forceinline__ void bc_emit_fastq(bool sliced, long off, long size, const BcLine (&ln)[4], const BcTags& t, W& w) {
   const bool tagged = (t.n[0] | t.n[1] | t.n[2]) != 0;
-  const bool sliced = bc_slices(P, x);
   if (tagged) {  // add_tags2readname, src/fastq_pre_barcodes.c:192-216
     w.ch((char)ln[0].p[0]);
     BC_LIT(w, "STAGS_CELL=");
@@ -448,7 +756,7 @@ __device__ __forceinline__ void bc_emit_fastq(const BcParams& P, int x, const Bc
   } else {
     w.bytes(ln[0].p, ln[0].len + ln[0].nl);
   }
-  if (sliced) w.cut(ln[1].p, bc_cut(ln[1].len + ln[1].nl, P.read_off[x], P.read_size[x]));
+  if (sliced) bc_put_cut(w, ln[1].p, bc_cut(ln[1].len + ln[1].nl, off, size));
   else w.bytes(ln[1].p, ln[1].len + ln[1].nl);
   if (tagged || sliced) {
     w.ch((char)ln[2].p[0]);
@@ -456,65 +764,48 @@ __device__ __forceinline__ void bc_emit_fastq(const BcParams& P, int x, const Bc
   } else {
     w.bytes(ln[2].p, ln[2].len + ln[2].nl);
   }
-  if (sliced) w.cut(ln[3].p, bc_cut(ln[3].len + ln[3].nl, P.read_off[x], P.read_size[x]));
+  if (sliced) bc_put_cut(w, ln[3].p, bc_cut(ln[3].len + ln[3].nl, off, size));
   else w.bytes(ln[3].p, ln[3].len + ln[3].nl);
 }
 
-__device__ __forceinline__ void bc_emit_sam(const BcParams& P, uint64_t k, const BcLine (&lines)[kBcFiles][4], const BcTags& t,
-                                   Writer& w) {
-  const bool se = !P.f[2].present;
-#pragma unroll
-  for (int x = 1; x <= 2; ++x) {
-    if (x == 2 && se) break;
-    const BcLine(&ln)[4] = lines[x];
-    const SamGeom g = bc_sam_geom(P, x, ln);
-    const unsigned flag = se ? 4u : (x == 1 ? 77u : 141u);  // BAM_FUNMAP | FMUNMAP | FPAIRED | FREAD1/2
-    w.dec(P.first_read_number + k + 1);
-    w.ch('\t');
-    w.dec(flag);
-    BC_LIT(w, "\t*\t0\t255\t*\t*\t0\t");
-    w.dec(g.shown);
-    w.ch('\t');
-    w.bytes(ln[1].p + g.cs.from, g.seq_n);
-    w.ch('\t');
-    w.bytes(ln[3].p + g.cq.from, g.qual_n);
-    BC_LIT(w, "\ton:Z:");
-    w.name(ln[0].p + 1, g.name_n);
-    BC_LIT(w, "\top:Z:");
-    w.bytes(ln[3].p + g.cq.from, g.qual_n);
-    if (t.n[0]) {
-      if (P.tenx) BC_LIT(w, "\tUB:Z:"); else BC_LIT(w, "\tRX:Z:");
-      w.bytes(t.s[0], t.n[0]);
-      if (P.tenx) BC_LIT(w, "\tUY:Z:"); else BC_LIT(w, "\tQX:Z:");
-      w.bytes(t.q[0], t.n[0]);
-    }
-    if (t.n[1]) {
-      if (x == 1) BC_LIT(w, "\tCR:Z:"); else BC_LIT(w, " CR:Z:");  // the second mate gets a blank (src/fastq_pre_barcodes.c:705)
-      w.bytes(t.s[1], t.n[1]);
-      BC_LIT(w, "\tCY:Z:");
-      w.bytes(t.q[1], t.n[1]);
-    }
-    if (t.n[2]) {
-      BC_LIT(w, "\tBC:Z:");
-      w.bytes(t.s[2], t.n[2]);
-      BC_LIT(w, "\tQT:Z:");
-      w.bytes(t.q[2], t.n[2]);
-    }
-    w.ch('\n');
+// one SAM line (src/fastq_pre_barcodes.c:666-711)
+template <class W>
+__device__ __forceinline__ void bc_emit_sam_line(const BcParams& P, unsigned long number, bool se, bool mate1,
+                                                 const BcLine (&ln)[4], const SamGeom& g, const BcTags& t, W& w) {
+  w.dec(number);
+  w.ch('\t');
+  w.dec(bc_sam_flag(se, mate1));
+  BC_LIT(w, "\t*\t0\t255\t*\t*\t0\t");
+  w.dec(g.shown);
+  w.ch('\t');
+  w.bytes(ln[1].p + g.cs.from, g.seq_n);
+  w.ch('\t');
+  w.bytes(ln[3].p + g.cq.from, g.qual_n);
+  BC_LIT(w, "\ton:Z:");
+  w.name(ln[0].p + 1, g.name_n);
+  BC_LIT(w, "\top:Z:");
+  w.bytes(ln[3].p + g.cq.from, g.qual_n);
+  if (t.n[0]) {
+    if (P.tenx) BC_LIT(w, "\tUB:Z:"); else BC_LIT(w, "\tRX:Z:");
+    w.bytes(t.s[0], t.n[0]);
+    if (P.tenx) BC_LIT(w, "\tUY:Z:"); else BC_LIT(w, "\tQX:Z:");
+    w.bytes(t.q[0], t.n[0]);
   }
+  if (t.n[1]) {
+    w.ch(mate1 ? '\t' : ' ');  // the second mate gets a blank (src/fastq_pre_barcodes.c:705)
+    BC_LIT(w, "CR:Z:");
+    w.bytes(t.s[1], t.n[1]);
+    BC_LIT(w, "\tCY:Z:");
+    w.bytes(t.q[1], t.n[1]);
+  }
+  if (t.n[2]) {
+    BC_LIT(w, "\tBC:Z:");
+    w.bytes(t.s[2], t.n[2]);
+    BC_LIT(w, "\tQT:Z:");
+    w.bytes(t.q[2], t.n[2]);
+  }
+  w.ch('\n');
 }
-
-// k_bc_emit<SAM>: one wavefront per kept iteration whose records and text fit the LDS buffers (all
-// but long reads; the others are kBcKeepBig and go through k_bc_emit_direct).
-//   1. The records of the iteration (the four lines are contiguous in the image) are copied into an
-//      LDS staging area with all loads in flight at once - the ~25 pieces of a SAM line would otherwise
-//      cost one memory round trip each.
-//   2. The output text is assembled piece by piece in a second LDS buffer (LDS -> LDS byte copies,
-//      literals as immediates).
-//   3. The text goes to its place in the output image with 16-byte stores: the buffer starts at the
-//      same residue mod 16 as the global address, so aligned 16-byte units of LDS and of the output
-//      coincide.
-constexpr int kEmitChunks = 10;  // kEmitSrc / 64 / 4: byte loads in flight per lane and round
 
 __device__ __forceinline__ void emit_flush(const uint8_t* __restrict__ buf, uint32_t skew, uint32_t len,
                                            uint8_t* __restrict__ dst, int lane) {
@@ -536,89 +827,128 @@ struct EmitOut {
   uint8_t* out;
 };
 
+// One wavefront per tile.  SAM: one lane per line (two per iteration for paired reads); FASTQ: one
+// lane per record, one output after the other.
 template <bool SAM>
-__global__ __launch_bounds__(kBlock) void k_bc_emit(BcParams P, uint64_t n_done, const uint8_t* __restrict__ status,
-                                                    EmitOut o0, EmitOut o1, EmitOut o2) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_buf[kBlock / kWave][kEmitBuf + 16];
-  __shared__ uint8_t s_src[kBlock / kWave][kEmitSrc];
-  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
-  // the wave index is uniform: say so, and everything derived from k (line index loads, pointers,
-  // lengths) lives in scalar registers instead of 64 copies
-  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* buf = s_buf[wv];
-  uint8_t* src = s_src[wv];
-  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_done; k += n_waves) {
-    if (status[k] != kBcKeep) continue;
-    BcLine lines[kBcFiles][4];
+__global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, uint64_t n_done,
+                                                        const uint8_t* __restrict__ status,
+                                                        const uint8_t* __restrict__ tile_big, EmitOut o0, EmitOut o1,
+                                                        EmitOut o2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+  uint8_t* s_in = s_lds;
+  uint8_t* s_out = s_lds + tc.in_cap;
+  const int lane = (int)threadIdx.x;
+  const bool se = !P.f[2].present;
+  const uint32_t lpi = SAM && !se ? 2u : 1u;  // lanes per iteration
+  const uint64_t n_tiles = (n_done + tc.T - 1) / tc.T;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (tile_big[tile]) continue;
+    const uint64_t k0 = tile * tc.T;
+    const uint32_t Tn = (uint32_t)(n_done - k0 < (uint64_t)tc.T ? n_done - k0 : (uint64_t)tc.T);
+    const uint32_t it_raw = lpi == 2 ? (uint32_t)lane >> 1 : (uint32_t)lane;
+    const bool mate1 = lpi == 2 ? !(lane & 1) : true;
+    const bool valid = it_raw < Tn;
+    const uint32_t it = valid ? it_raw : Tn - 1;
+    const uint64_t k = k0 + it;
+    const int last_lane = (int)((Tn - 1) * lpi);
+    BcLine L[kBcFiles][4];
     uint32_t at = 0;
 #pragma unroll
     for (int x = 1; x < kBcFiles; ++x) {
       if (!P.f[x].present) continue;
       if (SAM && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) continue;  // not printed, no tag
-      bc_lines(P.f[x], k, lines[x]);
-      const uint8_t* g = lines[x][0].p;
-      const uint32_t n = (uint32_t)((lines[x][3].p + lines[x][3].len + lines[x][3].nl) - g);
-      // stage: every lane issues its byte loads before the first one is consumed
-      for (uint32_t base = 0; base < n; base += kEmitChunks * kWave) {
-        uint8_t v[kEmitChunks];
-#pragma unroll
-        for (int c = 0; c < kEmitChunks; ++c) {
-          const uint32_t i = base + c * kWave + lane;
-          v[c] = i < n ? g[i] : (uint8_t)0;
-        }
-#pragma unroll
-        for (int c = 0; c < kEmitChunks; ++c) {
-          const uint32_t i = base + c * kWave + lane;
-          if (i < n) src[at + i] = v[c];
-        }
-      }
-#pragma unroll
-      for (int l = 0; l < 4; ++l) lines[x][l].p = src + at + (uint32_t)(lines[x][l].p - g);  // now in LDS
-      at += n;
+      (void)bc_stage_file(P.f[x], k0, it, last_lane, lane, s_in, tc.in_cap, at, L[x]);  // fits: the plan checked
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const bool keep = valid && status[k] == kBcKeep;
     BcTags t;
-    bc_tags_of_kept(P, lines, &t);
+    bc_tags_of_kept(P, L, &t);
+    if (SAM) {
+      BcLine own[4];
 #pragma unroll
-    for (int which = SAM ? 0 : 1; which < (SAM ? 1 : 3); ++which) {
-      if (!SAM && !P.emit[which]) continue;
-      const EmitOut& o = which == 0 ? o0 : (which == 1 ? o1 : o2);
-      uint8_t* dst = o.out + o.off[k] + o.sum[k / kScan64Span];
-      const uint32_t len = o.len[k];
+      for (int l = 0; l < 4; ++l) {
+        own[l].p = mate1 ? L[1][l].p : L[2][l].p;
+        own[l].len = mate1 ? L[1][l].len : L[2][l].len;
+        own[l].nl = mate1 ? L[1][l].nl : L[2][l].nl;
+      }
+      const bool sliced = mate1 ? bc_slices(P, 1) : bc_slices(P, 2);
+      const SamGeom g = bc_sam_geom(sliced, mate1 ? P.read_off[1] : P.read_off[2], mate1 ? P.read_size[1] : P.read_size[2],
+                                    mate1, own);
+      const unsigned long number = P.first_read_number + k + 1;
+      const uint32_t my_len = keep ? bc_sam_line_len(number, bc_sam_flag(se, mate1), g, t) : 0u;
+      const unsigned long long where = o0.off[k] + o0.sum[k / kScan64Span];
+      const unsigned long long tile_at = rfl64(where);
+      const uint32_t before = __shfl_up(my_len, 1, 64);
+      const uint32_t start = (uint32_t)(where - tile_at) + (mate1 ? 0u : before);
+      const uint32_t total = wave_max32(start + my_len);
+      uint8_t* dst = o0.out + tile_at;
       const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
-      Writer w{buf + skew, lane};
-      if (SAM) bc_emit_sam(P, k, lines, t, w);
-      else bc_emit_fastq(P, which, lines[which], t, w);
+      if (keep) {
+        LaneWriter w{s_out + skew + start};
+        bc_emit_sam_line(P, number, se, mate1, own, g, t, w);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      emit_flush(buf, skew, len, dst, lane);
+      emit_flush(s_out, skew, total, dst, lane);
       __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int which = 1; which <= 2; ++which) {
+        if (!P.emit[which]) continue;
+        const EmitOut& o = which == 1 ? o1 : o2;
+        const bool sliced = bc_slices(P, which);
+        const uint32_t my_len = keep ? bc_fastq_len(sliced, P.read_off[which], P.read_size[which], L[which], t) : 0u;
+        const unsigned long long where = o.off[k] + o.sum[k / kScan64Span];
+        const unsigned long long tile_at = rfl64(where);
+        const uint32_t start = (uint32_t)(where - tile_at);
+        const uint32_t total = wave_max32(start + my_len);
+        uint8_t* dst = o.out + tile_at;
+        const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
+        if (keep) {
+          LaneWriter w{s_out + skew + start};
+          bc_emit_fastq(sliced, P.read_off[which], P.read_size[which], L[which], t, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        emit_flush(s_out, skew, total, dst, lane);
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 }
 
-// kBcKeepBig iterations (long reads): the text is written straight to the output image
-__global__ __launch_bounds__(kBlock) void k_bc_emit_direct(BcParams P, uint64_t n_done,
-                                                           const uint8_t* __restrict__ status, EmitOut o0, EmitOut o1,
+// iterations of the tiles that do not fit LDS (long reads): one wavefront per iteration, records read
+// from the images, text written straight to the output image
+__global__ __launch_bounds__(kBlock) void k_bc_emit_direct(BcParams P, BcTile tc, uint64_t n_done,
+                                                           const uint8_t* __restrict__ status,
+                                                           const uint8_t* __restrict__ tile_big, EmitOut o0, EmitOut o1,
                                                            EmitOut o2) {
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool se = !P.f[2].present;
   for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_done; k += n_waves) {
-    if (status[k] != kBcKeepBig) continue;
-    BcLine lines[kBcFiles][4];
-#pragma unroll
-    for (int x = 1; x < kBcFiles; ++x)
-      if (P.f[x].present) bc_lines(P.f[x], k, lines[x]);
+    if (!tile_big[k / tc.T] || status[k] != kBcKeep) continue;
+    BcLine L[kBcFiles][4];
+    bc_lines_all(P, k, L);
     BcTags t;
-    bc_tags_of_kept(P, lines, &t);
-    for (int which = 0; which < 3; ++which) {
-      if (which == 0 ? !P.out_sam : (P.out_sam || !P.emit[which])) continue;
-      const EmitOut& o = which == 0 ? o0 : (which == 1 ? o1 : o2);
-      Writer w{o.out + o.off[k] + o.sum[k / kScan64Span], lane};
-      if (which == 0) bc_emit_sam(P, k, lines, t, w);
-      else if (which == 1) bc_emit_fastq(P, 1, lines[1], t, w);
-      else bc_emit_fastq(P, 2, lines[2], t, w);
+    bc_tags_of_kept(P, L, &t);
+    if (P.out_sam) {
+      Writer w{o0.out + o0.off[k] + o0.sum[k / kScan64Span], lane};
+      bc_emit_sam_line(P, P.first_read_number + k + 1, se, true, L[1],
+                       bc_sam_geom(bc_slices(P, 1), P.read_off[1], P.read_size[1], true, L[1]), t, w);
+      if (!se)
+        bc_emit_sam_line(P, P.first_read_number + k + 1, se, false, L[2],
+                         bc_sam_geom(bc_slices(P, 2), P.read_off[2], P.read_size[2], false, L[2]), t, w);
+    } else {
+      if (P.emit[1]) {
+        Writer w{o1.out + o1.off[k] + o1.sum[k / kScan64Span], lane};
+        bc_emit_fastq(bc_slices(P, 1), P.read_off[1], P.read_size[1], L[1], t, w);
+      }
+      if (P.emit[2]) {
+        Writer w{o2.out + o2.off[k] + o2.sum[k / kScan64Span], lane};
+        bc_emit_fastq(bc_slices(P, 2), P.read_off[2], P.read_size[2], L[2], t, w);
+      }
     }
   }
 }
