@@ -1127,7 +1127,7 @@ static BcTile bc_tile_for(const BcParams& P) {
   static const unsigned budget = [] {
     const char* e = getenv("FQGPU_BC_LDS");
     const long v = e ? atol(e) : 0;
-    return (unsigned)(v >= 4096 && v <= 65536 ? v : 32768);
+    return (unsigned)(v >= 4096 && v <= 65536 ? v : 20480);
   }();
   double in = 0, out_sam = 0, out_fq = 0;
   int files = 0;
@@ -1227,16 +1227,35 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   *c->h_bcall = z;
   HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
   const BcTile tc = bc_tile_for(P);
+  int file_mask = 0;  // the usual sets of inputs have kernels of their own (bc_has)
+  for (int x = 1; x < kBcFiles; ++x)
+    if (P.f[x].present) file_mask |= 1 << x;
   const uint64_t n_tiles = (n_iter + tc.T - 1) / tc.T;
   if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
-  const unsigned tile_waves = std::max(1u, (160u * 1024u) / (tc.in_cap + tc.out_cap));  // per CU, emit (LDS-bound)
+  // persistent grids: exactly the wavefronts that are resident at once (tiles are dealt round-robin,
+  // so a wavefront that starts late would do its whole share after the others have finished)
+  auto resident = [&](const void* kernel, unsigned lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    return (unsigned)per_cu * (unsigned)c->cu_count;
+  };
   {
     ProfScope ps(c, "k_bc_plan");
-    const unsigned per_cu = std::min(16u, std::max(1u, (160u * 1024u) / tc.in_cap));
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->cu_count * per_cu);
-    hipLaunchKernelGGL(k_bc_plan_tile, dim3(grid), dim3(kWave), tc.in_cap, c->stream, P, tc, n_iter,
-                       (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[0].p, (uint32_t*)c->bc_len[1].p,
-                       (uint32_t*)c->bc_len[2].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
+#define FQG_PLAN_TILE(MASK)                                                                                       \
+  do {                                                                                                            \
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_bc_plan_tile<MASK>, tc.in_cap)); \
+    hipLaunchKernelGGL(k_bc_plan_tile<MASK>, dim3(grid), dim3(kWave), tc.in_cap, c->stream, P, tc, n_iter,         \
+                       (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[0].p, (uint32_t*)c->bc_len[1].p,            \
+                       (uint32_t*)c->bc_len[2].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);                         \
+  } while (0)
+    switch (file_mask) {
+      case 0x02: FQG_PLAN_TILE(0x02); break;
+      case 0x06: FQG_PLAN_TILE(0x06); break;
+      case 0x0A: FQG_PLAN_TILE(0x0A); break;
+      case 0x0E: FQG_PLAN_TILE(0x0E); break;
+      default: FQG_PLAN_TILE(0); break;
+    }
+#undef FQG_PLAN_TILE
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1289,14 +1308,29 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
       eo[i] = EmitOut{(const uint32_t*)c->bc_len[i].p, (const unsigned long long*)c->bc_off[i].p,
                       (const unsigned long long*)c->bc_sum[i].p, (uint8_t*)c->bc_out[i].p};
     const uint64_t n_tiles_done = (n_done + tc.T - 1) / tc.T;
-    const unsigned grid_t = (unsigned)std::min<uint64_t>(n_tiles_done, (uint64_t)c->cu_count * tile_waves);
     const unsigned lds = tc.in_cap + tc.out_cap;
-    if (P.out_sam)
-      hipLaunchKernelGGL(k_bc_emit_tile<true>, dim3(grid_t), dim3(kWave), lds, c->stream, P, tc, n_done,
-                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);
-    else
-      hipLaunchKernelGGL(k_bc_emit_tile<false>, dim3(grid_t), dim3(kWave), lds, c->stream, P, tc, n_done,
-                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);
+    unsigned grid_t = 1;
+#define FQG_EMIT_TILE(SAM, MASK)                                                                                  \
+  do {                                                                                                            \
+    grid_t = (unsigned)std::min<uint64_t>(n_tiles_done, resident((const void*)k_bc_emit_tile<SAM, MASK>, lds));    \
+    hipLaunchKernelGGL((k_bc_emit_tile<SAM, MASK>), dim3(grid_t), dim3(kWave), lds, c->stream, P, tc, n_done,      \
+                       (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);     \
+  } while (0)
+#define FQG_EMIT_TILE_MASKS(SAM)                  \
+  switch (file_mask) {                            \
+    case 0x02: FQG_EMIT_TILE(SAM, 0x02); break;   \
+    case 0x06: FQG_EMIT_TILE(SAM, 0x06); break;   \
+    case 0x0A: FQG_EMIT_TILE(SAM, 0x0A); break;   \
+    case 0x0E: FQG_EMIT_TILE(SAM, 0x0E); break;   \
+    default: FQG_EMIT_TILE(SAM, 0); break;        \
+  }
+    if (P.out_sam) FQG_EMIT_TILE_MASKS(true)
+    else FQG_EMIT_TILE_MASKS(false)
+#undef FQG_EMIT_TILE_MASKS
+#undef FQG_EMIT_TILE
+    if (getenv("FQGPU_BC_DEBUG"))
+      fprintf(stderr, "fqgpu barcodes: T=%u in_cap=%u out_cap=%u emit grid=%u (%u/CU) big tiles=%llu\n", tc.T, tc.in_cap,
+              tc.out_cap, grid_t, grid_t / (unsigned)c->cu_count, (unsigned long long)n_big);
     if (n_big) {
       const unsigned grid_e =
           (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));

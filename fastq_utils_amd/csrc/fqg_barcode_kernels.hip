@@ -65,6 +65,13 @@ struct BcLine {
   uint32_t nl;
 };
 
+// Which input files exist.  MASK = 0: ask the parameters at run time; otherwise bit x of MASK says
+// it at compile time, and the code and registers of absent files disappear from the kernel.
+template <int MASK>
+__device__ __forceinline__ bool bc_has(const BcParams& P, int x) {
+  return MASK ? ((MASK >> x) & 1) != 0 : P.f[x].present != 0;
+}
+
 __device__ __forceinline__ void bc_lines(const BcFile& f, uint64_t k, BcLine ln[4]) {
   const uint64_t r = f.first + k * f.step + f.add;
   uint64_t prev = r == 0 ? ~0ull : f.fv.line_end[4 * r - 1];
@@ -207,7 +214,7 @@ __device__ __forceinline__ int bc_get(const BcLine (&ln)[4], long off, long size
 }
 
 // status + tags of one iteration from the lines of its records (in an image or in LDS)
-template <bool WIDE>
+template <bool WIDE, int MASK = 0>
 __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLine (&L)[kBcFiles][4], BcTags* tags,
                                                    uint32_t* finding) {
   *finding = 0;
@@ -216,14 +223,14 @@ __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLi
     // names: every file against READ1 (src/fastq_pre_barcodes.c:606-635); '@' first (src/fastq.c:448)
 #pragma unroll
     for (int x = 1; x < kBcFiles; ++x)
-      if (P.f[x].present && L[x][0].p[0] != '@') {
+      if (bc_has<MASK>(P, x) && L[x][0].p[0] != '@') {
         *finding = (FQG_E_WRONG_HEADER << 3) | x;
         return kBcFinding;
       }
     const uint32_t n1 = bc_name_len<WIDE>(L[1][0], P.f[1].fmt);
 #pragma unroll
     for (int x = 2; x < kBcFiles; ++x)
-      if (P.f[x].present) {
+      if (bc_has<MASK>(P, x)) {
         const uint32_t nx = bc_name_len<WIDE>(L[x][0], P.f[x].fmt);
         bool same = nx == n1;
         if (WIDE) same = same && bc_same_bytes_wide(L[1][0].p + 1, L[x][0].p + 1, n1);
@@ -238,7 +245,7 @@ __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLi
   // extract_info for each file in order: umi, sample, cell (src/fastq_pre_barcodes.c:262-285)
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x)
-    if (P.f[x].present) {
+    if (bc_has<MASK>(P, x)) {
       int rc = 0;
       if (P.umi_read == x) rc = bc_get<WIDE>(L[x], P.umi_off, P.umi_size, P.phred, P.min_qual, &tags->n[0], &tags->s[0], &tags->q[0]);
       if (!rc && P.sample_read == x)
@@ -252,11 +259,12 @@ __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLi
 
 // tags of an iteration that bc_decide_lines has already found to be kept: geometry only, none of
 // the byte-by-byte checks
+template <int MASK = 0>
 __device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine (&lines)[kBcFiles][4], BcTags* tags) {
   tags->n[0] = tags->n[1] = tags->n[2] = 0;
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x)
-    if (P.f[x].present && (P.umi_read == x || P.sample_read == x || P.cell_read == x)) {
+    if (bc_has<MASK>(P, x) && (P.umi_read == x || P.sample_read == x || P.cell_read == x)) {
       const BcLine(&ln)[4] = lines[x];
       auto take = [&](int slot, long off, long size) {
         if (off == -1 || size == 0) return;
@@ -377,55 +385,105 @@ __device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) {
   return v;
 }
 
-// ---- tiles: the records of T consecutive iterations of one file, copied into LDS -----------------
-// Lane `lane` is given the lines of iteration k0 + it (it already clamped below the tile's size;
-// last_lane holds the tile's last iteration).  The span is copied in 16-byte units aligned on the
-// image ADDRESS, so a unit always holds at least one byte of the image and never leaves its page.
-// Returns false (uniformly) when the span does not fit what is left of the LDS area.
-__device__ __forceinline__ bool bc_stage_file(const BcFile& f, uint64_t k0, uint32_t it, int last_lane, int lane,
-                                              uint8_t* s_in, uint32_t in_cap, uint32_t& at, BcLine (&ln)[4]) {
-  const uint64_t r = f.first + (k0 + it) * f.step + f.add;
+// ---- tiles: the records of T consecutive iterations of every file, copied into LDS ----------------
+// Two dependent round trips to memory per tile: the line index of the tile's records (what a lane
+// needs to know its iteration's lines, and lane 0 / the last lane to know the tile's byte span),
+// then the spans themselves.  The first is issued one tile AHEAD (TileGeo of the next tile is loaded
+// while the current one is copied and processed); the second is one loop over the 16-byte units of
+// all files together, 8 loads in flight per lane.  Units are aligned on the image ADDRESS, so a unit
+// always holds at least one byte of the image and never leaves its page.
+struct BcGeo {
+  uint64_t prev, e[4];  // line ends of the lane's record and of the line before it
+};
+struct TileGeo {
+  BcGeo f[kBcFiles];
+  unsigned long long where[3];  // emit: the iteration's place in each output
+  uint8_t st;                   // emit: status
+  uint8_t big;                  // emit: tile flag
+};
+__device__ __forceinline__ void bc_geo_load(const BcFile& f, uint64_t k, BcGeo& g) {
+  const uint64_t r = f.first + k * f.step + f.add;
   const uint64_t* __restrict__ le = f.fv.line_end + 4 * r;
-  const uint64_t prev = r == 0 ? ~0ull : le[-1];
-  const uint64_t e0 = le[0], e1 = le[1], e2 = le[2], e3 = le[3];
-  const uint64_t s0 = rfl64(prev + 1);
-  const uint64_t e3l = rl64(e3, last_lane);
-  const uint64_t s1 = e3l < f.fv.nbytes ? e3l + 1 : e3l;
-  const uint64_t n = s1 - s0;
-  const uint32_t skew = (uint32_t)((uintptr_t)(f.fv.img + s0) & 15u);
-  if (n > (uint64_t)in_cap || (uint64_t)at + skew + n + 32 > (uint64_t)in_cap) return false;
-  const uint8_t* __restrict__ g0 = f.fv.img + s0 - skew;
-  uint8_t* d0 = s_in + at;
-  const uint32_t units = (skew + (uint32_t)n + 15u) >> 4;
-  for (uint32_t u0 = 0; u0 < units; u0 += 4 * kWave) {
-    uint4 v[4];
+  g.prev = r == 0 ? ~0ull : le[-1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t u = u0 + j * kWave + lane;
-      v[j] = *reinterpret_cast<const uint4*>(g0 + 16ull * (u < units ? u : units - 1));  // clamped: no branch, 4 in flight
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t u = u0 + j * kWave + lane;
-      if (u < units) *reinterpret_cast<uint4*>(d0 + 16u * u) = v[j];
-    }
-  }
-  const uint32_t b = at + skew;
-  ln[0] = BcLine{s_in + b + (uint32_t)(prev + 1 - s0), (uint32_t)(e0 - prev - 1), e0 < f.fv.nbytes ? 1u : 0u};
-  ln[1] = BcLine{s_in + b + (uint32_t)(e0 + 1 - s0), (uint32_t)(e1 - e0 - 1), e1 < f.fv.nbytes ? 1u : 0u};
-  ln[2] = BcLine{s_in + b + (uint32_t)(e1 + 1 - s0), (uint32_t)(e2 - e1 - 1), e2 < f.fv.nbytes ? 1u : 0u};
-  ln[3] = BcLine{s_in + b + (uint32_t)(e2 + 1 - s0), (uint32_t)(e3 - e2 - 1), e3 < f.fv.nbytes ? 1u : 0u};
-  at += (skew + (uint32_t)n + 15u) & ~15u;
+  for (int i = 0; i < 4; ++i) g.e[i] = le[i];
+}
+// which files a kernel stages: the plan all of them, the SAM emit only what it prints or tags with
+template <bool SAM_EMIT, int MASK>
+__device__ __forceinline__ bool bc_staged(const BcParams& P, int x) {
+  if (!bc_has<MASK>(P, x)) return false;
+  if (SAM_EMIT && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) return false;
   return true;
 }
 
+// Copies the spans into s_in and gives the lane its lines (pointers into LDS).  Returns false
+// (uniformly, before copying anything) when the spans do not fit in_cap.
+template <bool SAM_EMIT, int MASK>
+__device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& tg, int last_lane, int lane, uint8_t* s_in,
+                                              uint32_t in_cap, BcLine (&L)[kBcFiles][4]) {
+  const uint8_t* gbase[kBcFiles];  // address of the file's unit 0 minus 16 * its first unit number
+  uint32_t first_unit[kBcFiles], skew[kBcFiles];
+  uint64_t s0[kBcFiles];
+  uint32_t units = 0;
+  bool fit = true;
+#pragma unroll
+  for (int x = 1; x < kBcFiles; ++x) {
+    first_unit[x] = 0xFFFFFFFFu;  // never selected
+    gbase[x] = P.f[1].fv.img;
+    if (!bc_staged<SAM_EMIT, MASK>(P, x)) continue;
+    const BcFile& f = P.f[x];
+    s0[x] = rfl64(tg.f[x].prev + 1);
+    const uint64_t e3l = rl64(tg.f[x].e[3], last_lane);
+    const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - s0[x];
+    skew[x] = (uint32_t)((uintptr_t)(f.fv.img + s0[x]) & 15u);
+    first_unit[x] = units;
+    gbase[x] = f.fv.img + s0[x] - skew[x] - 16ull * units;
+    if (n > (uint64_t)in_cap) fit = false;
+    else units += (skew[x] + (uint32_t)n + 15u) >> 4;
+    if ((uint64_t)units * 16u + 32u > (uint64_t)in_cap) fit = false;
+  }
+  if (!fit) return false;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  for (uint32_t u0 = 0; u0 < units; u0 += 8 * kWave) {
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t u = u0 + j * kWave + lane;
+      u = u < units ? u : units - 1;  // clamped: no branch, all 8 in flight
+      const uint8_t* base = gbase[1];  // file 1 is always there and always first
+#pragma unroll
+      for (int x = 2; x < kBcFiles; ++x) base = u >= first_unit[x] ? gbase[x] : base;
+      v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + 16ull * u));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t u = u0 + j * kWave + lane;
+      if (u < units) *reinterpret_cast<u32x4*>(s_in + 16u * u) = v[j];
+    }
+  }
+#pragma unroll
+  for (int x = 1; x < kBcFiles; ++x) {
+    if (!bc_staged<SAM_EMIT, MASK>(P, x)) continue;
+    const BcGeo& g = tg.f[x];
+    const uint64_t nb = P.f[x].fv.nbytes;
+    uint8_t* b = s_in + 16u * first_unit[x] + skew[x];
+    L[x][0] = BcLine{b + (uint32_t)(g.prev + 1 - s0[x]), (uint32_t)(g.e[0] - g.prev - 1), g.e[0] < nb ? 1u : 0u};
+    L[x][1] = BcLine{b + (uint32_t)(g.e[0] + 1 - s0[x]), (uint32_t)(g.e[1] - g.e[0] - 1), g.e[1] < nb ? 1u : 0u};
+    L[x][2] = BcLine{b + (uint32_t)(g.e[1] + 1 - s0[x]), (uint32_t)(g.e[2] - g.e[1] - 1), g.e[2] < nb ? 1u : 0u};
+    L[x][3] = BcLine{b + (uint32_t)(g.e[2] + 1 - s0[x]), (uint32_t)(g.e[3] - g.e[2] - 1), g.e[3] < nb ? 1u : 0u};
+  }
+  return true;
+}
+
+template <int MASK = 0>
 __device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLine (&L)[kBcFiles][4]) {
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x)
-    if (P.f[x].present) bc_lines(P.f[x], k, L[x]);
+    if (bc_has<MASK>(P, x)) bc_lines(P.f[x], k, L[x]);
 }
 
-// One wavefront per tile, one lane per iteration.
+// One wavefront per tile, one lane per iteration.  MASK: see bc_has.
+template <int MASK>
 __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
                                                         uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
                                                         uint32_t* __restrict__ len2, uint8_t* __restrict__ tile_big,
@@ -433,30 +491,39 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
   extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
   const int lane = (int)threadIdx.x;
   const uint64_t n_tiles = (n_iter + tc.T - 1) / tc.T;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t k0 = tile * tc.T;
-    const uint32_t Tn = (uint32_t)(n_iter - k0 < (uint64_t)tc.T ? n_iter - k0 : (uint64_t)tc.T);
-    const bool valid = (uint32_t)lane < Tn;
-    const uint32_t it = valid ? (uint32_t)lane : Tn - 1;
-    const uint64_t k = k0 + it;
-    BcLine L[kBcFiles][4];
-    uint32_t at = 0;
-    bool fit = true;
+  auto tile_size = [&](uint64_t tile) {
+    const uint64_t left = n_iter - tile * tc.T;
+    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
+  };
+  auto geo_of = [&](uint64_t tile, TileGeo& tg) {
+    const uint32_t Tn = tile_size(tile);
+    const uint64_t k = tile * tc.T + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1);
 #pragma unroll
     for (int x = 1; x < kBcFiles; ++x)
-      if (fit && P.f[x].present) fit = bc_stage_file(P.f[x], k0, it, (int)Tn - 1, lane, s_lds, tc.in_cap, at, L[x]);
+      if (bc_has<MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
+  };
+  TileGeo cur, nxt;
+  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t k0 = tile * tc.T;
+    const uint32_t Tn = tile_size(tile);
+    const bool valid = (uint32_t)lane < Tn;
+    const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
+    BcLine L[kBcFiles][4];
+    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);  // the next tile's index: in flight during this tile
+    const bool fit = bc_stage_tile<false, MASK>(P, cur, (int)Tn - 1, lane, s_lds, tc.in_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BcTags t;
     uint32_t finding = 0, a = 0, b = 0, c = 0;
     uint8_t st;
     if (fit) {
-      st = bc_decide_lines<true>(P, L, &t, &finding);
+      st = bc_decide_lines<true, MASK>(P, L, &t, &finding);
       if (st == kBcKeep) bc_out_lens(P, k, L, t, &a, &b, &c);
     } else {  // long reads: from the images
       BcLine G[kBcFiles][4];
-      bc_lines_all(P, k, G);
-      st = bc_decide_lines<false>(P, G, &t, &finding);
+      bc_lines_all<MASK>(P, k, G);
+      st = bc_decide_lines<false, MASK>(P, G, &t, &finding);
       if (st == kBcKeep) bc_out_lens(P, k, G, t, &a, &b, &c);
     }
     if (valid) {
@@ -483,6 +550,7 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
       if (dsc != none && dsc < __atomic_load_n(&call->first_discard, __ATOMIC_RELAXED)) atomicMin(&call->first_discard, dsc);
     }
     __builtin_amdgcn_wave_barrier();
+    cur = nxt;
   }
 }
 
@@ -829,7 +897,7 @@ struct EmitOut {
 
 // One wavefront per tile.  SAM: one lane per line (two per iteration for paired reads); FASTQ: one
 // lane per record, one output after the other.
-template <bool SAM>
+template <bool SAM, int MASK>
 __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, uint64_t n_done,
                                                         const uint8_t* __restrict__ status,
                                                         const uint8_t* __restrict__ tile_big, EmitOut o0, EmitOut o1,
@@ -838,32 +906,46 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
   uint8_t* s_in = s_lds;
   uint8_t* s_out = s_lds + tc.in_cap;
   const int lane = (int)threadIdx.x;
-  const bool se = !P.f[2].present;
+  const bool se = !bc_has<MASK>(P, 2);
   const uint32_t lpi = SAM && !se ? 2u : 1u;  // lanes per iteration
+  const uint32_t it_raw = lpi == 2 ? (uint32_t)lane >> 1 : (uint32_t)lane;
+  const bool mate1 = lpi == 2 ? !(lane & 1) : true;
   const uint64_t n_tiles = (n_done + tc.T - 1) / tc.T;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    if (tile_big[tile]) continue;
+  auto tile_size = [&](uint64_t tile) {
+    const uint64_t left = n_done - tile * tc.T;
+    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
+  };
+  auto geo_of = [&](uint64_t tile, TileGeo& tg) {
+    const uint32_t Tn = tile_size(tile);
+    const uint64_t k = tile * tc.T + (it_raw < Tn ? it_raw : Tn - 1);
+    tg.big = tile_big[tile];
+    tg.st = status[k];
+#pragma unroll
+    for (int x = 1; x < kBcFiles; ++x)
+      if (bc_staged<SAM, MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
+    if (SAM) tg.where[0] = o0.off[k] + o0.sum[k / kScan64Span];
+    else {
+      if (P.emit[1]) tg.where[1] = o1.off[k] + o1.sum[k / kScan64Span];
+      if (P.emit[2]) tg.where[2] = o2.off[k] + o2.sum[k / kScan64Span];
+    }
+  };
+  TileGeo cur, nxt;
+  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur = nxt) {
+    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);  // in flight during this tile
+    if (__builtin_amdgcn_readfirstlane((int)cur.big)) continue;
     const uint64_t k0 = tile * tc.T;
-    const uint32_t Tn = (uint32_t)(n_done - k0 < (uint64_t)tc.T ? n_done - k0 : (uint64_t)tc.T);
-    const uint32_t it_raw = lpi == 2 ? (uint32_t)lane >> 1 : (uint32_t)lane;
-    const bool mate1 = lpi == 2 ? !(lane & 1) : true;
+    const uint32_t Tn = tile_size(tile);
     const bool valid = it_raw < Tn;
-    const uint32_t it = valid ? it_raw : Tn - 1;
-    const uint64_t k = k0 + it;
+    const uint64_t k = k0 + (valid ? it_raw : Tn - 1);
     const int last_lane = (int)((Tn - 1) * lpi);
     BcLine L[kBcFiles][4];
-    uint32_t at = 0;
-#pragma unroll
-    for (int x = 1; x < kBcFiles; ++x) {
-      if (!P.f[x].present) continue;
-      if (SAM && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) continue;  // not printed, no tag
-      (void)bc_stage_file(P.f[x], k0, it, last_lane, lane, s_in, tc.in_cap, at, L[x]);  // fits: the plan checked
-    }
+    (void)bc_stage_tile<SAM, MASK>(P, cur, last_lane, lane, s_in, tc.in_cap, L);  // fits: the plan checked
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const bool keep = valid && status[k] == kBcKeep;
+    const bool keep = valid && cur.st == kBcKeep;
     BcTags t;
-    bc_tags_of_kept(P, L, &t);
+    bc_tags_of_kept<MASK>(P, L, &t);
     if (SAM) {
       BcLine own[4];
 #pragma unroll
@@ -877,10 +959,9 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
                                     mate1, own);
       const unsigned long number = P.first_read_number + k + 1;
       const uint32_t my_len = keep ? bc_sam_line_len(number, bc_sam_flag(se, mate1), g, t) : 0u;
-      const unsigned long long where = o0.off[k] + o0.sum[k / kScan64Span];
-      const unsigned long long tile_at = rfl64(where);
+      const unsigned long long tile_at = rfl64(cur.where[0]);
       const uint32_t before = __shfl_up(my_len, 1, 64);
-      const uint32_t start = (uint32_t)(where - tile_at) + (mate1 ? 0u : before);
+      const uint32_t start = (uint32_t)(cur.where[0] - tile_at) + (mate1 ? 0u : before);
       const uint32_t total = wave_max32(start + my_len);
       uint8_t* dst = o0.out + tile_at;
       const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
@@ -899,9 +980,8 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
         const EmitOut& o = which == 1 ? o1 : o2;
         const bool sliced = bc_slices(P, which);
         const uint32_t my_len = keep ? bc_fastq_len(sliced, P.read_off[which], P.read_size[which], L[which], t) : 0u;
-        const unsigned long long where = o.off[k] + o.sum[k / kScan64Span];
-        const unsigned long long tile_at = rfl64(where);
-        const uint32_t start = (uint32_t)(where - tile_at);
+        const unsigned long long tile_at = rfl64(cur.where[which]);
+        const uint32_t start = (uint32_t)(cur.where[which] - tile_at);
         const uint32_t total = wave_max32(start + my_len);
         uint8_t* dst = o.out + tile_at;
         const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
