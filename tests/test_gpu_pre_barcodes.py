@@ -111,3 +111,82 @@ def test_name_mismatch_and_oracle_agreement():
         assert "Readnames do not match across files (read #1235)" in err
         assert out == want["stdout"]
         assert strip_progress(err) == strip_progress(want["stderr"])
+
+
+# ---- the tiled kernels: every specialisation (set of input files), tiny tiles, tiles that do not fit ----
+def make_long_mix(rng, n, long_every=37, long_len=(3000, 9000)):
+    """Paired records with matching names; every long_every-th pair is a long read (its tile cannot be
+    staged in LDS and takes the direct path)."""
+    bases = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    r1, r2 = [], []
+    for i in range(n):
+        name = b"LR:%d:%d" % (i % 13, i)
+        for out, mate in ((r1, b"1"), (r2, b"2")):
+            ln = int(rng.integers(*long_len)) if i % long_every == long_every - 1 else int(rng.integers(30, 120))
+            s = bases[rng.integers(0, 5, ln)].tobytes()
+            q = (rng.integers(15, 41, ln) + 33).astype(np.uint8).tobytes()
+            out.append(b"@" + name + b"/" + mate + b"\n" + s + b"\n+\n" + q + b"\n")
+    return b"".join(r1), b"".join(r2)
+
+
+FILE_SETS = {
+    "read1_only_fastq": (["--read1", "r1.fastq", "--umi_read", "read1", "--umi_offset", "0", "--umi_size", "8",
+                          "--read1_offset", "8", "--outfile1", "o1.fastq.gz"], False),
+    "read1_only_sam": (["--read1", "r1.fastq", "--umi_read", "read1", "--umi_offset", "2", "--umi_size", "6",
+                        "--sam", "--outfile1", "-"], False),
+    "paired_fastq": (["--read1", "r1.fastq", "--read2", "r2.fastq", "--cell_read", "read2", "--cell_offset", "0",
+                      "--cell_size", "12", "--umi_read", "read1", "--umi_offset", "4", "--umi_size", "7",
+                      "--read2_offset", "12", "--outfile1", "o1.fastq.gz", "--outfile2", "o2.fastq.gz"], False),
+    "paired_sam": (["--read1", "r1.fastq", "--read2", "r2.fastq", "--cell_read", "read2", "--cell_offset", "0",
+                    "--cell_size", "12", "--umi_read", "read2", "--umi_offset", "12", "--umi_size", "8", "--min_qual", "16",
+                    "--phred_encoding", "33", "--sam", "--outfile1", "-"], False),
+    "paired_plus_index_sam": (["--read1", "r1.fastq", "--read2", "r2.fastq", "--index1", "r1.fastq", "--sample_read",
+                               "index1", "--sample_offset", "1", "--sample_size", "5", "--sam", "--10x", "--outfile1", "-"],
+                              False),
+    "four_files_fastq": (["--read1", "r1.fastq", "--read2", "r2.fastq", "--index1", "r2.fastq", "--index2", "r1.fastq",
+                          "--umi_read", "index2", "--umi_offset", "0", "--umi_size", "9", "--cell_read", "index1",
+                          "--cell_offset", "3", "--cell_size", "10", "--outfile1", "o1.fastq.gz", "--outfile2",
+                          "o2.fastq.gz"], False),
+}
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
+@pytest.mark.parametrize("lds", [None, "4096", "65536"], ids=["default_tiles", "tiny_tiles", "large_tiles"])
+@pytest.mark.parametrize("name", sorted(FILE_SETS))
+def test_file_sets_and_tile_sizes_against_reference_binary(name, lds):
+    args, _ = FILE_SETS[name]
+    rng = np.random.default_rng(sum(map(ord, name)))
+    r1, r2 = make_long_mix(rng, 3000)
+    env = {"FQGPU_CHUNK_MB": "1"}
+    if lds:
+        env["FQGPU_BC_LDS"] = lds
+    with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+        res = []
+        for d, binary, e in ((a, REF, None), (b, BIN, env)):
+            for fn, img in (("r1.fastq", r1), ("r2.fastq", r2)):
+                with open(os.path.join(d, fn), "wb") as f:
+                    f.write(img)
+            rc, out, err = run(binary, args, d, e)
+            res.append((rc, out, strip_progress(err), gunzip_file(os.path.join(d, "o1.fastq.gz")),
+                        gunzip_file(os.path.join(d, "o2.fastq.gz"))))
+        assert res[0][0] == res[1][0] == 0, res[1][2]
+        for i in range(1, 5):
+            assert res[0][i] == res[1][i], (name, i)
+        assert (res[0][1] or res[0][3])  # something was written
+
+
+@pytest.mark.parametrize("lds", ["4096", "12288"])
+@pytest.mark.parametrize("case", [c for c in GOLDEN if c["exit"] == 0][::3],
+                         ids=lambda c: " ".join(c["args"])[:50] if isinstance(c, dict) else str(c))
+def test_golden_invocations_other_tile_sizes(case, lds):
+    with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+        rel = os.path.relpath(tmp, GOLD)
+        args = [a.replace("OUT1", rel + "/o1.fastq.gz").replace("OUT2", rel + "/o2.fastq.gz") for a in case["args"]]
+        rc, out, err = run(BIN, args, GOLD, {"FQGPU_BC_LDS": lds})
+        out, err = out.replace(rel + "/", "SCRATCH/"), err.replace(rel + "/", "SCRATCH/")
+        assert rc == case["exit"], err
+        assert out == case["stdout"]
+        assert strip_progress(err) == strip_progress(case["stderr"])
+        for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
+            if tag in case["files"]:
+                assert gunzip_file(os.path.join(tmp, fn)) == case["files"][tag]
