@@ -130,6 +130,106 @@ __device__ inline bool stored_name(const IndexView& ix, uint64_t g, const uint8_
   return false;
 }
 
+// ---- the header line in registers ---------------------------------------------------------------
+// A thread that walks its header byte by byte pays a memory round trip per byte (64 lanes, 64
+// different cache lines per load).  Instead the first kHdrBytes of the line are fetched with eight
+// independent 16-byte loads, and name canonicalisation and hashing work on registers.  Lines that
+// are longer, hold NUL bytes, or sit at the very end of the image take the byte-wise path.
+constexpr int kHdrWords = 16;  // 64-bit words
+constexpr uint32_t kHdrBytes = 8 * kHdrWords;
+struct HdrRegs {
+  uint64_t w[kHdrWords + 1];  // w[kHdrWords] = 0: the funnel shifts read one word ahead
+};
+__device__ __forceinline__ void hdr_load(const uint8_t* __restrict__ line, HdrRegs& H) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+#pragma unroll
+  for (int j = 0; j < kHdrWords / 2; ++j) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(line + 16 * j);
+    H.w[2 * j] = ((uint64_t)v.y << 32) | v.x;
+    H.w[2 * j + 1] = ((uint64_t)v.w << 32) | v.z;
+  }
+  H.w[kHdrWords] = 0;
+}
+__device__ __forceinline__ uint64_t hdr_eq_mask(uint64_t x, uint8_t c) {  // 0x80 in every byte of x equal to c
+  const uint64_t y = x ^ (0x0101010101010101ull * c);
+  const uint64_t t = ((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y;
+  return ~(t | 0x7F7F7F7F7F7F7F7Full);
+}
+// canon_name on registers; cstr = C-string length of the line (no NUL inside), cstr <= kHdrBytes.
+// *ok = false: a Casava header without its blank - left to the byte-wise path (no dynamic register
+// indexing here: the byte two places before the blank is taken from the word the blank was found in).
+__device__ __forceinline__ uint32_t canon_name_regs(const HdrRegs& H, uint32_t cstr, int fmt, int is_pe, uint32_t* acct,
+                                                    bool* ok) {
+  const uint32_t L = cstr > 0 ? cstr - 1 : 0;  // strlen(&hdr[1])
+  *ok = true;
+  if (fmt == FQG_NAME_CASAVA18) {
+    uint32_t first = kHdrBytes;  // position in the line of the first blank at or after byte 1
+    uint32_t two_before = 0;     // line[first - 2]
+#pragma unroll
+    for (int k = kHdrWords - 1; k >= 0; --k) {
+      uint64_t m = hdr_eq_mask(H.w[k], (uint8_t)' ');
+      if (k == 0) m &= ~0xFFull;  // byte 0 is the '@'
+      if (m) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(m) >> 3;
+        first = 8u * k + j;
+        const uint64_t below = k ? H.w[k ? k - 1 : 0] : 0ull;
+        two_before = (uint32_t)(j >= 2 ? H.w[k] >> (8 * (j - 2)) : below >> (8 * (6 + j))) & 0xFFu;
+      }
+    }
+    if (first > L) {
+      *ok = false;
+      return 0;
+    }
+    uint32_t sp = first - 1;  // blank at line[1 + sp], sp < L
+    if (sp >= 2 && two_before == '/') sp -= 2;
+    *acct = sp;
+    return sp;
+  }
+  long l = (long)L;
+  if (fmt == FQG_NAME_DEFAULT && is_pe) l--;
+  *acct = (uint32_t)(l < 0 ? 0 : l);
+  return l >= 1 ? (uint32_t)(l - 1) : L;
+}
+// hash_name(line + 1, n) on registers: the same value, word for word
+__device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n) {
+  uint64_t h = 0x2545F4914F6CDD1Dull ^ n;
+#pragma unroll
+  for (int k = 0; k < kHdrWords; ++k) {
+    const uint64_t nw = (H.w[k] >> 8) | (H.w[k + 1] << 56);  // bytes 8k .. 8k+7 of the name
+    const bool full = 8u * k + 8u <= n;
+    const bool last = !full && 8u * k <= n;  // the partial (possibly empty) word that ends the name
+    const uint32_t rem = n - 8u * k;         // 0..7 when `last`
+    const uint64_t w = full ? nw : (nw & ((1ull << (8 * (rem & 7))) - 1ull));
+    if (full || last) h = mix_hash(h, w);
+  }
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  h ^= h >> 32;
+  return h;
+}
+// name (length, hash) of the header line at img + b; the fast path when the line allows it
+__device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ img, uint64_t nbytes, uint64_t b, uint64_t e,
+                                                  int fmt, int is_pe, int may_have_nul, uint32_t* acct, uint64_t* h,
+                                                  bool* at_sign) {
+  const uint8_t* line = img + b;
+  const uint32_t len = (uint32_t)(e - b), has_nl = e < nbytes ? 1u : 0u;
+  if (!may_have_nul && len + has_nl <= kHdrBytes - 1 && b + kHdrBytes <= nbytes) {
+    HdrRegs H;
+    hdr_load(line, H);
+    bool ok;
+    const uint32_t n = canon_name_regs(H, len + has_nl, fmt, is_pe, acct, &ok);
+    if (ok) {
+      *at_sign = (H.w[0] & 0xFF) == '@';
+      *h = hash_name_regs(H, n);
+      return n;
+    }
+  }
+  *at_sign = line[0] == '@';
+  const uint32_t n = canon_name(line, len, has_nl, fmt, is_pe, may_have_nul, acct);
+  *h = hash_name(line + 1, n);
+  return n;
+}
+
 // One thread per record of the frame: insert its canonical name, report repeats.
 __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView ix, uint64_t record_base,
                                                          IndexCall* __restrict__ call) {
@@ -138,30 +238,27 @@ __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView 
   for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
     const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
     const uint64_t e = f.line_end[4 * r];
-    const uint8_t* line = f.img + b;
-    if (line[0] != '@') {  // fastq_get_readname refuses it (src/fastq.c:448)
+    uint32_t acct;
+    uint64_t h;
+    bool at_sign;
+    const uint32_t n = name_and_hash(f.img, f.nbytes, b, e, ix.fmt, ix.is_pe, ix.may_have_nul, &acct, &h, &at_sign);
+    if (!at_sign) {  // fastq_get_readname refuses it (src/fastq.c:448)
       my_first_wrong = r < my_first_wrong ? r : my_first_wrong;
       continue;
     }
-    uint32_t acct;
-    const uint32_t n = canon_name(line, (uint32_t)(e - b), e < f.nbytes ? 1u : 0u, ix.fmt, ix.is_pe,
-                                  ix.may_have_nul, &acct);
-    const uint8_t* name = line + 1;
-    const uint64_t h = hash_name(name, n);
+    const uint8_t* name = f.img + b + 1;
     const unsigned long long g = record_base + r;
     const unsigned long long mine = ((h >> 40) << 40) | g;
     uint64_t at = h & ix.mask;
     bool done = false;
     for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
-      unsigned long long cur = __hip_atomic_load(&ix.slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // one round trip when the slot is free (most are: the table is at most half full)
+      const unsigned long long cur = atomicCAS(&ix.slots[at], kSlotEmpty, mine);
       if (cur == kSlotEmpty) {
-        cur = atomicCAS(&ix.slots[at], kSlotEmpty, mine);
-        if (cur == kSlotEmpty) {
-          ++inserted;
-          name_bytes += acct;
-          done = true;
-          break;
-        }
+        ++inserted;
+        name_bytes += acct;
+        done = true;
+        break;
       }
       if ((cur >> 40) == (mine >> 40)) {
         const uint8_t* other;
@@ -199,15 +296,15 @@ __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, Inde
   for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
     const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
     const uint64_t e = f.line_end[4 * r];
-    const uint8_t* line = f.img + b;
-    if (line[0] != '@') {
+    uint32_t acct;
+    uint64_t h;
+    bool at_sign;
+    const uint32_t n = name_and_hash(f.img, f.nbytes, b, e, fmt2, is_pe2, may_have_nul2, &acct, &h, &at_sign);
+    if (!at_sign) {
       my_wrong = r < my_wrong ? r : my_wrong;
       continue;
     }
-    uint32_t acct;
-    const uint32_t n = canon_name(line, (uint32_t)(e - b), e < f.nbytes ? 1u : 0u, fmt2, is_pe2, may_have_nul2, &acct);
-    const uint8_t* name = line + 1;
-    const uint64_t h = hash_name(name, n);
+    const uint8_t* name = f.img + b + 1;
     uint64_t at = h & ix.mask;
     bool found = false;
     for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
