@@ -350,15 +350,42 @@ __global__ __launch_bounds__(kBlock) void k_names_compare(FrameView a, int fmt_a
     const uint64_t ba = ra == 0 ? 0 : a.line_end[4 * ra - 1] + 1, ea = a.line_end[4 * ra];
     const uint64_t bb = rb == 0 ? 0 : fb.line_end[4 * rb - 1] + 1, eb = fb.line_end[4 * rb];
     const uint8_t *la = a.img + ba, *lb = fb.img + bb;
+    const uint32_t len_a = (uint32_t)(ea - ba), nl_a = ea < a.nbytes ? 1u : 0u;
+    const uint32_t len_b = (uint32_t)(eb - bb), nl_b = eb < fb.nbytes ? 1u : 0u;
+    uint32_t acct;
+    if (!may_have_nul && len_a + nl_a <= kHdrBytes - 1 && ba + kHdrBytes <= a.nbytes && len_b + nl_b <= kHdrBytes - 1 &&
+        bb + kHdrBytes <= fb.nbytes) {
+      // both headers in registers: no memory round trip per byte
+      HdrRegs A, B;
+      hdr_load(la, A);
+      hdr_load(lb, B);
+      bool ok_a, ok_b;
+      const uint32_t na = canon_name_regs(A, len_a + nl_a, fmt_a, pe_a, &acct, &ok_a);
+      const uint32_t nb = canon_name_regs(B, len_b + nl_b, fmt_b, pe_b, &acct, &ok_b);
+      if (ok_a && ok_b) {
+        if ((A.w[0] & 0xFF) != '@' || (B.w[0] & 0xFF) != '@') {
+          my_wrong = k < my_wrong ? k : my_wrong;
+          continue;
+        }
+        uint64_t diff = 0;
+#pragma unroll
+        for (int w = 0; w < kHdrWords; ++w) {
+          const uint64_t x = ((A.w[w] >> 8) | (A.w[w + 1] << 56)) ^ ((B.w[w] >> 8) | (B.w[w + 1] << 56));
+          const uint64_t m = 8u * w + 8u <= na ? ~0ull : (8u * w < na ? (1ull << (8 * (na - 8u * w))) - 1ull : 0ull);
+          diff |= x & m;
+        }
+        if (na != nb || diff) my_bad = k < my_bad ? k : my_bad;
+        continue;
+      }
+    }
     if (la[0] != '@' || lb[0] != '@') {
       // src/fastq.c:448; for interleaved input both names are taken before anything else,
       // for same-order files each record has already passed validation at this point
       my_wrong = k < my_wrong ? k : my_wrong;
       continue;
     }
-    uint32_t acct;
-    const uint32_t na = canon_name(la, (uint32_t)(ea - ba), ea < a.nbytes ? 1u : 0u, fmt_a, pe_a, may_have_nul, &acct);
-    const uint32_t nb = canon_name(lb, (uint32_t)(eb - bb), eb < fb.nbytes ? 1u : 0u, fmt_b, pe_b, may_have_nul, &acct);
+    const uint32_t na = canon_name(la, len_a, nl_a, fmt_a, pe_a, may_have_nul, &acct);
+    const uint32_t nb = canon_name(lb, len_b, nl_b, fmt_b, pe_b, may_have_nul, &acct);
     if (na != nb || !same_bytes(la + 1, lb + 1, na)) my_bad = k < my_bad ? k : my_bad;
   }
   if (my_bad != kNoRecord) atomicMin(&call->first_missing, my_bad);
@@ -398,11 +425,12 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
   if (r < f.n_records) {
     const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
     const uint64_t e = f.line_end[4 * r];
-    const uint8_t* line = f.img + b;
-    if (line[0] == '@') {  // (a wrong header is the local pass's finding, src/fastq.c:448)
-      uint32_t acct;
-      const uint32_t n = canon_name(line, (uint32_t)(e - b), e < f.nbytes ? 1u : 0u, fmt, is_pe, may_have_nul, &acct);
-      unsigned long long h = hash_name(line + 1, n);
+    uint32_t acct;
+    uint64_t h64;
+    bool at_sign;
+    (void)name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign);
+    if (at_sign) {  // (a wrong header is the local pass's finding, src/fastq.c:448)
+      unsigned long long h = h64;
       if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
       me.fp = h;
       me.idx = record_base + r;
