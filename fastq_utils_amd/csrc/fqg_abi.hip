@@ -18,6 +18,7 @@
 #include "fqg_stream_kernels.hip"
 #include "fqg_index_kernels.hip"
 #include "fqg_barcode_kernels.hip"
+#include "fqg_filter_kernels.hip"
 #include "fqg_umi_kernels.hip"
 
 using namespace fqg;
@@ -1343,6 +1344,92 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   return 0;
 }
 
+// ---- per-record filters ---------------------------------------------------------------------
+int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record, uint64_t n_rec,
+                       const fqg_filter_params* fp, fqg_filter_result* out) {
+  if (!c || !frame || !fp || !out) return FQG_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
+  if (fp->mode != FQG_FILTER_N && fp->mode != FQG_FILTER_POLY_AT) return fail(c, FQG_ERR_ARG, "fqg_records_filter: unknown mode");
+  if (frame->flags & kFlagNul) return fail(c, FQG_ERR_ARG, "fqg_records_filter: input holds NUL bytes");
+  if (first_record + n_rec > frame->fv.n_records) return fail(c, FQG_ERR_ARG, "fqg_records_filter: records beyond the frame");
+  HIP_TRY(c, hipSetDevice(c->device));
+  out->n_records = n_rec;
+  if (!n_rec) return 0;
+  BcParams F;
+  memset(&F, 0, sizeof(F));
+  F.f[1].fv = frame->fv;
+  F.f[1].first = first_record;
+  F.f[1].step = 1;
+  F.f[1].present = 1;
+  F.n_inputs = 1;
+  F.emit[1] = 1;
+  RfParams P;
+  P.mode = fp->mode;
+  P.max_n = fp->max_n_percent > 100 ? 100 : fp->max_n_percent;
+  P.min_poly = fp->min_poly_at_len;
+  P.min_len = (uint64_t)fp->min_len;
+  int rc;
+  const uint64_t nb = (n_rec + kScan64Span - 1) / kScan64Span;
+  if ((rc = ensure(c, c->bc_status, n_rec))) return rc;
+  if ((rc = ensure(c, c->bc_len[1], n_rec * 4))) return rc;
+  if ((rc = ensure(c, c->bc_off[1], n_rec * 8))) return rc;
+  if ((rc = ensure(c, c->bc_sum[1], nb * 8))) return rc;
+  BcCall z;
+  memset(&z, 0, sizeof(z));
+  *c->h_bcall = z;
+  HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
+  const BcTile tc = bc_tile_for(F);
+  const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
+  if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
+  auto resident = [&](const void* kernel, unsigned lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    return (unsigned)per_cu * (unsigned)c->cu_count;
+  };
+  unsigned long long* d_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_bcall) + sizeof(BcCall));
+  unsigned long long* h_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_bcall) + sizeof(BcCall));
+  {
+    ProfScope ps(c, "k_rf_plan");
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_rf_plan_tile, tc.in_cap));
+    hipLaunchKernelGGL(k_rf_plan_tile, dim3(grid), dim3(kWave), tc.in_cap, c->stream, F, P, tc, n_rec,
+                       (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
+  }
+  {
+    ProfScope ps(c, "k_rf_scan");
+    hipLaunchKernelGGL(k_rf_count, dim3((unsigned)std::min<uint64_t>((n_rec + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0,
+                       c->stream, (const uint8_t*)c->bc_status.p, n_rec, c->d_bcall);
+    hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const uint32_t*)c->bc_len[1].p, n_rec,
+                       (unsigned long long*)c->bc_off[1].p, (unsigned long long*)c->bc_sum[1].p);
+    hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->bc_sum[1].p, nb, d_tot + 1);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall) + 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out->n_discarded = c->h_bcall->discarded;
+  out->n_trimmed = c->h_bcall->short_warnings;
+  out->n_kept = n_rec - out->n_discarded;
+  out->out_bytes = h_tot[1];
+  c->bc_out_bytes[1] = h_tot[1];
+  if ((rc = ensure(c, c->bc_out[1], std::max<uint64_t>(h_tot[1], 16)))) return rc;
+  if (h_tot[1]) {
+    ProfScope ps(c, "k_rf_emit");
+    const EmitOut eo{(const uint32_t*)c->bc_len[1].p, (const unsigned long long*)c->bc_off[1].p,
+                     (const unsigned long long*)c->bc_sum[1].p, (uint8_t*)c->bc_out[1].p};
+    const unsigned lds = tc.in_cap + tc.out_cap;
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_rf_emit_tile, lds));
+    hipLaunchKernelGGL(k_rf_emit_tile, dim3(grid), dim3(kWave), lds, c->stream, F, P, tc, n_rec,
+                       (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo);
+    if (c->h_bcall->big) {
+      const unsigned grid_e = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + 3) / 4, (uint64_t)c->cu_count * 8));
+      hipLaunchKernelGGL(k_rf_emit_direct, dim3(grid_e), dim3(kBlock), 0, c->stream, F, P, tc, n_rec,
+                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo);
+    }
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
 int fqg_barcodes_output(fqg_ctx* c, int which, void* host_dst, uint64_t nbytes) {
   if (!c || which < 0 || which > 2 || (!host_dst && nbytes)) return FQG_ERR_ARG;
   if (nbytes > c->bc_out_bytes[which]) return fail(c, FQG_ERR_ARG, "fqg_barcodes_output: more than was produced");
@@ -1351,6 +1438,8 @@ int fqg_barcodes_output(fqg_ctx* c, int which, void* host_dst, uint64_t nbytes) 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return 0;
 }
+
+int fqg_records_filter_output(fqg_ctx* c, void* host_dst, uint64_t nbytes) { return fqg_barcodes_output(c, 1, host_dst, nbytes); }
 
 // ---- measurement ----------------------------------------------------------------------------
 int fqg_profile_enable(fqg_ctx* c, int on) {

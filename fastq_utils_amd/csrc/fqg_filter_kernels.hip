@@ -1,0 +1,278 @@
+// fqg_filter_kernels.hip - per-record filters of the reference's small FASTQ tools on the GPU:
+//   FQG_FILTER_N        fastq_filter_n        (reference src/fastq_filter_n.c:75-91): a record is
+//                       dropped when its sequence holds more N/n than max_n % of read_len allow
+//   FQG_FILTER_POLY_AT  fastq_trim_poly_at    (reference src/fastq_trim_poly_at.c:77-119, :214-222):
+//                       a poly-A (3') or else poly-T (5') run is cut off, records that end up
+//                       shorter than min_len are dropped
+// Same three launches and the same tiles as the barcode transform (fqg_barcode_kernels.hip): the
+// plan kernel decides and measures one record per lane from LDS, a 64-bit scan places the records,
+// the emit kernel writes one record per lane into the tile's LDS output area and flushes it with
+// 16-byte stores.  The decision is recomputed by the emit kernel (a few LDS reads) rather than
+// stored.  Tiles that do not fit LDS (long reads) go through the *_direct paths.
+#include "fqg_device.h"
+
+namespace fqg {
+
+struct RfParams {
+  int32_t mode;
+  uint32_t max_n;        // FILTER_N: percent, already clamped to 100
+  int64_t min_poly;      // POLY_AT: min_poly_at_len
+  uint64_t min_len;      // POLY_AT: min_len, compared unsigned like the reference's `read_len >= min_len`
+};
+
+enum : uint8_t { kRfDiscard = 1, kRfTrimmed = 2 };
+
+// what is printed for one record: hdr1, seq[s_from, s_from + s_n) (+'\n'), hdr2,
+// qual[q_from, q_from + q_n) followed by qual[q2_from, q2_from + q2_n) (+'\n')
+struct RfCut {
+  uint32_t s_from, s_n, s_nl;
+  uint32_t q_from, q_n, q2_from, q2_n, q_nl;
+  uint8_t flags;
+};
+
+template <bool WIDE>
+__device__ __forceinline__ uint32_t rf_count_n(const BcLine& seq) {
+  // N or n among the characters before the line's end (src/fastq_filter_n.c:79-85)
+  const uint32_t n = seq.len;
+  uint32_t cnt = 0;
+  if (WIDE) {
+    for (uint32_t i = 0; i < n; i += 8) {
+      uint64_t m = bytes_eq(ld8(seq.p + i) | 0x2020202020202020ull, (uint8_t)'n');
+      if (n - i < 8) m &= (1ull << (8 * (n - i))) - 1ull;
+      cnt += (uint32_t)__builtin_popcountll(m);
+    }
+  } else {
+    for (uint32_t i = 0; i < n; ++i) cnt += (seq.p[i] | 0x20) == 'n';
+  }
+  return cnt;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ RfCut rf_decide(const RfParams& P, const BcLine (&ln)[4]) {
+  const uint32_t L = ln[1].len + ln[1].nl;   // read_len = strlen(seq), the '\n' included
+  const uint32_t Lq = ln[3].len + ln[3].nl;  // strlen(qual)
+  RfCut c{0, L, 0, 0, Lq, 0, 0, 0, 0};
+  if (P.mode == FQG_FILTER_N) {
+    const uint32_t max_num_n = (uint32_t)((unsigned long)L * P.max_n / 100ul);
+    if (rf_count_n<WIDE>(ln[1]) > max_num_n) c.flags = kRfDiscard;
+    return c;
+  }
+  unsigned long read_len = L;
+  if (P.min_poly > 0) {
+    // 3' end: from seq[read_len - 2] backwards over N A n a
+    long x = (long)((unsigned long)L - 2ul), matched1 = 0;
+    for (; x >= 0; --x) {
+      const uint8_t ch = ln[1].p[x];
+      if (ch != 'N' && ch != 'A' && ch != 'n' && ch != 'a') break;
+      ++matched1;
+    }
+    if (matched1 >= P.min_poly) {
+      // seq[x+1] = '\n', seq[x+2] = 0; the same two stores into qual, whatever its length
+      const uint32_t keep = (uint32_t)(x + 1);
+      c.s_n = keep;
+      c.s_nl = 1;
+      c.q_n = keep < Lq ? keep : Lq;
+      c.q_nl = keep <= Lq ? 1u : 0u;
+      c.flags |= kRfTrimmed;
+      read_len = L - (unsigned long)matched1;
+    } else {
+      // 5' end: N T n t from the start (the '\n' stops the scan)
+      uint32_t matched2 = 0;
+      for (uint32_t i = 0; i < L; ++i) {
+        const uint8_t ch = ln[1].p[i];
+        if (ch != 'N' && ch != 'T' && ch != 'n' && ch != 't') break;
+        ++matched2;
+      }
+      if ((long)matched2 >= P.min_poly) {
+        // seq[i] = seq[i + matched2], qual[i] = qual[i + matched2] for i <= read_len - matched2
+        c.s_from = matched2;
+        c.s_n = L - matched2;
+        if (Lq >= matched2) {
+          c.q_from = matched2;
+          if (Lq <= L) c.q_n = Lq - matched2;
+          else {  // a quality line longer than the sequence keeps its unshifted end
+            c.q_n = L + 1 - matched2;
+            c.q2_from = L - matched2 + 1;
+            c.q2_n = Lq - c.q2_from;
+          }
+        } else {
+          c.q_n = 0;  // (the reference prints stale buffer content here: undefined)
+        }
+        c.flags |= kRfTrimmed;
+        read_len = L - matched2;
+      }
+    }
+  }
+  if (!(read_len >= P.min_len)) c.flags |= kRfDiscard;
+  return c;
+}
+
+__device__ __forceinline__ uint32_t rf_out_len(const BcLine (&ln)[4], const RfCut& c) {
+  return ln[0].len + ln[0].nl + c.s_n + c.s_nl + ln[2].len + ln[2].nl + c.q_n + c.q2_n + c.q_nl;
+}
+
+template <class W>
+__device__ __forceinline__ void rf_emit(const BcLine (&ln)[4], const RfCut& c, W& w) {
+  w.bytes(ln[0].p, ln[0].len + ln[0].nl);
+  w.bytes(ln[1].p + c.s_from, c.s_n);
+  if (c.s_nl) w.ch('\n');
+  w.bytes(ln[2].p, ln[2].len + ln[2].nl);
+  w.bytes(ln[3].p + c.q_from, c.q_n);
+  if (c.q2_n) w.bytes(ln[3].p + c.q2_from, c.q2_n);
+  if (c.q_nl) w.ch('\n');
+}
+
+// One wavefront per tile, one lane per record.  F holds the single input as file 1.
+__global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
+                                                        uint8_t* __restrict__ status, uint32_t* __restrict__ len1,
+                                                        uint8_t* __restrict__ tile_big, BcCall* __restrict__ call) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+  const int lane = (int)threadIdx.x;
+  const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
+  auto tile_size = [&](uint64_t tile) {
+    const uint64_t left = n_rec - tile * tc.T;
+    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
+  };
+  auto geo_of = [&](uint64_t tile, TileGeo& tg) {
+    const uint32_t Tn = tile_size(tile);
+    bc_geo_load(F.f[1], tile * tc.T + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1), tg.f[1]);
+  };
+  TileGeo cur, nxt;
+  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t k0 = tile * tc.T;
+    const uint32_t Tn = tile_size(tile);
+    const bool valid = (uint32_t)lane < Tn;
+    const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
+    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);
+    BcLine L[kBcFiles][4];
+    const bool fit = bc_stage_tile<false, 0x02>(F, cur, (int)Tn - 1, lane, s_lds, tc.in_cap, L);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    RfCut c;
+    uint32_t n = 0;
+    if (fit) {
+      c = rf_decide<true>(P, L[1]);
+      n = rf_out_len(L[1], c);
+    } else {
+      BcLine G[4];
+      bc_lines(F.f[1], k, G);
+      c = rf_decide<false>(P, G);
+      n = rf_out_len(G, c);
+    }
+    if (c.flags & kRfDiscard) n = 0;
+    if (valid) {
+      status[k] = c.flags;
+      len1[k] = n;
+    } else {
+      n = 0;
+    }
+    const uint32_t sum = wave_sum32(n);
+    if (lane == 0) {
+      const bool big = !fit || sum + 32 > tc.out_cap;
+      tile_big[tile] = big ? 1 : 0;
+      if (big) atomicAdd(&call->big, 1ull);
+    }
+    __builtin_amdgcn_wave_barrier();
+    cur = nxt;
+  }
+}
+
+// discarded / trimmed records: one atomic per workgroup
+__global__ __launch_bounds__(kBlock) void k_rf_count(const uint8_t* __restrict__ status, uint64_t n,
+                                                     BcCall* __restrict__ call) {
+  __shared__ unsigned long long s_d[kBlock / kWave], s_t[kBlock / kWave];
+  unsigned long long d = 0, t = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (uint64_t)gridDim.x * kBlock) {
+    const uint8_t st = status[k];
+    d += (st & kRfDiscard) ? 1u : 0u;
+    t += (st & kRfTrimmed) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    d += __shfl_xor(d, o, 64);
+    t += __shfl_xor(t, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_d[threadIdx.x >> 6] = d;
+    s_t[threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long td = 0, tt = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      td += s_d[w];
+      tt += s_t[w];
+    }
+    if (td) atomicAdd(&call->discarded, td);
+    if (tt) atomicAdd(&call->short_warnings, tt);  // (the field holds the trimmed count here)
+  }
+}
+
+__global__ __launch_bounds__(kWave) void k_rf_emit_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
+                                                        const uint8_t* __restrict__ status,
+                                                        const uint8_t* __restrict__ tile_big, EmitOut o) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+  uint8_t* s_in = s_lds;
+  uint8_t* s_out = s_lds + tc.in_cap;
+  const int lane = (int)threadIdx.x;
+  const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
+  auto tile_size = [&](uint64_t tile) {
+    const uint64_t left = n_rec - tile * tc.T;
+    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
+  };
+  auto geo_of = [&](uint64_t tile, TileGeo& tg) {
+    const uint32_t Tn = tile_size(tile);
+    const uint64_t k = tile * tc.T + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1);
+    tg.big = tile_big[tile];
+    tg.st = status[k];
+    bc_geo_load(F.f[1], k, tg.f[1]);
+    tg.where[1] = o.off[k] + o.sum[k / kScan64Span];
+  };
+  TileGeo cur, nxt;
+  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur = nxt) {
+    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);
+    if (__builtin_amdgcn_readfirstlane((int)cur.big)) continue;
+    const uint32_t Tn = tile_size(tile);
+    const bool valid = (uint32_t)lane < Tn;
+    BcLine L[kBcFiles][4];
+    (void)bc_stage_tile<false, 0x02>(F, cur, (int)Tn - 1, lane, s_in, tc.in_cap, L);  // fits: the plan checked
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool keep = valid && !(cur.st & kRfDiscard);
+    const RfCut c = rf_decide<true>(P, L[1]);
+    const uint32_t my_len = keep ? rf_out_len(L[1], c) : 0u;
+    const unsigned long long tile_at = rfl64(cur.where[1]);
+    const uint32_t start = (uint32_t)(cur.where[1] - tile_at);
+    const uint32_t total = wave_max32(keep ? start + my_len : 0u);
+    uint8_t* dst = o.out + tile_at;
+    const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
+    if (keep) {
+      LaneWriter w{s_out + skew + start};
+      rf_emit(L[1], c, w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    emit_flush(s_out, skew, total, dst, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// records of the tiles that do not fit LDS: one wavefront per record, straight from image to image
+__global__ __launch_bounds__(kBlock) void k_rf_emit_direct(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
+                                                           const uint8_t* __restrict__ status,
+                                                           const uint8_t* __restrict__ tile_big, EmitOut o) {
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_rec; k += n_waves) {
+    if (!tile_big[k / tc.T] || (status[k] & kRfDiscard)) continue;
+    BcLine G[4];
+    bc_lines(F.f[1], k, G);
+    const RfCut c = rf_decide<false>(P, G);
+    Writer w{o.out + o.off[k] + o.sum[k / kScan64Span], lane};
+    rf_emit(G, c, w);
+  }
+}
+
+}  // namespace fqg

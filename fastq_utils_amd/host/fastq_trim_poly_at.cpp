@@ -1,0 +1,131 @@
+// fastq_trim_poly_at - drop-in for the reference program (reference src/fastq_trim_poly_at.c:123-233):
+// cut a poly-A run off the 3' end or else a poly-T run off the 5' end of every read (N counts as
+// either), drop reads that end up shorter than --min_len, write the rest gzipped.  Options,
+// messages, exit codes as the reference; trim_poly_at (:77-119) and the length test run on the GPU
+// (fqg_records_filter, FQG_FILTER_POLY_AT).
+#include <getopt.h>
+
+#include "fq_filter_run.h"
+
+using namespace fqhost;
+
+#define FQ_PRINT_INFO(...)        \
+  do {                            \
+    fprintf(stderr, "INFO:");     \
+    fprintf(stderr, __VA_ARGS__); \
+    fprintf(stderr, "\n");        \
+  } while (0)
+
+static void print_usage() {  // src/fastq_trim_poly_at.c:121-133
+  const char msg[] =
+      "\n"
+      "  --help       :print the usage\n"
+      "  --file <filename> :fastq (optional gzipped) file name \n"
+      "  --ofile <filename> : fastq file name where the processed reads will be written \n"
+      "  --min_poly_at_len integer     : minimum length of poly-A|T sequence to remove.\n"
+      "  --min_len integer     : minimum read length.\n";
+  fprintf(stdout, "usage: fastq_trim_poly_at --file fastq_file --outfile out_file [optional parameters]");
+  fprintf(stdout, "%s", msg);
+}
+
+int main(int argc, char** argv) {
+  const char* file = nullptr;
+  const char* outfile = nullptr;
+  long min_poly_at_len = 10, min_len = 10;
+  static int help = 0;
+  opterr = 0;
+  fprintf(stderr, "fastq_utils %s\n", "0.25.3");
+  static struct option long_options[] = {{"help", no_argument, &help, 1},
+                                         {"min_poly_at_len", required_argument, 0, 'a'},
+                                         {"file", required_argument, 0, 'b'},
+                                         {"outfile", required_argument, 0, 'c'},
+                                         {"min_len", required_argument, 0, 'd'},
+                                         {0, 0, 0, 0}};
+  while (1) {
+    int option_index = 0;
+    const int c = getopt_long(argc, argv, "a:b:c:d:", long_options, &option_index);
+    if (c == -1) break;
+    switch (c) {
+      case 'a': min_poly_at_len = (int)atol(optarg); break;  // the field is an int (src/fastq_trim_poly_at.c:39)
+      case 'b': file = optarg; break;
+      case 'c': outfile = optarg; break;
+      case 'd': min_len = atol(optarg); break;
+      default: break;
+    }
+  }
+  if (help) {
+    print_usage();
+    exit(0);
+  }
+  FQ_PRINT_INFO("Validating options...");
+  if (!file) {
+    FQ_PRINT_ERROR("missing input file (--file)");
+    exit(kExitParams);
+  }
+  if (!outfile) {
+    FQ_PRINT_ERROR("missing output file name (--outfile)");
+    exit(kExitParams);
+  }
+  FQ_PRINT_INFO("Options OK.");
+
+  // the reference opens the input, then the output, before anything is read
+  {
+    gzFile probe = (file[0] == '-' && file[1] == 0) ? nullptr : gzopen(file, "r");
+    if (!(file[0] == '-' && file[1] == 0)) {
+      if (!probe) {
+        FQ_PRINT_ERROR("Unable to open %s", file);
+        exit(kExitParams);
+      }
+      gzclose(probe);
+    }
+  }
+  gzFile out = (outfile[0] == '-' && outfile[1] == 0) ? gzdopen(fileno(stdout), "wb") : gzopen(outfile, "w4");
+  if (!out) {
+    FQ_PRINT_ERROR("Unable to open %s", outfile);
+    exit(kExitParams);
+  }
+  gzbuffer(out, 1 << 20);
+
+  fqg_ctx* ctx = nullptr;
+  const char* dev = getenv("FQGPU_DEVICE");
+  const int rc = fqg_open(dev ? atoi(dev) : 0, &ctx);
+  if (rc != 0) {
+    FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
+    exit(kExitSys);
+  }
+  fqg_filter_params fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.mode = FQG_FILTER_POLY_AT;
+  fp.min_poly_at_len = min_poly_at_len;
+  fp.min_len = min_len;
+  const FilterTotals t = run_filter(
+      ctx, file, fp,
+      [&](const char* text, size_t n) {
+        size_t off = 0;
+        while (off < n) {
+          const unsigned chunk = (unsigned)std::min<size_t>(n - off, 1u << 30);
+          if (gzwrite(out, text + off, chunk) <= 0) {
+            int en = 0;
+            FQ_PRINT_ERROR("%s.\n", gzerror(out, &en));
+            exit(kExitSys);
+          }
+          off += chunk;
+        }
+      },
+      [](unsigned long before, unsigned long after) {
+        // PRINT_READS_PROCESSED(fdi->cline / 4, 100000) after every record
+        for (unsigned long c = (before / 100000 + 1) * 100000; c <= after; c += 100000) {
+          fprintf(stderr, "\b\b\b\b\b\b\b\b\b\b\b\b\b\b\b%lu", c);
+          fflush(stderr);
+        }
+      });
+  FQ_PRINT_INFO("Reads processed: %ld", (long)t.processed);
+  FQ_PRINT_INFO("Reads trimmed: %ld", (long)t.trimmed);
+  FQ_PRINT_INFO("Reads discarded: %ld", (long)t.discarded);
+  if (gzclose(out) != Z_OK) {
+    FQ_PRINT_ERROR("unable to close file descriptor");
+    exit(kExitSys);
+  }
+  fqg_close(ctx);
+  exit(0);
+}

@@ -274,6 +274,27 @@ int fqg_barcodes_transform(fqg_ctx *ctx, const fqg_frame *const frames[6], const
 /* copy output `which` (0 SAM, 1, 2) of the last transform to host memory */
 int fqg_barcodes_output(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
 
+/* ---- per-record filters (fastq_filter_n, fastq_trim_poly_at) ------------------------------------
+ * Replaces the record loops of fastq_filter_n (src/fastq_filter_n.c:75-91: count N/n in the sequence,
+ * drop the record when there are more than read_len * max_n / 100) and of fastq_trim_poly_at
+ * (src/fastq_trim_poly_at.c:77-119 trim_poly_at, :214-222 the min_len test and the counters).
+ * Works on records [first_record, first_record + n_records) of a retained frame; the kept (and
+ * trimmed) records are left as FASTQ text in device memory, fetched with fqg_records_filter_output.
+ * read_len is strlen(seq) with its '\n', as in the reference (src/fastq.c:259). */
+typedef struct {
+  int32_t mode;             /* FQG_FILTER_N or FQG_FILTER_POLY_AT (fqg_codes.h) */
+  uint32_t max_n_percent;   /* FILTER_N: -n (0: any N drops the record); values above 100 count as 100 */
+  int64_t min_poly_at_len;  /* POLY_AT: --min_poly_at_len (<= 0: nothing is trimmed) */
+  int64_t min_len;          /* POLY_AT: --min_len, compared as the reference does (unsigned) */
+} fqg_filter_params;
+typedef struct {
+  uint64_t n_records, n_kept, n_trimmed, n_discarded;
+  uint64_t out_bytes;
+} fqg_filter_result;
+int fqg_records_filter(fqg_ctx *ctx, const fqg_frame *frame, uint64_t first_record, uint64_t n_records,
+                       const fqg_filter_params *params, fqg_filter_result *out);
+int fqg_records_filter_output(fqg_ctx *ctx, void *host_dst, uint64_t nbytes);
+
 /* ---- UMI counting (bam_umi_count) ---------------------------------------------------------------
  * Replaces the alignment loop of bam_umi_count (src/bam_umi_count.c:942-1060: filters, aux tags,
  * char2uint_64 :364-382, the label maps :143-260, process_entry :444-509) and the output decisions

@@ -63,6 +63,8 @@ enum fqg_code {
 
 /* read-name formats, src/fastq.h:25-28 (INTEGERNAME and NOP share the value 2) */
 #define FQG_NAME_DEFAULT 0
+#define FQG_FILTER_N 1       /* fqg_filter_params.mode */
+#define FQG_FILTER_POLY_AT 2
 #define FQG_NAME_CASAVA18 1
 #define FQG_NAME_INTEGER 2
 #define FQG_NAME_NOP 2

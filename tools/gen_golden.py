@@ -352,6 +352,123 @@ def gen_umi():
     print("bam_umi_count invocations:", len(out), "by exit status:", by)
 
 
+FN_BIN = os.path.join(REPO, "oracle", "_ref", "fastq_filter_n")
+TP_BIN = os.path.join(REPO, "oracle", "_ref", "fastq_trim_poly_at")
+
+
+def filters_synthetic():
+    """A seeded FASTQ with what the two filters react to: poly-A tails and poly-T heads of many lengths
+    (upper / lower case, N mixed in), reads that are nothing but A or T, N-rich reads, very short reads,
+    and a few records whose quality line is longer or shorter than the sequence."""
+    import numpy as np
+
+    rng = np.random.default_rng(77)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(400):
+        n = int(rng.integers(1, 90))
+        seq = bytearray(bases[rng.integers(0, 4, n)].tobytes())
+        kind = i % 10
+        if kind in (0, 1, 2):  # poly-A tail
+            t = int(rng.integers(1, 25))
+            tail = bytes(rng.choice(list(b"AAAAAAaN"), t).astype(np.uint8))
+            seq += tail
+        elif kind in (3, 4):  # poly-T head
+            t = int(rng.integers(1, 25))
+            seq = bytearray(bytes(rng.choice(list(b"TTTTTTtn"), t).astype(np.uint8))) + seq
+        elif kind == 5:  # nothing but A / T / N
+            seq = bytearray(bytes(rng.choice(list(b"AAN" if i % 20 == 5 else b"TTn"), n).astype(np.uint8)))
+        elif kind == 6:  # N-rich
+            for j in range(len(seq)):
+                if rng.random() < 0.3:
+                    seq[j] = ord("N") if rng.random() < 0.7 else ord("n")
+        elif kind == 7 and n > 4:  # both ends
+            seq = bytearray(b"TTTTT") + seq + bytearray(b"AAAAAA")
+        qlen = len(seq)
+        if i % 57 == 11:
+            qlen += int(rng.integers(1, 6))  # quality longer than the sequence
+        elif i % 57 == 23 and qlen > 6:
+            qlen -= int(rng.integers(1, 4))  # shorter (but longer than any trimmed prefix here: kind 9 / no T head)
+        qual = (rng.integers(2, 41, qlen) + 33).astype(np.uint8).tobytes()
+        recs.append(b"@FLT:%d:%d/1\n" % (i % 7, i) + bytes(seq) + b"\n+\n" + qual + b"\n")
+    return b"".join(recs)
+
+
+def filters_jobs():
+    d = lambda n: "data/" + n
+    small = []
+    for path in sorted(glob.glob(os.path.join(DATA, "*.fastq.gz"))):
+        if os.path.getsize(path) < 60_000:
+            small.append(os.path.basename(path))
+    fn, tp = [], []
+    # run_tests.sh:211-216
+    fn += [[d("test_21_2.fastq.gz")], ["-n", "100", d("test_21_2.fastq.gz")], [d("test_1.fastq.gz")], ["--help"], []]
+    fn += [["-x", d("test_1.fastq.gz")], ["-n"], ["-n", "5"], [d("does_not_exist.fastq.gz")], ["-n", "-3", d("test_1.fastq.gz")],
+           ["-n", "250", d("test_1.fastq.gz")], [d("test_1.fastq.gz"), "extra"], [d("test_1.fastq.gz"), "extra", "more"]]
+    for n in small + ["syn_filters.fastq", "empty.fastq", "syn_filters_trunc.fastq"]:
+        for flags in ([], ["-n", "1"], ["-n", "10"], ["-n", "30"], ["-n", "100"]):
+            fn.append(flags + [d(n)])
+    # run_tests.sh:190-201
+    tp += [[], ["--help"], ["--file", d("a_1.fastq.gz")], ["--file", d("a_1xx.fastq.gz"), "--outfile", "OUT"],
+           ["--file", d("a_1.fastq.gz"), "--outfile", "/xxx/tmp.fastq.gz"],
+           ["--file", d("a_1.fastq.gz"), "--outfile", "OUT", "--min_poly_at_len", "20"],
+           ["--file", d("poly_at.fastq.gz"), "--outfile", "OUT", "--min_poly_at_len", "3"],
+           ["--file", d("poly_at.fastq.gz"), "--outfile", "OUT", "--min_poly_at_len", "300", "--min_len", "1"],
+           ["--outfile", "OUT"], ["--file", d("poly_at.fastq.gz"), "--outfile", "OUT", "--bogus", "--min_len", "5"]]
+    for n in small + ["syn_filters.fastq", "empty.fastq", "syn_filters_trunc.fastq"]:
+        for extra in ([], ["--min_poly_at_len", "3"], ["--min_poly_at_len", "5", "--min_len", "1"],
+                      ["--min_poly_at_len", "1", "--min_len", "30"], ["--min_poly_at_len", "0"],
+                      ["--min_poly_at_len", "8", "--min_len", "-1"], ["--min_poly_at_len", "2", "--min_len", "0"]):
+            tp.append(["--file", d(n), "--outfile", "OUT"] + extra)
+    return fn, tp
+
+
+def gen_filters():
+    import gzip
+    import hashlib
+    import tempfile
+
+    for b in (FN_BIN, TP_BIN):
+        if not os.path.exists(b):
+            sys.exit("build the reference first: make -C oracle ref")
+    syn = filters_synthetic()
+    with open(os.path.join(DATA, "syn_filters.fastq"), "wb") as f:
+        f.write(syn)
+    with open(os.path.join(DATA, "syn_filters_trunc.fastq"), "wb") as f:
+        f.write(syn[: syn.index(b"@FLT:5:40/1")] + b"@FLT:5:40/1\nACGT\n+\n")  # two lines short of a record
+    fn, tp = filters_jobs()
+
+    def pack(text):
+        h = hashlib.sha256(text).hexdigest()
+        return {"sha256": h, "len": len(text), "text": text.decode("latin-1") if len(text) <= 30000 else None}
+
+    out = {"filter_n": [], "trim_poly_at": []}
+    for args in fn:
+        p = subprocess.run(["fastq_filter_n"] + args, executable=FN_BIN, cwd=GOLD, capture_output=True, timeout=120)
+        out["filter_n"].append({"args": args, "exit": p.returncode, "stdout": pack(p.stdout),
+                                "stderr": p.stderr.decode("latin-1")})
+    for args in tp:
+        with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+            rel = os.path.relpath(tmp, GOLD)
+            real = [a.replace("OUT", rel + "/o.fastq.gz") if a == "OUT" else a for a in args]
+            p = subprocess.run(["fastq_trim_poly_at"] + real, executable=TP_BIN, cwd=GOLD, capture_output=True, timeout=120)
+            path = os.path.join(tmp, "o.fastq.gz")
+            written = None
+            if os.path.exists(path) and p.returncode == 0:
+                raw = open(path, "rb").read()
+                written = pack(gzip.decompress(raw) if raw else b"")
+            out["trim_poly_at"].append({"args": args, "exit": p.returncode, "stdout": p.stdout.decode("latin-1"),
+                                        "stderr": p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"),
+                                        "out": written})
+    with open(os.path.join(GOLD, "filters.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    for k, v in out.items():
+        by = {}
+        for o in v:
+            by[o["exit"]] = by.get(o["exit"], 0) + 1
+        print(k, "invocations:", len(v), "by exit status:", by)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "fastq_info"):
@@ -360,3 +477,5 @@ if __name__ == "__main__":
         gen_pre_barcodes()
     if which in ("all", "umi"):
         gen_umi()
+    if which in ("all", "filters"):
+        gen_filters()
