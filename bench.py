@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-barcodes-extra", action="store_true",
                     help="skip the extra: fastq_pre_barcodes 10x v2 layout (BASELINE.json configs[2])")
     ap.add_argument("--barcode-pairs", type=int, default=200_000_000, help="read pairs of that extra (BASELINE: 200 M)")
+    ap.add_argument("--no-filters-extra", action="store_true",
+                    help="skip the fastq_filter_n / fastq_trim_poly_at extra (fqg_records_filter on the same image)")
     ap.add_argument("--no-umi-extra", action="store_true",
                     help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
     ap.add_argument("--umi-triples", type=int, default=5_000_000)
@@ -176,6 +178,73 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs):
                                "sample": f"first {ms} pairs of the same batch, uncompressed files, SAM to /dev/null; "
                                          "reference fastq_pre_barcodes (single-threaded)",
                                "seconds": secs, "ok": p.returncode == 0}
+    return out
+
+
+def filters_extra(ctx, fq, torch, dev, image, n, R, st, read_len):
+    """fastq_filter_n and fastq_trim_poly_at record loops (fqg_records_filter) on the bench's own
+    image.  Checked at full size through counts recomputed with torch from the sequence bytes and output
+    sizes, and on the first 2 000 records against the oracle; the reference programs are timed on a sample."""
+    A = fq.abi
+    r = ctx.validate(image.data_ptr(), None, st, final=True, flags=A.VALIDATE_FRAME_ONLY, nbytes=n * R)
+    assert r["n_records"] == n, r
+    frame = ctx.retain_frame()
+    hdr = R - 2 * read_len - 4  # '@name\n' ; then seq\n+\n qual\n
+    seq = image.view(n, R)[:, hdr: hdr + read_len]
+    is_n = (seq == ord("N"))
+    out = {"what": "fastq_filter_n / fastq_trim_poly_at record loops (fqg_records_filter) on the same image", "reads": n}
+    from oracle import filter_oracle as fo
+
+    m = min(2000, n)
+    head = bytes(image[: m * R].cpu().numpy())
+    modes = (("filter_n", dict(mode=A.FILTER_N, max_n_percent=0), ["in.fastq"], fo.filter_n, "stdout"),
+             ("trim_poly_at", dict(mode=A.FILTER_POLY_AT, min_poly_at_len=3, min_len=10),
+              ["--file", "in.fastq", "--outfile", "x", "--min_poly_at_len", "3"], fo.trim_poly_at, "out"))
+    for name, kw, argv, oracle, field in modes:
+        ctx.records_filter(frame, n, **kw)
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        fr = ctx.records_filter(frame, n, **kw)
+        ctx.synchronize()
+        wall = time.perf_counter() - t1
+        prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_rf") and v[0] > 0}
+        ctx.profile(False)
+        if name == "filter_n":
+            want_disc = int(is_n.any(dim=1).sum().item())
+            ok = fr["n_discarded"] == want_disc and fr["out_bytes"] == (n - want_disc) * R and fr["n_trimmed"] == 0
+        else:
+            a_or_n = (seq[:, -3:] == ord("A")) | is_n[:, -3:]
+            t_or_n = (seq[:, :3] == ord("T")) | is_n[:, :3]
+            want_trim = int((a_or_n.all(dim=1) | t_or_n.all(dim=1)).sum().item())
+            ok = fr["n_trimmed"] == want_trim and fr["n_discarded"] == 0 and fr["out_bytes"] < n * R
+        want = oracle(argv, lambda p: head)
+        got = ctx.records_filter_output(len(want[field]))
+        kernels_ms = sum(prof.values())
+        algo = n * R + fr["out_bytes"]
+        out[name] = {"wall_ms_one_call": wall * 1e3, "Mreads_per_s_wall": n / wall / 1e6, "kernels_ms": kernels_ms,
+                     "kernels_ms_breakdown": prof, "result": fr, "algorithmic_GB": algo / 1e9,
+                     "achieved_GBps_kernels": algo / (kernels_ms * 1e-3) / 1e9 if kernels_ms else None,
+                     "properties_hold": bool(ok), "first_2000_records_identical_to_oracle": got == want[field]}
+    frame.release()
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, ms, argv in (("fastq_filter_n", min(n, 4_000_000), ["in.fastq"]),
+                               ("fastq_trim_poly_at", min(n, 1_000_000),
+                                ["--file", "in.fastq", "--outfile", "o.fastq.gz", "--min_poly_at_len", "3"])):
+            ref = os.path.join(REPO, "oracle", "_ref", name)
+            if not os.path.exists(ref):
+                continue
+            with open(os.path.join(tmp, "in.fastq"), "wb") as f:
+                f.write(bytes(image[: ms * R].cpu().numpy()))
+            t2 = time.perf_counter()
+            p = subprocess.run([name] + argv, executable=ref, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            secs = time.perf_counter() - t2
+            out[name.replace("fastq_", "")]["cpu_baseline"] = {
+                "value": ms / secs / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "reference",
+                "sample": f"first {ms} reads of the same image, uncompressed input; reference {name} (single-threaded"
+                          + (", gzip level 4 output included)" if "trim" in name else ", output to /dev/null)"),
+                "seconds": secs, "ok": p.returncode == 0}
     return out
 
 
@@ -465,6 +534,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             m = min(n, a.cpu_sample_reads)
             out["cpu_baseline"] = cpu_baseline(bytes(image[: m * R].cpu().numpy()), m)
+        if world == 1 and not a.no_filters_extra:
+            try:
+                out["filters_extra"] = filters_extra(ctx, fq, torch, dev, image, n, R, st, a.read_len)
+            except Exception as e:
+                out["filters_extra"] = {"error": repr(e)[:300]}
         if world == 1 and not (a.no_umi_extra and a.no_barcodes_extra):
             del image
             torch.cuda.empty_cache()

@@ -31,7 +31,7 @@ EXPORTS = [
     "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
     "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_index_create",
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_names_compare",
-    "fqg_barcodes_transform", "fqg_barcodes_output",
+    "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
     "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
@@ -60,6 +60,19 @@ class BarcodeParams(C.Structure):
                 ("umi_offset", C.c_int64), ("umi_size", C.c_int64), ("cell_offset", C.c_int64),
                 ("cell_size", C.c_int64), ("sample_offset", C.c_int64), ("sample_size", C.c_int64),
                 ("read_offset", C.c_int64 * 3), ("read_size", C.c_int64 * 3)]
+
+
+FILTER_N, FILTER_POLY_AT = 1, 2
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("max_n_percent", C.c_uint32), ("min_poly_at_len", C.c_int64),
+                ("min_len", C.c_int64)]
+
+
+class FilterResult(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_kept", C.c_uint64), ("n_trimmed", C.c_uint64),
+                ("n_discarded", C.c_uint64), ("out_bytes", C.c_uint64)]
 
 
 class BarcodeResult(C.Structure):
@@ -194,6 +207,8 @@ def load():
     L.fqg_barcodes_transform.argtypes = [vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64),
                                          C.POINTER(BarcodeParams), u64, u64, C.POINTER(BarcodeResult)]
     L.fqg_barcodes_output.argtypes = [vp, C.c_int, vp, u64]
+    L.fqg_records_filter.argtypes = [vp, vp, u64, u64, C.POINTER(FilterParams), C.POINTER(FilterResult)]
+    L.fqg_records_filter_output.argtypes = [vp, vp, u64]
     L.fqg_fp_owner.argtypes = [u64, C.c_uint32]
     L.fqg_fp_owner.restype = C.c_uint32
     L.fqg_names_fingerprints.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, C.POINTER(u64)]
@@ -428,6 +443,19 @@ class Context:
         out = {k: getattr(r, k) for k, _ in BarcodeResult._fields_ if k != "out_bytes"}
         out["out_bytes"] = list(r.out_bytes)
         return out
+
+    def records_filter(self, frame, n_records, mode, max_n_percent=0, min_poly_at_len=10, min_len=10, first_record=0):
+        """fastq_filter_n (mode FILTER_N) / fastq_trim_poly_at (FILTER_POLY_AT) on a retained frame; the kept
+        records stay on the device as FASTQ text (records_filter_output copies them)."""
+        p = FilterParams(mode, max_n_percent, min_poly_at_len, min_len)
+        r = FilterResult()
+        self._check(load().fqg_records_filter(self.h, frame.h, first_record, n_records, C.byref(p), C.byref(r)))
+        return {k: getattr(r, k) for k, _ in FilterResult._fields_}
+
+    def records_filter_output(self, nbytes):
+        buf = C.create_string_buffer(max(1, nbytes))
+        self._check(load().fqg_records_filter_output(self.h, buf, nbytes))
+        return buf.raw[:nbytes]
 
     def barcodes_output(self, which, nbytes):
         buf = C.create_string_buffer(max(1, nbytes))
