@@ -69,6 +69,8 @@ struct fqg_ctx {
   DevBuf umi_names, umi_cells, umi_entries[2];  // results of the last fqg_umi_count
   uint64_t umi_n_features = 0, umi_n_cells = 0, umi_n_entries[2] = {0, 0};
   void* umi_state = nullptr;  // UmiState of a deferred fqg_umi_count (fqg_umi_abi.inc)
+  DevBuf umi_arena;           // scratch memory of fqg_umi_count, kept between calls
+  size_t umi_arena_wanted = 0;
   CallState* d_cs = nullptr;
   CallState* h_cs = nullptr;  // pinned
   uint64_t* h_scalar = nullptr;  // pinned, 8 x u64
@@ -259,6 +261,7 @@ void fqg_close(fqg_ctx* c) {
   release(c->cinfo);
   release(c->queue);
   release(c->redo);
+  release(c->umi_arena);
   release(c->umi_names);
   release(c->umi_cells);
   release(c->umi_entries[0]);
