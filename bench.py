@@ -426,6 +426,60 @@ def main():
                 acc.merge(b)
             assert acc.read()["num_rds"] == n * a.steps * world
 
+    out = None
+    if rank == 0:
+        kernels = {k: v for k, v in prof.items() if k.startswith("k_") and v[0] > 0}
+        dom = max(kernels, key=lambda k: kernels[k][1])
+        launches, total_ms = kernels[dom]
+        avg_ms = total_ms / launches
+        algo_bytes = n * (R + ALGO_BYTES_PER_READ_EXTRA)  # per launch: one batch
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        all_ms = sum(v[1] for v in kernels.values()) / a.steps
+        traffic, traffic_src = committed_traffic(dom, n, a.read_len, R)
+        out = {
+            "metric": "Mreads/s validated (fastq_info, 150bp)",
+            "value": n * a.steps * world / dt / 1e6,
+            "unit": "Mreads/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"fastq_info -r (frame + validate + stats) on {n} synthetic {a.read_len}bp single-end "
+                            f"reads per GPU, {R} B/record, uncompressed, HBM-resident (BASELINE.json configs[1])",
+                "reads_per_gpu": n, "read_len": a.read_len, "record_bytes": R, "path": res["path"],
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms,
+                "all_kernels_ms_per_step": all_ms,
+                "pipeline_achieved": algo_bytes / (all_ms * 1e-3) / 1e9,
+                "kernels_ms_per_step": {k: v[1] / a.steps for k, v in kernels.items()},
+            },
+        }
+    # The extra below is the only part of a --gpus N run with collectives in the data path (RCCL all-to-all).
+    # If it should hang on some topology, the line above must still come out: a watchdog prints it and ends
+    # every rank.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            out["dedup_extra"] = {"error": "timed out (watchdog) - the headline numbers above are unaffected"}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = None
+    if not a.no_dedup_extra and world > 1:
+        watchdog = threading.Timer(float(os.environ.get("FQGPU_BENCH_EXTRA_TIMEOUT", "240")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
     dedup = None
     if not a.no_dedup_extra and (world > 1 or a.dedup_extra):
         # untimed extra on every rank: the unique-name test of fastq_info's index mode over the names of
@@ -468,43 +522,9 @@ def main():
         except Exception as e:  # the headline line must survive a failure of an extra
             dedup = {"error": repr(e)[:300]}
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        kernels = {k: v for k, v in prof.items() if k.startswith("k_") and v[0] > 0}
-        dom = max(kernels, key=lambda k: kernels[k][1])
-        launches, total_ms = kernels[dom]
-        avg_ms = total_ms / launches
-        algo_bytes = n * (R + ALGO_BYTES_PER_READ_EXTRA)  # per launch: one batch
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        all_ms = sum(v[1] for v in kernels.values()) / a.steps
-        traffic, traffic_src = committed_traffic(dom, n, a.read_len, R)
-        out = {
-            "metric": "Mreads/s validated (fastq_info, 150bp)",
-            "value": n * a.steps * world / dt / 1e6,
-            "unit": "Mreads/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": f"fastq_info -r (frame + validate + stats) on {n} synthetic {a.read_len}bp single-end "
-                            f"reads per GPU, {R} B/record, uncompressed, HBM-resident (BASELINE.json configs[1])",
-                "reads_per_gpu": n, "read_len": a.read_len, "record_bytes": R, "path": res["path"],
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms,
-                "all_kernels_ms_per_step": all_ms,
-                "pipeline_achieved": algo_bytes / (all_ms * 1e-3) / 1e9,
-                "kernels_ms_per_step": {k: v[1] / a.steps for k, v in kernels.items()},
-            },
-        }
         if dedup is not None:
             out["dedup_extra"] = dedup
         if world == 1 and not a.no_index_extra:
@@ -554,10 +574,13 @@ def main():
             except Exception as e:
                 out["umi_count_extra"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
+    if world > 1:
+        # every rank has what it needs; a rank that failed in the extra must not keep the others waiting in a
+        # collective tear-down
+        sys.stdout.flush()
+        os._exit(0)
     acc.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
