@@ -9,6 +9,7 @@
 //   GPU    everything per alignment: filters, aux tags, barcode packing, the label maps, the
 //          (cell, feature, UMI) set, float32 counters, which lines each cell prints
 // There is no CPU path for the record work: without a GPU the program fails at start-up.
+#include "fq_parallel.h"
 #include <errno.h>
 #include <getopt.h>
 #include <stdint.h>
@@ -79,50 +80,6 @@ bool read_all(FILE* f, std::vector<uint8_t>& raw) {
   size_t k;
   while ((k = fread(buf, 1, sizeof(buf), f)) > 0) raw.insert(raw.end(), buf, buf + k);
   return !ferror(f);
-}
-
-bool bgzf_inflate(const std::vector<uint8_t>& raw, std::vector<uint8_t>& out) {
-  size_t p = 0;
-  // first pass: sizes (ISIZE, the last four bytes of every member)
-  size_t total = 0;
-  std::vector<std::pair<size_t, size_t>> blocks;  // (offset, bsize + 1)
-  while (p + 18 <= raw.size()) {
-    if (raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) return false;
-    const size_t xlen = raw[p + 10] | (raw[p + 11] << 8);
-    size_t q = p + 12, bsize = 0;
-    bool found = false;
-    while (q + 4 <= p + 12 + xlen && q + 4 <= raw.size()) {
-      const size_t slen = raw[q + 2] | (raw[q + 3] << 8);
-      if (raw[q] == 66 && raw[q + 1] == 67 && slen == 2 && q + 6 <= raw.size()) {
-        bsize = (raw[q + 4] | (raw[q + 5] << 8)) + 1;
-        found = true;
-      }
-      q += 4 + slen;
-    }
-    if (!found || p + bsize > raw.size() || bsize < 12 + xlen + 8) return false;
-    const uint8_t* isz = &raw[p + bsize - 4];
-    total += (size_t)isz[0] | ((size_t)isz[1] << 8) | ((size_t)isz[2] << 16) | ((size_t)isz[3] << 24);
-    blocks.push_back({p, bsize});
-    p += bsize;
-  }
-  out.resize(total);
-  size_t o = 0;
-  for (auto& b : blocks) {
-    const size_t xlen = raw[b.first + 10] | (raw[b.first + 11] << 8);
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) return false;
-    zs.next_in = const_cast<Bytef*>(&raw[b.first + 12 + xlen]);
-    zs.avail_in = (uInt)(b.second - 12 - xlen - 8);
-    zs.next_out = out.data() + o;
-    zs.avail_out = (uInt)(total - o);
-    const int rc = inflate(&zs, Z_FINISH);
-    o += zs.total_out;
-    inflateEnd(&zs);
-    if (rc != Z_STREAM_END) return false;
-  }
-  out.resize(o);
-  return true;
 }
 
 void write_rows(const std::string& file, const std::vector<char>& names, uint64_t n) {  // write_map2fileL :271-290
@@ -245,7 +202,7 @@ int main(int argc, char* argv[]) {
     return 2;
   }
   std::vector<uint8_t> raw, stream;
-  if (!read_all(in, raw) || !bgzf_inflate(raw, stream)) {
+  if (!read_all(in, raw) || !fqhost::bgzf_inflate_parallel(raw, stream)) {
     PRINT_ERROR("%s is not a readable BGZF / BAM file", bam_file);
     return 2;
   }

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "fq_input.h"
+#include "fq_parallel.h"
 
 using namespace fqhost;
 
@@ -305,7 +306,8 @@ int main(int argc, char** argv) {
     FQ_PRINT_ERROR("--interleaved refers to an input that was not given");
     exit(kExitParams);
   }
-  gzFile outgz[3] = {nullptr, nullptr, nullptr};
+  GzipMembers outgz[3];  // gzip level 4 like the reference's "w4", one member per 4 MiB block, all cores
+  bool out_open[3] = {false, false, false};
   if (!out_sam) {
     for (int x = READ1; x <= READ2; ++x)
       if (outfile[x]) {
@@ -314,12 +316,12 @@ int main(int argc, char** argv) {
           exit(kExitParams);
         }
         P.emit[x] = 1;
-        outgz[x] = (outfile[x][0] == '-' && outfile[x][1] == 0) ? gzdopen(fileno(stdout), "wb") : gzopen(outfile[x], "w4");
-        if (!outgz[x]) {
+        // ("-": the reference's gzdopen(stdout, "wb") compresses at the default level; "w4" otherwise)
+        if (!outgz[x].open(outfile[x], (outfile[x][0] == '-' && outfile[x][1] == 0) ? Z_DEFAULT_COMPRESSION : 4)) {
           FQ_PRINT_ERROR("Unable to open %s", outfile[x]);
           exit(kExitParams);
         }
-        gzbuffer(outgz[x], 1 << 20);
+        out_open[x] = true;
       }
   } else {
     printf("@HD\tVN:1.0 SO:unknown\n");
@@ -395,15 +397,9 @@ int main(int argc, char** argv) {
         LIB(fqg_barcodes_output(g_ctx, which, hostbuf.data(), r.out_bytes[which]));
         if (which == 0) fwrite(hostbuf.data(), 1, r.out_bytes[0], stdout);
         else {
-          size_t off = 0;
-          while (off < r.out_bytes[which]) {
-            const unsigned chunk = (unsigned)std::min<uint64_t>(r.out_bytes[which] - off, 1u << 30);
-            if (gzwrite(outgz[which], hostbuf.data() + off, chunk) <= 0) {
-              int en = 0;
-              FQ_PRINT_ERROR("%s.\n", gzerror(outgz[which], &en));
-              exit(kExitSys);
-            }
-            off += chunk;
+          if (!outgz[which].write(hostbuf.data(), r.out_bytes[which])) {
+            FQ_PRINT_ERROR("%s.\n", "write error");
+            exit(kExitSys);
           }
         }
       }
@@ -464,7 +460,7 @@ int main(int argc, char** argv) {
   FQ_PRINT_INFO("Reads discarded: %ld", (long)discarded);
   if (!out_sam)
     for (int x = READ1; x <= READ2; ++x)
-      if (outgz[x] && gzclose(outgz[x]) != Z_OK) {
+      if (out_open[x] && !outgz[x].close()) {
         FQ_PRINT_ERROR("unable to close file descriptor");
         exit(kExitSys);
       }

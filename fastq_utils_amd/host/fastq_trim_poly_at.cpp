@@ -6,6 +6,7 @@
 #include <getopt.h>
 
 #include "fq_filter_run.h"
+#include "fq_parallel.h"
 
 using namespace fqhost;
 
@@ -79,12 +80,13 @@ int main(int argc, char** argv) {
       gzclose(probe);
     }
   }
-  gzFile out = (outfile[0] == '-' && outfile[1] == 0) ? gzdopen(fileno(stdout), "wb") : gzopen(outfile, "w4");
-  if (!out) {
+  // gzip level 4 like the reference's "w4" ("-": its gzdopen(stdout, "wb"), default level); one member per
+  // 4 MiB block, compressed on all cores (fq_parallel.h)
+  GzipMembers out;
+  if (!out.open(outfile, (outfile[0] == '-' && outfile[1] == 0) ? Z_DEFAULT_COMPRESSION : 4)) {
     FQ_PRINT_ERROR("Unable to open %s", outfile);
     exit(kExitParams);
   }
-  gzbuffer(out, 1 << 20);
 
   fqg_ctx* ctx = nullptr;
   const char* dev = getenv("FQGPU_DEVICE");
@@ -101,15 +103,9 @@ int main(int argc, char** argv) {
   const FilterTotals t = run_filter(
       ctx, file, fp,
       [&](const char* text, size_t n) {
-        size_t off = 0;
-        while (off < n) {
-          const unsigned chunk = (unsigned)std::min<size_t>(n - off, 1u << 30);
-          if (gzwrite(out, text + off, chunk) <= 0) {
-            int en = 0;
-            FQ_PRINT_ERROR("%s.\n", gzerror(out, &en));
-            exit(kExitSys);
-          }
-          off += chunk;
+        if (!out.write(text, n)) {
+          FQ_PRINT_ERROR("%s.\n", "write error");
+          exit(kExitSys);
         }
       },
       [](unsigned long before, unsigned long after) {
@@ -122,7 +118,7 @@ int main(int argc, char** argv) {
   FQ_PRINT_INFO("Reads processed: %ld", (long)t.processed);
   FQ_PRINT_INFO("Reads trimmed: %ld", (long)t.trimmed);
   FQ_PRINT_INFO("Reads discarded: %ld", (long)t.discarded);
-  if (gzclose(out) != Z_OK) {
+  if (!out.close()) {
     FQ_PRINT_ERROR("unable to close file descriptor");
     exit(kExitSys);
   }

@@ -1,0 +1,165 @@
+// fq_parallel.h - host-side (de)compression on all cores, the boundary work of SURVEY 8f-2.
+// The reference compresses its FASTQ output and inflates its BAM input on one thread, which is 7x the
+// cost of the transform itself (gzip level 4) and the whole cost of reading a BAM file.  Here:
+//   GzipMembers  the text is cut into blocks, every block becomes a complete gzip member on its own
+//                thread, members are written in order.  A multi-member file inflates to exactly the
+//                bytes a single-member file would (RFC 1952 2.2; zlib's gzread and gzip -d read through
+//                members), so what a consumer sees is unchanged.
+//   bgzf_inflate_parallel  BGZF blocks are independent deflate streams with their inflated size in the
+//                trailer: sizes first, then every block inflates to its own place.
+// FQGPU_HOST_THREADS sets the number of threads (default: the hardware's, at most 32).
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace fqhost {
+
+inline unsigned host_threads() {
+  const char* e = getenv("FQGPU_HOST_THREADS");
+  long v = e ? atol(e) : 0;
+  if (v < 1) v = (long)std::thread::hardware_concurrency();
+  if (v < 1) v = 1;
+  return (unsigned)std::min<long>(v, 32);
+}
+
+// fn(i) for i in [0, n) on up to host_threads() threads (dynamic: an atomic counter hands out items)
+template <class F>
+inline void parallel_items(size_t n, F fn) {
+  const unsigned nt = (unsigned)std::min<size_t>(host_threads(), n);
+  if (nt <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&] {
+      for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
+    });
+  for (auto& t : th) t.join();
+}
+
+// gzip output as a sequence of members
+class GzipMembers {
+ public:
+  // path "-": stdout (as the reference's gzdopen(fileno(stdout), "wb")).  false: cannot open.
+  bool open(const char* path, int level) {
+    level_ = level;
+    if (path[0] == '-' && path[1] == 0) f_ = stdout;
+    else {
+      f_ = fopen(path, "wb");
+      own_ = true;
+    }
+    return f_ != nullptr;
+  }
+  bool write(const char* text, size_t n) {
+    if (!n) return true;
+    const size_t block = 4u << 20;
+    const size_t nb = (n + block - 1) / block;
+    std::vector<std::vector<uint8_t>> out(nb);
+    std::atomic<bool> ok{true};
+    parallel_items(nb, [&](size_t i) {
+      const size_t from = i * block, len = std::min(block, n - from);
+      if (!member(text + from, len, out[i])) ok = false;
+    });
+    if (!ok) return false;
+    for (auto& m : out)
+      if (fwrite(m.data(), 1, m.size(), f_) != m.size()) return false;
+    wrote_ = true;
+    return true;
+  }
+  bool close() {
+    bool ok = true;
+    if (!f_) return true;
+    if (!wrote_) {  // an empty gzip stream is still a gzip stream
+      std::vector<uint8_t> m;
+      ok = member("", 0, m) && fwrite(m.data(), 1, m.size(), f_) == m.size();
+    }
+    if (own_) ok = fclose(f_) == 0 && ok;
+    else ok = fflush(f_) == 0 && ok;
+    f_ = nullptr;
+    return ok;
+  }
+
+ private:
+  bool member(const char* p, size_t n, std::vector<uint8_t>& out) const {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level_, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, (uLong)n) + 32);
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(p));
+    zs.avail_in = (uInt)n;
+    zs.next_out = out.data();
+    zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return rc == Z_STREAM_END;
+  }
+  FILE* f_ = nullptr;
+  bool own_ = false, wrote_ = false;
+  int level_ = 4;
+};
+
+// the whole file, BGZF members inflated back to back (SAM/BAM specification, section 4.1)
+inline bool bgzf_inflate_parallel(const std::vector<uint8_t>& raw, std::vector<uint8_t>& out) {
+  struct Block {
+    size_t at, size, xlen, out_at, isize;
+  };
+  std::vector<Block> blocks;
+  size_t p = 0, total = 0;
+  while (p + 18 <= raw.size()) {
+    if (raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) return false;
+    const size_t xlen = raw[p + 10] | (raw[p + 11] << 8);
+    size_t q = p + 12, bsize = 0;
+    bool found = false;
+    while (q + 4 <= p + 12 + xlen && q + 4 <= raw.size()) {
+      const size_t slen = raw[q + 2] | (raw[q + 3] << 8);
+      if (raw[q] == 66 && raw[q + 1] == 67 && slen == 2 && q + 6 <= raw.size()) {
+        bsize = (raw[q + 4] | (raw[q + 5] << 8)) + 1;
+        found = true;
+      }
+      q += 4 + slen;
+    }
+    if (!found || p + bsize > raw.size() || bsize < 12 + xlen + 8) return false;
+    const uint8_t* isz = &raw[p + bsize - 4];
+    const size_t isize = (size_t)isz[0] | ((size_t)isz[1] << 8) | ((size_t)isz[2] << 16) | ((size_t)isz[3] << 24);
+    blocks.push_back({p, bsize, xlen, total, isize});
+    total += isize;
+    p += bsize;
+  }
+  out.resize(total);
+  std::atomic<bool> ok{true};
+  // blocks are at most 64 KiB: hand them out in runs
+  const size_t run = 64, n_runs = (blocks.size() + run - 1) / run;
+  parallel_items(n_runs, [&](size_t r) {
+    for (size_t i = r * run; i < std::min(blocks.size(), (r + 1) * run); ++i) {
+      const Block& b = blocks[i];
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) {
+        ok = false;
+        return;
+      }
+      zs.next_in = const_cast<Bytef*>(&raw[b.at + 12 + b.xlen]);
+      zs.avail_in = (uInt)(b.size - 12 - b.xlen - 8);
+      zs.next_out = out.data() + b.out_at;
+      zs.avail_out = (uInt)b.isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      const bool good = rc == Z_STREAM_END && zs.total_out == b.isize;
+      inflateEnd(&zs);
+      if (!good) ok = false;
+    }
+  });
+  return ok;
+}
+
+}  // namespace fqhost
