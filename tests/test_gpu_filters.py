@@ -157,3 +157,39 @@ def test_stdin_stdout_and_truncated_input_like_the_oracle():
             assert rc == want["exit"] == 1
             assert out == want["stdout"]
             assert strip_progress(err) == want["stderr"].decode("latin-1")
+
+
+def odd_inputs():
+    rng = np.random.default_rng(31)
+    base = make_reads(rng, 400)
+    lines = base.split(b"\n")
+    out = {}
+    out["no_final_newline"] = base[:-1]
+    out["crlf"] = base.replace(b"\n", b"\r\n")
+    # empty sequence and quality lines, a one-base read, a read that is nothing but A, one of T, one of N
+    special = (b"@e1\n\n+\n\n" b"@one\nA\n+\nI\n" b"@allA\n" + b"A" * 60 + b"\n+\n" + b"I" * 60 + b"\n"
+               b"@allT\n" + b"T" * 33 + b"\n+\n" + b"5" * 33 + b"\n" b"@allN\n" + b"N" * 20 + b"\n+\n" + b"#" * 20 + b"\n"
+               b"@lower\nacgtnnnnaaaaaaaaaaaa\n+\nIIIIIIIIIIIIIIIIIIII\n" b"@tlow\nttttttttttttacgtacgtacgt\n+\nIIIIIIIIIIIIIIIIIIIIIIII\n")
+    out["special_records"] = special + base[:20000].rsplit(b"\n@R", 1)[0] + b"\n"
+    out["special_at_the_end_unterminated"] = base[:30000].rsplit(b"\n@R", 1)[0] + b"\n" + special[:-1]
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(REF_N), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", sorted(odd_inputs()))
+def test_odd_inputs_against_reference_binaries(name):
+    img = odd_inputs()[name]
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "in.fastq"), "wb") as f:
+            f.write(img)
+        for flags in ([], ["-n", "20"]):
+            a = run(REF_N, "fastq_filter_n", flags + ["in.fastq"], d)
+            b = run(BIN_N, "fastq_filter_n", flags + ["in.fastq"], d, {"FQGPU_BC_LDS": "8192"})
+            assert a[0] == b[0] and a[1] == b[1] and strip_progress(a[2]) == strip_progress(b[2]), (name, flags, b[2][-300:])
+        for flags in (["--min_poly_at_len", "3", "--min_len", "1"], ["--min_poly_at_len", "12"], ["--min_poly_at_len", "1", "--min_len", "0"]):
+            res = []
+            for binary, o in ((REF_T, "a.gz"), (BIN_T, "b.gz")):
+                rc, out, err = run(binary, "fastq_trim_poly_at", ["--file", "in.fastq", "--outfile", o] + flags, d)
+                raw = open(os.path.join(d, o), "rb").read() if os.path.exists(os.path.join(d, o)) else None
+                res.append((rc, out, strip_progress(err), gzip.decompress(raw) if raw else raw))
+            assert res[0] == res[1], (name, flags, res[1][2][-300:])

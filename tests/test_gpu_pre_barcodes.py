@@ -190,3 +190,27 @@ def test_golden_invocations_other_tile_sizes(case, lds):
         for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
             if tag in case["files"]:
                 assert gunzip_file(os.path.join(tmp, fn)) == case["files"][tag]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
+@pytest.mark.parametrize("variant", ["no_final_newline", "crlf", "empty_lines"])
+@pytest.mark.parametrize("extra", [["--sam", "--outfile1", "-"], ["--outfile1", "o.fastq.gz"]], ids=["sam", "fastq"])
+def test_odd_inputs_against_reference_binary(variant, extra):
+    rng = np.random.default_rng(17)
+    r1, r2 = make_10x(rng, 1500)
+    if variant == "no_final_newline":
+        r1, r2 = r1[:-1], r2[:-1]
+    elif variant == "crlf":
+        r1, r2 = r1.replace(b"\n", b"\r\n"), r2.replace(b"\n", b"\r\n")
+    else:  # a last pair with empty sequence and quality lines (the barcode cannot be cut: "read too short")
+        r1 += b"@SYN:1:FC:9:9:9:1500 1:N:0:ACGT\n\n+\n\n"
+        r2 += b"@SYN:1:FC:9:9:9:1500 2:N:0:ACGT\n\n+\n\n"
+    with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+        res = []
+        for d, binary, env in ((a, REF, None), (b, BIN, {"FQGPU_CHUNK_MB": "1", "FQGPU_BC_LDS": "8192"})):
+            for fn, img in (("r1.fastq", r1), ("r2.fastq", r2)):
+                with open(os.path.join(d, fn), "wb") as f:
+                    f.write(img)
+            rc, out, err = run(binary, V2 + extra, d, env)
+            res.append((rc, out, strip_progress(err), gunzip_file(os.path.join(d, "o.fastq.gz"))))
+        assert res[0] == res[1], (variant, res[1][2][-300:])
