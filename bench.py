@@ -504,11 +504,20 @@ def main():
             barrier()
             dt_dedup = time.perf_counter() - t1
             pd = ctx.profile_read()
+            # ... and the file-2 loop of a pair over all ranks: the same names once more as "file 2" (every name
+            # finds its mate on whatever rank holds it)
+            t2 = time.perf_counter()
+            pairing = fdist.global_pairing(ctx, [(frame, rv["n_records"])], st, rank * n, [(frame, rv["n_records"])], st,
+                                           rank * n, device=dev)
+            barrier()
+            dt_pair = time.perf_counter() - t2
             ctx.profile(False)
             frame.release()
-            tt = torch.tensor([dt_dedup], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt_dedup, dt_pair], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_pair = float(tt[1].item())
+            tt = tt[:1]
             dedup = {
                 "what": "unique read names over all ranks: fingerprint export + all-to-all (RCCL) + owner sets + candidate check",
                 "names_total": n * world, "finding": None if hit is None else [int(hit[0]), hit[1].decode("latin-1")],
@@ -516,6 +525,11 @@ def main():
                 "Mnames_per_s_whole_job": n * world / float(tt.item()) / 1e6,
                 "bytes_exchanged_per_rank": n * 16,
                 "kernels_ms_rank0": {k: v[1] for k, v in pd.items() if k.startswith("k_") and v[0] > 0},
+                "pairing": {"what": "file-2 loop over all ranks (both files' names exchanged, runs classified on the owners)",
+                            "matched": pairing["matched"], "leftover": pairing["leftover"], "unpaired": pairing["unpaired"],
+                            "ok": pairing["matched"] == n * world and pairing["first_unpaired"] is None,
+                            "wall_ms_max_over_ranks": dt_pair * 1e3,
+                            "Mpairs_per_s_whole_job": n * world / dt_pair / 1e6},
             }
             if own_group:
                 dist.destroy_process_group()

@@ -35,7 +35,7 @@ EXPORTS = [
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
     "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
-    "fqg_fpset_candidates", "fqg_frame_name",
+    "fqg_fpset_candidates", "fqg_fpset_pair_runs", "fqg_frame_name",
 ]
 
 
@@ -217,6 +217,7 @@ def load():
     L.fqg_fpset_destroy.restype = None
     L.fqg_fpset_insert.argtypes = [vp, vp, vp, u64]
     L.fqg_fpset_candidates.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
+    L.fqg_fpset_pair_runs.argtypes = [vp, vp, C.POINTER(PairSummary), C.POINTER(u64), u64]
     L.fqg_frame_name.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_char_p, u64]
     L.fqg_frame_name.restype = C.c_int64
     L.fqg_pack_barcode.argtypes = [C.c_char_p]
@@ -309,6 +310,14 @@ class Frame:
             self.h = None
 
 
+FP_FILE2 = 1 << 63  # FQG_FP_FILE2: the entry comes from the second file of a pair
+
+
+class PairSummary(C.Structure):
+    _fields_ = [("matched", C.c_uint64), ("leftover", C.c_uint64), ("unpaired", C.c_uint64),
+                ("first_unpaired", C.c_uint64), ("n_complex", C.c_uint64)]
+
+
 class FingerprintSet:
     """Owner-side collection of read-name fingerprints (fqg_fpset)."""
 
@@ -327,6 +336,17 @@ class FingerprintSet:
         self.ctx._check(load().fqg_fpset_candidates(self.ctx.h, self.h, pairs, cap, C.byref(found)))
         k = min(found.value, cap)
         return [(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(k)], int(found.value)
+
+    def pair_runs(self, cap=1 << 16):
+        """-> (summary dict, [(run id, index with FP_FILE2 for file 2)] of the runs that need the name bytes)"""
+        ent = (C.c_uint64 * (2 * cap))()
+        r = PairSummary()
+        self.ctx._check(load().fqg_fpset_pair_runs(self.ctx.h, self.h, C.byref(r), ent, cap))
+        k = min(r.n_complex, cap)
+        out = {f: int(getattr(r, f)) for f, _ in PairSummary._fields_}
+        if out["first_unpaired"] == (1 << 64) - 1:
+            out["first_unpaired"] = None
+        return out, [(int(ent[2 * i]), int(ent[2 * i + 1])) for i in range(k)]
 
     def close(self):
         if self.h:

@@ -473,6 +473,79 @@ __global__ __launch_bounds__(kBlock) void k_fp_runs(const unsigned long long* __
   }
 }
 
+// Pairing across GPUs (fastq_info's file-2 loop, reference src/fastq_info.c:333-356): the owner
+// receives the fingerprints of BOTH files, file-2 entries carrying kFpFile2 in their index.  After the sort
+// by fingerprint every run is one name (up to hash collisions).  Per run of h file-1 holders and a file-2
+// askers:   (1, 1)  a pair                        (h, 0)  h names nobody asked for (left over at the end)
+//           (0, a)  a askers without a holder: all unpaired; the serial loop stops at the smallest
+//           anything else (an asker met twice, or a collision): left to the exact resolution on the name
+//           bytes - its entries are exported as (run, index) pairs.
+constexpr unsigned long long kFpFile2 = 1ull << 63;
+struct FpPairSummary {
+  unsigned long long matched, leftover, unpaired, first_unpaired, n_complex;
+};
+__global__ __launch_bounds__(kBlock) void k_fp_pair_runs(const unsigned long long* __restrict__ fp,
+                                                         const unsigned long long* __restrict__ idx, uint64_t n,
+                                                         unsigned long long* __restrict__ entries, unsigned long long cap,
+                                                         FpPairSummary* __restrict__ sum) {
+  __shared__ unsigned long long s_acc[kBlock / kWave][4];
+  unsigned long long matched = 0, leftover = 0, unpaired = 0, first = ~0ull;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const unsigned long long f = fp[i];
+    if (i > 0 && fp[i - 1] == f) continue;  // not the start of a run
+    unsigned long long h = 0, a = 0, min_a = ~0ull;
+    uint64_t e = i;
+    for (; e < n && fp[e] == f; ++e) {
+      const unsigned long long v = idx[e];
+      if (v & kFpFile2) {
+        ++a;
+        min_a = (v & ~kFpFile2) < min_a ? (v & ~kFpFile2) : min_a;
+      } else ++h;
+    }
+    if (h == 1 && a == 1) ++matched;
+    else if (a == 0) leftover += h;
+    else if (h == 0) {
+      unpaired += a;
+      first = min_a < first ? min_a : first;
+    } else {
+      const unsigned long long at = atomicAdd(&sum->n_complex, (unsigned long long)(e - i));
+      for (uint64_t k = i; k < e; ++k)
+        if (at + (k - i) < cap) {
+          entries[2 * (at + (k - i))] = i;  // the run
+          entries[2 * (at + (k - i)) + 1] = idx[k];
+        }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    matched += __shfl_xor(matched, d, 64);
+    leftover += __shfl_xor(leftover, d, 64);
+    unpaired += __shfl_xor(unpaired, d, 64);
+    const unsigned long long o = __shfl_xor(first, d, 64);
+    first = o < first ? o : first;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_acc[threadIdx.x >> 6][0] = matched;
+    s_acc[threadIdx.x >> 6][1] = leftover;
+    s_acc[threadIdx.x >> 6][2] = unpaired;
+    s_acc[threadIdx.x >> 6][3] = first;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long m = 0, l = 0, u = 0, fst = ~0ull;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      m += s_acc[w][0];
+      l += s_acc[w][1];
+      u += s_acc[w][2];
+      fst = s_acc[w][3] < fst ? s_acc[w][3] : fst;
+    }
+    if (m) atomicAdd(&sum->matched, m);
+    if (l) atomicAdd(&sum->leftover, l);
+    if (u) atomicAdd(&sum->unpaired, u);
+    if (fst != ~0ull) atomicMin(&sum->first_unpaired, fst);
+  }
+}
+
 // split (fp, idx) records into key / value arrays for the sort
 __global__ __launch_bounds__(kBlock) void k_fp_split(const FpRec* __restrict__ in, uint64_t n,
                                                      unsigned long long* __restrict__ fp,

@@ -225,6 +225,143 @@ def global_first_duplicate(ctx, frames, state, record_base, group=None, device=N
     return None if hit is None else (hit, table[hit])
 
 
+# ---- pairing across ranks (the file-2 loop of fastq_info) --------------------------------------------
+FP_FILE2 = 1 << 63
+
+
+def resolve_pair_runs(entries, name_of):
+    """Exact outcome of the runs the device could not classify (fqg_fpset_pair_runs): entries =
+    [(run id, index)], file-2 indices carry FP_FILE2; name_of(index with flag) -> bytes.  Per NAME the serial
+    loop pairs the file-1 holder with the smallest file-2 asker; later askers of that name, and askers of a
+    name without holder, are unpaired; holders nobody asked for are left over.
+    Returns (matched, leftover, unpaired, smallest unpaired file-2 index or None)."""
+    runs = {}
+    for run, idx in entries:
+        runs.setdefault(run, []).append(idx)
+    matched = leftover = unpaired = 0
+    first = None
+    for idxs in runs.values():
+        by_name = {}
+        for g in idxs:
+            h, a = by_name.setdefault(name_of(g), ([], []))
+            (a if g & FP_FILE2 else h).append(g & ~FP_FILE2)
+        for holders, askers in by_name.values():
+            askers.sort()
+            if holders:  # names of file 1 are unique (its index pass has checked that): one holder
+                if askers:
+                    matched += 1
+                    bad = askers[1:]
+                    leftover += len(holders) - 1
+                else:
+                    bad = []
+                    leftover += len(holders)
+            else:
+                bad = askers
+            unpaired += len(bad)
+            if bad and (first is None or bad[0] < first):
+                first = bad[0]
+    return matched, leftover, unpaired, first
+
+
+def merge_pairing(parts):
+    """parts: per owner (matched, leftover, unpaired, first unpaired or None) -> the whole job's"""
+    firsts = [p[3] for p in parts if p[3] is not None]
+    return (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts), min(firsts) if firsts else None)
+
+
+def _export_fingerprints(ctx, frames, state, base, world, dev, torch):
+    """fingerprints of the frames [(frame, n)] bucketed by owner -> (uint8 tensor, counts per owner)"""
+    n_local = sum(n for _, n in frames)
+    send = torch.empty(max(1, n_local) * FP_BYTES, dtype=torch.uint8, device=dev)
+    per_frame, off = [], 0
+    for fr, n in frames:
+        counts = ctx.names_fingerprints(fr, state, base, world, send.data_ptr() + off * FP_BYTES)
+        per_frame.append((off, counts))
+        off += sum(counts)
+        base += n
+    parts = [[] for _ in range(world)]
+    for o0, counts in per_frame:
+        p = o0
+        for o, c in enumerate(counts):
+            parts[o].append(send[p * FP_BYTES:(p + c) * FP_BYTES])
+            p += c
+    return parts, [sum(c[o] for _, c in per_frame) for o in range(world)]
+
+
+def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=None, device=None):
+    """The file-2 loop of fastq_info over ranks that hold ARBITRARY shards of the two files:
+    frames1 / frames2 = this rank's retained frames [(frame, n_records)] of file 1 / file 2, whose records are
+    base1 / base2, +1, ... in their file.  Every name travels as a 16-byte (fingerprint, index) pair to the
+    owner of its fingerprint (one all-to-all over RCCL for both files together); owners sort and classify runs
+    of equal fingerprints on the device; what a fingerprint cannot decide is resolved on the name bytes.
+    Returns, identically on every rank: dict(matched, leftover, unpaired, first_unpaired = (file-2 record
+    index, its name) or None) - first_unpaired is where the serial loop prints "unpaired read", leftover what
+    it reports as "found N unpaired reads" when it gets to the end."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    p1, c1 = _export_fingerprints(ctx, frames1, state1, base1, world, dev, torch)
+    p2, c2 = _export_fingerprints(ctx, frames2, state2, base2 | FP_FILE2, world, dev, torch)
+    pieces = [t for o in range(world) for t in (p1[o] + p2[o])]
+    send = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=dev)
+    send_counts = [a + b for a, b in zip(c1, c2)]
+    recv, recv_counts = exchange_fingerprints(send, send_counts, group)
+    n_recv = sum(recv_counts)
+    fps = ctx.fingerprint_set(max(1024, n_recv))
+    try:
+        fps.insert(recv.data_ptr(), n_recv)
+        summary, entries = fps.pair_runs()
+    finally:
+        fps.close()
+    if summary["n_complex"] > len(entries):
+        raise RuntimeError(f"{summary['n_complex']} entries need their names: the inputs repeat names massively")
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (summary, entries), group=group)
+    flat = [e for _, ents in gathered for e in ents]
+    # every rank names the entries it holds; then everybody resolves identically
+    spans = []
+    for frames, state, base, flag in ((frames1, state1, base1, 0), (frames2, state2, base2, FP_FILE2)):
+        b = base
+        for fr, n in frames:
+            spans.append((b, n, fr, state, flag))
+            b += n
+
+    def local_name(g):
+        raw, flag = g & ~FP_FILE2, g & FP_FILE2
+        for b0, n, fr, state, fl in spans:
+            if fl == flag and b0 <= raw < b0 + n:
+                return ctx.frame_name(fr, state, raw - b0)
+        return None
+
+    mine = {}
+    for _, g in flat:
+        if g not in mine:
+            nm = local_name(g)
+            if nm is not None:
+                mine[g] = nm
+    names = [None] * world
+    dist.all_gather_object(names, mine, group=group)
+    table = {}
+    for d in names:
+        table.update(d)
+    parts = [(s["matched"], s["leftover"], s["unpaired"], s["first_unpaired"]) for s, _ in gathered]
+    # runs are owner-local: resolve owner by owner (run ids are only unique within one owner)
+    for _, ents in gathered:
+        if ents:
+            parts.append(resolve_pair_runs(ents, table.__getitem__))
+    matched, leftover, unpaired, first = merge_pairing(parts)
+    out = {"matched": matched, "leftover": leftover, "unpaired": unpaired, "first_unpaired": None}
+    if first is not None:
+        # its name: held by the rank that holds the record
+        nm = local_name(first | FP_FILE2)
+        got = [None] * world
+        dist.all_gather_object(got, nm, group=group)
+        out["first_unpaired"] = (first, next(x for x in got if x is not None))
+    return out
+
+
 # ---- bam_umi_count over shards ---------------------------------------------------------------------
 def merge_umi_shards(infos):
     """infos: per rank, in rank order, the dict umi_count(defer_output=True) returned (code, record,

@@ -232,6 +232,17 @@ int fqg_fpset_insert(fqg_ctx *ctx, fqg_fpset *set, const void *fps_device, uint6
 /* After every insert: pairs[2k], pairs[2k+1] (host) = (earliest holder, another holder) for every
  * fingerprint value held by more than one of the inserted records; *n_found may exceed cap. */
 int fqg_fpset_candidates(fqg_ctx *ctx, fqg_fpset *set, uint64_t *pairs, uint64_t cap, uint64_t *n_found);
+/* Pairing across GPUs (the file-2 loop of fastq_info, src/fastq_info.c:333-356): the set holds the
+ * fingerprints of file 1 AND of file 2, file-2 entries with FQG_FP_FILE2 set in their index.  Runs of
+ * equal fingerprints are classified on the device: a pair, names nobody asked for, askers without a
+ * holder (first_unpaired = the smallest index among them, without the flag).  Runs of any other shape
+ * (a name asked for twice, a hash collision) are exported as (run id, index) pairs for the exact
+ * resolution on the name bytes; n_complex counts their entries (it may exceed cap). */
+#define FQG_FP_FILE2 (1ull << 63)
+typedef struct {
+  uint64_t matched, leftover, unpaired, first_unpaired, n_complex;
+} fqg_pair_summary;
+int fqg_fpset_pair_runs(fqg_ctx *ctx, fqg_fpset *set, fqg_pair_summary *out, uint64_t *entries, uint64_t cap);
 /* canonical read name (fastq_get_readname, src/fastq.c:488-512) of record `record` of a retained frame,
  * NUL-terminated into out[cap]; returns its length or a negative FQG_ERR_* */
 int64_t fqg_frame_name(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t record, char *out,
