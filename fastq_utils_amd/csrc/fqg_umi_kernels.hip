@@ -72,6 +72,9 @@ struct UmiCall {
   unsigned long long n_tags, n_umis_disc, n_cells_disc;
   unsigned long long n_counted, n_new;     // records that reached process_entry / that brought a new UMI
   unsigned long long n_lines[2], tot[2];  // matrix lines / sum of truncated counts: [0] ucounts, [1] rcounts
+  // counters that every wavefront adds to: 64 copies each, picked by workgroup, summed on the host
+  // (a hundred thousand atomic adds to ONE address cost more than the kernels that issue them)
+  unsigned long long spread[3][64];  // [0] n_tags, [1] n_counted, [2] n_new
   unsigned int all_unit;         // 1 while every increment seen is exactly 1.0f
   unsigned int table_full;
   float db_reads, db_umi;
@@ -278,7 +281,9 @@ __global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict_
   rec[i] = out;
   stage[i] = st;
   const unsigned long long tags = __ballot(st >= kStNoUmi);
-  if ((threadIdx.x & 63) == 0 && tags) atomicAdd(&call->n_tags, (unsigned long long)__builtin_popcountll(tags));
+  if ((threadIdx.x & 63) == 0 && tags)
+    atomicAdd(&call->spread[0][(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) & 63],
+              (unsigned long long)__builtin_popcountll(tags));
 }
 
 // ---- hash tables --------------------------------------------------------------------------------
@@ -292,6 +297,35 @@ struct NameTable {         // feature names: slot = tag32 << 32 | claimant recor
   uint32_t* first;
   uint64_t mask;
 };
+
+// The two tables of the counting step are touched at random by every record: key and smallest record
+// index share one 16-byte slot there, so that an insert costs one cache line, not two.
+struct KeySlot {
+  unsigned long long key;
+  uint32_t first;
+  uint32_t pad;
+};
+struct SlotTable {
+  KeySlot* s;  // all bytes 0xFF: empty
+  uint64_t mask;
+};
+__device__ __forceinline__ uint32_t slot_insert(const SlotTable& T, unsigned long long key, uint32_t idx, UmiCall* call) {
+  uint64_t h = umi_mix(key) & T.mask;
+  for (uint64_t probes = 0; probes <= T.mask; ++probes) {
+    unsigned long long k = T.s[h].key;
+    if (k == kKeyEmpty) {
+      k = atomicCAS(&T.s[h].key, kKeyEmpty, key);
+      if (k == kKeyEmpty) k = key;
+    }
+    if (k == key) {
+      if (T.s[h].first > idx) atomicMin(&T.s[h].first, idx);  // look first: see table_insert
+      return (uint32_t)h;
+    }
+    h = (h + 1) & T.mask;
+  }
+  atomicOr(&call->table_full, 1u);
+  return kNoIdx;
+}
 
 __device__ __forceinline__ uint32_t table_insert(const KeyTable& T, unsigned long long key, uint32_t idx,
                                                  UmiCall* call) {
@@ -483,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_assign(uint32_t n, UmiParams P, 
 
 // ---- counting -------------------------------------------------------------------------------------
 struct PairTable {
-  KeyTable t;            // key = cell << 32 | feature
+  SlotTable t;           // key = cell << 32 | feature
   uint32_t* reads;       // records of the pair
   uint32_t* umis;        // records that brought a new UMI
 };
@@ -493,7 +527,7 @@ __device__ __forceinline__ unsigned long long pair_key(uint32_t cell, uint32_t f
 }
 
 // (cell, feature, UMI) set: key = slot of the (cell, feature) pair << 32 | umi id - exact and unbounded
-__global__ __launch_bounds__(kBlock) void k_umi_count(uint32_t n, uint32_t limit, UmiIds ids, KeyTable T,
+__global__ __launch_bounds__(kBlock) void k_umi_count(uint32_t n, uint32_t limit, UmiIds ids, SlotTable T,
                                                       PairTable Pt, uint32_t* __restrict__ pslot,
                                                       uint32_t* __restrict__ tslot, UmiCall* __restrict__ call) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -501,10 +535,10 @@ __global__ __launch_bounds__(kBlock) void k_umi_count(uint32_t n, uint32_t limit
   uint32_t ps = kNoIdx, ts = kNoIdx;
   const uint32_t fid = ids.feat[i];
   if (fid && i < limit) {
-    ps = table_insert(Pt.t, pair_key(ids.cell[i], fid), i, call);
+    ps = slot_insert(Pt.t, pair_key(ids.cell[i], fid), i, call);
     if (ps != kNoIdx) {
       atomicAdd(&Pt.reads[ps], 1u);
-      ts = table_insert(T, ((unsigned long long)ps << 32) | ids.umi[i], i, call);
+      ts = slot_insert(T, ((unsigned long long)ps << 32) | ids.umi[i], i, call);
     }
   }
   pslot[i] = ps;
@@ -513,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_count(uint32_t n, uint32_t limit
 
 // is_new[i]: record i is the first one of its (cell, feature, UMI); unit-increment counters
 __global__ __launch_bounds__(kBlock) void k_umi_new(uint32_t n, const uint32_t* __restrict__ tslot,
-                                                    const uint32_t* __restrict__ pslot, KeyTable T, PairTable Pt,
+                                                    const uint32_t* __restrict__ pslot, SlotTable T, PairTable Pt,
                                                     UmiIds ids, uint8_t* __restrict__ is_new,
                                                     uint32_t* __restrict__ cell_reads, uint32_t* __restrict__ cell_umis,
                                                     UmiCall* __restrict__ call) {
@@ -522,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_new(uint32_t n, const uint32_t* 
   const uint32_t ts = tslot[i];
   uint8_t nw = 0;
   if (ts != kNoIdx) {
-    nw = T.first[ts] == i;
+    nw = T.s[ts].first == i;
     const uint32_t cid = ids.cell[i];
     atomicAdd(&cell_reads[cid], 1u);
     if (nw) {
@@ -533,8 +567,9 @@ __global__ __launch_bounds__(kBlock) void k_umi_new(uint32_t n, const uint32_t* 
   is_new[i] = nw;
   const unsigned long long cnt = __ballot(ts != kNoIdx), nws = __ballot(nw != 0);
   if ((threadIdx.x & 63) == 0) {
-    if (cnt) atomicAdd(&call->n_counted, (unsigned long long)__builtin_popcountll(cnt));
-    if (nws) atomicAdd(&call->n_new, (unsigned long long)__builtin_popcountll(nws));
+    const uint32_t which = (blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) & 63;
+    if (cnt) atomicAdd(&call->spread[1][which], (unsigned long long)__builtin_popcountll(cnt));
+    if (nws) atomicAdd(&call->spread[2][which], (unsigned long long)__builtin_popcountll(nws));
   }
 }
 
@@ -609,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_pairs_count(uint64_t n_slots, Pa
                                                             uint32_t* __restrict__ cell_pairs) {
   const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (h >= n_slots) return;
-  const unsigned long long k = Pt.t.keys[h];
+  const unsigned long long k = Pt.t.s[h].key;
   if (k != kKeyEmpty) atomicAdd(&cell_pairs[(uint32_t)(k >> 32)], 1u);
 }
 __global__ __launch_bounds__(kBlock) void k_umi_pairs_fill(uint64_t n_slots, PairTable Pt, Prefix start,
@@ -617,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_pairs_fill(uint64_t n_slots, Pai
                                                            uint32_t* __restrict__ pair_of) {
   const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (h >= n_slots) return;
-  const unsigned long long k = Pt.t.keys[h];
+  const unsigned long long k = Pt.t.s[h].key;
   if (k == kKeyEmpty) return;
   const uint32_t c = (uint32_t)(k >> 32);
   pair_of[start.at(c) + atomicAdd(&cursor[c], 1u)] = (uint32_t)h;
@@ -666,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
   // sweeps over the feature id space, 131072 ids at a time (one sweep unless --max_feat is huge)
   uint32_t max_f = 0;
   auto feat_of = [&](uint32_t slot) {
-    const uint32_t f = (uint32_t)A.Pt.t.keys[slot];
+    const uint32_t f = (uint32_t)A.Pt.t.s[slot].key;
     return A.remap ? A.remap[f] : f;
   };
   for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
