@@ -409,6 +409,7 @@ __device__ __forceinline__ uint32_t fp_owner(unsigned long long fp, uint32_t n_o
 }
 
 // pass 0: count per owner; pass 1: write into the owner's bucket (cursor[] starts at the bucket offsets)
+constexpr int kFpPerThread = 8;  // records per thread: a workgroup reserves its bucket space once per 2048 records
 template <int PASS>
 __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int fmt, int is_pe, int may_have_nul,
                                                               uint64_t record_base, uint32_t n_owners,
@@ -416,35 +417,44 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
                                                               FpRec* __restrict__ out) {
   __shared__ unsigned int s_cnt[kMaxOwners];
   __shared__ unsigned long long s_base[kMaxOwners];
-  const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (threadIdx.x < kMaxOwners) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  bool have = false;
-  FpRec me{0, 0};
-  uint32_t owner = 0, slot = 0;
-  if (r < f.n_records) {
-    const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
-    const uint64_t e = f.line_end[4 * r];
-    uint32_t acct;
-    uint64_t h64;
-    bool at_sign;
-    (void)name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign);
-    if (at_sign) {  // (a wrong header is the local pass's finding, src/fastq.c:448)
-      unsigned long long h = h64;
-      if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
-      me.fp = h;
-      me.idx = record_base + r;
-      owner = fp_owner(h, n_owners);
-      slot = atomicAdd(&s_cnt[owner], 1u);
-      have = true;
+  FpRec me[kFpPerThread];
+  uint32_t owner[kFpPerThread], slot[kFpPerThread];
+  bool have[kFpPerThread];
+#pragma unroll
+  for (int j = 0; j < kFpPerThread; ++j) {
+    const uint64_t r = ((uint64_t)blockIdx.x * kFpPerThread + j) * kBlock + threadIdx.x;
+    have[j] = false;
+    owner[j] = slot[j] = 0;
+    me[j] = FpRec{0, 0};
+    if (r < f.n_records) {
+      const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+      const uint64_t e = f.line_end[4 * r];
+      uint32_t acct;
+      uint64_t h64;
+      bool at_sign;
+      (void)name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign);
+      if (at_sign) {  // (a wrong header is the local pass's finding, src/fastq.c:448)
+        unsigned long long h = h64;
+        if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
+        me[j].fp = h;
+        me[j].idx = record_base + r;
+        owner[j] = fp_owner(h, n_owners);
+        slot[j] = atomicAdd(&s_cnt[owner[j]], 1u);
+        have[j] = true;
+      }
     }
   }
   __syncthreads();
+  // one reservation per owner and workgroup (many more of them on one address would cost more than the hashing)
   if (threadIdx.x < n_owners && s_cnt[threadIdx.x])
     s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
   if (PASS == 0) return;
   __syncthreads();
-  if (have) out[s_base[owner] + slot] = me;
+#pragma unroll
+  for (int j = 0; j < kFpPerThread; ++j)
+    if (have[j]) out[s_base[owner[j]] + slot[j]] = me[j];
 }
 
 // Owner side: the received pairs are radix-sorted by fingerprint (rocPRIM, stable); equal
