@@ -369,11 +369,19 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # (test hook: FQGPU_BENCH_ONE_DEVICE=1 runs every rank on GPU 0 over gloo, to exercise the multi-rank control
+    # flow on a one-GPU box; RCCL itself refuses two ranks on one device)
+    one_device = os.environ.get("FQGPU_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx = fq.Context(local_rank)
     R = fq.abi.synth_record_bytes(a.read_len)

@@ -1,0 +1,33 @@
+"""bench.py's multi-rank control flow (barriers, max-over-ranks time, statistics merge, the cross-rank
+unique-name and pairing extra, the exit without a collective tear-down) on a ONE-GPU box: two ranks on
+GPU 0 over gloo (FQGPU_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on one device).  The numbers mean
+nothing here; the line must come out once, complete, with exit status 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_two_ranks_on_one_device(ranks):
+    env = dict(os.environ, FQGPU_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(29720 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+           "--reads", "2000000"]
+    p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode("latin-1")[-2000:]
+    lines = [ln for ln in p.stdout.decode("latin-1").splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["scaling"] == "weak" and d["value"] > 0
+    assert d["steps"] == 2 and d["warmup"] == 1
+    x = d["dedup_extra"]
+    assert "error" not in x, x
+    assert x["names_total"] == ranks * 2000000 and x["finding"] is None
+    assert x["pairing"]["ok"] and x["pairing"]["matched"] == ranks * 2000000
