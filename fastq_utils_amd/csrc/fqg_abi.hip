@@ -1155,7 +1155,8 @@ static BcTile bc_tile_for(const BcParams& P) {
   tc.in_cap = ((unsigned)(1.06 * in * T + 48.0 * files + 48.0) + 15u) & ~15u;
   if (tc.in_cap + 1024u > budget) tc.in_cap = (budget / 2) & ~15u;
   tc.out_cap = (budget - tc.in_cap) & ~15u;
-  tc.pad = 0;
+  // the plan kernel: several tiles at once while one lane per iteration and 32 KiB of LDS allow it
+  tc.plan_m = std::max(1u, std::min(std::min(64u / tc.T, 32768u / std::max(tc.in_cap, 1u)), 4u));
   return tc;
 }
 
@@ -1247,8 +1248,10 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
     ProfScope ps(c, "k_bc_plan");
 #define FQG_PLAN_TILE(MASK)                                                                                       \
   do {                                                                                                            \
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_bc_plan_tile<MASK>, tc.in_cap)); \
-    hipLaunchKernelGGL(k_bc_plan_tile<MASK>, dim3(grid), dim3(kWave), tc.in_cap, c->stream, P, tc, n_iter,         \
+    const unsigned plan_lds = tc.in_cap * tc.plan_m;                                                              \
+    const uint64_t plan_tiles = (n_tiles + tc.plan_m - 1) / tc.plan_m;                                            \
+    const unsigned grid = (unsigned)std::min<uint64_t>(plan_tiles, resident((const void*)k_bc_plan_tile<MASK>, plan_lds)); \
+    hipLaunchKernelGGL(k_bc_plan_tile<MASK>, dim3(grid), dim3(kWave), plan_lds, c->stream, P, tc, n_iter,          \
                        (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[0].p, (uint32_t*)c->bc_len[1].p,            \
                        (uint32_t*)c->bc_len[2].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);                         \
   } while (0)
@@ -1382,7 +1385,8 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   memset(&z, 0, sizeof(z));
   *c->h_bcall = z;
   HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
-  const BcTile tc = bc_tile_for(F);
+  BcTile tc = bc_tile_for(F);
+  tc.plan_m = 1;  // the decisions here are a few LDS reads per record: wavefronts in flight matter more than lanes per tile
   const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
   if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
   auto resident = [&](const void* kernel, unsigned lds) {
@@ -1394,8 +1398,10 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   unsigned long long* h_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_bcall) + sizeof(BcCall));
   {
     ProfScope ps(c, "k_rf_plan");
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_rf_plan_tile, tc.in_cap));
-    hipLaunchKernelGGL(k_rf_plan_tile, dim3(grid), dim3(kWave), tc.in_cap, c->stream, F, P, tc, n_rec,
+    const unsigned plan_lds = tc.in_cap * tc.plan_m;
+    const uint64_t plan_tiles = (n_tiles + tc.plan_m - 1) / tc.plan_m;
+    const unsigned grid = (unsigned)std::min<uint64_t>(plan_tiles, resident((const void*)k_rf_plan_tile, plan_lds));
+    hipLaunchKernelGGL(k_rf_plan_tile, dim3(grid), dim3(kWave), plan_lds, c->stream, F, P, tc, n_rec,
                        (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
   }
   {

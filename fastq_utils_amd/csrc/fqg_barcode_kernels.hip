@@ -28,7 +28,7 @@ struct BcTile {
   uint32_t T;        // iterations per tile (<= 64 / lines per iteration)
   uint32_t in_cap;   // LDS bytes for the staged records
   uint32_t out_cap;  // LDS bytes for the output text (emit only)
-  uint32_t pad;
+  uint32_t plan_m;   // the plan kernel works on plan_m tiles at once (one lane per iteration: T * plan_m <= 64)
 };
 
 struct BcFile {
@@ -475,6 +475,29 @@ __device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& 
   return true;
 }
 
+// Would the records of the iterations held by lanes first_lane .. last_lane fit the input area of ONE emit
+// tile?  The same unit count as bc_stage_tile makes for that tile (sam: the emit kernel's staging rule).
+template <int MASK>
+__device__ __forceinline__ bool bc_emit_tile_fits(const BcParams& P, const TileGeo& tg, int first_lane, int last_lane,
+                                                  bool sam, uint32_t in_cap) {
+  uint32_t units = 0;
+  bool fit = true;
+#pragma unroll
+  for (int x = 1; x < kBcFiles; ++x) {
+    if (!bc_has<MASK>(P, x)) continue;
+    if (sam && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) continue;
+    const BcFile& f = P.f[x];
+    const uint64_t s0 = rl64(tg.f[x].prev + 1, first_lane);
+    const uint64_t e3l = rl64(tg.f[x].e[3], last_lane);
+    const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - s0;
+    const uint32_t skew = (uint32_t)((uintptr_t)(f.fv.img + s0) & 15u);
+    if (n > (uint64_t)in_cap) fit = false;
+    else units += (skew + (uint32_t)n + 15u) >> 4;
+    if ((uint64_t)units * 16u + 32u > (uint64_t)in_cap) fit = false;
+  }
+  return fit;
+}
+
 template <int MASK = 0>
 __device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLine (&L)[kBcFiles][4]) {
 #pragma unroll
@@ -482,7 +505,10 @@ __device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLi
     if (bc_has<MASK>(P, x)) bc_lines(P.f[x], k, L[x]);
 }
 
-// One wavefront per tile, one lane per iteration.  MASK: see bc_has.
+// One wavefront per PLAN tile = plan_m consecutive tiles of the emit kernel, one lane per iteration: the plan
+// needs LDS only for the records, so more iterations fit, and its per-lane work (names, qualities) then runs on
+// three times as many lanes.  What it decides per emit tile - does the tile fit the emit kernel's LDS areas -
+// is worked out per group of T lanes.  MASK: see bc_has.
 template <int MASK>
 __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
                                                         uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
@@ -490,14 +516,15 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
                                                         BcCall* __restrict__ call) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
   const int lane = (int)threadIdx.x;
-  const uint64_t n_tiles = (n_iter + tc.T - 1) / tc.T;
+  const uint32_t Tp = tc.T * tc.plan_m, plan_cap = tc.in_cap * tc.plan_m;
+  const uint64_t n_tiles = (n_iter + Tp - 1) / Tp;
   auto tile_size = [&](uint64_t tile) {
-    const uint64_t left = n_iter - tile * tc.T;
-    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
+    const uint64_t left = n_iter - tile * Tp;
+    return (uint32_t)(left < (uint64_t)Tp ? left : (uint64_t)Tp);
   };
   auto geo_of = [&](uint64_t tile, TileGeo& tg) {
     const uint32_t Tn = tile_size(tile);
-    const uint64_t k = tile * tc.T + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1);
+    const uint64_t k = tile * Tp + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1);
 #pragma unroll
     for (int x = 1; x < kBcFiles; ++x)
       if (bc_has<MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
@@ -505,13 +532,13 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
   TileGeo cur, nxt;
   if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t k0 = tile * tc.T;
+    const uint64_t k0 = tile * Tp;
     const uint32_t Tn = tile_size(tile);
     const bool valid = (uint32_t)lane < Tn;
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
     BcLine L[kBcFiles][4];
     if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);  // the next tile's index: in flight during this tile
-    const bool fit = bc_stage_tile<false, MASK>(P, cur, (int)Tn - 1, lane, s_lds, tc.in_cap, L);
+    const bool fit = bc_stage_tile<false, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BcTags t;
@@ -540,11 +567,19 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
     const unsigned long long fnd = wave_min64(valid && st == kBcFinding ? (unsigned long long)((k << 8) | finding) : none);
     const unsigned long long dsc =
         wave_min64(valid && (st == kBcDiscardShort || st == kBcDiscardQual) ? (unsigned long long)k : none);
-    const uint32_t sa = wave_sum32(a), sb = wave_sum32(b), sc = wave_sum32(c);
+    // the emit tiles inside this plan tile
+    for (uint32_t j = 0; j * tc.T < Tn; ++j) {
+      const uint32_t first = j * tc.T, last = (first + tc.T < Tn ? first + tc.T : Tn) - 1;
+      const bool mine = (uint32_t)lane >= first && (uint32_t)lane <= last;
+      const uint32_t sa = wave_sum32(mine ? a : 0u), sb = wave_sum32(mine ? b : 0u), sc = wave_sum32(mine ? c : 0u);
+      const bool fits_in = bc_emit_tile_fits<MASK>(P, cur, (int)first, (int)last, P.out_sam != 0, tc.in_cap);
+      if (lane == 0) {
+        const bool big = !fits_in || sa + 32 > tc.out_cap || sb + 32 > tc.out_cap || sc + 32 > tc.out_cap;
+        tile_big[tile * tc.plan_m + j] = big ? 1 : 0;
+        if (big) atomicAdd(&call->big, 1ull);
+      }
+    }
     if (lane == 0) {
-      const bool big = !fit || sa + 32 > tc.out_cap || sb + 32 > tc.out_cap || sc + 32 > tc.out_cap;
-      tile_big[tile] = big ? 1 : 0;
-      if (big) atomicAdd(&call->big, 1ull);
       // tiles run roughly in order: look before the atomic, almost every later tile has nothing to add
       if (fnd != none && fnd < __atomic_load_n(&call->first_finding, __ATOMIC_RELAXED)) atomicMin(&call->first_finding, fnd);
       if (dsc != none && dsc < __atomic_load_n(&call->first_discard, __ATOMIC_RELAXED)) atomicMin(&call->first_discard, dsc);

@@ -122,31 +122,33 @@ __device__ __forceinline__ void rf_emit(const BcLine (&ln)[4], const RfCut& c, W
   if (c.q_nl) w.ch('\n');
 }
 
-// One wavefront per tile, one lane per record.  F holds the single input as file 1.
+// One wavefront per PLAN tile = plan_m tiles of the emit kernel (see k_bc_plan_tile), one lane per record.
+// F holds the single input as file 1.
 __global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
                                                         uint8_t* __restrict__ status, uint32_t* __restrict__ len1,
                                                         uint8_t* __restrict__ tile_big, BcCall* __restrict__ call) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
   const int lane = (int)threadIdx.x;
-  const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
+  const uint32_t Tp = tc.T * tc.plan_m, plan_cap = tc.in_cap * tc.plan_m;
+  const uint64_t n_tiles = (n_rec + Tp - 1) / Tp;
   auto tile_size = [&](uint64_t tile) {
-    const uint64_t left = n_rec - tile * tc.T;
-    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
+    const uint64_t left = n_rec - tile * Tp;
+    return (uint32_t)(left < (uint64_t)Tp ? left : (uint64_t)Tp);
   };
   auto geo_of = [&](uint64_t tile, TileGeo& tg) {
     const uint32_t Tn = tile_size(tile);
-    bc_geo_load(F.f[1], tile * tc.T + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1), tg.f[1]);
+    bc_geo_load(F.f[1], tile * Tp + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1), tg.f[1]);
   };
   TileGeo cur, nxt;
   if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t k0 = tile * tc.T;
+    const uint64_t k0 = tile * Tp;
     const uint32_t Tn = tile_size(tile);
     const bool valid = (uint32_t)lane < Tn;
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
     if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);
     BcLine L[kBcFiles][4];
-    const bool fit = bc_stage_tile<false, 0x02>(F, cur, (int)Tn - 1, lane, s_lds, tc.in_cap, L);
+    const bool fit = bc_stage_tile<false, 0x02>(F, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     RfCut c;
@@ -167,11 +169,15 @@ __global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, 
     } else {
       n = 0;
     }
-    const uint32_t sum = wave_sum32(n);
-    if (lane == 0) {
-      const bool big = !fit || sum + 32 > tc.out_cap;
-      tile_big[tile] = big ? 1 : 0;
-      if (big) atomicAdd(&call->big, 1ull);
+    for (uint32_t j = 0; j * tc.T < Tn; ++j) {  // the emit tiles inside this plan tile
+      const uint32_t first = j * tc.T, last = (first + tc.T < Tn ? first + tc.T : Tn) - 1;
+      const uint32_t sum = wave_sum32((uint32_t)lane >= first && (uint32_t)lane <= last ? n : 0u);
+      const bool fits_in = bc_emit_tile_fits<0x02>(F, cur, (int)first, (int)last, false, tc.in_cap);
+      if (lane == 0) {
+        const bool big = !fits_in || sum + 32 > tc.out_cap;
+        tile_big[tile * tc.plan_m + j] = big ? 1 : 0;
+        if (big) atomicAdd(&call->big, 1ull);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     cur = nxt;
