@@ -560,7 +560,7 @@ int frame_two_pass(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n
 }
 
 
-constexpr uint32_t kStreamBootBytes = 64u << 10;   // prefix whose quality range seeds the range test
+constexpr uint32_t kStreamBootBytes = kBootMax;   // prefix whose quality range seeds the range test (64 KiB: LDS of k_stream_boot)
 constexpr uint64_t kStreamQueueCap = 1ull << 20;
 
 // One pass over the image (see fqg_stream_kernels.hip).  Returns 1 when the image is not eligible

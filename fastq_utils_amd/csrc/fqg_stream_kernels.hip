@@ -68,12 +68,19 @@ __device__ __forceinline__ uint32_t in_range7(uint32_t w, uint32_t lob, uint32_t
 // quality range of the complete records inside the first `span` bytes (span: multiple of 256,
 // span <= image size).  One workgroup.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kBootMax = 64u << 10;  // span <= kBootMax (host: kStreamBootBytes)
 __global__ __launch_bounds__(kBlock) void k_stream_boot(const uint8_t* __restrict__ img, uint32_t span,
                                                         CallState* __restrict__ cs) {
   __shared__ uint32_t s_cnt[kBlock / kWave];
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[kBootMax];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const uint32_t part = span / (kBlock / kWave);
-  const uint8_t* p = img + (uint64_t)wv * part;
+  // the prefix goes to LDS first (all loads in flight at once): the two byte-wise walks below would
+  // otherwise pay a memory round trip per 64 bytes each
+  for (uint32_t o = threadIdx.x * 16u; o < span; o += kBlock * 16u)
+    *reinterpret_cast<uint4*>(s_img + o) = *reinterpret_cast<const uint4*>(img + o);
+  __syncthreads();
+  const uint8_t* p = s_img + (uint64_t)wv * part;
   uint32_t cnt = 0;
   for (uint32_t o = lane; o < part; o += kWave) cnt += (p[o] == '\n');
   cnt = wave_sum(cnt);
