@@ -63,7 +63,82 @@ def lib():
         _lib.fqo_result_free.argtypes = [C.POINTER(Result)]
         _lib.fqo_qual_range_to_enc.argtypes = [C.c_uint, C.c_uint]
         _lib.fqo_qual_range_to_enc.restype = C.c_char_p
+        # rl_oracle.c: the reference's RL_Tree as it behaves
+        _lib.orl_new.restype = C.c_void_p
+        _lib.orl_new.argtypes = [C.c_uint64]
+        _lib.orl_free.argtypes = [C.c_void_p]
+        _lib.orl_insert.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.orl_member.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.orl_member.restype = C.c_int
+        _lib.orl_all_out.argtypes = [C.c_void_p]
+        for f in ("orl_size", "orl_undefined_reads", "orl_wild_writes", "orl_overwrites"):
+            getattr(_lib, f).argtypes = [C.c_void_p]
+            getattr(_lib, f).restype = C.c_uint64
+        _lib.orl_node.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.orl_node.restype = C.c_uint16
+        _lib.orl_ever_written.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.orl_replay.argtypes = [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p]
     return _lib
+
+
+class RLTree:
+    """The reference's RL_Tree (src/range_list.c) as restated in oracle/rl_oracle.c."""
+
+    def __init__(self, max_size=1048576):
+        self.L = lib()
+        self.h = self.L.orl_new(max_size)
+
+    def insert(self, number):  # set_in_rl(tree, number, IN)
+        self.L.orl_insert(self.h, number)
+
+    def __contains__(self, number):  # in_rl
+        return bool(self.L.orl_member(self.h, number))
+
+    def all_out(self):  # rl_all(tree, OUT)
+        self.L.orl_all_out(self.h)
+
+    @property
+    def size(self):
+        return self.L.orl_size(self.h)
+
+    @property
+    def undefined_reads(self):
+        return self.L.orl_undefined_reads(self.h)
+
+    @property
+    def overwrites(self):
+        return self.L.orl_overwrites(self.h)
+
+    @property
+    def wild_writes(self):
+        return self.L.orl_wild_writes(self.h)
+
+    def node(self, idx):
+        return self.L.orl_node(self.h, idx)
+
+    def ever_written(self, idx):
+        return bool(self.L.orl_ever_written(self.h, idx))
+
+    def __del__(self):
+        try:
+            self.L.orl_free(self.h)
+        except Exception:
+            pass
+
+
+def rl_replay(tree_of, umi, epoch, incr, n_trees):
+    """is_new per record + (undefined reads, wild writes, overwrites): oracle/rl_oracle.c orl_replay."""
+    import numpy as np
+    tree_of = np.ascontiguousarray(tree_of, dtype=np.uint32)
+    umi = np.ascontiguousarray(umi, dtype=np.uint32)
+    epoch = np.ascontiguousarray(epoch, dtype=np.uint32)
+    incr = np.ascontiguousarray(incr, dtype=np.float32)
+    n = tree_of.size
+    is_new = np.zeros(n, dtype=np.uint8)
+    stats = np.zeros(3, dtype=np.uint64)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().orl_replay(n, P(tree_of), P(umi), P(epoch), P(incr), int(n_trees), P(is_new), P(stats))
+    return is_new, tuple(int(x) for x in stats)
 
 
 def parse_args(args):

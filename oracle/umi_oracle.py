@@ -10,11 +10,18 @@ sources).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 Pure-Python loops: meant for small inputs.  Each function names the reference lines it follows.
 Counters are float32 (numpy) exactly where the reference's are `float`.
+
+The UMI container of a (cell, gene) is the reference's RL_Tree AS IT BEHAVES (oracle/rl_oracle.c,
+restating src/range_list.c incl. its defects: members are lost or invented when ids arrive out of
+order); `undefined_reads` in the result counts reads of tree memory the reference never wrote, where
+its output depends on heap contents (the restatement reads 0 there).
 """
 import struct
 import zlib
 
 import numpy as np
+
+from oracle.loader import RLTree
 
 VERSION = "0.25.3"
 F32 = np.float32
@@ -197,7 +204,7 @@ class Feature:
     __slots__ = ("umi", "reads", "ht")
 
     def __init__(self):
-        self.umi, self.reads, self.ht = F32(0), F32(0), None  # ht: set of umi ids (RL_Tree), None = NULL
+        self.umi, self.reads, self.ht = F32(0), F32(0), None  # ht: RLTree, None = NULL
 
 
 class Cell:
@@ -292,9 +299,12 @@ def run_bam_umi_count(argv, reader, writable=lambda path: True):
     """argv without the program name.  reader(path) -> bytes or None (missing file).
     Returns {"exit", "stderr", "files": {path: bytes}}."""
     err, files = [], {}
+    trees = []
 
     def finish(status):
-        return {"exit": status, "stderr": "".join(err), "files": files}
+        return {"exit": status, "stderr": "".join(err), "files": files,
+                "undefined_reads": sum(t.undefined_reads for t in trees),
+                "overwrites": sum(t.overwrites for t in trees)}
 
     try:
         err.append("bam_umi_count version %sb\n" % VERSION)
@@ -414,7 +424,7 @@ def run_bam_umi_count(argv, reader, writable=lambda path: True):
             if c.features:
                 for fe in c.features.values():
                     if fe.umi > 0:
-                        fe.ht = set()
+                        fe.ht.all_out()
                         fe.umi = fe.reads = F32(0)
 
         def process_entry(feat_id, umi_id, cid, incr):  # :444-509
@@ -438,7 +448,9 @@ def run_bam_umi_count(argv, reader, writable=lambda path: True):
             if fe is None:
                 fe = c.features[feat_id] = Feature()
             if fe.ht is None:
-                fe.ht = {umi_id}
+                fe.ht = RLTree(UMIS_FEATURE)
+                trees.append(fe.ht)
+                fe.ht.insert(umi_id)
                 fe.umi = F32(fe.umi + incr)
                 fe.reads = F32(fe.reads + incr)
                 c.reads = F32(c.reads + incr)
@@ -447,7 +459,7 @@ def run_bam_umi_count(argv, reader, writable=lambda path: True):
                 db_umi = F32(db_umi + incr)
                 return
             if umi_id not in fe.ht:
-                fe.ht.add(umi_id)
+                fe.ht.insert(umi_id)
                 fe.umi = F32(fe.umi + incr)
                 c.umi = F32(c.umi + incr)
                 db_umi = F32(db_umi + incr)
