@@ -89,7 +89,7 @@ class UmiParams(C.Structure):
                 ("max_cells", C.c_uint32), ("max_features", C.c_uint32), ("min_reads", C.c_uint32),
                 ("min_umis", C.c_uint32), ("known_umis", C.POINTER(C.c_uint64)),
                 ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64),
-                ("defer_output", C.c_int32), ("reserved2", C.c_int32)]
+                ("defer_output", C.c_int32), ("strict_set", C.c_int32)]
 
 
 class UmiResult(C.Structure):
@@ -98,7 +98,8 @@ class UmiResult(C.Structure):
                 ("n_entries", C.c_uint64 * 2), ("total", C.c_uint64 * 2), ("tot_reads", C.c_float),
                 ("tot_umi", C.c_float), ("code", C.c_int32), ("reserved", C.c_int32), ("record", C.c_uint64),
                 ("aux", C.c_uint64), ("n_counted", C.c_uint64), ("n_new", C.c_uint64),
-                ("unit_increments", C.c_int32), ("reserved3", C.c_int32)]
+                ("unit_increments", C.c_int32), ("reserved3", C.c_int32), ("rl_replayed", C.c_uint64),
+                ("rl_changed", C.c_uint64), ("rl_undefined", C.c_uint64), ("rl_unresolved", C.c_uint64)]
 
 
 class UmiEntry(C.Structure):
@@ -530,7 +531,8 @@ class Context:
 
     def umi_count(self, stream, offsets=None, sorted_by_cell=True, uniq_mapped_only=False, feat_tag=b"GX",
                   cell_tag=b"CR", umi_tag=b"RX", max_cells=None, max_features=100000, min_reads=0, min_umis=0,
-                  known_umis=None, known_cells=None, nbytes=None, want_entries=True, defer_output=False):
+                  known_umis=None, known_cells=None, nbytes=None, want_entries=True, defer_output=False,
+                  strict_set=False):
         """bam_umi_count's alignment loop on an inflated BAM stream: bytes (host) or an int device pointer
         (then `nbytes` and `offsets` are required).  Returns the result fields plus, when the call
         succeeded, feature names / packed cells in id order and the (row, col, value) lines."""
@@ -557,6 +559,7 @@ class Context:
         p.max_cells = (1 if sorted_by_cell else 1000000) if max_cells is None else max_cells
         p.max_features, p.min_reads, p.min_umis = max_features, min_reads, min_umis
         p.defer_output = int(defer_output)
+        p.strict_set = int(strict_set)
         keep = []
         for name, vals in (("known_umis", known_umis), ("known_cells", known_cells)):
             if vals is not None:

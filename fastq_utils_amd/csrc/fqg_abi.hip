@@ -20,6 +20,7 @@
 #include "fqg_barcode_kernels.hip"
 #include "fqg_filter_kernels.hip"
 #include "fqg_umi_kernels.hip"
+#include "fqg_umi_rl_kernels.hip"
 
 using namespace fqg;
 

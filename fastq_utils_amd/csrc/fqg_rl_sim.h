@@ -1,0 +1,476 @@
+// fqg_rl_sim.h - the reference's UMI container as it BEHAVES (reference src/range_list.c, 0.25.3), for the
+// few (cell, gene) epochs in which it differs from a set.
+//
+// bam_umi_count keeps the UMI ids of a (cell, gene) in an RL_Tree: a 4-ary tree over [1..1048576]
+// (src/bam_umi_count.c:48,479) stored as ONE array of 16-bit nodes in pre-order (src/range_list.h:35-41,
+// 96-103).  An inner node = four 2-bit quadrant states (quadrant 1 in bits 0-1; 0 = empty, 2 = has a child
+// node, 3 = full) + an 8-bit count of the nodes of its subtree that saturates at 255; a leaf = a bitmap of
+// 16 numbers.  Nine levels: the root (depth 0), inner nodes at depths 1..7 (widths 4^9 .. 4^3 = 64) and
+// leaves at depth 8.  In sorted mode the tree of a gene lives for the whole file: rl_all(OUT) between two
+// cells (quick_reset_db, src/bam_umi_count.c:418-441 -> src/range_list.c:187-198) resets the root's
+// quadrants and size = 1 and leaves every other array slot as it is.
+//
+// Where it is not a set (all restated exactly below, as in oracle/rl_oracle.c, which is the checker):
+//   * new_node (src/range_list.c:325-372) opens a gap with shift_right (:287-301), which moves NOTHING when
+//     exactly one node lies at / behind the insertion point: the new node overwrites the array's last
+//     node, the array still grows by one, and its new last slot keeps what the memory held - the node
+//     some EARLIER cell left there.  From then on membership answers depend on stale bytes.
+//   * the count refresh of a saturated node is computed one level short (:485).
+//
+// While no overwrite has happened in an epoch (one gene in one cell), the array is exactly the pre-order
+// trie of the set of members, whatever the array held before.  So:
+//   detect  (rl_detect_step)  the first overwrite of an epoch is a function of the arrival order of its
+//           members alone: a new member x opens a leaf directly in front of the array's last node iff
+//           it falls into the 64-block of the largest member so far, into a leaf of that block that is
+//           still empty, and exactly one occupied leaf of that block lies above it.
+//   replay  (Sim)  only flagged epochs are replayed on the array, node for node.  What the array held
+//           before the epoch (slots the epoch reads before writing them) comes from
+//   history (History)  the final arrays of the gene's earlier epochs, newest first: slot k holds what the
+//           most recent epoch with more than k nodes left there.  A clean epoch's final array is the
+//           pre-order trie of its sorted members and is built on demand, slot by slot (trie_node); a
+//           replayed epoch's final array was stored when it was replayed.
+// Slots no epoch ever wrote are heap bytes in the reference: they read as 0 here and are counted
+// (`undefined`): the reference's own output is then not a function of its input.
+//
+// Execution model: one wavefront per chain (gene, or (cell, gene) in unsorted mode).  The tree walk is
+// scalar work that every lane executes identically on LDS-resident arrays; shifts, sorts, scans and trie
+// construction are lane-parallel.  The template parameter W supplies lane id / lane count / barrier, so
+// that tests/cxx/rl_sim_check.cpp can run the very same code on the CPU (1 lane) against the oracle.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FQG_HD __host__ __device__ __forceinline__
+#else
+#define FQG_HD inline
+#endif
+
+namespace fqg {
+namespace rl {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kMaxUmi = 1048576u;  // UMIS_FEATURE, src/bam_umi_count.c:48
+enum : uint32_t { kQOut = 0, kQPart = 2, kQAll = 3 };
+
+// ---- detection -----------------------------------------------------------------------------------
+// state: bits 0..3 occupied leaves of the 64-block of the largest member so far, bits 4.. that block + 1
+// (0 = no member yet).  Feed the NEW members of an epoch in arrival order; returns true at the first
+// insert that overwrites the array's last node.
+FQG_HD bool rl_detect_step(uint32_t& state, uint32_t umi_id) {
+  const uint32_t v = umi_id - 1u, blk = (v >> 6) + 1u, leaf = (v >> 4) & 3u;
+  const uint32_t cur = state >> 4;
+  if (blk > cur) {
+    state = (blk << 4) | (1u << leaf);
+    return false;
+  }
+  if (blk < cur) return false;
+  const uint32_t occ = state & 15u;
+  if (occ & (1u << leaf)) return false;
+  const uint32_t above = occ >> (leaf + 1u);
+  if (above && !(above & (above - 1u))) return true;  // exactly one occupied leaf above: it is the last node
+  state |= 1u << leaf;
+  return false;
+}
+
+// ---- the pre-order trie of a sorted set ------------------------------------------------------------
+// v[0..t): sorted distinct (umi id - 1), 20 bits = 8 two-bit digits (depths 0..7) + 4 leaf bits.
+// shared_digits(a, b): leading digits two members have in common (8 = same leaf)
+FQG_HD uint32_t shared_digits(uint32_t a, uint32_t b) {
+  const uint32_t x = (a ^ b) >> 4;  // 16 bits
+  if (!x) return 8;
+  uint32_t hi = 15;
+  while (!((x >> hi) & 1u)) --hi;   // highest differing bit
+  return (15u - hi) >> 1;
+}
+FQG_HD uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+// base[i] = array index of the first node member i brings (1 + nodes of earlier members), base[t] = size.
+// Node at array index p (1 <= p < base[t]):
+FQG_HD uint16_t trie_node(const uint32_t* v, const uint32_t* base, uint32_t t, uint32_t p) {
+  // the member that brings node p: the largest i with base[i] <= p
+  uint32_t lo = 0, hi = t;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (base[mid] <= p) lo = mid;
+    else hi = mid;
+  }
+  const uint32_t i = lo;
+  const uint32_t sh = i ? shared_digits(v[i - 1], v[i]) : 0u;
+  const uint32_t d = sh + 1u + (p - base[i]);  // depth 1..8
+  if (d >= 8) {
+    uint32_t bits = 0;
+    for (uint32_t j = i; j < t && (v[j] >> 4) == (v[i] >> 4); ++j) bits |= 1u << (v[j] & 15u);
+    return (uint16_t)bits;
+  }
+  const uint32_t sft = 20u - 2u * d;  // bits below the node's d digits
+  const uint32_t prefix = v[i] >> sft;
+  const uint32_t end = lower_bound_u32(v, t, (prefix + 1u) << sft);  // one past the last member below this node
+  uint32_t quads = 0;
+  for (uint32_t q = 0; q < 4; ++q) {
+    const uint32_t key = ((prefix << 2) | q) << (sft - 2u);
+    const uint32_t at = lower_bound_u32(v, t, key);
+    if (at < t && (v[at] >> (sft - 2u)) == ((prefix << 2) | q)) quads |= kQPart << (2u * q);
+  }
+  uint32_t cnt = (9u - d) + (base[end] - base[i + 1]);
+  if (cnt > 254u) cnt = 255u;
+  return (uint16_t)(quads | (cnt << 8));
+}
+
+// ---- what a chain kernel reads ----------------------------------------------------------------------
+struct ChainView {
+  const uint32_t* chain_runs;   // run ids of this chain in cell order
+  uint32_t n_runs;              // runs of this chain
+  const uint32_t* run_start;    // per run: first position in order[]
+  const uint32_t* run_len;
+  const uint32_t* order;        // record indices grouped by run, record order inside a run
+  const uint32_t* umi_id;       // per record
+  const uint8_t* set_new;       // per record: first record of its (cell, gene, UMI) - exact for clean epochs
+  const uint32_t* run_flag;     // per run: index into the flagged list, or kNone
+  const uint32_t* flag_off;     // per flagged run: where its final array is stored in `arena`
+  uint32_t* flag_ext;           // per flagged run: nodes stored (written when it has been replayed)
+  uint16_t* arena;
+};
+
+struct Stats {
+  uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
+};
+
+// LDS (or, on the CPU, heap) arrays of one chain worker
+struct Work {
+  uint16_t* node;     // [cap] the array being replayed
+  uint32_t* known;    // [cap / 32] bit: node[] holds the slot's current content
+  uint16_t* stale;    // [cap] history: stale[1..S) materialised
+  uint32_t* mem;      // [mcap] sorted members of the epoch being looked at
+  uint32_t* base;     // [mcap + 1]
+  uint32_t* scratch;  // [lanes + 1] for the scan
+  uint32_t cap, mcap;
+};
+
+template <class W>
+struct History {
+  const ChainView* cv;
+  Work* wk;
+  Stats* st;
+  uint32_t pos;   // runs [0, pos) of the chain have not been looked at yet
+  uint32_t S;     // stale[1..S) valid
+  bool count;     // count undefined reads (off while a final array is being stored)
+
+  FQG_HD void reset(const ChainView* c, Work* w, Stats* s, uint32_t cur) {
+    cv = c; wk = w; st = s; pos = cur; S = 1; count = true;
+  }
+
+  // bitonic sort of mem[0..P), P a power of two
+  FQG_HD void sort_members(uint32_t P) {
+    uint32_t* m = wk->mem;
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = W::lane(); i < P; i += W::lanes) {
+          const uint32_t l = i ^ j;
+          if (l > i) {
+            const uint32_t a = m[i], b = m[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { m[i] = b; m[l] = a; }
+          }
+        }
+        W::sync();
+      }
+  }
+
+  // members of a clean run -> mem[] sorted, base[]; returns the node count of its trie (its final size)
+  FQG_HD uint32_t load_run(uint32_t run, uint32_t* t_out) {
+    const uint32_t s0 = cv->run_start[run], len = cv->run_len[run];
+    // compact the new members (uniform scalar loop per 64 records: every lane counts the same)
+    uint32_t t = 0;
+    for (uint32_t k0 = 0; k0 < len; k0 += W::lanes) {
+      const uint32_t k = k0 + W::lane();
+      uint32_t rec = 0; bool isn = false;
+      if (k < len) { rec = cv->order[s0 + k]; isn = cv->set_new[rec] != 0; }
+      const uint32_t before = W::rank(isn);   // new members in lower lanes
+      const uint32_t total = W::count(isn);
+      if (isn && t + before < wk->mcap) wk->mem[t + before] = cv->umi_id[rec] - 1u;
+      t += total;
+    }
+    if (t > wk->mcap) { st->overflow = 1; t = wk->mcap; }
+    uint32_t P = 1;
+    while (P < t) P <<= 1;
+    W::sync();
+    for (uint32_t i = t + W::lane(); i < P; i += W::lanes) wk->mem[i] = kNone;
+    W::sync();
+    if (P > 1) sort_members(P);
+    // new nodes per member -> exclusive prefix (+1): every lane sums a contiguous piece
+    const uint32_t per = (t + W::lanes - 1) / W::lanes;
+    const uint32_t a = W::lane() * per, b = a + per < t ? a + per : t;
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; ++i) sum += i ? 8u - shared_digits(wk->mem[i - 1], wk->mem[i]) : 8u;
+    wk->scratch[W::lane()] = sum;
+    W::sync();
+    uint32_t off = 1;
+    for (uint32_t l = 0; l < W::lane(); ++l) off += wk->scratch[l];
+    for (uint32_t i = a; i < b; ++i) {
+      wk->base[i] = off;
+      off += i ? 8u - shared_digits(wk->mem[i - 1], wk->mem[i]) : 8u;
+    }
+    W::sync();
+    uint32_t size = 1;
+    for (uint32_t l = 0; l < (uint32_t)W::lanes; ++l) size += wk->scratch[l];
+    if (W::lane() == 0) wk->base[t] = size;
+    W::sync();
+    *t_out = t;
+    return size;
+  }
+
+  // one more run of the past: extends stale[] if that run left more nodes than anything newer
+  FQG_HD void extend() {
+    const uint32_t run = cv->chain_runs[--pos];
+    st->lookback_runs++;
+    const uint32_t fi = cv->run_flag[run];
+    if (fi != kNone) {  // replayed earlier by this worker: its array was stored
+      uint32_t ext = W::load_shared(&cv->flag_ext[fi]);  // (written by this worker: read past its own L1)
+      if (ext > wk->cap) ext = wk->cap;
+      if (ext > S) {
+        const uint16_t* src = cv->arena + cv->flag_off[fi];
+        for (uint32_t p = S + W::lane(); p < ext; p += W::lanes) wk->stale[p] = src[p];
+        W::sync();
+        S = ext;
+      }
+      return;
+    }
+    if (1u + 8u * cv->run_len[run] <= S) return;  // cannot have more than S nodes
+    uint32_t t;
+    uint32_t size = load_run(run, &t);
+    if (size > wk->cap) size = wk->cap;  // only slots the replayed array can have are ever asked for
+    if (size > S) {
+      for (uint32_t p = S + W::lane(); p < size; p += W::lanes) wk->stale[p] = trie_node(wk->mem, wk->base, t, p);
+      W::sync();
+      S = size;
+    }
+  }
+
+  FQG_HD uint16_t get(uint32_t k) {
+    while (S <= k && pos > 0) extend();
+    if (k < S) return wk->stale[k];
+    if (count) st->undefined++;
+    return 0;
+  }
+};
+
+template <class W>
+struct Sim {
+  Work* wk;
+  History<W>* hist;
+  Stats* st;
+  uint32_t size, unknown_live;
+
+  FQG_HD bool known(uint32_t idx) const { return (wk->known[idx >> 5] >> (idx & 31u)) & 1u; }
+  FQG_HD void mark(uint32_t idx) { wk->known[idx >> 5] |= 1u << (idx & 31u); }
+
+  FQG_HD void begin() {
+    for (uint32_t i = W::lane(); i < wk->cap / 32u; i += W::lanes) wk->known[i] = 0;
+    W::sync();
+    wk->node[0] = 1u << 8;  // rl_all(OUT): quadrants empty (the root's count is never looked at by anyone else)
+    mark(0);
+    size = 1;
+    unknown_live = 0;
+  }
+  FQG_HD uint16_t rd(uint32_t idx) {
+    if (idx >= wk->cap) { st->overflow = 1; return 0; }
+    if (!known(idx)) {
+      wk->node[idx] = hist->get(idx);
+      mark(idx);
+      if (idx < size) --unknown_live;
+    }
+    return wk->node[idx];
+  }
+  FQG_HD void wr(uint32_t idx, uint16_t v) {
+    if (idx >= wk->cap) { st->overflow = 1; return; }
+    if (!known(idx)) {
+      mark(idx);
+      if (idx < size) --unknown_live;
+    }
+    wk->node[idx] = v;
+  }
+  FQG_HD uint32_t quad(uint32_t idx, uint32_t q) { return (rd(idx) >> (2u * (q - 1u))) & 3u; }
+  FQG_HD uint32_t count(uint32_t idx) { return rd(idx) >> 8; }
+
+  // tree_size (src/range_list.c:566-593) of the node at idx taken as a node of depth d
+  FQG_HD uint32_t subtree_nodes(uint32_t idx, uint32_t d) {
+    if (d >= 8) return 1;
+    const uint32_t c0 = count(idx);
+    if (c0 != 255u) return c0;
+    uint32_t s_idx[9], s_c[9], s_q[9];
+    int sp = 0;
+    s_idx[0] = idx; s_c[0] = 1; s_q[0] = 1;
+    for (;;) {
+      if (s_q[sp] > 4) {
+        const uint32_t r = s_c[sp];
+        if (!sp) return r;
+        --sp;
+        s_c[sp] += r;
+        ++s_q[sp];
+        continue;
+      }
+      if (quad(s_idx[sp], s_q[sp]) == kQPart) {
+        const uint32_t child = s_idx[sp] + s_c[sp], cd = d + (uint32_t)sp + 1u;
+        uint32_t cc = 1;
+        if (cd < 8 && (cc = count(child)) == 255u && sp < 8) {
+          ++sp;
+          s_idx[sp] = child; s_c[sp] = 1; s_q[sp] = 1;
+          continue;
+        }
+        s_c[sp] += cc;
+      }
+      ++s_q[sp];
+    }
+  }
+  // get_location (src/range_list.c:375-408): node at depth d, quadrant q (1..4)
+  FQG_HD uint32_t child_offset(uint32_t idx, uint32_t q, uint32_t d) {
+    if (q == 1) return 1;
+    uint32_t c = 1;
+    if (d == 7) {
+      for (uint32_t i = 1; i < q; ++i) c += quad(idx, i) == kQPart;
+      return c;
+    }
+    uint32_t at = idx + 1;
+    for (uint32_t i = 1; i < q; ++i)
+      if (quad(idx, i) == kQPart) {
+        const uint32_t s = subtree_nodes(at, d + 1);
+        at += s;
+        c += s;
+      }
+    return c;
+  }
+  // slots [lo, hi] must hold their content before lanes move them
+  FQG_HD void ensure_known(uint32_t lo, uint32_t hi) {
+    for (uint32_t i = lo; i <= hi && unknown_live; ++i)
+      if (!known(i)) (void)rd(i);
+  }
+  // new_node(.., IN) (src/range_list.c:325-372)
+  FQG_HD uint32_t open_node(uint32_t father, uint32_t q, uint32_t d) {
+    const uint32_t at = father + child_offset(father, q, d);
+    const long behind = (long)size - 1 - (long)at;
+    if (behind > 0) {
+      if (at + (uint32_t)behind + 1u >= wk->cap) { st->overflow = 1; }
+      else {
+        if (unknown_live) ensure_known(at, at + (uint32_t)behind);
+        // move node[at .. at + behind] one slot up, top chunk first
+        uint32_t hi = at + (uint32_t)behind;  // = size - 1
+        for (;;) {
+          const uint32_t n = hi - at + 1u < (uint32_t)W::lanes ? hi - at + 1u : (uint32_t)W::lanes;
+          const uint32_t lo = hi + 1u - n;
+          uint16_t v = 0;
+          const uint32_t mine = lo + W::lane();
+          if (W::lane() < n) v = wk->node[mine];
+          W::sync();
+          if (W::lane() < n) wk->node[mine + 1u] = v;
+          W::sync();
+          if (lo == at) break;
+          hi = lo - 1u;
+        }
+        if (!known(size)) mark(size);  // (size is not live yet: no unknown_live bookkeeping)
+      }
+    } else if (behind == 0) {
+      st->overwrites++;
+    } else if (at > size) {
+      st->wild_writes++;
+    }
+    // set_quadrant(father, q, PART)
+    wr(father, (uint16_t)((rd(father) & ~(3u << (2u * (q - 1u)))) | (kQPart << (2u * (q - 1u)))));
+    wr(at, d + 1u >= 8u ? (uint16_t)0 : (uint16_t)(1u << 8));
+    ++size;
+    if (size - 1u < wk->cap && !known(size - 1u)) ++unknown_live;
+    return at;
+  }
+  // in_rl (src/range_list.c:203-207 -> in_tree :664-690)
+  FQG_HD bool member(uint32_t umi_id) {
+    const uint32_t v = umi_id - 1u;
+    uint32_t idx = 0;
+    for (uint32_t d = 0; d < 8; ++d) {
+      const uint32_t q = ((v >> (18u - 2u * d)) & 3u) + 1u;
+      const uint32_t s = quad(idx, q);
+      if (s == kQAll) return true;
+      if (s != kQPart) return false;
+      idx += child_offset(idx, q, d);
+    }
+    return (rd(idx) >> (v & 15u)) & 1u;
+  }
+  // set_in_rl(.., IN) (src/range_list.c:169-183 -> set_in :417-496)
+  FQG_HD void insert(uint32_t umi_id) {
+    const uint32_t v = umi_id - 1u;
+    uint32_t path[8], before[8];
+    uint32_t idx = 0, d = 0;
+    bool reached_leaf = true;
+    for (; d < 8; ++d) {
+      path[d] = idx;
+      before[d] = size;
+      const uint32_t q = ((v >> (18u - 2u * d)) & 3u) + 1u;
+      const uint32_t s = quad(idx, q);
+      if (s == kQOut) idx = open_node(idx, q, d);
+      else if (s == kQAll) { reached_leaf = false; break; }  // returns 0 at this level: no count refresh here
+      else idx += child_offset(idx, q, d);
+    }
+    if (reached_leaf) wr(idx, (uint16_t)(rd(idx) | (1u << (v & 15u))));
+    for (int k = (int)d - 1; k >= 0; --k) {
+      const uint32_t node = path[k];
+      const uint32_t added = size - before[k];
+      const uint32_t c0 = count(node);
+      uint32_t c = c0 == 255u ? subtree_nodes(node, (uint32_t)k + 1u) : added + c0;  // (:485: the child's width)
+      if (c > 254u) c = 255u;
+      wr(node, (uint16_t)((rd(node) & 0xFFu) | (c << 8)));
+    }
+  }
+};
+
+// Replays every flagged run of one chain in order.  new_out[rec] (may alias cv.set_new's storage through a
+// non-const pointer the caller passes) receives the reference's decision for every record of a flagged run;
+// on_change(record, is_new, run) is called (lane 0) for every record whose decision differs from set semantics.
+template <class W, class OnChange>
+FQG_HD void replay_chain(const ChainView& cv, Work& wk, Stats& st, uint8_t* new_out, OnChange on_change) {
+  History<W> hist;
+  Sim<W> sim;
+  sim.wk = &wk;
+  sim.hist = &hist;
+  sim.st = &st;
+  for (uint32_t j = 0; j < cv.n_runs; ++j) {
+    const uint32_t run = cv.chain_runs[j];
+    const uint32_t fi = cv.run_flag[run];
+    if (fi == kNone) continue;
+    hist.reset(&cv, &wk, &st, j);
+    sim.begin();
+    const uint32_t s0 = cv.run_start[run], len = cv.run_len[run];
+    for (uint32_t k = 0; k < len; ++k) {
+      const uint32_t rec = cv.order[s0 + k];
+      const uint32_t u = cv.umi_id[rec];
+      const bool in = sim.member(u);
+      if (!in) sim.insert(u);
+      const uint8_t nw = in ? 0 : 1;
+      if (nw != cv.set_new[rec]) {
+        st.changed++;
+        if (W::lane() == 0) {
+          new_out[rec] = nw;
+          on_change(rec, nw, run);
+        }
+      }
+    }
+    // keep the final array for the later epochs of this chain
+    uint32_t ext = sim.size < wk.cap ? sim.size : wk.cap;
+    hist.count = false;
+    sim.ensure_known(0, ext - 1u);
+    hist.count = true;
+    uint16_t* dst = cv.arena + cv.flag_off[fi];
+    W::sync();
+    for (uint32_t p = W::lane(); p < ext; p += W::lanes) dst[p] = wk.node[p];
+    if (W::lane() == 0) cv.flag_ext[fi] = ext;
+    W::fence();
+    W::sync();
+  }
+}
+
+}  // namespace rl
+}  // namespace fqg

@@ -1,0 +1,207 @@
+// fqg_umi_rl_kernels.hip - bam_umi_count's distinct-UMI decision where the reference's RL_Tree is not a set
+// (reference src/range_list.c; the algorithm and its derivation are in fqg_rl_sim.h).
+//
+// The counting kernels (fqg_umi_kernels.hip) decide "new UMI" with set semantics.  That is what the reference
+// computes for every (cell, gene) epoch in which its tree never overwrites its last node - on
+// BASELINE.json configs[3] all but 63 of 766 569.  This stage finds the others and replays them:
+//
+//   k_rl_starts / k_rl_detect   records sorted by (pair slot, record index) [rocPRIM]; one thread per run
+//                    feeds the run's new UMIs, in arrival order, through rl_detect_step (4 bits of state)
+//   k_rl_chain_keys / k_rl_heads   sorted mode: the runs of one gene in cell order form a chain (the gene's
+//                    tree lives for the whole file); chains that hold a flagged run are listed
+//   k_rl_replay      one wavefront per listed chain: exact replay of its flagged runs on the node array
+//                    (LDS), earlier cells' arrays rebuilt on demand; patches is_new[] and the counters
+#include "fqg_rl_sim.h"
+
+namespace fqg {
+
+struct GpuWave {
+  static constexpr int lanes = kWave;
+  static __device__ __forceinline__ uint32_t lane() { return threadIdx.x; }
+  static __device__ __forceinline__ void sync() { __syncthreads(); }
+  static __device__ __forceinline__ uint32_t rank(bool b) {
+    const unsigned long long m = __ballot(b);
+    return (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
+  }
+  static __device__ __forceinline__ uint32_t count(bool b) { return (uint32_t)__popcll(__ballot(b)); }
+  static __device__ __forceinline__ uint32_t load_shared(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  static __device__ __forceinline__ void fence() { __threadfence(); }
+};
+
+struct RlCall {
+  uint32_t n_flagged, n_chains, max_len, max_flagged_len;
+  uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
+};
+
+struct RlRuns {      // per run (= per (cell, feature) pair), in order of the sorted pair slots
+  uint32_t* start;   // first position in the sorted order
+  uint32_t* len;
+  uint32_t* pslot;
+  uint32_t* flag;    // index into the flagged list, or kNone (host fills with 0xFF)
+};
+
+__global__ __launch_bounds__(kBlock) void k_rl_starts(uint32_t n, const uint32_t* __restrict__ key,
+                                                      uint32_t* __restrict__ flag) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t k = key[j];
+  flag[j] = (k != kNoIdx && (j == 0 || key[j - 1] != k)) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rl_detect(uint32_t n, const uint32_t* __restrict__ key,
+                                                      const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ start_flag, Prefix run_of,
+                                                      const uint32_t* __restrict__ umi_id,
+                                                      const uint8_t* __restrict__ is_new, RlRuns runs,
+                                                      uint32_t* __restrict__ flagged, RlCall* __restrict__ call) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n || !start_flag[j]) return;
+  const uint32_t r = run_of.at(j), k = key[j];
+  uint32_t state = 0, len = 0;
+  bool hit = false;
+  for (uint32_t p = j; p < n && key[p] == k; ++p, ++len) {
+    const uint32_t rec = order[p];
+    if (!hit && is_new[rec]) hit = rl::rl_detect_step(state, umi_id[rec]);
+  }
+  runs.start[r] = j;
+  runs.len[r] = len;
+  runs.pslot[r] = k;
+  if (len > call->max_len) atomicMax(&call->max_len, len);
+  if (hit) {
+    const uint32_t fi = atomicAdd(&call->n_flagged, 1u);
+    flagged[fi] = r;
+    runs.flag[r] = fi;
+    atomicMax(&call->max_flagged_len, len);
+  }
+}
+
+// sorted mode: chain = feature; key = feature << 32 | cell puts a feature's runs in cell order
+__global__ __launch_bounds__(kBlock) void k_rl_chain_keys(uint32_t n_runs, const uint32_t* __restrict__ run_pslot,
+                                                          PairTable Pt, unsigned long long* __restrict__ key,
+                                                          uint32_t* __restrict__ val) {
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n_runs) return;
+  const unsigned long long k = Pt.t.s[run_pslot[r]].key;  // cell << 32 | feature
+  key[r] = (k << 32) | (k >> 32);
+  val[r] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_rl_positions(uint32_t n_runs, const uint32_t* __restrict__ chain_runs,
+                                                         uint32_t* __restrict__ pos_of_run) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p < n_runs) pos_of_run[chain_runs[p]] = p;
+}
+// one thread per flagged run: is it the first flagged run of its chain?  then list the chain
+__global__ __launch_bounds__(kBlock) void k_rl_heads(uint32_t n_flagged, uint32_t n_runs,
+                                                     const uint32_t* __restrict__ flagged,
+                                                     const uint32_t* __restrict__ pos_of_run,
+                                                     const unsigned long long* __restrict__ key,
+                                                     const uint32_t* __restrict__ chain_runs,
+                                                     const uint32_t* __restrict__ run_flag,
+                                                     uint32_t* __restrict__ chain_begin, uint32_t* __restrict__ chain_len,
+                                                     RlCall* __restrict__ call) {
+  const uint32_t fi = blockIdx.x * kBlock + threadIdx.x;
+  if (fi >= n_flagged) return;
+  const uint32_t p = pos_of_run[flagged[fi]];
+  const uint32_t feat = (uint32_t)(key[p] >> 32);
+  uint32_t q = p;
+  while (q > 0 && (uint32_t)(key[q - 1] >> 32) == feat) {
+    --q;
+    if (run_flag[chain_runs[q]] != rl::kNone) return;  // an earlier flagged run heads this chain
+  }
+  uint32_t e = p + 1;
+  while (e < n_runs && (uint32_t)(key[e] >> 32) == feat) ++e;
+  const uint32_t c = atomicAdd(&call->n_chains, 1u);
+  chain_begin[c] = q;
+  chain_len[c] = e - q;
+}
+
+struct RlReplayArgs {
+  const uint32_t* chain_runs;    // sorted mode: run ids by (feature, cell); unsorted mode: the flagged list
+  const uint32_t* chain_begin;   // per listed chain (null in unsorted mode: chain c = entry c, length 1)
+  const uint32_t* chain_len;
+  uint32_t n_chains;
+  RlRuns runs;
+  const uint32_t* order;
+  const uint32_t* umi_id;
+  const uint32_t* cell_id;
+  uint8_t* is_new;
+  const uint32_t* flag_off;
+  uint32_t* flag_ext;
+  uint16_t* arena;
+  uint32_t cap, mcap;            // nodes of the replayed array / members of a looked-up run
+  int in_lds;                    // the worker's arrays fit the LDS budget
+  uint8_t* scratch;              // else: per workgroup node | stale | known | mem | base
+  uint64_t scratch_stride;
+  // counters to patch
+  uint32_t* pair_umis;
+  uint32_t* cell_umis;
+  unsigned long long* n_new_spread;  // 64 copies
+  RlCall* call;
+};
+
+__global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  __shared__ uint32_t s_scan[kWave + 1];
+  // the worker's arrays: LDS when they fit (the usual case), else this workgroup's slice of a global scratch
+  uint8_t* g = A.in_lds ? s_dyn : A.scratch + (uint64_t)blockIdx.x * A.scratch_stride;
+  auto carve = [&](uint64_t bytes) {
+    uint8_t* p = g;
+    g += (bytes + 15) & ~15ull;
+    return p;
+  };
+  rl::Work wk;
+  wk.cap = A.cap;
+  wk.mcap = A.mcap;
+  wk.node = reinterpret_cast<uint16_t*>(carve((uint64_t)A.cap * 2));
+  wk.stale = reinterpret_cast<uint16_t*>(carve((uint64_t)A.cap * 2));
+  wk.known = reinterpret_cast<uint32_t*>(carve((uint64_t)A.cap / 8 + 4));
+  wk.mem = reinterpret_cast<uint32_t*>(carve((uint64_t)A.mcap * 4));
+  wk.base = reinterpret_cast<uint32_t*>(carve((uint64_t)(A.mcap + 1) * 4));
+  wk.scratch = s_scan;
+  rl::Stats st{};
+  for (uint32_t c = blockIdx.x; c < A.n_chains; c += gridDim.x) {
+    rl::ChainView cv;
+    cv.chain_runs = A.chain_runs + (A.chain_begin ? A.chain_begin[c] : c);
+    cv.n_runs = A.chain_len ? A.chain_len[c] : 1u;
+    cv.run_start = A.runs.start;
+    cv.run_len = A.runs.len;
+    cv.order = A.order;
+    cv.umi_id = A.umi_id;
+    cv.set_new = A.is_new;
+    cv.run_flag = A.runs.flag;
+    cv.flag_off = A.flag_off;
+    cv.flag_ext = A.flag_ext;
+    cv.arena = A.arena;
+    rl::replay_chain<GpuWave>(cv, wk, st, A.is_new, [&](uint32_t rec, uint8_t nw, uint32_t run) {
+      const uint32_t d = nw ? 1u : 0xFFFFFFFFu;  // +1 / -1
+      atomicAdd(&A.pair_umis[A.runs.pslot[run]], d);
+      atomicAdd(&A.cell_umis[A.cell_id[rec]], d);
+      atomicAdd(&A.n_new_spread[blockIdx.x & 63], nw ? 1ull : ~0ull);
+    });
+  }
+  if (threadIdx.x == 0) {
+    if (st.undefined) atomicAdd(&A.call->undefined, st.undefined);
+    if (st.overwrites) atomicAdd(&A.call->overwrites, st.overwrites);
+    if (st.wild_writes) atomicAdd(&A.call->wild_writes, st.wild_writes);
+    if (st.overflow) atomicOr(&A.call->overflow, 1u);
+    if (st.changed) atomicAdd(&A.call->changed, st.changed);
+    if (st.lookback_runs) atomicAdd(&A.call->lookback_runs, st.lookback_runs);
+  }
+}
+
+// bytes of a worker's arrays (the carve-up of k_rl_replay)
+static inline uint64_t rl_work_bytes(uint32_t cap, uint32_t mcap) {
+  auto r = [](uint64_t b) { return (b + 15) & ~15ull; };
+  return 2 * r((uint64_t)cap * 2) + r((uint64_t)cap / 8 + 4) + r((uint64_t)mcap * 4) + r((uint64_t)(mcap + 1) * 4);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rl_flag_lens(uint32_t n_flagged, const uint32_t* __restrict__ flagged,
+                                                         const uint32_t* __restrict__ run_len,
+                                                         uint32_t* __restrict__ out) {
+  const uint32_t fi = blockIdx.x * kBlock + threadIdx.x;
+  if (fi < n_flagged) out[fi] = run_len[flagged[fi]];
+}
+
+}  // namespace fqg

@@ -261,7 +261,12 @@ int main(int argc, char* argv[]) {
     prm.n_known_cells = kcells.size();
   }
   fqg_umi_result res;
+  prm.strict_set = getenv("FQGPU_UMI_STRICT_SET") ? 1 : 0;  // an extra: UMI sets as src/range_list.h documents them
   LIB(fqg_umi_count(g_ctx, stream.data(), stream.size(), FQG_MEM_HOST, offsets.data(), n_rec, &prm, &res));
+  if (res.rl_unresolved) {  // never silently different from the reference
+    fprintf(stderr, "\nERROR: bam_umi_count: a UMI set could not be replayed within this build's limits\n");
+    return 2;
+  }
 
   const uint64_t alns_seen = res.code ? res.record + 1 : res.n_alignments;
   if (!bam_sorted_by_cell)

@@ -311,7 +311,8 @@ int fqg_records_filter_output(fqg_ctx *ctx, void *host_dst, uint64_t nbytes);
  * char2uint_64 :364-382, the label maps :143-260, process_entry :444-509) and the output decisions
  * of cell2MM (:666-705) / write2MM (:584-663).  Input: the inflated BAM stream of a file (the host
  * inflates BGZF; libbam does that inside bam_read1) and the offset of every alignment record in
- * it (fqg_bam_index_records).  The UMIs of a (cell, feature) form a set (src/range_list.h:150-162);
+ * it (fqg_bam_index_records).  The UMIs of a (cell, feature) are kept as the reference's RL_Tree keeps them
+ * (src/range_list.c: a set except where its array insert overwrites a node, see fqg_umi_params.strict_set);
  * counters are float32 and are added in record order, as the reference's `float` fields are. */
 typedef struct {
   char feat_tag[2], cell_tag[2], umi_tag[2];      /* -x / -X / RX or UB (--10x) */
@@ -322,7 +323,9 @@ typedef struct {
   uint64_t n_known_umis, n_known_cells;
   int32_t defer_output;   /* 1: count only; the lines are made by fqg_umi_emit (shards of one file: the output
                              rules need the GLOBAL feature ids, known only after every shard has counted) */
-  int32_t reserved2;
+  int32_t strict_set;     /* 0 (default): the UMIs of a (cell, feature) are kept as the reference's RL_Tree keeps them
+                             (src/range_list.c), which loses / invents members in rare arrival orders - bit-exact with
+                             the reference program; 1: the set src/range_list.h:150-162 documents (an extra) */
 } fqg_umi_params;
 
 typedef struct {
@@ -337,6 +340,11 @@ typedef struct {
   uint64_t n_counted, n_new; /* alignments that reached process_entry / that brought a new UMI */
   int32_t unit_increments;   /* 1: every increment was 1.0 (then tot_reads = min(n_counted, 2^24) as a float) */
   int32_t reserved3;
+  /* RL_Tree replay (strict_set = 0): (cell, feature) sets replayed node for node because the reference's tree
+   * overwrites a node there (src/range_list.c:287-301,338-339); alignments whose "new UMI" decision differs from a
+   * set's; reads of tree memory the reference never wrote (its output then depends on its heap: 0 is read here);
+   * 1 if a replay did not fit this library's limits (results then follow set semantics for that set) */
+  uint64_t rl_replayed, rl_changed, rl_undefined, rl_unresolved;
 } fqg_umi_result;
 
 typedef struct {

@@ -77,6 +77,8 @@ def lib():
         _lib.orl_node.argtypes = [C.c_void_p, C.c_uint64]
         _lib.orl_node.restype = C.c_uint16
         _lib.orl_ever_written.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.orl_first_difference.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orl_first_difference.restype = C.c_long
         _lib.orl_replay.argtypes = [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -115,6 +117,10 @@ class RLTree:
 
     def node(self, idx):
         return self.L.orl_node(self.h, idx)
+
+    def first_difference(self, other_nodes):
+        """first live slot (written at some time) that differs from another implementation's uint16 array, or -1"""
+        return self.L.orl_first_difference(self.h, other_nodes)
 
     def ever_written(self, idx):
         return bool(self.L.orl_ever_written(self.h, idx))

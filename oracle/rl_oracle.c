@@ -282,3 +282,9 @@ int orl_replay(uint64_t n, const uint32_t *tree_of, const uint32_t *umi, const u
     return 0;
 }
 int orl_ever_written(orl_tree *t, uint64_t idx) { return idx < t->cap ? t->ever[idx] : 0; }
+/* first live slot that the reference has written and that differs from other[] (another implementation's array), or -1 */
+long orl_first_difference(orl_tree *t, const uint16_t *other) {
+    for (uint64_t i = 0; i < t->size && i < t->cap; i++)
+        if (t->ever[i] && t->node[i] != other[i]) return (long)i;
+    return -1;
+}

@@ -223,3 +223,34 @@ def expected_matrix(cell, gene, umi):
     tot = np.bincount(c, weights=umis, minlength=n_cells + 1)
     keep = (g - 1) < tot[c]
     return c[keep], g[keep], umis[keep], reads[keep], n_cells, n_genes
+
+
+def expected_matrix_reference(cell, gene, umi):
+    """The same answer as the REFERENCE gives it (sorted mode, unit increments): "new UMI" decided by its
+    RL_Tree as it behaves (oracle/rl_oracle.c through oracle.loader.rl_replay), counters and cell2MM's
+    rules (src/bam_umi_count.c:444-509, 666-705, 418-441) in numpy.  Returns (lines_u, lines_r, total_u,
+    total_r, n_cells, n_genes, stats) with lines as (gene id, cell id, value) in file order."""
+    from oracle import loader
+
+    def first_ids(x):
+        u, first, inv = np.unique(x, return_index=True, return_inverse=True)
+        rank = np.empty(u.size, dtype=np.int64)
+        rank[np.argsort(first, kind="stable")] = np.arange(1, u.size + 1)
+        return rank[inv], u.size
+    cid, n_cells = first_ids(cell)
+    gid, n_genes = first_ids(gene)
+    uid, _ = first_ids(umi)
+    n = cid.size
+    is_new, stats = loader.rl_replay(gid, uid, cid, np.ones(n, dtype=np.float32), n_genes + 1)
+    pair = cid.astype(np.int64) * (n_genes + 1) + gid
+    up, inv, reads = np.unique(pair, return_inverse=True, return_counts=True)
+    umis = np.bincount(inv, weights=is_new, minlength=up.size).astype(np.int64)
+    c, g = up // (n_genes + 1), up % (n_genes + 1)
+    # a feature whose UMI total of a cell is 0 is not reset (quick_reset_db :428-434): its reads would carry over
+    # into the next cell.  Every epoch starts on an emptied tree, so its first record is always new.
+    assert (umis >= 1).all()
+    tot = np.bincount(c, weights=umis, minlength=n_cells + 1)
+    keep = (g - 1) < tot[c]
+    lu = list(zip(g[keep].tolist(), c[keep].tolist(), umis[keep].tolist()))
+    lr = list(zip(g[keep].tolist(), c[keep].tolist(), reads[keep].tolist()))
+    return lu, lr, int(umis[keep].sum()), int(reads[keep].sum()), n_cells, n_genes, stats

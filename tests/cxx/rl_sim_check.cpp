@@ -1,0 +1,99 @@
+// TEST DRIVER (CPU): runs fastq_utils_amd/csrc/fqg_rl_sim.h - the code the GPU chain kernel executes - with a
+// one-lane "wavefront" so that tests/test_rl_sim.py can compare it with the oracle (oracle/rl_oracle.c) here,
+// without a GPU.  Not part of the product: libfqgpu.so only instantiates the 64-lane device policy.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "../../fastq_utils_amd/csrc/fqg_rl_sim.h"
+
+namespace {
+struct CpuWave {
+  static constexpr int lanes = 1;
+  static uint32_t lane() { return 0; }
+  static void sync() {}
+  static uint32_t rank(bool) { return 0; }
+  static uint32_t count(bool b) { return b ? 1u : 0u; }
+  static uint32_t load_shared(const uint32_t* p) { return *p; }
+  static void fence() {}
+};
+}  // namespace
+
+// chain[i]: tree the record touches (gene id in sorted mode, a (cell, gene) number in unsorted mode);
+// epoch[i]: the cell (records of one cell are contiguous in sorted mode).  Epochs of a chain in file order.
+// out_new[i]: the decision for record i; stats[0..5] = undefined, overwrites, wild writes, overflow, changed,
+// flagged runs.  cap / mcap: array sizes of the worker (to exercise the overflow paths).
+extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* epoch, const uint32_t* umi,
+                            uint32_t cap, uint32_t mcap, uint8_t* out_new, uint64_t* stats) {
+  using namespace fqg::rl;
+  // runs = (chain, epoch) groups in order of first appearance; order[] = records grouped by run
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t> run_of;
+  std::vector<std::vector<uint32_t>> recs;
+  std::vector<std::pair<uint32_t, uint32_t>> key;
+  for (uint32_t i = 0; i < n; ++i) {
+    auto k = std::make_pair(chain[i], epoch[i]);
+    auto it = run_of.find(k);
+    if (it == run_of.end()) {
+      it = run_of.emplace(k, (uint32_t)recs.size()).first;
+      recs.emplace_back();
+      key.push_back(k);
+    }
+    recs[it->second].push_back(i);
+  }
+  const uint32_t n_runs = (uint32_t)recs.size();
+  std::vector<uint32_t> order, run_start(n_runs), run_len(n_runs), run_flag(n_runs, kNone);
+  std::vector<uint8_t> set_new(n, 0);
+  std::vector<uint32_t> flagged;
+  for (uint32_t r = 0; r < n_runs; ++r) {
+    run_start[r] = (uint32_t)order.size();
+    run_len[r] = (uint32_t)recs[r].size();
+    std::set<uint32_t> seen;
+    uint32_t state = 0;
+    bool hit = false;
+    for (uint32_t i : recs[r]) {
+      order.push_back(i);
+      if (seen.insert(umi[i]).second) {
+        set_new[i] = 1;
+        if (!hit && rl_detect_step(state, umi[i])) hit = true;
+      }
+    }
+    if (hit) {
+      run_flag[r] = (uint32_t)flagged.size();
+      flagged.push_back(r);
+    }
+  }
+  memcpy(out_new, set_new.data(), n);
+  // chains: runs of a chain in order of appearance (= cell order for sorted input)
+  std::map<uint32_t, std::vector<uint32_t>> chains;
+  for (uint32_t r = 0; r < n_runs; ++r) chains[key[r].first].push_back(r);
+  std::vector<uint32_t> flag_off(flagged.size()), flag_ext(flagged.size(), 0);
+  uint64_t arena_n = 0;
+  for (size_t f = 0; f < flagged.size(); ++f) {
+    flag_off[f] = (uint32_t)arena_n;
+    arena_n += cap;
+  }
+  std::vector<uint16_t> arena(arena_n + 1);
+  std::vector<uint16_t> node(cap), stale(cap);
+  std::vector<uint32_t> known(cap / 32 + 1), mem(mcap + 1), base(mcap + 2), scratch(4);
+  Work wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap};
+  Stats st{};
+  for (auto& kv : chains) {
+    bool any = false;
+    for (uint32_t r : kv.second) any |= run_flag[r] != kNone;
+    if (!any) continue;
+    ChainView cv{kv.second.data(), (uint32_t)kv.second.size(), run_start.data(), run_len.data(), order.data(), umi,
+                 out_new, run_flag.data(), flag_off.data(), flag_ext.data(), arena.data()};
+    replay_chain<CpuWave>(cv, wk, st, out_new, [](uint32_t, uint8_t, uint32_t) {});
+  }
+  stats[0] = st.undefined;
+  stats[1] = st.overwrites;
+  stats[2] = st.wild_writes;
+  stats[3] = st.overflow;
+  stats[4] = st.changed;
+  stats[5] = flagged.size();
+  stats[6] = st.lookback_runs;
+  return 0;
+}

@@ -67,8 +67,9 @@ def lines_of(text):
 
 @pytest.mark.parametrize("variant", ["plain", "nh", "multi", "noise", "unsorted", "whitelist", "uniq", "thresholds"])
 def test_abi_matches_oracle_on_reused_umis(ctx, variant):
-    """UMIs re-used across genes and cells (the regime where the reference's own RL_Tree breaks,
-    tests/test_oracle_umi.py::test_reference_rl_tree_defect): the oracle's set semantics are the bar."""
+    """UMIs re-used across genes and cells: the regime in which the reference's RL_Tree loses and invents
+    members (tests/test_oracle_umi.py::test_reference_rl_tree_defect).  The oracle restates the tree as it
+    behaves; the HIP path detects the affected (cell, gene) sets and replays them (fqg_rl_sim.h)."""
     rng = np.random.default_rng(abs(hash(variant)) % 9999)
     for trial in range(3):
         kw = dict(n_cells=int(rng.integers(3, 60)), genes=int(rng.integers(5, 400)), umi_len=int(rng.integers(2, 9)),
@@ -134,14 +135,47 @@ def test_abi_findings(ctx):
     assert want["exit"] == 1 and got["code"] == 20 and ("Too many cells %d " % got["aux"]) in want["stderr"]
 
 
-def test_fixed_geometry_batch_against_numpy(ctx):
-    """BASELINE.json configs[3] geometry at 1/10 size: the printed matrix must equal the one numpy
-    derives from the generated (cell, gene, UMI) columns (distinct counts, first-appearance ids,
-    early break), for UMI and read counts."""
+def test_fixed_geometry_batch_against_the_tree_replay(ctx):
+    """BASELINE.json configs[3] geometry at 1/10 size, answer as the reference gives it: the oracle's RL_Tree
+    replay over the generated (cell, gene, UMI) columns + numpy for the counters and the output rules."""
     rng = np.random.default_rng(2024)
     rec, cell, gene, umi = bamgen.config4(rng, n_cells=1500, n_genes=20000, n_triples=500000)
     stream = bamgen.header() + rec.tobytes()
     got = ctx.umi_count(stream)
+    lu, lr, tu, tr, n_cells, n_genes, stats = bamgen.expected_matrix_reference(cell, gene, umi)
+    assert got["code"] == 0 and (got["n_cells"], got["n_features"]) == (n_cells, n_genes)
+    assert got["rl_unresolved"] == 0
+    assert got["entries"][0] == lu and got["entries"][1] == lr
+    assert got["total"] == [tu, tr]
+    assert got["rl_replayed"] >= 1 and stats[2] >= 1   # the input does exercise the defect
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_umi_reuse_against_the_tree_replay(ctx, seed):
+    """Few UMI values, many reads per (cell, gene): most sets hit the overwrite, many read slots that only an
+    earlier cell of the same gene wrote (the look-back), some read memory the reference never wrote."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(2000, 60000))
+    n_cells, n_genes = int(rng.integers(2, 80)), int(rng.integers(1, 30))
+    cell = np.sort(rng.integers(0, n_cells, n))
+    gene = rng.zipf(1.5, n) % n_genes
+    space = int(rng.choice([300, 5000, 4 ** 10]))
+    umi = (rng.integers(0, space, n) * int(rng.choice([1, 7, 64]))) % (4 ** 10)
+    cells_code = rng.choice(np.uint64(1) << np.uint64(32), size=n_cells, replace=False).astype(np.uint64)
+    rec = bamgen.fixed_records(cells_code[cell], gene, umi.astype(np.uint64))
+    got = ctx.umi_count(bamgen.header() + rec.tobytes())
+    lu, lr, tu, tr, nc, ng, stats = bamgen.expected_matrix_reference(cell, gene, umi)
+    assert got["code"] == 0 and got["rl_unresolved"] == 0
+    assert got["entries"][0] == lu and got["entries"][1] == lr and got["total"] == [tu, tr]
+
+
+def test_strict_set_extra_against_numpy(ctx):
+    """strict_set = 1 (an extra, off by default): the set that src/range_list.h:150-162 documents; the matrix numpy
+    derives from the generated columns (distinct counts, first-appearance ids, early break)."""
+    rng = np.random.default_rng(2024)
+    rec, cell, gene, umi = bamgen.config4(rng, n_cells=1500, n_genes=20000, n_triples=500000)
+    stream = bamgen.header() + rec.tobytes()
+    got = ctx.umi_count(stream, strict_set=True)
     c, g, u, r, n_cells, n_genes = bamgen.expected_matrix(cell, gene, umi)
     assert got["code"] == 0 and (got["n_cells"], got["n_features"]) == (n_cells, n_genes)
     assert got["entries"][0] == list(zip(g.tolist(), c.tolist(), u.tolist()))
@@ -150,15 +184,17 @@ def test_fixed_geometry_batch_against_numpy(ctx):
     assert got["tot_reads"] == float(len(cell)) and got["n_alignments"] == len(cell)
 
 
-def test_reference_binary_differential_on_fresh_umis():
+@pytest.mark.parametrize("fresh", [True, False])
+def test_reference_binary_differential(fresh):
     """The reference program itself (oracle/_ref, built from the reference's sources) on a CR-sorted
-    BAM of 300 k alignments whose UMI ids only grow (the regime in which its RL_Tree is a set): all
-    three output files of both programs must be byte-identical."""
+    BAM of 300 k alignments - with UMI ids that only grow (its RL_Tree is a set there) and with UMIs
+    re-used across genes and cells (it is not): all three output files of both programs must be
+    byte-identical."""
     ref = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref/bam_umi_count not built")
     rng = np.random.default_rng(31)
-    rec, *_ = bamgen.config4(rng, n_cells=800, n_genes=5000, n_triples=230000, fresh_umis=True)
+    rec, *_ = bamgen.config4(rng, n_cells=800, n_genes=5000, n_triples=230000, fresh_umis=fresh)
     with tempfile.TemporaryDirectory() as tmp:
         with open(os.path.join(tmp, "in.bam"), "wb") as f:
             f.write(bamgen.bgzf(bamgen.header() + rec.tobytes(), level=1))
@@ -211,7 +247,8 @@ def test_shards_at_cell_boundaries_give_the_file(ctx, n_shards):
     from fastq_utils_amd import dist as fdist
 
     rng = np.random.default_rng(100 + n_shards)
-    bam, stream = bamgen.tagged_bam(rng, n_cells=40, genes=150, reads_per_cell=(1, 200), umi_len=5)
+    # (fresh UMIs: a replayed UMI set looks back into earlier cells of its gene, which a shard does not hold)
+    bam, stream = bamgen.tagged_bam(rng, n_cells=40, genes=150, reads_per_cell=(1, 200), umi_len=8, fresh_umis=True)
     want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"], {"in.bam": bam}.get)
     assert want["exit"] == 0
     whole = ctx.umi_count(stream)
@@ -248,7 +285,7 @@ def test_sharded_protocol_through_a_one_rank_group(ctx):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         rng = np.random.default_rng(5)
-        bam, stream = bamgen.tagged_bam(rng, n_cells=25, genes=80)
+        bam, stream = bamgen.tagged_bam(rng, n_cells=25, genes=80, fresh_umis=True)
         whole = ctx.umi_count(stream)
         got = fdist.umi_count_sharded(ctx, stream)
         assert got["finding"] is None and got["entries"] == whole["entries"]

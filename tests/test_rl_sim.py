@@ -1,0 +1,148 @@
+"""The replay of the reference's RL_Tree that the HIP chain kernel executes (fastq_utils_amd/csrc/fqg_rl_sim.h:
+overwrite detection from arrival order, node-for-node replay of flagged (cell, gene) sets, earlier cells' arrays
+rebuilt from their sorted members) run on the CPU with a one-lane wavefront (tests/cxx/rl_sim_check.cpp) and
+compared, record by record, with the oracle's restatement of src/range_list.c (oracle/rl_oracle.c, itself
+checked against the reference's own range_list.c in test_oracle_rl_matches_reference_source)."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import loader
+from tests.util import REPO
+
+SRC = os.path.join(REPO, "tests", "cxx", "rl_sim_check.cpp")
+
+
+@pytest.fixture(scope="module")
+def sim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("rl") / "librl_sim_check.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, SRC], check=True)
+    L = C.CDLL(so)
+    L.rl_sim_check.argtypes = [C.c_uint32] + [C.c_void_p] * 3 + [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+
+    def run(chain, epoch, umi, cap=16384, mcap=4096):
+        chain, epoch, umi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (chain, epoch, umi))
+        out = np.zeros(chain.size, dtype=np.uint8)
+        st = np.zeros(8, dtype=np.uint64)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.rl_sim_check(chain.size, P(chain), P(epoch), P(umi), cap, mcap, P(out), P(st))
+        return out, dict(zip(("undefined", "overwrites", "wild_writes", "overflow", "changed", "flagged", "lookback"),
+                             (int(x) for x in st)))
+    return run
+
+
+def synth(rng, n_cells, n_genes, n, space, blocks):
+    cell = np.sort(rng.integers(0, n_cells, n)).astype(np.uint32) + 1
+    gene = (rng.zipf(1.5, n) % n_genes).astype(np.uint32) + 1
+    if blocks:  # concentrate the UMIs in a few 64-blocks: many overwrites
+        umi = (rng.integers(0, blocks, n) * 64 + rng.integers(0, 64, n)) % 1048576 + 1
+    else:
+        umi = rng.integers(0, space, n) + 1
+    return cell, gene, umi.astype(np.uint32)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_sorted_mode_chains(sim, seed):
+    rng = np.random.default_rng(seed)
+    n_cells, n_genes, n = int(rng.integers(1, 30)), int(rng.integers(1, 12)), int(rng.integers(10, 3000))
+    cell, gene, umi = synth(rng, n_cells, n_genes, n, int(rng.choice([256, 4096, 1048576])),
+                            int(rng.choice([0, 0, 3, 20, 200])))
+    want, ost = loader.rl_replay(gene, umi, cell, np.ones(n, np.float32), n_genes + 1)
+    got, st = sim(gene, cell, umi)
+    assert st["overflow"] == 0 and (want == got).all()
+    assert st["overwrites"] == ost[2]  # every overwrite of the reference happens inside a flagged set
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_unsorted_mode_one_tree_per_pair(sim, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_cells, n_genes, n = int(rng.integers(1, 10)), int(rng.integers(1, 8)), int(rng.integers(10, 4000))
+    cell, gene, umi = synth(rng, n_cells, n_genes, n, int(rng.choice([256, 4096, 1048576])), int(rng.choice([0, 3, 20, 200])))
+    p = rng.permutation(n)
+    cell, gene, umi = cell[p], gene[p], umi[p]
+    _, pid = np.unique(cell.astype(np.int64) * (n_genes + 1) + gene, return_inverse=True)
+    pid = (pid + 1).astype(np.uint32)
+    zero = np.zeros(n, np.uint32)
+    want, _ = loader.rl_replay(pid, umi, zero, np.ones(n, np.float32), int(pid.max()) + 1)
+    got, st = sim(pid, zero, umi)
+    assert st["overflow"] == 0 and (want == got).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_large_sets_saturate_the_node_counts(sim, seed):
+    rng = np.random.default_rng(2000 + seed)
+    n, n_cells, n_genes = int(rng.integers(2000, 20000)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    cell = np.sort(rng.integers(0, n_cells, n)).astype(np.uint32) + 1
+    gene = rng.integers(0, n_genes, n).astype(np.uint32) + 1
+    umi = (rng.integers(0, int(rng.choice([2000, 20000, 1048576])), n) + 1).astype(np.uint32)
+    want, _ = loader.rl_replay(gene, umi, cell, np.ones(n, np.float32), n_genes + 1)
+    got, st = sim(gene, cell, umi, cap=1 << 16, mcap=1 << 15)
+    assert st["overflow"] == 0 and (want == got).all()
+
+
+def test_limits_are_reported_not_hidden(sim):
+    rng = np.random.default_rng(7)
+    n = 4000
+    cell = np.ones(n, np.uint32)
+    gene = np.ones(n, np.uint32)
+    umi = (rng.integers(0, 1048576 - 64, n) + 1).astype(np.uint32)   # ~30 000 nodes: more than cap below
+    top = 1048576 - 64
+    umi[-3:] = [top + 41, top + 2, top + 42]  # the last block: leaf 2, then leaf 0 in front of it -> flagged
+    _, st = sim(gene, cell, umi, cap=1024, mcap=64)
+    assert st["flagged"] >= 1 and st["overflow"] == 1
+
+
+def test_oracle_rl_matches_reference_source():
+    """oracle/rl_oracle.c against the reference's own range_list.c (oracle/_ref/librange_list_ref.so, built by
+    oracle/Makefile from /root/reference/src): same answers and the same node array after every operation,
+    until the reference reads memory it never wrote (where its behaviour is not defined by its input)."""
+    so = os.path.join(REPO, "oracle", "_ref", "librange_list_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/librange_list_ref.so not built")
+    ref = C.CDLL(so)
+    ref.new_rl.restype = C.c_void_p
+    ref.new_rl.argtypes = [C.c_ulong]
+    ref.set_in_rl.argtypes = [C.c_void_p, C.c_ulong, C.c_int]
+    ref.set_in_rl.restype = C.c_void_p
+    ref.in_rl.argtypes = [C.c_void_p, C.c_ulong]
+    ref.in_rl.restype = C.c_short
+    ref.rl_all.argtypes = [C.c_void_p, C.c_int]
+
+    class RL(C.Structure):
+        _fields_ = [("root", C.POINTER(C.c_uint16)), ("size", C.c_ulong), ("mem", C.c_ulong), ("max", C.c_ulong),
+                    ("root_i", C.c_ulong)]
+    compared = overwrites = 0
+    for seed in range(400):
+        rng = random.Random(seed)
+        a, b = ref.new_rl(1048576), loader.RLTree(1048576)
+        ra = C.cast(a, C.POINTER(RL)).contents
+        nvals, span = rng.choice([5, 20, 100, 1000]), rng.choice([64, 1000, 100000, 1048576])
+        base = rng.randrange(1, 1048576 - span + 2)
+        stop = False
+        for _ in range(rng.randrange(1, 6)):
+            for _ in range(nvals):
+                v = base + rng.randrange(span)
+                x, y = bool(ref.in_rl(a, v)), v in b
+                if b.undefined_reads:
+                    stop = True
+                    break
+                assert x == y
+                if not x:
+                    ref.set_in_rl(a, v, 1)
+                    b.insert(v)
+                if b.undefined_reads:
+                    stop = True
+                    break
+                assert ra.size == b.size
+                assert b.first_difference(ra.root) == -1
+                compared += 1
+            if stop:
+                break
+            ref.rl_all(a, 0)
+            b.all_out()
+        overwrites += b.overwrites
+    assert compared > 20000 and overwrites > 100
