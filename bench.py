@@ -251,9 +251,10 @@ def filters_extra(ctx, fq, torch, dev, image, n, R, st, read_len):
 def umi_extra(ctx, torch, dev, n_triples):
     """bam_umi_count's alignment loop (fqg_umi_count) on BASELINE.json configs[3]: CR-sorted synthetic
     alignments, 10 k cells x 20 k genes, `n_triples` distinct (cell, gene, UMI) + 30 % duplicate reads,
-    inflated records resident in HBM.  Checked at full size against the matrix numpy derives from the
-    generated columns; the reference program is timed on a sample whose UMI ids only grow (the regime in
-    which its RL_Tree is a set) and must produce byte-identical files."""
+    inflated records resident in HBM.  Checked at FULL size against the reference program itself
+    (oracle/_ref/bam_umi_count on the same alignments as a BGZF file): the matrix lines fqg_umi_count returns
+    and all six files the drop-in program writes must be identical to the reference's - including the
+    (cell, gene) sets in which the reference's RL_Tree loses or invents members (fqg_rl_sim.h)."""
     import numpy as np
 
     from tests import bamgen  # generator only (no oracle code)
@@ -270,9 +271,9 @@ def umi_extra(ctx, torch, dev, n_triples):
     torch.cuda.synchronize()
     offs = (np.arange(n, dtype=np.uint64) * np.uint64(bamgen.REC_BYTES) + np.uint64(len(hdr)))
 
-    def run(want_entries):
+    def run(want_entries, **kw):
         return ctx.umi_count(stream.data_ptr(), offsets=_OffsetArray(offs), nbytes=len(hdr) + rec.size,
-                             want_entries=want_entries)
+                             want_entries=want_entries, **kw)
 
     run(False)  # warm-up
     ctx.profile(True)
@@ -282,33 +283,32 @@ def umi_extra(ctx, torch, dev, n_triples):
     r = run(False)
     ctx.synchronize()
     wall = time.perf_counter() - t1
-    prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_umi")}
+    prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith(("k_umi", "k_rl"))}
     ctx.profile(False)
     got = run(True)
-    c, g, u, rd, n_cells, n_genes = bamgen.expected_matrix(cell, gene, umi)
-    exact = (got["code"] == 0 and (got["n_cells"], got["n_features"]) == (n_cells, n_genes)
-             and got["entries"][0] == list(zip(g.tolist(), c.tolist(), u.tolist()))
-             and got["entries"][1] == list(zip(g.tolist(), c.tolist(), rd.tolist())))
     kernels_ms = sum(prof.values())
     out = {
         "what": "bam_umi_count alignment loop + output decisions (fqg_umi_count), BASELINE.json configs[3]",
         "alignments": n, "distinct_triples": int(len(np.unique((cell.astype(np.int64) * 20000 + gene) * 4 ** 10 + umi.astype(np.int64)))),
-        "cells": n_cells, "genes": n_genes, "matrix_lines": len(got["entries"][0]) if got["code"] == 0 else None,
+        "cells": got["n_cells"], "genes": got["n_features"],
+        "matrix_lines": len(got["entries"][0]) if got["code"] == 0 else None,
         "record_bytes": bamgen.REC_BYTES, "wall_ms_one_call_incl_allocations": wall * 1e3,
         "kernels_ms": kernels_ms, "Malignments_per_s_wall": n / wall / 1e6,
         "Malignments_per_s_kernels_only": n / (kernels_ms * 1e-3) / 1e6 if kernels_ms else None,
-        "kernels_ms_breakdown": prof, "matrix_identical_to_numpy_expectation": bool(exact),
+        "input_GBps_kernels_only": n * bamgen.REC_BYTES / (kernels_ms * 1e-3) / 1e9 if kernels_ms else None,
+        "kernels_ms_breakdown": prof,
+        "rl_tree_replay": {"sets_replayed": got["rl_replayed"], "alignments_decided_differently_from_a_set": got["rl_changed"],
+                           "reads_of_memory_the_reference_never_wrote": got["rl_undefined"],
+                           "unresolved": got["rl_unresolved"]},
         "host_generation_s": gen_s,
     }
-    # the reference program on a sample it can count correctly
+    # the reference program on the SAME alignments (the whole of configs[3])
     ref = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
     mine = os.path.join(REPO, "bin", "bam_umi_count")
     if os.path.exists(ref) and os.path.exists(mine):
-        m = min(n_triples, 1_000_000)
-        rec2, *_ = bamgen.config4(np.random.default_rng(7), n_cells=2000, n_genes=20000, n_triples=m, fresh_umis=True)
         with tempfile.TemporaryDirectory() as tmp:
             with open(os.path.join(tmp, "in.bam"), "wb") as f:
-                f.write(bamgen.bgzf(hdr + rec2.tobytes(), level=1))
+                f.write(bamgen.bgzf(hdr + rec.tobytes(), level=1))
             files, secs = {}, {}
             for tag, exe in (("ref", ref), ("gpu", mine)):
                 t2 = time.perf_counter()
@@ -317,10 +317,21 @@ def umi_extra(ctx, torch, dev, n_triples):
                 secs[tag] = time.perf_counter() - t2
                 files[tag] = [open(os.path.join(tmp, tag + b + e), "rb").read() if p.returncode == 0 else None
                               for b in ("_u", "_r") for e in ("", "_rows", "_cols")]
+
+        def lines(blob):
+            return [tuple(int(x) for x in ln.split()) for ln in blob.decode().splitlines()[2:]]
+        abi_same = (files["ref"][0] is not None and got["code"] == 0 and got["entries"][0] == lines(files["ref"][0])
+                    and got["entries"][1] == lines(files["ref"][3]))
+        if files["ref"][0] is not None and got["code"] == 0:
+            mine_u, ref_u = set(got["entries"][0]), set(lines(files["ref"][0]))
+            out["matrix_lines_differing_from_reference"] = len(mine_u ^ ref_u)
+            strict = run(True, strict_set=True)  # what a set would have given (the extra mode), for the record
+            out["matrix_lines_a_set_would_get_differently"] = len(set(strict["entries"][0]) ^ ref_u)
+        out["matrix_identical_to_reference_program"] = bool(abi_same)
         out["cpu_baseline"] = {
-            "value": rec2.shape[0] / secs["ref"] / 1e6, "unit": "Malignments/s", "cores": 1, "kind": "reference",
-            "sample": f"{rec2.shape[0]} alignments, 2000 cells, {m} distinct triples with increasing UMI ids, BGZF level 1; "
-                      "reference bam_umi_count (single-threaded), whole program incl. BGZF inflate",
+            "value": n / secs["ref"] / 1e6, "unit": "Malignments/s", "cores": 1, "kind": "reference",
+            "sample": f"all {n} alignments of configs[3] as a BGZF level-1 file; reference bam_umi_count "
+                      "(single-threaded), whole program incl. BGZF inflate and writing the files",
             "seconds": secs["ref"], "drop_in_program_seconds_same_input": secs["gpu"],
             "files_byte_identical_to_reference": files["ref"] == files["gpu"] and files["ref"][0] is not None,
         }

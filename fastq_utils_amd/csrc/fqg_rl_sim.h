@@ -125,21 +125,25 @@ FQG_HD uint16_t trie_node(const uint32_t* v, const uint32_t* base, uint32_t t, u
 
 // ---- what a chain kernel reads ----------------------------------------------------------------------
 struct ChainView {
-  const uint32_t* chain_runs;   // run ids of this chain in cell order
-  uint32_t n_runs;              // runs of this chain
+  const uint32_t* chain_runs;            // run ids ordered by (chain, cell); null: the run has no history (unsorted mode)
+  const unsigned long long* chain_key;   // per position of chain_runs: chain id << 32 | cell
+  uint32_t pos;                          // position of the run to replay in chain_runs
+  uint32_t run;                          // the run to replay
   const uint32_t* run_start;    // per run: first position in order[]
   const uint32_t* run_len;
   const uint32_t* order;        // record indices grouped by run, record order inside a run
   const uint32_t* umi_id;       // per record
   const uint8_t* set_new;       // per record: first record of its (cell, gene, UMI) - exact for clean epochs
   const uint32_t* run_flag;     // per run: index into the flagged list, or kNone
+  const uint32_t* flag_k0;      // per flagged run: records before the one whose insert overwrites (set semantics hold there)
   const uint32_t* flag_off;     // per flagged run: where its final array is stored in `arena`
-  uint32_t* flag_ext;           // per flagged run: nodes stored (written when it has been replayed)
+  uint32_t* flag_ext;           // per flagged run: nodes stored; 0 until it has been replayed (then >= 1)
   uint16_t* arena;
 };
 
 struct Stats {
   uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
+  unsigned long long clk_replay, clk_lookback, clk_store;  // device clock ticks spent per phase (0 on the CPU)
 };
 
 // LDS (or, on the CPU, heap) arrays of one chain worker
@@ -162,8 +166,12 @@ struct History {
   uint32_t S;     // stale[1..S) valid
   bool count;     // count undefined reads (off while a final array is being stored)
 
-  FQG_HD void reset(const ChainView* c, Work* w, Stats* s, uint32_t cur) {
-    cv = c; wk = w; st = s; pos = cur; S = 1; count = true;
+  FQG_HD void reset(const ChainView* c, Work* w, Stats* s) {
+    cv = c; wk = w; st = s; pos = c->chain_runs ? c->pos : 0; S = 1; count = true;
+  }
+  // is there an earlier run of the same chain?
+  FQG_HD bool more() const {
+    return pos > 0 && (uint32_t)(cv->chain_key[pos - 1] >> 32) == (uint32_t)(cv->chain_key[cv->pos] >> 32);
   }
 
   // bitonic sort of mem[0..P), P a power of two
@@ -184,8 +192,9 @@ struct History {
   }
 
   // members of a clean run -> mem[] sorted, base[]; returns the node count of its trie (its final size)
-  FQG_HD uint32_t load_run(uint32_t run, uint32_t* t_out) {
-    const uint32_t s0 = cv->run_start[run], len = cv->run_len[run];
+  // (only the first `limit` records of the run are looked at)
+  FQG_HD uint32_t load_run(uint32_t run, uint32_t* t_out, uint32_t limit = kNone) {
+    const uint32_t s0 = cv->run_start[run], len = cv->run_len[run] < limit ? cv->run_len[run] : limit;
     // compact the new members (uniform scalar loop per 64 records: every lane counts the same)
     uint32_t t = 0;
     for (uint32_t k0 = 0; k0 < len; k0 += W::lanes) {
@@ -231,8 +240,8 @@ struct History {
     const uint32_t run = cv->chain_runs[--pos];
     st->lookback_runs++;
     const uint32_t fi = cv->run_flag[run];
-    if (fi != kNone) {  // replayed earlier by this worker: its array was stored
-      uint32_t ext = W::load_shared(&cv->flag_ext[fi]);  // (written by this worker: read past its own L1)
+    if (fi != kNone) {  // a replayed run: its final array is stored once its worker is done (it started before us)
+      uint32_t ext = W::wait_nonzero(&cv->flag_ext[fi]);
       if (ext > wk->cap) ext = wk->cap;
       if (ext > S) {
         const uint16_t* src = cv->arena + cv->flag_off[fi];
@@ -254,7 +263,11 @@ struct History {
   }
 
   FQG_HD uint16_t get(uint32_t k) {
-    while (S <= k && pos > 0) extend();
+    if (S <= k && more()) {
+      const unsigned long long t0 = W::clock();
+      while (S <= k && more()) extend();
+      st->clk_lookback += W::clock() - t0;
+    }
     if (k < S) return wk->stale[k];
     if (count) st->undefined++;
     return 0;
@@ -266,7 +279,7 @@ struct Sim {
   Work* wk;
   History<W>* hist;
   Stats* st;
-  uint32_t size, unknown_live;
+  uint32_t size, unknown_live, pending;
 
   FQG_HD bool known(uint32_t idx) const { return (wk->known[idx >> 5] >> (idx & 31u)) & 1u; }
   FQG_HD void mark(uint32_t idx) { wk->known[idx >> 5] |= 1u << (idx & 31u); }
@@ -278,8 +291,10 @@ struct Sim {
     mark(0);
     size = 1;
     unknown_live = 0;
+    pending = 0;
   }
   FQG_HD uint16_t rd(uint32_t idx) {
+    if (!unknown_live && idx < size && idx < wk->cap) return wk->node[idx];  // the usual case: a live, written slot
     if (idx >= wk->cap) { st->overflow = 1; return 0; }
     if (!known(idx)) {
       wk->node[idx] = hist->get(idx);
@@ -298,6 +313,7 @@ struct Sim {
   }
   FQG_HD uint32_t quad(uint32_t idx, uint32_t q) { return (rd(idx) >> (2u * (q - 1u))) & 3u; }
   FQG_HD uint32_t count(uint32_t idx) { return rd(idx) >> 8; }
+  static FQG_HD uint32_t quad_of(uint16_t nv, uint32_t q) { return (nv >> (2u * (q - 1u))) & 3u; }
 
   // tree_size (src/range_list.c:566-593) of the node at idx taken as a node of depth d
   FQG_HD uint32_t subtree_nodes(uint32_t idx, uint32_t d) {
@@ -329,17 +345,17 @@ struct Sim {
       ++s_q[sp];
     }
   }
-  // get_location (src/range_list.c:375-408): node at depth d, quadrant q (1..4)
-  FQG_HD uint32_t child_offset(uint32_t idx, uint32_t q, uint32_t d) {
+  // get_location (src/range_list.c:375-408): node at depth d holding value nv, quadrant q (1..4)
+  FQG_HD uint32_t child_offset(uint32_t idx, uint16_t nv, uint32_t q, uint32_t d) {
     if (q == 1) return 1;
     uint32_t c = 1;
     if (d == 7) {
-      for (uint32_t i = 1; i < q; ++i) c += quad(idx, i) == kQPart;
+      for (uint32_t i = 1; i < q; ++i) c += quad_of(nv, i) == kQPart;
       return c;
     }
     uint32_t at = idx + 1;
     for (uint32_t i = 1; i < q; ++i)
-      if (quad(idx, i) == kQPart) {
+      if (quad_of(nv, i) == kQPart) {
         const uint32_t s = subtree_nodes(at, d + 1);
         at += s;
         c += s;
@@ -351,37 +367,53 @@ struct Sim {
     for (uint32_t i = lo; i <= hi && unknown_live; ++i)
       if (!known(i)) (void)rd(i);
   }
-  // new_node(.., IN) (src/range_list.c:325-372)
-  FQG_HD uint32_t open_node(uint32_t father, uint32_t q, uint32_t d) {
-    const uint32_t at = father + child_offset(father, q, d);
-    const long behind = (long)size - 1 - (long)at;
-    if (behind > 0) {
-      if (at + (uint32_t)behind + 1u >= wk->cap) { st->overflow = 1; }
-      else {
-        if (unknown_live) ensure_known(at, at + (uint32_t)behind);
-        // move node[at .. at + behind] one slot up, top chunk first
-        uint32_t hi = at + (uint32_t)behind;  // = size - 1
-        for (;;) {
-          const uint32_t n = hi - at + 1u < (uint32_t)W::lanes ? hi - at + 1u : (uint32_t)W::lanes;
-          const uint32_t lo = hi + 1u - n;
-          uint16_t v = 0;
-          const uint32_t mine = lo + W::lane();
-          if (W::lane() < n) v = wk->node[mine];
-          W::sync();
-          if (W::lane() < n) wk->node[mine + 1u] = v;
-          W::sync();
-          if (lo == at) break;
-          hi = lo - 1u;
+  // new_node(.., IN) (src/range_list.c:325-372).  A node that has just been created has no children, so an insert
+  // that creates a node at depth d + 1 creates every node below it too, m = 8 - d in all, at consecutive slots
+  // at, at + 1, .. - each of the reference's m calls sees the same number of nodes behind its slot.  The m
+  // one-slot shifts (or the m non-shifts of the defect) are therefore done as ONE move by m slots.
+  FQG_HD uint32_t open_node(uint32_t father, uint16_t fv, uint32_t q, uint32_t d) {
+    const uint32_t at = father + child_offset(father, fv, q, d);
+    if (pending) --pending;  // the gap was opened by the first new node of this insert
+    else {
+      const uint32_t m = 8u - d;
+      const long behind = (long)size - 1 - (long)at;
+      if (behind > 0) {
+        if (size - 1u + m >= wk->cap) { st->overflow = 1; }
+        else {
+          if (unknown_live) ensure_known(at, size - 1u);
+          // move node[at .. size - 1] m slots up, top piece first, 8 nodes per lane and piece
+          uint32_t hi = size - 1u, remaining = (uint32_t)behind + 1u;
+          while (remaining) {
+            const uint32_t n = remaining < 8u * W::lanes ? remaining : 8u * (uint32_t)W::lanes;
+            const uint32_t lo = hi + 1u - n;
+            uint16_t v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+              const uint32_t i = lo + j * W::lanes + W::lane();
+              v[j] = i <= hi ? wk->node[i] : (uint16_t)0;
+            }
+            W::sync();
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+              const uint32_t i = lo + j * W::lanes + W::lane();
+              if (i <= hi) wk->node[i + m] = v[j];
+            }
+            W::sync();
+            hi = lo - 1u;
+            remaining -= n;
+          }
+          for (uint32_t i = size; i < size + m; ++i)
+            if (!known(i)) mark(i);  // (not live yet: no unknown_live bookkeeping)
         }
-        if (!known(size)) mark(size);  // (size is not live yet: no unknown_live bookkeeping)
+      } else if (behind == 0) {
+        st->overwrites += m;
+      } else if (at > size) {
+        st->wild_writes += m;
       }
-    } else if (behind == 0) {
-      st->overwrites++;
-    } else if (at > size) {
-      st->wild_writes++;
+      pending = m - 1u;
     }
     // set_quadrant(father, q, PART)
-    wr(father, (uint16_t)((rd(father) & ~(3u << (2u * (q - 1u)))) | (kQPart << (2u * (q - 1u)))));
+    wr(father, (uint16_t)((fv & ~(3u << (2u * (q - 1u)))) | (kQPart << (2u * (q - 1u)))));
     wr(at, d + 1u >= 8u ? (uint16_t)0 : (uint16_t)(1u << 8));
     ++size;
     if (size - 1u < wk->cap && !known(size - 1u)) ++unknown_live;
@@ -393,10 +425,11 @@ struct Sim {
     uint32_t idx = 0;
     for (uint32_t d = 0; d < 8; ++d) {
       const uint32_t q = ((v >> (18u - 2u * d)) & 3u) + 1u;
-      const uint32_t s = quad(idx, q);
+      const uint16_t nv = rd(idx);
+      const uint32_t s = quad_of(nv, q);
       if (s == kQAll) return true;
       if (s != kQPart) return false;
-      idx += child_offset(idx, q, d);
+      idx += child_offset(idx, nv, q, d);
     }
     return (rd(idx) >> (v & 15u)) & 1u;
   }
@@ -410,66 +443,92 @@ struct Sim {
       path[d] = idx;
       before[d] = size;
       const uint32_t q = ((v >> (18u - 2u * d)) & 3u) + 1u;
-      const uint32_t s = quad(idx, q);
-      if (s == kQOut) idx = open_node(idx, q, d);
+      const uint16_t nv = rd(idx);
+      const uint32_t s = quad_of(nv, q);
+      if (s == kQOut) idx = open_node(idx, nv, q, d);
       else if (s == kQAll) { reached_leaf = false; break; }  // returns 0 at this level: no count refresh here
-      else idx += child_offset(idx, q, d);
+      else idx += child_offset(idx, nv, q, d);
     }
     if (reached_leaf) wr(idx, (uint16_t)(rd(idx) | (1u << (v & 15u))));
     for (int k = (int)d - 1; k >= 0; --k) {
       const uint32_t node = path[k];
       const uint32_t added = size - before[k];
-      const uint32_t c0 = count(node);
+      const uint16_t nv = rd(node);
+      const uint32_t c0 = nv >> 8;
       uint32_t c = c0 == 255u ? subtree_nodes(node, (uint32_t)k + 1u) : added + c0;  // (:485: the child's width)
       if (c > 254u) c = 255u;
-      wr(node, (uint16_t)((rd(node) & 0xFFu) | (c << 8)));
+      wr(node, (uint16_t)((nv & 0xFFu) | (c << 8)));
     }
   }
 };
 
-// Replays every flagged run of one chain in order.  new_out[rec] (may alias cv.set_new's storage through a
-// non-const pointer the caller passes) receives the reference's decision for every record of a flagged run;
-// on_change(record, is_new, run) is called (lane 0) for every record whose decision differs from set semantics.
+// Replays one flagged run.  new_out[rec] (the storage cv.set_new points to, through a non-const pointer) receives
+// the reference's decision for every record of the run whose decision differs from set semantics;
+// on_change(record, is_new, run) is called (lane 0) for each of them.
 template <class W, class OnChange>
-FQG_HD void replay_chain(const ChainView& cv, Work& wk, Stats& st, uint8_t* new_out, OnChange on_change) {
+FQG_HD void replay_run(const ChainView& cv, Work& wk, Stats& st, uint8_t* new_out, OnChange on_change) {
   History<W> hist;
   Sim<W> sim;
   sim.wk = &wk;
   sim.hist = &hist;
   sim.st = &st;
-  for (uint32_t j = 0; j < cv.n_runs; ++j) {
-    const uint32_t run = cv.chain_runs[j];
-    const uint32_t fi = cv.run_flag[run];
-    if (fi == kNone) continue;
-    hist.reset(&cv, &wk, &st, j);
-    sim.begin();
-    const uint32_t s0 = cv.run_start[run], len = cv.run_len[run];
-    for (uint32_t k = 0; k < len; ++k) {
-      const uint32_t rec = cv.order[s0 + k];
-      const uint32_t u = cv.umi_id[rec];
-      const bool in = sim.member(u);
-      if (!in) sim.insert(u);
-      const uint8_t nw = in ? 0 : 1;
-      if (nw != cv.set_new[rec]) {
-        st.changed++;
-        if (W::lane() == 0) {
-          new_out[rec] = nw;
-          on_change(rec, nw, run);
-        }
+  const uint32_t run = cv.run, fi = cv.run_flag[run];
+  const unsigned long long t0 = W::clock();
+  hist.reset(&cv, &wk, &st);
+  sim.begin();
+  const uint32_t s0 = cv.run_start[run], len = cv.run_len[run];
+  const uint32_t k0 = cv.flag_k0[fi];
+  uint32_t k_first = 0;
+  if (k0) {
+    // up to the first overwrite the array is the pre-order trie of the members so far: build it, do not replay it
+    uint32_t t;
+    uint32_t size = hist.load_run(run, &t, k0);
+    if (size > wk.cap) st.overflow = 1;
+    else {
+      for (uint32_t p = 1 + W::lane(); p < size; p += W::lanes) wk.node[p] = trie_node(wk.mem, wk.base, t, p);
+      uint32_t quads = 0;
+      for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t at = lower_bound_u32(wk.mem, t, q << 18);
+        if (at < t && (wk.mem[at] >> 18) == q) quads |= kQPart << (2u * q);
+      }
+      wk.node[0] = (uint16_t)(quads | (1u << 8));
+      for (uint32_t w = W::lane(); w * 32u < size; w += W::lanes)
+        wk.known[w] = w * 32u + 32u <= size ? 0xFFFFFFFFu : (1u << (size - w * 32u)) - 1u;
+      W::sync();
+      sim.size = size;
+      k_first = k0;
+    }
+  }
+  for (uint32_t k = k_first; k < len; ++k) {
+    const uint32_t rec = cv.order[s0 + k];
+    const uint32_t u = cv.umi_id[rec];
+    const bool in = sim.member(u);
+    if (!in) sim.insert(u);
+    const uint8_t nw = in ? 0 : 1;
+    if (nw != cv.set_new[rec]) {
+      st.changed++;
+      if (W::lane() == 0) {
+        new_out[rec] = nw;
+        on_change(rec, nw, run);
       }
     }
-    // keep the final array for the later epochs of this chain
-    uint32_t ext = sim.size < wk.cap ? sim.size : wk.cap;
-    hist.count = false;
-    sim.ensure_known(0, ext - 1u);
-    hist.count = true;
-    uint16_t* dst = cv.arena + cv.flag_off[fi];
-    W::sync();
-    for (uint32_t p = W::lane(); p < ext; p += W::lanes) dst[p] = wk.node[p];
-    if (W::lane() == 0) cv.flag_ext[fi] = ext;
-    W::fence();
-    W::sync();
   }
+  const unsigned long long t1 = W::clock();
+  // keep the final array for the later epochs of this chain
+  uint32_t ext = sim.size < wk.cap ? sim.size : wk.cap;
+  hist.count = false;
+  sim.ensure_known(0, ext - 1u);
+  hist.count = true;
+  uint16_t* dst = cv.arena + cv.flag_off[fi];
+  W::sync();
+  for (uint32_t p = W::lane(); p < ext; p += W::lanes) dst[p] = wk.node[p];
+  W::fence();
+  W::sync();
+  if (W::lane() == 0) W::publish(&cv.flag_ext[fi], ext);
+  W::sync();
+  const unsigned long long t2 = W::clock();
+  st.clk_replay += t1 - t0;
+  st.clk_store += t2 - t1;
 }
 
 }  // namespace rl

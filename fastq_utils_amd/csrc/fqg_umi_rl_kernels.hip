@@ -24,15 +24,24 @@ struct GpuWave {
     return (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
   }
   static __device__ __forceinline__ uint32_t count(bool b) { return (uint32_t)__popcll(__ballot(b)); }
-  static __device__ __forceinline__ uint32_t load_shared(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the final array of an earlier replayed run of the same chain: its worker took its ticket before ours, so it
+  // is running (or done) and this wait ends
+  static __device__ __forceinline__ uint32_t wait_nonzero(const uint32_t* p) {
+    uint32_t v;
+    while (!(v = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))) __builtin_amdgcn_s_sleep(8);
+    return v;
+  }
+  static __device__ __forceinline__ void publish(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   static __device__ __forceinline__ void fence() { __threadfence(); }
+  static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
 };
 
 struct RlCall {
-  uint32_t n_flagged, n_chains, max_len, max_flagged_len;
+  uint32_t n_flagged, next_item, max_len, max_flagged_len;
   uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
+  unsigned long long clk_replay, clk_lookback, clk_store;  // wall_clock64 ticks (100 MHz) summed over the workers
 };
 
 struct RlRuns {      // per run (= per (cell, feature) pair), in order of the sorted pair slots
@@ -55,15 +64,19 @@ __global__ __launch_bounds__(kBlock) void k_rl_detect(uint32_t n, const uint32_t
                                                       const uint32_t* __restrict__ start_flag, Prefix run_of,
                                                       const uint32_t* __restrict__ umi_id,
                                                       const uint8_t* __restrict__ is_new, RlRuns runs,
-                                                      uint32_t* __restrict__ flagged, RlCall* __restrict__ call) {
+                                                      uint32_t* __restrict__ flagged, uint32_t* __restrict__ flag_k0,
+                                                      RlCall* __restrict__ call) {
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= n || !start_flag[j]) return;
   const uint32_t r = run_of.at(j), k = key[j];
-  uint32_t state = 0, len = 0;
+  uint32_t state = 0, len = 0, k0 = 0;
   bool hit = false;
   for (uint32_t p = j; p < n && key[p] == k; ++p, ++len) {
     const uint32_t rec = order[p];
-    if (!hit && is_new[rec]) hit = rl::rl_detect_step(state, umi_id[rec]);
+    if (!hit && is_new[rec] && rl::rl_detect_step(state, umi_id[rec])) {
+      hit = true;
+      k0 = len;  // records of the run before the one whose insert overwrites
+    }
   }
   runs.start[r] = j;
   runs.len[r] = len;
@@ -72,6 +85,7 @@ __global__ __launch_bounds__(kBlock) void k_rl_detect(uint32_t n, const uint32_t
   if (hit) {
     const uint32_t fi = atomicAdd(&call->n_flagged, 1u);
     flagged[fi] = r;
+    flag_k0[fi] = k0;
     runs.flag[r] = fi;
     atomicMax(&call->max_flagged_len, len);
   }
@@ -92,41 +106,30 @@ __global__ __launch_bounds__(kBlock) void k_rl_positions(uint32_t n_runs, const 
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p < n_runs) pos_of_run[chain_runs[p]] = p;
 }
-// one thread per flagged run: is it the first flagged run of its chain?  then list the chain
-__global__ __launch_bounds__(kBlock) void k_rl_heads(uint32_t n_flagged, uint32_t n_runs,
-                                                     const uint32_t* __restrict__ flagged,
-                                                     const uint32_t* __restrict__ pos_of_run,
-                                                     const unsigned long long* __restrict__ key,
-                                                     const uint32_t* __restrict__ chain_runs,
-                                                     const uint32_t* __restrict__ run_flag,
-                                                     uint32_t* __restrict__ chain_begin, uint32_t* __restrict__ chain_len,
-                                                     RlCall* __restrict__ call) {
+// replay order: flagged runs by position in the (chain, cell) order, so that a run a replay may have to wait
+// for always holds an earlier ticket
+__global__ __launch_bounds__(kBlock) void k_rl_item_keys(uint32_t n_flagged, const uint32_t* __restrict__ flagged,
+                                                         const uint32_t* __restrict__ pos_of_run,
+                                                         uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
   const uint32_t fi = blockIdx.x * kBlock + threadIdx.x;
   if (fi >= n_flagged) return;
-  const uint32_t p = pos_of_run[flagged[fi]];
-  const uint32_t feat = (uint32_t)(key[p] >> 32);
-  uint32_t q = p;
-  while (q > 0 && (uint32_t)(key[q - 1] >> 32) == feat) {
-    --q;
-    if (run_flag[chain_runs[q]] != rl::kNone) return;  // an earlier flagged run heads this chain
-  }
-  uint32_t e = p + 1;
-  while (e < n_runs && (uint32_t)(key[e] >> 32) == feat) ++e;
-  const uint32_t c = atomicAdd(&call->n_chains, 1u);
-  chain_begin[c] = q;
-  chain_len[c] = e - q;
+  key[fi] = pos_of_run[flagged[fi]];
+  val[fi] = fi;
 }
 
 struct RlReplayArgs {
-  const uint32_t* chain_runs;    // sorted mode: run ids by (feature, cell); unsorted mode: the flagged list
-  const uint32_t* chain_begin;   // per listed chain (null in unsorted mode: chain c = entry c, length 1)
-  const uint32_t* chain_len;
-  uint32_t n_chains;
+  const uint32_t* chain_runs;          // sorted mode: run ids by (feature, cell); unsorted mode: null (no history)
+  const unsigned long long* chain_key; // feature << 32 | cell per position of chain_runs
+  const uint32_t* pos_of_run;
+  const uint32_t* items;               // flagged indices in replay order (null: 0, 1, 2, ...)
+  const uint32_t* flagged;             // flagged index -> run
+  uint32_t n_items;
   RlRuns runs;
   const uint32_t* order;
   const uint32_t* umi_id;
   const uint32_t* cell_id;
   uint8_t* is_new;
+  const uint32_t* flag_k0;
   const uint32_t* flag_off;
   uint32_t* flag_ext;
   uint16_t* arena;
@@ -144,6 +147,7 @@ struct RlReplayArgs {
 __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
   __shared__ uint32_t s_scan[kWave + 1];
+  __shared__ uint32_t s_item;
   // the worker's arrays: LDS when they fit (the usual case), else this workgroup's slice of a global scratch
   uint8_t* g = A.in_lds ? s_dyn : A.scratch + (uint64_t)blockIdx.x * A.scratch_stride;
   auto carve = [&](uint64_t bytes) {
@@ -161,20 +165,29 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
   wk.base = reinterpret_cast<uint32_t*>(carve((uint64_t)(A.mcap + 1) * 4));
   wk.scratch = s_scan;
   rl::Stats st{};
-  for (uint32_t c = blockIdx.x; c < A.n_chains; c += gridDim.x) {
+  for (;;) {  // tickets in replay order
+    if (threadIdx.x == 0) s_item = atomicAdd(&A.call->next_item, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    __syncthreads();
+    if (item >= A.n_items) break;
+    const uint32_t fi = A.items ? A.items[item] : item;
     rl::ChainView cv;
-    cv.chain_runs = A.chain_runs + (A.chain_begin ? A.chain_begin[c] : c);
-    cv.n_runs = A.chain_len ? A.chain_len[c] : 1u;
+    cv.run = A.flagged[fi];
+    cv.chain_runs = A.chain_runs;
+    cv.chain_key = A.chain_key;
+    cv.pos = A.pos_of_run ? A.pos_of_run[cv.run] : 0u;
     cv.run_start = A.runs.start;
     cv.run_len = A.runs.len;
     cv.order = A.order;
     cv.umi_id = A.umi_id;
     cv.set_new = A.is_new;
     cv.run_flag = A.runs.flag;
+    cv.flag_k0 = A.flag_k0;
     cv.flag_off = A.flag_off;
     cv.flag_ext = A.flag_ext;
     cv.arena = A.arena;
-    rl::replay_chain<GpuWave>(cv, wk, st, A.is_new, [&](uint32_t rec, uint8_t nw, uint32_t run) {
+    rl::replay_run<GpuWave>(cv, wk, st, A.is_new, [&](uint32_t rec, uint8_t nw, uint32_t run) {
       const uint32_t d = nw ? 1u : 0xFFFFFFFFu;  // +1 / -1
       atomicAdd(&A.pair_umis[A.runs.pslot[run]], d);
       atomicAdd(&A.cell_umis[A.cell_id[rec]], d);
@@ -188,6 +201,9 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
     if (st.overflow) atomicOr(&A.call->overflow, 1u);
     if (st.changed) atomicAdd(&A.call->changed, st.changed);
     if (st.lookback_runs) atomicAdd(&A.call->lookback_runs, st.lookback_runs);
+    atomicAdd(&A.call->clk_replay, st.clk_replay);
+    atomicAdd(&A.call->clk_lookback, st.clk_lookback);
+    atomicAdd(&A.call->clk_store, st.clk_store);
   }
 }
 

@@ -17,8 +17,10 @@ struct CpuWave {
   static void sync() {}
   static uint32_t rank(bool) { return 0; }
   static uint32_t count(bool b) { return b ? 1u : 0u; }
-  static uint32_t load_shared(const uint32_t* p) { return *p; }
+  static uint32_t wait_nonzero(const uint32_t* p) { return *p; }  // (runs are replayed in chain order here)
+  static void publish(uint32_t* p, uint32_t v) { *p = v; }
   static void fence() {}
+  static unsigned long long clock() { return 0; }
 };
 }  // namespace
 
@@ -27,7 +29,7 @@ struct CpuWave {
 // out_new[i]: the decision for record i; stats[0..5] = undefined, overwrites, wild writes, overflow, changed,
 // flagged runs.  cap / mcap: array sizes of the worker (to exercise the overflow paths).
 extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* epoch, const uint32_t* umi,
-                            uint32_t cap, uint32_t mcap, uint8_t* out_new, uint64_t* stats) {
+                            uint32_t cap, uint32_t mcap, int history, int from_overwrite, uint8_t* out_new, uint64_t* stats) {
   using namespace fqg::rl;
   // runs = (chain, epoch) groups in order of first appearance; order[] = records grouped by run
   std::map<std::pair<uint32_t, uint32_t>, uint32_t> run_of;
@@ -46,29 +48,37 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
   const uint32_t n_runs = (uint32_t)recs.size();
   std::vector<uint32_t> order, run_start(n_runs), run_len(n_runs), run_flag(n_runs, kNone);
   std::vector<uint8_t> set_new(n, 0);
-  std::vector<uint32_t> flagged;
+  std::vector<uint32_t> flagged, flag_k0;
   for (uint32_t r = 0; r < n_runs; ++r) {
     run_start[r] = (uint32_t)order.size();
     run_len[r] = (uint32_t)recs[r].size();
     std::set<uint32_t> seen;
-    uint32_t state = 0;
+    uint32_t state = 0, k = 0, k0 = 0;
     bool hit = false;
     for (uint32_t i : recs[r]) {
       order.push_back(i);
       if (seen.insert(umi[i]).second) {
         set_new[i] = 1;
-        if (!hit && rl_detect_step(state, umi[i])) hit = true;
+        if (!hit && rl_detect_step(state, umi[i])) {
+          hit = true;
+          k0 = k;
+        }
       }
+      ++k;
     }
     if (hit) {
       run_flag[r] = (uint32_t)flagged.size();
       flagged.push_back(r);
+      flag_k0.push_back(from_overwrite ? k0 : 0);
     }
   }
   memcpy(out_new, set_new.data(), n);
-  // chains: runs of a chain in order of appearance (= cell order for sorted input)
-  std::map<uint32_t, std::vector<uint32_t>> chains;
-  for (uint32_t r = 0; r < n_runs; ++r) chains[key[r].first].push_back(r);
+  // all runs ordered by (chain, first appearance): a chain's runs are in cell order for sorted input
+  std::vector<uint32_t> chain_runs(n_runs);
+  for (uint32_t r = 0; r < n_runs; ++r) chain_runs[r] = r;
+  std::stable_sort(chain_runs.begin(), chain_runs.end(), [&](uint32_t a, uint32_t b) { return key[a].first < key[b].first; });
+  std::vector<unsigned long long> chain_key(n_runs);
+  for (uint32_t p = 0; p < n_runs; ++p) chain_key[p] = ((unsigned long long)key[chain_runs[p]].first << 32) | p;
   std::vector<uint32_t> flag_off(flagged.size()), flag_ext(flagged.size(), 0);
   uint64_t arena_n = 0;
   for (size_t f = 0; f < flagged.size(); ++f) {
@@ -80,13 +90,12 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
   std::vector<uint32_t> known(cap / 32 + 1), mem(mcap + 1), base(mcap + 2), scratch(4);
   Work wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap};
   Stats st{};
-  for (auto& kv : chains) {
-    bool any = false;
-    for (uint32_t r : kv.second) any |= run_flag[r] != kNone;
-    if (!any) continue;
-    ChainView cv{kv.second.data(), (uint32_t)kv.second.size(), run_start.data(), run_len.data(), order.data(), umi,
-                 out_new, run_flag.data(), flag_off.data(), flag_ext.data(), arena.data()};
-    replay_chain<CpuWave>(cv, wk, st, out_new, [](uint32_t, uint8_t, uint32_t) {});
+  for (uint32_t p = 0; p < n_runs; ++p) {  // flagged runs in (chain, cell) order: the order the GPU hands them out
+    const uint32_t r = chain_runs[p];
+    if (run_flag[r] == kNone) continue;
+    ChainView cv{history ? chain_runs.data() : nullptr, chain_key.data(), p, r, run_start.data(), run_len.data(),
+                 order.data(), umi, out_new, run_flag.data(), flag_k0.data(), flag_off.data(), flag_ext.data(), arena.data()};
+    replay_run<CpuWave>(cv, wk, st, out_new, [](uint32_t, uint8_t, uint32_t) {});
   }
   stats[0] = st.undefined;
   stats[1] = st.overwrites;
