@@ -304,7 +304,8 @@ int fqg_synchronize(fqg_ctx* c) {
 
 void* fqg_host_alloc(fqg_ctx* c, size_t bytes) {
   void* p = nullptr;
-  if (!c || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;  // (callable from the programs' reader threads)
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
   return p;
 }
 void fqg_host_free(fqg_ctx* c, void* p) {
