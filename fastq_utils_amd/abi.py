@@ -29,8 +29,10 @@ EXPORTS = [
     "fqg_acc_reset", "fqg_acc_read", "fqg_acc_hist_nonzero", "fqg_acc_median", "fqg_acc_export",
     "fqg_acc_merge", "fqg_validate", "fqg_frame_records", "fqg_profile_enable",
     "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
-    "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_index_create",
-    "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_names_compare",
+    "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_frame_make_current", "fqg_index_create",
+    "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_index_probe_delete",
+    "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_records_gather",
+    "fqg_records_gather_output", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
@@ -204,6 +206,8 @@ def load():
     L.fqg_index_destroy.restype = None
     L.fqg_index_insert_unique.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
+    L.fqg_index_probe_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(u64), C.POINTER(IndexResult)]
+    L.fqg_index_alive.argtypes = [vp, vp, C.POINTER(C.c_uint8), u64]
     L.fqg_names_compare.argtypes = [vp, vp, C.POINTER(FileState), vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_barcodes_transform.argtypes = [vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64),
                                          C.POINTER(BarcodeParams), u64, u64, C.POINTER(BarcodeResult)]
@@ -373,6 +377,22 @@ class NameIndex:
         r = IndexResult()
         self.ctx._check(load().fqg_index_match_delete(self.ctx.h, self.h, C.byref(state), C.byref(r)))
         return r.as_dict()
+
+    def probe_delete(self, state, n_records):
+        """match_delete with one answer per record of the current frame: the inserted record (insertion order) whose
+        entry the record took, or None"""
+        r = IndexResult()
+        m = (C.c_uint64 * max(1, n_records))()
+        self.ctx._check(load().fqg_index_probe_delete(self.ctx.h, self.h, C.byref(state), m, C.byref(r)))
+        d = r.as_dict()
+        d["match"] = [None if m[i] >= 0xFFFFFFFFFFFFFFFE else int(m[i]) for i in range(n_records)]
+        d["wrong_header"] = [i for i in range(n_records) if m[i] == 0xFFFFFFFFFFFFFFFE]
+        return d
+
+    def alive(self, n_inserted):
+        a = (C.c_uint8 * max(1, n_inserted))()
+        self.ctx._check(load().fqg_index_alive(self.ctx.h, self.h, a, n_inserted))
+        return [bool(a[i]) for i in range(n_inserted)]
 
     def close(self):
         if self.h:

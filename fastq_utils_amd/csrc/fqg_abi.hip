@@ -79,6 +79,7 @@ struct fqg_ctx {
   FrameView frame{};
   bool frame_valid = false;
   bool frame_img_owned = false;  // the frame's image lives in `image` (host input), not with the caller
+  bool frame_borrowed = false;   // the current frame is a retained frame made current again (fqg_frame_make_current)
   uint32_t frame_flags = 0;      // kFlagNul / kFlagCr of the framed image
   DevBuf bc_status, bc_len[3], bc_off[3], bc_sum[3], bc_out[3], bc_tile_big;
   BcCall* d_bcall = nullptr;
@@ -654,6 +655,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   if (flags & FQG_VALIDATE_NO_STATS) acc = nullptr;
   memset(out, 0, sizeof(*out));
   c->frame_valid = false;
+  c->frame_borrowed = false;
   HIP_TRY(c, hipSetDevice(c->device));
   if (nbytes == 0) return 0;
   if (nbytes >= (1ull << 44)) return fail(c, FQG_ERR_ARG, "image too large");
@@ -859,9 +861,21 @@ struct fqg_frame {
   uint32_t flags = 0;
 };
 
+int fqg_frame_make_current(fqg_ctx* c, const fqg_frame* f) {
+  if (!c || !f || f->ctx != c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->frame = f->fv;
+  c->frame_flags = f->flags;
+  c->frame_valid = true;
+  c->frame_img_owned = false;
+  c->frame_borrowed = true;
+  return 0;
+}
+
 int fqg_frame_retain(fqg_ctx* c, fqg_frame** out) {
   if (!c || !out) return FQG_ERR_ARG;
   if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  if (c->frame_borrowed) return fail(c, FQG_ERR_STATE, "the current frame is a retained one: it cannot be retained again");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   fqg_frame* f = new fqg_frame();
   f->ctx = c;
@@ -897,6 +911,7 @@ struct fqg_index {
   std::vector<fqg_frame*> frames;
   std::vector<IndexSeg> segs;
   uint64_t n_records_total = 0;  // records fed so far = global index of the next frame's first record
+  uint64_t n_askers_total = 0;   // records of the asking file(s) matched against the index so far
   uint64_t inserted = 0, matched = 0, name_bytes = 0;
   int fmt = FQG_NAME_UNDEF, is_pe = 0;
   uint32_t flags = 0;
@@ -966,6 +981,7 @@ int index_grow(fqg_index* ix, uint64_t need_names) {
   if ((rc = index_alloc_table(ix, cap))) return rc;
   if ((rc = index_upload_segs(ix))) return rc;
   for (size_t s = 0; s < ix->segs.size(); ++s) {
+    if (!ix->segs[s].n_records) continue;  // (a frame whose insert failed: kept for ownership only)
     if ((rc = index_reset_call(c))) return rc;
     FrameView fv = ix->frames[s]->fv;
     ProfScope ps(c, "k_index_insert(regrow)");
@@ -1024,24 +1040,34 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   sg.record_base = ix->n_records_total;
   ix->frames.push_back(fr);
   ix->segs.push_back(sg);
+  // on any failure below the frame stays registered with the index (freed by fqg_index_destroy), but its records do
+  // not count: n_records_total / inserted only move once the insert has succeeded
   if (2 * (ix->inserted + sg.n_records) > ix->capacity) {
     // grow first (re-inserting the earlier segments), then insert this one
     ix->segs.pop_back();
     ix->frames.pop_back();
-    if ((rc = index_grow(ix, ix->inserted + sg.n_records))) return rc;
+    rc = index_grow(ix, ix->inserted + sg.n_records);
     ix->frames.push_back(fr);
     ix->segs.push_back(sg);
+    if (rc) {
+      ix->segs.back().n_records = 0;
+      return rc;
+    }
   }
-  if ((rc = index_upload_segs(ix))) return rc;
-  if ((rc = index_reset_call(c))) return rc;
+  auto drop = [&](int code) {
+    ix->segs.back().n_records = 0;  // (kept for ownership only)
+    return code;
+  };
+  if ((rc = index_upload_segs(ix))) return drop(rc);
+  if ((rc = index_reset_call(c))) return drop(rc);
   if (sg.n_records) {
     ProfScope ps(c, "k_index_insert");
     hipLaunchKernelGGL(k_index_insert, dim3(index_grid(c, sg.n_records)), dim3(kBlock), 0, c->stream, fr->fv,
                        index_view(ix), sg.record_base, c->d_icall);
   }
-  if ((rc = index_fetch_call(c))) return rc;
-  HIP_TRY(c, hipGetLastError());
-  if (c->h_icall->table_full) return fail(c, FQG_ERR_STATE, "name index full");
+  if ((rc = index_fetch_call(c))) return drop(rc);
+  if (hipGetLastError() != hipSuccess) return drop(fail(c, FQG_ERR_HIP, "k_index_insert"));
+  if (c->h_icall->table_full) return drop(fail(c, FQG_ERR_STATE, "name index full"));
   ix->n_records_total += sg.n_records;
   ix->inserted += c->h_icall->inserted;
   ix->name_bytes += c->h_icall->name_bytes;
@@ -1060,7 +1086,7 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   return 0;
 }
 
-int fqg_index_match_delete(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, fqg_index_result* out) {
+static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, uint64_t* match, fqg_index_result* out) {
   if (!c || !ix || !st || !out || ix->ctx != c) return FQG_ERR_ARG;
   if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
   memset(out, 0, sizeof(*out));
@@ -1074,15 +1100,32 @@ int fqg_index_match_delete(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, 
   if ((rc = index_upload_segs(ix))) return rc;
   if ((rc = index_reset_call(c))) return rc;
   const FrameView fv = c->frame;
+  unsigned long long *d_slot = nullptr, *d_match = nullptr;
+  if (match && fv.n_records) {
+    if (hipMalloc((void**)&d_slot, fv.n_records * 8) != hipSuccess || hipMalloc((void**)&d_match, fv.n_records * 8) != hipSuccess) {
+      if (d_slot) (void)hipFree(d_slot);
+      return fail(c, FQG_ERR_NOMEM, "fqg_index_probe_delete: device allocation failed");
+    }
+  }
   if (fv.n_records) {
     ProfScope ps(c, "k_index_match_delete");
     hipLaunchKernelGGL(k_index_match_delete, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv,
                        index_view(ix), st->readname_format, st->is_pe, (c->frame_flags & kFlagNul) ? 1 : 0,
-                       c->d_icall);
+                       ix->n_askers_total, d_slot, c->d_icall);
+    if (match) {
+      hipLaunchKernelGGL(k_index_probe_resolve, dim3((unsigned)((fv.n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                         c->stream, fv.n_records, (const unsigned long long*)d_slot, index_view(ix), ix->n_askers_total,
+                         d_match);
+      (void)hipMemcpyAsync(match, d_match, fv.n_records * 8, hipMemcpyDeviceToHost, c->stream);
+    }
   }
-  if ((rc = index_fetch_call(c))) return rc;
+  rc = index_fetch_call(c);
+  if (d_slot) (void)hipFree(d_slot);
+  if (d_match) (void)hipFree(d_match);
+  if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
   ix->matched += c->h_icall->matched;
+  ix->n_askers_total += fv.n_records;
   const uint64_t w = c->h_icall->first_wrong, m = c->h_icall->first_missing;
   if (w != kNoRecord && w < m) {
     out->code = FQG_E_WRONG_HEADER;
@@ -1093,6 +1136,36 @@ int fqg_index_match_delete(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, 
   }
   out->n_entries = ix->inserted - ix->matched;
   out->index_mem = 8 + ix->inserted * (16 + 1 + 24) + ix->name_bytes;
+  return 0;
+}
+
+int fqg_index_match_delete(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, fqg_index_result* out) {
+  return index_match_impl(c, ix, st, nullptr, out);
+}
+
+int fqg_index_probe_delete(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, uint64_t* match, fqg_index_result* out) {
+  if (!match && c && c->frame_valid && c->frame.n_records) return FQG_ERR_ARG;
+  return index_match_impl(c, ix, st, match, out);
+}
+
+int fqg_index_alive(fqg_ctx* c, fqg_index* ix, uint8_t* alive, uint64_t cap) {
+  if (!c || !ix || ix->ctx != c || (!alive && cap)) return FQG_ERR_ARG;
+  if (cap < ix->n_records_total) return fail(c, FQG_ERR_ARG, "fqg_index_alive: buffer too small");
+  if (!ix->n_records_total) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = index_upload_segs(ix))) return rc;
+  uint8_t* d = nullptr;
+  if (hipMalloc((void**)&d, ix->n_records_total) != hipSuccess) return fail(c, FQG_ERR_NOMEM, "fqg_index_alive: device allocation failed");
+  (void)hipMemsetAsync(d, 0, ix->n_records_total, c->stream);
+  IndexView v = index_view(ix);
+  if (!ix->claims_ready) v.claims = nullptr;
+  hipLaunchKernelGGL(k_index_alive, dim3((unsigned)((ix->capacity + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, v,
+                     ix->n_records_total, d);
+  hipError_t e = hipMemcpyAsync(alive, d, ix->n_records_total, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(c, FQG_ERR_HIP, "fqg_index_alive", e);
   return 0;
 }
 
@@ -1451,6 +1524,54 @@ int fqg_barcodes_output(fqg_ctx* c, int which, void* host_dst, uint64_t nbytes) 
 }
 
 int fqg_records_filter_output(fqg_ctx* c, void* host_dst, uint64_t nbytes) { return fqg_barcodes_output(c, 1, host_dst, nbytes); }
+
+int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* records, uint64_t n, uint64_t* out_bytes) {
+  if (!c || !frame || !out_bytes || (!records && n)) return FQG_ERR_ARG;
+  *out_bytes = 0;
+  c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
+  if (!n) return 0;
+  for (uint64_t k = 0; k < n; ++k)
+    if (records[k] >= frame->fv.n_records) return fail(c, FQG_ERR_ARG, "fqg_records_gather: record outside the frame");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  const uint64_t nb = (n + kScan64Span - 1) / kScan64Span;
+  if ((rc = ensure(c, c->bc_off[1], n * 8))) return rc;     // the list
+  if ((rc = ensure(c, c->bc_len[1], n * 4))) return rc;
+  if ((rc = ensure(c, c->bc_off[2], n * 8))) return rc;     // local offsets
+  if ((rc = ensure(c, c->bc_sum[1], nb * 8 + 16))) return rc;
+  unsigned long long* d_tot = (unsigned long long*)c->bc_sum[1].p + nb;
+  HIP_TRY(c, hipMemcpyAsync(c->bc_off[1].p, records, n * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, "k_gather_plan");
+    hipLaunchKernelGGL(k_gather_lens, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, frame->fv,
+                       (const unsigned long long*)c->bc_off[1].p, n, (uint32_t*)c->bc_len[1].p);
+    hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const uint32_t*)c->bc_len[1].p, n,
+                       (unsigned long long*)c->bc_off[2].p, (unsigned long long*)c->bc_sum[1].p);
+    hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->bc_sum[1].p, nb, d_tot);
+  }
+  HIP_TRY(c, hipMemcpyAsync(&c->h_scalar[2], d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint64_t total = c->h_scalar[2];
+  if ((rc = ensure(c, c->bc_out[1], total + 64))) return rc;
+  {
+    ProfScope ps(c, "k_gather_copy");
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, (uint64_t)c->cu_count * 16);
+    hipLaunchKernelGGL(k_gather_copy, dim3(grid), dim3(kBlock), 0, c->stream, frame->fv,
+                       (const unsigned long long*)c->bc_off[1].p, n, (const unsigned long long*)c->bc_off[2].p,
+                       (const unsigned long long*)c->bc_sum[1].p, (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_out[1].p);
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->bc_out_bytes[1] = total;
+  *out_bytes = total;
+  return 0;
+}
+int fqg_records_gather_output(fqg_ctx* c, void* host_dst, uint64_t nbytes) { return fqg_barcodes_output(c, 1, host_dst, nbytes); }
+
+const fqg_frame* fqg_index_frame(const fqg_index* ix, uint64_t k) {
+  return (ix && k < ix->frames.size()) ? ix->frames[k] : nullptr;
+}
+uint64_t fqg_index_n_frames(const fqg_index* ix) { return ix ? ix->frames.size() : 0; }
 
 // ---- measurement ----------------------------------------------------------------------------
 int fqg_profile_enable(fqg_ctx* c, int on) {

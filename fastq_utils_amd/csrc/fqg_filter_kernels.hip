@@ -281,4 +281,37 @@ __global__ __launch_bounds__(kBlock) void k_rf_emit_direct(BcParams F, RfParams 
   }
 }
 
+// ---- ordered gather of whole records (fastq_filterpair: the paired / unpaired partitions) ----------
+// What fastq_write_entry / fastq_quick_copy_entry write per record (src/fastq.c:125-157, 265-272): the four lines
+// as they stand in the input.  list[k] = record of the frame that comes k-th in the output.
+__global__ __launch_bounds__(kBlock) void k_gather_lens(FrameView f, const unsigned long long* __restrict__ list,
+                                                        uint64_t n, uint32_t* __restrict__ lens) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t r = list[k];
+  const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+  const uint64_t e = f.line_end[4 * r + 3];
+  lens[k] = (uint32_t)(e - b) + (e < f.nbytes ? 1u : 0u);
+}
+// one wavefront per record: 16-byte pieces at any alignment
+__global__ __launch_bounds__(kBlock) void k_gather_copy(FrameView f, const unsigned long long* __restrict__ list, uint64_t n,
+                                                        const unsigned long long* __restrict__ off_local,
+                                                        const unsigned long long* __restrict__ off_span,
+                                                        const uint32_t* __restrict__ lens, uint8_t* __restrict__ out) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+  const int lane = (int)(threadIdx.x & 63);
+  const uint64_t stride = (uint64_t)gridDim.x * (kBlock / kWave);
+  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); k < n; k += stride) {
+    const uint64_t r = list[k];
+    const uint8_t* src = f.img + (r == 0 ? 0 : f.line_end[4 * r - 1] + 1);
+    uint8_t* dst = out + off_local[k] + off_span[k / kScan64Span];
+    const uint32_t len = lens[k];
+    for (uint32_t o = (uint32_t)lane * 16u; o < len; o += 16u * kWave) {
+      if (o + 16u <= len) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
+      else
+        for (uint32_t j = o; j < len; ++j) dst[j] = src[j];
+    }
+  }
+}
+
 }  // namespace fqg

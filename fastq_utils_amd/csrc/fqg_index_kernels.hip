@@ -288,9 +288,13 @@ __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView 
   }
 }
 
-// One thread per record of the (file-2) frame: find the name, claim its slot.
+// One thread per record of the (file-2) frame: find the name, claim its slot.  claims[] holds the GLOBAL index
+// (asker_base + r: the pieces of the asking file share the index) of the smallest asker; slot_of[r] (optional)
+// remembers where record r found its name (kSlotEmpty: nowhere) for k_index_probe_resolve.
 __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, IndexView ix, int fmt2, int is_pe2,
-                                                               int may_have_nul2, IndexCall* __restrict__ call) {
+                                                               int may_have_nul2, uint64_t asker_base,
+                                                               unsigned long long* __restrict__ slot_of,
+                                                               IndexCall* __restrict__ call) {
   unsigned long long my_missing = kNoRecord, my_wrong = kNoRecord, matched = 0;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
@@ -300,11 +304,13 @@ __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, Inde
     uint64_t h;
     bool at_sign;
     const uint32_t n = name_and_hash(f.img, f.nbytes, b, e, fmt2, is_pe2, may_have_nul2, &acct, &h, &at_sign);
+    if (slot_of) slot_of[r] = at_sign ? kSlotEmpty : kSlotEmpty - 1;
     if (!at_sign) {
       my_wrong = r < my_wrong ? r : my_wrong;
       continue;
     }
     const uint8_t* name = f.img + b + 1;
+    const unsigned long long g2 = asker_base + r;
     uint64_t at = h & ix.mask;
     bool found = false;
     for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
@@ -315,13 +321,15 @@ __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, Inde
         uint32_t on;
         if (stored_name(ix, cur & kIdxMask, &other, &on) && on == n && same_bytes(other, name, n)) {
           // the smallest asker gets the entry; every other asker is what the serial loop would
-          // have found missing after the delete
-          const unsigned long long prev = atomicMin(&ix.claims[at], (unsigned long long)r);
+          // have found missing after the delete.  An asker of an EARLIER piece is smaller than every
+          // record of this one, so `late` always lies in this piece.
+          const unsigned long long prev = atomicMin(&ix.claims[at], g2);
           if (prev == kSlotEmpty) ++matched;
           else {
-            const unsigned long long late = prev > r ? prev : r;
+            const unsigned long long late = (prev > g2 ? prev : g2) - asker_base;
             my_missing = late < my_missing ? late : my_missing;
           }
+          if (slot_of) slot_of[r] = at;
           found = true;
           break;
         }
@@ -334,6 +342,28 @@ __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, Inde
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) matched += __shfl_down(matched, d, 64);
   if ((threadIdx.x & 63) == 0 && matched) atomicAdd(&call->matched, matched);
+}
+
+// After k_index_match_delete: match[r] = global index (insertion order) of the entry record r took, or kNoRecord
+// when its name is not in the index or an earlier asker took it (src/fastq_filterpair.c:150-170: lookup, then
+// fastq_index_delete)
+__global__ __launch_bounds__(kBlock) void k_index_probe_resolve(uint64_t n, const unsigned long long* __restrict__ slot_of,
+                                                                IndexView ix, uint64_t asker_base,
+                                                                unsigned long long* __restrict__ match) {
+  const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n) return;
+  const unsigned long long at = slot_of[r];
+  if (at >= kSlotEmpty - 1) match[r] = at;  // not in the index / no '@' (FQG_NO_MATCH / FQG_MATCH_WRONG_HEADER)
+  else match[r] = ix.claims[at] == asker_base + r ? (ix.slots[at] & kIdxMask) : kNoRecord;
+}
+// alive[g] = 1 for every inserted record g whose entry nobody has taken (the table still holds it)
+__global__ __launch_bounds__(kBlock) void k_index_alive(IndexView ix, uint64_t n_records, uint8_t* __restrict__ alive) {
+  const uint64_t at = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (at > ix.mask) return;
+  const unsigned long long cur = ix.slots[at];
+  if (cur == kSlotEmpty) return;
+  const unsigned long long g = cur & kIdxMask;
+  if (g < n_records) alive[g] = (!ix.claims || ix.claims[at] == kSlotEmpty) ? 1 : 0;
 }
 
 // Names of paired records must be equal: record 2k against 2k+1 of one frame (interleaved

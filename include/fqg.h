@@ -170,6 +170,9 @@ typedef struct fqg_frame fqg_frame;
 int fqg_frame_retain(fqg_ctx *ctx, fqg_frame **out);
 void fqg_frame_release(fqg_frame *frame);
 uint64_t fqg_frame_n_records(const fqg_frame *frame);
+/* make a retained frame the context's current frame again (for the calls that work on "the current frame", e.g.
+ * fqg_index_probe_delete of one file's records against the other file's index); it stays owned by whoever holds it */
+int fqg_frame_make_current(fqg_ctx *ctx, const fqg_frame *frame);
 
 /* ---- read-name index --------------------------------------------------------------------
  * Replaces hash.c as fastq.c uses it: new_hashtable() + the fastq_index_readnames() loop
@@ -198,6 +201,21 @@ int fqg_index_insert_unique(fqg_ctx *ctx, fqg_index *index, const fqg_file_state
  * first record with a wrong header or without a partner (FQG_E_UNPAIRED, src/fastq_info.c:338). */
 int fqg_index_match_delete(fqg_ctx *ctx, fqg_index *index, const fqg_file_state *state,
                            fqg_index_result *out);
+/* The same pass with one answer per record (the lookup + fastq_index_delete of src/fastq_filterpair.c:150-170,
+ * 196-216): match[r] (host, one per record of the current frame) = which inserted record's entry record r found
+ * and took - its index in insertion order over all inserted frames - or UINT64_MAX when the name is not in the
+ * index or an earlier record (of this or an earlier frame of the asking file) took it (FQG_NO_MATCH), or
+ * FQG_MATCH_WRONG_HEADER for a record whose header does not start with '@' (src/fastq.c:448). */
+#define FQG_NO_MATCH UINT64_MAX
+#define FQG_MATCH_WRONG_HEADER (UINT64_MAX - 1)
+int fqg_index_probe_delete(fqg_ctx *ctx, fqg_index *index, const fqg_file_state *state, uint64_t *match,
+                           fqg_index_result *out);
+/* alive[g] = 1 for every inserted record g (insertion order) whose entry nobody has taken yet: what a lookup of
+ * the file's own names finds after the pairing loop (src/fastq_filterpair.c:196-216); cap >= records inserted */
+int fqg_index_alive(fqg_ctx *ctx, fqg_index *index, uint8_t *alive, uint64_t cap);
+/* the frames an index has retained, in insertion order (borrowed: they live as long as the index) */
+uint64_t fqg_index_n_frames(const fqg_index *index);
+const fqg_frame *fqg_index_frame(const fqg_index *index, uint64_t k);
 /* Pairwise name agreement without an index.  b == NULL: records 2k and 2k+1 of frame a
  * (interleaved input, src/fastq_info.c:81-91, finding FQG_E_UNPAIRED at pair k -> record 2k);
  * otherwise record k of a against record k of b (src/fastq_info.c:133-138, FQG_E_NAME_MISMATCH). */
@@ -305,6 +323,14 @@ typedef struct {
 int fqg_records_filter(fqg_ctx *ctx, const fqg_frame *frame, uint64_t first_record, uint64_t n_records,
                        const fqg_filter_params *params, fqg_filter_result *out);
 int fqg_records_filter_output(fqg_ctx *ctx, void *host_dst, uint64_t nbytes);
+
+/* ---- ordered gather of records (fastq_filterpair) -----------------------------------------------
+ * The output side of fastq_filterpair (src/fastq_filterpair.c:150-216): records of a retained frame written in a
+ * given order - what fastq_write_entry (src/fastq.c:265-272) / fastq_quick_copy_entry (:125-157) produce record by
+ * record.  records[k] = index in the frame of the k-th record of the output; the text stays on the device until
+ * fqg_records_gather_output copies it. */
+int fqg_records_gather(fqg_ctx *ctx, const fqg_frame *frame, const uint64_t *records, uint64_t n, uint64_t *out_bytes);
+int fqg_records_gather_output(fqg_ctx *ctx, void *host_dst, uint64_t nbytes);
 
 /* ---- UMI counting (bam_umi_count) ---------------------------------------------------------------
  * Replaces the alignment loop of bam_umi_count (src/bam_umi_count.c:942-1060: filters, aux tags,

@@ -469,6 +469,107 @@ def gen_filters():
         print(k, "invocations:", len(v), "by exit status:", by)
 
 
+FP_BIN = os.path.join(REPO, "oracle", "_ref", "fastq_filterpair")
+
+
+def filterpair_synthetic():
+    """Two seeded FASTQ files for fastq_filterpair: mates in different orders, reads without a mate in either file -
+    in file 1 both before and behind the last mated read (the reference only finds the latter, src/fastq_filterpair.c:
+    196-216 reads file 1 on from where its last copy ended) -, and a name that file 2 asks for twice."""
+    import numpy as np
+
+    rng = np.random.default_rng(2718)
+
+    def rec(i, mate, n=40):
+        seq = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)])
+        qual = bytes((rng.integers(2, 41, n) + 33).astype(np.uint8))
+        return b"@SYN:1:FC:1:1:%d:%d %d:N:0:ACGT\n" % (i % 11, i, mate) + seq + b"\n+\n" + qual + b"\n"
+    ids = list(range(300))
+    only1 = set(int(x) for x in rng.choice(300, 40, replace=False))
+    only2 = list(range(1000, 1030))
+    f1 = [i for i in ids]
+    f2 = [i for i in ids if i not in only1] + only2
+    rng.shuffle(f2)
+    f2.insert(50, f2[10])  # asked for twice: the second asker finds nothing
+    return b"".join(rec(i, 1) for i in f1), b"".join(rec(i, 2) for i in f2)
+
+
+def filterpair_jobs():
+    d = lambda n: "data/" + n
+    jobs = []
+    # run_tests.sh:361-370
+    jobs += [[d("test_2.fastq.gz"), d("test_2.fastq.gz")], [d("a_1.fastq.gz"), d("a_2.fastq.gz")],
+             [d("casava.1.8_2.fastq.gz"), d("casava.1.8_2.fastq.gz")], [d("casava.1.8_1.fastq.gz"), d("casava.1.8_1.fastq.gz")],
+             [d("c18_10000_1.fastq.gz"), d("c18_10000_2.fastq.gz")], [d("c18_10000_1.fastq.gz"), d("c18_10000_2.fastq.gz"), "sorted"],
+             [d("c18_10000_1.fastq.gz"), d("casava.1.8_2.fastq.gz")], [d("c18_10000_1.fastq_missing.gz"), d("c18_10000_2.fastq.gz")]]
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(DATA, "*.fastq.gz")))
+    for n in names:
+        if "_1." in n and n.replace("_1.", "_2.") in names and os.path.getsize(os.path.join(DATA, n)) < 200_000:
+            m = n.replace("_1.", "_2.")
+            for extra in ([], ["sorted"]):
+                jobs.append([d(n), d(m)] + extra)
+                jobs.append([d(m), d(n)] + extra)
+    for a, b in (("syn_fp_1.fastq", "syn_fp_2.fastq"), ("syn_fp_2.fastq", "syn_fp_1.fastq"), ("syn_fp_1.fastq", "syn_fp_1.fastq"),
+                 ("syn_fp_1.fastq", "empty.fastq"), ("empty.fastq", "syn_fp_1.fastq"), ("syn_fp_1.fastq", "syn_fp_2_trunc.fastq"),
+                 ("syn_fp_1.fastq", "syn_fp_2_noat.fastq"), ("test_e9.fastq.gz", "test_1.fastq.gz"),
+                 ("test_1.fastq.gz", "test_e3.fastq.gz"), ("test_e3.fastq.gz", "test_1.fastq.gz")):
+        for extra in ([], ["sorted"]):
+            jobs.append([d(a), d(b)] + extra)
+    seen, out = set(), []
+    for j in jobs:
+        if tuple(j) not in seen:
+            seen.add(tuple(j))
+            out.append(j)
+    return out + [[], ["a"], [d("test_1.fastq.gz"), d("test_1.fastq.gz"), "O1", "O2"]]
+
+
+def gen_filterpair():
+    import gzip
+    import hashlib
+    import tempfile
+
+    if not os.path.exists(FP_BIN):
+        sys.exit("build the reference first: make -C oracle ref")
+    s1, s2 = filterpair_synthetic()
+    with open(os.path.join(DATA, "syn_fp_1.fastq"), "wb") as f:
+        f.write(s1)
+    with open(os.path.join(DATA, "syn_fp_2.fastq"), "wb") as f:
+        f.write(s2)
+    with open(os.path.join(DATA, "syn_fp_2_trunc.fastq"), "wb") as f:
+        f.write(s2[: len(s2) // 2].rsplit(b"\n+\n", 1)[0] + b"\n")  # ends after a sequence line
+    with open(os.path.join(DATA, "syn_fp_2_noat.fastq"), "wb") as f:
+        recs = s2.split(b"\n@SYN")
+        recs[120] = b"XSYN" + recs[120]  # a header without '@' in the middle of file 2
+        f.write(recs[0] + b"".join((b"\n" + r) if r.startswith(b"XSYN") else (b"\n@SYN" + r) for r in recs[1:]))
+
+    def pack(text):
+        return {"sha256": hashlib.sha256(text).hexdigest(), "len": len(text),
+                "text": text.decode("latin-1") if len(text) <= 40000 else None}
+    out = []
+    for args in filterpair_jobs():
+        with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+            rel = os.path.relpath(tmp, GOLD)
+            real = list(args)
+            if len(real) in (2, 3):
+                real = real[:2] + [rel + "/p1.fastq.gz", rel + "/p2.fastq.gz", rel + "/up.fastq.gz"] + real[2:]
+            real = [rel + "/" + a if a in ("O1", "O2") else a for a in real]
+            p = subprocess.run(["fastq_filterpair"] + real, executable=FP_BIN, cwd=GOLD, capture_output=True, timeout=300)
+            files = {}
+            if p.returncode in (0, 3):
+                for k in ("p1", "p2", "up"):
+                    path = os.path.join(tmp, k + ".fastq.gz")
+                    if os.path.exists(path) and p.returncode == 0:
+                        files[k] = pack(gzip.decompress(open(path, "rb").read()))
+            out.append({"args": args, "exit": p.returncode, "stdout": p.stdout.decode("latin-1"),
+                        "stderr": p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"), "files": files})
+    with open(os.path.join(GOLD, "filterpair.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    by = {}
+    for o in out:
+        by[o["exit"]] = by.get(o["exit"], 0) + 1
+    print("filterpair invocations:", len(out), "by exit status:", by)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "fastq_info"):
@@ -477,5 +578,7 @@ if __name__ == "__main__":
         gen_pre_barcodes()
     if which in ("all", "umi"):
         gen_umi()
+    if which in ("all", "filterpair"):
+        gen_filterpair()
     if which in ("all", "filters"):
         gen_filters()
