@@ -13,9 +13,13 @@
 //                         message and returns 1.
 //   fastq_index_readnames one bulk validation + fqg_index_insert_unique; findings are ordered and
 //                         worded as the reference's loop (src/fastq.c:414-436) would.
-//   fastq_index_lookup_header / fastq_index_delete   the pairing loop of fastq_info (:333-350):
-//                         the first lookup after a file was loaded runs fqg_index_match_delete on
-//                         that file; calls answer from its result (first unpaired record).
+//   fastq_index_lookup_header / fastq_index_delete   the pairing loops of fastq_info (:333-350) and of
+//                         fastq_filterpair (src/fastq_filterpair.c:108-216): the first lookup of a file's
+//                         records in an index runs ONE fqg_index_probe_delete of that file against it (which
+//                         entry every record finds and takes, with the serial loop's answers); a file's
+//                         lookups in its OWN index (filterpair's last loop) answer from fqg_index_alive.
+//   fastq_rewind / fastq_quick_copy_entry / fastq_seek_copy_read   positions are record starts of the
+//                         decompressed file (INDEX_ENTRY.entry_start): they move the record cursor.
 // The host keeps only bookkeeping on values it already has (counters, copies, text).
 #include <errno.h>
 #include <fcntl.h>
@@ -82,8 +86,6 @@ struct FileCtx {
   std::vector<fqg_record> rec;
   uint64_t n_records = 0, next = 0;
   int tail_lines = 0;   // lines of an incomplete last record
-  bool matched = false; // fqg_index_match_delete ran for this file
-  uint64_t first_unpaired = ~0ull;
   std::vector<Verdict> verdicts;
 };
 
@@ -97,9 +99,12 @@ Origin g_last_read{nullptr, 0};
 
 struct IndexCtx {
   fqg_index* ix = nullptr;
-  hashtable table = nullptr;
+  FileCtx* owner = nullptr;                                  // the file whose names it holds
+  std::unordered_map<FileCtx*, std::vector<uint64_t>> asked; // per asking file: which entry each record took
+  std::vector<uint8_t> alive;                                // entries nobody has taken (own-file lookups)
+  bool alive_valid = false;
 };
-IndexCtx g_index;
+std::unordered_map<hashtable, IndexCtx*> g_indexes;
 
 FileCtx* ctx_of(FASTQ_FILE* fd) {
   auto it = g_files.find(fd);
@@ -537,19 +542,37 @@ void fastq_index_readnames(FASTQ_FILE* fd1, hashtable index, long long start_off
   while (gzgetc(fd1->fd) >= 0) {
   }
   index->n_entries = ir.n_entries;
-  index_mem += ir.index_mem;
-  g_index.ix = ix;
-  g_index.table = index;
+  index_mem += ir.index_mem >= 8 ? ir.index_mem - 8 : 0;  // (the caller adds sizeof(hashtable) itself)
+  IndexCtx* ic = new IndexCtx();
+  ic->ix = ix;
+  ic->owner = f;
+  g_indexes[index] = ic;
 }
 
 INDEX_ENTRY* fastq_index_lookup_header(hashtable sn_index, char* hdr) {
   static INDEX_ENTRY found;
-  if (g_index.table != sn_index || !g_index.ix) return nullptr;
-  FileCtx* f = g_last_read.f;
+  auto it = g_indexes.find(sn_index);
+  if (it == g_indexes.end()) return nullptr;
+  IndexCtx* ic = it->second;
+  FileCtx* f = g_last_read.f;  // the name is the one of the record read last (every caller's loop does that)
   if (!f) return nullptr;
-  if (!f->matched) {
-    // the pairing loop of fastq_info (src/fastq_info.c:333-350) over the whole second file at once
-    f->matched = true;
+  const uint64_t k = g_last_read.record;
+  found.hdr = hdr;
+  if (f == ic->owner) {
+    // a file asking its own index: the entry is there unless another file's record took it
+    if (!ic->alive_valid) {
+      ic->alive.assign(f->n_records ? f->n_records : 1, 0);
+      if (f->n_records) LIB(fqg_index_alive(gpu(), ic->ix, ic->alive.data(), ic->alive.size()));
+      ic->alive_valid = true;
+    }
+    if (k >= f->n_records || !ic->alive[k]) return nullptr;
+    found.entry_start = (off_t)f->rec[k].offset;
+    return &found;
+  }
+  auto asked = ic->asked.find(f);
+  if (asked == ic->asked.end()) {
+    // the whole loop of this file against the index at once (src/fastq_info.c:333-350, src/fastq_filterpair.c:
+    // 108-170): which entry every record finds and takes
     fqg_file_state st;
     memset(&st, 0, sizeof(st));
     st.is_pe = f->fd->is_pe;
@@ -558,17 +581,92 @@ INDEX_ENTRY* fastq_index_lookup_header(hashtable sn_index, char* hdr) {
     fqg_validate_result r;
     LIB(fqg_validate(gpu(), nullptr, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st,
                      FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS, &r));
+    std::vector<uint64_t> m(r.n_records ? r.n_records : 1, FQG_NO_MATCH);
     fqg_index_result ir;
-    LIB(fqg_index_match_delete(gpu(), g_index.ix, &st, &ir));
-    f->first_unpaired = ir.code == FQG_E_UNPAIRED ? ir.record : ~0ull;
+    if (r.n_records) LIB(fqg_index_probe_delete(gpu(), ic->ix, &st, m.data(), &ir));
+    asked = ic->asked.emplace(f, std::move(m)).first;
+    ic->alive_valid = false;
   }
-  (void)hdr;
-  return g_last_read.record < f->first_unpaired ? &found : nullptr;
+  if (k >= asked->second.size() || asked->second[k] >= FQG_MATCH_WRONG_HEADER) return nullptr;
+  found.entry_start = (off_t)ic->owner->rec[asked->second[k]].offset;
+  return &found;
 }
 
 void fastq_index_delete(char* rname, hashtable index) {
   (void)rname;
   if (index->n_entries) --index->n_entries;
+}
+
+// ---- positions (src/fastq.c:77-80, 124-157, 191-199) -----------------------------------------------------------
+static uint64_t cursor_offset(const FileCtx* f) {
+  return f->next < f->n_records ? f->rec[f->next].offset : (uint64_t)f->image.size();
+}
+// the record that starts at `offset`, n_records for the end of the file, ~0 for anything else
+static uint64_t record_at(const FileCtx* f, uint64_t offset) {
+  if (offset >= f->image.size()) return offset == f->image.size() ? f->n_records : ~0ull;
+  uint64_t lo = 0, hi = f->n_records;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (f->rec[mid].offset < offset) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < f->n_records && f->rec[lo].offset == offset) ? lo : ~0ull;
+}
+static void move_cursor(FileCtx* f, uint64_t k) {
+  f->next = k;
+  gzseek(f->fd->fd, (z_off_t)k, SEEK_SET);  // the stand-in stream holds one byte per record
+}
+
+void fastq_rewind(FASTQ_FILE* fd) {
+  fd->cline = 1;
+  FileCtx* f = ctx_of(fd);
+  if (f->loaded) move_cursor(f, 0);
+  else gzrewind(fd->fd);
+}
+
+static unsigned long ctr_seek = 0, ctr_noseek = 0;
+static void seek_to(FileCtx* f, long offset) {
+  const uint64_t k = offset < 0 ? ~0ull : record_at(f, (uint64_t)offset);
+  if (k == ~0ull) {  // not a record start: the reference would read lines from the middle of a record
+    PRINT_ERROR("Error in file %s: line %lu: gzseek failed", f->fd->filename, f->fd->cline);
+    exit(kExitSys);
+  }
+  move_cursor(f, k);
+}
+
+void fastq_quick_copy_entry(long offset, FASTQ_FILE* from, FASTQ_FILE* to) {
+  FileCtx* f = ctx_of(from);
+  load(f);
+  if ((long)cursor_offset(f) != offset) {
+    seek_to(f, offset);
+    ++ctr_seek;
+  } else ++ctr_noseek;
+  fprintf(stderr, "%lu / %lu\n", ctr_seek, ctr_noseek);
+  if (f->next >= f->n_records) {  // nothing (complete) to read there
+    PRINT_ERROR("Error in file %s: line %lu: file truncated", from->filename, from->cline);
+    exit(kExitFormat);
+  }
+  const fqg_record& d = f->rec[f->next];
+  const char* p = f->image.data() + d.offset;
+  const uint32_t len[4] = {d.hdr1_len, d.seq_len, d.hdr2_len, d.qual_len};
+  std::string line;
+  for (int i = 0; i < 4; ++i) {
+    line.assign(p, len[i]);
+    GZ_WRITE(to->fd, const_cast<char*>(line.c_str()));
+    p += len[i];
+  }
+  move_cursor(f, f->next + 1);
+  from->cur_offset = (long long)cursor_offset(f);
+}
+
+void fastq_seek_copy_read(long offset, FASTQ_FILE* from, FASTQ_FILE* to) {
+  static FASTQ_ENTRY* tmp = nullptr;
+  FileCtx* f = ctx_of(from);
+  load(f);
+  seek_to(f, offset);
+  if (!tmp) tmp = fastq_new_entry();
+  fastq_read_entry(from, tmp);
+  fastq_write_entry(to, tmp);
 }
 
 char* fastq_qualRange2enc(unsigned int min_qual, unsigned int max_qual) {  // src/fastq.c:274-297
@@ -726,8 +824,23 @@ void* next_hash_object(hashtable t) {
   return n ? n->obj : nullptr;
 }
 
-void hashtable_stats(hashtable t) {
-  fprintf(stderr, "hashtable: %llu buckets, %llu entries\n", t->size, t->n_entries);
+void hashtable_stats(hashtable t) {  // src/hash.c:125-150: empty buckets, chains longer than one
+  fq_ulong zbuckets = 0, collisions = 0, max_col = 0;
+  for (fq_ulong i = 0; i < t->size; ++i) {
+    fq_ulong ctr = 0;
+    for (const hashnode* b = t->buckets[i]; b; b = b->next) ++ctr;
+    if (!ctr) ++zbuckets;
+    else if (ctr > 1) {
+      collisions += ctr;
+      if (ctr > max_col) max_col = ctr;
+    }
+  }
+  fprintf(stderr, "size: %llu\n", t->size);
+  fprintf(stderr, "max. col: %llu\n", max_col);
+  fprintf(stderr, "zbuckets: %llu\n", zbuckets);
+  fprintf(stderr, "%% zbuckets: %.2f\n", zbuckets * 1.0 / t->size);
+  fprintf(stderr, "collisions: %llu\n", collisions);
+  fprintf(stderr, "avg. collisions: %.2f\n", collisions * 1.0 / (t->size - zbuckets));
 }
 
 }  // extern "C"

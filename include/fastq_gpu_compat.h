@@ -107,9 +107,49 @@ void fastq_destroy(FASTQ_FILE *);
 void fastq_is_pe(FASTQ_FILE *fd);
 void fastq_index_readnames(FASTQ_FILE *, hashtable, long long, int);
 void fastq_write_entry2stdout(FASTQ_ENTRY *e);
+/* src/fastq.h:151-155 (src/fastq.c:77-80, 124-157, 191-199), as fastq_filterpair.c uses them: positions are the
+ * offsets of record starts in the decompressed file (INDEX_ENTRY.entry_start) */
+void fastq_seek_copy_read(long offset, FASTQ_FILE *from, FASTQ_FILE *to);
+void fastq_rewind(FASTQ_FILE *fd);
+void fastq_quick_copy_entry(long offset, FASTQ_FILE *from, FASTQ_FILE *to);
 char *fastq_qualRange2enc(unsigned int min_qual, unsigned int max_qual);
 gzFile fastq_open(const char *filename, const char *mode);
 void GZ_WRITE(gzFile fd, char *s);
+
+/* ---- range_list.h (src/range_list.h:19-162): the integer set bam_umi_count keeps per (cell, gene) ----
+ * Same names, layouts and behaviour as the reference's implementation (src/range_list.c), including where it is
+ * not a set (fastq_utils_amd/compat/range_list_compat.cpp).  intersect_rl is declared by the reference but not
+ * defined anywhere in it; it is not exported here either. */
+typedef union {
+  struct {
+    unsigned short int quadrant_1 : 2;
+    unsigned short int quadrant_2 : 2;
+    unsigned short int quadrant_3 : 2;
+    unsigned short int quadrant_4 : 2;
+    unsigned short int num_subnodes : 8;
+  } i_node;
+  unsigned short int leaf;
+} RL_Node;
+struct rl_struct {
+  RL_Node *root;
+  unsigned long size;      /* number of nodes */
+  unsigned long mem_alloc; /* bytes allocated for root */
+  unsigned long range_max;
+  unsigned long root_i;    /* width of a root quadrant */
+};
+typedef struct rl_struct RL_Tree;
+typedef short BOOLEAN;
+typedef enum { IN = 1, OUT = 0 } STATUS;
+RL_Tree *new_rl(unsigned long max_size);
+RL_Tree *copy_rl(RL_Tree *tree);
+void free_rl(RL_Tree *range);
+void rl_all(RL_Tree *tree, STATUS status);
+void display_tree(RL_Tree *tree);
+RL_Tree *set_in_rl(RL_Tree *tree, unsigned long number, STATUS status);
+BOOLEAN in_rl(RL_Tree *range, unsigned long number);
+BOOLEAN freeze_rl(RL_Tree *tree);
+RL_Tree *minus_rl(RL_Tree *range1, RL_Tree *range2);
+unsigned long rl_next_in_bigger(RL_Tree *tree, unsigned long min);
 
 #ifdef __cplusplus
 }

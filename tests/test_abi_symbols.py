@@ -63,6 +63,11 @@ COMPAT_EXPORTS = [
     "index_mem", "encodings", "new_hashtable", "get_next_object", "delete", "get_object", "insere",
     "free_hashtable", "reset_hashtable", "init_hash_traversal", "next_hash_object", "next_hashnode",
     "hashtable_stats",
+    # src/fastq.h:151-155
+    "fastq_seek_copy_read", "fastq_rewind", "fastq_quick_copy_entry",
+    # src/range_list.h:150-162 (intersect_rl is declared there but defined nowhere in the reference)
+    "new_rl", "copy_rl", "free_rl", "rl_all", "display_tree", "set_in_rl", "in_rl", "freeze_rl", "minus_rl",
+    "rl_next_in_bigger",
 ]
 
 
@@ -101,15 +106,33 @@ int main(void) {
          offsetof(FASTQ_FILE, space));
   printf("%zu %zu %zu %zu %zu\n", sizeof(struct hashtable_s), offsetof(struct hashtable_s, size),
          offsetof(struct hashtable_s, n_entries), sizeof(hashnode), sizeof(INDEX_ENTRY));
+  printf("%zu %zu %zu %zu %zu %d %d\n", sizeof(RL_Tree), offsetof(RL_Tree, size), offsetof(RL_Tree, mem_alloc),
+         offsetof(RL_Tree, root_i), sizeof(RL_Node), (int)IN, (int)OUT);
   return 0;
 }
 '''
     outs = []
     for tag, inc, hdr in (("ours", os.path.join(repo, "include"), '#include "fastq_gpu_compat.h"'),
-                          ("ref", ref, '#include "fastq.h"')):
+                          ("ref", ref, '#include "fastq.h"\n#include "range_list.h"')):
         src = tmp_path / (tag + ".c")
         src.write_text(hdr + body)
         exe = tmp_path / tag
         subprocess.run(["gcc", "-w", "-I", inc, "-o", str(exe), str(src)], check=True)
         outs.append(subprocess.run([str(exe)], capture_output=True, check=True).stdout)
     assert outs[0] == outs[1]
+
+
+def test_reference_unit_test_program_runs_on_the_compat_library():
+    """src/fastq_tests.c - the reference's only C test (hash.h + range_list.h, run_tests.sh:512) - compiled from the
+    reference's source against the reference's headers and linked with libfastq_gpu.so (oracle/Makefile): same
+    stdout, stderr and exit status as the same program linked with the reference's own objects.  Needs no GPU."""
+    import subprocess
+
+    a = os.path.join(REPO, "oracle", "_ref", "fastq_tests")
+    b = os.path.join(REPO, "oracle", "_ref", "fastq_tests_on_libfastq_gpu")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref/fastq_tests* not built (needs the reference checkout at build time)")
+    ra = subprocess.run([a], capture_output=True, timeout=60)
+    rb = subprocess.run([b], capture_output=True, timeout=60)
+    assert (ra.returncode, ra.stdout, ra.stderr) == (rb.returncode, rb.stdout, rb.stderr)
+    assert b"Size:3 -[1,100]" in ra.stdout

@@ -148,3 +148,71 @@ def test_oracle_rl_matches_reference_source():
             b.all_out()
         overwrites += b.overwrites
     assert compared > 20000 and overwrites > 100
+
+
+def test_compat_range_list_matches_reference_source():
+    """The range_list.h API exported by libfastq_gpu.so (fastq_utils_amd/compat/range_list_compat.cpp) against the
+    reference's own range_list.c: same answers, sizes and node arrays for ranges of every shape, IN and OUT, rl_all,
+    rl_next_in_bigger.  Sequences that insert out of order are followed while the oracle says the reference has not
+    read memory it never wrote (two heaps hold different garbage there).  Needs no GPU."""
+    so_ref = os.path.join(REPO, "oracle", "_ref", "librange_list_ref.so")
+    so_mine = os.path.join(REPO, "fastq_utils_amd", "libfastq_gpu.so")
+    if not (os.path.exists(so_ref) and os.path.exists(so_mine)):
+        pytest.skip("needs oracle/_ref/librange_list_ref.so and libfastq_gpu.so")
+
+    class RL(C.Structure):
+        _fields_ = [("root", C.POINTER(C.c_uint16)), ("size", C.c_ulong), ("mem", C.c_ulong), ("max", C.c_ulong),
+                    ("root_i", C.c_ulong)]
+    libs = []
+    for path in (so_ref, so_mine):
+        L = C.CDLL(path)
+        L.new_rl.restype = C.POINTER(RL)
+        L.new_rl.argtypes = [C.c_ulong]
+        L.set_in_rl.argtypes = [C.POINTER(RL), C.c_ulong, C.c_int]
+        L.set_in_rl.restype = C.POINTER(RL)
+        L.in_rl.argtypes = [C.POINTER(RL), C.c_ulong]
+        L.in_rl.restype = C.c_short
+        L.rl_all.argtypes = [C.POINTER(RL), C.c_int]
+        L.rl_next_in_bigger.argtypes = [C.POINTER(RL), C.c_ulong]
+        L.rl_next_in_bigger.restype = C.c_ulong
+        libs.append(L)
+    ref, mine = libs
+    ops = 0
+    for seed in range(600):
+        rng = random.Random(seed)
+        mx = rng.choice([2, 17, 64, 100, 1000, 4096, 65536, 100000, 1048576])
+        a, b = ref.new_rl(mx), mine.new_rl(mx)
+        assert (a.contents.size, a.contents.max, a.contents.root_i, a.contents.root[0]) == (
+            b.contents.size, b.contents.max, b.contents.root_i, b.contents.root[0])
+        span = rng.choice([20, mx])
+        base = rng.randrange(1, max(2, mx - span + 2))
+        top = min(mx, base + span)
+        vals = sorted(rng.sample(range(base, top + 1), min(top - base + 1, rng.choice([3, 30, 300]))))
+        monotone = rng.random() < 0.5
+        guide = None
+        if not monotone:
+            rng.shuffle(vals)
+            guide = loader.RLTree(mx)
+        for v in vals:
+            st = 1 if (guide is not None or rng.random() < 0.85) else 0
+            if guide is not None:
+                if v not in guide:
+                    guide.insert(v)
+                if guide.undefined_reads:
+                    break
+            assert ref.in_rl(a, v) == mine.in_rl(b, v)
+            ref.set_in_rl(a, v, st)
+            mine.set_in_rl(b, v, st)
+            assert a.contents.size == b.contents.size
+            if guide is None:
+                assert all(a.contents.root[i] == b.contents.root[i] for i in range(a.contents.size))
+                q = rng.randrange(0, mx + 2)
+                assert ref.rl_next_in_bigger(a, q) == mine.rl_next_in_bigger(b, q)
+            ops += 1
+        if guide is None:
+            for st in (1, 0):
+                ref.rl_all(a, st)
+                mine.rl_all(b, st)
+                for v in rng.sample(range(1, mx + 1), min(mx, 20)):
+                    assert ref.in_rl(a, v) == mine.in_rl(b, v)
+    assert ops > 15000
