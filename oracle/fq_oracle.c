@@ -41,6 +41,8 @@ typedef struct {
   void *owned[64]; /* heap blocks released when the run ends, whichever way it ends */
   int n_owned;
   struct nameset_s *idx;
+  void *map[2]; /* fastq_filterpair's indexes */
+  sink_t files[3]; /* ... and its three outputs (in the heap block: read again after the longjmp) */
 } run_t;
 
 static void *own(run_t *r, void *p) {
@@ -746,6 +748,253 @@ static void run_fastq_info(run_t *r, const fqo_job *job, fqo_summary *sum) {
   eprintf(r, "Read length: %lu %lu %u\n", min_rl - 1, max_rl - 1, med - 1);
   eprintf(r, "OK\n");
   leave(r, 0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fastq_filterpair (src/fastq_filterpair.c:38-228)
+ * ---------------------------------------------------------------------------------------- */
+/* name -> entry_start (INDEX_ENTRY, src/fastq.h:91-95): the index of fastq_index_readnames with the offsets the
+ * pairing loop hands to fastq_quick_copy_entry */
+typedef struct {
+  char **name;
+  long long *start;
+  size_t cap, live;
+} namemap;
+static void nm_init(namemap *m, size_t cap) {
+  m->cap = cap;
+  m->live = 0;
+  m->name = (char **)calloc(cap, sizeof(char *));
+  m->start = (long long *)calloc(cap, sizeof(long long));
+}
+static void nm_free(namemap *m) {
+  for (size_t i = 0; i < m->cap; ++i)
+    if (m->name[i] && m->name[i] != TOMB) free(m->name[i]);
+  free(m->name);
+  free(m->start);
+}
+static long nm_find(const namemap *m, const char *s) {
+  size_t i = fnv(s) & (m->cap - 1);
+  while (m->name[i]) {
+    if (m->name[i] != TOMB && !strcmp(m->name[i], s)) return (long)i;
+    i = (i + 1) & (m->cap - 1);
+  }
+  return -1;
+}
+static void nm_add(namemap *m, const char *s, long long start) {
+  size_t i = fnv(s) & (m->cap - 1);
+  while (m->name[i]) i = (i + 1) & (m->cap - 1);
+  m->name[i] = strdup(s);
+  m->start[i] = start;
+  m->live++;
+}
+static void nm_del(namemap *m, long i) {
+  free(m->name[i]);
+  m->name[i] = TOMB;
+  m->live--;
+}
+static size_t count_newlines(const unsigned char *b, size_t n) {
+  size_t c = 0;
+  for (size_t i = 0; i < n; ++i) c += b[i] == '\n';
+  return c;
+}
+/* fastq_index_readnames (src/fastq.c:396-439) into a namemap */
+static void index_readnames_map(run_t *r, file_t *f, namemap *idx) {
+  entry_t *e = entry_new(r);
+  char namebuf[FQG_MAX_LABEL_LENGTH + 8];
+  unsigned long len;
+  while (!f->gz.past) {
+    if (read_next_entry(r, f, e) == 0) break;
+    uint64_t rec = f->cline / 4 - 1;
+    char *name = get_readname(r, f, e, namebuf + 8, &len, 1);
+    if (nm_find(idx, name) >= 0) {
+      ERR_OPEN(r);
+      eprintf(r, "Error in file %s: line %lu: duplicated sequence %s", f->filename, f->cline, name);
+      ERR_CLOSE(r);
+      note(r, FQG_E_DUP_NAME, rec, f->cline, 0, 0);
+      leave(r, 3);
+    }
+    char stored[FQG_MAX_LABEL_LENGTH + 1];
+    strncpy(stored, name, len);
+    stored[len] = '\0';
+    nm_add(idx, stored, e->offset);
+    r->index_mem += 16 + len + 1 + 24;
+    if (validate_entry(r, f, e, rec) != 0) leave(r, 3);
+    progress(r, f->cline / 4, 100000);
+  }
+}
+static void put_entry(sink_t *o, const entry_t *e) { /* fastq_write_entry, src/fastq.c:265-272 */
+  const char *l[4] = {e->hdr1, e->seq, e->hdr2, e->qual};
+  for (int i = 0; i < 4; ++i) {
+    size_t n = strlen(l[i]);
+    if (o->n + n + 1 > o->cap) {
+      size_t cap = o->cap ? o->cap * 2 : 65536;
+      while (cap < o->n + n + 1) cap *= 2;
+      o->p = (char *)realloc(o->p, cap);
+      o->cap = cap;
+    }
+    memcpy(o->p + o->n, l[i], n);
+    o->n += n;
+  }
+}
+static void mg_rewind(file_t *f) { /* fastq_rewind, src/fastq.c:77-80 */
+  f->cline = 1;
+  f->gz.pos = 0;
+  f->gz.past = 0;
+}
+static void run_filterpair(run_t *r, const fqo_job *job, sink_t out[3]) {
+  int argc = 6 + ((job->flags & FQO_FLAG_S) ? 1 : 0);
+  eprintf(r, "%d", argc);
+  file_t *fd1 = file_new(r, job->buf1, job->n1, job->name1);
+  fd1->is_pe = 1;
+  file_t *fd2 = file_new(r, job->buf2, job->n2, job->name2);
+  fd2->is_pe = 1;
+  int sorted = (job->flags & FQO_FLAG_S) != 0;
+  eprintf(r, "HASHSIZE=%u\n", 100000001u);
+  if (sorted) eprintf(r, "Assuming sorted fastq files\n");
+  namemap *idx = (namemap *)own(r, calloc(1, sizeof(namemap))), *idx2 = NULL;
+  size_t cap = 1024;
+  while (cap < count_newlines(job->buf1, job->n1)) cap <<= 1;
+  nm_init(idx, cap);
+  r->map[0] = idx;
+  r->index_mem += 8;
+  eprintf(r, "Scanning and indexing all reads from %s\n", fd1->filename);
+  index_readnames_map(r, fd1, idx);
+  eprintf(r, "Scanning complete.\n");
+  eprintf(r, "Reads indexed: %llu\n", (unsigned long long)idx->live);
+  eprintf(r, "Memory used in indexing: %ld MB\n", (long)(r->index_mem / 1024 / 1024));
+  unsigned long up2 = 0, paired = 0;
+  entry_t *m1 = entry_new(r), *m2 = entry_new(r), *tmp = entry_new(r);
+  char namebuf[FQG_MAX_LABEL_LENGTH + 8];
+  unsigned long len;
+  if (sorted) {
+    idx2 = (namemap *)own(r, calloc(1, sizeof(namemap)));
+    cap = 1024;
+    while (cap < count_newlines(job->buf2, job->n2)) cap <<= 1;
+    nm_init(idx2, cap);
+    r->map[1] = idx2;
+    r->index_mem += 8;
+    eprintf(r, "Scanning and indexing all reads from %s\n", fd2->filename);
+    index_readnames_map(r, fd2, idx2);
+    eprintf(r, "Scanning complete.\n");
+    eprintf(r, "Reads indexed: %llu\n", (unsigned long long)idx2->live);
+    eprintf(r, "Memory used in indexing: %ld MB\n", (long)(r->index_mem / 1024 / 1024));
+    mg_rewind(fd1);
+    mg_rewind(fd2);
+    file_t *fs[2] = {fd1, fd2};
+    namemap *other[2] = {idx2, idx};
+    for (int s = 0; s < 2; ++s) {
+      file_t *f = fs[s];
+      eprintf(r, "Filtering %s...\n", f->filename);
+      while (!f->gz.past) {
+        if (read_next_entry(r, f, m2) == 0) break;
+        char *name = get_readname(r, f, m2, namebuf + 8, &len, 1);
+        long at = nm_find(other[s], name);
+        if (at < 0) {
+          ++up2;
+          put_entry(&out[2], m2);
+        } else {
+          if (s == 0) ++paired;
+          put_entry(&out[s], m2);
+          nm_del(other[s], at);
+        }
+        progress(r, f->cline / 4, 10000);
+      }
+    }
+  } else {
+    mg_rewind(fd1);
+    eprintf(r, "Processing %s\n", fd2->filename);
+    unsigned long ctr_seek = 0, ctr_noseek = 0;
+    while (!fd2->gz.past) {
+      if (read_next_entry(r, fd2, m2) == 0) break;
+      char *name = get_readname(r, fd2, m2, namebuf + 8, &len, 1);
+      long at = nm_find(idx, name);
+      if (at < 0) {
+        ++up2;
+        put_entry(&out[2], m2);
+      } else {
+        ++paired;
+        put_entry(&out[1], m2);
+        /* fastq_quick_copy_entry, src/fastq.c:125-157 */
+        long long off = idx->start[at];
+        if ((long long)fd1->gz.pos != off) {
+          fd1->gz.pos = (size_t)off;
+          fd1->gz.past = 0;
+          ++ctr_seek;
+        } else ++ctr_noseek;
+        eprintf(r, "%lu / %lu\n", ctr_seek, ctr_noseek);
+        if (fd1->gz.past) {
+          ERR_OPEN(r);
+          eprintf(r, "Error in file %s: line %lu: premature eof", fd1->filename, fd1->cline);
+          ERR_CLOSE(r);
+          leave(r, 3);
+        }
+        mg_line(&fd1->gz, tmp->hdr1, FQG_MAX_LABEL_LENGTH);
+        int bad = tmp->hdr1[0] == '\0';
+        if (!bad) {
+          mg_line(&fd1->gz, tmp->seq, FQG_MAX_READ_LENGTH);
+          mg_line(&fd1->gz, tmp->hdr2, FQG_MAX_LABEL_LENGTH);
+          mg_line(&fd1->gz, tmp->qual, FQG_MAX_READ_LENGTH);
+          bad = tmp->seq[0] == '\0' || tmp->hdr2[0] == '\0' || tmp->qual[0] == '\0';
+        }
+        if (bad) {
+          ERR_OPEN(r);
+          eprintf(r, "Error in file %s: line %lu: file truncated", fd1->filename, fd1->cline);
+          ERR_CLOSE(r);
+          leave(r, 3);
+        }
+        put_entry(&out[0], tmp);
+        nm_del(idx, at);
+      }
+      progress(r, fd2->cline / 4, 10000);
+    }
+    eprintf(r, "\n");
+    eprintf(r, "Recording %llu unpaired reads from %s\n", (unsigned long long)idx->live, job->name1);
+    unsigned long remaining = idx->live;
+    while (!fd1->gz.past && remaining) {
+      if (read_next_entry(r, fd1, m1) == 0) break;
+      char *name = get_readname(r, fd1, m1, namebuf + 8, &len, 1);
+      if (nm_find(idx, name) >= 0) {
+        put_entry(&out[2], m1);
+        remaining--;
+      }
+      progress(r, fd1->cline / 4, 100000);
+    }
+    eprintf(r, "Unpaired from %s: %llu\n", job->name1, (unsigned long long)idx->live);
+    eprintf(r, "Unpaired from %s: %ld\n", job->name2, (long)up2);
+  }
+  eprintf(r, "\n");
+  eprintf(r, "Paired: %ld\n", (long)paired);
+  if (paired == 0) {
+    eprintf(r, "!!!WARNING!!! 0 paired reads! are the headers ok?\n");
+    leave(r, 3);
+  }
+  leave(r, 0);
+}
+
+/* job: buf1/buf2 = the two inputs (decompressed), flags & FQO_FLAG_S = the 7th argument "sorted".  The three
+ * outputs (paired1, paired2, unpaired: what the reference gzips) come back uncompressed in out[0..2]. */
+int fqo_fastq_filterpair(const fqo_job *job, fqo_result *res, char *out[3], size_t out_len[3]) {
+  run_t *r = (run_t *)calloc(1, sizeof(run_t));
+  sink_t *o = r->files;
+  memset(res, 0, sizeof(*res));
+  eprintf(r, "fastq_utils %s\n", "0.25.3");
+  if (setjmp(r->bail) == 0) run_filterpair(r, job, r->files);
+  o = r->files;
+  for (int k = 0; k < 2; ++k)
+    if (r->map[k]) nm_free((namemap *)r->map[k]);
+  for (int i = 0; i < r->n_owned; ++i) free(r->owned[i]);
+  res->exit_status = r->status;
+  res->first = r->first;
+  res->out = r->out.p ? r->out.p : strdup("");
+  res->out_len = r->out.n;
+  res->err = r->err.p ? r->err.p : strdup("");
+  res->err_len = r->err.n;
+  for (int k = 0; k < 3; ++k) {
+    out[k] = o[k].p ? o[k].p : strdup("");
+    out_len[k] = o[k].n;
+  }
+  free(r);
+  return res->exit_status;
 }
 
 int fqo_fastq_info(const fqo_job *job, fqo_result *res) {

@@ -60,6 +60,8 @@ typedef struct {
 } fqo_result;
 
 int fqo_fastq_info(const fqo_job *job, fqo_result *res);
+/* fastq_filterpair (src/fastq_filterpair.c:38-228) on two images; flags & FQO_FLAG_S = the argument "sorted" */
+int fqo_fastq_filterpair(const fqo_job *job, fqo_result *res, char *out[3], size_t out_len[3]);
 void fqo_result_free(fqo_result *res);
 const char *fqo_qual_range_to_enc(unsigned int min_qual, unsigned int max_qual);
 

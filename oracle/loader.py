@@ -147,6 +147,27 @@ def rl_replay(tree_of, umi, epoch, incr, n_trees):
     return is_new, tuple(int(x) for x in stats)
 
 
+def fastq_filterpair(buf1, name1, buf2, name2, sorted_mode=False):
+    """The restated fastq_filterpair (oracle/fq_oracle.c) on two decompressed images.
+    Returns dict(exit, stderr, stdout, files=[paired1, paired2, unpaired] uncompressed)."""
+    L = lib()
+    L.fqo_fastq_filterpair.argtypes = [C.POINTER(Job), C.POINTER(Result), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    job = Job(buf1, len(buf1), name1.encode(), buf2, len(buf2), name2.encode(), ARG2_FILE, FLAG_S if sorted_mode else 0)
+    res = Result()
+    outs = (C.c_void_p * 3)()
+    lens = (C.c_size_t * 3)()
+    L.fqo_fastq_filterpair(C.byref(job), C.byref(res), outs, lens)
+    d = {"exit": res.exit_status, "stdout": C.string_at(res.out, res.out_len).decode("latin-1"),
+         "stderr": C.string_at(res.err, res.err_len).decode("latin-1"),
+         "files": [C.string_at(outs[k], lens[k]) for k in range(3)]}
+    L.fqo_result_free(C.byref(res))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for k in range(3):
+        libc.free(outs[k])
+    return d
+
+
 def parse_args(args):
     """Split a fastq_info argv (without argv[0]) the way the reference does
     (src/fastq_info.c:214-267): flags first, then one or two positionals."""
