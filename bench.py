@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-umi-extra", action="store_true",
                     help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
     ap.add_argument("--umi-triples", type=int, default=5_000_000)
+    ap.add_argument("--no-shapes-extra", action="store_true",
+                    help="skip the validate pass on mixed-length short reads and on ONT-like long reads")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-fed measurement (the same reads from pinned host RAM / from a tmpfs file)")
     return ap.parse_args()
@@ -337,6 +339,7 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
                 assert ("Number of reads: %d" % n).encode() in p.stderr, p.stderr[-300:]
             med = sorted(runs)[1]
             threads = min(32, os.cpu_count() or 1)
+            out["negative_controls"] = negative_controls(exe, path, arr, n, R)
             out["cli_fastq_info_r_tmpfs_file"] = {
                 "seconds_median_of_3": med, "seconds": runs, "Mreads_per_s": n / med / 1e6, "GBps": nbytes / med / 1e9,
                 "stager": f"3 pinned slots of 256 MiB, {threads} pread threads per slot (FQGPU_CHUNK_MB / FQGPU_HOST_THREADS)",
@@ -347,6 +350,118 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
     else:
         out["cli_fastq_info_r_tmpfs_file"] = {"skipped": "no bin/fastq_info or not enough room in /dev/shm"}
     return out
+
+
+def shapes_extra(ctx, fq, torch, dev, target_bytes=8 << 30):
+    """The validate pass on inputs that are less friendly to the single-pass kernels than fixed 150 bp reads:
+    (a) short reads of mixed length (30-150 bp), (b) ONT-like reads of 2-20 kb, where most 4 KiB chunks hold no
+    "+" line, so the line type cannot be speculated and the chunks are re-checked once their rank is known
+    (k_stream_redo).  A seeded 64 MiB block generated on the host is repeated in HBM up to `target_bytes` (names
+    repeat: this is the -r pass, which does not look at them)."""
+    import numpy as np
+
+    out = {}
+    for tag, lo, hi in (("short_reads_30_150bp", 30, 150), ("long_reads_2_20kb", 2000, 20000)):
+        rng = np.random.default_rng(99)
+        parts, size, i = [], 0, 0
+        while size < (64 << 20):
+            L = int(rng.integers(lo, hi + 1))
+            seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].tobytes()
+            qual = (rng.integers(2, 41, L) + 33).astype(np.uint8).tobytes()
+            r = b"@SHP:1:FC:1:%d:%d:%d 1:N:0:ACGT\n" % (i % 97, L, i) + seq + b"\n+\n" + qual + b"\n"
+            parts.append(r)
+            size += len(r)
+            i += 1
+        block = b"".join(parts)
+        reps = max(1, target_bytes // len(block))
+        tb = torch.frombuffer(bytearray(block), dtype=torch.uint8).to(dev)
+        image = tb.repeat(reps)
+        del tb
+        n_reads = i * reps
+        st = fq.abi.probe_first_record(block[:100000], True)
+        acc = ctx.accumulator()
+        ctx.validate(image.data_ptr(), acc, st, final=True, nbytes=image.numel())  # warm-up
+        acc.reset()
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        steps = 3
+        for _ in range(steps):
+            r = ctx.validate(image.data_ptr(), acc, st, final=True, nbytes=image.numel())
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        prof = {k: v[1] / steps for k, v in ctx.profile_read().items() if k.startswith("k_") and v[0] > 0}
+        ctx.profile(False)
+        s_ = acc.read()
+        ok = r["code"] == 0 and r["n_records"] == n_reads and s_["num_rds"] == n_reads * steps and \
+            s_["min_rl"] >= lo + 1 and s_["max_rl"] <= hi + 1
+        kms = sum(prof.values())
+        out[tag] = {"reads": n_reads, "bytes": int(image.numel()), "ms_per_pass": dt * 1e3, "Mreads_per_s": n_reads / dt / 1e6,
+                    "GBps_wall": image.numel() / dt / 1e9, "kernels_ms_per_pass": prof, "GBps_kernels_only": image.numel() / (kms * 1e-3) / 1e9,
+                    "path": r["path"], "ok": bool(ok)}
+        acc.close()
+        del image
+        torch.cuda.empty_cache()
+    return out
+
+
+def negative_controls(exe, path, arr, n, R):
+    """SURVEY 8(d)-2 at full size: one bad base / one duplicated name injected into the tmpfs file (a few bytes
+    written in place, restored afterwards); the drop-in program must stop with the error line the oracle prints for
+    the same defect (the oracle reads a 3-record window around it; only the line number is shifted)."""
+    from oracle import loader as orc  # the checker, not the thing measured
+
+    res = {}
+    k = n - 12345 if n > 20000 else n // 2          # deep into the file
+    rec = lambda i: bytes(arr[i * R:(i + 1) * R])
+
+    def oracle_line(window, first_record, flags):
+        o = orc.fastq_info(window, path, flags=flags)
+        line = [ln for ln in o["stderr"].splitlines() if ln.startswith("ERROR:")]
+        if not line:
+            return None
+        import re
+        return re.sub(r"line (\d+)", lambda m: "line %d" % (int(m.group(1)) + 4 * first_record), line[0])
+
+    def patched(offset, data, args, flags, window_first, window):
+        with open(path, "r+b") as f:
+            f.seek(offset)
+            old = f.read(len(data))
+            f.seek(offset)
+            f.write(data)
+        try:
+            p = subprocess.run([exe] + args + [path], capture_output=True)
+        finally:
+            with open(path, "r+b") as f:
+                f.seek(offset)
+                f.write(old)
+        got = [ln for ln in p.stderr.decode("latin-1").splitlines() if ln.startswith("ERROR:")]
+        want = oracle_line(window, window_first, flags)
+        return {"exit": p.returncode, "line": got[0] if got else None, "oracle_line": want,
+                "same_line_as_oracle": bool(got) and got[0] == want and p.returncode == 3}
+
+    # (a) a base outside the alphabet in the middle of record k's sequence
+    r0 = rec(k)
+    seq_at = r0.index(b"\n") + 1 + 70
+    bad = bytearray(rec(k - 1) + r0 + rec(k + 1))
+    bad[R + seq_at] = ord("X")
+    res["bad_base"] = patched(k * R + seq_at, b"X", ["-r"], orc.FLAG_R, k - 1, bytes(bad))
+    res["bad_base"]["record"] = k
+    # (b) record k gets the name of record j: the unique-name index must report k
+    j = k - 777
+    hdr = rec(j)[: rec(j).index(b"\n")]
+    if len(hdr) == r0.index(b"\n"):
+        win = bytearray(rec(j) + rec(k - 1) + r0)
+        win[2 * R:2 * R + len(hdr)] = hdr
+        d = patched(k * R, hdr, [], 0, 0, bytes(win))
+        # the window holds records j, k-1, k as records 0, 1, 2: its line 12 is line 4 (k + 1) of the file
+        if d["oracle_line"]:
+            d["oracle_line"] = d["oracle_line"].replace("line 12:", "line %d:" % (4 * (k + 1)))
+            d["same_line_as_oracle"] = d["line"] == d["oracle_line"] and d["exit"] == 3
+        d["records"] = [j, k]
+        res["duplicate_name"] = d
+    return res
 
 
 def umi_extra(ctx, torch, dev, n_triples):
@@ -593,7 +708,7 @@ def main():
         if rank == 0:
             out["dedup_extra"] = {"error": "timed out (watchdog) - the headline numbers above are unaffected"}
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)  # the headline line is out, but the run did not complete: not a success
 
     watchdog = None
     if not a.no_dedup_extra and world > 1:
@@ -698,8 +813,14 @@ def main():
                 out["filters_extra"] = filters_extra(ctx, fq, torch, dev, image, n, R, st, a.read_len)
             except Exception as e:
                 out["filters_extra"] = {"error": repr(e)[:300]}
-        if world == 1 and not (a.no_umi_extra and a.no_barcodes_extra):
+        if world == 1 and not (a.no_umi_extra and a.no_barcodes_extra and a.no_shapes_extra):
             del image
+            torch.cuda.empty_cache()
+        if world == 1 and not a.no_shapes_extra:
+            try:
+                out["read_shapes_extra"] = shapes_extra(ctx, fq, torch, dev)
+            except Exception as e:
+                out["read_shapes_extra"] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
         if world == 1 and not a.no_barcodes_extra:
             try:
@@ -717,7 +838,7 @@ def main():
         # every rank has what it needs; a rank that failed in the extra must not keep the others waiting in a
         # collective tear-down
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(4 if (dedup is not None and "error" in dedup) else 0)
     acc.close()
     ctx.close()
 

@@ -455,22 +455,34 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass2(const uint8_t* __restri
     for (uint32_t i = kWave + lane; i < tot[b]; i += kWave)  // more than 64 newlines in 4 KiB: rare
       entry(c0 + b, r0[b], i, stage[(uint64_t)(c0 + b) * kStageCap + i]);
   }
-  if (lane < kP2Batch && mine < n_chunks) {
+  const bool own = lane < kP2Batch && mine < n_chunks;
+  bool again = false;
+  if (own) {
     if (mine == 0 && limit > 0 && (img[0] != '@' || (n > 1 && img[1] == '\n'))) mark_suspect(suspect, 0);
     // only chunks that hold bytes of complete records need their byte checks to stand
     if (rank0 < limit) {
       // (a chunk that reaches beyond the last complete record is repeated too: its quality range may
       // include bytes of an incomplete record)
-      if ((info & kInfoUnknown) || (info & 3u) != ((uint32_t)rank0 & 3u) || rank0 + cnt >= limit) {
-        const uint32_t at = atomicAdd(&cs->redo_count, 1u);
-        if (at < n_chunks) redo[at] = mine;
-      } else if (info & kInfoRange) {
+      if ((info & kInfoUnknown) || (info & 3u) != ((uint32_t)rank0 & 3u) || rank0 + cnt >= limit) again = true;
+      else if (info & kInfoRange) {
         atomicMin(&cs->qmin_byte, (info >> 8) & 0xFFu);
         atomicMax(&cs->qmax_byte, (info >> 16) & 0xFFu);
       }
     }
     if (mine == n_chunks - 1 && n > 0 && !cs->last_byte_is_nl && cs->n_newlines < line_cap)
       line_end[cs->n_newlines] = n;
+  }
+  // the redo list: one reservation per wavefront (long reads send EVERY chunk here - no "+" line in 4 KiB to
+  // speculate from - and two million single adds to one address took longer than the rest of the kernel)
+  const unsigned long long am = __ballot(again);
+  if (am) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cs->redo_count, (uint32_t)__builtin_popcountll(am));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (again) {
+      const uint32_t at = base + (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
+      if (at < n_chunks) redo[at] = mine;
+    }
   }
 }
 

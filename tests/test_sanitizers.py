@@ -1,0 +1,99 @@
+"""ASan / UBSan (and TSan for the reader thread) builds of the CPU-side C / C++ of this repository (SURVEY section 5,
+sanitizer row): the oracle restatements (oracle/fq_oracle.c, rl_oracle.c), the container code of libfastq_gpu.so that
+needs no GPU (compat/range_list_compat.cpp), the host-side (de)compression (host/fq_parallel.h) and the host stager
+(host/fq_input.h).  Each is compiled with a small driver under tests/cxx/ and must run clean."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, REPO, read_image
+
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+CXX = os.path.join(REPO, "tests", "cxx")
+
+
+def build(tmp, name, cc, srcs, extra=()):
+    exe = str(tmp / name)
+    subprocess.run([cc] + SAN + list(extra) + ["-o", exe] + srcs, check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def tmpdir(tmp_path_factory):
+    return tmp_path_factory.mktemp("san")
+
+
+def test_oracle_c_restatements_run_clean(tmpdir):
+    exe = build(tmpdir, "oracle_san", "gcc", ["-std=gnu11", os.path.join(CXX, "oracle_sanitize.c"),
+                                               os.path.join(REPO, "oracle", "fq_oracle.c"), os.path.join(REPO, "oracle", "rl_oracle.c")])
+    names = ["test_21_1.fastq.gz", "test_21_2.fastq.gz", "test_e9.fastq.gz", "test_e3.fastq.gz", "test_e5.fastq.gz",
+             "casava.1.8i.fastq.gz", "test_solid_1.fastq.gz", "nanopore_rna2.fastq.gz", "test_empty.fastq.gz",
+             "c18_10000_1.fastq.gz", "c18_10000_2.fastq.gz", "syn_fp_1.fastq", "syn_fp_2.fastq", "syn_fp_2_noat.fastq"]
+    plain = {}
+    for n in names:
+        p = tmpdir / (n + ".txt")
+        p.write_bytes(read_image(os.path.join(GOLD, "data", n)))
+        plain[n] = str(p)
+    for n in names:
+        p = subprocess.run([exe, "info", plain[n]], env=ENV, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+    for a, b in (("test_21_1.fastq.gz", "test_21_2.fastq.gz"), ("c18_10000_1.fastq.gz", "c18_10000_2.fastq.gz")):
+        p = subprocess.run([exe, "info", plain[a], plain[b]], env=ENV, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+    for a, b in (("syn_fp_1.fastq", "syn_fp_2.fastq"), ("syn_fp_2.fastq", "syn_fp_1.fastq"), ("syn_fp_1.fastq", "syn_fp_2_noat.fastq"),
+                 ("c18_10000_1.fastq.gz", "c18_10000_2.fastq.gz"), ("test_e9.fastq.gz", "test_21_1.fastq.gz")):
+        p = subprocess.run([exe, "pair", plain[a], plain[b]], env=ENV, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+    p = subprocess.run([exe, "rl"], env=ENV, capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith(b"rl "), p.stderr.decode()[-2000:]
+
+
+def test_compat_range_list_runs_clean(tmpdir):
+    exe = build(tmpdir, "compat_san", "g++", ["-std=c++17", os.path.join(CXX, "compat_sanitize.cpp"),
+                                               os.path.join(REPO, "fastq_utils_amd", "compat", "range_list_compat.cpp")])
+    p = subprocess.run([exe], env=ENV, capture_output=True, timeout=300)
+    assert p.returncode == 0 and b"members seen" in p.stdout, p.stderr.decode()[-2000:]
+
+
+def test_host_parallel_compression_runs_clean(tmpdir):
+    exe = build(tmpdir, "hp_san", "g++", ["-std=c++17", "-pthread", os.path.join(CXX, "host_parallel_check.cpp")], extra=["-lz"])
+    rng = np.random.default_rng(3)
+    src = tmpdir / "in.txt"
+    src.write_bytes(bytes(rng.choice(np.frombuffer(b"ACGTN\n@+IIFF#", dtype=np.uint8), 3_000_000).astype(np.uint8)))
+    dst = tmpdir / "out.gz"
+    p = subprocess.run([exe, "gz", str(src), str(dst), "4"], env=dict(ENV, FQGPU_HOST_THREADS="4"), capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert gzip.decompress(dst.read_bytes()) == src.read_bytes()
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_host_input_stager_runs_clean(tmpdir, san):
+    flags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g", "-O1"]
+    exe = str(tmpdir / ("input_" + san.split(",")[0]))
+    subprocess.run(["g++", "-std=c++17", "-pthread"] + flags + ["-o", exe, os.path.join(CXX, "input_sanitize.cpp"), "-lz"], check=True)
+    rng = np.random.default_rng(11)
+    lines = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(1, 400))).astype(np.uint8)) for _ in range(20000)]
+    data = b"\n".join(lines) + b"\n"
+    plain = tmpdir / "x.txt"
+    plain.write_bytes(data)
+    gz = tmpdir / "x.txt.gz"
+    gz.write_bytes(gzip.compress(data, 1))
+    empty = tmpdir / "empty.txt"
+    empty.write_bytes(b"")
+
+    def fnv(b):
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    want = ("%d %d" % (len(data), fnv(data))).encode()
+    for path, wanted in ((plain, want), (gz, want), (empty, ("0 %d" % fnv(b"")).encode())):
+        for piece in ("4096", "100000", "50000000"):
+            for mode in ("0", "1", "2"):
+                p = subprocess.run([exe, str(path), piece, mode], env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"),
+                                   capture_output=True, timeout=300)
+                assert p.returncode == 0 and p.stdout.strip() == wanted, (path, piece, mode, p.stdout, p.stderr.decode()[-1500:])
