@@ -501,6 +501,7 @@ struct Framed {
   bool last_nl = false;
   uint32_t img_flags = 0;
   bool checks_done = false;  // the byte-class checks of the tiled path ran over the image
+  bool records_done = false; // lengths, statistics and suspect bits of every record are done too (k_stream_lines)
 };
 
 void init_call_state(fqg_ctx* c) {
@@ -569,8 +570,15 @@ constexpr uint64_t kStreamQueueCap = 1ull << 20;
 // One pass over the image (see fqg_stream_kernels.hip).  Returns 1 when the image is not eligible
 // (NUL / CR bytes, bytes >= 0x80, more newlines per chunk than the staging area holds): the caller
 // then runs frame_two_pass, which also decides about the exact path.
+struct RecordDuties {  // what k_stream_lines needs from the caller of frame_stream
+  int space;
+  uint32_t weight;
+  AccState* acc;
+  unsigned long long* hist;
+};
+
 int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_chunks, bool final, SuspectMap sm,
-                 Framed* out) {
+                 const RecordDuties& rd, Framed* out) {
   int rc;
   const uint32_t n_spans = (n_chunks + kScanSpan - 1) / kScanSpan;
   if ((rc = ensure(c, c->tile_counts, (size_t)n_chunks * 4))) return rc;
@@ -616,13 +624,60 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
   const uint64_t line_cap = n_lines_all + 17;
   const uint64_t limit = 4 * (usable / 4);
   if ((rc = ensure(c, c->line_end, (size_t)line_cap * 8))) return rc;
-  {
+  static const bool old_pass2 = getenv("FQGPU_STREAM_PASS2_OLD") != nullptr;  // (A/B: the chunk-owned second pass)
+  if (old_pass2) {
     ProfScope ps(c, "k_stream_pass2");
     const unsigned per_wg = (kBlock / kWave) * kP2Batch;
     hipLaunchKernelGGL(k_stream_pass2, dim3((n_chunks + per_wg - 1) / per_wg), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
                        (const uint32_t*)c->tile_counts.p, (const uint32_t*)c->cinfo.p, (const uint16_t*)c->stage.p,
                        (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
                        (uint64_t*)c->line_end.p, line_cap, limit, sm, (uint32_t*)c->redo.p, c->d_cs);
+  } else {
+    ChunkRanks cr;
+    cr.counts = (const uint32_t*)c->tile_counts.p;
+    cr.local = (const uint32_t*)c->tile_local.p;
+    cr.span_excl = (const unsigned long long*)c->span_sums.p;
+    cr.n_chunks = n_chunks;
+    {
+      ProfScope ps(c, "k_stream_chunks");
+      hipLaunchKernelGGL(k_stream_chunks, dim3((n_chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, cr,
+                         (const uint32_t*)c->cinfo.p, limit, (uint32_t*)c->redo.p, c->d_cs);
+    }
+    LinesArgs A;
+    A.img = d_img;
+    A.n = nbytes;
+    A.cr = cr;
+    A.stage = (const uint16_t*)c->stage.p;
+    A.line_end = (uint64_t*)c->line_end.p;
+    A.line_cap = line_cap;
+    A.n_newlines = out->n_newlines;
+    A.n_lines = n_lines_all;
+    A.limit = limit;
+    A.suspect_bits = sm.bits;
+    A.suspect_cap = sm.cap;
+    A.flags = sm.flags;
+    A.space = rd.space;
+    A.weight = rd.weight;
+    A.acc = rd.acc;
+    A.hist = rd.hist;
+    static const int lines_abl = getenv("FQGPU_LINES_ABL") ? atoi(getenv("FQGPU_LINES_ABL")) : 0;
+    A.ablate = lines_abl;
+    {
+      ProfScope ps(c, "k_stream_lines");
+      const uint64_t groups = (n_lines_all + 4 * kWave - 1) / (4 * kWave);
+      // a persistent grid: every workgroup must be resident from the start (one that is not would do its whole
+      // share after the others have finished)
+      static int per_cu = 0;
+      if (!per_cu) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines), kBlock, 0) != hipSuccess || nb < 1)
+          nb = 4;
+        per_cu = nb;
+      }
+      const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)c->cu_count * per_cu));
+      hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A);
+    }
+    out->records_done = true;
   }
   {
     ProfScope ps(c, "k_stream_queue");
@@ -692,7 +747,8 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   Framed fr;
   bool streamed = false;
   if (want_checks && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS)) {
-    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, &fr);
+    RecordDuties rd{st->space, weight, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr};
+    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, &fr);
     if (rc < 0) return rc;
     streamed = rc == 0;
     if (!streamed) HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(sm.cap / 32 + 2) * 4, c->stream));
@@ -757,7 +813,13 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
       if ((rc = ensure(c, c->list, (size_t)list_cap * 8))) return rc;
       const unsigned grid_r =
           (unsigned)std::min<uint64_t>((n_records + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 8);
-      {
+      if (fr.records_done) {
+        ProfScope ps(c, "k_suspect_list");
+        hipLaunchKernelGGL(k_suspect_list, dim3((unsigned)std::min<uint64_t>((n_records / 32 + kBlock) / kBlock, 1024)), dim3(kBlock), 0,
+                           c->stream, (const uint32_t*)sm.bits, std::min<uint64_t>(n_records, sm.cap),
+                           (unsigned long long*)c->list.p, list_cap, &c->d_cs->list_count, acc ? acc->d_state : nullptr,
+                           (const CallState*)c->d_cs);
+      } else {
         ProfScope ps(c, "k_records_fast");
         hipLaunchKernelGGL(k_records_fast, dim3(grid_r), dim3(kBlock), 0, c->stream, fv, st->space, weight, sm,
                            (unsigned long long*)c->list.p, list_cap, &c->d_cs->list_count,

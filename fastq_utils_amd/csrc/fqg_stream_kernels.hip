@@ -486,6 +486,323 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass2(const uint8_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// pass 2, second form: the per-chunk duties (k_stream_chunks) and the per-line / per-record duties
+// (k_stream_lines) separately.  k_stream_pass2 above walks the image chunk by chunk, so a wavefront's
+// line_end[] stores start wherever its first chunk's rank happens to fall, and the per-record statistics
+// needed a further pass over the 32 B / record it had just written (k_records_fast).  Here a LANE OWNS A
+// RECORD: it fetches the five staged entries that bound its four lines (2-byte loads, neighbouring lanes
+// neighbouring addresses), writes the record's four line ends as one aligned 32-byte piece (a wavefront writes
+// 2 KiB, aligned), checks the header starts, and derives the lengths, the statistics and the suspect bit from
+// registers - the line index is written once and not read again.
+// ------------------------------------------------------------------------------------------
+struct ChunkRanks {
+  const uint32_t* counts;              // newlines per chunk
+  const uint32_t* local;               // exclusive prefix inside a span of kScanSpan chunks
+  const unsigned long long* span_excl; // exclusive prefix over the spans
+  uint32_t n_chunks;
+  __device__ __forceinline__ uint64_t rank0(uint32_t c) const { return span_excl[c / kScanSpan] + local[c]; }
+};
+
+__global__ __launch_bounds__(kBlock) void k_stream_chunks(ChunkRanks cr, const uint32_t* __restrict__ cinfo, uint64_t limit,
+                                                          uint32_t* __restrict__ redo, CallState* __restrict__ cs) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = lane_id();
+  bool again = false;
+  if (c < cr.n_chunks) {
+    const uint64_t rank0 = cr.rank0(c);
+    const uint32_t cnt = cr.counts[c], info = cinfo[c];
+    // only chunks that hold bytes of complete records need their byte checks to stand (a chunk that reaches
+    // beyond the last complete record is repeated too: its quality range may include bytes of an incomplete one)
+    if (rank0 < limit) {
+      if ((info & kInfoUnknown) || (info & 3u) != ((uint32_t)rank0 & 3u) || rank0 + cnt >= limit) again = true;
+      else if (info & kInfoRange) {
+        atomicMin(&cs->qmin_byte, (info >> 8) & 0xFFu);
+        atomicMax(&cs->qmax_byte, (info >> 16) & 0xFFu);
+      }
+    }
+  }
+  const unsigned long long am = __ballot(again);
+  if (am) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cs->redo_count, (uint32_t)__builtin_popcountll(am));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (again) {
+      const uint32_t at = base + (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
+      if (at < cr.n_chunks) redo[at] = c;
+    }
+  }
+}
+
+// the chunk that holds the newline of rank R (R < total newlines): the LAST chunk whose first rank is <= R (chunks
+// without newlines share their first rank with the chunk behind them).  `g` = where to start looking.
+__device__ __forceinline__ uint32_t chunk_of_rank(const ChunkRanks& cr, uint64_t R, uint32_t g) {
+  const uint32_t n = cr.n_chunks;
+  if (g >= n) g = n - 1;
+  uint32_t lo, hi, step = 1;  // invariant: rank0(lo) <= R and (hi == n or rank0(hi) > R)
+  if (cr.rank0(g) <= R) {
+    lo = g;
+    for (;;) {
+      const uint32_t t = lo + step;
+      if (t >= n) {
+        hi = n;
+        break;
+      }
+      if (cr.rank0(t) <= R) {
+        lo = t;
+        step <<= 1;
+      } else {
+        hi = t;
+        break;
+      }
+    }
+  } else {
+    hi = g;
+    for (;;) {
+      const uint32_t t = hi > step ? hi - step : 0;  // (rank0(0) = 0 <= R)
+      if (cr.rank0(t) <= R) {
+        lo = t;
+        break;
+      }
+      hi = t;
+      step <<= 1;
+    }
+  }
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (cr.rank0(mid) <= R) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+struct LinesArgs {
+  const uint8_t* img;
+  uint64_t n;                 // image bytes
+  ChunkRanks cr;
+  const uint16_t* stage;
+  uint64_t* line_end;
+  uint64_t line_cap;
+  uint64_t n_newlines;        // ranks 0 .. n_newlines - 1 have a staged entry
+  uint64_t n_lines;           // + 1 when the image ends in an unterminated line
+  uint64_t limit;             // 4 * complete records
+  uint32_t* suspect_bits;     // one bit per record; this kernel owns whole words
+  uint64_t suspect_cap;
+  unsigned int* flags;
+  int space;
+  uint32_t weight;
+  AccState* acc;              // null: no statistics
+  unsigned long long* hist;
+  int ablate;                 // measurement only (FQGPU_LINES_ABL): 1 = no line-index stores, 2 = no staged-entry loads
+};
+
+constexpr int kLinesHist = 4096;
+__global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
+  __shared__ uint32_t s_hist[kLinesHist];
+  __shared__ unsigned long long s_red[3][kBlock / kWave];
+  __shared__ uint64_t s_wr0[kBlock / kWave][kWave];   // per wavefront: first rank of the window's chunks
+  __shared__ uint32_t s_wcnt[kBlock / kWave][kWave];  // ... and their newline counts
+  for (int i = threadIdx.x; i < kLinesHist; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+  uint32_t win0 = 0;
+  const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);  // 64 records (256 lines) per wavefront step
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
+  unsigned long long n_ok = 0, min_rl = ~0ull, max_rl = 0;
+  uint64_t nx_r0 = ~0ull;
+  uint32_t nx_cnt = 0, nx_win = 0;
+  auto window_load = [&](uint64_t g) {
+    if (g >= n_groups) return;
+    const uint64_t Rw = g ? 4 * g * kWave - 1 : 0;
+    const double est = (double)Rw * chunks_per_line;
+    uint32_t cw = est > 2.0 ? (uint32_t)(est - 2.0) : 0u;
+    if (cw + kWave > A.cr.n_chunks) cw = A.cr.n_chunks > (uint32_t)kWave ? A.cr.n_chunks - kWave : 0u;
+    const uint32_t cm = cw + (uint32_t)lane;
+    const bool in = cm < A.cr.n_chunks;
+    nx_r0 = in ? A.cr.rank0(cm) : ~0ull;
+    nx_cnt = in ? A.cr.counts[cm] : 0u;
+    nx_win = cw;
+  };
+  window_load(wave0);
+  for (uint64_t g = wave0; g < n_groups; g += n_waves) {
+    const uint64_t r = g * kWave + (uint64_t)lane;   // my record
+    const uint64_t L0 = 4 * r;                       // its first line
+    // e[0] = end of the line before mine, e[1..4] = ends of my four lines; ent[] = their staged entries
+    uint64_t e[5];
+    uint32_t ent[5];
+    bool have[5];
+    uint64_t R = r ? L0 - 1 : 0;  // first rank to fetch
+    const int k0 = r ? 0 : 1;
+    e[0] = ~0ull;                 // (record 0: the line before starts at -1)
+    ent[0] = (kClsAt << 12);      // ... and the image's first byte is checked directly below
+    have[0] = r == 0;
+    // The chunks this wavefront's 257 ranks live in: a window of 64 chunks starting a little before the estimated
+    // chunk of its first rank, loaded by all lanes at once into LDS.  A lane whose rank falls outside it (reads
+    // of kilobases: few newlines per chunk) searches the chunk prefix on its own.  The window of the NEXT step is
+    // requested before this step's work, so its memory round trip is hidden.
+    s_wr0[wv][lane] = nx_r0;
+    s_wcnt[wv][lane] = nx_cnt;
+    win0 = nx_win;
+    window_load(g + n_waves);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t c = 0, i = 0, cnt = 0;
+    bool windowed = false;  // c is an index INTO the window (then counts come from LDS)
+    if (R < A.n_newlines) {
+      const uint64_t* w0 = s_wr0[wv];
+      if (R >= w0[0] && (R < w0[kWave - 1] + s_wcnt[wv][kWave - 1])) {
+        uint32_t lo = 0, hi = kWave;  // last window entry whose first rank is <= R
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (w0[mid] <= R) lo = mid;
+          else hi = mid;
+        }
+        c = lo;
+        i = (uint32_t)(R - w0[lo]);
+        cnt = s_wcnt[wv][lo];
+        windowed = true;
+      } else {
+        c = chunk_of_rank(A.cr, R, (uint32_t)((double)R * chunks_per_line));
+        i = (uint32_t)(R - A.cr.rank0(c));
+        cnt = A.cr.counts[c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (k < k0) continue;
+      if (R < A.n_newlines) {
+        while (i >= cnt) {  // next chunk that holds a newline
+          ++c;
+          i = 0;
+          if (windowed && c >= (uint32_t)kWave) {  // ran out of the window
+            windowed = false;
+            c += win0;
+          }
+          cnt = windowed ? s_wcnt[wv][c] : A.cr.counts[c];
+        }
+        const uint32_t cg = windowed ? win0 + c : c;
+        const uint32_t v = (A.ablate & 2) ? (i * 80u) : A.stage[(uint64_t)cg * kStageCap + i];
+        ent[k] = v;
+        e[k] = (uint64_t)cg * kChunkBytes + (v & 0xFFFu);
+        have[k] = true;
+        ++i;
+      } else if (R == A.n_newlines && A.n_lines > A.n_newlines) {  // the unterminated last line
+        ent[k] = 0;
+        e[k] = A.n;
+        have[k] = true;
+      } else {
+        ent[k] = 0;
+        e[k] = 0;
+        have[k] = false;
+      }
+      ++R;
+    }
+    __builtin_amdgcn_wave_barrier();  // (the window is rewritten by the next step)
+    // ---- the line index: four ends per lane, 32 contiguous bytes ----
+    if (A.ablate & 1) {
+    } else if (have[4] && L0 + 3 < A.line_cap) {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 lo2, hi2;
+      lo2.x = e[1]; lo2.y = e[2]; hi2.x = e[3]; hi2.y = e[4];
+      __builtin_nontemporal_store(lo2, reinterpret_cast<u64x2*>(A.line_end + L0));
+      __builtin_nontemporal_store(hi2, reinterpret_cast<u64x2*>(A.line_end + L0 + 2));
+    } else {
+#pragma unroll
+      for (int k = 1; k < 5; ++k)
+        if (have[k] && L0 + k - 1 < A.line_cap) A.line_end[L0 + k - 1] = e[k];
+    }
+    // ---- checks (complete records only) ----
+    bool sus = false, complete = have[4] && L0 + 3 < A.limit;
+    if (complete) {
+      // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
+      if (r == 0) sus |= A.img[0] != '@' || (A.n > 1 && A.img[1] == '\n');
+      else sus |= !(((ent[0] >> 12) & 3u) == kClsAt && !((ent[0] >> 14) & 1u));
+      sus |= !(((ent[2] >> 12) & 3u) == kClsPlus && ((ent[2] >> 14) & 1u));
+      const uint64_t l0 = e[1] - e[0] - 1, l1 = e[2] - e[1] - 1, l2 = e[3] - e[2] - 1, l3 = e[4] - e[3] - 1;
+      const uint32_t has_nl = e[4] < A.n ? 1u : 0u;  // only the very last line can lack it
+      sus |= l1 < 1 || l1 != l3 || A.space != FQG_SPACE_SEQ;
+      sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
+             l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + has_nl > FQG_MAX_READ_LENGTH - 1;
+      if (A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1) {
+        const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line always ends in '\n' here
+        ++n_ok;
+        min_rl = rl < min_rl ? rl : min_rl;
+        max_rl = rl > max_rl ? rl : max_rl;
+        if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
+        else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
+      }
+    }
+    // the wavefront owns records g*64 .. g*64+63 = two whole words of the bitmap
+    const unsigned long long sm = __ballot(sus);
+    if (lane == 0 && sm) {
+      const uint64_t w = g * 2;
+      if ((g + 1) * kWave <= A.suspect_cap) {
+        if ((uint32_t)sm) A.suspect_bits[w] = (uint32_t)sm;
+        if ((uint32_t)(sm >> 32)) A.suspect_bits[w + 1] = (uint32_t)(sm >> 32);
+      } else atomicOr(A.flags, kFlagSuspectOverflow);
+    }
+  }
+  if (!A.acc) return;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    n_ok += __shfl_down(n_ok, d, 64);
+    const unsigned long long a = __shfl_down(min_rl, d, 64), b = __shfl_down(max_rl, d, 64);
+    min_rl = a < min_rl ? a : min_rl;
+    max_rl = b > max_rl ? b : max_rl;
+  }
+  if (lane == 0) {
+    s_red[0][threadIdx.x >> 6] = n_ok;
+    s_red[1][threadIdx.x >> 6] = min_rl;
+    s_red[2][threadIdx.x >> 6] = max_rl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      n_ok += s_red[0][w];
+      min_rl = s_red[1][w] < min_rl ? s_red[1][w] : min_rl;
+      max_rl = s_red[2][w] > max_rl ? s_red[2][w] : max_rl;
+    }
+    if (n_ok) {
+      atomicAdd(&A.acc->num_rds, n_ok * A.weight);
+      if (min_rl < A.acc->min_rl) atomicMin(&A.acc->min_rl, min_rl);
+      if (max_rl > A.acc->max_rl) atomicMax(&A.acc->max_rl, max_rl);
+    }
+  }
+  for (int i = threadIdx.x; i < kLinesHist; i += kBlock) {
+    const uint32_t cc = s_hist[i];
+    if (cc) atomicAdd(&A.hist[i], (unsigned long long)cc * A.weight);
+  }
+}
+
+// After every marking kernel: the suspect bitmap -> the list the exact validator walks; the image's quality range
+// -> the statistics (what k_records_fast does at its end on the other paths)
+__global__ __launch_bounds__(kBlock) void k_suspect_list(const uint32_t* __restrict__ bits, uint64_t n_records,
+                                                         unsigned long long* __restrict__ list,
+                                                         unsigned long long list_cap,
+                                                         unsigned long long* __restrict__ list_count,
+                                                         AccState* __restrict__ acc, const CallState* __restrict__ cs) {
+  const uint64_t n_words = (n_records + 31) / 32;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < n_words; w += stride) {
+    uint32_t m = bits[w];
+    while (m) {
+      const uint32_t j = (uint32_t)__builtin_ctz(m);
+      m &= m - 1;
+      const uint64_t r = w * 32 + j;
+      if (r < n_records) {
+        const unsigned long long at = atomicAdd(list_count, 1ull);
+        if (at < list_cap) list[at] = r;
+      }
+    }
+  }
+  if (acc && blockIdx.x == 0 && threadIdx.x == 0 && cs->qmin_byte <= cs->qmax_byte) {
+    atomicMin(&acc->min_qbyte, cs->qmin_byte);
+    atomicMax(&acc->max_qbyte, cs->qmax_byte);
+  }
+}
+
 // queued suspect byte positions -> records
 __global__ __launch_bounds__(kBlock) void k_stream_queue(const unsigned long long* __restrict__ queue,
                                                          unsigned long long queue_cap,
