@@ -21,6 +21,7 @@
 #include "fqg_filter_kernels.hip"
 #include "fqg_umi_kernels.hip"
 #include "fqg_umi_rl_kernels.hip"
+#include "fqg_umi_cell_kernels.hip"
 
 using namespace fqg;
 

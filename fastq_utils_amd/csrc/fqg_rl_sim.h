@@ -139,6 +139,15 @@ struct ChainView {
   const uint32_t* flag_off;     // per flagged run: where its final array is stored in `arena`
   uint32_t* flag_ext;           // per flagged run: nodes stored; 0 until it has been replayed (then >= 1)
   uint16_t* arena;
+  // by_cell = 1: a run is a (cell, feature) pair of CR-sorted input (fqg_umi_cell_kernels.hip): its records are those
+  // of the cell's record range [run_start, run_start + run_len) whose feature is run_feat (order[] is not used),
+  // its sorted distinct members are stored, and flag_k0 is a RECORD INDEX (records below it precede the overwrite)
+  int by_cell;
+  const uint32_t* rec_feat;     // per record
+  const uint32_t* run_feat;     // per run
+  const uint32_t* run_mem;      // per run: first of its members in members[]
+  const uint32_t* run_nmem;
+  const uint32_t* members;      // (UMI id - 1), sorted inside a run
 };
 
 struct Stats {
@@ -192,19 +201,35 @@ struct History {
   }
 
   // members of a clean run -> mem[] sorted, base[]; returns the node count of its trie (its final size)
-  // (only the first `limit` records of the run are looked at)
+  // (limit: only the records before it are looked at - a count of records, or a record index when by_cell)
   FQG_HD uint32_t load_run(uint32_t run, uint32_t* t_out, uint32_t limit = kNone) {
-    const uint32_t s0 = cv->run_start[run], len = cv->run_len[run] < limit ? cv->run_len[run] : limit;
-    // compact the new members (uniform scalar loop per 64 records: every lane counts the same)
+    const uint32_t s0 = cv->run_start[run], len = cv->run_len[run];
     uint32_t t = 0;
-    for (uint32_t k0 = 0; k0 < len; k0 += W::lanes) {
-      const uint32_t k = k0 + W::lane();
-      uint32_t rec = 0; bool isn = false;
-      if (k < len) { rec = cv->order[s0 + k]; isn = cv->set_new[rec] != 0; }
-      const uint32_t before = W::rank(isn);   // new members in lower lanes
-      const uint32_t total = W::count(isn);
-      if (isn && t + before < wk->mcap) wk->mem[t + before] = cv->umi_id[rec] - 1u;
-      t += total;
+    if (cv->by_cell && limit == kNone) {
+      // a clean (cell, feature) pair: its members were stored sorted
+      t = cv->run_nmem[run];
+      const uint32_t* src = cv->members + cv->run_mem[run];
+      for (uint32_t i = W::lane(); i < t && i < wk->mcap; i += W::lanes) wk->mem[i] = src[i];
+    } else {
+      // compact the new members (uniform scalar loop per 64 records: every lane counts the same)
+      const uint32_t feat = cv->by_cell ? cv->run_feat[run] : 0u;
+      for (uint32_t k0 = 0; k0 < len; k0 += W::lanes) {
+        const uint32_t k = k0 + W::lane();
+        uint32_t rec = 0; bool isn = false;
+        if (k < len) {
+          if (cv->by_cell) {
+            rec = s0 + k;
+            isn = rec < limit && cv->rec_feat[rec] == feat && cv->set_new[rec] != 0;
+          } else {
+            rec = cv->order[s0 + k];
+            isn = k < limit && cv->set_new[rec] != 0;
+          }
+        }
+        const uint32_t before = W::rank(isn);   // new members in lower lanes
+        const uint32_t total = W::count(isn);
+        if (isn && t + before < wk->mcap) wk->mem[t + before] = cv->umi_id[rec] - 1u;
+        t += total;
+      }
     }
     if (t > wk->mcap) { st->overflow = 1; t = wk->mcap; }
     uint32_t P = 1;
@@ -212,7 +237,7 @@ struct History {
     W::sync();
     for (uint32_t i = t + W::lane(); i < P; i += W::lanes) wk->mem[i] = kNone;
     W::sync();
-    if (P > 1) sort_members(P);
+    if (P > 1 && !(cv->by_cell && limit == kNone)) sort_members(P);
     // new nodes per member -> exclusive prefix (+1): every lane sums a contiguous piece
     const uint32_t per = (t + W::lanes - 1) / W::lanes;
     const uint32_t a = W::lane() * per, b = a + per < t ? a + per : t;
@@ -251,7 +276,7 @@ struct History {
       }
       return;
     }
-    if (1u + 8u * cv->run_len[run] <= S) return;  // cannot have more than S nodes
+    if (1u + 8u * (cv->by_cell ? cv->run_nmem[run] : cv->run_len[run]) <= S) return;  // cannot have more than S nodes
     uint32_t t;
     uint32_t size = load_run(run, &t);
     if (size > wk->cap) size = wk->cap;  // only slots the replayed array can have are ever asked for
@@ -499,8 +524,10 @@ FQG_HD void replay_run(const ChainView& cv, Work& wk, Stats& st, uint8_t* new_ou
       k_first = k0;
     }
   }
-  for (uint32_t k = k_first; k < len; ++k) {
-    const uint32_t rec = cv.order[s0 + k];
+  const uint32_t my_feat = cv.by_cell ? cv.run_feat[run] : 0u;
+  for (uint32_t k = cv.by_cell ? 0u : k_first; k < len; ++k) {
+    const uint32_t rec = cv.by_cell ? s0 + k : cv.order[s0 + k];
+    if (cv.by_cell && (cv.rec_feat[rec] != my_feat || rec < k_first)) continue;
     const uint32_t u = cv.umi_id[rec];
     const bool in = sim.member(u);
     if (!in) sim.insert(u);

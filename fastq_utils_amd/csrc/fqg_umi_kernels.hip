@@ -77,6 +77,8 @@ struct UmiCall {
   unsigned long long spread[3][64];  // [0] n_tags, [1] n_counted, [2] n_new
   unsigned int all_unit;         // 1 while every increment seen is exactly 1.0f
   unsigned int table_full;
+  unsigned int max_cell_records; // sorted mode: records of the largest cell (k_umi_cell_sizes)
+  unsigned int pad_;
   float db_reads, db_umi;
 };
 

@@ -134,6 +134,13 @@ struct RlReplayArgs {
   uint32_t* flag_ext;
   uint16_t* arena;
   uint32_t cap, mcap;            // nodes of the replayed array / members of a looked-up run
+  // by_cell: runs are (cell, feature) pairs of CR-sorted input (fqg_umi_cell_kernels.hip)
+  int by_cell;
+  const uint32_t* rec_feat;
+  const uint32_t* run_feat;
+  const uint32_t* run_mem;
+  const uint32_t* run_nmem;
+  const uint32_t* members;
   int in_lds;                    // the worker's arrays fit the LDS budget
   uint8_t* scratch;              // else: per workgroup node | stale | known | mem | base
   uint64_t scratch_stride;
@@ -187,6 +194,12 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
     cv.flag_off = A.flag_off;
     cv.flag_ext = A.flag_ext;
     cv.arena = A.arena;
+    cv.by_cell = A.by_cell;
+    cv.rec_feat = A.rec_feat;
+    cv.run_feat = A.run_feat;
+    cv.run_mem = A.run_mem;
+    cv.run_nmem = A.run_nmem;
+    cv.members = A.members;
     rl::replay_run<GpuWave>(cv, wk, st, A.is_new, [&](uint32_t rec, uint8_t nw, uint32_t run) {
       const uint32_t d = nw ? 1u : 0xFFFFFFFFu;  // +1 / -1
       atomicAdd(&A.pair_umis[A.runs.pslot[run]], d);

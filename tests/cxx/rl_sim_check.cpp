@@ -29,7 +29,7 @@ struct CpuWave {
 // out_new[i]: the decision for record i; stats[0..5] = undefined, overwrites, wild writes, overflow, changed,
 // flagged runs.  cap / mcap: array sizes of the worker (to exercise the overflow paths).
 extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* epoch, const uint32_t* umi,
-                            uint32_t cap, uint32_t mcap, int history, int from_overwrite, uint8_t* out_new, uint64_t* stats) {
+                            uint32_t cap, uint32_t mcap, int history, int from_overwrite, int by_cell, uint8_t* out_new, uint64_t* stats) {
   using namespace fqg::rl;
   // runs = (chain, epoch) groups in order of first appearance; order[] = records grouped by run
   std::map<std::pair<uint32_t, uint32_t>, uint32_t> run_of;
@@ -47,6 +47,21 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
   }
   const uint32_t n_runs = (uint32_t)recs.size();
   std::vector<uint32_t> order, run_start(n_runs), run_len(n_runs), run_flag(n_runs, kNone);
+  // by_cell: runs as fqg_umi_cell_kernels.hip hands them over (records of a cell are contiguous in the input)
+  std::vector<uint32_t> run_feat(n_runs), run_mem(n_runs), run_nmem(n_runs), members, cell_lo(n_runs), cell_n(n_runs);
+  if (by_cell) {
+    std::map<uint32_t, std::pair<uint32_t, uint32_t>> span;  // epoch -> [first record, one past the last]
+    for (uint32_t i = 0; i < n; ++i) {
+      auto it = span.find(epoch[i]);
+      if (it == span.end()) span[epoch[i]] = {i, i + 1};
+      else it->second.second = i + 1;
+    }
+    for (uint32_t r = 0; r < n_runs; ++r) {
+      cell_lo[r] = span[key[r].second].first;
+      cell_n[r] = span[key[r].second].second - cell_lo[r];
+      run_feat[r] = key[r].first;
+    }
+  }
   std::vector<uint8_t> set_new(n, 0);
   std::vector<uint32_t> flagged, flag_k0;
   for (uint32_t r = 0; r < n_runs; ++r) {
@@ -61,10 +76,17 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
         set_new[i] = 1;
         if (!hit && rl_detect_step(state, umi[i])) {
           hit = true;
-          k0 = k;
+          k0 = by_cell ? i : k;
         }
       }
       ++k;
+    }
+    if (by_cell) {
+      run_mem[r] = (uint32_t)members.size();
+      run_nmem[r] = (uint32_t)seen.size();
+      for (uint32_t u : seen) members.push_back(u - 1);  // (std::set: ascending)
+      run_start[r] = cell_lo[r];
+      run_len[r] = cell_n[r];
     }
     if (hit) {
       run_flag[r] = (uint32_t)flagged.size();
@@ -94,7 +116,8 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
     const uint32_t r = chain_runs[p];
     if (run_flag[r] == kNone) continue;
     ChainView cv{history ? chain_runs.data() : nullptr, chain_key.data(), p, r, run_start.data(), run_len.data(),
-                 order.data(), umi, out_new, run_flag.data(), flag_k0.data(), flag_off.data(), flag_ext.data(), arena.data()};
+                 order.data(), umi, out_new, run_flag.data(), flag_k0.data(), flag_off.data(), flag_ext.data(), arena.data(),
+                 by_cell, chain, run_feat.data(), run_mem.data(), run_nmem.data(), members.data()};
     replay_run<CpuWave>(cv, wk, st, out_new, [](uint32_t, uint8_t, uint32_t) {});
   }
   stats[0] = st.undefined;

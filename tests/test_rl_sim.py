@@ -22,14 +22,14 @@ def sim(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("rl") / "librl_sim_check.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, SRC], check=True)
     L = C.CDLL(so)
-    L.rl_sim_check.argtypes = [C.c_uint32] + [C.c_void_p] * 3 + [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.rl_sim_check.argtypes = [C.c_uint32] + [C.c_void_p] * 3 + [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 
-    def run(chain, epoch, umi, cap=16384, mcap=4096, history=1, from_overwrite=1):
+    def run(chain, epoch, umi, cap=16384, mcap=4096, history=1, from_overwrite=1, by_cell=0):
         chain, epoch, umi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (chain, epoch, umi))
         out = np.zeros(chain.size, dtype=np.uint8)
         st = np.zeros(8, dtype=np.uint64)
         P = lambda a: a.ctypes.data_as(C.c_void_p)
-        L.rl_sim_check(chain.size, P(chain), P(epoch), P(umi), cap, mcap, history, from_overwrite, P(out), P(st))
+        L.rl_sim_check(chain.size, P(chain), P(epoch), P(umi), cap, mcap, history, from_overwrite, by_cell, P(out), P(st))
         return out, dict(zip(("undefined", "overwrites", "wild_writes", "overflow", "changed", "flagged", "lookback"),
                              (int(x) for x in st)))
     return run
@@ -56,6 +56,8 @@ def test_sorted_mode_chains(sim, seed):
     assert st["overflow"] == 0 and (want == got).all()
     assert st["overwrites"] == ost[2]  # every overwrite of the reference happens inside a flagged set
     got, st = sim(gene, cell, umi, from_overwrite=0)  # replaying flagged sets from their first record: the same
+    assert st["overflow"] == 0 and (want == got).all()
+    got, st = sim(gene, cell, umi, by_cell=1)  # runs = (cell, gene) pairs with stored members (the sorted-mode path)
     assert st["overflow"] == 0 and (want == got).all()
 
 
