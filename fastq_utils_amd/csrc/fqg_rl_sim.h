@@ -82,7 +82,8 @@ FQG_HD uint32_t shared_digits(uint32_t a, uint32_t b) {
   while (!((x >> hi) & 1u)) --hi;   // highest differing bit
   return (15u - hi) >> 1;
 }
-FQG_HD uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
+template <class P32>
+FQG_HD uint32_t lower_bound_u32(P32 a, uint32_t n, uint32_t key) {
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -93,7 +94,8 @@ FQG_HD uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
 }
 // base[i] = array index of the first node member i brings (1 + nodes of earlier members), base[t] = size.
 // Node at array index p (1 <= p < base[t]):
-FQG_HD uint16_t trie_node(const uint32_t* v, const uint32_t* base, uint32_t t, uint32_t p) {
+template <class P32>
+FQG_HD uint16_t trie_node(P32 v, P32 base, uint32_t t, uint32_t p) {
   // the member that brings node p: the largest i with base[i] <= p
   uint32_t lo = 0, hi = t;
   while (hi - lo > 1) {
@@ -155,27 +157,29 @@ struct Stats {
   unsigned long long clk_replay, clk_lookback, clk_store;  // device clock ticks spent per phase (0 on the CPU)
 };
 
-// LDS (or, on the CPU, heap) arrays of one chain worker
-struct Work {
-  uint16_t* node;     // [cap] the array being replayed
-  uint32_t* known;    // [cap / 32] bit: node[] holds the slot's current content
-  uint16_t* stale;    // [cap] history: stale[1..S) materialised
-  uint32_t* mem;      // [mcap] sorted members of the epoch being looked at
-  uint32_t* base;     // [mcap + 1]
-  uint32_t* scratch;  // [lanes + 1] for the scan
+// LDS (or, on the CPU, heap) arrays of one chain worker.  W::p16 / W::p32 are the pointer types of the memory they
+// live in: on the device LDS pointers (ds_read / ds_write instead of flat accesses) or plain global ones.
+template <class W>
+struct WorkT {
+  typename W::p16 node;     // [cap] the array being replayed
+  typename W::p32 known;    // [cap / 32] bit: node[] holds the slot's current content
+  typename W::p16 stale;    // [cap] history: stale[1..S) materialised
+  typename W::p32 mem;      // [mcap] sorted members of the epoch being looked at
+  typename W::p32 base;     // [mcap + 1]
+  typename W::p32 scratch;  // [lanes + 1] for the scan
   uint32_t cap, mcap;
 };
 
 template <class W>
 struct History {
   const ChainView* cv;
-  Work* wk;
+  WorkT<W>* wk;
   Stats* st;
   uint32_t pos;   // runs [0, pos) of the chain have not been looked at yet
   uint32_t S;     // stale[1..S) valid
   bool count;     // count undefined reads (off while a final array is being stored)
 
-  FQG_HD void reset(const ChainView* c, Work* w, Stats* s) {
+  FQG_HD void reset(const ChainView* c, WorkT<W>* w, Stats* s) {
     cv = c; wk = w; st = s; pos = c->chain_runs ? c->pos : 0; S = 1; count = true;
   }
   // is there an earlier run of the same chain?
@@ -185,7 +189,7 @@ struct History {
 
   // bitonic sort of mem[0..P), P a power of two
   FQG_HD void sort_members(uint32_t P) {
-    uint32_t* m = wk->mem;
+    typename W::p32 m = wk->mem;
     for (uint32_t k = 2; k <= P; k <<= 1)
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
         for (uint32_t i = W::lane(); i < P; i += W::lanes) {
@@ -301,7 +305,7 @@ struct History {
 
 template <class W>
 struct Sim {
-  Work* wk;
+  WorkT<W>* wk;
   History<W>* hist;
   Stats* st;
   uint32_t size, unknown_live, pending;
@@ -491,7 +495,7 @@ struct Sim {
 // the reference's decision for every record of the run whose decision differs from set semantics;
 // on_change(record, is_new, run) is called (lane 0) for each of them.
 template <class W, class OnChange>
-FQG_HD void replay_run(const ChainView& cv, Work& wk, Stats& st, uint8_t* new_out, OnChange on_change) {
+FQG_HD void replay_run(const ChainView& cv, WorkT<W>& wk, Stats& st, uint8_t* new_out, OnChange on_change) {
   History<W> hist;
   Sim<W> sim;
   sim.wk = &wk;

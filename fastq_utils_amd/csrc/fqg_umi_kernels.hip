@@ -126,6 +126,41 @@ __device__ const uint8_t* aux_get(const uint8_t* s, const uint8_t* end, const ui
   return nullptr;
 }
 
+// Four bam_aux_get calls in ONE walk over the aux area: hit[k] = what bam_aux_get(tag[k]) returns (the first field of
+// that name; null when there is none or the walk runs into `lim` first).  A call for one tag skips every field
+// before its hit exactly as the calls for the other tags do, so one walk that remembers first hits is the same.
+__device__ __forceinline__ void aux_get4(const uint8_t* s, const uint8_t* end, const uint8_t* lim, const uint8_t (*tag)[2],
+                                         const uint8_t** hit) {
+  uint32_t open = 15u;  // tags still looked for
+  hit[0] = hit[1] = hit[2] = hit[3] = nullptr;
+  while (s < end && open) {
+    if (s + 2 > lim) return;
+    const int x0 = s[0], x1 = s[1];
+    s += 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((open >> k) & 1u)
+        if (x0 == tag[k][0] && x1 == tag[k][1]) {
+          hit[k] = s < lim ? s : nullptr;
+          open &= ~(1u << k);
+        }
+    if (s >= lim) return;
+    const int type = c_toupper(*s);
+    ++s;
+    if (type == 'Z' || type == 'H') {
+      while (s < lim && *s) ++s;
+      ++s;
+    } else if (type == 'B') {
+      if (s + 5 > lim) return;
+      const int sub = *s;
+      const int32_t cnt = (int32_t)((uint32_t)s[1] | ((uint32_t)s[2] << 8) | ((uint32_t)s[3] << 16) | ((uint32_t)s[4] << 24));
+      s += 5 + (long)aux_type2size(sub) * cnt;
+    } else {
+      s += aux_type2size(type);
+    }
+  }
+}
+
 // bam_aux2Z + get_tag (src/bam_umi_count.c:513-522): string bytes and length (0 = EMPTY_STRING)
 __device__ __forceinline__ uint32_t aux_string(const uint8_t* t, const uint8_t* lim, const uint8_t** str) {
   *str = nullptr;
@@ -233,20 +268,22 @@ __global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict_
     const uint8_t* aux = r + 36 + l_qname + 4ull * n_cigar + (l_qseq + 1) / 2 + l_qseq;
     if (aux > end) aux = end;
     int nh_i = 1;
-    const uint8_t nh_tag[2] = {'N', 'H'};
-    const uint8_t* t = aux_get(aux, end, lim, nh_tag);
-    if (t) {
-      nh_i = aux_int(t, lim);
+    const uint8_t tags[4][2] = {{'N', 'H'}, {P.feat_tag[0], P.feat_tag[1]}, {P.umi_tag[0], P.umi_tag[1]},
+                                {P.cell_tag[0], P.cell_tag[1]}};
+    const uint8_t* hit[4];
+    aux_get4(aux, end, lim, tags, hit);
+    if (hit[0]) {
+      nh_i = aux_int(hit[0], lim);
       if (nh_i > 1 && P.uniq_mapped_only) break;
     }
     const uint8_t *feat, *umi, *cell;
-    const uint32_t lf = aux_string(aux_get(aux, end, lim, P.feat_tag), lim, &feat);
+    const uint32_t lf = aux_string(hit[1], lim, &feat);
     if (!lf) break;
     st = kStNoUmi;
-    const uint32_t lu = aux_string(aux_get(aux, end, lim, P.umi_tag), lim, &umi);
+    const uint32_t lu = aux_string(hit[2], lim, &umi);
     if (!lu) break;
     st = kStUmi;
-    const uint32_t lc = aux_string(aux_get(aux, end, lim, P.cell_tag), lim, &cell);
+    const uint32_t lc = aux_string(hit[3], lim, &cell);
     out.umi_i = pack_barcode(umi, lu);
     out.cell_i = lc ? pack_barcode(cell, lc) : 0ull;
     // strtok(feat, ","): tokens are the maximal runs of non-comma bytes.  n_feat counts the first

@@ -15,7 +15,7 @@
 
 namespace fqg {
 
-struct GpuWave {
+struct GpuWaveBase {
   static constexpr int lanes = kWave;
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x; }
   static __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -36,6 +36,16 @@ struct GpuWave {
   }
   static __device__ __forceinline__ void fence() { __threadfence(); }
   static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
+};
+// where the worker's arrays live: LDS (the usual case: ds_read / ds_write) or a global scratch (flagged sets too
+// large for LDS)
+struct GpuWaveLds : GpuWaveBase {
+  typedef __attribute__((address_space(3))) uint16_t* p16;
+  typedef __attribute__((address_space(3))) uint32_t* p32;
+};
+struct GpuWaveGlobal : GpuWaveBase {
+  typedef uint16_t* p16;
+  typedef uint32_t* p32;
 };
 
 struct RlCall {
@@ -151,31 +161,27 @@ struct RlReplayArgs {
   RlCall* call;
 };
 
-__global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-  __shared__ uint32_t s_scan[kWave + 1];
-  __shared__ uint32_t s_item;
-  // the worker's arrays: LDS when they fit (the usual case), else this workgroup's slice of a global scratch
-  uint8_t* g = A.in_lds ? s_dyn : A.scratch + (uint64_t)blockIdx.x * A.scratch_stride;
+template <class W, class P8>
+__device__ __forceinline__ void rl_replay_body(const RlReplayArgs& A, P8 g, typename W::p32 scan, uint32_t* s_item) {
   auto carve = [&](uint64_t bytes) {
-    uint8_t* p = g;
+    P8 p = g;
     g += (bytes + 15) & ~15ull;
     return p;
   };
-  rl::Work wk;
+  rl::WorkT<W> wk;
   wk.cap = A.cap;
   wk.mcap = A.mcap;
-  wk.node = reinterpret_cast<uint16_t*>(carve((uint64_t)A.cap * 2));
-  wk.stale = reinterpret_cast<uint16_t*>(carve((uint64_t)A.cap * 2));
-  wk.known = reinterpret_cast<uint32_t*>(carve((uint64_t)A.cap / 8 + 4));
-  wk.mem = reinterpret_cast<uint32_t*>(carve((uint64_t)A.mcap * 4));
-  wk.base = reinterpret_cast<uint32_t*>(carve((uint64_t)(A.mcap + 1) * 4));
-  wk.scratch = s_scan;
+  wk.node = (typename W::p16)carve((uint64_t)A.cap * 2);
+  wk.stale = (typename W::p16)carve((uint64_t)A.cap * 2);
+  wk.known = (typename W::p32)carve((uint64_t)A.cap / 8 + 4);
+  wk.mem = (typename W::p32)carve((uint64_t)A.mcap * 4);
+  wk.base = (typename W::p32)carve((uint64_t)(A.mcap + 1) * 4);
+  wk.scratch = scan;
   rl::Stats st{};
   for (;;) {  // tickets in replay order
-    if (threadIdx.x == 0) s_item = atomicAdd(&A.call->next_item, 1u);
+    if (threadIdx.x == 0) *s_item = atomicAdd(&A.call->next_item, 1u);
     __syncthreads();
-    const uint32_t item = s_item;
+    const uint32_t item = *s_item;
     __syncthreads();
     if (item >= A.n_items) break;
     const uint32_t fi = A.items ? A.items[item] : item;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
     cv.run_mem = A.run_mem;
     cv.run_nmem = A.run_nmem;
     cv.members = A.members;
-    rl::replay_run<GpuWave>(cv, wk, st, A.is_new, [&](uint32_t rec, uint8_t nw, uint32_t run) {
+    rl::replay_run<W>(cv, wk, st, A.is_new, [&](uint32_t rec, uint8_t nw, uint32_t run) {
       const uint32_t d = nw ? 1u : 0xFFFFFFFFu;  // +1 / -1
       atomicAdd(&A.pair_umis[A.runs.pslot[run]], d);
       atomicAdd(&A.cell_umis[A.cell_id[rec]], d);
@@ -217,6 +223,18 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
     atomicAdd(&A.call->clk_replay, st.clk_replay);
     atomicAdd(&A.call->clk_lookback, st.clk_lookback);
     atomicAdd(&A.call->clk_store, st.clk_store);
+  }
+}
+
+__global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+  __shared__ uint32_t s_scan[kWave + 1];
+  __shared__ uint32_t s_item;
+  if (A.in_lds) {
+    typedef __attribute__((address_space(3))) uint8_t* lds8;
+    rl_replay_body<GpuWaveLds, lds8>(A, (lds8)s_dyn, (GpuWaveLds::p32)s_scan, &s_item);
+  } else {
+    rl_replay_body<GpuWaveGlobal, uint8_t*>(A, A.scratch + (uint64_t)blockIdx.x * A.scratch_stride, (uint32_t*)s_scan, &s_item);
   }
 }
 

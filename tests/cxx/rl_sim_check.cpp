@@ -12,6 +12,8 @@
 
 namespace {
 struct CpuWave {
+  typedef uint16_t* p16;
+  typedef uint32_t* p32;
   static constexpr int lanes = 1;
   static uint32_t lane() { return 0; }
   static void sync() {}
@@ -110,7 +112,7 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
   std::vector<uint16_t> arena(arena_n + 1);
   std::vector<uint16_t> node(cap), stale(cap);
   std::vector<uint32_t> known(cap / 32 + 1), mem(mcap + 1), base(mcap + 2), scratch(4);
-  Work wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap};
+  WorkT<CpuWave> wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap};
   Stats st{};
   for (uint32_t p = 0; p < n_runs; ++p) {  // flagged runs in (chain, cell) order: the order the GPU hands them out
     const uint32_t r = chain_runs[p];
