@@ -89,20 +89,35 @@ __device__ inline uint32_t canon_name(const uint8_t* __restrict__ line, uint32_t
   return l >= 1 ? (uint32_t)(l - 1) : L;
 }
 
-__device__ __forceinline__ uint64_t hash_name(const uint8_t* __restrict__ p, uint32_t n) {
-  uint64_t h = 0x2545F4914F6CDD1Dull ^ n;
+// a second, independent hash over the same 8-byte words (the fingerprints that travel between GPUs carry 23 of its
+// bits next to the 64 of the first: fqg_fp kernels below)
+__device__ __forceinline__ uint64_t mix_hash2(uint64_t h, uint64_t w) {
+  h = (h ^ w) * 0xC2B2AE3D27D4EB4Full;
+  h ^= h >> 31;
+  return h;
+}
+__device__ __forceinline__ uint64_t fin_hash2(uint64_t h) {
+  h *= 0x94D049BB133111EBull;
+  h ^= h >> 29;
+  return h;
+}
+__device__ __forceinline__ uint64_t hash_name(const uint8_t* __restrict__ p, uint32_t n, uint64_t* second = nullptr) {
+  uint64_t h = 0x2545F4914F6CDD1Dull ^ n, g = 0x9E3779B97F4A7C15ull + n;
   uint32_t i = 0;
   for (; i + 8 <= n; i += 8) {
     uint64_t w;
     __builtin_memcpy(&w, p + i, 8);
     h = mix_hash(h, w);
+    g = mix_hash2(g, w);
   }
   uint64_t w = 0;
   for (uint32_t k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
   h = mix_hash(h, w);
+  g = mix_hash2(g, w);
   h ^= h >> 32;
   h *= 0xD6E8FEB86659FD93ull;
   h ^= h >> 32;
+  if (second) *second = fin_hash2(g);
   return h;
 }
 
@@ -191,8 +206,8 @@ __device__ __forceinline__ uint32_t canon_name_regs(const HdrRegs& H, uint32_t c
   return l >= 1 ? (uint32_t)(l - 1) : L;
 }
 // hash_name(line + 1, n) on registers: the same value, word for word
-__device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n) {
-  uint64_t h = 0x2545F4914F6CDD1Dull ^ n;
+__device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n, uint64_t* second = nullptr) {
+  uint64_t h = 0x2545F4914F6CDD1Dull ^ n, g = 0x9E3779B97F4A7C15ull + n;
 #pragma unroll
   for (int k = 0; k < kHdrWords; ++k) {
     const uint64_t nw = (H.w[k] >> 8) | (H.w[k + 1] << 56);  // bytes 8k .. 8k+7 of the name
@@ -200,17 +215,21 @@ __device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n)
     const bool last = !full && 8u * k <= n;  // the partial (possibly empty) word that ends the name
     const uint32_t rem = n - 8u * k;         // 0..7 when `last`
     const uint64_t w = full ? nw : (nw & ((1ull << (8 * (rem & 7))) - 1ull));
-    if (full || last) h = mix_hash(h, w);
+    if (full || last) {
+      h = mix_hash(h, w);
+      g = mix_hash2(g, w);
+    }
   }
   h ^= h >> 32;
   h *= 0xD6E8FEB86659FD93ull;
   h ^= h >> 32;
+  if (second) *second = fin_hash2(g);
   return h;
 }
 // name (length, hash) of the header line at img + b; the fast path when the line allows it
 __device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ img, uint64_t nbytes, uint64_t b, uint64_t e,
                                                   int fmt, int is_pe, int may_have_nul, uint32_t* acct, uint64_t* h,
-                                                  bool* at_sign) {
+                                                  bool* at_sign, uint64_t* second = nullptr) {
   const uint8_t* line = img + b;
   const uint32_t len = (uint32_t)(e - b), has_nl = e < nbytes ? 1u : 0u;
   if (!may_have_nul && len + has_nl <= kHdrBytes - 1 && b + kHdrBytes <= nbytes) {
@@ -220,13 +239,13 @@ __device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ im
     const uint32_t n = canon_name_regs(H, len + has_nl, fmt, is_pe, acct, &ok);
     if (ok) {
       *at_sign = (H.w[0] & 0xFF) == '@';
-      *h = hash_name_regs(H, n);
+      *h = hash_name_regs(H, n, second);
       return n;
     }
   }
   *at_sign = line[0] == '@';
   const uint32_t n = canon_name(line, len, has_nl, fmt, is_pe, may_have_nul, acct);
-  *h = hash_name(line + 1, n);
+  *h = hash_name(line + 1, n, second);
   return n;
 }
 
@@ -433,6 +452,12 @@ struct FpRec {
   unsigned long long fp, idx;
 };
 constexpr int kMaxOwners = 64;
+// idx word of an exchanged record: bit 63 = file 2 (kFpFile2), bits 40..62 = 23 bits of the second hash of the
+// name, bits 0..39 = global record index.  A run of one holder and one asker only counts as a pair when those
+// 23 bits agree too: 87 bits in all; anything else is resolved on the name bytes.
+constexpr unsigned long long kFpIndexMask = (1ull << 40) - 1;
+constexpr int kFpCheckShift = 40;
+constexpr unsigned long long kFpCheckMask = ((1ull << 23) - 1) << kFpCheckShift;
 
 __device__ __forceinline__ uint32_t fp_owner(unsigned long long fp, uint32_t n_owners) {
   return (uint32_t)(((fp >> 32) * (unsigned long long)n_owners) >> 32);  // high bits: the table uses the low ones
@@ -462,14 +487,14 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
       const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
       const uint64_t e = f.line_end[4 * r];
       uint32_t acct;
-      uint64_t h64;
+      uint64_t h64, h2;
       bool at_sign;
-      (void)name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign);
+      (void)name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign, &h2);
       if (at_sign) {  // (a wrong header is the local pass's finding, src/fastq.c:448)
         unsigned long long h = h64;
         if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
         me[j].fp = h;
-        me[j].idx = record_base + r;
+        me[j].idx = (record_base + r) | ((h2 << kFpCheckShift) & kFpCheckMask);
         owner[j] = fp_owner(h, n_owners);
         slot[j] = atomicAdd(&s_cnt[owner[j]], 1u);
         have[j] = true;
@@ -500,15 +525,16 @@ __global__ __launch_bounds__(kBlock) void k_fp_runs(const unsigned long long* __
   const unsigned long long f = fp[i];
   if (i > 0 && fp[i - 1] == f) return;          // not the start of a run
   if (i + 1 >= n || fp[i + 1] != f) return;     // a run of one: the common case
-  unsigned long long mn = idx[i];
+  const unsigned long long keep = ~kFpCheckMask;  // (the check bits are not part of the index)
+  unsigned long long mn = idx[i] & keep;
   uint64_t e = i + 1;
-  for (; e < n && fp[e] == f; ++e) mn = idx[e] < mn ? idx[e] : mn;
+  for (; e < n && fp[e] == f; ++e) mn = (idx[e] & keep) < mn ? (idx[e] & keep) : mn;
   for (uint64_t k = i; k < e; ++k) {
-    if (idx[k] == mn) continue;
+    if ((idx[k] & keep) == mn) continue;
     const unsigned long long at = atomicAdd(count, 1ull);
     if (at < cap) {
       pairs[2 * at] = mn;
-      pairs[2 * at + 1] = idx[k];
+      pairs[2 * at + 1] = idx[k] & keep;
     }
   }
 }
@@ -533,16 +559,20 @@ __global__ __launch_bounds__(kBlock) void k_fp_pair_runs(const unsigned long lon
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const unsigned long long f = fp[i];
     if (i > 0 && fp[i - 1] == f) continue;  // not the start of a run
-    unsigned long long h = 0, a = 0, min_a = ~0ull;
+    unsigned long long h = 0, a = 0, min_a = ~0ull, chk_h = 0, chk_a = 0;
     uint64_t e = i;
     for (; e < n && fp[e] == f; ++e) {
       const unsigned long long v = idx[e];
       if (v & kFpFile2) {
         ++a;
-        min_a = (v & ~kFpFile2) < min_a ? (v & ~kFpFile2) : min_a;
-      } else ++h;
+        chk_a = v & kFpCheckMask;
+        min_a = (v & kFpIndexMask) < min_a ? (v & kFpIndexMask) : min_a;
+      } else {
+        ++h;
+        chk_h = v & kFpCheckMask;
+      }
     }
-    if (h == 1 && a == 1) ++matched;
+    if (h == 1 && a == 1 && chk_h == chk_a) ++matched;
     else if (a == 0) leftover += h;
     else if (h == 0) {
       unpaired += a;
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_fp_pair_runs(const unsigned long lon
       for (uint64_t k = i; k < e; ++k)
         if (at + (k - i) < cap) {
           entries[2 * (at + (k - i))] = i;  // the run
-          entries[2 * (at + (k - i)) + 1] = idx[k];
+          entries[2 * (at + (k - i)) + 1] = idx[k] & ~kFpCheckMask;
         }
     }
   }
