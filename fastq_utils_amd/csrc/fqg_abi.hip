@@ -307,7 +307,8 @@ int fqg_synchronize(fqg_ctx* c) {
 void* fqg_host_alloc(fqg_ctx* c, size_t bytes) {
   void* p = nullptr;
   if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;  // (callable from the programs' reader threads)
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  // (portable: the pieces one reader thread fills are handed to whichever device's context is free, host/fq_multi.h)
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
   return p;
 }
 void fqg_host_free(fqg_ctx* c, void* p) {
@@ -325,6 +326,7 @@ int fqg_acc_reset(fqg_acc* a) {
   init.max_rl = 0;
   init.min_qbyte = 255;
   init.max_qbyte = 0;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(a->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemset(a->d_hist, 0, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH));
@@ -335,7 +337,8 @@ int fqg_acc_create(fqg_ctx* c, fqg_acc** out) {
   if (!c || !out) return FQG_ERR_ARG;
   fqg_acc* a = new fqg_acc();
   a->ctx = c;
-  if (hipMalloc((void**)&a->d_state, sizeof(AccState)) != hipSuccess ||
+  if (hipSetDevice(c->device) != hipSuccess ||
+      hipMalloc((void**)&a->d_state, sizeof(AccState)) != hipSuccess ||
       hipMalloc((void**)&a->d_hist, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH) != hipSuccess) {
     fqg_acc_destroy(a);
     return fail(c, FQG_ERR_NOMEM, "accumulator allocation");
@@ -351,6 +354,7 @@ int fqg_acc_create(fqg_ctx* c, fqg_acc** out) {
 
 void fqg_acc_destroy(fqg_acc* a) {
   if (!a) return;
+  if (a->ctx) (void)hipSetDevice(a->ctx->device);
   if (a->d_state) (void)hipFree(a->d_state);
   if (a->d_hist) (void)hipFree(a->d_hist);
   delete a;
@@ -358,6 +362,7 @@ void fqg_acc_destroy(fqg_acc* a) {
 
 static int acc_fetch_state(fqg_acc* a, AccState* s) {
   fqg_ctx* c = a->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(s, a->d_state, sizeof(AccState), hipMemcpyDeviceToHost));
   return 0;
@@ -388,6 +393,7 @@ int fqg_acc_read(fqg_acc* a, fqg_file_stats* out) {
 static int acc_fetch_hist(fqg_acc* a) {
   fqg_ctx* c = a->ctx;
   a->h_hist.resize(FQG_MAX_READ_LENGTH);
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(a->h_hist.data(), a->d_hist, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH,
                        hipMemcpyDeviceToHost));

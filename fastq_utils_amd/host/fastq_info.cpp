@@ -14,7 +14,10 @@
 #include <string>
 #include <vector>
 
+#include <map>
+
 #include "fq_common.h"
+#include "fq_multi.h"
 
 namespace {
 
@@ -60,6 +63,151 @@ void run_single_noindex(const char* path, Stats& S) {
   fqg_file_stats fs;
   LIB(fqg_acc_read(S.acc1, &fs));
   S.num_reads1 = fs.num_rds;
+}
+
+// ---- -r, one file, several GPUs (FQGPU_DEVICES=0,1,..): the same loop over record-aligned pieces that have no
+// order among them (fq_multi.h).  One thread + context + accumulator per device; this thread takes the results in
+// file order, so the ticker, the first finding and its text are the serial loop's; the statistics of a clean file
+// are the element-wise merge of the devices' accumulators (fqg_acc_export / fqg_acc_merge).
+void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>& devs) {
+  struct Dev {
+    fqg_ctx* ctx = nullptr;
+    fqg_acc* acc = nullptr;
+  };
+  std::vector<Dev> D(devs.size());
+  D[0].ctx = g_ctx;  // (opened on devs[0])
+  D[0].acc = S.acc1;
+  for (size_t i = 1; i < devs.size(); ++i) {
+    const int rc = fqg_open(devs[i], &D[i].ctx);
+    if (rc != 0) {
+      FQ_PRINT_ERROR("FQGPU_DEVICES: device %d is not a usable MI355X GPU (fqg_open: %d)", devs[i], rc);
+      exit(kExitSys);
+    }
+    if (fqg_acc_create(D[i].ctx, &D[i].acc) != 0) die_lib("fqg_acc_create", -1);
+  }
+  const size_t piece = getenv("FQGPU_CHUNK_MB") ? piece_bytes() : (size_t)128 << 20;
+  struct Done {
+    Piece p;
+    fqg_validate_result r{};
+    int rc = 0;
+    std::string err;
+  };
+  std::map<uint64_t, Done> done;
+  std::mutex mu, fetch_mu;
+  std::condition_variable cv;
+  std::atomic<bool> stop{false};
+  bool exhausted = false;  // (under fetch_mu)
+  uint64_t n_pieces = ~0ull;  // known once the final piece was handed out (under mu)
+  Probe pr;
+  bool rerun_serial = false;
+  {
+    AlignedPieces src(g_ctx, path, piece, (int)(2 * devs.size() + 2));
+    auto work = [&](size_t di) {
+      for (;;) {
+        Done d;
+        fqg_file_state st;
+        {
+          std::lock_guard<std::mutex> lk(fetch_mu);
+          if (exhausted || stop || !src.next(&d.p)) {
+            exhausted = true;
+            return;
+          }
+          if (d.p.final) exhausted = true;
+          probe_piece(pr, d.p.data, d.p.size, 1);  // piece 0 is handed out first: the state is the first record's
+          st = pr.st;
+        }
+        d.rc = fqg_validate(D[di].ctx, D[di].acc, d.p.data, d.p.size, FQG_MEM_HOST, d.p.final ? 1 : 0, &st, 0, &d.r);
+        if (d.rc) d.err = fqg_last_error(D[di].ctx);
+        else if (!d.p.final && d.r.code == FQG_OK && !d.r.stopped && d.r.consumed != d.p.size) {
+          d.rc = FQG_ERR_ARG;
+          d.err = "a piece cut at a record boundary was not consumed whole";
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (d.p.final) n_pieces = d.p.seq + 1;
+        done.emplace(d.p.seq, std::move(d));
+        cv.notify_all();
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < devs.size(); ++i) th.emplace_back(work, i);
+    auto join_all = [&] {
+      stop = true;
+      for (auto& t : th)
+        if (t.joinable()) t.join();
+    };
+    bool info_pending = true;
+    for (uint64_t k = 0;; ++k) {
+      Done d;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done.count(k) || k >= n_pieces; });
+        if (!done.count(k)) break;
+        d = std::move(done[k]);
+        done.erase(k);
+      }
+      const uint64_t base = d.p.first_record;
+      const fqg_validate_result& r = d.r;
+      if (d.rc) {
+        join_all();
+        FQ_PRINT_ERROR("GPU library failure in fqg_validate (%d): %s", d.rc, d.err.c_str());
+        exit(kExitSys);
+      }
+      if (info_pending && base == 0 && r.n_records > 0) {
+        if (!(r.code && r.record == 0 && is_early_code(r.code))) print_probe(pr);
+        info_pending = false;
+      }
+      if (r.code) {
+        join_all();
+        const uint64_t R = base + r.record;
+        ticker(base + 1, R, 100000);
+        if (r.code == FQG_E_TRUNCATED) fail_truncated(path, 4 * R);
+        if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, R);
+        print_validation_error(path, 4 * (R + 1), r, locate_record(d.p.data, d.p.size, r.record));
+        exit(kExitFormat);
+      }
+      if (r.stopped) {
+        // a NUL at a record start ends the file here (src/fastq.c:250): what later pieces added to the accumulators
+        // does not belong to it.  Rare enough to simply run the serial loop again on one device.
+        join_all();
+        rerun_serial = true;
+        break;
+      }
+      ticker(base + 1, base + r.n_records, 100000);
+      src.release(d.p);
+      if (d.p.final) break;
+    }
+    join_all();
+  }
+  if (rerun_serial) {
+    for (size_t i = 1; i < D.size(); ++i) {
+      fqg_acc_destroy(D[i].acc);
+      fqg_close(D[i].ctx);
+    }
+    if (strcmp(path, "-") == 0) {
+      FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES on a stream: use one device",
+                     path);
+      exit(kExitSys);
+    }
+    LIB(fqg_acc_reset(S.acc1));
+    run_single_noindex(path, S);
+    return;
+  }
+  {
+    std::vector<char> buf;
+    for (size_t i = 1; i < D.size(); ++i) {
+      size_t used = 0;
+      if (fqg_acc_export(D[i].acc, nullptr, 0, &used) != 0) die_lib("fqg_acc_export", -1);
+      buf.resize(used);
+      if (fqg_acc_export(D[i].acc, buf.data(), buf.size(), &used) != 0) die_lib("fqg_acc_export", -1);
+      LIB(fqg_acc_merge(S.acc1, buf.data(), used));
+      fqg_acc_destroy(D[i].acc);
+      fqg_close(D[i].ctx);
+    }
+    printf("\n");
+    fqg_file_stats fs;
+    LIB(fqg_acc_read(S.acc1, &fs));
+    S.num_reads1 = fs.num_rds;
+  }
 }
 
 // ---- second file of a pair: src/fastq_info.c:322-362 ----------------------------------------
@@ -329,7 +477,8 @@ int main(int argc, char** argv) {
   const char* file2 = is_paired_data ? argv[2 + nopt] : nullptr;
 
   const char* dev = getenv("FQGPU_DEVICE");
-  int rc = fqg_open(dev ? atoi(dev) : 0, &g_ctx);
+  const std::vector<int> devices = devices_from_env();  // FQGPU_DEVICES=0,1,..: the -r pass over several GPUs
+  int rc = fqg_open(!devices.empty() ? devices[0] : dev ? atoi(dev) : 0, &g_ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
     exit(kExitSys);
@@ -349,7 +498,8 @@ int main(int argc, char** argv) {
     S.acc2 = nullptr;  // the summary only looks at file 1 (src/fastq_info.c:316-319)
   } else if (!is_paired_data && skip_readname_check) {
     fprintf(stderr, "Skipping check for duplicated read names\n");
-    run_single_noindex(file1, S);
+    if (devices.size() > 1) run_single_noindex_multi(file1, S, devices);
+    else run_single_noindex(file1, S);
   } else {
     fprintf(stderr, "DEFAULT_HASHSIZE=%lu\n", 39000001ul);
     fprintf(stderr, "Scanning and indexing all reads from %s\n", file1);

@@ -1,0 +1,296 @@
+// fq_multi.h - the -r pass of fastq_info (validate_single_fastq_file, reference src/fastq_info.c:155-176) over
+// several GPUs of one node: FQGPU_DEVICES=0,1,...  ("validation shards naturally").
+//
+// One host thread + one fqg_ctx + one statistics accumulator per device.  The file is cut into pieces that START AND
+// END AT RECORD BOUNDARIES without looking at a GPU: a record starts at every fourth line, so counting newlines on
+// the host (the reader threads do it while the bytes are in their cache) gives every piece its first line number,
+// and the bytes of the record that straddles a cut are moved to the piece it began in.  Pieces then have no order
+// among them: whichever device is free takes the next one.  What the serial loop would report - the first finding
+// in file order, the progress ticker, the statistics of a clean file - is put together on the host: findings by
+// piece order, statistics by fqg_acc_export / fqg_acc_merge.  No collective is needed on this path.
+#pragma once
+#include <deque>
+#include <functional>
+
+#include "fq_input.h"
+
+namespace fqhost {
+
+struct Piece {
+  char* data = nullptr;        // record-aligned image (points into a slot)
+  size_t size = 0;
+  uint64_t first_record = 0;   // records of the file before it
+  bool final = false;
+  int slot = -1;
+  uint64_t seq = 0;            // position in file order
+};
+
+class AlignedPieces {
+ public:
+  AlignedPieces(fqg_ctx* ctx, const char* path, size_t piece_bytes, int n_slots)
+      : ctx_(ctx), cap_(piece_bytes), slots_((size_t)n_slots) {
+    path_ = path;
+    if (path_ == "-") gz_ = gzdopen(fileno(stdin), "rb");
+    else {
+      const int fd = open(path, O_RDONLY);
+      struct stat sb;
+      if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = pread(fd, magic, 2, 0);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+          plain_fd_ = fd;
+          plain_size_ = (uint64_t)sb.st_size;
+        }
+      }
+      if (plain_fd_ < 0) {
+        if (fd >= 0) close(fd);
+        gz_ = gzopen(path, "r");
+      }
+    }
+    if (!gz_ && plain_fd_ < 0) {
+      FQ_PRINT_ERROR("Unable to open %s", path);
+      exit(kExitParams);
+    }
+    if (gz_) gzbuffer(gz_, 1 << 20);
+    producer_ = std::thread([this] { produce(); });
+  }
+  ~AlignedPieces() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    if (producer_.joinable()) producer_.join();
+    if (gz_) gzclose(gz_);
+    if (plain_fd_ >= 0) close(plain_fd_);
+    for (auto& s : slots_)
+      if (s.buf) fqg_host_free(ctx_, s.buf);
+  }
+  // next piece in file order; false when the file is exhausted.  Thread-safe.
+  bool next(Piece* out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !ready_.empty() || done_ || failed_; });
+    if (failed_) {
+      FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
+      exit(kExitSys);
+    }
+    if (ready_.empty()) return false;
+    *out = ready_.front();
+    ready_.pop_front();
+    return true;
+  }
+  void release(const Piece& p) {
+    std::lock_guard<std::mutex> lk(mu_);
+    slots_[(size_t)p.slot].busy = false;
+    cv_.notify_all();
+  }
+
+ private:
+  static constexpr size_t kTail = 8u << 20;  // room behind a slot's bytes for the rest of a straddling record
+  struct Slot {
+    char* buf = nullptr;
+    bool busy = false;
+  };
+
+  size_t read_some(char* dst, size_t want, bool* at_end, uint64_t* newlines) {
+    size_t len = 0;
+    if (plain_fd_ >= 0) {
+      const uint64_t left = plain_size_ - plain_off_;
+      len = (size_t)std::min<uint64_t>(want, left);
+      const unsigned T = (unsigned)std::min<uint64_t>(host_read_threads(), std::max<uint64_t>(1, len >> 22));
+      std::vector<uint64_t> cnt(T, 0);
+      std::atomic<bool> bad{false};
+      auto part = [&](unsigned t) {
+        const size_t a = (len * t / T) & ~(size_t)4095, b = t + 1 == T ? len : (len * (t + 1) / T) & ~(size_t)4095;
+        size_t done = a;
+        while (done < b) {
+          const ssize_t got = pread(plain_fd_, dst + done, b - done, (off_t)(plain_off_ + done));
+          if (got <= 0) {
+            bad = true;
+            return;
+          }
+          done += (size_t)got;
+        }
+        uint64_t c = 0;
+        for (const char* p = dst + a; (p = (const char*)memchr(p, '\n', (size_t)(dst + b - p))) != nullptr; ++p) ++c;
+        cnt[t] = c;
+      };
+      if (T <= 1) part(0);
+      else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(part, t);
+        part(0);
+        for (auto& x : th) x.join();
+      }
+      if (bad) {
+        fail("read error");
+        return 0;
+      }
+      for (uint64_t c : cnt) *newlines += c;
+      plain_off_ += len;
+      if (plain_off_ >= plain_size_) *at_end = true;
+      return len;
+    }
+    while (len < want) {
+      const int got = gzread(gz_, dst + len, (unsigned)std::min<size_t>(want - len, 1u << 30));
+      if (got < 0) {
+        int en = 0;
+        fail(gzerror(gz_, &en));
+        return len;
+      }
+      if (got == 0) {
+        *at_end = true;
+        break;
+      }
+      len += (size_t)got;
+    }
+    if (!*at_end) {
+      const int c = gzgetc(gz_);
+      if (c < 0) *at_end = true;
+      else gzungetc(c, gz_);
+    }
+    for (const char* p = dst; (p = (const char*)memchr(p, '\n', (size_t)(dst + len - p))) != nullptr; ++p) ++*newlines;
+    return len;
+  }
+  void fail(const char* msg) {
+    std::lock_guard<std::mutex> lk(mu_);
+    fail_msg_ = msg;
+    failed_ = true;
+    cv_.notify_all();
+  }
+  int free_slot() {
+    std::unique_lock<std::mutex> lk(mu_);
+    int s = -1;
+    cv_.wait(lk, [&] {
+      if (quit_) return true;
+      for (size_t i = 0; i < slots_.size(); ++i)
+        if (!slots_[i].busy) {
+          s = (int)i;
+          return true;
+        }
+      return false;
+    });
+    if (s >= 0) slots_[(size_t)s].busy = true;
+    return s;
+  }
+
+  void produce() {
+    // `held`: the piece whose end is not known yet (the record that straddles the next cut still has to be added)
+    Piece held;
+    bool have_held = false;
+    size_t held_tail = 0;       // bytes of later slots already added behind it
+    uint64_t lines_before = 0;  // newlines in the file before the raw bytes being read
+    bool mid_line = false;      // the previous raw byte was not a newline
+    bool at_end = false;
+    uint64_t seq = 0;
+    while (!at_end) {
+      const int si = free_slot();
+      if (si < 0) return;
+      Slot& s = slots_[(size_t)si];
+      if (!s.buf) {
+        s.buf = static_cast<char*>(fqg_host_alloc(ctx_, cap_ + kTail + 1));
+        if (!s.buf) {
+          fail("unable to allocate pinned memory");
+          return;
+        }
+      }
+      uint64_t nl = 0;
+      const size_t len = read_some(s.buf, cap_, &at_end, &nl);
+      if (failed_) return;
+      // where the first record of these bytes starts: at the first line whose number is a multiple of four
+      uint64_t skip_lines = (4 - lines_before % 4) % 4;
+      if (mid_line && skip_lines == 0) skip_lines = 4;
+      if (!have_held) skip_lines = 0;  // the file starts with a record
+      size_t skip = 0;
+      bool found = true;
+      for (uint64_t k = 0; k < skip_lines; ++k) {
+        const char* p = (const char*)memchr(s.buf + skip, '\n', len - skip);
+        if (!p) {
+          found = false;
+          break;
+        }
+        skip = (size_t)(p - s.buf) + 1;
+      }
+      if (!found) skip = len;  // no record starts in these bytes: all of them belong to the held piece
+      if (have_held) {
+        if (held_tail + skip > kTail) {
+          fail("more than 8 MiB of one record straddle two pieces (FQGPU_DEVICES): use one device");
+          return;
+        }
+        memcpy(held.data + held.size, s.buf, skip);
+        held.size += skip;
+        held_tail += skip;
+      }
+      if (found && (skip < len || at_end)) {
+        if (have_held) publish(held);
+        held = Piece();
+        held.data = s.buf + skip;
+        held.size = len - skip;
+        held.first_record = (lines_before + skip_lines) / 4;
+        held.slot = si;
+        held.seq = seq++;
+        held_tail = 0;
+        have_held = true;
+      } else {
+        // nothing of this slot starts a piece: give it back (its bytes were appended to the held piece)
+        std::lock_guard<std::mutex> lk(mu_);
+        s.busy = false;
+      }
+      lines_before += nl;
+      if (len) mid_line = s.buf[len - 1] != '\n';
+    }
+    if (have_held) {
+      held.final = true;
+      publish(held);
+    } else {
+      // an empty file: one empty, final piece
+      const int si = free_slot();
+      if (si < 0) return;
+      Slot& s = slots_[(size_t)si];
+      if (!s.buf) s.buf = static_cast<char*>(fqg_host_alloc(ctx_, cap_ + kTail + 1));
+      Piece p;
+      p.data = s.buf;
+      p.final = true;
+      p.slot = si;
+      publish(p);
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    done_ = true;
+    cv_.notify_all();
+  }
+  void publish(const Piece& p) {
+    std::lock_guard<std::mutex> lk(mu_);
+    ready_.push_back(p);
+    cv_.notify_all();
+  }
+
+  fqg_ctx* ctx_;
+  std::string path_;
+  gzFile gz_ = nullptr;
+  int plain_fd_ = -1;
+  uint64_t plain_size_ = 0, plain_off_ = 0;
+  size_t cap_;
+  std::vector<Slot> slots_;
+  std::deque<Piece> ready_;
+  std::thread producer_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool quit_ = false, failed_ = false, done_ = false;
+  std::string fail_msg_;
+};
+
+inline std::vector<int> devices_from_env() {
+  std::vector<int> d;
+  const char* e = getenv("FQGPU_DEVICES");
+  if (!e) return d;
+  for (const char* p = e; *p;) {
+    char* end = nullptr;
+    const long v = strtol(p, &end, 10);
+    if (end == p) break;
+    d.push_back((int)v);
+    p = *end == ',' ? end + 1 : end;
+  }
+  return d;
+}
+
+}  // namespace fqhost

@@ -122,3 +122,47 @@ def test_small_pieces_exercise_the_carry():
         env = {"FQGPU_CHUNK_MB": "1"}
         for args in (["-r", "a.fastq"], ["a.fastq"], ["a.fastq", "b.fastq"], ["d.fastq"]):
             compare_with_oracle(tmp, args, files, env)
+
+
+# ---- FQGPU_DEVICES: the -r pass over several contexts (host/fq_multi.h) ---------------------------------------------
+# (the test box has one GPU: "0,0,0" opens three contexts on it - the same threads, pieces, result order and
+# accumulator merge as three GPUs)
+MULTI = {"FQGPU_DEVICES": "0,0,0"}
+
+
+def test_several_devices_golden_dash_r_invocations():
+    cases = [c for c in GOLDEN if "-r" in c["args"] and len([a for a in c["args"] if not a.startswith("-")]) == 1]
+    assert len(cases) > 20
+
+    def one(case):
+        rc, out, err = run_cli(case["args"], GOLD, MULTI)
+        ok = (rc == case["exit"] and out == case["stdout"]
+              and strip_progress(err) == strip_progress(case["stderr"]))
+        return None if ok else (case["args"], rc, case["exit"], err[-400:], case["stderr"][-400:])
+
+    with ThreadPoolExecutor(4) as ex:
+        bad = [b for b in ex.map(one, cases) if b]
+    assert not bad, f"{len(bad)} of {len(cases)} differ; first: {bad[:3]}"
+
+
+@pytest.mark.parametrize("kind", ["clean"] + fuzz.MUTATIONS)
+def test_several_devices_many_pieces(kind):
+    """1 MiB pieces of a ~9 MB file: ~9 pieces over three contexts; a finding anywhere (or none: merged statistics)
+    must read exactly as the serial loop's."""
+    rng = np.random.default_rng(abs(hash("multi" + kind)) % 100000)
+    env = dict(MULTI, FQGPU_CHUNK_MB="1")
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(2):
+            img = fuzz.make_fastq(rng, 30000, 20 if trial else 100, 250 if trial else 101, ["casava", "slash"][trial])
+            if kind != "clean":
+                img = fuzz.mutate(rng, img, kind)
+            with open(os.path.join(tmp, "f.fastq"), "wb") as f:
+                f.write(img)
+            compare_with_oracle(tmp, ["-r", "f.fastq"], {"f.fastq": img}, env)
+            if trial == 0:
+                import gzip
+                with open(os.path.join(tmp, "g.fastq.gz"), "wb") as f:
+                    f.write(gzip.compress(img, 1))
+                rc, out, err = run_cli(["-r", "g.fastq.gz"], tmp, env)
+                want = oracle_run(["-r", "g.fastq.gz"], {"g.fastq.gz": img})
+                assert (rc, out, strip_progress(err)) == (want["exit"], want["stdout"], strip_progress(want["stderr"])), err[-500:]

@@ -97,3 +97,30 @@ def test_host_input_stager_runs_clean(tmpdir, san):
                 p = subprocess.run([exe, str(path), piece, mode], env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"),
                                    capture_output=True, timeout=300)
                 assert p.returncode == 0 and p.stdout.strip() == wanted, (path, piece, mode, p.stdout, p.stderr.decode()[-1500:])
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_record_aligned_piece_cutter_runs_clean(tmpdir, san):
+    """fq_multi.h (FQGPU_DEVICES): pieces cut on the host by counting lines must tile the file, start at records
+    4*first_record and - all but the last - hold whole records; several consumers, plain / gz / truncated / empty."""
+    flags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g", "-O1"]
+    exe = str(tmpdir / ("pieces_" + san.split(",")[0]))
+    subprocess.run(["g++", "-std=c++17", "-pthread"] + flags + ["-o", exe, os.path.join(CXX, "pieces_check.cpp"), "-lz"], check=True)
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(4000):
+        n = int(rng.integers(1, 300))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).astype(np.uint8))
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * n + b"\n")
+    data = b"".join(recs)
+    files = {"full.fq": data, "full.fq.gz": gzip.compress(data, 1), "cut.fq": data[:-57], "nonl.fq": data[:-1],
+             "empty.fq": b"", "one.fq": recs[0], "blank.fq": b"\n" * 1001}
+    for name, content in files.items():
+        (tmpdir / name).write_bytes(content)
+        size = len(data if name.endswith(".gz") else content)
+        for piece in ("512", "4096", "100000", "50000000"):
+            for consumers in ("1", "3"):
+                p = subprocess.run([exe, str(tmpdir / name), piece, consumers],
+                                   env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"), capture_output=True, timeout=300)
+                out = p.stdout.decode().split()
+                assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, piece, consumers, p.stdout, p.stderr.decode()[-1500:])
