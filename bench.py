@@ -567,20 +567,36 @@ class _OffsetArray:
         return self.n
 
 
+def kernel_sources_digest():
+    """what a committed PMC traffic file is valid for: the text of the framing kernels it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("fqg_kernels.hip", "fqg_stream_kernels.hip"):
+        with open(os.path.join(REPO, "fastq_utils_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(kernel, n_reads, read_len, record_bytes):
-    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE and
+    """HBM bytes per launch of `kernel` from the newest PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 runs, corrected as MI355X_MICROARCH.md prescribes, by
-    tools/pmc_traffic.py).  Only valid for the exact workload it was measured on; otherwise None."""
-    path = os.path.join(REPO, "profiles", f"r01d_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")
-    if not os.path.exists(path):
+    tools/pmc_traffic.py).  Only valid for the exact workload AND kernel text it was measured on: a file that
+    names other kernel sources is refused (traffic null, the reason in traffic_source)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_traffic_{n_reads // 1_000_000}M_{read_len}bp.json")))
+    if not paths:
         return None, None
+    path = paths[-1]
     with open(path) as f:
         t = json.load(f)
     if int(t["image_bytes"]) != n_reads * record_bytes:
         return None, None
+    rel = os.path.relpath(path, REPO)
+    if t.get("kernel_sources_digest") != kernel_sources_digest():
+        return None, f"stale: {rel} was measured on other kernel sources"
     for k, v in t["kernels"].items():
         if k.split("<")[0] == {"k_frame_fast": "k_frame_fast_t", "k_stream_redo": "k_frame_fast_t"}.get(kernel, kernel):
-            return v["total"] / 1e9, os.path.relpath(path, REPO)
+            return v["total"] / 1e9, rel
     return None, None
 
 

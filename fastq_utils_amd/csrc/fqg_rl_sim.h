@@ -155,10 +155,18 @@ struct ChainView {
 struct Stats {
   uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
   unsigned long long clk_replay, clk_lookback, clk_store;  // device clock ticks spent per phase (0 on the CPU)
+  unsigned long long clk_max;                              // the slowest run: loop ticks << 32 | records used << 16 | inserts
+  unsigned long long clk_build, clk_loop;                  // inside clk_replay: building the array up to the first overwrite / the inserts after it
 };
 
 // LDS (or, on the CPU, heap) arrays of one chain worker.  W::p16 / W::p32 are the pointer types of the memory they
 // live in: on the device LDS pointers (ds_read / ds_write instead of flat accesses) or plain global ones.
+// tree_size() of a node whose count byte is saturated walks the node's whole subtree (src/range_list.c:566-593) -
+// for the root of a set of a hundred UMIs that is a thousand dependent reads per insert, twice.  The walks are
+// memoised: an entry (slot, depth, size) stays valid until something is written inside [slot, slot + size), and
+// moves along when an insert shifts the nodes behind its place.
+constexpr uint32_t kMemo = 64;
+
 template <class W>
 struct WorkT {
   typename W::p16 node;     // [cap] the array being replayed
@@ -168,6 +176,7 @@ struct WorkT {
   typename W::p32 base;     // [mcap + 1]
   typename W::p32 scratch;  // [lanes + 1] for the scan
   uint32_t cap, mcap;
+  typename W::p32 memo;     // [3 * kMemo] sizes of saturated subtrees: slot | depth | size (0: free entry)
 };
 
 template <class W>
@@ -308,13 +317,73 @@ struct Sim {
   WorkT<W>* wk;
   History<W>* hist;
   Stats* st;
-  uint32_t size, unknown_live, pending;
+  uint32_t size, unknown_live, pending, memo_next, memo_live;  // memo_live: valid entries (the same in every lane)
+
+  FQG_HD uint32_t memo_get(uint32_t idx, uint32_t d) {
+    for (uint32_t e0 = 0; e0 < kMemo; e0 += (uint32_t)W::lanes) {
+      const uint32_t e = e0 + W::lane();
+      const bool hit = e < kMemo && wk->memo[2 * kMemo + e] && wk->memo[e] == idx && wk->memo[kMemo + e] == d;
+      const uint32_t f = W::find_first(hit);
+      if (f != kNone) return wk->memo[2 * kMemo + e0 + f];
+    }
+    return 0;
+  }
+  FQG_HD void memo_put(uint32_t idx, uint32_t d, uint32_t t) {
+    uint32_t slot = kNone;
+    for (uint32_t e0 = 0; e0 < kMemo && slot == kNone; e0 += (uint32_t)W::lanes) {
+      const uint32_t e = e0 + W::lane();
+      const uint32_t f = W::find_first(e < kMemo && wk->memo[2 * kMemo + e] == 0);
+      if (f != kNone) slot = e0 + f;
+    }
+    if (slot == kNone) slot = memo_next++ % kMemo;
+    else ++memo_live;
+    if (W::lane() == 0) {
+      wk->memo[slot] = idx;
+      wk->memo[kMemo + slot] = d;
+      wk->memo[2 * kMemo + slot] = t;
+    }
+    W::sync();
+  }
+  // a write to slot idx: entries whose subtree holds it are void
+  FQG_HD void memo_touch(uint32_t idx) {
+    if (!memo_live) return;
+    for (uint32_t e0 = 0; e0 < kMemo; e0 += (uint32_t)W::lanes) {
+      const uint32_t e = e0 + W::lane();
+      const uint32_t t = e < kMemo ? wk->memo[2 * kMemo + e] : 0u;
+      const bool gone = t && idx - wk->memo[e] < t;
+      if (gone) wk->memo[2 * kMemo + e] = 0;
+      memo_live -= W::count(gone);
+    }
+    W::sync();
+  }
+  // nodes [at, size) move m slots up
+  FQG_HD void memo_shift(uint32_t at, uint32_t m) {
+    if (!memo_live) return;
+    for (uint32_t e0 = 0; e0 < kMemo; e0 += (uint32_t)W::lanes) {
+      const uint32_t e = e0 + W::lane();
+      const uint32_t t = e < kMemo ? wk->memo[2 * kMemo + e] : 0u;
+      bool gone = false;
+      if (t) {
+        const uint32_t ci = wk->memo[e];
+        if (ci >= at) {
+          if (ci + t > size) gone = true;  // (it read slots behind the last node: they do not move)
+          else wk->memo[e] = ci + m;
+        } else if (ci + t > at) gone = true;
+        if (gone) wk->memo[2 * kMemo + e] = 0;
+      }
+      memo_live -= W::count(gone);
+    }
+    W::sync();
+  }
 
   FQG_HD bool known(uint32_t idx) const { return (wk->known[idx >> 5] >> (idx & 31u)) & 1u; }
   FQG_HD void mark(uint32_t idx) { wk->known[idx >> 5] |= 1u << (idx & 31u); }
 
   FQG_HD void begin() {
     for (uint32_t i = W::lane(); i < wk->cap / 32u; i += W::lanes) wk->known[i] = 0;
+    for (uint32_t e = W::lane(); e < kMemo; e += (uint32_t)W::lanes) wk->memo[2 * kMemo + e] = 0;
+    memo_next = 0;
+    memo_live = 0;
     W::sync();
     wk->node[0] = 1u << 8;  // rl_all(OUT): quadrants empty (the root's count is never looked at by anyone else)
     mark(0);
@@ -339,6 +408,7 @@ struct Sim {
       if (idx < size) --unknown_live;
     }
     wk->node[idx] = v;
+    memo_touch(idx);
   }
   FQG_HD uint32_t quad(uint32_t idx, uint32_t q) { return (rd(idx) >> (2u * (q - 1u))) & 3u; }
   FQG_HD uint32_t count(uint32_t idx) { return rd(idx) >> 8; }
@@ -349,12 +419,17 @@ struct Sim {
     if (d >= 8) return 1;
     const uint32_t c0 = count(idx);
     if (c0 != 255u) return c0;
+    {
+      const uint32_t m = memo_get(idx, d);
+      if (m) return m;
+    }
     uint32_t s_idx[9], s_c[9], s_q[9];
     int sp = 0;
     s_idx[0] = idx; s_c[0] = 1; s_q[0] = 1;
     for (;;) {
       if (s_q[sp] > 4) {
         const uint32_t r = s_c[sp];
+        memo_put(s_idx[sp], d + (uint32_t)sp, r);
         if (!sp) return r;
         --sp;
         s_c[sp] += r;
@@ -365,9 +440,13 @@ struct Sim {
         const uint32_t child = s_idx[sp] + s_c[sp], cd = d + (uint32_t)sp + 1u;
         uint32_t cc = 1;
         if (cd < 8 && (cc = count(child)) == 255u && sp < 8) {
-          ++sp;
-          s_idx[sp] = child; s_c[sp] = 1; s_q[sp] = 1;
-          continue;
+          const uint32_t m = memo_get(child, cd);
+          if (m) cc = m;
+          else {
+            ++sp;
+            s_idx[sp] = child; s_c[sp] = 1; s_q[sp] = 1;
+            continue;
+          }
         }
         s_c[sp] += cc;
       }
@@ -393,8 +472,28 @@ struct Sim {
   }
   // slots [lo, hi] must hold their content before lanes move them
   FQG_HD void ensure_known(uint32_t lo, uint32_t hi) {
-    for (uint32_t i = lo; i <= hi && unknown_live; ++i)
-      if (!known(i)) (void)rd(i);
+    // (a slot of the range may stay unknown for as long as one before it does: the bitmap is looked at a word per
+    // lane, not a slot per step)
+    for (uint32_t w0 = lo >> 5; w0 <= (hi >> 5) && unknown_live; w0 += (uint32_t)W::lanes) {
+      const uint32_t w = w0 + W::lane();
+      uint32_t missing = 0;
+      if (w <= (hi >> 5)) {
+        missing = ~wk->known[w];
+        if (w == (lo >> 5)) missing &= ~0u << (lo & 31u);
+        if (w == (hi >> 5) && (hi & 31u) != 31u) missing &= (1u << ((hi & 31u) + 1u)) - 1u;
+      }
+      for (;;) {
+        const uint32_t f = W::find_first(missing != 0);
+        if (f == kNone) break;
+        uint32_t bits = W::bcast(missing, f);
+        while (bits) {
+          const uint32_t b = (uint32_t)__builtin_ctz(bits);
+          bits &= bits - 1u;
+          (void)rd((w0 + f) * 32u + b);
+        }
+        if (W::lane() == f) missing = 0;
+      }
+    }
   }
   // new_node(.., IN) (src/range_list.c:325-372).  A node that has just been created has no children, so an insert
   // that creates a node at depth d + 1 creates every node below it too, m = 8 - d in all, at consecutive slots
@@ -410,6 +509,7 @@ struct Sim {
         if (size - 1u + m >= wk->cap) { st->overflow = 1; }
         else {
           if (unknown_live) ensure_known(at, size - 1u);
+          memo_shift(at, m);
           // move node[at .. size - 1] m slots up, top piece first, 8 nodes per lane and piece
           uint32_t hi = size - 1u, remaining = (uint32_t)behind + 1u;
           while (remaining) {
@@ -489,8 +589,42 @@ struct Sim {
       wr(node, (uint16_t)((nv & 0xFFu) | (c << 8)));
     }
   }
+  // in_rl and, when it says no, set_in_rl(.., IN) in ONE walk: insert() goes down the path member() has just taken and
+  // reads the same values (nothing is written in between), so the second descent is skipped.  True: was a member.
+  FQG_HD bool member_or_insert(uint32_t umi_id) {
+    const uint32_t v = umi_id - 1u;
+    uint32_t path[8], before[8];
+    uint32_t idx = 0, d = 0;
+    bool opened = false;
+    for (; d < 8; ++d) {
+      path[d] = idx;
+      before[d] = size;
+      const uint32_t q = ((v >> (18u - 2u * d)) & 3u) + 1u;
+      const uint16_t nv = rd(idx);
+      const uint32_t s = quad_of(nv, q);
+      if (s == kQOut) {
+        idx = open_node(idx, nv, q, d);
+        opened = true;
+      } else if (s == kQAll) return true;  // (never on a freshly opened path)
+      else idx += child_offset(idx, nv, q, d);
+    }
+    const uint16_t leaf = rd(idx);
+    if (!opened && ((leaf >> (v & 15u)) & 1u)) return true;
+    wr(idx, (uint16_t)(leaf | (1u << (v & 15u))));
+    for (int k = 7; k >= 0; --k) {
+      const uint32_t node = path[k];
+      const uint32_t added = size - before[k];
+      const uint16_t nv = rd(node);
+      const uint32_t c0 = nv >> 8;
+      uint32_t c = c0 == 255u ? subtree_nodes(node, (uint32_t)k + 1u) : added + c0;  // (:485: the child's width)
+      if (c > 254u) c = 255u;
+      wr(node, (uint16_t)((nv & 0xFFu) | (c << 8)));
+    }
+    return false;
+  }
 };
 
+// (Sim::member_or_insert is defined with the struct; see below)
 // Replays one flagged run.  new_out[rec] (the storage cv.set_new points to, through a non-const pointer) receives
 // the reference's decision for every record of the run whose decision differs from set semantics;
 // on_change(record, is_new, run) is called (lane 0) for each of them.
@@ -528,19 +662,36 @@ FQG_HD void replay_run(const ChainView& cv, WorkT<W>& wk, Stats& st, uint8_t* ne
       k_first = k0;
     }
   }
+  const unsigned long long t_built = W::clock();
+  uint32_t dbg_used = 0, dbg_ins = 0;
   const uint32_t my_feat = cv.by_cell ? cv.run_feat[run] : 0u;
-  for (uint32_t k = cv.by_cell ? 0u : k_first; k < len; ++k) {
-    const uint32_t rec = cv.by_cell ? s0 + k : cv.order[s0 + k];
-    if (cv.by_cell && (cv.rec_feat[rec] != my_feat || rec < k_first)) continue;
-    const uint32_t u = cv.umi_id[rec];
-    const bool in = sim.member(u);
-    if (!in) sim.insert(u);
-    const uint8_t nw = in ? 0 : 1;
-    if (nw != cv.set_new[rec]) {
-      st.changed++;
-      if (W::lane() == 0) {
-        new_out[rec] = nw;
-        on_change(rec, nw, run);
+  // The records of the run, a wavefront's worth at a time: every lane fetches the ids of one record, then the replay
+  // takes them lane by lane - one round trip to memory per 64 records instead of three per record.
+  for (uint32_t kb = cv.by_cell ? 0u : k_first; kb < len; kb += (uint32_t)W::lanes) {
+    const uint32_t kk = kb + W::lane();
+    uint32_t m_rec = 0, m_u = 0, m_use = 0, m_set = 0;
+    if (kk < len) {
+      m_rec = cv.by_cell ? s0 + kk : cv.order[s0 + kk];
+      m_use = !(cv.by_cell && (cv.rec_feat[m_rec] != my_feat || m_rec < k_first));
+      if (m_use) {
+        m_u = cv.umi_id[m_rec];
+        m_set = cv.set_new[m_rec];
+      }
+    }
+    const uint32_t nb = len - kb < (uint32_t)W::lanes ? len - kb : (uint32_t)W::lanes;
+    for (uint32_t j = 0; j < nb; ++j) {
+      if (!W::bcast(m_use, j)) continue;
+      const uint32_t rec = W::bcast(m_rec, j), u = W::bcast(m_u, j);
+      const bool in = sim.member_or_insert(u);
+      ++dbg_used;
+      dbg_ins += in ? 0u : 1u;
+      const uint8_t nw = in ? 0 : 1;
+      if (nw != (uint8_t)W::bcast(m_set, j)) {
+        st.changed++;
+        if (W::lane() == 0) {
+          new_out[rec] = nw;
+          on_change(rec, nw, run);
+        }
       }
     }
   }
@@ -560,6 +711,12 @@ FQG_HD void replay_run(const ChainView& cv, WorkT<W>& wk, Stats& st, uint8_t* ne
   const unsigned long long t2 = W::clock();
   st.clk_replay += t1 - t0;
   st.clk_store += t2 - t1;
+  st.clk_build += t_built - t0;
+  st.clk_loop += t1 - t_built;
+  {
+    const unsigned long long packed = ((t1 - t_built) << 32) | ((unsigned long long)(dbg_used & 0xFFFFu) << 16) | (dbg_ins & 0xFFFFu);
+    if (packed > st.clk_max) st.clk_max = packed;
+  }
 }
 
 }  // namespace rl

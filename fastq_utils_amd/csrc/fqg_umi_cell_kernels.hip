@@ -279,32 +279,18 @@ __global__ __launch_bounds__(kBlock) void k_umi_cell_unit_sums(uint32_t n_cells,
 }
 
 // ---- RL_Tree replay on (cell, feature) runs: what k_rl_replay (by_cell) reads per run ----
-__global__ __launch_bounds__(kBlock) void k_rl_cell_runs(uint32_t n_runs, const uint32_t* __restrict__ pair_of,
-                                                         const KeySlot* __restrict__ pair_key,
-                                                         const uint32_t* __restrict__ cell_first,
-                                                         const uint32_t* __restrict__ pair_mem,
-                                                         const uint32_t* __restrict__ pair_umis, RlRuns runs,
-                                                         uint32_t* __restrict__ run_feat, uint32_t* __restrict__ run_mem,
-                                                         uint32_t* __restrict__ run_nmem, RlCall* __restrict__ call) {
-  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-  if (r >= n_runs) return;
-  const uint32_t slot = pair_of[r];
-  const unsigned long long key = pair_key[slot].key;
-  const uint32_t cell = (uint32_t)(key >> 32);
-  runs.start[r] = cell_first[cell];
-  runs.len[r] = cell_first[cell + 1] - cell_first[cell];
-  run_feat[r] = (uint32_t)key;
-  run_mem[r] = pair_mem[slot];
-  const uint32_t nm = pair_umis[slot];  // (set semantics: distinct members; read before any replay patches it)
-  run_nmem[r] = nm;
-  if (nm > call->max_len) atomicMax(&call->max_len, nm);
-}
+// The replay looks back along a feature's earlier (cell, feature) pairs - but only for the features that have a
+// flagged pair at all (63 of 20 000 on BASELINE.json configs[3]).  k_rl_cell_flags marks those features,
+// k_rl_cell_chain keeps the pairs ("runs") of marked features: their description for the replay (records of the cell,
+// members) and an entry (feature << 32 | cell, run) in the list that is then sorted into the chains.
 __global__ __launch_bounds__(kBlock) void k_rl_cell_flags(uint32_t n_flagged, const uint32_t* __restrict__ flagged_slot,
                                                           const uint32_t* __restrict__ slot_hit,
                                                           const uint32_t* __restrict__ run_of_slot,
+                                                          const KeySlot* __restrict__ pair_key,
                                                           const uint32_t* __restrict__ pair_reads, RlRuns runs,
                                                           uint32_t* __restrict__ flagged, uint32_t* __restrict__ flag_k0,
-                                                          uint32_t* __restrict__ flag_len, RlCall* __restrict__ call) {
+                                                          uint32_t* __restrict__ flag_len, uint8_t* __restrict__ feat_flag,
+                                                          RlCall* __restrict__ call) {
   const uint32_t fi = blockIdx.x * kBlock + threadIdx.x;
   if (fi >= n_flagged) return;
   const uint32_t slot = flagged_slot[fi], run = run_of_slot[slot];
@@ -313,7 +299,45 @@ __global__ __launch_bounds__(kBlock) void k_rl_cell_flags(uint32_t n_flagged, co
   flag_k0[fi] = slot_hit[slot];       // the record whose insert overwrites: records below it precede it
   const uint32_t len = pair_reads[slot];
   flag_len[fi] = len;
+  feat_flag[(uint32_t)pair_key[slot].key] = 1;
   atomicMax(&call->max_flagged_len, len);
+}
+__global__ __launch_bounds__(kBlock) void k_rl_cell_chain(uint32_t n_runs, const uint32_t* __restrict__ pair_of,
+                                                          const KeySlot* __restrict__ pair_key,
+                                                          const uint8_t* __restrict__ feat_flag,
+                                                          const uint32_t* __restrict__ cell_first,
+                                                          const uint32_t* __restrict__ pair_mem,
+                                                          const uint32_t* __restrict__ pair_umis, RlRuns runs,
+                                                          uint32_t* __restrict__ run_feat, uint32_t* __restrict__ run_mem,
+                                                          uint32_t* __restrict__ run_nmem,
+                                                          unsigned long long* __restrict__ chain_key,
+                                                          uint32_t* __restrict__ chain_run, RlCall* __restrict__ call) {
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  bool keep = false;
+  unsigned long long key = 0;
+  uint32_t slot = 0;
+  if (r < n_runs) {
+    slot = pair_of[r];
+    key = pair_key[slot].key;  // cell << 32 | feature
+    keep = feat_flag[(uint32_t)key] != 0;
+  }
+  const unsigned long long m = __ballot(keep);
+  if (!m) return;
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(&call->n_chain, (uint32_t)__popcll(m));
+  base = __shfl(base, 0);
+  if (!keep) return;
+  const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+  chain_key[at] = (key << 32) | (key >> 32);
+  chain_run[at] = r;
+  const uint32_t cell = (uint32_t)(key >> 32);
+  runs.start[r] = cell_first[cell];
+  runs.len[r] = cell_first[cell + 1] - cell_first[cell];
+  run_feat[r] = (uint32_t)key;
+  run_mem[r] = pair_mem[slot];
+  const uint32_t nm = pair_umis[slot];  // (set semantics: distinct members; read before any replay patches it)
+  run_nmem[r] = nm;
+  if (nm > call->max_len) atomicMax(&call->max_len, nm);
 }
 
 }  // namespace fqg

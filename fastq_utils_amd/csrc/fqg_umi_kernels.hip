@@ -100,108 +100,132 @@ __device__ __forceinline__ int aux_type2size(int x) {
 }
 __device__ __forceinline__ int c_toupper(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 
-// bam_aux_get: pointer to the type byte of the first field named tag, or null.  [s, end) is the aux
-// area; `lim` bounds every read (a malformed field may run past `end`, as in libbam).
-__device__ const uint8_t* aux_get(const uint8_t* s, const uint8_t* end, const uint8_t* lim, const uint8_t tag[2]) {
-  while (s < end) {
-    if (s + 2 > lim) return nullptr;
-    const int x0 = s[0], x1 = s[1];
-    s += 2;
-    if (x0 == tag[0] && x1 == tag[1]) return s < lim ? s : nullptr;
-    if (s >= lim) return nullptr;
-    const int type = c_toupper(*s);
-    ++s;
-    if (type == 'Z' || type == 'H') {
-      while (s < lim && *s) ++s;
-      ++s;
-    } else if (type == 'B') {
-      if (s + 5 > lim) return nullptr;
-      const int sub = *s;
-      const int32_t cnt = (int32_t)((uint32_t)s[1] | ((uint32_t)s[2] << 8) | ((uint32_t)s[3] << 16) | ((uint32_t)s[4] << 24));
-      s += 5 + (long)aux_type2size(sub) * cnt;
-    } else {
-      s += aux_type2size(type);
-    }
+// The walks below run one record per lane over bytes in LDS: a chain of dependent reads, whose LATENCY is the cost
+// (two or three wavefronts per SIMD hide little of it).  Strings are therefore scanned 8 bytes per read, and every
+// function is a template over the pointer type, so that the staged walk is compiled to DS instructions (a pointer
+// that may be LDS or global memory costs FLAT accesses).
+typedef const __attribute__((address_space(3))) uint8_t* LdsBytes;
+typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
+__device__ __forceinline__ uint64_t ld8(LdsBytes p) { return *(const __attribute__((address_space(3))) u64_unaligned*)p; }
+__device__ __forceinline__ uint32_t ld4(LdsBytes p) { return *(const __attribute__((address_space(3))) u32_unaligned*)p; }
+__device__ __forceinline__ uint32_t ld4(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+// the first NUL in [s, lim), or lim
+template <class B>
+__device__ __forceinline__ B find_nul(B s, B lim) {
+  while (lim - s >= 8) {
+    const uint64_t m = bytes_eq(ld8(s), 0);
+    if (m) return s + (__builtin_ctzll(m) >> 3);
+    s += 8;
   }
-  return nullptr;
+  while (s < lim && *s) ++s;
+  return s;
+}
+// index of the first byte equal to c in s[from, n), or n (s + n <= lim)
+template <class B>
+__device__ __forceinline__ uint32_t find_byte(B s, uint32_t from, uint32_t n, uint8_t c, B lim) {
+  uint32_t p = from;
+  while (p + 8 <= n) {
+    const uint64_t m = bytes_eq(ld8(s + p), c);
+    if (m) return p + (uint32_t)(__builtin_ctzll(m) >> 3);
+    p += 8;
+  }
+  if (p < n && lim - (s + p) >= 8) {
+    const uint64_t m = bytes_eq(ld8(s + p), c) & ((1ull << (8 * (n - p))) - 1ull);
+    return m ? p + (uint32_t)(__builtin_ctzll(m) >> 3) : n;
+  }
+  while (p < n && s[p] != c) ++p;
+  return p;
 }
 
-// Four bam_aux_get calls in ONE walk over the aux area: hit[k] = what bam_aux_get(tag[k]) returns (the first field of
-// that name; null when there is none or the walk runs into `lim` first).  A call for one tag skips every field
-// before its hit exactly as the calls for the other tags do, so one walk that remembers first hits is the same.
-__device__ __forceinline__ void aux_get4(const uint8_t* s, const uint8_t* end, const uint8_t* lim, const uint8_t (*tag)[2],
-                                         const uint8_t** hit) {
-  uint32_t open = 15u;  // tags still looked for
-  hit[0] = hit[1] = hit[2] = hit[3] = nullptr;
+// Four bam_aux_get calls (bam_aux.c: the type byte of the first field named tag, or null) in ONE walk over the aux area
+// [s, end): bit k of the result says that tag[k] has a hit, hit[k] = its type byte.  A call for one tag skips every
+// field before its hit exactly as the calls for the other tags do, so one walk that remembers first hits is the same.
+// `lim` bounds every read (a malformed field may run past `end`, as in libbam); a 'B' field whose count leads outside
+// [s, lim) ends the walk.
+template <class B>
+__device__ __forceinline__ uint32_t aux_get4(B s, B end, B lim, const uint8_t (*tag)[2], B* hit) {
+  uint32_t open = 15u, got = 0;  // tags still looked for / found
   while (s < end && open) {
-    if (s + 2 > lim) return;
+    if (lim - s < 2) break;
     const int x0 = s[0], x1 = s[1];
     s += 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if ((open >> k) & 1u)
         if (x0 == tag[k][0] && x1 == tag[k][1]) {
-          hit[k] = s < lim ? s : nullptr;
           open &= ~(1u << k);
+          if (s < lim) {
+            hit[k] = s;
+            got |= 1u << k;
+          }
         }
-    if (s >= lim) return;
+    if (s >= lim) break;
     const int type = c_toupper(*s);
     ++s;
     if (type == 'Z' || type == 'H') {
-      while (s < lim && *s) ++s;
-      ++s;
+      s = find_nul(s, lim) + 1;
     } else if (type == 'B') {
-      if (s + 5 > lim) return;
-      const int sub = *s;
-      const int32_t cnt = (int32_t)((uint32_t)s[1] | ((uint32_t)s[2] << 8) | ((uint32_t)s[3] << 16) | ((uint32_t)s[4] << 24));
-      s += 5 + (long)aux_type2size(sub) * cnt;
+      if (lim - s < 5) break;
+      const long skip = 5 + (long)aux_type2size(*s) * (long)(int32_t)ld4(s + 1);
+      if (skip < 0 || skip > (long)(lim - s)) break;
+      s += skip;
     } else {
       s += aux_type2size(type);
     }
   }
+  return got;
 }
 
 // bam_aux2Z + get_tag (src/bam_umi_count.c:513-522): string bytes and length (0 = EMPTY_STRING)
-__device__ __forceinline__ uint32_t aux_string(const uint8_t* t, const uint8_t* lim, const uint8_t** str) {
-  *str = nullptr;
-  if (!t) return 0;
+template <class B>
+__device__ __forceinline__ uint32_t aux_string(bool have, B t, B lim, B* str) {
+  if (!have) return 0;
   if (*t != 'Z' && *t != 'H') return 0;
-  const uint8_t* p = t + 1;
-  uint32_t n = 0;
-  while (p + n < lim && p[n]) ++n;
-  *str = p;
-  return n;
+  *str = t + 1;
+  return (uint32_t)(find_nul(t + 1, lim) - (t + 1));
 }
 
-__device__ __forceinline__ int32_t aux_int(const uint8_t* t, const uint8_t* lim) {  // bam_aux2i
-  if (!t || t + 2 > lim) return 0;
+template <class B>
+__device__ __forceinline__ int32_t aux_int(B t, B lim) {  // bam_aux2i
+  if (lim - t < 2) return 0;
   const int type = *t;
-  const uint8_t* s = t + 1;
-  if (((type == 's' || type == 'S') && t + 3 > lim) || ((type == 'i' || type == 'I') && t + 5 > lim)) return 0;
+  B s = t + 1;
+  if (((type == 's' || type == 'S') && lim - t < 3) || ((type == 'i' || type == 'I') && lim - t < 5)) return 0;
   if (type == 'c') return (int32_t)(int8_t)s[0];
   if (type == 'C') return (int32_t)s[0];
   if (type == 's') return (int32_t)(int16_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8));
   if (type == 'S') return (int32_t)((uint16_t)s[0] | ((uint16_t)s[1] << 8));
-  if (type == 'i' || type == 'I') return (int32_t)((uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24));
+  if (type == 'i' || type == 'I') return (int32_t)ld4(s);
   return 0;
 }
 
 // char2uint_64 (src/bam_umi_count.c:364-382): base 10, A C G T N -> 1..5, parsed from the end, stops
 // at the first other character
-__device__ __forceinline__ unsigned long long pack_barcode(const uint8_t* s, uint32_t n) {
-  uint32_t pos = 0;
-  while (pos < n && s[pos] != '\n') ++pos;
+__device__ __forceinline__ int base2int(uint32_t c) {  // :321-337
+  c |= 0x20u;
+  return c == 'a' ? 1 : c == 'c' ? 2 : c == 'g' ? 3 : c == 't' ? 4 : c == 'n' ? 5 : 0;
+}
+template <class B>
+__device__ __forceinline__ unsigned long long pack_barcode(B s, uint32_t n, B lim) {
+  uint32_t pos = find_byte(s, 0, n, (uint8_t)'\n', lim);
   unsigned long long v = 0;
-  while (pos > 0) {
-    int b;
-    switch (s[pos - 1]) {  // base2int :321-337
-      case 'A': case 'a': b = 1; break;
-      case 'C': case 'c': b = 2; break;
-      case 'G': case 'g': b = 3; break;
-      case 'T': case 't': b = 4; break;
-      case 'N': case 'n': b = 5; break;
-      default: b = 0;
+  while (pos >= 8) {  // 8 characters per read, the last one first
+    const uint64_t w = ld8(s + pos - 8);
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+      const int b = base2int((uint32_t)(w >> (8 * k)) & 0xFFu);
+      if (!b) return v;
+      v = v * 10ull + (unsigned long long)b;
     }
+    pos -= 8;
+  }
+  while (pos > 0) {
+    const int b = base2int(s[pos - 1]);
     if (!b) break;
     v = v * 10ull + (unsigned long long)b;
     --pos;
@@ -215,77 +239,46 @@ __device__ __forceinline__ unsigned long long pack_barcode(const uint8_t* s, uin
 // records) are walked in global memory.
 constexpr int kParseStage = 16 * 1024;  // bytes per wavefront
 
-__global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict__ gbuf, uint64_t nbytes,
-                                                      const unsigned long long* __restrict__ offs, uint32_t n,
-                                                      UmiParams P, UmiRec* __restrict__ rec,
-                                                      uint8_t* __restrict__ stage, UmiCall* __restrict__ call) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kBlock / kWave][kParseStage + 32];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t i0 = blockIdx.x * kBlock + (uint32_t)wv * kWave;
-  if (i0 >= n) return;
-  const uint32_t i_last = i0 + kWave - 1 < n - 1 ? i0 + kWave - 1 : n - 1;
-  const uint64_t span0 = offs[i0] & ~15ull;  // aligned down: 16-byte loads
-  const uint64_t span1 = i_last + 1 < n ? offs[i_last + 1] : nbytes;
-  const bool staged = span1 - span0 <= (uint64_t)kParseStage;
-  if (staged) {
-    uint8_t* dstb = s_stage[wv];
-    for (uint64_t o = (uint64_t)lane * 16; o < span1 - span0; o += 16 * kWave) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (span0 + o + 16 <= nbytes) v = *reinterpret_cast<const uint4*>(gbuf + span0 + o);
-      else
-        for (uint64_t b = 0; span0 + o + b < nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&v)[b] = gbuf[span0 + o + b];
-      *reinterpret_cast<uint4*>(dstb + o) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (i >= n) return;
-  // `base` is byte span0 of the stream either way (every pointer stays inside its buffer); offsets
-  // written out are stream offsets
-  const uint8_t* base = staged ? s_stage[wv] : gbuf + span0;
-  const uint8_t* lim = base + ((staged ? span1 : nbytes) - span0);
-  const uint8_t* r = base + (offs[i] - span0);
+// one record: `base` is byte span0 of the stream (its LDS copy or the stream itself); every read stays inside
+// [base, lim); offsets written out are stream offsets
+template <class B>
+__device__ __forceinline__ uint8_t parse_record(B base, B lim, B r, uint64_t span0, const UmiParams& P, UmiRec& out) {
   uint8_t st = kStSkipped;
-  UmiRec out;
-  out.umi_i = out.cell_i = 0;
-  out.tok_off = 0;
-  out.tok_len = 0;
-  out.incr = 1.0f;
   do {
-    if (r + 36 > lim) break;
-    auto rd32 = [&](int o) { return (uint32_t)r[o] | ((uint32_t)r[o + 1] << 8) | ((uint32_t)r[o + 2] << 16) | ((uint32_t)r[o + 3] << 24); };
-    const int32_t block_len = (int32_t)rd32(0);
-    const int32_t tid = (int32_t)rd32(4);
-    const uint32_t l_qname = rd32(12) & 0xFFu;
-    const uint32_t flag_nc = rd32(16);
+    if (lim - r < 36) break;
+    const int32_t block_len = (int32_t)ld4(r);
+    const int32_t tid = (int32_t)ld4(r + 4);
+    const uint32_t l_qname = ld4(r + 12) & 0xFFu;
+    const uint32_t flag_nc = ld4(r + 16);
     const uint32_t flag = flag_nc >> 16, n_cigar = flag_nc & 0xFFFFu;
-    const uint32_t l_qseq = rd32(20);
+    const uint32_t l_qseq = ld4(r + 20);
     if (tid < 0) break;          // :950
     if (flag & 4u) break;        // BAM_FUNMAP :951
-    const uint8_t* end = r + 4 + (long)block_len;
-    if (end > lim) end = lim;
-    const uint8_t* aux = r + 36 + l_qname + 4ull * n_cigar + (l_qseq + 1) / 2 + l_qseq;
-    if (aux > end) aux = end;
+    const uint64_t room = (uint64_t)(lim - r);
+    uint64_t end_o = block_len < -4 ? 0ull : (uint64_t)(4l + (long)block_len);  // (negative: nothing to walk)
+    if (end_o > room) end_o = room;
+    uint64_t aux_o = 36ull + l_qname + 4ull * n_cigar + (l_qseq + 1) / 2 + (uint64_t)l_qseq;
+    if (aux_o > end_o) aux_o = end_o;
+    const B end = r + end_o, aux = r + aux_o;
     int nh_i = 1;
     const uint8_t tags[4][2] = {{'N', 'H'}, {P.feat_tag[0], P.feat_tag[1]}, {P.umi_tag[0], P.umi_tag[1]},
                                 {P.cell_tag[0], P.cell_tag[1]}};
-    const uint8_t* hit[4];
-    aux_get4(aux, end, lim, tags, hit);
-    if (hit[0]) {
+    B hit[4] = {r, r, r, r};
+    const uint32_t got = aux_get4(aux, end, lim, tags, hit);
+    if (got & 1u) {
       nh_i = aux_int(hit[0], lim);
       if (nh_i > 1 && P.uniq_mapped_only) break;
     }
-    const uint8_t *feat, *umi, *cell;
-    const uint32_t lf = aux_string(hit[1], lim, &feat);
+    B feat = r, umi = r, cell = r;
+    const uint32_t lf = aux_string((got & 2u) != 0, hit[1], lim, &feat);
     if (!lf) break;
     st = kStNoUmi;
-    const uint32_t lu = aux_string(hit[2], lim, &umi);
+    const uint32_t lu = aux_string((got & 4u) != 0, hit[2], lim, &umi);
     if (!lu) break;
     st = kStUmi;
-    const uint32_t lc = aux_string(hit[3], lim, &cell);
-    out.umi_i = pack_barcode(umi, lu);
-    out.cell_i = lc ? pack_barcode(cell, lc) : 0ull;
+    const uint32_t lc = aux_string((got & 8u) != 0, hit[3], lim, &cell);
+    out.umi_i = pack_barcode(umi, lu, lim);
+    out.cell_i = lc ? pack_barcode(cell, lc, lim) : 0ull;
     // strtok(feat, ","): tokens are the maximal runs of non-comma bytes.  n_feat counts the first
     // token and every token equal to its predecessor; only the first token is processed (the first
     // pass replaced the commas by NULs)
@@ -295,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict_
       while (p < lf && feat[p] == ',') ++p;
       if (p >= lf) break;
       const uint32_t s0 = p;
-      while (p < lf && feat[p] != ',') ++p;
+      p = find_byte(feat, p, lf, (uint8_t)',', lim);
       const uint32_t len = p - s0;
       bool same = have_prev && len == prev_l;
       if (same)
@@ -317,6 +310,49 @@ __global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict_
     out.tok_len = l0;
     out.incr = (float)(1.0 / (double)((int)n_feat * nh_i));  // float incr=1.0/(n_feat*nh_i) :1044
   } while (false);
+  return st;
+}
+
+__global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict__ gbuf, uint64_t nbytes,
+                                                      const unsigned long long* __restrict__ offs, uint32_t n,
+                                                      UmiParams P, UmiRec* __restrict__ rec,
+                                                      uint8_t* __restrict__ stage, UmiCall* __restrict__ call) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kBlock / kWave][kParseStage + 32];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t i0 = blockIdx.x * kBlock + (uint32_t)wv * kWave;
+  if (i0 >= n) return;
+  const uint32_t i_last = i0 + kWave - 1 < n - 1 ? i0 + kWave - 1 : n - 1;
+  const uint64_t my_off = offs[i < n ? i : n - 1];
+  const uint64_t span0 = __shfl(my_off, 0) & ~15ull;  // aligned down: 16-byte loads
+  const uint64_t span1 = i_last + 1 < n ? offs[i_last + 1] : nbytes;
+  const bool staged = span1 - span0 <= (uint64_t)kParseStage;
+  if (staged) {
+    uint8_t* dstb = s_stage[wv];
+    for (uint64_t o = (uint64_t)lane * 16; o < span1 - span0; o += 16 * kWave) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (span0 + o + 16 <= nbytes) v = *reinterpret_cast<const uint4*>(gbuf + span0 + o);
+      else
+        for (uint64_t b = 0; span0 + o + b < nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&v)[b] = gbuf[span0 + o + b];
+      *reinterpret_cast<uint4*>(dstb + o) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (i >= n) return;
+  UmiRec out;
+  out.umi_i = out.cell_i = 0;
+  out.tok_off = 0;
+  out.tok_len = 0;
+  out.incr = 1.0f;
+  uint8_t st;
+  if (staged) {
+    const LdsBytes lb = (LdsBytes)s_stage[wv];
+    st = parse_record(lb, lb + (uint32_t)(span1 - span0), lb + (uint32_t)(my_off - span0), span0, P, out);
+  } else {
+    const uint8_t* gb = gbuf + span0;
+    st = parse_record(gb, gbuf + nbytes, gbuf + my_off, span0, P, out);
+  }
   rec[i] = out;
   stage[i] = st;
   const unsigned long long tags = __ballot(st >= kStNoUmi);
@@ -333,6 +369,7 @@ struct KeyTable {          // u64 key -> smallest record index
 };
 struct NameTable {         // feature names: slot = tag32 << 32 | claimant record
   unsigned long long* slots;
+  unsigned long long* words;  // 3 per slot: the claimant's name (k_umi_insert)
   uint32_t* first;
   uint64_t mask;
 };
@@ -414,7 +451,31 @@ __device__ __forceinline__ bool sorted_contains(const unsigned long long* a, uin
 // kNoIdx | (whitelist order) for UMIs that the whitelist already numbered.
 constexpr uint32_t kWhiteBit = 0x80000000u;
 
-__global__ __launch_bounds__(kBlock) void k_umi_insert(const uint8_t* __restrict__ buf, uint32_t n, UmiParams P,
+// a feature name (at most kFeatIdMaxLen - 2 = 23 bytes) as three words, bytes beyond its length zero: hashing and
+// comparing names byte by byte is a chain of dependent memory round trips per name, this is one
+__device__ __forceinline__ void name_words(const uint8_t* buf, uint64_t nbytes, uint64_t off, uint32_t len, uint64_t w[3]) {
+  const uint8_t* s = buf + off;
+  if (off + 24 <= nbytes) {
+    w[0] = ld8(s);
+    w[1] = ld8(s + 8);
+    w[2] = ld8(s + 16);
+  } else {
+    w[0] = w[1] = w[2] = 0;
+    for (uint32_t k = 0; k < len && k < 24; ++k) {
+      const uint64_t b = (uint64_t)s[k] << (8 * (k & 7));
+      if (k < 8) w[0] |= b;
+      else if (k < 16) w[1] |= b;
+      else w[2] |= b;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const uint32_t have = len > 8u * j ? len - 8u * j : 0u;
+    if (have < 8) w[j] &= have ? (1ull << (8 * have)) - 1ull : 0ull;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_umi_insert(const uint8_t* __restrict__ buf, uint64_t nbytes, uint32_t n, UmiParams P,
                                                        const UmiRec* __restrict__ rec, uint8_t* __restrict__ stage,
                                                        KeyTable U, KeyTable C, NameTable F,
                                                        uint32_t* __restrict__ uslot, uint32_t* __restrict__ cslot,
@@ -429,47 +490,80 @@ __global__ __launch_bounds__(kBlock) void k_umi_insert(const uint8_t* __restrict
     if (P.have_known_umis && !(r.umi_i >= 1 && r.umi_i <= (unsigned long long)P.n_known_umis)) st = kStUmiDiscarded;
     else {
       uint32_t at;
-      if (P.have_known_umis && sorted_contains(P.known_umis_sorted, P.n_known_umis, r.umi_i, &at))
-        us = kWhiteBit | P.known_umis_order[at];
-      else
-        us = table_insert(U, r.umi_i, i, call);
-      if (P.have_known_cells && !sorted_contains(P.known_cells_sorted, P.n_known_cells, r.cell_i, nullptr))
-        st = kStCellDiscarded;
+      const bool white = P.have_known_umis && sorted_contains(P.known_umis_sorted, P.n_known_umis, r.umi_i, &at);
+      if (white) us = kWhiteBit | P.known_umis_order[at];
+      const bool cell_ok = !(P.have_known_cells && !sorted_contains(P.known_cells_sorted, P.n_known_cells, r.cell_i, nullptr));
+      const bool do_f = cell_ok && r.tok_len > 0 && r.tok_len + 1 < (uint32_t)kFeatIdMaxLen;
+      uint64_t w[3] = {0, 0, 0};
+      if (do_f) name_words(buf, nbytes, r.tok_off, r.tok_len, w);
+      w[2] |= (uint64_t)r.tok_len << 56;  // (a name has at most 23 bytes)
+      const uint64_t hsh = umi_mix(umi_mix(umi_mix(0x9E3779B97F4A7C15ull ^ w[0]) ^ w[1]) ^ w[2]);
+      const unsigned long long tag = (hsh >> 32) << 32;
+      // Most records repeat keys that are in the tables already (a cell's run, an expressed gene, a UMI seen before)
+      // with an earlier first record: nothing to write.  That case is decided from the keys' HOME slots, read for all
+      // three tables at once - one round trip to memory instead of three dependent chains.
+      const uint64_t hu = umi_mix(r.umi_i) & U.mask, hc = umi_mix(r.cell_i) & C.mask, hf = hsh & F.mask;
+      unsigned long long ku = 0, kc = 0, vf = 0, q0 = 0, q1 = 0, q2 = 0;
+      uint32_t fu = 0, fc = 0, ff = 0;
+      if (!white) {
+        ku = U.keys[hu];
+        fu = U.first[hu];
+      }
+      if (cell_ok) {
+        kc = C.keys[hc];
+        fc = C.first[hc];
+      }
+      if (do_f) {
+        vf = F.slots[hf];
+        ff = F.first[hf];
+        q0 = F.words[3 * hf];
+        q1 = F.words[3 * hf + 1];
+        q2 = F.words[3 * hf + 2];
+      }
+      if (!white) us = (ku == r.umi_i && fu <= i) ? (uint32_t)hu : table_insert(U, r.umi_i, i, call);
+      if (!cell_ok) st = kStCellDiscarded;
       else {
         st = kStCounted;
-        cs = table_insert(C, r.cell_i, i, call);
-        if (r.tok_len > 0 && r.tok_len + 1 < (uint32_t)kFeatIdMaxLen) {
-          const uint8_t* s = buf + r.tok_off;
-          uint64_t hsh = 0x9E3779B97F4A7C15ull;
-          for (uint32_t k = 0; k < r.tok_len; ++k) hsh = umi_mix(hsh ^ s[k]);
-          const unsigned long long tag = (hsh >> 32) << 32;
-          uint64_t h = hsh & F.mask;
-          for (uint64_t probes = 0; probes <= F.mask; ++probes) {
-            unsigned long long v = F.slots[h];
-            if (v == kKeyEmpty) {
-              v = atomicCAS(&F.slots[h], kKeyEmpty, tag | i);
-              if (v == kKeyEmpty) v = tag | i;
-            }
-            if ((v >> 32) == (tag >> 32)) {
-              const UmiRec o = rec[(uint32_t)v];
-              bool same = o.tok_len == r.tok_len;
-              if (same) {
-                const uint8_t* q = buf + o.tok_off;
-                for (uint32_t k = 0; k < r.tok_len; ++k)
-                  if (q[k] != s[k]) {
-                    same = false;
-                    break;
+        cs = (kc == r.cell_i && fc <= i) ? (uint32_t)hc : table_insert(C, r.cell_i, i, call);
+        if (do_f) {
+          // F.words[] holds the claimant's name, written after its claim without any ordering: three words that all
+          // equal mine can only be the finished name (no word of a name reads ~0: the third carries the length, and
+          // names whose first 16 bytes hold eight 0xFF in a row take the slow path)
+          if ((vf >> 32) == (tag >> 32) && q0 == w[0] && q1 == w[1] && q2 == w[2] && w[0] != ~0ull && w[1] != ~0ull && ff <= i)
+            fs = (uint32_t)hf;
+          else {
+            uint64_t h = hf;
+            for (uint64_t probes = 0; probes <= F.mask; ++probes) {
+              unsigned long long v = F.slots[h];
+              if (v == kKeyEmpty) {
+                v = atomicCAS(&F.slots[h], kKeyEmpty, tag | i);
+                if (v == kKeyEmpty) {
+                  v = tag | i;
+                  F.words[3 * h] = w[0];
+                  F.words[3 * h + 1] = w[1];
+                  F.words[3 * h + 2] = w[2];
+                }
+              }
+              if ((v >> 32) == (tag >> 32)) {
+                bool same = (uint32_t)v == i;
+                if (!same) {
+                  const UmiRec o = rec[(uint32_t)v];
+                  if (o.tok_len == r.tok_len) {
+                    uint64_t q[3];
+                    name_words(buf, nbytes, o.tok_off, o.tok_len, q);
+                    same = q[0] == w[0] && q[1] == w[1] && (q[2] | ((uint64_t)o.tok_len << 56)) == w[2];
                   }
+                }
+                if (same) {
+                  if (F.first[h] > i) atomicMin(&F.first[h], i);
+                  fs = (uint32_t)h;
+                  break;
+                }
               }
-              if (same) {
-                if (F.first[h] > i) atomicMin(&F.first[h], i);
-                fs = (uint32_t)h;
-                break;
-              }
+              h = (h + 1) & F.mask;
             }
-            h = (h + 1) & F.mask;
+            if (fs == kNoIdx) atomicOr(&call->table_full, 1u);
           }
-          if (fs == kNoIdx) atomicOr(&call->table_full, 1u);
         }
       }
     }

@@ -24,6 +24,15 @@ struct GpuWaveBase {
     return (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
   }
   static __device__ __forceinline__ uint32_t count(bool b) { return (uint32_t)__popcll(__ballot(b)); }
+  // the lowest lane whose b is set, or rl::kNone
+  static __device__ __forceinline__ uint32_t find_first(bool b) {
+    const unsigned long long m = __ballot(b);
+    return m ? (uint32_t)__builtin_ctzll(m) : 0xFFFFFFFFu;
+  }
+  // lane `src`'s value of v (src is the same in every lane)
+  static __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src));
+  }
   // the final array of an earlier replayed run of the same chain: its worker took its ticket before ours, so it
   // is running (or done) and this wait ends
   static __device__ __forceinline__ uint32_t wait_nonzero(const uint32_t* p) {
@@ -51,7 +60,9 @@ struct GpuWaveGlobal : GpuWaveBase {
 struct RlCall {
   uint32_t n_flagged, next_item, max_len, max_flagged_len;
   uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
+  uint32_t n_chain, pad_;   // sorted mode by cell: runs of the features that have a flagged run
   unsigned long long clk_replay, clk_lookback, clk_store;  // wall_clock64 ticks (100 MHz) summed over the workers
+  unsigned long long clk_build, clk_loop, clk_max;
 };
 
 struct RlRuns {      // per run (= per (cell, feature) pair), in order of the sorted pair slots
@@ -176,6 +187,7 @@ __device__ __forceinline__ void rl_replay_body(const RlReplayArgs& A, P8 g, type
   wk.known = (typename W::p32)carve((uint64_t)A.cap / 8 + 4);
   wk.mem = (typename W::p32)carve((uint64_t)A.mcap * 4);
   wk.base = (typename W::p32)carve((uint64_t)(A.mcap + 1) * 4);
+  wk.memo = (typename W::p32)carve((uint64_t)3 * rl::kMemo * 4);
   wk.scratch = scan;
   rl::Stats st{};
   for (;;) {  // tickets in replay order
@@ -223,6 +235,9 @@ __device__ __forceinline__ void rl_replay_body(const RlReplayArgs& A, P8 g, type
     atomicAdd(&A.call->clk_replay, st.clk_replay);
     atomicAdd(&A.call->clk_lookback, st.clk_lookback);
     atomicAdd(&A.call->clk_store, st.clk_store);
+    atomicAdd(&A.call->clk_build, st.clk_build);
+    atomicAdd(&A.call->clk_loop, st.clk_loop);
+    atomicMax(&A.call->clk_max, st.clk_max);
   }
 }
 
@@ -241,7 +256,8 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
 // bytes of a worker's arrays (the carve-up of k_rl_replay)
 static inline uint64_t rl_work_bytes(uint32_t cap, uint32_t mcap) {
   auto r = [](uint64_t b) { return (b + 15) & ~15ull; };
-  return 2 * r((uint64_t)cap * 2) + r((uint64_t)cap / 8 + 4) + r((uint64_t)mcap * 4) + r((uint64_t)(mcap + 1) * 4);
+  return 2 * r((uint64_t)cap * 2) + r((uint64_t)cap / 8 + 4) + r((uint64_t)mcap * 4) + r((uint64_t)(mcap + 1) * 4) +
+         r((uint64_t)3 * rl::kMemo * 4);
 }
 
 __global__ __launch_bounds__(kBlock) void k_rl_flag_lens(uint32_t n_flagged, const uint32_t* __restrict__ flagged,

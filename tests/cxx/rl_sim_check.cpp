@@ -19,6 +19,8 @@ struct CpuWave {
   static void sync() {}
   static uint32_t rank(bool) { return 0; }
   static uint32_t count(bool b) { return b ? 1u : 0u; }
+  static uint32_t bcast(uint32_t v, uint32_t) { return v; }
+  static uint32_t find_first(bool b) { return b ? 0u : 0xFFFFFFFFu; }
   static uint32_t wait_nonzero(const uint32_t* p) { return *p; }  // (runs are replayed in chain order here)
   static void publish(uint32_t* p, uint32_t v) { *p = v; }
   static void fence() {}
@@ -112,7 +114,8 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
   std::vector<uint16_t> arena(arena_n + 1);
   std::vector<uint16_t> node(cap), stale(cap);
   std::vector<uint32_t> known(cap / 32 + 1), mem(mcap + 1), base(mcap + 2), scratch(4);
-  WorkT<CpuWave> wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap};
+  std::vector<uint32_t> memo(3 * kMemo);
+  WorkT<CpuWave> wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap, memo.data()};
   Stats st{};
   for (uint32_t p = 0; p < n_runs; ++p) {  // flagged runs in (chain, cell) order: the order the GPU hands them out
     const uint32_t r = chain_runs[p];

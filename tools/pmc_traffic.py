@@ -28,7 +28,14 @@ def main():
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     fc = per_kernel(sys.argv[4], "FETCH_SIZE") if len(sys.argv) > 4 else f
     calib = image_bytes / (fc["k_count_nl"] * 1024.0)
-    out = {"image_bytes": image_bytes, "fetch_correction_measured_on_k_count_nl": calib,
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    for name in ("fqg_kernels.hip", "fqg_stream_kernels.hip"):  # (what bench.py checks before quoting this file)
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fastq_utils_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    out = {"image_bytes": image_bytes, "kernel_sources_digest": h.hexdigest()[:16],
+           "fetch_correction_measured_on_k_count_nl": calib,
            "fetch_correction_applied": 2.0, "unit": "bytes per launch", "kernels": {}}
     for k in sorted(set(f) | set(w)):
         if not k.startswith("k_"):

@@ -1,0 +1,56 @@
+#!/bin/bash
+# The rocprofv3 evidence of a round, collected on the GPU box: tools/profile_round.sh <tag> [bench|traffic|umi ...]
+#   bench    the judged bench line as the driver runs it + `--kernel-trace --stats` of the same workload
+#   traffic  FETCH_SIZE / WRITE_SIZE in separate passes on the headline workload (+ a --two-pass run: k_count_nl, the
+#            kernel with a known byte count the read correction is checked on) -> <tag>_traffic_100M_150bp.json
+#   umi      FETCH_SIZE / WRITE_SIZE / SQ counters of the bam_umi_count kernels on configs[3]
+# Counter passes never carry another trace domain than --kernel-trace.  Summaries land in gpurun_out/<tag>/; copy what
+# is to be judged into profiles/.
+set -u
+TAG=$1; shift
+WHAT=${*:-bench traffic umi}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+ONLY_HEADLINE="--no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra"
+ONLY_UMI="--reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra"
+for w in $WHAT; do
+  case $w in
+  bench)
+    python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-e2e > $O/under_rocprof.json 2> $O/under_rocprof.err
+    find $O/stats -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
+    find $O/stats -name '*kernel_trace.csv' -delete
+    ;;
+  traffic)
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 2 $ONLY_HEADLINE > $O/pmc_$c.json 2> $O/pmc_$c.err
+    done
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib -o pmc -- python3 $R/bench.py --steps 2 --two-pass $ONLY_HEADLINE > $O/pmc_calib.json 2> $O/pmc_calib.err
+    python3 $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv') $(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv') \
+        34900000000 $(find $O/pmc_calib -name '*counter_collection.csv') > $O/traffic_100M_150bp.json
+    find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_calib -name '*kernel_trace.csv' -delete
+    ;;
+  umistats)
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/umi_stats -o stats -- python3 $R/bench.py $ONLY_UMI > $O/umi_under_rocprof.json 2> $O/umi_under_rocprof.err
+    find $O/umi_stats -name '*kernel_stats.csv' -exec cp {} $O/umi_kernel_stats.csv \;
+    find $O/umi_stats -name '*kernel_trace.csv' -delete
+    ;;
+  umi)
+    i=0
+    for set in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+               "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+      i=$((i+1))
+      rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/umi_pmc/p$i -o pmc -- python3 $R/bench.py $ONLY_UMI > $O/umi_pmc_$i.json 2> $O/umi_pmc_$i.err
+      find $O/umi_pmc/p$i -name '*kernel_trace.csv' -delete
+    done
+    python3 $R/tools/pmc_sum.py $O/umi_pmc k_umi > $O/umi_counters.json
+    python3 $R/tools/pmc_sum.py $O/umi_pmc k_rl >> $O/umi_counters.json
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/umi_stats -o stats -- python3 $R/bench.py $ONLY_UMI > $O/umi_under_rocprof.json 2> $O/umi_under_rocprof.err
+    find $O/umi_stats -name '*kernel_stats.csv' -exec cp {} $O/umi_kernel_stats.csv \;
+    find $O/umi_stats -name '*kernel_trace.csv' -delete
+    ;;
+  esac
+done
+du -sh $O; ls $O
