@@ -17,6 +17,7 @@ sweep of every fixture through the single-file modes, and every _1/_2 pair throu
 modes.  Nothing here is needed at test time on the GPU box; only the outputs are.
 """
 import glob
+import gzip
 import json
 import os
 import shutil
@@ -570,6 +571,121 @@ def gen_filterpair():
     print("filterpair invocations:", len(out), "by exit status:", by)
 
 
+# ---- bam_add_tags (run_tests.sh:485-499) ---------------------------------------------------------------------------
+BT_BIN = os.path.join(REPO, "oracle", "_ref", "bam_add_tags")
+BT_DATA = os.path.join(GOLD, "data_tags")
+
+
+def bam_tags_synthetic():
+    """Seeded BAMs (tests/bamgen.py) whose read names stop get_barcodes (src/bam_add_tags.c:43-99) at every one of its
+    exits: no STAGS_, a wrong CELL= / UMI= / SAMPLE= keyword, empty and non-empty values, names of other shapes mixed
+    in, unmapped reads (tid -1: no tx tag), records that already carry aux tags, reads on several references."""
+    import numpy as np
+
+    sys.path.insert(0, REPO)
+    from tests import bamgen
+
+    rng = np.random.default_rng(4242)
+    refs = tuple((b"ENST%011d" % (1000 + i), 5000 + i) for i in range(40))
+
+    def bc(n):
+        return bamgen.barcode(rng, n) if n else b""
+
+    recs = []
+    shapes = [
+        lambda c, u, s, t: b"STAGS_CELL=%s_UMI=%s_SAMPLE=%s_ETAGS_%s" % (c, u, s, t),
+        lambda c, u, s, t: b"STAGS_CELL=%s_UMI=%s_SAMPLE=%s_" % (c, u, s),          # nothing behind the last '_'
+        lambda c, u, s, t: t,                                                        # a plain read name
+        lambda c, u, s, t: b"STAGS_" + t + b"_x",                                    # STAGS_ but no CELL=
+        lambda c, u, s, t: b"STAGS_CELL=%s_UMX=%s_SAMPLE=%s_ETAGS_%s" % (c, u, s, t),
+        lambda c, u, s, t: b"STAGS_CELL=%s_UMI=%s_SAMPLX=%s_ETAGS_%s" % (c, u, s, t),
+        lambda c, u, s, t: b"XSTAGS_CELL=%s_UMI=%s_SAMPLE=%s_ETAGS_%s" % (c, u, s, t),
+        lambda c, u, s, t: b"STAGS_CELL=%s_UMI=%s_SAMPLE=%s_ETAGS_STAGS_CELL=AA_UMI=CC_SAMPLE=GG_ETAGS_%s" % (c, u, s, t),
+    ]
+    for i in range(3000):
+        c, u, s = bc(int(rng.choice([0, 0, 8, 16, 30]))), bc(int(rng.choice([0, 6, 10, 12, 49]))), bc(int(rng.choice([0, 0, 0, 8])))
+        tail = b"R%d:%d:%d" % (i, int(rng.integers(0, 99999)), int(rng.integers(0, 9)))
+        shape = shapes[0] if rng.random() < 0.7 else shapes[int(rng.integers(0, len(shapes)))]
+        name = shape(c, u, s, tail)[:250]
+        aux = b""
+        if rng.random() < 0.4:
+            aux += bamgen.aux_int(b"NH", int(rng.integers(1, 4)))
+        if rng.random() < 0.3:
+            aux += bamgen.aux_z(b"XS", b"old_tag")
+        tid = -1 if rng.random() < 0.1 else int(rng.integers(0, len(refs)))
+        recs.append(bamgen.record(name, aux, tid=tid, flag=4 if tid < 0 else 0, seq_len=int(rng.integers(1, 120))))
+    stream = bamgen.header(refs) + b"".join(recs)
+    # gene <tab> transcript; a transcript listed twice (the first line wins), transcripts that are not references,
+    # references without a line
+    lines = []
+    for i, (name, _) in enumerate(refs):
+        if i % 5 != 4:
+            lines.append(b"GENE%05d\t%s\n" % (i // 3, name))
+    lines.insert(7, b"GENEDUP\t%s\n" % refs[2][0])
+    lines.append(b"GENEX\tENSTnot_a_reference\n")
+    return {"syn_tags.bam": bamgen.bgzf(stream, level=4), "syn_tags_map.tsv": b"".join(lines),
+            "syn_tags_badmap.tsv": b"GENE1\tENST1\nonly_one_field\n"}
+
+
+def bam_tags_jobs():
+    d = lambda n: "data_tags/" + n
+    jobs = []
+    for bam, mp in (("trans_small.bam", "mapTrans2Gene.tsv"), ("syn_tags.bam", "syn_tags_map.tsv")):
+        for extra in ([], ["--10x"], ["--tx"], ["--tx", "--tx_2_gx", d(mp)], ["--10x", "--tx", "--tx_2_gx", d(mp)]):
+            jobs.append(["--inbam", d(bam), "--outbam", "OUT"] + extra)
+        jobs.append(["--inbam", d(bam), "--outbam", "-", "--tx"])
+    jobs.append(["--inbam", d("syn_tags.bam"), "--outbam", "OUT", "--tx", "--tx_2_gx", d("syn_tags_badmap.tsv")])
+    # run_tests.sh:493-499
+    jobs.append(["--inbam", d("trans_small.bam"), "--outbam", "OUT", "--tx", "--tx_2_gx", "aaaa" + d("mapTrans2Gene.tsv")])
+    jobs.append([])
+    jobs.append(["--inbam", d("trans_small.bam"), "--outbam", "OUT", "--tx_2_gx", d("mapTrans2Gene.tsv")])
+    jobs.append(["--inbam", d("trans_small.bam_missing"), "--outbam", "OUT", "--tx", "--tx_2_gx", d("mapTrans2Gene.tsv")])
+    jobs.append(["--inbam", d("trans_small.bam"), "--outbam", "folder/does/not/exist/tmp.bam", "--tx"])
+    jobs.append(["--help"])
+    jobs.append(["--inbam", d("trans_small.bam")])
+    return jobs
+
+
+def gen_bam_tags():
+    import hashlib
+    import tempfile
+
+    if not os.path.exists(BT_BIN):
+        sys.exit("build the reference first: make -C oracle ref")
+    os.makedirs(BT_DATA, exist_ok=True)
+    for n in ("trans_small.bam", "mapTrans2Gene.tsv"):   # the reference's own fixtures for this program
+        shutil.copyfile(os.path.join(REF, "tests", n), os.path.join(BT_DATA, n))
+        os.chmod(os.path.join(BT_DATA, n), 0o644)
+    for n, b in bam_tags_synthetic().items():
+        with open(os.path.join(BT_DATA, n), "wb") as f:
+            f.write(b)
+    out = []
+    for args in bam_tags_jobs():
+        with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+            rel = os.path.relpath(tmp, GOLD)
+            real = [rel + "/o.bam" if a == "OUT" else a for a in args]
+            p = subprocess.run(["bam_add_tags"] + real, executable=BT_BIN, cwd=GOLD, capture_output=True, timeout=300)
+            entry = {"args": args, "exit": p.returncode, "stderr": p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/")}
+            # the BAM written (file or stdout): its INFLATED bytes are what a reader sees
+            path = os.path.join(tmp, "o.bam")
+            blob = open(path, "rb").read() if os.path.exists(path) else (p.stdout if "-" in args else None)
+            if blob is not None and p.returncode == 0:
+                data = gzip.decompress(blob)
+                entry["out_sha256"] = hashlib.sha256(data).hexdigest()
+                entry["out_bytes"] = len(data)
+            entry["out_created"] = os.path.exists(path)
+            entry["stdout_is_bam"] = "-" in args
+            if "-" not in args:
+                entry["stdout"] = p.stdout.decode("latin-1")
+            out.append(entry)
+    with open(os.path.join(GOLD, "bam_tags.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    by = {}
+    for o in out:
+        by[o["exit"]] = by.get(o["exit"], 0) + 1
+    print("bam_add_tags invocations:", len(out), "by exit status:", by)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "fastq_info"):
@@ -582,3 +698,5 @@ if __name__ == "__main__":
         gen_filterpair()
     if which in ("all", "filters"):
         gen_filters()
+    if which in ("all", "bam_tags"):
+        gen_bam_tags()
