@@ -34,7 +34,8 @@ EXPORTS = [
     "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_records_gather",
     "fqg_records_gather_output", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
-    "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_umi_count", "fqg_umi_features",
+    "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
+    "fqg_umi_count", "fqg_umi_features",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
     "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
     "fqg_fpset_candidates", "fqg_fpset_pair_runs", "fqg_frame_name",
@@ -92,6 +93,17 @@ class UmiParams(C.Structure):
                 ("min_umis", C.c_uint32), ("known_umis", C.POINTER(C.c_uint64)),
                 ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64),
                 ("defer_output", C.c_int32), ("strict_set", C.c_int32)]
+
+
+class BamTagsParams(C.Structure):
+    _fields_ = [("tenx", C.c_int32), ("tx_tag", C.c_int32), ("n_targets", C.c_uint32), ("reserved", C.c_uint32),
+                ("tx_off", C.POINTER(C.c_uint32)), ("tx_len", C.POINTER(C.c_uint32)), ("gx_off", C.POINTER(C.c_uint32)),
+                ("gx_len", C.POINTER(C.c_uint32)), ("names", C.c_char_p), ("names_bytes", C.c_uint64)]
+
+
+class BamTagsResult(C.Structure):
+    _fields_ = [("n_alignments", C.c_uint64), ("n_tagged", C.c_uint64), ("out_bytes", C.c_uint64), ("record", C.c_uint64),
+                ("code", C.c_int32), ("reserved", C.c_int32)]
 
 
 class UmiResult(C.Structure):
@@ -231,6 +243,8 @@ def load():
     L.fqg_unpack_barcode.restype = None
     L.fqg_bam_index_records.argtypes = [vp, u64, C.POINTER(u64), u64, C.POINTER(u64), C.POINTER(u64)]
     L.fqg_umi_count.argtypes = [vp, vp, u64, C.c_int, C.POINTER(u64), u64, C.POINTER(UmiParams), C.POINTER(UmiResult)]
+    L.fqg_bam_add_tags.argtypes = [vp, vp, u64, C.c_int, C.POINTER(u64), u64, C.POINTER(BamTagsParams), C.POINTER(BamTagsResult)]
+    L.fqg_bam_add_tags_output.argtypes = [vp, vp, u64]
     L.fqg_umi_emit.argtypes = [vp, C.POINTER(C.c_uint32), u64, C.c_uint32, C.POINTER(UmiResult)]
     L.fqg_umi_features.argtypes = [vp, vp, u64]
     L.fqg_umi_cells.argtypes = [vp, C.POINTER(u64), u64]
@@ -600,6 +614,51 @@ class Context:
             out["cells"] = [int(cells[i]) for i in range(r.n_cells)]
             if not defer_output:
                 out["entries"] = self._umi_entries(r)
+        return out
+
+    def bam_add_tags(self, stream, tenx=False, tx_tag=False, targets=(), genes=None, offsets=None, nbytes=None,
+                     want_output=True):
+        """bam_add_tags' alignment loop (src/bam_add_tags.c:250-294) on an inflated BAM stream: bytes (host) or an
+        int device pointer (then `nbytes` and `offsets` are required).  targets: the header's reference names;
+        genes: {transcript name: gene} (--tx_2_gx) or None.  Returns the result fields and, with want_output, the
+        records with their new tags (everything behind the header) as bytes."""
+        L = load()
+        host = isinstance(stream, (bytes, bytearray))
+        if host:
+            buf = (C.c_char * max(1, len(stream))).from_buffer_copy(stream)
+            nbytes = len(stream)
+        if offsets is None:
+            n, used = C.c_uint64(), C.c_uint64()
+            self._check(L.fqg_bam_index_records(buf, nbytes, None, 0, C.byref(n), C.byref(used)))
+            offs = (C.c_uint64 * max(1, n.value))()
+            self._check(L.fqg_bam_index_records(buf, nbytes, offs, n.value, C.byref(n), C.byref(used)))
+            n_rec = n.value
+        else:
+            n_rec = len(offsets)
+            offs = offsets.c if hasattr(offsets, "c") else (offsets if isinstance(offsets, C.Array) else (C.c_uint64 * max(1, n_rec))(*offsets))
+        nt = len(targets)
+        blob, tx_off, tx_len, gx_off, gx_len = bytearray(), [], [], [], []
+        for t in targets:
+            tx_off.append(len(blob)); tx_len.append(len(t)); blob += t + b"\0"
+            g = genes.get(t) if genes is not None else None
+            if g is None:
+                gx_off.append(0); gx_len.append(0xFFFFFFFF)
+            else:
+                gx_off.append(len(blob)); gx_len.append(len(g)); blob += g + b"\0"
+        arr = lambda v: (C.c_uint32 * max(1, nt))(*v)
+        p = BamTagsParams()
+        p.tenx, p.tx_tag, p.n_targets = int(tenx), int(tx_tag), nt
+        keep = [arr(tx_off), arr(tx_len), arr(gx_off), arr(gx_len), bytes(blob) + b"\0"]
+        p.tx_off, p.tx_len, p.gx_off, p.gx_len = keep[0], keep[1], keep[2], keep[3]
+        p.names, p.names_bytes = keep[4], len(blob)
+        r = BamTagsResult()
+        self._check(L.fqg_bam_add_tags(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
+                                       MEM_HOST if host else MEM_DEVICE, offs, n_rec, C.byref(p), C.byref(r)))
+        out = {k: getattr(r, k) for k, _ in BamTagsResult._fields_ if k != "reserved"}
+        if r.code == 0 and want_output:
+            dst = C.create_string_buffer(max(1, r.out_bytes))
+            self._check(L.fqg_bam_add_tags_output(self.h, dst, r.out_bytes))
+            out["records"] = dst.raw[:r.out_bytes]
         return out
 
     @staticmethod

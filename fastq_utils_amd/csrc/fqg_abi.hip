@@ -22,6 +22,7 @@
 #include "fqg_umi_kernels.hip"
 #include "fqg_umi_rl_kernels.hip"
 #include "fqg_umi_cell_kernels.hip"
+#include "fqg_bamtags_kernels.hip"
 
 using namespace fqg;
 
@@ -86,6 +87,8 @@ struct fqg_ctx {
   BcCall* d_bcall = nullptr;
   BcCall* h_bcall = nullptr;  // pinned
   uint64_t bc_out_bytes[3] = {0, 0, 0};
+  DevBuf bt_in, bt_off, bt_tables, bt_rec, bt_size, bt_local, bt_sums, bt_call, bt_out;  // fqg_bam_add_tags
+  uint64_t bt_out_bytes = 0;
   IndexCall* d_icall = nullptr;
   IndexCall* h_icall = nullptr;  // pinned
 
@@ -271,6 +274,9 @@ void fqg_close(fqg_ctx* c) {
   release(c->umi_entries[1]);
   release(c->bc_status);
   release(c->bc_tile_big);
+  for (DevBuf* b : {&c->bt_in, &c->bt_off, &c->bt_tables, &c->bt_rec, &c->bt_size, &c->bt_local, &c->bt_sums, &c->bt_call,
+                    &c->bt_out})
+    release(*b);
   for (int i = 0; i < 3; ++i) {
     release(c->bc_len[i]);
     release(c->bc_off[i]);
@@ -1700,5 +1706,6 @@ int fqg_synth_fastq(fqg_ctx* c, void* device_out, uint64_t n_records, uint32_t r
 
 #include "fqg_umi_abi.inc"
 #include "fqg_fp_abi.inc"
+#include "fqg_bamtags_abi.inc"
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace fqhost {
@@ -143,6 +144,7 @@ inline bool bgzf_inflate_parallel(const std::vector<uint8_t>& raw, std::vector<u
   parallel_items(n_runs, [&](size_t r) {
     for (size_t i = r * run; i < std::min(blocks.size(), (r + 1) * run); ++i) {
       const Block& b = blocks[i];
+      if (b.isize == 0) continue;  // (the end-of-file block; zlib refuses a null output pointer when nothing else was inflated)
       z_stream zs;
       memset(&zs, 0, sizeof(zs));
       if (inflateInit2(&zs, -15) != Z_OK) {
@@ -160,6 +162,80 @@ inline bool bgzf_inflate_parallel(const std::vector<uint8_t>& raw, std::vector<u
     }
   });
   return ok;
+}
+
+// BGZF output (SAM/BAM specification 4.1, what libbam's bgzf_write / bgzf_close produce): blocks of at most 0xff00
+// input bytes, each a gzip member with the BC extra field, every block deflated on its own thread; the empty block
+// that marks the end of the file last.  What a reader inflates is `data`; the block boundaries are not part of it.
+inline bool bgzf_deflate_parallel(const std::vector<std::pair<const uint8_t*, size_t>>& pieces, int level, std::vector<uint8_t>& out) {
+  constexpr size_t kBlock = 0xff00;
+  size_t n = 0;
+  for (auto& pc : pieces) n += pc.second;
+  const size_t nb = (n + kBlock - 1) / kBlock;
+  std::vector<std::vector<uint8_t>> blocks(nb);
+  std::atomic<bool> ok{true};
+  // byte k of the concatenation of the pieces
+  auto gather = [&](size_t from, size_t len, uint8_t* dst) {
+    size_t skip = from;
+    for (auto& pc : pieces) {
+      if (skip >= pc.second) {
+        skip -= pc.second;
+        continue;
+      }
+      const size_t take = std::min(len, pc.second - skip);
+      memcpy(dst, pc.first + skip, take);
+      dst += take;
+      len -= take;
+      skip = 0;
+      if (!len) break;
+    }
+  };
+  const size_t run = 16, n_runs = (nb + run - 1) / run;
+  parallel_items(n_runs, [&](size_t r) {
+    std::vector<uint8_t> in(kBlock);
+    for (size_t b = r * run; b < std::min(nb, (r + 1) * run); ++b) {
+      const size_t len = std::min(kBlock, n - b * kBlock);
+      gather(b * kBlock, len, in.data());
+      std::vector<uint8_t>& o = blocks[b];
+      o.resize(18 + compressBound((uLong)len) + 8);
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+        ok = false;
+        return;
+      }
+      zs.next_in = in.data();
+      zs.avail_in = (uInt)len;
+      zs.next_out = o.data() + 18;
+      zs.avail_out = (uInt)(o.size() - 26);
+      const int rc = deflate(&zs, Z_FINISH);
+      const size_t clen = zs.total_out;
+      deflateEnd(&zs);
+      const size_t bsize = 18 + clen + 8;
+      if (rc != Z_STREAM_END || bsize > 65536) {
+        ok = false;
+        return;
+      }
+      static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+      memcpy(o.data(), head, 16);
+      o[16] = (uint8_t)((bsize - 1) & 0xff);
+      o[17] = (uint8_t)((bsize - 1) >> 8);
+      const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in.data(), (uInt)len);
+      uint8_t* t = o.data() + 18 + clen;
+      for (int k = 0; k < 4; ++k) t[k] = (uint8_t)(crc >> (8 * k));
+      for (int k = 0; k < 4; ++k) t[4 + k] = (uint8_t)((uint32_t)len >> (8 * k));
+      o.resize(bsize);
+    }
+  });
+  if (!ok) return false;
+  size_t total = 28;
+  for (auto& b : blocks) total += b.size();
+  out.clear();
+  out.reserve(total);
+  for (auto& b : blocks) out.insert(out.end(), b.begin(), b.end());
+  static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  out.insert(out.end(), eof, eof + 28);
+  return true;
 }
 
 }  // namespace fqhost

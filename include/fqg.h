@@ -420,6 +420,40 @@ uint64_t fqg_synth_record_bytes(uint32_t read_len);
 int fqg_synth_fastq(fqg_ctx *ctx, void *device_out, uint64_t n_records, uint32_t read_len,
                     uint64_t first_index, uint64_t seed, int mate);
 
+/* ---- bam_add_tags -----------------------------------------------------------------------------------
+ * Replaces the alignment loop of bam_add_tags (src/bam_add_tags.c:250-294: get_barcodes :43-99 on the read name,
+ * bam_aux_append of RX|UB / CR / BC, and with --tx of tx and GX) - the step between fastq_pre_barcodes and
+ * bam_umi_count (sh/fastq2bam:116-273).  Input as for fqg_umi_count: the inflated BAM stream and the offset of every
+ * alignment (fqg_bam_index_records).  Output: the alignment records with their new tags, back to back, in input
+ * order; it stays on the device until fqg_bam_add_tags_output copies it.  The header (everything before the first
+ * alignment) is not touched: the caller writes it as it read it (bam_header_write after bam_header_read).
+ * The transcript -> gene map (--tx_2_gx, :203-232, get_gene :118-129) is resolved by the caller once per reference
+ * of the header: gx_len[t] = FQG_NO_GENE when reference t has no gene. */
+#define FQG_NO_GENE 0xFFFFFFFFu
+typedef struct {
+  int32_t tenx;           /* --10x: the UMI goes to UB instead of RX (src/sam_tags.h:40-47) */
+  int32_t tx_tag;         /* --tx */
+  uint32_t n_targets;     /* references of the header */
+  uint32_t reserved;
+  const uint32_t *tx_off; /* [n_targets] header->target_name[t] = names + tx_off[t], tx_len[t] bytes */
+  const uint32_t *tx_len;
+  const uint32_t *gx_off; /* [n_targets] its gene, or gx_len[t] = FQG_NO_GENE */
+  const uint32_t *gx_len;
+  const char *names;
+  uint64_t names_bytes;
+} fqg_bam_tags_params;
+typedef struct {
+  uint64_t n_alignments;
+  uint64_t n_tagged;  /* alignments whose name get_barcodes accepted */
+  uint64_t out_bytes; /* size of the output record stream */
+  uint64_t record;    /* first alignment with a finding */
+  int32_t code;       /* FQG_OK, FQG_E_TAGS_NAME, FQG_E_TAGS_TID */
+  int32_t reserved;
+} fqg_bam_tags_result;
+int fqg_bam_add_tags(fqg_ctx *ctx, const void *stream, uint64_t nbytes, int mem, const uint64_t *offsets,
+                     uint64_t n_records, const fqg_bam_tags_params *params, fqg_bam_tags_result *out);
+int fqg_bam_add_tags_output(fqg_ctx *ctx, void *host_dst, uint64_t nbytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,13 @@ enum fqg_code {
   /* process_entry :451-453, :455-457, :459-461  "Too many umi barcodes / cells / features"; aux = the id */
   FQG_E_UMI_TOO_MANY_UMIS = 19,
   FQG_E_UMI_TOO_MANY_CELLS = 20,
-  FQG_E_UMI_TOO_MANY_FEATURES = 21
+  FQG_E_UMI_TOO_MANY_FEATURES = 21,
+  /* Not reference outcomes.  bam_add_tags, src/bam_add_tags.c:43-99: get_barcodes scans for '_' without a bound and
+   * copies into 50-byte arrays; a read name whose value runs to the end of the alignment record, or is 50
+   * characters or longer, makes the reference read / write memory it does not own.  Refused. */
+  FQG_E_TAGS_NAME = 22,
+  /* :275-277  header->target_name[tid] with tid beyond the header's references (--tx).  Refused. */
+  FQG_E_TAGS_TID = 23
 };
 
 /* read-name formats, src/fastq.h:25-28 (INTEGERNAME and NOP share the value 2) */

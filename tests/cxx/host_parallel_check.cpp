@@ -1,6 +1,7 @@
 // Test driver for fastq_utils_amd/host/fq_parallel.h (no GPU):
 //   host_parallel_check gz <in> <out.gz> <level>     file -> multi-member gzip
 //   host_parallel_check bgzf <in.bam> <out>          BGZF file -> inflated stream
+//   host_parallel_check tobgzf <in> <out.bgzf> <split>   file, handed over as two pieces cut at <split>, -> BGZF file
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -30,6 +31,15 @@ int main(int argc, char** argv) {
     return g.close() ? 0 : 6;
   }
   std::vector<uint8_t> out;
+  if (!strcmp(argv[1], "tobgzf")) {
+    const size_t split = std::min<size_t>(in.size(), (size_t)atoll(argv[4]));
+    if (!fqhost::bgzf_deflate_parallel({{in.data(), split}, {in.data() + split, in.size() - split}}, Z_DEFAULT_COMPRESSION, out)) return 9;
+    FILE* f = fopen(argv[3], "wb");
+    if (!f) return 8;
+    fwrite(out.data(), 1, out.size(), f);
+    fclose(f);
+    return 0;
+  }
   if (!fqhost::bgzf_inflate_parallel(in, out)) return 7;
   FILE* f = fopen(argv[3], "wb");
   if (!f) return 8;

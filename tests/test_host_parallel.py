@@ -58,3 +58,25 @@ def test_bgzf_rejects_a_plain_gzip_file(driver, tmp_path):
     src = tmp_path / "x.gz"
     src.write_bytes(gzip.compress(b"not bgzf"))
     assert subprocess.run([driver, "bgzf", str(src), str(tmp_path / "o")]).returncode == 7
+
+
+@pytest.mark.parametrize("threads", ["1", "6"])
+@pytest.mark.parametrize("size,split", [(0, 0), (1, 0), (65280, 65280), (65281, 10), (3_000_000, 1_234_567)])
+def test_bgzf_writer_makes_a_file_every_bgzf_reader_takes(driver, tmp_path, threads, size, split):
+    """bgzf_deflate_parallel (the output side of bin/bam_add_tags): blocks of at most 64 KiB with the BC field, the
+    empty end-of-file block last; inflating gives the two pieces back to back - with python's gzip, with the oracle's
+    block walker, and with this repo's own parallel reader."""
+    from oracle.umi_oracle import bgzf_inflate
+    rng = np.random.default_rng(size + 3)
+    data = bytes(rng.integers(0, 256, size, dtype=np.uint8)) if size < 100000 else \
+        bytes(rng.choice(np.frombuffer(b"ACGT\0\x01\x02STAGS_", dtype=np.uint8), size).astype(np.uint8))
+    src, dst, back = tmp_path / "in.bin", tmp_path / "out.bgzf", tmp_path / "back.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, FQGPU_HOST_THREADS=threads)
+    subprocess.run([driver, "tobgzf", str(src), str(dst), str(split)], check=True, env=env)
+    raw = dst.read_bytes()
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    assert gzip.decompress(raw) == data
+    assert bgzf_inflate(raw) == data
+    subprocess.run([driver, "bgzf", str(dst), str(back)], check=True, env=env)
+    assert back.read_bytes() == data
