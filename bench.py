@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-umi-extra", action="store_true",
                     help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
     ap.add_argument("--umi-triples", type=int, default=5_000_000)
+    ap.add_argument("--no-tags-extra", action="store_true", help="skip the bam_add_tags extra")
+    ap.add_argument("--tags-alignments", type=int, default=6_500_000)
     ap.add_argument("--no-shapes-extra", action="store_true",
                     help="skip the validate pass on mixed-length short reads and on ONT-like long reads")
     ap.add_argument("--no-e2e", action="store_true",
@@ -464,6 +466,76 @@ def negative_controls(exe, path, arr, n, R):
     return res
 
 
+def bam_tags_extra(ctx, torch, dev, n):
+    """bam_add_tags' alignment loop (fqg_bam_add_tags) on `n` synthetic alignments whose names carry a
+    16-base cell and a 10-base UMI the way fastq_pre_barcodes writes them, --tx over 300 references, records resident
+    in HBM.  Checked against the oracle on the first 2 000 alignments and by size at full length."""
+    import numpy as np
+
+    from tests import bamgen  # generator only
+
+    rng = np.random.default_rng(77)
+    refs = tuple((b"ENST%011d" % i, 1000) for i in range(300))
+    tid = rng.integers(-1, len(refs), n).astype(np.int32)
+    rec = bamgen.tagged_name_records(rng.integers(0, 1 << 32, n).astype(np.uint64), rng.integers(0, 1 << 20, n).astype(np.uint64), tid)
+    hdr = bamgen.header(refs)
+    R = bamgen.TAGGED_NAME_REC_BYTES
+    stream = torch.empty(len(hdr) + rec.size + 64, dtype=torch.uint8, device=dev)
+    stream[: len(hdr)] = torch.frombuffer(bytearray(hdr), dtype=torch.uint8).to(dev)
+    stream[len(hdr): len(hdr) + rec.size] = torch.from_numpy(rec.reshape(-1)).to(dev)
+    torch.cuda.synchronize()
+    offs = _OffsetArray(np.arange(n, dtype=np.uint64) * np.uint64(R) + np.uint64(len(hdr)))
+    names = [r[0] for r in refs]
+
+    def run(want_output):
+        return ctx.bam_add_tags(stream.data_ptr(), tx_tag=True, targets=names, offsets=offs, nbytes=len(hdr) + rec.size,
+                                want_output=want_output)
+
+    run(False)  # warm-up
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    r = run(False)
+    ctx.synchronize()
+    wall = time.perf_counter() - t1
+    prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_bt")}
+    ctx.profile(False)
+    kernels_ms = sum(prof.values())
+    in_bytes = n * R
+    # every record gains RX:Z:<10> (14 bytes), CR:Z:<16> (20) and, when mapped, tx:Z:<15> (19)
+    want_out = in_bytes + 34 * n + 19 * int((tid >= 0).sum())
+    out = {"what": "bam_add_tags alignment loop (fqg_bam_add_tags), names as fastq_pre_barcodes writes them, --tx",
+           "alignments": n, "record_bytes": R, "out_bytes": r["out_bytes"], "out_bytes_expected": want_out,
+           "size_as_expected": r["out_bytes"] == want_out and r["n_tagged"] == n and r["code"] == 0,
+           "wall_ms_one_call": wall * 1e3, "kernels_ms": kernels_ms, "kernels_ms_breakdown": prof,
+           "Malignments_per_s_kernels_only": n / (kernels_ms * 1e-3) / 1e6 if kernels_ms else None,
+           "algorithmic_GB": (in_bytes + r["out_bytes"]) / 1e9,
+           "achieved_GBps_kernels": (in_bytes + r["out_bytes"]) / (kernels_ms * 1e-3) / 1e9 if kernels_ms else None}
+    # the first 2 000 alignments against the oracle
+    from oracle import bam_tags_oracle as bto
+    m = min(n, 2000)
+    small = hdr + rec[:m].tobytes()
+    got = ctx.bam_add_tags(small, tx_tag=True, targets=names)
+    want, _ = bto.add_tags_stream(small, tx_tag=True)
+    out["first_2000_alignments_identical_to_oracle"] = got["code"] == 0 and got["records"] == want[len(hdr):]
+    # the reference program on a bounded sample (its BGZF inflate and deflate, single-threaded, are part of it)
+    ref = os.path.join(REPO, "oracle", "_ref", "bam_add_tags")
+    if os.path.exists(ref):
+        ms = min(n, 500_000)
+        with tempfile.TemporaryDirectory() as tmp:
+            with open(os.path.join(tmp, "in.bam"), "wb") as f:
+                f.write(bamgen.bgzf(hdr + rec[:ms].tobytes(), level=1))
+            t2 = time.perf_counter()
+            p = subprocess.run(["bam_add_tags", "--inbam", "in.bam", "--outbam", "out.bam", "--tx"], executable=ref, cwd=tmp,
+                               capture_output=True)
+            secs = time.perf_counter() - t2
+        out["cpu_baseline"] = {"value": ms / secs / 1e6, "unit": "Malignments/s", "cores": 1, "kind": "reference",
+                               "sample": f"first {ms} alignments as a BGZF file; reference bam_add_tags --tx (single-threaded, BGZF "
+                                         "inflate and deflate included)", "seconds": secs, "ok": p.returncode == 0}
+    return out
+
+
 def umi_extra(ctx, torch, dev, n_triples):
     """bam_umi_count's alignment loop (fqg_umi_count) on BASELINE.json configs[3]: CR-sorted synthetic
     alignments, 10 k cells x 20 k genes, `n_triples` distinct (cell, gene, UMI) + 30 % duplicate reads,
@@ -849,6 +921,11 @@ def main():
                 out["umi_count_extra"] = umi_extra(ctx, torch, dev, a.umi_triples)
             except Exception as e:
                 out["umi_count_extra"] = {"error": repr(e)[:300]}
+        if world == 1 and not a.no_tags_extra:
+            try:
+                out["bam_add_tags_extra"] = bam_tags_extra(ctx, torch, dev, a.tags_alignments)
+            except Exception as e:
+                out["bam_add_tags_extra"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         # every rank has what it needs; a rank that failed in the extra must not keep the others waiting in a

@@ -4,12 +4,14 @@
 // RX or UB (--10x), CR, BC, and with --tx the reference's name (tx) and its gene (GX, --tx_2_gx).
 //
 // Input: the inflated BAM stream and the offset of every alignment (fqg_bam_index_records), as for bam_umi_count.
-//   k_bt_plan   one thread per alignment: get_barcodes on the name, the bytes the record grows by
+//   k_bt_tile<false>  one wavefront per tile of T consecutive alignments, whose bytes are ONE span of the stream: the
+//               span is copied to LDS with 16-byte loads, every lane runs get_barcodes on the name of ITS alignment
+//               there and writes the size the record grows to
 //   scan        64-bit exclusive prefix of the new record sizes (k_scan64_a / _b)
-//   k_bt_emit   one wavefront per tile of T consecutive alignments: their bytes are one span of the input and one
-//               span of the output.  The input span is copied to LDS with 16-byte loads, every lane rebuilds ITS
-//               record in an LDS image of the output span (block_size patched, tags appended), and the image goes
-//               out with 16-byte stores.  Tiles that do not fit (long reads) are copied record by record.
+//   k_bt_tile<true>   the same tiles again: the lane parses the name once more (cheaper than keeping what pass 1
+//               found), rebuilds its record in an LDS image of the tile's OUTPUT span (block_size patched, tags
+//               appended), and the image goes out with 16-byte stores.
+//   Tiles that do not fit LDS (long reads) read the stream itself and are copied record by record.
 // Everything else of the program is host work: BGZF, the header (copied verbatim), the transcript -> gene map.
 #include "fqg_device.h"
 
@@ -35,27 +37,35 @@ struct BtRec {
 };
 struct BtCall {
   unsigned long long first_finding;  // min (record << 8 | code)
-  unsigned long long n_tagged;
+  unsigned long long n_tagged[64];   // 64 copies picked by tile (every wavefront adds: one address would serialise them)
 };
 
 // get_barcodes (src/bam_add_tags.c:43-99) on the C string at buf[s..]; the scans for '_' are scans of memory (they do
 // not stop at the NUL), `end` = end of the record.  1 tags found, 0 not a tagged name, -1 the reference would read
-// behind the record or write behind its 50-byte arrays.
-__device__ __forceinline__ int bt_get_barcodes(const uint8_t* __restrict__ buf, uint64_t s, uint64_t end, uint64_t rec0,
-                                               BtRec& r) {
-  auto expect = [&](uint64_t i, const char* lit, int n) {  // 1 all equal, 0 a difference, -1 out of the record first
-    for (int k = 0; k < n; ++k) {
-      if (i + k >= end) return -1;
-      if (buf[i + k] != (uint8_t)lit[k]) return 0;
-    }
-    return 1;
+// behind the record or write behind its 50-byte arrays.  The name is read 8 bytes at a time: word(i) = bytes i .. i+7
+// of the stream (what lies behind `end` is read, never looked at).
+template <class Word>
+__device__ __forceinline__ int bt_get_barcodes(Word word, uint64_t s, uint64_t end, uint64_t rec0, BtRec& r) {
+  // the || chains of the reference stop at the first difference: a difference inside the record is "no" even when the
+  // literal would run past the record's end
+  auto expect = [&](uint64_t i, uint64_t lit, int n) {
+    const uint64_t room = end > i ? end - i : 0;
+    const int cmp = room < (uint64_t)n ? (int)room : n;
+    const uint64_t mask = cmp >= 8 ? ~0ull : (1ull << (8 * cmp)) - 1ull;
+    if ((word(i) ^ lit) & mask) return 0;
+    return cmp < n ? -1 : 1;
   };
   auto value = [&](uint64_t i, int slot, uint64_t* next) {
     uint64_t z = i;
     for (;;) {
       if (z >= end) return -1;
-      if (buf[z] == '_') break;
-      ++z;
+      uint64_t m = bytes_eq(word(z), (uint8_t)'_');
+      if (end - z < 8) m &= (1ull << (8 * (end - z))) - 1ull;
+      if (m) {
+        z += (uint64_t)(__builtin_ctzll(m) >> 3);
+        break;
+      }
+      z += 8;
     }
     if (z - i >= (uint64_t)kBtMaxBarcode) return -1;
     r.off[slot] = (uint32_t)(i - rec0);
@@ -63,58 +73,21 @@ __device__ __forceinline__ int bt_get_barcodes(const uint8_t* __restrict__ buf, 
     *next = z + 1;
     return 1;
   };
+  constexpr uint64_t kStags = 0x5F5347415453ull;        // "STAGS_"
+  constexpr uint64_t kCell = 0x3D4C4C4543ull;           // "CELL="
+  constexpr uint64_t kUmi = 0x3D494D55ull;              // "UMI="
+  constexpr uint64_t kSample = 0x3D454C504D4153ull;     // "SAMPLE="
   int e;
   uint64_t i = s;
-  if ((e = expect(i, "STAGS_", 6)) != 1) return e;
+  if ((e = expect(i, kStags, 6)) != 1) return e;
   i += 6;
-  if ((e = expect(i, "CELL=", 5)) != 1) return e;
+  if ((e = expect(i, kCell, 5)) != 1) return e;
   if ((e = value(i + 5, 1, &i)) != 1) return e;
-  if ((e = expect(i, "UMI=", 4)) != 1) return e;
+  if ((e = expect(i, kUmi, 4)) != 1) return e;
   if ((e = value(i + 4, 0, &i)) != 1) return e;
-  if ((e = expect(i, "SAMPLE=", 7)) != 1) return e;
+  if ((e = expect(i, kSample, 7)) != 1) return e;
   if ((e = value(i + 7, 2, &i)) != 1) return e;
   return 1;
-}
-
-__global__ __launch_bounds__(kBlock) void k_bt_plan(const uint8_t* __restrict__ buf, const unsigned long long* __restrict__ offs,
-                                                    uint32_t n, BtParams P, BtRec* __restrict__ rec,
-                                                    uint32_t* __restrict__ new_size, BtCall* __restrict__ call) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  bool tagged = false;
-  if (i < n) {
-    const uint64_t o = offs[i];
-    uint32_t block;
-    int32_t tid;
-    __builtin_memcpy(&block, buf + o, 4);
-    __builtin_memcpy(&tid, buf + o + 4, 4);
-    BtRec r;
-    r.off[0] = r.off[1] = r.off[2] = 0;
-    r.len[0] = r.len[1] = r.len[2] = 0;
-    r.ok = 0;
-    uint32_t add = 0;
-    const int g = bt_get_barcodes(buf, o + 36, o + 4 + block, o, r);
-    if (g < 0) atomicMin(&call->first_finding, ((unsigned long long)i << 8) | (unsigned)FQG_E_TAGS_NAME);
-    if (g == 1) {
-      r.ok = 1;
-      tagged = true;
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (r.len[k]) add += 4u + r.len[k];
-      if (P.tx_tag && tid >= 0) {
-        if ((uint32_t)tid >= P.n_targets) atomicMin(&call->first_finding, ((unsigned long long)i << 8) | (unsigned)FQG_E_TAGS_TID);
-        else {
-          add += 4u + P.tx_len[tid];
-          if (P.gx_len[tid] != kBtNone) add += 4u + P.gx_len[tid];
-        }
-      }
-    } else {
-      r.len[0] = r.len[1] = r.len[2] = 0;  // (a name that fails half-way gets no tag at all)
-    }
-    rec[i] = r;
-    new_size[i] = 4u + block + add;
-  }
-  const unsigned long long m = __ballot(tagged);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&call->n_tagged, (unsigned long long)__popcll(m));
 }
 
 typedef __attribute__((address_space(3))) uint8_t* BtLds;
@@ -130,18 +103,48 @@ __device__ __forceinline__ void bt_copy(BtLds dst, BtLds src, uint32_t n) {
   for (; i < n; ++i) dst[i] = src[i];
 }
 
-struct BtEmit {
+struct BtTiles {
   const uint8_t* buf;
   uint64_t nbytes;
   const unsigned long long* offs;
-  uint32_t n, T;
-  const BtRec* rec;
-  const uint32_t* new_size;
+  uint32_t n, T;                  // alignments; per tile
+  uint32_t in_cap, out_cap;       // LDS bytes of the two areas (dynamic shared memory: in_cap + out_cap + 64)
+  uint32_t* new_size;             // pass 1 writes, pass 2 reads
   const unsigned long long* out_local;  // exclusive prefix of new_size: local part + span sums
   const unsigned long long* out_sums;
   uint8_t* out;
   BtParams P;
+  BtCall* call;
 };
+
+// what the record at stream offset o grows by (and its parsed name): shared by both passes
+template <class Word>
+__device__ __forceinline__ uint32_t bt_growth(const BtParams& P, Word word, uint64_t o, uint32_t block, int32_t tid, BtRec& r,
+                                              uint32_t* finding) {
+  r.off[0] = r.off[1] = r.off[2] = 0;
+  r.len[0] = r.len[1] = r.len[2] = 0;
+  r.ok = 0;
+  *finding = 0;
+  uint32_t add = 0;
+  const int g = bt_get_barcodes(word, o + 36, o + 4 + block, o, r);
+  if (g < 0) *finding = (uint32_t)FQG_E_TAGS_NAME;
+  if (g == 1) {
+    r.ok = 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (r.len[k]) add += 4u + r.len[k];
+    if (P.tx_tag && tid >= 0) {
+      if ((uint32_t)tid >= P.n_targets) *finding = (uint32_t)FQG_E_TAGS_TID;
+      else {
+        add += 4u + P.tx_len[tid];
+        if (P.gx_len[tid] != kBtNone) add += 4u + P.gx_len[tid];
+      }
+    }
+  } else {
+    r.len[0] = r.len[1] = r.len[2] = 0;  // (a name that fails half-way gets no tag at all)
+  }
+  return add;
+}
 
 // the tags of one record, written byte by byte through put(byte)
 template <class Src, class Put>
@@ -170,9 +173,14 @@ __device__ __forceinline__ void bt_tags(const BtParams& P, const BtRec& r, int32
   }
 }
 
-__global__ __launch_bounds__(kWave) void k_bt_emit(BtEmit A) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_in[kBtInCap + 32];
-  __shared__ __attribute__((aligned(16))) uint8_t s_out[kBtOutCap + 32];
+// One wavefront per tile of A.T consecutive alignments, one lane per alignment.  EMIT = false: the new record sizes
+// (pass 1).  EMIT = true: the records with their tags (pass 2, after the scan of the sizes).  Both read the tile's
+// bytes once, as one span, through LDS; a tile that does not fit there (long reads) works on the stream itself.
+template <bool EMIT>
+__global__ __launch_bounds__(kWave) void k_bt_tile(BtTiles A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_bt[];
+  uint8_t* s_in = s_bt;
+  uint8_t* s_out = s_bt + A.in_cap + 32;
   const int lane = (int)threadIdx.x;
   const uint32_t i0 = blockIdx.x * A.T;
   if (i0 >= A.n) return;
@@ -180,57 +188,115 @@ __global__ __launch_bounds__(kWave) void k_bt_emit(BtEmit A) {
   const bool valid = (uint32_t)lane < Tn;
   const uint32_t i = i0 + (valid ? (uint32_t)lane : Tn - 1);
   const uint64_t in_off = A.offs[i];
-  uint32_t block;
-  int32_t tid;
-  __builtin_memcpy(&block, A.buf + in_off, 4);
-  __builtin_memcpy(&tid, A.buf + in_off + 4, 4);
-  const uint32_t in_len = 4u + block, out_len = A.new_size[i];
-  const uint64_t out_off = A.out_local[i] + A.out_sums[i / kScan64Span];
-  const BtRec r = A.rec[i];
-  const uint64_t in0 = rfl64(in_off), out0 = rfl64(out_off);
-  const uint64_t in_end = rl64(in_off + in_len, (int)Tn - 1), out_end = rl64(out_off + out_len, (int)Tn - 1);
+  const uint64_t in0 = rfl64(in_off);
+  // the tile's span: up to the end of its last record, which only the record itself tells
+  uint64_t out_off = 0, out0 = 0, out_end = 0;
+  uint32_t out_len = 0;
+  if (EMIT) {
+    out_len = A.new_size[i];
+    out_off = A.out_local[i] + A.out_sums[i / kScan64Span];
+    out0 = rfl64(out_off);
+    out_end = rl64(out_off + out_len, (int)Tn - 1);
+  }
   const uint32_t in_skew = (uint32_t)(in0 & 15u);  // (the stream starts at a 16-byte boundary)
-  const uint32_t out_skew = (uint32_t)((uintptr_t)(A.out + out0) & 15u);
-  const bool fits = in_skew + (in_end - in0) + 16 <= (uint64_t)kBtInCap && out_skew + (out_end - out0) + 16 <= (uint64_t)kBtOutCap;
+  const uint32_t out_skew = EMIT ? (uint32_t)((uintptr_t)(A.out + out0) & 15u) : 0u;
+  // bound of the span before the last record's length is known: its start + 4 (the length field) is inside for sure;
+  // the true end follows from the staged length field
+  const uint64_t last_off = rl64(in_off, (int)Tn - 1);
+  uint32_t last_block = 0;
+  if (last_off + 4 <= A.nbytes) __builtin_memcpy(&last_block, A.buf + last_off, 4);
+  const uint64_t in_end = last_off + 4ull + last_block;
+  const bool fits = in_skew + (in_end - in0) + 16 <= (uint64_t)A.in_cap &&
+                    (!EMIT || out_skew + (out_end - out0) + 16 <= (uint64_t)A.out_cap);
+  uint32_t block = 0;
+  int32_t tid = -1;
+  BtRec r;
+  uint32_t finding = 0, add = 0;
   if (fits) {
     const uint32_t span = in_skew + (uint32_t)(in_end - in0);
     const uint64_t base = in0 - in_skew;
-    for (uint32_t u = (uint32_t)lane * 16u; u < span; u += 16u * kWave) {
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 v = {0, 0, 0, 0};
-      if (base + u + 16 <= A.nbytes) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.buf + base + u));
-      else
-        for (uint64_t b = 0; base + u + b < A.nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&v)[b] = A.buf[base + u + b];
-      *reinterpret_cast<u32x4*>(s_in + u) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (valid) {
-      const BtLds src = (BtLds)s_in + in_skew + (uint32_t)(in_off - in0);
-      BtLds dst = (BtLds)s_out + out_skew + (uint32_t)(out_off - out0);
-      bt_copy(dst, src, in_len);
-      bt_st4(dst, out_len - 4u);  // block_size
-      BtLds w = dst + in_len;
-      bt_tags(A.P, r, tid, [&](uint32_t o) { return (uint8_t)src[o]; }, [&](uint8_t b) { *w++ = b; });
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    emit_flush(s_out, out_skew, (uint32_t)(out_end - out0), A.out + out0, lane);
-  } else {
-    // long records: straight from the stream to the output, one record after the other
-    for (uint32_t k = 0; k < Tn; ++k) {
-      const uint64_t so = rl64(in_off, (int)k), dofs = rl64(out_off, (int)k);
-      const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)in_len, (int)k);
-      const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)out_len, (int)k);
-      const uint8_t* src = A.buf + so;
-      uint8_t* dst = A.out + dofs;
-      const uint32_t nb = dl - 4u;
-      for (uint32_t j = (uint32_t)lane; j < sl; j += kWave) dst[j] = j < 4 ? (uint8_t)(nb >> (8 * j)) : src[j];
-      if ((uint32_t)lane == k) {
-        uint8_t* w = dst + sl;
-        bt_tags(A.P, r, tid, [&](uint32_t o) { return src[o]; }, [&](uint8_t b) { *w++ = b; });
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t units = (span + 15u) >> 4;
+    // whole 16-byte units that lie inside the stream: 8 loads in flight per lane; the last unit(s) of the stream byte by byte
+    const uint64_t safe_units = A.nbytes > base ? (A.nbytes - base) >> 4 : 0;
+    for (uint32_t u0 = 0; u0 < units; u0 += 8 * kWave) {
+      u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint32_t u = u0 + j * kWave + (uint32_t)lane;
+        u = u < units ? u : units - 1;
+        if ((uint64_t)u < safe_units) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.buf + base + 16ull * u));
+        else {
+          u32x4 t = {0, 0, 0, 0};
+          for (uint64_t b = 0; base + 16ull * u + b < A.nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&t)[b] = A.buf[base + 16ull * u + b];
+          v[j] = t;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t u = u0 + j * kWave + (uint32_t)lane;
+        if (u < units) *reinterpret_cast<u32x4*>(s_in + 16u * u) = v[j];
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const BtLds img = (BtLds)s_in;  // img[k] = stream byte base + k
+    block = *(__attribute__((address_space(3))) bt_u32*)(img + (uint32_t)(in_off - base));
+    tid = (int32_t) * (__attribute__((address_space(3))) bt_u32*)(img + (uint32_t)(in_off - base) + 4);
+    add = bt_growth(A.P, [&](uint64_t p) { return bt_ld8(img + (uint32_t)(p - base)); }, in_off, block, tid, r, &finding);
+    if (EMIT) {
+      if (valid) {
+        const BtLds src = img + (uint32_t)(in_off - base);
+        BtLds dst = (BtLds)s_out + out_skew + (uint32_t)(out_off - out0);
+        const uint32_t in_len = 4u + block;
+        bt_copy(dst, src, in_len);
+        bt_st4(dst, out_len - 4u);  // block_size
+        BtLds w = dst + in_len;
+        bt_tags(A.P, r, tid, [&](uint32_t o) { return (uint8_t)src[o]; }, [&](uint8_t b) { *w++ = b; });
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      emit_flush(s_out, out_skew, (uint32_t)(out_end - out0), A.out + out0, lane);
+    }
+  } else {
+    __builtin_memcpy(&block, A.buf + in_off, 4);
+    __builtin_memcpy(&tid, A.buf + in_off + 4, 4);
+    const uint8_t* gb = A.buf;
+    const uint64_t nbytes = A.nbytes;
+    add = bt_growth(A.P,
+                    [&](uint64_t p) {
+                      uint64_t v = 0;
+                      if (p + 8 <= nbytes) __builtin_memcpy(&v, gb + p, 8);
+                      else
+                        for (uint64_t k = 0; p + k < nbytes && k < 8; ++k) v |= (uint64_t)gb[p + k] << (8 * k);
+                      return v;
+                    },
+                    in_off, block, tid, r, &finding);
+    if (EMIT) {
+      // long records: straight from the stream to the output, one record after the other
+      const uint32_t in_len = 4u + block;
+      for (uint32_t k = 0; k < Tn; ++k) {
+        const uint64_t so = rl64(in_off, (int)k), dofs = rl64(out_off, (int)k);
+        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)in_len, (int)k);
+        const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)out_len, (int)k);
+        const uint8_t* src = A.buf + so;
+        uint8_t* dst = A.out + dofs;
+        const uint32_t nb = dl - 4u;
+        for (uint32_t j = (uint32_t)lane; j < sl; j += kWave) dst[j] = j < 4 ? (uint8_t)(nb >> (8 * j)) : src[j];
+        if ((uint32_t)lane == k) {
+          uint8_t* w = dst + sl;
+          bt_tags(A.P, r, tid, [&](uint32_t o) { return src[o]; }, [&](uint8_t b) { *w++ = b; });
+        }
+      }
+    }
+  }
+  if (!EMIT) {
+    if (valid) {
+      A.new_size[i] = 4u + block + add;
+      if (finding) atomicMin(&A.call->first_finding, ((unsigned long long)i << 8) | finding);
+    }
+    const unsigned long long m = __ballot(valid && r.ok);
+    if (lane == 0 && m) atomicAdd(&A.call->n_tagged[blockIdx.x & 63], (unsigned long long)__popcll(m));
   }
 }
 

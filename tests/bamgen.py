@@ -172,6 +172,32 @@ def fixed_records(cell_code, gene, umi_code):
     return rec
 
 
+TAGGED_NAME_REC_BYTES = 137
+
+
+def tagged_name_records(cell_code, umi_code, tid):
+    """One 137-byte alignment per element whose read name carries the barcodes as fastq_pre_barcodes writes them:
+    STAGS_CELL=<16 bases>_UMI=<10 bases>_SAMPLE=_ETAGS_r<8 digits> (what bam_add_tags parses).  uint8 [n, 137]."""
+    n = cell_code.size
+    R = TAGGED_NAME_REC_BYTES
+    rec = np.zeros((n, R), dtype=np.uint8)
+    core = struct.pack("<iiiIIiiii", R - 4, 0, 100, (4680 << 16) | (255 << 8) | 67, (0 << 16) | 1, 20, -1, -1, 0)
+    rec[:, :36] = np.frombuffer(core, dtype=np.uint8)
+    rec[:, 4:8] = np.asarray(tid, dtype="<i4").reshape(-1, 1).view(np.uint8).reshape(n, 4)
+    q = 36
+    for text, width, fill in ((b"STAGS_CELL=", 11, None), (None, 16, _bases(cell_code, 16)), (b"_UMI=", 5, None),
+                              (None, 10, _bases(umi_code, 10)), (b"_SAMPLE=_ETAGS_r", 16, None),
+                              (None, 8, _digits(np.arange(n, dtype=np.int64) % 100000000, 8))):
+        rec[:, q:q + width] = np.frombuffer(text, dtype=np.uint8) if text is not None else fill
+        q += width
+    q += 1  # the name's NUL
+    rec[:, q:q + 4] = np.frombuffer(struct.pack("<I", 20 << 4), dtype=np.uint8)
+    rec[:, q + 4:q + 14] = 0x12
+    rec[:, q + 14:q + 34] = 30
+    assert q + 34 == R
+    return rec
+
+
 def config4(rng, n_cells=10000, n_genes=20000, n_triples=5000000, dup=0.3, fresh_umis=False):
     """CR-sorted synthetic alignments: `n_triples` distinct (cell, gene, UMI) plus `dup` duplicate reads.
     fresh_umis: every distinct triple gets a UMI string of its own, in increasing order of first use

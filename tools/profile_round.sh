@@ -13,8 +13,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ONLY_HEADLINE="--no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra"
-ONLY_UMI="--reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra"
+ONLY_HEADLINE="--no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra"
+ONLY_UMI="--reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-tags-extra"
 for w in $WHAT; do
   case $w in
   bench)
