@@ -22,6 +22,11 @@ for w in $WHAT; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-e2e > $O/under_rocprof.json 2> $O/under_rocprof.err
     find $O/stats -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
     find $O/stats -name '*kernel_trace.csv' -delete
+    # the headline workload alone (what bench.py's roofline block times): its average launch durations are the ones to
+    # hold against roofline.avg_launch_ms
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -o stats -- python3 $R/bench.py $ONLY_HEADLINE > $O/headline_under_rocprof.json 2> $O/headline_under_rocprof.err
+    find $O/stats_headline -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats_headline.csv \;
+    find $O/stats_headline -name '*kernel_trace.csv' -delete
     ;;
   traffic)
     for c in FETCH_SIZE WRITE_SIZE; do
