@@ -321,13 +321,23 @@ __global__ __launch_bounds__(kBlock) void k_rl_cell_chain(uint32_t n_runs, const
     key = pair_key[slot].key;  // cell << 32 | feature
     keep = feat_flag[(uint32_t)key] != 0;
   }
+  // one atomic per WORKGROUP for the place in the list (25 000 wavefronts asking one address for a return value
+  // take longer than everything else this kernel does)
+  __shared__ uint32_t s_cnt[kBlock / kWave], s_base;
   const unsigned long long m = __ballot(keep);
-  if (!m) return;
-  uint32_t base = 0;
-  if ((threadIdx.x & 63) == 0) base = atomicAdd(&call->n_chain, (uint32_t)__popcll(m));
-  base = __shfl(base, 0);
+  const int wv = (int)(threadIdx.x >> 6);
+  if ((threadIdx.x & 63) == 0) s_cnt[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) tot += s_cnt[w];
+    s_base = tot ? atomicAdd(&call->n_chain, tot) : 0u;
+  }
+  __syncthreads();
   if (!keep) return;
-  const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+  uint32_t at = s_base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+  for (int w = 0; w < wv; ++w) at += s_cnt[w];
   chain_key[at] = (key << 32) | (key >> 32);
   chain_run[at] = r;
   const uint32_t cell = (uint32_t)(key >> 32);

@@ -54,3 +54,21 @@ def test_get_barcodes_exits():
         bto.get_barcodes(b"STAGS_CELL=ACGT", 0, 15)
     with pytest.raises(bto.Undefined):
         gb(b"STAGS_CELL=" + b"A" * 50 + b"_UMI=_SAMPLE=_")
+
+
+def test_bench_stream_generator_and_its_size_formula():
+    """bench.py's bam_add_tags extra checks the output size at full length with a formula: every alignment of
+    tests/bamgen.tagged_name_records gains RX (14 bytes) and CR (20), mapped ones tx (19 with 15-character names)."""
+    import numpy as np
+    from tests import bamgen
+    rng = np.random.default_rng(1)
+    n = 3000
+    refs = tuple((b"ENST%011d" % i, 1000) for i in range(300))
+    tid = rng.integers(-1, len(refs), n).astype(np.int32)
+    rec = bamgen.tagged_name_records(rng.integers(0, 1 << 32, n).astype(np.uint64), rng.integers(0, 1 << 20, n).astype(np.uint64), tid)
+    stream = bamgen.header(refs) + rec.tobytes()
+    out, m = bto.add_tags_stream(stream, tx_tag=True)
+    assert m == n
+    assert len(out) == len(stream) + 34 * n + 19 * int((tid >= 0).sum())
+    ok, cell, umi, sample = bto.get_barcodes(stream, len(bamgen.header(refs)) + 36, len(stream))
+    assert ok and len(cell) == 16 and len(umi) == 10 and sample == b""
