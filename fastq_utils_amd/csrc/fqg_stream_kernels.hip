@@ -597,6 +597,7 @@ struct LinesArgs {
 };
 
 constexpr int kLinesHist = 4096;
+constexpr int kLinesPer = 2;  // records per lane and step: their staged-entry loads are in flight together (2.07 -> 1.58 ms; 4: 1.86 ms - registers; 3 does not compile with ROCm 7.2)
 __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
   __shared__ uint32_t s_hist[kLinesHist];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
@@ -606,15 +607,18 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
   __syncthreads();
   const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
   uint32_t win0 = 0;
-  const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);  // 64 records (256 lines) per wavefront step
+  // a step = kLinesPer * 64 consecutive records (kLinesPer * 256 lines) per wavefront
+  const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);
+  const uint64_t n_steps = (n_groups + kLinesPer - 1) / kLinesPer;
   const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
   unsigned long long n_ok = 0, min_rl = ~0ull, max_rl = 0;
   uint64_t nx_r0 = ~0ull;
   uint32_t nx_cnt = 0, nx_win = 0;
-  auto window_load = [&](uint64_t g) {
-    if (g >= n_groups) return;
+  auto window_load = [&](uint64_t step) {
+    if (step >= n_steps) return;
+    const uint64_t g = step * kLinesPer;
     const uint64_t Rw = g ? 4 * g * kWave - 1 : 0;
     const double est = (double)Rw * chunks_per_line;
     uint32_t cw = est > 2.0 ? (uint32_t)(est - 2.0) : 0u;
@@ -626,122 +630,142 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
     nx_win = cw;
   };
   window_load(wave0);
-  for (uint64_t g = wave0; g < n_groups; g += n_waves) {
-    const uint64_t r = g * kWave + (uint64_t)lane;   // my record
-    const uint64_t L0 = 4 * r;                       // its first line
+  for (uint64_t step = wave0; step < n_steps; step += n_waves) {
     // e[0] = end of the line before mine, e[1..4] = ends of my four lines; ent[] = their staged entries
-    uint64_t e[5];
-    uint32_t ent[5];
-    bool have[5];
-    uint64_t R = r ? L0 - 1 : 0;  // first rank to fetch
-    const int k0 = r ? 0 : 1;
-    e[0] = ~0ull;                 // (record 0: the line before starts at -1)
-    ent[0] = (kClsAt << 12);      // ... and the image's first byte is checked directly below
-    have[0] = r == 0;
-    // The chunks this wavefront's 257 ranks live in: a window of 64 chunks starting a little before the estimated
+    uint64_t e[kLinesPer][5];
+    uint32_t ent[kLinesPer][5];
+    bool have[kLinesPer][5];
+    // The chunks this wavefront's ranks live in: a window of 64 chunks starting a little before the estimated
     // chunk of its first rank, loaded by all lanes at once into LDS.  A lane whose rank falls outside it (reads
     // of kilobases: few newlines per chunk) searches the chunk prefix on its own.  The window of the NEXT step is
     // requested before this step's work, so its memory round trip is hidden.
     s_wr0[wv][lane] = nx_r0;
     s_wcnt[wv][lane] = nx_cnt;
     win0 = nx_win;
-    window_load(g + n_waves);
+    window_load(step + n_waves);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t c = 0, i = 0, cnt = 0;
-    bool windowed = false;  // c is an index INTO the window (then counts come from LDS)
-    if (R < A.n_newlines) {
-      const uint64_t* w0 = s_wr0[wv];
-      if (R >= w0[0] && (R < w0[kWave - 1] + s_wcnt[wv][kWave - 1])) {
-        uint32_t lo = 0, hi = kWave;  // last window entry whose first rank is <= R
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (w0[mid] <= R) lo = mid;
-          else hi = mid;
-        }
-        c = lo;
-        i = (uint32_t)(R - w0[lo]);
-        cnt = s_wcnt[wv][lo];
-        windowed = true;
-      } else {
-        c = chunk_of_rank(A.cr, R, (uint32_t)((double)R * chunks_per_line));
-        i = (uint32_t)(R - A.cr.rank0(c));
-        cnt = A.cr.counts[c];
-      }
-    }
+    // ---- phase 1: where the entries are, and their loads (all kLinesPer * 5 of a lane before any is looked at) ----
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      if (k < k0) continue;
+    for (int q = 0; q < kLinesPer; ++q) {
+      const uint64_t g = step * kLinesPer + q;
+      const uint64_t r = g * kWave + (uint64_t)lane;   // my record
+      const uint64_t L0 = 4 * r;                       // its first line
+      uint64_t R = r ? L0 - 1 : 0;  // first rank to fetch
+      const int k0 = r ? 0 : 1;
+      e[q][0] = ~0ull;                 // (record 0: the line before starts at -1)
+      ent[q][0] = (kClsAt << 12);      // ... and the image's first byte is checked directly below
+      have[q][0] = r == 0;
+      uint32_t c = 0, i = 0, cnt = 0;
+      bool windowed = false;  // c is an index INTO the window (then counts come from LDS)
       if (R < A.n_newlines) {
-        while (i >= cnt) {  // next chunk that holds a newline
-          ++c;
-          i = 0;
-          if (windowed && c >= (uint32_t)kWave) {  // ran out of the window
-            windowed = false;
-            c += win0;
+        const uint64_t* w0 = s_wr0[wv];
+        if (R >= w0[0] && (R < w0[kWave - 1] + s_wcnt[wv][kWave - 1])) {
+          uint32_t lo = 0, hi = kWave;  // last window entry whose first rank is <= R
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (w0[mid] <= R) lo = mid;
+            else hi = mid;
           }
-          cnt = windowed ? s_wcnt[wv][c] : A.cr.counts[c];
+          c = lo;
+          i = (uint32_t)(R - w0[lo]);
+          cnt = s_wcnt[wv][lo];
+          windowed = true;
+        } else {
+          c = chunk_of_rank(A.cr, R, (uint32_t)((double)R * chunks_per_line));
+          i = (uint32_t)(R - A.cr.rank0(c));
+          cnt = A.cr.counts[c];
         }
-        const uint32_t cg = windowed ? win0 + c : c;
-        const uint32_t v = (A.ablate & 2) ? (i * 80u) : A.stage[(uint64_t)cg * kStageCap + i];
-        ent[k] = v;
-        e[k] = (uint64_t)cg * kChunkBytes + (v & 0xFFFu);
-        have[k] = true;
-        ++i;
-      } else if (R == A.n_newlines && A.n_lines > A.n_newlines) {  // the unterminated last line
-        ent[k] = 0;
-        e[k] = A.n;
-        have[k] = true;
-      } else {
-        ent[k] = 0;
-        e[k] = 0;
-        have[k] = false;
       }
-      ++R;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if (k < k0) continue;
+        if (R < A.n_newlines) {
+          while (i >= cnt) {  // next chunk that holds a newline
+            ++c;
+            i = 0;
+            if (windowed && c >= (uint32_t)kWave) {  // ran out of the window
+              windowed = false;
+              c += win0;
+            }
+            cnt = windowed ? s_wcnt[wv][c] : A.cr.counts[c];
+          }
+          const uint32_t cg = windowed ? win0 + c : c;
+          ent[q][k] = (A.ablate & 2) ? (i * 80u) : A.stage[(uint64_t)cg * kStageCap + i];
+          e[q][k] = (uint64_t)cg * kChunkBytes;  // (+ the entry's offset, below)
+          have[q][k] = true;
+          ++i;
+        } else if (R == A.n_newlines && A.n_lines > A.n_newlines) {  // the unterminated last line
+          ent[q][k] = 0;
+          e[q][k] = A.n;
+          have[q][k] = true;
+        } else {
+          ent[q][k] = 0;
+          e[q][k] = 0;
+          have[q][k] = false;
+        }
+        ++R;
+      }
     }
     __builtin_amdgcn_wave_barrier();  // (the window is rewritten by the next step)
-    // ---- the line index: four ends per lane, 32 contiguous bytes ----
-    if (A.ablate & 1) {
-    } else if (have[4] && L0 + 3 < A.line_cap) {
-      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-      u64x2 lo2, hi2;
-      lo2.x = e[1]; lo2.y = e[2]; hi2.x = e[3]; hi2.y = e[4];
-      __builtin_nontemporal_store(lo2, reinterpret_cast<u64x2*>(A.line_end + L0));
-      __builtin_nontemporal_store(hi2, reinterpret_cast<u64x2*>(A.line_end + L0 + 2));
-    } else {
+    // ---- phase 2: the line index, the checks, the statistics ----
 #pragma unroll
-      for (int k = 1; k < 5; ++k)
-        if (have[k] && L0 + k - 1 < A.line_cap) A.line_end[L0 + k - 1] = e[k];
-    }
-    // ---- checks (complete records only) ----
-    bool sus = false, complete = have[4] && L0 + 3 < A.limit;
-    if (complete) {
-      // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
-      if (r == 0) sus |= A.img[0] != '@' || (A.n > 1 && A.img[1] == '\n');
-      else sus |= !(((ent[0] >> 12) & 3u) == kClsAt && !((ent[0] >> 14) & 1u));
-      sus |= !(((ent[2] >> 12) & 3u) == kClsPlus && ((ent[2] >> 14) & 1u));
-      const uint64_t l0 = e[1] - e[0] - 1, l1 = e[2] - e[1] - 1, l2 = e[3] - e[2] - 1, l3 = e[4] - e[3] - 1;
-      const uint32_t has_nl = e[4] < A.n ? 1u : 0u;  // only the very last line can lack it
-      sus |= l1 < 1 || l1 != l3 || A.space != FQG_SPACE_SEQ;
-      sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
-             l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + has_nl > FQG_MAX_READ_LENGTH - 1;
-      if (A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1) {
-        const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line always ends in '\n' here
-        ++n_ok;
-        min_rl = rl < min_rl ? rl : min_rl;
-        max_rl = rl > max_rl ? rl : max_rl;
-        if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
-        else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
+    for (int q = 0; q < kLinesPer; ++q) {
+      const uint64_t g = step * kLinesPer + q;
+      const uint64_t r = g * kWave + (uint64_t)lane;
+      const uint64_t L0 = 4 * r;
+      {
+        uint64_t R = r ? L0 - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          if (k < (r ? 0 : 1)) continue;
+          if (R < A.n_newlines) e[q][k] += (ent[q][k] & 0xFFFu);
+          ++R;
+        }
       }
-    }
-    // the wavefront owns records g*64 .. g*64+63 = two whole words of the bitmap
-    const unsigned long long sm = __ballot(sus);
-    if (lane == 0 && sm) {
-      const uint64_t w = g * 2;
-      if ((g + 1) * kWave <= A.suspect_cap) {
-        if ((uint32_t)sm) A.suspect_bits[w] = (uint32_t)sm;
-        if ((uint32_t)(sm >> 32)) A.suspect_bits[w + 1] = (uint32_t)(sm >> 32);
-      } else atomicOr(A.flags, kFlagSuspectOverflow);
+      // four ends per lane, 32 contiguous bytes
+      if (A.ablate & 1) {
+      } else if (have[q][4] && L0 + 3 < A.line_cap) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 lo2, hi2;
+        lo2.x = e[q][1]; lo2.y = e[q][2]; hi2.x = e[q][3]; hi2.y = e[q][4];
+        __builtin_nontemporal_store(lo2, reinterpret_cast<u64x2*>(A.line_end + L0));
+        __builtin_nontemporal_store(hi2, reinterpret_cast<u64x2*>(A.line_end + L0 + 2));
+      } else {
+#pragma unroll
+        for (int k = 1; k < 5; ++k)
+          if (have[q][k] && L0 + k - 1 < A.line_cap) A.line_end[L0 + k - 1] = e[q][k];
+      }
+      // checks (complete records only)
+      bool sus = false, complete = have[q][4] && L0 + 3 < A.limit;
+      if (complete) {
+        // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
+        if (r == 0) sus |= A.img[0] != '@' || (A.n > 1 && A.img[1] == '\n');
+        else sus |= !(((ent[q][0] >> 12) & 3u) == kClsAt && !((ent[q][0] >> 14) & 1u));
+        sus |= !(((ent[q][2] >> 12) & 3u) == kClsPlus && ((ent[q][2] >> 14) & 1u));
+        const uint64_t l0 = e[q][1] - e[q][0] - 1, l1 = e[q][2] - e[q][1] - 1, l2 = e[q][3] - e[q][2] - 1, l3 = e[q][4] - e[q][3] - 1;
+        const uint32_t has_nl = e[q][4] < A.n ? 1u : 0u;  // only the very last line can lack it
+        sus |= l1 < 1 || l1 != l3 || A.space != FQG_SPACE_SEQ;
+        sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
+               l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + has_nl > FQG_MAX_READ_LENGTH - 1;
+        if (A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1) {
+          const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line always ends in '\n' here
+          ++n_ok;
+          min_rl = rl < min_rl ? rl : min_rl;
+          max_rl = rl > max_rl ? rl : max_rl;
+          if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
+          else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
+        }
+      }
+      // the wavefront owns records g*64 .. g*64+63 = two whole words of the bitmap
+      const unsigned long long sm = __ballot(sus);
+      if (lane == 0 && sm) {
+        const uint64_t w = g * 2;
+        if ((g + 1) * kWave <= A.suspect_cap) {
+          if ((uint32_t)sm) A.suspect_bits[w] = (uint32_t)sm;
+          if ((uint32_t)(sm >> 32)) A.suspect_bits[w + 1] = (uint32_t)(sm >> 32);
+        } else atomicOr(A.flags, kFlagSuspectOverflow);
+      }
     }
   }
   if (!A.acc) return;
