@@ -291,6 +291,7 @@ __global__ __launch_bounds__(kWave) void k_bt_tile(BtTiles A) {
     }
   }
   if (!EMIT) {
+    if (in_off + 4ull + block > A.nbytes) finding = (uint32_t)FQG_E_TAGS_NAME;  // (a block_size that leaves the stream: nothing is emitted)
     if (valid) {
       A.new_size[i] = 4u + block + add;
       if (finding) atomicMin(&A.call->first_finding, ((unsigned long long)i << 8) | finding);

@@ -155,11 +155,14 @@ constexpr uint32_t kHdrBytes = 8 * kHdrWords;
 struct HdrRegs {
   uint64_t w[kHdrWords + 1];  // w[kHdrWords] = 0: the funnel shifts read one word ahead
 };
-__device__ __forceinline__ void hdr_load(const uint8_t* __restrict__ line, HdrRegs& H) {
+// (only the 16-byte pieces that hold bytes of the line are fetched - `cstr` of them count; the words behind read as
+// zero: a 45-byte header costs three loads, not eight, and a name kernel is made of exactly this traffic)
+__device__ __forceinline__ void hdr_load(const uint8_t* __restrict__ line, HdrRegs& H, uint32_t cstr) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
 #pragma unroll
   for (int j = 0; j < kHdrWords / 2; ++j) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(line + 16 * j);
+    u32x4 v = {0, 0, 0, 0};
+    if (16u * j < cstr) v = *reinterpret_cast<const u32x4*>(line + 16 * j);
     H.w[2 * j] = ((uint64_t)v.y << 32) | v.x;
     H.w[2 * j + 1] = ((uint64_t)v.w << 32) | v.z;
   }
@@ -234,7 +237,7 @@ __device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ im
   const uint32_t len = (uint32_t)(e - b), has_nl = e < nbytes ? 1u : 0u;
   if (!may_have_nul && len + has_nl <= kHdrBytes - 1 && b + kHdrBytes <= nbytes) {
     HdrRegs H;
-    hdr_load(line, H);
+    hdr_load(line, H, len + has_nl);
     bool ok;
     const uint32_t n = canon_name_regs(H, len + has_nl, fmt, is_pe, acct, &ok);
     if (ok) {
@@ -406,8 +409,8 @@ __global__ __launch_bounds__(kBlock) void k_names_compare(FrameView a, int fmt_a
         bb + kHdrBytes <= fb.nbytes) {
       // both headers in registers: no memory round trip per byte
       HdrRegs A, B;
-      hdr_load(la, A);
-      hdr_load(lb, B);
+      hdr_load(la, A, len_a + nl_a);
+      hdr_load(lb, B, len_b + nl_b);
       bool ok_a, ok_b;
       const uint32_t na = canon_name_regs(A, len_a + nl_a, fmt_a, pe_a, &acct, &ok_a);
       const uint32_t nb = canon_name_regs(B, len_b + nl_b, fmt_b, pe_b, &acct, &ok_b);
