@@ -87,14 +87,12 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, T* s_tmp, uint32
   return incl - v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_umi_cells(CellArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
-  __shared__ uint32_t s_tmp[kBlock];
-  __shared__ uint32_t s_n;
-  const uint32_t c = blockIdx.x + 1u;
-  if (c > A.n_cells) return;
-  const uint32_t s0 = A.cell_first[c], s1 = A.cell_first[c + 1], m = s1 - s0;
-  unsigned long long* keys = m <= A.lds_keys ? s_keys : A.big_keys + 2ull * s0;
+// the work of one cell on its keys, which are in LDS (KP = an LDS pointer: ds_read / ds_write) or, for a cell that does
+// not fit there, in a global scratch (KP = a plain pointer).  One body for a pointer that "may be either" would reach
+// LDS through FLAT instructions - 700 of them per wavefront in the sort alone.
+template <class KP>
+__device__ __forceinline__ void umi_cell_body(const CellArgs& A, KP keys, uint32_t c, uint32_t s0, uint32_t m, uint32_t* s_tmp,
+                                              uint32_t& s_n) {
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   // ---- the counted records of the cell ----
@@ -248,6 +246,18 @@ __global__ __launch_bounds__(kBlock) void k_umi_cells(CellArgs A) {
       if (old == ~0u) A.flagged_slot[atomicAdd(&A.rl->n_flagged, 1u)] = s0 + rank;
     }
   }
+}
+
+typedef __attribute__((address_space(3))) unsigned long long* CellKeysLds;
+__global__ __launch_bounds__(kBlock) void k_umi_cells(CellArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+  __shared__ uint32_t s_tmp[kBlock];
+  __shared__ uint32_t s_n;
+  const uint32_t c = blockIdx.x + 1u;
+  if (c > A.n_cells) return;
+  const uint32_t s0 = A.cell_first[c], s1 = A.cell_first[c + 1], m = s1 - s0;
+  if (m <= A.lds_keys) umi_cell_body(A, (CellKeysLds)s_keys, c, s0, m, s_tmp, s_n);
+  else umi_cell_body(A, A.big_keys + 2ull * s0, c, s0, m, s_tmp, s_n);
 }
 
 // pair_of[] (pairs grouped by cell, as the output kernels walk them) for the worst-case pair layout
