@@ -75,6 +75,7 @@ struct UmiCall {
   // counters that every wavefront adds to: 64 copies each, picked by workgroup, summed on the host
   // (a hundred thousand atomic adds to ONE address cost more than the kernels that issue them)
   unsigned long long spread[3][64];  // [0] n_tags, [1] n_counted, [2] n_new
+  unsigned long long tot_spread[2][64];  // the same for tot[] (k_umi_emit: one add per workgroup)
   unsigned int all_unit;         // 1 while every increment seen is exactly 1.0f
   unsigned int table_full;
   unsigned int max_cell_records; // sorted mode: records of the largest cell (k_umi_cell_sizes)
@@ -813,6 +814,7 @@ struct EmitArgs {
   const uint32_t* remap;        // feature id -> id used for the output rules and printed (null: identity);
                                 // sharded runs pass the global first-appearance ids here
   uint32_t cell_offset;         // added to the printed cell id (cells of earlier shards)
+  int pairs_by_feature;         // pair_of[] lists a cell's pairs in ascending feature id (the per-cell counting path)
   UmiEntry* out_u;              // scratch, one entry per pair
   UmiEntry* out_r;
 };
@@ -831,6 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
   // unsorted mode never prints cell ids >= max_cells (write2MM loops while cell_id < max_cells, :612)
   const bool cell_printed = A.P.sorted_by_cell || c + A.cell_offset < A.P.max_cells;
   unsigned long long tu = 0, tr = 0;
+  uint32_t np_sweep = 1;
   // sweeps over the feature id space, 131072 ids at a time (one sweep unless --max_feat is huge)
   uint32_t max_f = 0;
   auto feat_of = [&](uint32_t slot) {
@@ -851,7 +854,45 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
   max_f = 0;
   for (int w = 0; w < kBlock / kWave; ++w) max_f = s_wave[w] > max_f ? s_wave[w] : max_f;
   __syncthreads();
-  for (uint32_t sweep0 = 0; sweep0 <= max_f; sweep0 += kUmiBitmapWords * 32) {
+  // the output rules for one pair of the cell; `rank` = its place among the cell's features
+  auto emit_pair = [&](uint32_t slot, uint32_t feat, uint32_t rank) {
+    // the walk over cf stops once `pr >= tot_umi_obs` (:697 / :643).  Sorted mode counts every feature
+    // seen so far in the file (ids 1..feat-1 precede this one), unsorted mode the cell's own.
+    const uint32_t pr_before = A.P.sorted_by_cell ? feat - 1u : rank;
+    if (!cell_printed || feat >= A.P.max_features || (float)pr_before >= tot) return;
+    const float u = A.pair_umis[slot], r = A.pair_reads[slot];
+    if (!(r >= (float)A.P.min_reads && u >= (float)A.P.min_umis)) return;
+    // ucounts: UMIs, or the reads when the UMI count truncates to 0 (:685-695)
+    uint32_t val_u = 0, val_r = 0;
+    bool pu = false, prd = false;
+    if ((uint32_t)u >= 1u) {
+      pu = true;
+      val_u = (uint32_t)roundf(u);
+      tu += (uint32_t)u;
+    } else if ((uint32_t)r >= 1u) {
+      pu = true;
+      val_u = (uint32_t)roundf(r);
+      tu += (uint32_t)r;
+    }
+    if ((uint32_t)r >= 1u) {
+      prd = true;
+      val_r = (uint32_t)roundf(r);
+      tr += (uint32_t)r;
+    }
+    if (pu) A.out_u[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c + A.cell_offset, val_u};
+    if (prd) A.out_r[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c + A.cell_offset, val_r};
+  };
+  if (A.pairs_by_feature && !A.remap) {
+    // the per-cell counting path hands the pairs over in feature order: the rank is the position, and the bitmap
+    // (16 KiB zeroed, counted and prefixed per cell for a few hundred pairs) is not needed
+    for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
+      const uint32_t slot = A.pair_of[p0 + k];
+      emit_pair(slot, (uint32_t)A.Pt.t.s[slot].key, k);
+    }
+    max_f = 0;  // (no sweep below)
+    np_sweep = 0;
+  }
+  for (uint32_t sweep0 = 0; np_sweep && sweep0 <= max_f; sweep0 += kUmiBitmapWords * 32) {
     for (int w = threadIdx.x; w < kUmiBitmapWords; w += kBlock) s_bits[w] = 0;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < np; k += kBlock) {
@@ -890,31 +931,7 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
       const uint32_t f = feat - sweep0;
       if (f >= (uint32_t)kUmiBitmapWords * 32) continue;
       const uint32_t rank = s_pre[f >> 5] + __popc(s_bits[f >> 5] & ((1u << (f & 31)) - 1u));  // among the cell's features
-      // the walk over cf stops once `pr >= tot_umi_obs` (:697 / :643).  Sorted mode counts every feature
-      // seen so far in the file (ids 1..feat-1 precede this one), unsorted mode the cell's own.
-      const uint32_t pr_before = A.P.sorted_by_cell ? feat - 1u : rank;
-      if (!cell_printed || feat >= A.P.max_features || (float)pr_before >= tot) continue;
-      const float u = A.pair_umis[slot], r = A.pair_reads[slot];
-      if (!(r >= (float)A.P.min_reads && u >= (float)A.P.min_umis)) continue;
-      // ucounts: UMIs, or the reads when the UMI count truncates to 0 (:685-695)
-      uint32_t val_u = 0, val_r = 0;
-      bool pu = false, prd = false;
-      if ((uint32_t)u >= 1u) {
-        pu = true;
-        val_u = (uint32_t)roundf(u);
-        tu += (uint32_t)u;
-      } else if ((uint32_t)r >= 1u) {
-        pu = true;
-        val_u = (uint32_t)roundf(r);
-        tu += (uint32_t)r;
-      }
-      if ((uint32_t)r >= 1u) {
-        prd = true;
-        val_r = (uint32_t)roundf(r);
-        tr += (uint32_t)r;
-      }
-      if (pu) A.out_u[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c + A.cell_offset, val_u};
-      if (prd) A.out_r[p0 + rank] = UmiEntry{A.P.sorted_by_cell ? feat : 0u, c + A.cell_offset, val_r};
+      emit_pair(slot, feat, rank);
     }
     __syncthreads();
     if (threadIdx.x == 0) s_base = base + all;
@@ -925,9 +942,21 @@ __global__ __launch_bounds__(kBlock) void k_umi_emit(EmitArgs A, UmiCall* __rest
     tu += __shfl_down(tu, d, 64);
     tr += __shfl_down(tr, d, 64);
   }
+  // one add per WORKGROUP, to one of 64 copies (40 000 wavefronts adding to two addresses were most of this kernel)
+  __shared__ unsigned long long s_tot[2][kBlock / kWave];
   if ((threadIdx.x & 63) == 0) {
-    if (tu) atomicAdd(&call->tot[0], tu);
-    if (tr) atomicAdd(&call->tot[1], tr);
+    s_tot[0][threadIdx.x >> 6] = tu;
+    s_tot[1][threadIdx.x >> 6] = tr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, b = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      a += s_tot[0][w];
+      b += s_tot[1][w];
+    }
+    if (a) atomicAdd(&call->tot_spread[0][blockIdx.x & 63], a);
+    if (b) atomicAdd(&call->tot_spread[1][blockIdx.x & 63], b);
   }
 }
 
