@@ -238,7 +238,7 @@ __device__ __forceinline__ unsigned long long pack_barcode(B s, uint32_t n, B li
 // 16-byte loads, and every thread then walks ITS record there (a thread-per-record walk over global
 // memory touches 64 different cache lines per instruction).  Spans larger than the buffer (long
 // records) are walked in global memory.
-constexpr int kParseStage = 16 * 1024;  // bytes per wavefront
+constexpr int kParseStage = 16 * 1024;  // most bytes per wavefront
 
 // one record: `base` is byte span0 of the stream (its LDS copy or the stream itself); every read stays inside
 // [base, lim); offsets written out are stream offsets
@@ -314,52 +314,70 @@ __device__ __forceinline__ uint8_t parse_record(B base, B lim, B r, uint64_t spa
   return st;
 }
 
-__global__ __launch_bounds__(kBlock) void k_umi_parse(const uint8_t* __restrict__ gbuf, uint64_t nbytes,
-                                                      const unsigned long long* __restrict__ offs, uint32_t n,
-                                                      UmiParams P, UmiRec* __restrict__ rec,
-                                                      uint8_t* __restrict__ stage, UmiCall* __restrict__ call) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kBlock / kWave][kParseStage + 32];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t i0 = blockIdx.x * kBlock + (uint32_t)wv * kWave;
+// One wavefront per tile of T consecutive records (T <= 64, one lane per record): T and the LDS area follow the mean
+// record size (host: umi_parse_tile) - 64 records of 124 bytes in 9 KiB, 48 of 275 in 16 KiB - so that the usual
+// tile is staged and many wavefronts share a CU; a tile that does not fit anyway is walked in global memory.
+__global__ __launch_bounds__(kWave) void k_umi_parse(const uint8_t* __restrict__ gbuf, uint64_t nbytes,
+                                                     const unsigned long long* __restrict__ offs, uint32_t n, uint32_t T,
+                                                     uint32_t cap, UmiParams P, UmiRec* __restrict__ rec,
+                                                     uint8_t* __restrict__ stage, UmiCall* __restrict__ call) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_parse[];
+  const int lane = (int)threadIdx.x;
+  const uint32_t i0 = blockIdx.x * T;
   if (i0 >= n) return;
-  const uint32_t i_last = i0 + kWave - 1 < n - 1 ? i0 + kWave - 1 : n - 1;
-  const uint64_t my_off = offs[i < n ? i : n - 1];
+  const uint32_t Tn = n - i0 < T ? n - i0 : T;
+  const bool valid = (uint32_t)lane < Tn;
+  const uint32_t i = i0 + (valid ? (uint32_t)lane : Tn - 1);
+  const uint32_t i_last = i0 + Tn - 1;
+  const uint64_t my_off = offs[i];
   const uint64_t span0 = __shfl(my_off, 0) & ~15ull;  // aligned down: 16-byte loads
   const uint64_t span1 = i_last + 1 < n ? offs[i_last + 1] : nbytes;
-  const bool staged = span1 - span0 <= (uint64_t)kParseStage;
+  const bool staged = span1 - span0 <= (uint64_t)cap;
   if (staged) {
-    uint8_t* dstb = s_stage[wv];
-    for (uint64_t o = (uint64_t)lane * 16; o < span1 - span0; o += 16 * kWave) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (span0 + o + 16 <= nbytes) v = *reinterpret_cast<const uint4*>(gbuf + span0 + o);
-      else
-        for (uint64_t b = 0; span0 + o + b < nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&v)[b] = gbuf[span0 + o + b];
-      *reinterpret_cast<uint4*>(dstb + o) = v;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t units = (uint32_t)((span1 - span0 + 15) >> 4);
+    const uint64_t safe_units = (nbytes - span0) >> 4;  // whole units inside the stream
+    for (uint32_t u0 = 0; u0 < units; u0 += 4 * kWave) {
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // four loads in flight per lane
+        uint32_t u = u0 + j * kWave + (uint32_t)lane;
+        u = u < units ? u : units - 1;
+        if ((uint64_t)u < safe_units) v[j] = *reinterpret_cast<const u32x4*>(gbuf + span0 + 16ull * u);
+        else {
+          u32x4 t = {0, 0, 0, 0};
+          for (uint64_t b = 0; span0 + 16ull * u + b < nbytes && b < 16; ++b) reinterpret_cast<uint8_t*>(&t)[b] = gbuf[span0 + 16ull * u + b];
+          v[j] = t;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t u = u0 + j * kWave + (uint32_t)lane;
+        if (u < units) *reinterpret_cast<u32x4*>(s_parse + 16u * u) = v[j];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  if (i >= n) return;
   UmiRec out;
   out.umi_i = out.cell_i = 0;
   out.tok_off = 0;
   out.tok_len = 0;
   out.incr = 1.0f;
-  uint8_t st;
-  if (staged) {
-    const LdsBytes lb = (LdsBytes)s_stage[wv];
-    st = parse_record(lb, lb + (uint32_t)(span1 - span0), lb + (uint32_t)(my_off - span0), span0, P, out);
-  } else {
-    const uint8_t* gb = gbuf + span0;
-    st = parse_record(gb, gbuf + nbytes, gbuf + my_off, span0, P, out);
+  uint8_t st = kStSkipped;
+  if (valid) {
+    if (staged) {
+      const LdsBytes lb = (LdsBytes)s_parse;
+      st = parse_record(lb, lb + (uint32_t)(span1 - span0), lb + (uint32_t)(my_off - span0), span0, P, out);
+    } else {
+      const uint8_t* gb = gbuf + span0;
+      st = parse_record(gb, gbuf + nbytes, gbuf + my_off, span0, P, out);
+    }
+    rec[i] = out;
+    stage[i] = st;
   }
-  rec[i] = out;
-  stage[i] = st;
-  const unsigned long long tags = __ballot(st >= kStNoUmi);
-  if ((threadIdx.x & 63) == 0 && tags)
-    atomicAdd(&call->spread[0][(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) & 63],
-              (unsigned long long)__builtin_popcountll(tags));
+  const unsigned long long tags = __ballot(valid && st >= kStNoUmi);
+  if (lane == 0 && tags) atomicAdd(&call->spread[0][blockIdx.x & 63], (unsigned long long)__builtin_popcountll(tags));
 }
 
 // ---- hash tables --------------------------------------------------------------------------------
