@@ -498,91 +498,119 @@ __global__ __launch_bounds__(kBlock) void k_umi_insert(const uint8_t* __restrict
                                                        const UmiRec* __restrict__ rec, uint8_t* __restrict__ stage,
                                                        KeyTable U, KeyTable C, NameTable F,
                                                        uint32_t* __restrict__ uslot, uint32_t* __restrict__ cslot,
-                                                       uint32_t* __restrict__ fslot, UmiCall* __restrict__ call) {
+                                                       uint32_t* __restrict__ fslot, UmiCall* __restrict__ call, int ablate) {
+  // ablate (measurement only, FQGPU_UMI_INSERT_ABL): 1 = no UMI table, 2 = no cell table, 4 = no feature table
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63);
   uint8_t st = i < n ? stage[i] : kStSkipped;
   uint32_t us = kNoIdx, cs = kNoIdx, fs = kNoIdx;
+  UmiRec r;
+  r.umi_i = r.cell_i = r.tok_off = 0;
+  r.tok_len = 0;
+  r.incr = 1.0f;
+  bool live = false, white = false, cell_ok = false, do_f = false;
+  uint64_t w[3] = {0, 0, 0};
   if (st == kStUmi) {
-    const UmiRec r = rec[i];
+    r = rec[i];
     // valid_barcode() looks the PACKED umi up among the whitelist's dense IDS (src/bam_umi_count.c:559-571,
     // 984): true iff 1 <= packed <= number of distinct whitelist entries
     if (P.have_known_umis && !(r.umi_i >= 1 && r.umi_i <= (unsigned long long)P.n_known_umis)) st = kStUmiDiscarded;
     else {
+      live = true;
       uint32_t at;
-      const bool white = P.have_known_umis && sorted_contains(P.known_umis_sorted, P.n_known_umis, r.umi_i, &at);
-      if (white) us = kWhiteBit | P.known_umis_order[at];
-      const bool cell_ok = !(P.have_known_cells && !sorted_contains(P.known_cells_sorted, P.n_known_cells, r.cell_i, nullptr));
-      const bool do_f = cell_ok && r.tok_len > 0 && r.tok_len + 1 < (uint32_t)kFeatIdMaxLen;
-      uint64_t w[3] = {0, 0, 0};
+      white = (ablate & 1) || (P.have_known_umis && sorted_contains(P.known_umis_sorted, P.n_known_umis, r.umi_i, &at));
+      if (white && !(ablate & 1)) us = kWhiteBit | P.known_umis_order[at];
+      cell_ok = !(P.have_known_cells && !sorted_contains(P.known_cells_sorted, P.n_known_cells, r.cell_i, nullptr));
+      do_f = cell_ok && r.tok_len > 0 && r.tok_len + 1 < (uint32_t)kFeatIdMaxLen && !(ablate & 4);
       if (do_f) name_words(buf, nbytes, r.tok_off, r.tok_len, w);
-      w[2] |= (uint64_t)r.tok_len << 56;  // (a name has at most 23 bytes)
-      const uint64_t hsh = umi_mix(umi_mix(umi_mix(0x9E3779B97F4A7C15ull ^ w[0]) ^ w[1]) ^ w[2]);
-      const unsigned long long tag = (hsh >> 32) << 32;
-      // Most records repeat keys that are in the tables already (a cell's run, an expressed gene, a UMI seen before)
-      // with an earlier first record: nothing to write.  That case is decided from the keys' HOME slots, read for all
-      // three tables at once - one round trip to memory instead of three dependent chains.
-      const uint64_t hu = umi_mix(r.umi_i) & U.mask, hc = umi_mix(r.cell_i) & C.mask, hf = hsh & F.mask;
-      unsigned long long ku = 0, kc = 0, vf = 0, q0 = 0, q1 = 0, q2 = 0;
-      uint32_t fu = 0, fc = 0, ff = 0;
-      if (!white) {
-        ku = U.keys[hu];
-        fu = U.first[hu];
-      }
-      if (cell_ok) {
-        kc = C.keys[hc];
-        fc = C.first[hc];
-      }
+    }
+  }
+  // ---- cells.  Consecutive records mostly share their cell (the default mode REQUIRES the file to be grouped by cell):
+  // hundreds of threads asking the table for one key at once are hundreds of atomics on one address.  Inside a
+  // wavefront only the first lane of every run of equal cells asks (with its record index, the smallest of the run),
+  // the others take its answer.
+  {
+    const bool want_c = live && cell_ok && !(ablate & 2);
+    const unsigned long long ckey = r.cell_i;
+    const bool prev_want = __shfl_up((int)want_c, 1, 64) != 0;
+    const unsigned long long prev_key = __shfl_up(ckey, 1, 64);
+    const bool leader = want_c && (lane == 0 || !prev_want || prev_key != ckey);
+    uint32_t cs_lead = kNoIdx;
+    if (leader) {
+      const uint64_t hc = umi_mix(ckey) & C.mask;
+      const unsigned long long kc = C.keys[hc];
+      const uint32_t fc = C.first[hc];
+      cs_lead = (kc == ckey && fc <= i) ? (uint32_t)hc : table_insert(C, ckey, i, call);
+    }
+    const unsigned long long lm = __ballot(leader);
+    const unsigned long long at_or_below = lm & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int src = at_or_below ? 63 - __builtin_clzll(at_or_below) : 0;
+    const uint32_t cs_run = __shfl(cs_lead, src, 64);
+    if (want_c) cs = cs_run;
+  }
+  if (live) {
+    w[2] |= (uint64_t)r.tok_len << 56;  // (a name has at most 23 bytes)
+    const uint64_t hsh = umi_mix(umi_mix(umi_mix(0x9E3779B97F4A7C15ull ^ w[0]) ^ w[1]) ^ w[2]);
+    const unsigned long long tag = (hsh >> 32) << 32;
+    // Most records repeat keys that are in the tables already (an expressed gene, a UMI seen before) with an earlier
+    // first record: nothing to write.  That case is decided from the keys' HOME slots, read for both tables at once -
+    // one round trip to memory instead of dependent chains.
+    const uint64_t hu = umi_mix(r.umi_i) & U.mask, hf = hsh & F.mask;
+    unsigned long long ku = 0, vf = 0, q0 = 0, q1 = 0, q2 = 0;
+    uint32_t fu = 0, ff = 0;
+    if (!white) {
+      ku = U.keys[hu];
+      fu = U.first[hu];
+    }
+    if (do_f) {
+      vf = F.slots[hf];
+      ff = F.first[hf];
+      q0 = F.words[3 * hf];
+      q1 = F.words[3 * hf + 1];
+      q2 = F.words[3 * hf + 2];
+    }
+    if (!white) us = (ku == r.umi_i && fu <= i) ? (uint32_t)hu : table_insert(U, r.umi_i, i, call);
+    if (!cell_ok) st = kStCellDiscarded;
+    else {
+      st = kStCounted;
       if (do_f) {
-        vf = F.slots[hf];
-        ff = F.first[hf];
-        q0 = F.words[3 * hf];
-        q1 = F.words[3 * hf + 1];
-        q2 = F.words[3 * hf + 2];
-      }
-      if (!white) us = (ku == r.umi_i && fu <= i) ? (uint32_t)hu : table_insert(U, r.umi_i, i, call);
-      if (!cell_ok) st = kStCellDiscarded;
-      else {
-        st = kStCounted;
-        cs = (kc == r.cell_i && fc <= i) ? (uint32_t)hc : table_insert(C, r.cell_i, i, call);
-        if (do_f) {
-          // F.words[] holds the claimant's name, written after its claim without any ordering: three words that all
-          // equal mine can only be the finished name (no word of a name reads ~0: the third carries the length, and
-          // names whose first 16 bytes hold eight 0xFF in a row take the slow path)
-          if ((vf >> 32) == (tag >> 32) && q0 == w[0] && q1 == w[1] && q2 == w[2] && w[0] != ~0ull && w[1] != ~0ull && ff <= i)
-            fs = (uint32_t)hf;
-          else {
-            uint64_t h = hf;
-            for (uint64_t probes = 0; probes <= F.mask; ++probes) {
-              unsigned long long v = F.slots[h];
+        // F.words[] holds the claimant's name, written after its claim without any ordering: three words that all
+        // equal mine can only be the finished name (no word of a name reads ~0: the third carries the length, and
+        // names whose first 16 bytes hold eight 0xFF in a row take the slow path)
+        if ((vf >> 32) == (tag >> 32) && q0 == w[0] && q1 == w[1] && q2 == w[2] && w[0] != ~0ull && w[1] != ~0ull && ff <= i)
+          fs = (uint32_t)hf;
+        else {
+          uint64_t h = hf;
+          for (uint64_t probes = 0; probes <= F.mask; ++probes) {
+            unsigned long long v = F.slots[h];
+            if (v == kKeyEmpty) {
+              v = atomicCAS(&F.slots[h], kKeyEmpty, tag | i);
               if (v == kKeyEmpty) {
-                v = atomicCAS(&F.slots[h], kKeyEmpty, tag | i);
-                if (v == kKeyEmpty) {
-                  v = tag | i;
-                  F.words[3 * h] = w[0];
-                  F.words[3 * h + 1] = w[1];
-                  F.words[3 * h + 2] = w[2];
-                }
+                v = tag | i;
+                F.words[3 * h] = w[0];
+                F.words[3 * h + 1] = w[1];
+                F.words[3 * h + 2] = w[2];
               }
-              if ((v >> 32) == (tag >> 32)) {
-                bool same = (uint32_t)v == i;
-                if (!same) {
-                  const UmiRec o = rec[(uint32_t)v];
-                  if (o.tok_len == r.tok_len) {
-                    uint64_t q[3];
-                    name_words(buf, nbytes, o.tok_off, o.tok_len, q);
-                    same = q[0] == w[0] && q[1] == w[1] && (q[2] | ((uint64_t)o.tok_len << 56)) == w[2];
-                  }
-                }
-                if (same) {
-                  if (F.first[h] > i) atomicMin(&F.first[h], i);
-                  fs = (uint32_t)h;
-                  break;
-                }
-              }
-              h = (h + 1) & F.mask;
             }
-            if (fs == kNoIdx) atomicOr(&call->table_full, 1u);
+            if ((v >> 32) == (tag >> 32)) {
+              bool same = (uint32_t)v == i;
+              if (!same) {
+                const UmiRec o = rec[(uint32_t)v];
+                if (o.tok_len == r.tok_len) {
+                  uint64_t q[3];
+                  name_words(buf, nbytes, o.tok_off, o.tok_len, q);
+                  same = q[0] == w[0] && q[1] == w[1] && (q[2] | ((uint64_t)o.tok_len << 56)) == w[2];
+                }
+              }
+              if (same) {
+                if (F.first[h] > i) atomicMin(&F.first[h], i);
+                fs = (uint32_t)h;
+                break;
+              }
+            }
+            h = (h + 1) & F.mask;
           }
+          if (fs == kNoIdx) atomicOr(&call->table_full, 1u);
         }
       }
     }
