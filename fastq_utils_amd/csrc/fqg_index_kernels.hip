@@ -304,9 +304,23 @@ __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView 
     inserted += __shfl_down(inserted, d, 64);
     name_bytes += __shfl_down(name_bytes, d, 64);
   }
-  if ((threadIdx.x & 63) == 0 && inserted) {
-    atomicAdd(&call->inserted, inserted);
-    atomicAdd(&call->name_bytes, name_bytes);
+  // one add per workgroup (the wavefronts of a grid finish together: tens of thousands of adds to two addresses)
+  __shared__ unsigned long long s_ins[kBlock / kWave], s_nb[kBlock / kWave];
+  if ((threadIdx.x & 63) == 0) {
+    s_ins[threadIdx.x >> 6] = inserted;
+    s_nb[threadIdx.x >> 6] = name_bytes;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, b = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      a += s_ins[w];
+      b += s_nb[w];
+    }
+    if (a) {
+      atomicAdd(&call->inserted, a);
+      atomicAdd(&call->name_bytes, b);
+    }
   }
 }
 
