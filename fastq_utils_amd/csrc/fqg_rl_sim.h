@@ -157,6 +157,7 @@ struct ChainView {
 struct Stats {
   uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
   unsigned long long clk_replay, clk_lookback, clk_store;  // device clock ticks spent per phase (0 on the CPU)
+  unsigned long long clk_max_wait;                         // most look-back ticks (incl. waiting for an earlier replay) of one run
   unsigned long long clk_max;                              // the slowest run: loop ticks << 32 | records used << 16 | inserts
   unsigned long long clk_build, clk_loop;                  // inside clk_replay: building the array up to the first overwrite / the inserts after it
 };
@@ -168,6 +169,7 @@ struct Stats {
 // memoised: an entry (slot, depth, size) stays valid until something is written inside [slot, slot + size), and
 // moves along when an insert shifts the nodes behind its place.
 constexpr uint32_t kMemo = 64;
+constexpr uint32_t kMemoMin = 1024;  // subtrees smaller than this are walked again (keeping the memo valid costs more)
 
 template <class W>
 struct WorkT {
@@ -378,7 +380,9 @@ struct Sim {
     W::sync();
   }
 
-  FQG_HD bool known(uint32_t idx) const { return (wk->known[idx >> 5] >> (idx & 31u)) & 1u; }
+  // (what the tree walk reads is the same in every lane: telling the compiler - W::uni = readfirstlane - moves the
+  // walk's arithmetic and its branches from the vector unit, masks and all, to the scalar one)
+  FQG_HD bool known(uint32_t idx) const { return (W::uni(wk->known[idx >> 5]) >> (idx & 31u)) & 1u; }
   FQG_HD void mark(uint32_t idx) { wk->known[idx >> 5] |= 1u << (idx & 31u); }
 
   FQG_HD void begin() {
@@ -394,17 +398,22 @@ struct Sim {
     pending = 0;
   }
   FQG_HD uint16_t rd(uint32_t idx) {
-    if (!unknown_live && idx < size && idx < wk->cap) return wk->node[idx];  // the usual case: a live, written slot
+    if (!unknown_live && idx < size && idx < wk->cap) return (uint16_t)W::uni(wk->node[idx]);  // the usual case: a live, written slot
     if (idx >= wk->cap) { st->overflow = 1; return 0; }
     if (!known(idx)) {
       wk->node[idx] = hist->get(idx);
       mark(idx);
       if (idx < size) --unknown_live;
     }
-    return wk->node[idx];
+    return (uint16_t)W::uni(wk->node[idx]);
   }
   FQG_HD void wr(uint32_t idx, uint16_t v) {
     if (idx >= wk->cap) { st->overflow = 1; return; }
+    if (!unknown_live && idx < size) {  // a live slot while every live slot is known: no look at the bitmap
+      wk->node[idx] = v;
+      memo_touch(idx);
+      return;
+    }
     if (!known(idx)) {
       mark(idx);
       if (idx < size) --unknown_live;
@@ -431,7 +440,7 @@ struct Sim {
     for (;;) {
       if (s_q[sp] > 4) {
         const uint32_t r = s_c[sp];
-        memo_put(s_idx[sp], d + (uint32_t)sp, r);
+        if (r >= kMemoMin) memo_put(s_idx[sp], d + (uint32_t)sp, r);
         if (!sp) return r;
         --sp;
         s_c[sp] += r;
@@ -533,8 +542,17 @@ struct Sim {
             hi = lo - 1u;
             remaining -= n;
           }
-          for (uint32_t i = size; i < size + m; ++i)
-            if (!known(i)) mark(i);  // (not live yet: no unknown_live bookkeeping)
+          // slots size .. size + m - 1 now hold moved nodes (not live yet: no unknown_live bookkeeping): at most two
+          // words of the bitmap
+          {
+            const uint32_t lo = size, hi = size + m - 1u;
+            for (uint32_t wq = lo >> 5; wq <= (hi >> 5); ++wq) {
+              uint32_t mask = ~0u;
+              if (wq == (lo >> 5)) mask &= ~0u << (lo & 31u);
+              if (wq == (hi >> 5) && (hi & 31u) != 31u) mask &= (1u << ((hi & 31u) + 1u)) - 1u;
+              wk->known[wq] |= mask;
+            }
+          }
         }
       } else if (behind == 0) {
         st->overwrites += m;
@@ -639,6 +657,7 @@ FQG_HD void replay_run(const ChainView& cv, WorkT<W>& wk, Stats& st, uint8_t* ne
   sim.st = &st;
   const uint32_t run = cv.run, fi = cv.run_flag[run];
   const unsigned long long t0 = W::clock();
+  const unsigned long long lb0 = st.clk_lookback;
   hist.reset(&cv, &wk, &st);
   sim.begin();
   const uint32_t s0 = cv.run_start[run], len = cv.run_len[run];
@@ -713,6 +732,7 @@ FQG_HD void replay_run(const ChainView& cv, WorkT<W>& wk, Stats& st, uint8_t* ne
   const unsigned long long t2 = W::clock();
   st.clk_replay += t1 - t0;
   st.clk_store += t2 - t1;
+  if (st.clk_lookback - lb0 > st.clk_max_wait) st.clk_max_wait = st.clk_lookback - lb0;
   st.clk_build += t_built - t0;
   st.clk_loop += t1 - t_built;
   {

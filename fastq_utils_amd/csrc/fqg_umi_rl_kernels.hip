@@ -29,6 +29,8 @@ struct GpuWaveBase {
     const unsigned long long m = __ballot(b);
     return m ? (uint32_t)__builtin_ctzll(m) : 0xFFFFFFFFu;
   }
+  // v, which is the same in every lane, as a scalar
+  static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
   // lane `src`'s value of v (src is the same in every lane)
   static __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src));
@@ -62,7 +64,7 @@ struct RlCall {
   uint32_t undefined, overwrites, wild_writes, overflow, changed, lookback_runs;
   uint32_t n_chain, pad_;   // sorted mode by cell: runs of the features that have a flagged run
   unsigned long long clk_replay, clk_lookback, clk_store;  // wall_clock64 ticks (100 MHz) summed over the workers
-  unsigned long long clk_build, clk_loop, clk_max;
+  unsigned long long clk_build, clk_loop, clk_max, clk_max_wait;
 };
 
 struct RlRuns {      // per run (= per (cell, feature) pair), in order of the sorted pair slots
@@ -238,6 +240,7 @@ __device__ __forceinline__ void rl_replay_body(const RlReplayArgs& A, P8 g, type
     atomicAdd(&A.call->clk_build, st.clk_build);
     atomicAdd(&A.call->clk_loop, st.clk_loop);
     atomicMax(&A.call->clk_max, st.clk_max);
+    atomicMax(&A.call->clk_max_wait, st.clk_max_wait);
   }
 }
 

@@ -20,6 +20,7 @@ struct CpuWave {
   static uint32_t rank(bool) { return 0; }
   static uint32_t count(bool b) { return b ? 1u : 0u; }
   static uint32_t bcast(uint32_t v, uint32_t) { return v; }
+  static uint32_t uni(uint32_t v) { return v; }
   static uint32_t find_first(bool b) { return b ? 0u : 0xFFFFFFFFu; }
   static uint32_t wait_nonzero(const uint32_t* p) { return *p; }  // (runs are replayed in chain order here)
   static void publish(uint32_t* p, uint32_t v) { *p = v; }
