@@ -29,8 +29,21 @@ constexpr int kStageCap = 256;  // entries per chunk; denser images take the two
 // (1 = '@', 2 = '+', 0 = other); bit 14: the byte after that one is a '\n'
 constexpr uint32_t kClsAt = 1u, kClsPlus = 2u;
 // chunk info word: bits 0..1 speculated line type of the chunk's first byte; bit 2: no speculation
-// (the chunk must be re-checked once its true rank is known); bit 3: qmin/qmax valid (bits 8..15, 16..23)
-constexpr uint32_t kInfoUnknown = 4u, kInfoRange = 8u;
+// (the chunk must be re-checked once its true rank is known); bit 3: qmin/qmax valid (bits 8..15, 16..23);
+// bit 4: the chunk holds no newline - it lies inside ONE line, whose type the rank will tell - and was checked for
+// both kinds of line: bit 5 = it holds a byte that is no base (matters if the line is a sequence), qmin/qmax = the
+// range of ALL its bytes when one is outside the boot range (matters if the line is a quality line)
+constexpr uint32_t kInfoUnknown = 4u, kInfoRange = 8u, kInfoOneLine = 16u, kInfoNotBases = 32u;
+// does the chunk with this info word and this true rank of its first byte need its checks repeated?  (the range of a
+// quality line's bytes is merged by the caller when this says no)
+__host__ __device__ inline bool chunk_info_redo(uint32_t info, uint32_t rank0) {
+  if (info & kInfoOneLine) return (rank0 & 3u) == 1u && (info & kInfoNotBases);
+  return (info & kInfoUnknown) || (info & 3u) != (rank0 & 3u);
+}
+__host__ __device__ inline bool chunk_info_range(uint32_t info, uint32_t rank0) {
+  if (!(info & kInfoRange)) return false;
+  return (info & kInfoOneLine) ? (rank0 & 3u) == 3u : true;
+}
 
 // Scalars of one fqg_validate() call.  Lives in device memory; the host copies it back once.
 struct CallState {

@@ -391,6 +391,47 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         }
         if (qmin <= qmax) info |= kInfoRange | ((qmin & 0xFFu) << 8) | ((qmax & 0xFFu) << 16);
       }
+    } else if (total == 0) {
+      // A chunk without any newline lies inside ONE line (reads of kilobases: most chunks).  There is no type to
+      // speculate on, but both kinds of check can be made on all of its bytes, and the rank says later which one
+      // counts (chunk_info_redo / chunk_info_range).  A branch of its own: the path above is the 150 bp path and
+      // pays for every instruction.
+      info = kInfoOneLine;
+      uint32_t lo = boot_lo, hi = boot_hi;
+      if (lo > hi || lo > 127u) {
+        lo = 127u;
+        hi = 0u;
+      }
+      const uint32_t lob = lo * 0x01010101u, hihb = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
+      uint32_t not_base = 0, outside = 0;
+#pragma unroll
+      for (int k = 0; k < kHalves; ++k) {
+        const uint32_t w[8] = {v[k].a.x, v[k].a.y, v[k].a.z, v[k].a.w, v[k].b.x, v[k].b.y, v[k].b.z, v[k].b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          not_base |= not_acgtn7(w[j]);
+          outside |= ~in_range7(w[j], lob, hihb) & kH;
+        }
+      }
+      if (__ballot(not_base != 0)) info |= kInfoNotBases;  // (which byte: the repeated check finds it, if the line is a sequence)
+      if (__ballot(outside != 0)) {  // rare: the exact range of the chunk's bytes
+        QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < kHalves; ++k) {
+          qrange_accum(v[k].a, 0xFFFFu, q);
+          qrange_accum(v[k].b, 0xFFFFu, q);
+        }
+        uint32_t qmin = pk_min_u16(q.mn_e, q.mn_o), qmax = pk_max_u16(q.mx_e, q.mx_o);
+        qmin = (qmin & 0xFFFFu) < (qmin >> 16) ? (qmin & 0xFFFFu) : (qmin >> 16);
+        qmax = (qmax & 0xFFFFu) > (qmax >> 16) ? (qmax & 0xFFFFu) : (qmax >> 16);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          const uint32_t x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
+          qmin = x < qmin ? x : qmin;
+          qmax = y > qmax ? y : qmax;
+        }
+        if (qmin <= qmax) info |= kInfoRange | ((qmin & 0xFFu) << 8) | ((qmax & 0xFFu) << 16);
+      }
     }
   }
 
@@ -463,10 +504,12 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass2(const uint8_t* __restri
     if (rank0 < limit) {
       // (a chunk that reaches beyond the last complete record is repeated too: its quality range may
       // include bytes of an incomplete record)
-      if ((info & kInfoUnknown) || (info & 3u) != ((uint32_t)rank0 & 3u) || rank0 + cnt >= limit) again = true;
-      else if (info & kInfoRange) {
-        atomicMin(&cs->qmin_byte, (info >> 8) & 0xFFu);
-        atomicMax(&cs->qmax_byte, (info >> 16) & 0xFFu);
+      if (chunk_info_redo(info, (uint32_t)rank0) || rank0 + cnt >= limit) again = true;
+      else if (chunk_info_range(info, (uint32_t)rank0)) {
+        // (look first: the hull settles after a few chunks, and every later one would still be an atomic on one address)
+        const uint32_t qlo = (info >> 8) & 0xFFu, qhi = (info >> 16) & 0xFFu;
+        if (qlo < __atomic_load_n(&cs->qmin_byte, __ATOMIC_RELAXED)) atomicMin(&cs->qmin_byte, qlo);
+        if (qhi > __atomic_load_n(&cs->qmax_byte, __ATOMIC_RELAXED)) atomicMax(&cs->qmax_byte, qhi);
       }
     }
     if (mine == n_chunks - 1 && n > 0 && !cs->last_byte_is_nl && cs->n_newlines < line_cap)
@@ -515,22 +558,33 @@ __global__ __launch_bounds__(kBlock) void k_stream_chunks(ChunkRanks cr, const u
     // only chunks that hold bytes of complete records need their byte checks to stand (a chunk that reaches
     // beyond the last complete record is repeated too: its quality range may include bytes of an incomplete one)
     if (rank0 < limit) {
-      if ((info & kInfoUnknown) || (info & 3u) != ((uint32_t)rank0 & 3u) || rank0 + cnt >= limit) again = true;
-      else if (info & kInfoRange) {
-        atomicMin(&cs->qmin_byte, (info >> 8) & 0xFFu);
-        atomicMax(&cs->qmax_byte, (info >> 16) & 0xFFu);
+      if (chunk_info_redo(info, (uint32_t)rank0) || rank0 + cnt >= limit) again = true;
+      else if (chunk_info_range(info, (uint32_t)rank0)) {
+        // (look first: the hull settles after a few chunks, and every later one would still be an atomic on one address)
+        const uint32_t qlo = (info >> 8) & 0xFFu, qhi = (info >> 16) & 0xFFu;
+        if (qlo < __atomic_load_n(&cs->qmin_byte, __ATOMIC_RELAXED)) atomicMin(&cs->qmin_byte, qlo);
+        if (qhi > __atomic_load_n(&cs->qmax_byte, __ATOMIC_RELAXED)) atomicMax(&cs->qmax_byte, qhi);
       }
     }
   }
+  // the redo list: one reservation per WORKGROUP (reads of kilobases send a quarter of their chunks here - a
+  // reservation per wavefront was 33 000 atomics with a return value on one address, most of this kernel)
+  __shared__ uint32_t s_cnt[kBlock / kWave], s_base;
   const unsigned long long am = __ballot(again);
-  if (am) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cs->redo_count, (uint32_t)__builtin_popcountll(am));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (again) {
-      const uint32_t at = base + (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
-      if (at < cr.n_chunks) redo[at] = c;
-    }
+  const int wv = (int)(threadIdx.x >> 6);
+  if (lane == 0) s_cnt[wv] = (uint32_t)__builtin_popcountll(am);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) tot += s_cnt[w];
+    s_base = tot ? atomicAdd(&cs->redo_count, tot) : 0u;
+  }
+  __syncthreads();
+  if (again) {
+    uint32_t at = s_base + (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; ++w) at += s_cnt[w];
+    if (at < cr.n_chunks) redo[at] = c;
   }
 }
 
