@@ -863,16 +863,32 @@ __global__ __launch_bounds__(kBlock) void k_suspect_list(const uint32_t* __restr
                                                          AccState* __restrict__ acc, const CallState* __restrict__ cs) {
   const uint64_t n_words = (n_records + 31) / 32;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < n_words; w += stride) {
-    uint32_t m = bits[w];
+  // one reservation per wavefront and step (a file whose every read is a suspect - lower-case bases, say - would
+  // otherwise add to one address a hundred million times)
+  const int lane = lane_id();
+  for (uint64_t w0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); w0 < n_words; w0 += stride) {
+    const uint64_t w = w0 + (uint64_t)lane;
+    uint32_t m = w < n_words ? bits[w] : 0u;
+    if (w * 32 + 32 > n_records) m &= w * 32 < n_records ? (uint32_t)((1ull << (n_records - w * 32)) - 1ull) : 0u;
+    const uint32_t cnt = (uint32_t)__popc(m);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (!total) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(list_count, (unsigned long long)total);
+    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    unsigned long long at = base + (incl - cnt);
     while (m) {
       const uint32_t j = (uint32_t)__builtin_ctz(m);
       m &= m - 1;
-      const uint64_t r = w * 32 + j;
-      if (r < n_records) {
-        const unsigned long long at = atomicAdd(list_count, 1ull);
-        if (at < list_cap) list[at] = r;
-      }
+      if (at < list_cap) list[at] = w * 32 + j;
+      ++at;
     }
   }
   if (acc && blockIdx.x == 0 && threadIdx.x == 0 && cs->qmin_byte <= cs->qmax_byte) {
