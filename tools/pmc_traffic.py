@@ -27,7 +27,7 @@ def main():
     fetch, write, image_bytes = sys.argv[1], sys.argv[2], float(sys.argv[3])
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     fc = per_kernel(sys.argv[4], "FETCH_SIZE") if len(sys.argv) > 4 else f
-    calib = image_bytes / (fc["k_count_nl"] * 1024.0)
+    calib = image_bytes / (fc["k_count_nl"] * 1024.0) if "k_count_nl" in fc else None  # (None: no calibration kernel in these runs)
     import hashlib
     import os
     h = hashlib.sha256()

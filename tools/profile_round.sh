@@ -4,6 +4,7 @@
 #   traffic  FETCH_SIZE / WRITE_SIZE in separate passes on the headline workload (+ a --two-pass run: k_count_nl, the
 #            kernel with a known byte count the read correction is checked on) -> <tag>_traffic_100M_150bp.json
 #   umi      FETCH_SIZE / WRITE_SIZE / SQ counters of the bam_umi_count kernels on configs[3]
+#   index    FETCH_SIZE / WRITE_SIZE of the default-mode extra (k_index_insert) -> traffic_index_100M.json
 # Counter passes never carry another trace domain than --kernel-trace.  Summaries land in gpurun_out/<tag>/; copy what
 # is to be judged into profiles/.
 set -u
@@ -36,6 +37,16 @@ for w in $WHAT; do
     python3 $R/tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv') $(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv') \
         34900000000 $(find $O/pmc_calib -name '*counter_collection.csv') > $O/traffic_100M_150bp.json
     find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_calib -name '*kernel_trace.csv' -delete
+    ;;
+  index)
+    # HBM bytes of the name kernels (default mode: validate + k_index_insert over 100 M unique names)
+    ONLY_INDEX="--steps 2 --no-cpu-baseline --no-e2e --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra"
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/idx_pmc_$c -o pmc -- python3 $R/bench.py $ONLY_INDEX > $O/idx_pmc_$c.json 2> $O/idx_pmc_$c.err
+      find $O/idx_pmc_$c -name '*kernel_trace.csv' -delete
+    done
+    python3 $R/tools/pmc_traffic.py $(find $O/idx_pmc_FETCH_SIZE -name '*counter_collection.csv') $(find $O/idx_pmc_WRITE_SIZE -name '*counter_collection.csv') \
+        34900000000 > $O/traffic_index_100M.json 2>$O/traffic_index.err || true
     ;;
   umistats)
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/umi_stats -o stats -- python3 $R/bench.py $ONLY_UMI > $O/umi_under_rocprof.json 2> $O/umi_under_rocprof.err
