@@ -732,20 +732,34 @@ __global__ __launch_bounds__(kBlock) void k_umi_new(uint32_t n, const uint32_t* 
                                                     uint32_t* __restrict__ cell_reads, uint32_t* __restrict__ cell_umis,
                                                     UmiCall* __restrict__ call) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t ts = tslot[i];
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t ts = i < n ? tslot[i] : kNoIdx;
   uint8_t nw = 0;
+  uint32_t cid = 0;
   if (ts != kNoIdx) {
     nw = T.s[ts].first == i;
-    const uint32_t cid = ids.cell[i];
-    atomicAdd(&cell_reads[cid], 1u);
-    if (nw) {
-      atomicAdd(&Pt.umis[pslot[i]], 1u);
-      atomicAdd(&cell_umis[cid], 1u);
+    cid = ids.cell[i];
+    if (nw) atomicAdd(&Pt.umis[pslot[i]], 1u);
+  }
+  if (i < n) is_new[i] = nw;
+  const unsigned long long cnt = __ballot(ts != kNoIdx), nws = __ballot(nw != 0);
+  // the cell counters: neighbouring records mostly share their cell (a file grouped by cell: all 64 lanes one address),
+  // so the first lane of every run of equal cells adds the run's counts
+  {
+    const uint32_t key = ts != kNoIdx ? cid : 0u;  // (cell ids start at 1: 0 = not counted)
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool leader = key != 0u && (lane == 0 || prev != key);
+    const unsigned long long lm = __ballot(leader), zm = __ballot(key == 0u);
+    if (leader) {
+      // my run ends in front of the next leader or the next lane that is not counted
+      const unsigned long long stop = (lm | zm) & (lane == 63 ? 0ull : (~0ull << (lane + 1)));
+      const int end = stop ? __builtin_ctzll(stop) : 64;
+      const unsigned long long run = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & (~0ull << lane);
+      atomicAdd(&cell_reads[cid], (uint32_t)__builtin_popcountll(cnt & run));
+      const uint32_t nn = (uint32_t)__builtin_popcountll(nws & run);
+      if (nn) atomicAdd(&cell_umis[cid], nn);
     }
   }
-  is_new[i] = nw;
-  const unsigned long long cnt = __ballot(ts != kNoIdx), nws = __ballot(nw != 0);
   if ((threadIdx.x & 63) == 0) {
     const uint32_t which = (blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) & 63;
     if (cnt) atomicAdd(&call->spread[1][which], (unsigned long long)__builtin_popcountll(cnt));
