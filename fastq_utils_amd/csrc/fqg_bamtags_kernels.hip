@@ -252,7 +252,45 @@ __global__ __launch_bounds__(kWave) void k_bt_tile(BtTiles A) {
         bt_copy(dst, src, in_len);
         bt_st4(dst, out_len - 4u);  // block_size
         BtLds w = dst + in_len;
-        bt_tags(A.P, r, tid, [&](uint32_t o) { return (uint8_t)src[o]; }, [&](uint8_t b) { *w++ = b; });
+        // the tags, values 8 bytes per LDS access (bt_tags, byte by byte, is the form for the slow path)
+        if (r.ok) {
+          auto head = [&](char a, char b) {
+            w[0] = (uint8_t)a;
+            w[1] = (uint8_t)b;
+            w[2] = (uint8_t)'Z';
+            w += 3;
+          };
+          auto from_record = [&](char a, char b, uint32_t off, uint32_t len) {
+            head(a, b);
+            bt_copy(w, src + off, len);
+            w[len] = 0;
+            w += len + 1u;
+          };
+          auto from_names = [&](char a, char b, uint32_t off, uint32_t len) {  // (the table has 8 readable bytes behind it)
+            head(a, b);
+            const uint8_t* g = A.P.names + off;
+            uint32_t k = 0;
+            for (; k + 8 <= len; k += 8) {
+              uint64_t v;
+              __builtin_memcpy(&v, g + k, 8);
+              bt_st8(w + k, v);
+            }
+            if (k < len) {
+              uint64_t v;
+              __builtin_memcpy(&v, g + k, 8);
+              for (; k < len; ++k, v >>= 8) w[k] = (uint8_t)v;
+            }
+            w[len] = 0;
+            w += len + 1u;
+          };
+          if (r.len[0]) from_record(A.P.tenx ? 'U' : 'R', A.P.tenx ? 'B' : 'X', r.off[0], r.len[0]);  // GET_UMI_TAG
+          if (r.len[1]) from_record('C', 'R', r.off[1], r.len[1]);
+          if (r.len[2]) from_record('B', 'C', r.off[2], r.len[2]);
+          if (A.P.tx_tag && tid >= 0 && (uint32_t)tid < A.P.n_targets) {
+            from_names('t', 'x', A.P.tx_off[tid], A.P.tx_len[tid]);
+            if (A.P.gx_len[tid] != kBtNone) from_names('G', 'X', A.P.gx_off[tid], A.P.gx_len[tid]);
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
