@@ -153,8 +153,8 @@ __device__ __forceinline__ void umi_cell_body(const CellArgs& A, KP keys, uint32
     atomicAdd(&A.call->spread[1][blockIdx.x & 63], (unsigned long long)nc);
     atomicAdd(&A.call->spread[2][blockIdx.x & 63], (unsigned long long)n_trip);
   }
-  // per record: is_new; per triple start: a member; per pair start: key, first record, where its members start, and
-  // (as a negative number to be completed by the NEXT pair start) the prefix counts that give reads / UMIs
+  // per record: is_new; per triple start: a member; per pair start: key, first record, where its members start and
+  // its position in the sorted order (pair_pos) - reads / UMIs follow below as differences to the next pair
   for (uint32_t j = a; j < b; ++j) {
     const unsigned long long k1 = keys[j], k0 = j ? keys[j - 1] : kCellPad;
     const bool ts = (k1 >> kCellIdxBits) != (k0 >> kCellIdxBits);

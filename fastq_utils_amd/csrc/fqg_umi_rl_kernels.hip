@@ -7,10 +7,12 @@
 //
 //   k_rl_starts / k_rl_detect   records sorted by (pair slot, record index) [rocPRIM]; one thread per run
 //                    feeds the run's new UMIs, in arrival order, through rl_detect_step (4 bits of state)
-//   k_rl_chain_keys / k_rl_heads   sorted mode: the runs of one gene in cell order form a chain (the gene's
-//                    tree lives for the whole file); chains that hold a flagged run are listed
-//   k_rl_replay      one wavefront per listed chain: exact replay of its flagged runs on the node array
-//                    (LDS), earlier cells' arrays rebuilt on demand; patches is_new[] and the counters
+//   k_rl_chain_keys / k_rl_positions / k_rl_item_keys   the runs of one gene in cell order form a chain (the gene's
+//                    tree lives for the whole file); flagged runs are ordered by their place in their chain, so that
+//                    a run a replay may have to wait for always holds an earlier ticket
+//   k_rl_replay      one wavefront per flagged run (tickets in that order): exact replay on the node array (LDS),
+//                    earlier cells' arrays rebuilt on demand or taken from the arena where an earlier replay left
+//                    them; patches is_new[] and the counters
 #include "fqg_rl_sim.h"
 
 namespace fqg {
