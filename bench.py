@@ -530,6 +530,24 @@ def bam_tags_extra(ctx, torch, dev, n):
             p = subprocess.run(["bam_add_tags", "--inbam", "in.bam", "--outbam", "out.bam", "--tx"], executable=ref, cwd=tmp,
                                capture_output=True)
             secs = time.perf_counter() - t2
+            # the drop-in program on the same file: what it writes must inflate to what the reference writes
+            mine = os.path.join(REPO, "bin", "bam_add_tags")
+            if os.path.exists(mine) and p.returncode == 0:
+                import gzip
+                import hashlib
+                t3 = time.perf_counter()
+                q = subprocess.run(["bam_add_tags", "--inbam", "in.bam", "--outbam", "mine.bam", "--tx"], executable=mine, cwd=tmp,
+                                   capture_output=True)
+                secs_mine = time.perf_counter() - t3
+                same = False
+                if q.returncode == 0:
+                    h = [hashlib.sha256(gzip.decompress(open(os.path.join(tmp, f), "rb").read())).hexdigest()
+                         for f in ("out.bam", "mine.bam")]
+                    same = h[0] == h[1] and q.stderr == p.stderr
+                out["program_vs_reference_program"] = {
+                    "alignments": ms, "reference_s": secs, "bin_bam_add_tags_s": secs_mine,
+                    "includes": "process start, HIP initialisation, BGZF inflate and deflate (all cores here, one thread there)",
+                    "inflated_output_and_stderr_identical": same}
         out["cpu_baseline"] = {"value": ms / secs / 1e6, "unit": "Malignments/s", "cores": 1, "kind": "reference",
                                "sample": f"first {ms} alignments as a BGZF file; reference bam_add_tags --tx (single-threaded, BGZF "
                                          "inflate and deflate included)", "seconds": secs, "ok": p.returncode == 0}
