@@ -53,6 +53,8 @@ def parse():
                     help="skip the extra: bam_umi_count on BASELINE.json configs[3] (10k cells x 20k genes x 5M triples)")
     ap.add_argument("--umi-triples", type=int, default=5_000_000)
     ap.add_argument("--no-tags-extra", action="store_true", help="skip the bam_add_tags extra")
+    ap.add_argument("--no-filterpair-extra", action="store_true", help="skip the fastq_filterpair extra")
+    ap.add_argument("--filterpair-records", type=int, default=40_000_000, help="records per file of that extra")
     ap.add_argument("--tags-alignments", type=int, default=6_500_000)
     ap.add_argument("--no-shapes-extra", action="store_true",
                     help="skip the validate pass on mixed-length short reads and on ONT-like long reads")
@@ -464,6 +466,79 @@ def negative_controls(exe, path, arr, n, R):
         d["records"] = [j, k]
         res["duplicate_name"] = d
     return res
+
+
+def filterpair_extra(ctx, fq, torch, dev, n, read_len):
+    """fastq_filterpair's pairing + partition (src/fastq_filterpair.c:38-228) through the bulk calls the
+    drop-in program makes: file 1's names into the index, file 2's records probe and take them
+    (fqg_index_probe_delete), what is left of file 1 (fqg_index_alive), and the ordered gather of the three outputs
+    (fqg_records_gather).  Two synthetic files of `n` records, 90 % of them mates of each other (file 2 starts with the
+    reads file 1 lacks, file 1 ends with the reads file 2 lacks), HBM-resident; the same calls on files of 3 000
+    records are compared with the oracle byte for byte."""
+    import numpy as np
+
+    A = fq.abi
+    R = A.synth_record_bytes(read_len)
+    shift = n // 10
+
+    def run(m, sh, want_text):
+        img = [torch.empty(m * R + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+        ctx.synth_fastq(img[0].data_ptr(), m, read_len, sh, 4242, 1)  # file 1: reads sh .. m + sh - 1
+        ctx.synth_fastq(img[1].data_ptr(), m, read_len, 0, 4242, 2)   # file 2: reads 0 .. m - 1
+        torch.cuda.synchronize()
+        st = [A.probe_first_record(bytes(img[k][:4096].cpu().numpy()), True) for k in range(2)]
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        v1 = ctx.validate(img[0].data_ptr(), None, st[0], final=True, flags=A.VALIDATE_NO_STATS, nbytes=m * R)
+        idx = ctx.name_index(m)
+        ir = idx.insert_unique(st[0])
+        v2 = ctx.validate(img[1].data_ptr(), None, st[1], final=True, flags=A.VALIDATE_NO_STATS, nbytes=m * R)
+        f2 = ctx.retain_frame()
+        ctx.frame_make_current(f2)
+        pr, match = idx.probe_delete_np(st[1], m)
+        alive = idx.alive_np(m)
+        found = match < np.uint64(0xFFFFFFFFFFFFFFFE)
+        # file 1's leftovers are read on from behind the LAST record that was copied (src/fastq_filterpair.c:196-216)
+        k_found = np.nonzero(found)[0]
+        next1 = int(match[k_found[-1]]) + 1 if k_found.size else 0
+        left = np.nonzero(alive)[0]
+        lists = [(idx.frame(0), match[found]), (f2, k_found), (f2, np.nonzero(~found)[0]), (idx.frame(0), left[left >= next1])]
+        outs = [ctx.records_gather(fr, rec, want_output=want_text) for fr, rec in lists]
+        ctx.synchronize()
+        wall = time.perf_counter() - t0
+        prof = {k: v[1] for k, v in ctx.profile_read().items() if v[0] > 0 and k.startswith(("k_index", "k_gather", "k_scan64"))}
+        ctx.profile(False)
+        res = {"codes": [v1["code"], ir["code"], v2["code"], pr["code"]], "matched": int(found.sum()), "alive": int(alive.sum()),
+               "bytes": [o[0] for o in outs], "wall": wall, "prof": prof, "text": [o[1] for o in outs],
+               "images": img if want_text else None}
+        f2.release()
+        idx.close()
+        return res
+
+    small = run(3000, 300, True)
+    from oracle import loader as orc
+    b1, b2 = (bytes(small["images"][k][: 3000 * R].cpu().numpy()) for k in range(2))
+    want = orc.fastq_filterpair(b1, "a_1.fastq", b2, "a_2.fastq", False)
+    same = (want["exit"] == 0 and small["text"][0] == want["files"][0] and small["text"][1] == want["files"][1]
+            and small["text"][2] + small["text"][3] == want["files"][2])
+    run(n, shift, False)  # warm-up (allocations)
+    big = run(n, shift, False)
+    kernels_ms = sum(big["prof"].values())
+    gathered = sum(big["bytes"])
+    # names in (two header lines of ~45 bytes per pair of records), one 8-byte slot written and read, records in and out
+    alg = 2 * n * 45 + 2 * n * 8 + 2 * gathered
+    return {"what": "fastq_filterpair: index file 1, probe + take with file 2, ordered gather of paired / unpaired records",
+            "records_per_file": n, "mates": n - shift, "matched": big["matched"], "left_in_file1": big["alive"],
+            "as_expected": big["codes"] == [0, 0, 0, 13] and  # (13: FQG_E_UNPAIRED - file 2 has reads without a mate)
+                           big["matched"] == n - shift and big["alive"] == shift
+                           and big["bytes"] == [(n - shift) * R, (n - shift) * R, shift * R, shift * R],
+            "codes": big["codes"], "gathered_bytes": big["bytes"],
+            "first_3000_records_identical_to_oracle": bool(same),
+            "wall_ms_all_calls_incl_host_lists": big["wall"] * 1e3, "kernels_ms": kernels_ms, "kernels_ms_breakdown": big["prof"],
+            "Mpairs_per_s_kernels_only": n / (kernels_ms * 1e-3) / 1e6 if kernels_ms else None,
+            "algorithmic_GB": alg / 1e9, "achieved_GBps_kernels": alg / (kernels_ms * 1e-3) / 1e9 if kernels_ms else None}
 
 
 def bam_tags_extra(ctx, torch, dev, n):
@@ -939,6 +1014,12 @@ def main():
                 out["umi_count_extra"] = umi_extra(ctx, torch, dev, a.umi_triples)
             except Exception as e:
                 out["umi_count_extra"] = {"error": repr(e)[:300]}
+        if world == 1 and not a.no_filterpair_extra:
+            try:
+                out["filterpair_extra"] = filterpair_extra(ctx, fq, torch, dev, a.filterpair_records, a.read_len)
+            except Exception as e:
+                out["filterpair_extra"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_tags_extra:
             try:
                 out["bam_add_tags_extra"] = bam_tags_extra(ctx, torch, dev, a.tags_alignments)

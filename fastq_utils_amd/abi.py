@@ -220,6 +220,11 @@ def load():
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_probe_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(u64), C.POINTER(IndexResult)]
     L.fqg_index_alive.argtypes = [vp, vp, C.POINTER(C.c_uint8), u64]
+    L.fqg_records_gather.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
+    L.fqg_records_gather_output.argtypes = [vp, vp, u64]
+    L.fqg_index_frame.argtypes = [vp, u64]
+    L.fqg_index_frame.restype = vp
+    L.fqg_frame_make_current.argtypes = [vp, vp]
     L.fqg_names_compare.argtypes = [vp, vp, C.POINTER(FileState), vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_barcodes_transform.argtypes = [vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64),
                                          C.POINTER(BarcodeParams), u64, u64, C.POINTER(BarcodeResult)]
@@ -403,6 +408,26 @@ class NameIndex:
         d["wrong_header"] = [i for i in range(n_records) if m[i] == 0xFFFFFFFFFFFFFFFE]
         return d
 
+    def probe_delete_np(self, state, n_records):
+        """probe_delete for large frames: (result fields, numpy uint64 array: per record of the current frame the
+        inserted record whose entry it took, FQG_NO_MATCH or FQG_MATCH_WRONG_HEADER)"""
+        import numpy as np
+        r = IndexResult()
+        m = np.empty(max(1, n_records), dtype=np.uint64)
+        self.ctx._check(load().fqg_index_probe_delete(self.ctx.h, self.h, C.byref(state), m.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      C.byref(r)))
+        return r.as_dict(), m[:n_records]
+
+    def alive_np(self, n_inserted):
+        import numpy as np
+        a = np.empty(max(1, n_inserted), dtype=np.uint8)
+        self.ctx._check(load().fqg_index_alive(self.ctx.h, self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), n_inserted))
+        return a[:n_inserted]
+
+    def frame(self, k=0):
+        """the k-th frame the index has retained (borrowed)"""
+        return load().fqg_index_frame(self.h, k)
+
     def alive(self, n_inserted):
         a = (C.c_uint8 * max(1, n_inserted))()
         self.ctx._check(load().fqg_index_alive(self.ctx.h, self.h, a, n_inserted))
@@ -543,6 +568,24 @@ class Context:
         self._check(load().fqg_names_compare(self.h, frame_a.h, C.byref(state_a), frame_b.h if frame_b else None,
                                              C.byref(state_b) if state_b is not None else None, C.byref(r)))
         return r.as_dict()
+
+    def records_gather(self, frame_handle, records, want_output=False):
+        """fqg_records_gather: the records of a frame (a Frame or a borrowed handle) in the given order (numpy uint64);
+        returns the byte count and, with want_output, the text"""
+        import numpy as np
+        rec = np.ascontiguousarray(records, dtype=np.uint64)
+        nb = C.c_uint64()
+        h = frame_handle.h if hasattr(frame_handle, "h") else frame_handle
+        self._check(load().fqg_records_gather(self.h, h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), rec.size, C.byref(nb)))
+        if not want_output:
+            return nb.value, None
+        dst = C.create_string_buffer(max(1, nb.value))
+        self._check(load().fqg_records_gather_output(self.h, dst, nb.value))
+        return nb.value, dst.raw[:nb.value]
+
+    def frame_make_current(self, frame_handle):
+        h = frame_handle.h if hasattr(frame_handle, "h") else frame_handle
+        self._check(load().fqg_frame_make_current(self.h, h))
 
     def frame_records(self, first, count):
         out = (Record * max(1, count))()

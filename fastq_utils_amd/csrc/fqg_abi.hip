@@ -1191,9 +1191,9 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
       hipLaunchKernelGGL(k_index_probe_resolve, dim3((unsigned)((fv.n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                          c->stream, fv.n_records, (const unsigned long long*)d_slot, index_view(ix), ix->n_askers_total,
                          d_match);
-      (void)hipMemcpyAsync(match, d_match, fv.n_records * 8, hipMemcpyDeviceToHost, c->stream);
     }
   }
+  if (match && fv.n_records) (void)hipMemcpyAsync(match, d_match, fv.n_records * 8, hipMemcpyDeviceToHost, c->stream);
   rc = index_fetch_call(c);
   if (d_slot) (void)hipFree(d_slot);
   if (d_match) (void)hipFree(d_match);
@@ -1630,7 +1630,7 @@ int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* recor
   if ((rc = ensure(c, c->bc_out[1], total + 64))) return rc;
   {
     ProfScope ps(c, "k_gather_copy");
-    const unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, (uint64_t)c->cu_count * 16);
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 4 * kWave - 1) / (4 * kWave), (uint64_t)c->cu_count * 16);
     hipLaunchKernelGGL(k_gather_copy, dim3(grid), dim3(kBlock), 0, c->stream, frame->fv,
                        (const unsigned long long*)c->bc_off[1].p, n, (const unsigned long long*)c->bc_off[2].p,
                        (const unsigned long long*)c->bc_sum[1].p, (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_out[1].p);

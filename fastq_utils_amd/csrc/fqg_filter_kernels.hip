@@ -293,23 +293,60 @@ __global__ __launch_bounds__(kBlock) void k_gather_lens(FrameView f, const unsig
   const uint64_t e = f.line_end[4 * r + 3];
   lens[k] = (uint32_t)(e - b) + (e < f.nbytes ? 1u : 0u);
 }
-// one wavefront per record: 16-byte pieces at any alignment
+// One wavefront per 64 consecutive entries of the list: every lane fetches where ONE record lies, where it goes and how
+// long it is (one round trip to memory for 64 records - per record these were three dependent ones), then the records
+// are copied one after the other by all lanes, 16-byte pieces at any alignment.
 __global__ __launch_bounds__(kBlock) void k_gather_copy(FrameView f, const unsigned long long* __restrict__ list, uint64_t n,
                                                         const unsigned long long* __restrict__ off_local,
                                                         const unsigned long long* __restrict__ off_span,
                                                         const uint32_t* __restrict__ lens, uint8_t* __restrict__ out) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
   const int lane = (int)(threadIdx.x & 63);
-  const uint64_t stride = (uint64_t)gridDim.x * (kBlock / kWave);
-  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); k < n; k += stride) {
-    const uint64_t r = list[k];
-    const uint8_t* src = f.img + (r == 0 ? 0 : f.line_end[4 * r - 1] + 1);
-    uint8_t* dst = out + off_local[k] + off_span[k / kScan64Span];
-    const uint32_t len = lens[k];
-    for (uint32_t o = (uint32_t)lane * 16u; o < len; o += 16u * kWave) {
-      if (o + 16u <= len) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
-      else
-        for (uint32_t j = o; j < len; ++j) dst[j] = src[j];
+  const uint64_t stride = (uint64_t)gridDim.x * (kBlock / kWave) * kWave;
+  for (uint64_t k0 = ((uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWave; k0 < n; k0 += stride) {
+    const uint64_t k = k0 + (uint64_t)lane;
+    uint64_t s_off = 0, d_off = 0;
+    uint32_t len = 0;
+    if (k < n) {
+      const uint64_t r = list[k];
+      s_off = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+      d_off = off_local[k] + off_span[k / kScan64Span];
+      len = lens[k];
+    }
+    const int cnt = n - k0 < (uint64_t)kWave ? (int)(n - k0) : kWave;
+    // four records at a time: their loads are all in flight before the first store (records of at most 1 KiB - one
+    // 16-byte piece per lane; longer ones take the loop below)
+    const bool small = __ballot(len > 16u * kWave) == 0;
+    int j = 0;
+    if (small) {
+      for (; j + 4 <= cnt; j += 4) {
+        u32x4 v[4];
+        uint32_t L[4];
+        uint8_t* dst[4];
+        const uint32_t o = (uint32_t)lane * 16u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint8_t* __restrict__ src = f.img + rl64(s_off, j + q);
+          dst[q] = out + rl64(d_off, j + q);
+          L[q] = (uint32_t)__builtin_amdgcn_readlane((int)len, j + q);
+          if (o + 16u <= L[q]) v[q] = *reinterpret_cast<const u32x4*>(src + o);
+          else if (o < L[q])
+            for (uint32_t t = o; t < L[q]; ++t) dst[q][t] = src[t];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (o + 16u <= L[q]) *reinterpret_cast<u32x4*>(dst[q] + o) = v[q];
+      }
+    }
+    for (; j < cnt; ++j) {
+      const uint8_t* __restrict__ src = f.img + rl64(s_off, j);
+      uint8_t* __restrict__ dst = out + rl64(d_off, j);
+      const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
+      for (uint32_t o = (uint32_t)lane * 16u; o < L; o += 16u * kWave) {
+        if (o + 16u <= L) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
+        else
+          for (uint32_t q = o; q < L; ++q) dst[q] = src[q];
+      }
     }
   }
 }

@@ -14,8 +14,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ONLY_HEADLINE="--no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra"
-ONLY_UMI="--reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-tags-extra"
+ONLY_HEADLINE="--no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra"
+ONLY_UMI="--reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra"
 for w in $WHAT; do
   case $w in
   bench)
@@ -40,7 +40,7 @@ for w in $WHAT; do
     ;;
   index)
     # HBM bytes of the name kernels (default mode: validate + k_index_insert over 100 M unique names)
-    ONLY_INDEX="--steps 2 --no-cpu-baseline --no-e2e --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra"
+    ONLY_INDEX="--steps 2 --no-cpu-baseline --no-e2e --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra"
     for c in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/idx_pmc_$c -o pmc -- python3 $R/bench.py $ONLY_INDEX > $O/idx_pmc_$c.json 2> $O/idx_pmc_$c.err
       find $O/idx_pmc_$c -name '*kernel_trace.csv' -delete
