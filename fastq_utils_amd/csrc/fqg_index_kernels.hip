@@ -323,8 +323,12 @@ __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView 
         break;
       }
       if ((cur >> 40) == (mine >> 40)) {
-        if (stored_name_equals(ix, cur & kIdxMask, f.img + b, (uint32_t)(e - b) + (e < f.nbytes ? 1u : 0u), f.nbytes - b, ix.fmt,
-                               ix.is_pe, ix.may_have_nul, n)) {
+        // (a name whose fingerprint is already in the table - a duplicate, a collision - is rare here: the byte-wise
+        // confirmation keeps this kernel at 70 VGPRs; stored_name_equals, with both header lines in registers, is for
+        // the pass in which EVERY record finds its name)
+        const uint8_t* other;
+        uint32_t on;
+        if (stored_name(ix, cur & kIdxMask, &other, &on) && on == n && same_bytes(other, f.img + b + 1, n)) {
           const unsigned long long prev = atomicMin(&ix.slots[at], mine);
           const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
           my_first_dup = late < my_first_dup ? late : my_first_dup;
