@@ -314,6 +314,23 @@ __global__ __launch_bounds__(kBlock) void k_gather_copy(FrameView f, const unsig
       len = lens[k];
     }
     const int cnt = n - k0 < (uint64_t)kWave ? (int)(n - k0) : kWave;
+    // Neighbours in the list are usually neighbours in the image (the mates of two files in the same order, the runs
+    // of reads without a mate): 64 records that follow each other are ONE span and are copied as one, all lanes busy.
+    {
+      const uint64_t next_s = __shfl_down(s_off, 1, 64);
+      const bool breaks = lane + 1 < cnt && s_off + len != next_s;
+      if (__ballot(breaks) == 0) {
+        const uint8_t* __restrict__ src = f.img + rfl64(s_off);
+        uint8_t* __restrict__ dst = out + rfl64(d_off);
+        const uint64_t total = rl64(d_off + len, cnt - 1) - rfl64(d_off);
+        for (uint64_t o = (uint64_t)lane * 16u; o < total; o += 16u * kWave) {
+          if (o + 16u <= total) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
+          else
+            for (uint64_t q = o; q < total; ++q) dst[q] = src[q];
+        }
+        continue;
+      }
+    }
     // four records at a time: their loads are all in flight before the first store (records of at most 1 KiB - one
     // 16-byte piece per lane; longer ones take the loop below)
     const bool small = __ballot(len > 16u * kWave) == 0;
