@@ -979,6 +979,22 @@ def main():
                 "index_entries": ir["n_entries"],
                 "Mreads_per_s_kernels_only": n / ((all_ms + ki[1] / max(1, ki[0])) * 1e-3) / 1e6,
             }
+            # ... and the file-2 loop of a pair (src/fastq_info.c:333-356): the same names once more as the second file -
+            # every record finds its name, confirms it on the bytes and takes the entry
+            try:
+                ctx.validate(image.data_ptr(), None, st, final=True, flags=fq.abi.VALIDATE_NO_STATS, nbytes=n * R)
+                ctx.profile(True)
+                ctx.profile_reset()
+                mr = idx.match_delete(st)
+                ctx.synchronize()
+                p3 = ctx.profile_read()
+                ctx.profile(False)
+                km = p3.get("k_index_match_delete", (1, 0.0))
+                out["default_mode_extra"]["file2_loop"] = {
+                    "k_index_match_delete_ms": km[1] / max(1, km[0]), "code": mr["code"], "entries_left": mr["n_entries"],
+                    "ok": mr["code"] == 0 and mr["n_entries"] == 0}
+            except Exception as e:
+                out["default_mode_extra"]["file2_loop"] = {"error": repr(e)[:200]}
             idx.close()
             acc2.close()
         if world == 1 and not a.no_cpu_baseline:
