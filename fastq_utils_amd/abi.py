@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libfqgpu.so")
 MEM_HOST, MEM_DEVICE = 0, 1
 VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE, VALIDATE_FRAME_ONLY = 0, 1, 2, 4, 8
 VALIDATE_TWO_PASS = 16
+VALIDATE_NAMES = 32
 NAME_DEFAULT, NAME_CASAVA18, NAME_INTEGER, NAME_UNDEF = 0, 1, 2, -1
 SPACE_SEQ, SPACE_COLOUR, SPACE_UNDEF = 0, 1, -1
 
@@ -31,7 +32,7 @@ EXPORTS = [
     "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
     "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_frame_make_current", "fqg_index_create",
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_index_probe_delete",
-    "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_records_gather",
+    "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_index_names_captured", "fqg_records_gather",
     "fqg_records_gather_output", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
@@ -220,6 +221,8 @@ def load():
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_probe_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(u64), C.POINTER(IndexResult)]
     L.fqg_index_alive.argtypes = [vp, vp, C.POINTER(C.c_uint8), u64]
+    L.fqg_index_names_captured.argtypes = [vp]
+    L.fqg_index_names_captured.restype = u64
     L.fqg_records_gather.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
     L.fqg_records_gather_output.argtypes = [vp, vp, u64]
     L.fqg_index_frame.argtypes = [vp, u64]
@@ -423,6 +426,10 @@ class NameIndex:
         a = np.empty(max(1, n_inserted), dtype=np.uint8)
         self.ctx._check(load().fqg_index_alive(self.ctx.h, self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), n_inserted))
         return a[:n_inserted]
+
+    def names_captured(self):
+        """of the last insert / match call: records whose name came from a capture record of the streaming pass"""
+        return int(load().fqg_index_names_captured(self.ctx.h))
 
     def frame(self, k=0):
         """the k-th frame the index has retained (borrowed)"""

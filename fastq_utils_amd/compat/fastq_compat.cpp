@@ -467,7 +467,7 @@ void fastq_index_readnames(FASTQ_FILE* fd1, hashtable index, long long start_off
   fqg_acc* acc = nullptr;
   LIB(fqg_acc_create(c, &acc));
   fqg_validate_result r;
-  LIB(fqg_validate(c, acc, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st, FQG_VALIDATE_COUNT_TWICE, &r));
+  LIB(fqg_validate(c, acc, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st, FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES, &r));
   fqg_index* ix = nullptr;
   LIB(fqg_index_create(c, r.n_records, &ix));
   fqg_index_result ir;
@@ -580,7 +580,7 @@ INDEX_ENTRY* fastq_index_lookup_header(hashtable sn_index, char* hdr) {
     st.space = f->fd->space;
     fqg_validate_result r;
     LIB(fqg_validate(gpu(), nullptr, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st,
-                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS, &r));
+                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | FQG_VALIDATE_NAMES, &r));
     std::vector<uint64_t> m(r.n_records ? r.n_records : 1, FQG_NO_MATCH);
     fqg_index_result ir;
     if (r.n_records) LIB(fqg_index_probe_delete(gpu(), ic->ix, &st, m.data(), &ir));

@@ -69,6 +69,12 @@ struct fqg_ctx {
   DevBuf cinfo;       // streaming path: u32 info word per chunk
   DevBuf queue;       // streaming path: u64 suspect byte positions
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
+  DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
+  DevBuf name_hcount; // ... and the headers every chunk saw
+  NamesView names{};            // what the name kernels need of the last capture
+  uint64_t last_names_captured = 0;    // of the last index call: records whose name came straight from a capture record
+  const uint8_t* names_img = nullptr;  // the image it belongs to (null: no capture) - the current frame's, or the
+  uint64_t names_nbytes = 0;           // capture is not used
   DevBuf umi_names, umi_cells, umi_entries[2];  // results of the last fqg_umi_count
   uint64_t umi_n_features = 0, umi_n_cells = 0, umi_n_entries[2] = {0, 0};
   void* umi_state = nullptr;  // UmiState of a deferred fqg_umi_count (fqg_umi_abi.inc)
@@ -267,6 +273,8 @@ void fqg_close(fqg_ctx* c) {
   release(c->cinfo);
   release(c->queue);
   release(c->redo);
+  release(c->name_recs);
+  release(c->name_hcount);
   release(c->umi_arena);
   release(c->umi_names);
   release(c->umi_cells);
@@ -591,8 +599,9 @@ struct RecordDuties {  // what k_stream_lines needs from the caller of frame_str
 };
 
 int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_chunks, bool final, SuspectMap sm,
-                 const RecordDuties& rd, Framed* out) {
+                 const RecordDuties& rd, bool want_names, Framed* out) {
   int rc;
+  c->names_img = nullptr;
   const uint32_t n_spans = (n_chunks + kScanSpan - 1) / kScanSpan;
   if ((rc = ensure(c, c->tile_counts, (size_t)n_chunks * 4))) return rc;
   if ((rc = ensure(c, c->tile_local, (size_t)n_chunks * 4))) return rc;
@@ -614,10 +623,31 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     const uint32_t span = (uint32_t)std::min<uint64_t>(kStreamBootBytes, nbytes & ~255ull);
     hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBlock), 0, c->stream, d_img, span, c->d_cs);
   }
+  NameCapture nc{};
+  if (want_names) {
+    // record slots per chunk from the mean record of the boot window: a power of two with a quarter of headroom
+    // (a chunk that sees more headers is read through the line index instead)
+    HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t span = (uint32_t)std::min<uint64_t>(kStreamBootBytes, nbytes & ~255ull);
+    const double per_chunk = (double)(c->h_cs->boot_lines / 4 + 1) * (double)kChunkBytes / (double)std::max<uint32_t>(span, 1);
+    uint32_t shift = 3;
+    while (shift < 7 && (double)(1u << shift) < 1.25 * per_chunk + 1.0) ++shift;
+    nc.K = 1u << shift;
+    if ((rc = ensure(c, c->name_recs, ((size_t)n_chunks << shift) * kNameRecWords * 8))) return rc;
+    if ((rc = ensure(c, c->name_hcount, (size_t)n_chunks * 2))) return rc;
+    nc.recs = (unsigned long long*)c->name_recs.p;
+    nc.hcount = (uint16_t*)c->name_hcount.p;
+    c->names.k_shift = shift;
+  }
   {
-    ProfScope ps(c, "k_stream_pass1");
-    hipLaunchKernelGGL(k_stream_pass1<0u>, dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
-                       so, c->d_cs);
+    ProfScope ps(c, want_names ? "k_stream_pass1(names)" : "k_stream_pass1");
+    if (want_names)
+      hipLaunchKernelGGL((k_stream_pass1<0u, true>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
+                         n_chunks, so, c->d_cs, nc);
+    else
+      hipLaunchKernelGGL((k_stream_pass1<0u, false>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
+                         n_chunks, so, c->d_cs, nc);
   }
   {
     ProfScope ps(c, "k_scan");
@@ -709,6 +739,18 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
                        (const uint32_t*)&c->d_cs->redo_count);
   }
   out->checks_done = true;
+  if (want_names && !old_pass2) {
+    c->names.recs = nc.recs;
+    c->names.hcount = nc.hcount;
+    c->names.cinfo = (const uint32_t*)c->cinfo.p;
+    c->names.cr.counts = (const uint32_t*)c->tile_counts.p;
+    c->names.cr.local = (const uint32_t*)c->tile_local.p;
+    c->names.cr.span_excl = (const unsigned long long*)c->span_sums.p;
+    c->names.cr.n_chunks = n_chunks;
+    c->names.K = nc.K;
+    c->names_img = d_img;
+    c->names_nbytes = nbytes;
+  }
   return 0;
 }
 
@@ -724,6 +766,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   memset(out, 0, sizeof(*out));
   c->frame_valid = false;
   c->frame_borrowed = false;
+  c->names_img = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
   if (nbytes == 0) return 0;
   if (nbytes >= (1ull << 44)) return fail(c, FQG_ERR_ARG, "image too large");
@@ -742,7 +785,9 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   const uint32_t n_chunks = (uint32_t)((nbytes + kChunkBytes - 1) / kChunkBytes);
   const bool frame_only = (flags & FQG_VALIDATE_FRAME_ONLY) != 0;
   if (frame_only) acc = nullptr;
-  const bool want_checks = !(flags & FQG_VALIDATE_FORCE_EXACT) && !frame_only;
+  // (frame only + names: the single-pass framing runs for its capture records; what its checks find is not looked at)
+  const bool names_only = frame_only && (flags & FQG_VALIDATE_NAMES) && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS);
+  const bool want_checks = !(flags & FQG_VALIDATE_FORCE_EXACT) && (!frame_only || names_only);
   const uint32_t weight = (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u;
 
   // suspect bitmap, sized from the image (>= 16 bytes per record assumed; denser images overflow
@@ -761,12 +806,12 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   bool streamed = false;
   if (want_checks && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS)) {
     RecordDuties rd{st->space, weight, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr};
-    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, &fr);
+    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, (flags & FQG_VALIDATE_NAMES) != 0, &fr);
     if (rc < 0) return rc;
     streamed = rc == 0;
     if (!streamed) HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(sm.cap / 32 + 2) * 4, c->stream));
   }
-  if (!streamed && (rc = frame_two_pass(c, d_img, nbytes, n_chunks, final != 0, want_checks, sm, &fr))) return rc;
+  if (!streamed && (rc = frame_two_pass(c, d_img, nbytes, n_chunks, final != 0, want_checks && !frame_only, sm, &fr))) return rc;
   const uint64_t n_newlines = fr.n_newlines;
   const bool last_nl = fr.last_nl;
   const uint32_t img_flags = fr.img_flags;
@@ -816,7 +861,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   // The tiled path needs an image without NUL / CR bytes (then every line is terminated by its
   // '\n' alone and the statistics follow from the line index); anything else goes through the
   // exact wave-per-record validator as a whole.
-  const bool fast = fr.checks_done;
+  const bool fast = fr.checks_done && !frame_only;
   uint64_t list_cap = 0;
   if (fast) {
     out->path = streamed ? 3 : 2;
@@ -980,9 +1025,8 @@ uint64_t fqg_frame_n_records(const fqg_frame* f) { return f ? f->fv.n_records : 
 // ---- read-name index ------------------------------------------------------------------------
 struct fqg_index {
   fqg_ctx* ctx = nullptr;
-  DevBuf slots, claims, segs_dev;
+  DevBuf buckets, segs_dev, slot_of, match;
   uint64_t capacity = 0;
-  bool claims_ready = false;
   std::vector<fqg_frame*> frames;
   std::vector<IndexSeg> segs;
   uint64_t n_records_total = 0;  // records fed so far = global index of the next frame's first record
@@ -997,17 +1041,15 @@ namespace {
 int index_alloc_table(fqg_index* ix, uint64_t capacity) {
   fqg_ctx* c = ix->ctx;
   int rc;
-  if ((rc = ensure(c, ix->slots, (size_t)capacity * 8))) return rc;
-  HIP_TRY(c, hipMemsetAsync(ix->slots.p, 0xFF, (size_t)capacity * 8, c->stream));
+  if ((rc = ensure(c, ix->buckets, (size_t)capacity * sizeof(NameBucket)))) return rc;
+  HIP_TRY(c, hipMemsetAsync(ix->buckets.p, 0xFF, (size_t)capacity * sizeof(NameBucket), c->stream));  // empty keys, no claims
   ix->capacity = capacity;
-  ix->claims_ready = false;
   return 0;
 }
 
 IndexView index_view(fqg_index* ix) {
   IndexView v;
-  v.slots = (unsigned long long*)ix->slots.p;
-  v.claims = (unsigned long long*)ix->claims.p;
+  v.buckets = (NameBucket*)ix->buckets.p;
   v.mask = ix->capacity - 1;
   v.segs = (const IndexSeg*)ix->segs_dev.p;
   v.n_segs = (int)ix->segs.size();
@@ -1044,6 +1086,16 @@ int index_fetch_call(fqg_ctx* c) {
 
 unsigned index_grid(fqg_ctx* c, uint64_t n) {
   return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 16));
+}
+
+// the capture records of the last fqg_validate belong to this frame (FQG_VALIDATE_NAMES, streamed)
+bool names_usable(const fqg_ctx* c, const FrameView& fv) {
+  static const bool off = getenv("FQGPU_NO_NAME_CAPTURE") != nullptr;  // (A/B: always go through the line index)
+  return !off && c->names_img && c->names_img == fv.img && c->names_nbytes == fv.nbytes;
+}
+unsigned names_grid(fqg_ctx* c) {
+  const uint64_t n_slots = (uint64_t)c->names.cr.n_chunks << c->names.k_shift;
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_slots + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 16));
 }
 
 // rebuild the table at a larger capacity from the retained segments
@@ -1088,9 +1140,10 @@ void fqg_index_destroy(fqg_index* ix) {
   if (!ix) return;
   (void)hipStreamSynchronize(ix->ctx->stream);
   for (auto* f : ix->frames) fqg_frame_release(f);
-  release(ix->slots);
-  release(ix->claims);
+  release(ix->buckets);
   release(ix->segs_dev);
+  release(ix->slot_of);
+  release(ix->match);
   delete ix;
 }
 
@@ -1135,7 +1188,12 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   };
   if ((rc = index_upload_segs(ix))) return drop(rc);
   if ((rc = index_reset_call(c))) return drop(rc);
-  if (sg.n_records) {
+  const bool captured = names_usable(c, fr->fv);
+  if (sg.n_records && captured) {
+    ProfScope ps(c, "k_names_insert");
+    hipLaunchKernelGGL(k_names_pass<false>, dim3(names_grid(c)), dim3(kBlock), 0, c->stream, fr->fv, c->names, index_view(ix),
+                       st->readname_format, st->is_pe, sg.record_base, (unsigned long long*)nullptr, c->d_icall);
+  } else if (sg.n_records) {
     ProfScope ps(c, "k_index_insert");
     hipLaunchKernelGGL(k_index_insert, dim3(index_grid(c, sg.n_records)), dim3(kBlock), 0, c->stream, fr->fv,
                        index_view(ix), sg.record_base, c->d_icall);
@@ -1143,6 +1201,8 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   if ((rc = index_fetch_call(c))) return drop(rc);
   if (hipGetLastError() != hipSuccess) return drop(fail(c, FQG_ERR_HIP, "k_index_insert"));
   if (c->h_icall->table_full) return drop(fail(c, FQG_ERR_STATE, "name index full"));
+  if (sg.n_records && c->h_icall->seen != sg.n_records) return drop(fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once"));
+  c->last_names_captured = c->h_icall->captured;
   ix->n_records_total += sg.n_records;
   ix->inserted += c->h_icall->inserted;
   ix->name_bytes += c->h_icall->name_bytes;
@@ -1167,38 +1227,39 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   memset(out, 0, sizeof(*out));
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if (!ix->claims_ready) {
-    if ((rc = ensure(c, ix->claims, (size_t)ix->capacity * 8))) return rc;
-    HIP_TRY(c, hipMemsetAsync(ix->claims.p, 0xFF, (size_t)ix->capacity * 8, c->stream));
-    ix->claims_ready = true;
-  }
   if ((rc = index_upload_segs(ix))) return rc;
   if ((rc = index_reset_call(c))) return rc;
   const FrameView fv = c->frame;
   unsigned long long *d_slot = nullptr, *d_match = nullptr;
   if (match && fv.n_records) {
-    if (hipMalloc((void**)&d_slot, fv.n_records * 8) != hipSuccess || hipMalloc((void**)&d_match, fv.n_records * 8) != hipSuccess) {
-      if (d_slot) (void)hipFree(d_slot);
-      return fail(c, FQG_ERR_NOMEM, "fqg_index_probe_delete: device allocation failed");
-    }
+    if ((rc = ensure(c, ix->slot_of, fv.n_records * 8))) return rc;
+    if ((rc = ensure(c, ix->match, fv.n_records * 8))) return rc;
+    d_slot = (unsigned long long*)ix->slot_of.p;
+    d_match = (unsigned long long*)ix->match.p;
   }
   if (fv.n_records) {
-    ProfScope ps(c, "k_index_match_delete");
-    hipLaunchKernelGGL(k_index_match_delete, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv,
-                       index_view(ix), st->readname_format, st->is_pe, (c->frame_flags & kFlagNul) ? 1 : 0,
-                       ix->n_askers_total, d_slot, c->d_icall);
+    if (names_usable(c, fv)) {
+      ProfScope ps(c, "k_names_match");
+      hipLaunchKernelGGL(k_names_pass<true>, dim3(names_grid(c)), dim3(kBlock), 0, c->stream, fv, c->names, index_view(ix),
+                         st->readname_format, st->is_pe, ix->n_askers_total, d_slot, c->d_icall);
+    } else {
+      ProfScope ps(c, "k_index_match_delete");
+      hipLaunchKernelGGL(k_index_match_delete, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv,
+                         index_view(ix), st->readname_format, st->is_pe, (c->frame_flags & kFlagNul) ? 1 : 0,
+                         ix->n_askers_total, d_slot, c->d_icall);
+    }
     if (match) {
+      ProfScope ps(c, "k_index_probe_resolve");
       hipLaunchKernelGGL(k_index_probe_resolve, dim3((unsigned)((fv.n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                          c->stream, fv.n_records, (const unsigned long long*)d_slot, index_view(ix), ix->n_askers_total,
                          d_match);
+      HIP_TRY(c, hipMemcpyAsync(match, d_match, fv.n_records * 8, hipMemcpyDeviceToHost, c->stream));
     }
   }
-  if (match && fv.n_records) (void)hipMemcpyAsync(match, d_match, fv.n_records * 8, hipMemcpyDeviceToHost, c->stream);
-  rc = index_fetch_call(c);
-  if (d_slot) (void)hipFree(d_slot);
-  if (d_match) (void)hipFree(d_match);
-  if (rc) return rc;
+  if ((rc = index_fetch_call(c))) return rc;
   HIP_TRY(c, hipGetLastError());
+  if (fv.n_records && c->h_icall->seen != fv.n_records) return fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once");
+  c->last_names_captured = c->h_icall->captured;
   ix->matched += c->h_icall->matched;
   ix->n_askers_total += fv.n_records;
   const uint64_t w = c->h_icall->first_wrong, m = c->h_icall->first_missing;
@@ -1234,7 +1295,6 @@ int fqg_index_alive(fqg_ctx* c, fqg_index* ix, uint8_t* alive, uint64_t cap) {
   if (hipMalloc((void**)&d, ix->n_records_total) != hipSuccess) return fail(c, FQG_ERR_NOMEM, "fqg_index_alive: device allocation failed");
   (void)hipMemsetAsync(d, 0, ix->n_records_total, c->stream);
   IndexView v = index_view(ix);
-  if (!ix->claims_ready) v.claims = nullptr;
   hipLaunchKernelGGL(k_index_alive, dim3((unsigned)((ix->capacity + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, v,
                      ix->n_records_total, d);
   hipError_t e = hipMemcpyAsync(alive, d, ix->n_records_total, hipMemcpyDeviceToHost, c->stream);
@@ -1643,6 +1703,7 @@ int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* recor
 }
 int fqg_records_gather_output(fqg_ctx* c, void* host_dst, uint64_t nbytes) { return fqg_barcodes_output(c, 1, host_dst, nbytes); }
 
+uint64_t fqg_index_names_captured(const fqg_ctx* c) { return c ? c->last_names_captured : 0; }
 const fqg_frame* fqg_index_frame(const fqg_index* ix, uint64_t k) {
   return (ix && k < ix->frames.size()) ? ix->frames[k] : nullptr;
 }

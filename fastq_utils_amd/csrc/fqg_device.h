@@ -45,6 +45,28 @@ __host__ __device__ inline bool chunk_info_range(uint32_t info, uint32_t rank0) 
   return (info & kInfoOneLine) ? (rank0 & 3u) == 3u : true;
 }
 
+// ---- header lines captured by the streaming pass (FQG_VALIDATE_NAMES) -----------------------------
+// While a chunk's bytes are in LDS, pass 1 copies the start of every header line that BEGINS in the chunk
+// (under its speculated line type) into a 64-byte record, so that the name kernels never go back to the image:
+//     bytes 0..3   meta: bits 0..9  bytes of the line in front of its '\n', the '@' included (1023 = that or more)
+//                        bits 10..18 v: the line starts behind the chunk's v-th newline (v = 0: at the chunk's
+//                                    first byte) - with the chunk's first rank this gives the record index
+//                        bit 19      the line's '\n' lies in the chunk (its length is known)
+//                        bit 20      the line starts with '@'
+//     bytes 4..63  the 60 bytes behind the '@' (whatever follows the line when it is shorter)
+// Records sit at [chunk * K + ordinal of the header in the chunk]; hcount[chunk] = headers the chunk saw
+// (kNoCapture: none captured - no speculation in this chunk).  A consumer trusts a chunk's records only when the
+// speculated type was the true one and hcount <= K; every other header is found through the line index.
+constexpr uint32_t kNameRecWords = 8;       // 64-bit words per record
+constexpr uint32_t kNameRecText = 60;       // header bytes behind the '@' in a record
+constexpr uint32_t kNameInline = 48;        // name bytes an index bucket carries
+constexpr uint32_t kNoCapture = 0xFFFFu;
+struct NameCapture {
+  unsigned long long* recs;  // n_chunks * K records
+  uint16_t* hcount;          // per chunk
+  uint32_t K;                // record slots per chunk
+};
+
 // Scalars of one fqg_validate() call.  Lives in device memory; the host copies it back once.
 struct CallState {
   unsigned long long first_key;   // min over failing records of (record << 8 | code)
@@ -58,7 +80,7 @@ struct CallState {
   unsigned long long queue_count;     // streaming pass: suspect byte positions queued
   unsigned int redo_count;            // streaming pass: chunks whose checks must be repeated
   unsigned int boot_qmin, boot_qmax;  // streaming pass: quality range of the image's first records
-  unsigned int pad0;
+  unsigned int boot_lines;            // streaming pass: newlines in the boot window (mean record size -> NameCapture::K)
 };
 
 // Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).

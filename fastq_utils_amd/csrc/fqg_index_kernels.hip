@@ -2,20 +2,29 @@
 // fastq_index_readnames (reference src/fastq.c:396-439, :577-611) and by the file-2 pairing
 // loop of fastq_info (reference src/fastq_info.c:333-356).
 //
-// Table: open addressing, linear probing, ONE 8-byte word per slot
-//     { tag : 24 | record : 40 }          (all ones = empty)
-// `record` is the global index of the record that owns the name, `tag` 24 further bits of the
-// name's 64-bit hash.  Names themselves are not copied: the index keeps references to the framed
-// images it was fed (segments), and a slot's record index leads back to the header bytes.
-// Equality is decided on the name BYTES (a tag match only nominates a candidate), so hash
-// collisions can neither fake nor hide a duplicate.
+// Table: open addressing, linear probing, one 64-BYTE BUCKET per name - a cache line that holds everything a
+// look-up needs, so that finding a name, confirming it on its bytes and taking it is ONE memory access:
+//     key    { tag : 24 | record : 40 }   (all ones = empty)   the word the insert claims with a CAS
+//     claim  smallest record of the asking file that took the entry (all ones = nobody)
+//     name   the first 48 bytes of the canonical name, zero padded
+// `record` is the global index of the record that owns the name, `tag` 24 further bits of the name's 64-bit hash.
+// Equality is decided on the name BYTES: a name shorter than 48 bytes is compared inside the bucket (names hold no
+// NUL byte, so equal padded words mean equal lengths too); for longer names the index keeps references to the framed
+// images it was fed (segments) and the record index leads back to the header bytes.  Hash collisions can neither
+// fake nor hide a duplicate.
+//
+// Where the names come from: the streaming pass copies every header line it sees into a 64-byte record while the
+// chunk is in LDS (NameCapture, fqg_device.h), and k_names_insert / k_names_match work from those records - a
+// sequential read instead of one header line per 349-byte stride.  Headers the capture could not vouch for
+// (mis-speculated chunks, lines that straddle a chunk, lines longer than a record) and frames that were not
+// streamed go through the line index and the image (k_index_insert / k_index_match_delete: same table, same results).
 //
 // Serial semantics in a parallel insert: the reference stops at the first record (file order)
 // whose name is already present.  Every thread that meets its own name in the table does
-// atomicMin(slot, tag|me) and reports max(previous owner, me); the minimum over all reports is
+// atomicMin(key, tag|me) and reports max(previous owner, me); the minimum over all reports is
 // exactly the second-smallest index of the earliest repeated name, i.e. the record the serial
 // loop would have stopped at.  The same argument gives the first unpaired record in the
-// match-and-delete pass (claims[] holds the smallest file-2 record that asked for the slot).
+// match-and-delete pass (claim holds the smallest file-2 record that asked for the entry).
 #include "fqg_device.h"
 
 namespace fqg {
@@ -31,9 +40,14 @@ struct IndexSeg {
   uint64_t record_base;  // global index of the segment's first record
 };
 
+struct NameBucket {
+  unsigned long long key, claim;
+  unsigned long long name[kNameInline / 8];
+};
+static_assert(sizeof(NameBucket) == 64, "a bucket is one 64-byte line");
+
 struct IndexView {
-  unsigned long long* slots;
-  unsigned long long* claims;  // per slot, match-and-delete only (may be null)
+  NameBucket* buckets;
   uint64_t mask;               // capacity - 1 (capacity is a power of two)
   const IndexSeg* segs;
   int n_segs;
@@ -48,6 +62,8 @@ struct IndexCall {
   unsigned long long inserted;      // names added
   unsigned long long matched;       // slots claimed for the first time
   unsigned long long name_bytes;    // sum of the `len` the reference accounts per name (src/fastq.c:609)
+  unsigned long long seen;          // records the call looked at (a check on the enumeration by chunk: must be the frame's)
+  unsigned long long captured;      // ... of them straight from a capture record
   unsigned int table_full;
   unsigned int pad;
 };
@@ -252,176 +268,313 @@ __device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ im
   return n;
 }
 
-// Is the canonical name of the stored record g the name (n bytes behind the '@') of the header line at mine[0 .. cstr)?
-// Both header lines go to registers (a few 16-byte loads each) and the names are compared word by word; a byte-wise
-// walk of the two lines - a memory round trip per byte, twice - is the fallback for lines that do not fit.
-// (Every record of a second file that finds its mate comes through here: at one round trip per byte the pairing
-// pass of 40 M records took 44 ms, 12 times the insert of the same names.)
-__device__ __forceinline__ bool stored_name_equals(const IndexView& ix, uint64_t g, const uint8_t* __restrict__ mine, uint32_t cstr,
-                                                   uint64_t room, int fmt_mine, int pe_mine, int nul_mine, uint32_t n) {
-  for (int s = 0; s < ix.n_segs; ++s) {
-    const IndexSeg& sg = ix.segs[s];
-    if (g < sg.record_base || g >= sg.record_base + sg.n_records) continue;
-    const uint64_t r = g - sg.record_base;
-    const uint64_t b = r == 0 ? 0 : sg.line_end[4 * r - 1] + 1;
-    const uint64_t e = sg.line_end[4 * r];
-    const uint32_t len = (uint32_t)(e - b), nl = e < sg.nbytes ? 1u : 0u;
-    uint32_t acct;
-    if (!ix.may_have_nul && !nul_mine && len + nl <= kHdrBytes - 1 && b + kHdrBytes <= sg.nbytes && cstr <= kHdrBytes - 1 &&
-        room >= kHdrBytes) {
-      HdrRegs O, M;
-      hdr_load(sg.img + b, O, len + nl);
-      hdr_load(mine, M, cstr);
-      bool ok_o, ok_m;
-      const uint32_t on = canon_name_regs(O, len + nl, ix.fmt, ix.is_pe, &acct, &ok_o);
-      const uint32_t mn = canon_name_regs(M, cstr, fmt_mine, pe_mine, &acct, &ok_m);
-      if (ok_o && ok_m && mn == n) {
-        if (on != n) return false;
-        uint64_t diff = 0;
+// ---- buckets -----------------------------------------------------------------------------------
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+
+struct NameKey {
+  uint32_t n, acct;  // canonical name length; the `len` the reference accounts for it (src/fastq.c:609)
+  uint64_t h;
+  unsigned long long nm[kNameInline / 8];  // first 48 name bytes, zero padded
+};
+
+// the first 48 bytes of the name at p (n bytes, no NUL inside) as padded words; byte-wise - the slow path only
+__device__ inline void name_words_from_image(const uint8_t* __restrict__ p, uint32_t n, unsigned long long (&nm)[kNameInline / 8]) {
 #pragma unroll
-        for (int w = 0; w < kHdrWords; ++w) {
-          const uint64_t x = ((O.w[w] >> 8) | (O.w[w + 1] << 56)) ^ ((M.w[w] >> 8) | (M.w[w + 1] << 56));
-          const uint64_t m = 8u * w + 8u <= n ? ~0ull : (8u * w < n ? (1ull << (8 * (n - 8u * w))) - 1ull : 0ull);
-          diff |= x & m;
-        }
-        return diff == 0;
-      }
-    }
-    const uint32_t on = canon_name(sg.img + b, len, nl, ix.fmt, ix.is_pe, ix.may_have_nul, &acct);
-    return on == n && same_bytes(sg.img + b + 1, mine + 1, n);
-  }
-  return false;
+  for (uint32_t k = 0; k < kNameInline / 8; ++k) nm[k] = 0;
+  const uint32_t m = n < kNameInline ? n : kNameInline;
+  for (uint32_t i = 0; i < m; ++i) nm[i >> 3] |= (unsigned long long)p[i] << (8 * (i & 7));
 }
 
-// One thread per record of the frame: insert its canonical name, report repeats.
+// Name of a captured header line (NameCapture record in w[]).  false: the record cannot give it - the line's end is
+// not in the chunk, the line is longer than the record holds, a Casava header has no blank - and the caller goes
+// through the line index instead.  *v = which newline of the chunk the line starts behind.
+__device__ __forceinline__ bool name_from_record(const unsigned long long (&w)[kNameRecWords], int fmt, int is_pe, NameKey& k,
+                                                 bool* at_sign, uint32_t* v) {
+  const uint32_t meta = (uint32_t)w[0];
+  const uint32_t L = meta & 1023u;  // strlen(&hdr[1]): the bytes behind the '@' and the '\n'
+  *v = (meta >> 10) & 511u;
+  *at_sign = ((meta >> 20) & 1u) != 0;
+  if (!((meta >> 19) & 1u) || L >= (uint32_t)FQG_MAX_LABEL_LENGTH) return false;
+  uint64_t t[kNameRecWords];  // the bytes behind the '@'
+#pragma unroll
+  for (uint32_t i = 0; i + 1 < kNameRecWords; ++i) t[i] = (w[i] >> 32) | (w[i + 1] << 32);
+  t[kNameRecWords - 1] = w[kNameRecWords - 1] >> 32;
+  uint32_t n, acct;
+  if (fmt == FQG_NAME_CASAVA18) {
+    const uint32_t lim = L < kNameRecText ? L : kNameRecText;
+    uint32_t first = ~0u, two_before = 0;
+#pragma unroll
+    for (int i = (int)kNameRecWords - 1; i >= 0; --i) {
+      const uint64_t m = hdr_eq_mask(t[i], (uint8_t)' ');
+      if (m) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(m) >> 3;
+        first = 8u * i + j;
+        const uint64_t below = i ? t[i ? i - 1 : 0] : 0ull;
+        two_before = (uint32_t)(j >= 2 ? t[i] >> (8 * (j - 2)) : below >> (8 * (6 + j))) & 0xFFu;
+      }
+    }
+    if (first >= lim) return false;  // (no blank in the line, or none in what the record holds of it)
+    uint32_t sp = first;
+    if (sp >= 2 && two_before == '/') sp -= 2;
+    n = acct = sp;
+  } else {
+    if (L > kNameRecText) return false;
+    long l = (long)L;
+    if (fmt == FQG_NAME_DEFAULT && is_pe) l--;
+    acct = (uint32_t)(l < 0 ? 0 : l);
+    n = l >= 1 ? (uint32_t)(l - 1) : L;
+  }
+  // hash_name(line + 1, n), word for word
+  uint64_t h = 0x2545F4914F6CDD1Dull ^ n;
+#pragma unroll
+  for (uint32_t i = 0; i < kNameRecWords; ++i) {
+    const bool full = 8u * i + 8u <= n;
+    const bool last = !full && 8u * i <= n;
+    const uint32_t rem = n - 8u * i;
+    const uint64_t x = full ? t[i] : (t[i] & ((1ull << (8 * (rem & 7))) - 1ull));
+    if (full || last) h = mix_hash(h, x);
+    if (i < kNameInline / 8) k.nm[i] = (full || last) ? x : 0ull;
+  }
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  h ^= h >> 32;
+  k.h = h;
+  k.n = n;
+  k.acct = acct;
+  return true;
+}
+
+// where the name of frame-local record r starts in the image (looked up only when bytes must be compared)
+struct NameAt {
+  const FrameView& f;
+  uint64_t r;
+  __device__ __forceinline__ const uint8_t* operator()() const { return f.img + (r == 0 ? 0 : f.line_end[4 * r - 1] + 1) + 1; }
+};
+
+// the same key from the image, through the line index: any line the capture could not give
+__device__ inline void name_from_image(const FrameView& f, uint64_t r, int fmt, int is_pe, int may_have_nul, NameKey& k,
+                                       bool* at_sign) {
+  const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+  const uint64_t e = f.line_end[4 * r];
+  k.n = name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &k.acct, &k.h, at_sign);
+  name_words_from_image(f.img + b + 1, k.n, k.nm);
+}
+
+// Is the canonical name of the stored record g the n bytes at `mine`?  Byte-wise: only names of 48 bytes or more, and
+// tag matches during an insert, come here.
+__device__ inline bool stored_name_is(const IndexView& ix, uint64_t g, const uint8_t* __restrict__ mine, uint32_t n) {
+  const uint8_t* other;
+  uint32_t on;
+  return stored_name(ix, g, &other, &on) && on == n && same_bytes(other, mine, n);
+}
+
+struct IndexTally {  // per-thread findings and counts of the name kernels
+  unsigned long long first_dup = kNoRecord, first_wrong = kNoRecord, first_missing = kNoRecord;
+  unsigned long long inserted = 0, matched = 0, name_bytes = 0, seen = 0, captured = 0;
+};
+
+// Insert the name of frame-local record r (global record_base + r), report a repeat.
+__device__ __forceinline__ void insert_name(const IndexView& ix, const NameKey& k, bool at_sign, const FrameView& f, uint64_t r,
+                                            uint64_t record_base, IndexTally& t, IndexCall* __restrict__ call) {
+  ++t.seen;
+  if (!at_sign) {  // fastq_get_readname refuses it (src/fastq.c:448)
+    t.first_wrong = r < t.first_wrong ? r : t.first_wrong;
+    return;
+  }
+  const unsigned long long g = record_base + r;
+  const unsigned long long me = ((k.h >> 40) << 40) | g;
+  uint64_t at = k.h & ix.mask;
+  for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
+    NameBucket* bk = ix.buckets + at;
+    // one round trip when the bucket is free (most are: the table is at most half full)
+    const unsigned long long cur = atomicCAS(&bk->key, kSlotEmpty, me);
+    if (cur == kSlotEmpty) {
+      // (nobody reads these words before the kernel has ended: a tag match inside an insert is confirmed on the images)
+      u64x2_t* dst = reinterpret_cast<u64x2_t*>(bk->name);
+#pragma unroll
+      for (uint32_t i = 0; i < kNameInline / 16; ++i) {
+        u64x2_t x;
+        x.x = k.nm[2 * i];
+        x.y = k.nm[2 * i + 1];
+        dst[i] = x;
+      }
+      ++t.inserted;
+      t.name_bytes += k.acct;
+      return;
+    }
+    if ((cur >> 40) == (me >> 40) && stored_name_is(ix, cur & kIdxMask, NameAt{f, r}(), k.n)) {
+      const unsigned long long prev = atomicMin(&bk->key, me);
+      const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
+      t.first_dup = late < t.first_dup ? late : t.first_dup;
+      return;
+    }
+  }
+  atomicOr(&call->table_full, 1u);
+}
+
+// Find the name of frame-local record r of the asking file and take its entry.  The whole bucket is fetched at once:
+// key, claim and name bytes arrive in one round trip.  slot_of[r] (optional) remembers where the name was found.
+__device__ __forceinline__ void match_name(const IndexView& ix, const NameKey& k, bool at_sign, const FrameView& f, uint64_t r,
+                                           uint64_t asker_base, unsigned long long* __restrict__ slot_of, IndexTally& t) {
+  ++t.seen;
+  if (slot_of) slot_of[r] = at_sign ? kSlotEmpty : kSlotEmpty - 1;
+  if (!at_sign) {
+    t.first_wrong = r < t.first_wrong ? r : t.first_wrong;
+    return;
+  }
+  const unsigned long long g2 = asker_base + r;
+  uint64_t at = k.h & ix.mask;
+  for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
+    NameBucket* bk = ix.buckets + at;
+    const u64x2_t* src = reinterpret_cast<const u64x2_t*>(bk);
+    const u64x2_t a = src[0], b = src[1], c = src[2], d = src[3];
+    if (a.x == kSlotEmpty) break;
+    if ((a.x >> 40) != (k.h >> 40)) continue;
+    const unsigned long long diff =
+        (b.x ^ k.nm[0]) | (b.y ^ k.nm[1]) | (c.x ^ k.nm[2]) | (c.y ^ k.nm[3]) | (d.x ^ k.nm[4]) | (d.y ^ k.nm[5]);
+    if (diff) continue;
+    // (names hold no NUL byte: equal padded words of a name shorter than 48 bytes mean equal names)
+    if (k.n >= kNameInline && !stored_name_is(ix, a.x & kIdxMask, NameAt{f, r}(), k.n)) continue;
+    // the smallest asker gets the entry; every other asker is what the serial loop would have found missing
+    // after the delete.  An asker of an EARLIER piece is smaller than every record of this one, so `late`
+    // always lies in this piece.
+    const unsigned long long prev = atomicMin(&bk->claim, g2);
+    if (prev == kSlotEmpty) ++t.matched;
+    else {
+      const unsigned long long late = (prev > g2 ? prev : g2) - asker_base;
+      t.first_missing = late < t.first_missing ? late : t.first_missing;
+    }
+    if (slot_of) slot_of[r] = at;
+    return;
+  }
+  t.first_missing = r < t.first_missing ? r : t.first_missing;
+}
+
+// fold a thread's tally into the call's scalars: minima straight away (rare), sums once per workgroup (the wavefronts of
+// a grid finish together: tens of thousands of adds to a few addresses)
+__device__ __forceinline__ void tally_flush(IndexTally& t, IndexCall* __restrict__ call) {
+  if (t.first_dup != kNoRecord) atomicMin(&call->first_dup, t.first_dup);
+  if (t.first_wrong != kNoRecord) atomicMin(&call->first_wrong, t.first_wrong);
+  if (t.first_missing != kNoRecord) atomicMin(&call->first_missing, t.first_missing);
+  unsigned long long v[5] = {t.inserted, t.matched, t.name_bytes, t.seen, t.captured};
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] += __shfl_down(v[i], d, 64);
+  __shared__ unsigned long long s_sum[kBlock / kWave][5];
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s_sum[threadIdx.x >> 6][i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long a = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) a += s_sum[w][threadIdx.x];
+    unsigned long long* dst = threadIdx.x == 0   ? &call->inserted
+                              : threadIdx.x == 1 ? &call->matched
+                              : threadIdx.x == 2 ? &call->name_bytes
+                              : threadIdx.x == 3 ? &call->seen
+                                                 : &call->captured;
+    if (a) atomicAdd(dst, a);
+  }
+}
+
+// ---- through the line index: one thread per record of the frame (frames that were not streamed, re-inserts) ----
 __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView ix, uint64_t record_base,
                                                          IndexCall* __restrict__ call) {
-  unsigned long long my_first_dup = kNoRecord, my_first_wrong = kNoRecord, inserted = 0, name_bytes = 0;
+  IndexTally t;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
-    const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
-    const uint64_t e = f.line_end[4 * r];
-    uint32_t acct;
-    uint64_t h;
+    NameKey k;
     bool at_sign;
-    const uint32_t n = name_and_hash(f.img, f.nbytes, b, e, ix.fmt, ix.is_pe, ix.may_have_nul, &acct, &h, &at_sign);
-    if (!at_sign) {  // fastq_get_readname refuses it (src/fastq.c:448)
-      my_first_wrong = r < my_first_wrong ? r : my_first_wrong;
-      continue;
-    }
-    const unsigned long long g = record_base + r;
-    const unsigned long long mine = ((h >> 40) << 40) | g;
-    uint64_t at = h & ix.mask;
-    bool done = false;
-    for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
-      // one round trip when the slot is free (most are: the table is at most half full)
-      const unsigned long long cur = atomicCAS(&ix.slots[at], kSlotEmpty, mine);
-      if (cur == kSlotEmpty) {
-        ++inserted;
-        name_bytes += acct;
-        done = true;
-        break;
-      }
-      if ((cur >> 40) == (mine >> 40)) {
-        // (a name whose fingerprint is already in the table - a duplicate, a collision - is rare here: the byte-wise
-        // confirmation keeps this kernel at 70 VGPRs; stored_name_equals, with both header lines in registers, is for
-        // the pass in which EVERY record finds its name)
-        const uint8_t* other;
-        uint32_t on;
-        if (stored_name(ix, cur & kIdxMask, &other, &on) && on == n && same_bytes(other, f.img + b + 1, n)) {
-          const unsigned long long prev = atomicMin(&ix.slots[at], mine);
-          const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
-          my_first_dup = late < my_first_dup ? late : my_first_dup;
-          done = true;
-          break;
-        }
-      }
-    }
-    if (!done) atomicOr(&call->table_full, 1u);
+    name_from_image(f, r, ix.fmt, ix.is_pe, ix.may_have_nul, k, &at_sign);
+    insert_name(ix, k, at_sign, f, r, record_base, t, call);
   }
-  if (my_first_dup != kNoRecord) atomicMin(&call->first_dup, my_first_dup);
-  if (my_first_wrong != kNoRecord) atomicMin(&call->first_wrong, my_first_wrong);
-  // wave-level sums before touching the global counters
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    inserted += __shfl_down(inserted, d, 64);
-    name_bytes += __shfl_down(name_bytes, d, 64);
-  }
-  // one add per workgroup (the wavefronts of a grid finish together: tens of thousands of adds to two addresses)
-  __shared__ unsigned long long s_ins[kBlock / kWave], s_nb[kBlock / kWave];
-  if ((threadIdx.x & 63) == 0) {
-    s_ins[threadIdx.x >> 6] = inserted;
-    s_nb[threadIdx.x >> 6] = name_bytes;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long a = 0, b = 0;
-    for (int w = 0; w < kBlock / kWave; ++w) {
-      a += s_ins[w];
-      b += s_nb[w];
-    }
-    if (a) {
-      atomicAdd(&call->inserted, a);
-      atomicAdd(&call->name_bytes, b);
-    }
-  }
+  tally_flush(t, call);
 }
 
-// One thread per record of the (file-2) frame: find the name, claim its slot.  claims[] holds the GLOBAL index
+// One thread per record of the (file-2) frame: find the name, claim its entry.  claim holds the GLOBAL index
 // (asker_base + r: the pieces of the asking file share the index) of the smallest asker; slot_of[r] (optional)
 // remembers where record r found its name (kSlotEmpty: nowhere) for k_index_probe_resolve.
 __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, IndexView ix, int fmt2, int is_pe2,
                                                                int may_have_nul2, uint64_t asker_base,
                                                                unsigned long long* __restrict__ slot_of,
                                                                IndexCall* __restrict__ call) {
-  unsigned long long my_missing = kNoRecord, my_wrong = kNoRecord, matched = 0;
+  IndexTally t;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < f.n_records; r += stride) {
-    const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
-    const uint64_t e = f.line_end[4 * r];
-    uint32_t acct;
-    uint64_t h;
+    NameKey k;
     bool at_sign;
-    const uint32_t n = name_and_hash(f.img, f.nbytes, b, e, fmt2, is_pe2, may_have_nul2, &acct, &h, &at_sign);
-    if (slot_of) slot_of[r] = at_sign ? kSlotEmpty : kSlotEmpty - 1;
-    if (!at_sign) {
-      my_wrong = r < my_wrong ? r : my_wrong;
-      continue;
-    }
-    const unsigned long long g2 = asker_base + r;
-    uint64_t at = h & ix.mask;
-    bool found = false;
-    for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
-      const unsigned long long cur = ix.slots[at];
-      if (cur == kSlotEmpty) break;
-      if ((cur >> 40) == (h >> 40)) {
-        if (stored_name_equals(ix, cur & kIdxMask, f.img + b, (uint32_t)(e - b) + (e < f.nbytes ? 1u : 0u), f.nbytes - b, fmt2,
-                               is_pe2, may_have_nul2, n)) {
-          // the smallest asker gets the entry; every other asker is what the serial loop would
-          // have found missing after the delete.  An asker of an EARLIER piece is smaller than every
-          // record of this one, so `late` always lies in this piece.
-          const unsigned long long prev = atomicMin(&ix.claims[at], g2);
-          if (prev == kSlotEmpty) ++matched;
-          else {
-            const unsigned long long late = (prev > g2 ? prev : g2) - asker_base;
-            my_missing = late < my_missing ? late : my_missing;
-          }
-          if (slot_of) slot_of[r] = at;
-          found = true;
-          break;
-        }
-      }
-    }
-    if (!found) my_missing = r < my_missing ? r : my_missing;
+    name_from_image(f, r, fmt2, is_pe2, may_have_nul2, k, &at_sign);
+    match_name(ix, k, at_sign, f, r, asker_base, slot_of, t);
   }
-  if (my_missing != kNoRecord) atomicMin(&call->first_missing, my_missing);
-  if (my_wrong != kNoRecord) atomicMin(&call->first_wrong, my_wrong);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) matched += __shfl_down(matched, d, 64);
-  if ((threadIdx.x & 63) == 0 && matched) atomicAdd(&call->matched, matched);
+  tally_flush(t, call);
 }
 
-// After k_index_match_delete: match[r] = global index (insertion order) of the entry record r took, or kNoRecord
+// ---- from the capture records of the streaming pass ----------------------------------------------
+// One thread per record SLOT (chunk c, ordinal j < K).  A chunk whose speculated line type was the true one and that
+// saw at most K headers is taken from its records; the headers of every other chunk are enumerated by rank - the
+// records whose header starts behind one of the chunk's newlines (or behind the last byte of the chunk before) - and
+// read through the line index.  Every record of the frame is met exactly once (the call's `seen` is checked).
+struct NamesView {
+  const unsigned long long* recs;
+  const uint16_t* hcount;
+  const uint32_t* cinfo;
+  ChunkRanks cr;
+  uint32_t K, k_shift;  // K = 1 << k_shift record slots per chunk
+};
+
+template <bool MATCH>
+__global__ __launch_bounds__(kBlock) void k_names_pass(FrameView f, NamesView nv, IndexView ix, int fmt, int is_pe,
+                                                       uint64_t base /* record_base or asker_base */,
+                                                       unsigned long long* __restrict__ slot_of,
+                                                       IndexCall* __restrict__ call) {
+  IndexTally t;
+  const uint64_t n_slots = (uint64_t)nv.cr.n_chunks << nv.k_shift;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < n_slots; s += stride) {
+    const uint32_t c = (uint32_t)(s >> nv.k_shift), j = (uint32_t)s & (nv.K - 1u);
+    const uint32_t hc = nv.hcount[c], info = nv.cinfo[c];
+    const uint64_t rank0 = nv.cr.rank0(c);
+    const bool trusted = hc != kNoCapture && hc <= nv.K && !(info & (kInfoUnknown | kInfoOneLine)) && (info & 3u) == ((uint32_t)rank0 & 3u);
+    if (trusted) {
+      if (j >= hc) continue;
+      unsigned long long w[kNameRecWords];
+      const u64x2_t* src = reinterpret_cast<const u64x2_t*>(nv.recs + s * kNameRecWords);
+#pragma unroll
+      for (uint32_t i = 0; i < kNameRecWords / 2; ++i) {
+        const u64x2_t x = __builtin_nontemporal_load(src + i);
+        w[2 * i] = x.x;
+        w[2 * i + 1] = x.y;
+      }
+      NameKey k;
+      bool at_sign;
+      uint32_t v;
+      const bool ok = name_from_record(w, fmt, is_pe, k, &at_sign, &v);
+      const uint64_t r = (rank0 + v) >> 2;  // (rank0 + v = 4 r: the line behind newline 4 r - 1)
+      if (r >= f.n_records) continue;        // a header of the incomplete tail
+      if (ok) ++t.captured;
+      else name_from_image(f, r, fmt, is_pe, 0, k, &at_sign);
+      if (MATCH) match_name(ix, k, at_sign, f, r, base, slot_of, t);
+      else insert_name(ix, k, at_sign, f, r, base, t, call);
+    } else {
+      // records r with 4 r in [rank0, rank0 + count]: their header starts behind a newline of this chunk or behind the
+      // last byte of the chunk before; the one that starts in THIS chunk is this chunk's
+      const uint64_t r_lo = (rank0 + 3) >> 2, r_hi = (rank0 + nv.cr.counts[c]) >> 2;
+      for (uint64_t r = r_lo + j; r <= r_hi && r < f.n_records; r += nv.K) {
+        const uint64_t start = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+        if ((uint32_t)(start / kChunkBytes) != c) continue;
+        NameKey k;
+        bool at_sign;
+        name_from_image(f, r, fmt, is_pe, 0, k, &at_sign);
+        if (MATCH) match_name(ix, k, at_sign, f, r, base, slot_of, t);
+        else insert_name(ix, k, at_sign, f, r, base, t, call);
+      }
+    }
+  }
+  tally_flush(t, call);
+}
+
+// After a matching pass: match[r] = global index (insertion order) of the entry record r took, or kNoRecord
 // when its name is not in the index or an earlier asker took it (src/fastq_filterpair.c:150-170: lookup, then
 // fastq_index_delete)
 __global__ __launch_bounds__(kBlock) void k_index_probe_resolve(uint64_t n, const unsigned long long* __restrict__ slot_of,
@@ -431,16 +584,16 @@ __global__ __launch_bounds__(kBlock) void k_index_probe_resolve(uint64_t n, cons
   if (r >= n) return;
   const unsigned long long at = slot_of[r];
   if (at >= kSlotEmpty - 1) match[r] = at;  // not in the index / no '@' (FQG_NO_MATCH / FQG_MATCH_WRONG_HEADER)
-  else match[r] = ix.claims[at] == asker_base + r ? (ix.slots[at] & kIdxMask) : kNoRecord;
+  else match[r] = ix.buckets[at].claim == asker_base + r ? (ix.buckets[at].key & kIdxMask) : kNoRecord;
 }
 // alive[g] = 1 for every inserted record g whose entry nobody has taken (the table still holds it)
 __global__ __launch_bounds__(kBlock) void k_index_alive(IndexView ix, uint64_t n_records, uint8_t* __restrict__ alive) {
   const uint64_t at = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (at > ix.mask) return;
-  const unsigned long long cur = ix.slots[at];
-  if (cur == kSlotEmpty) return;
-  const unsigned long long g = cur & kIdxMask;
-  if (g < n_records) alive[g] = (!ix.claims || ix.claims[at] == kSlotEmpty) ? 1 : 0;
+  const u64x2_t kc = *reinterpret_cast<const u64x2_t*>(ix.buckets + at);
+  if (kc.x == kSlotEmpty) return;
+  const unsigned long long g = kc.x & kIdxMask;
+  if (g < n_records) alive[g] = kc.y == kSlotEmpty ? 1 : 0;
 }
 
 // Names of paired records must be equal: record 2k against 2k+1 of one frame (interleaved

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_boot(const uint8_t* __restric
     total += s_cnt[w];
   }
   const uint32_t limit = total & ~3u;
+  if (threadIdx.x == 0) cs->boot_lines = total;
   uint32_t line = before, qmin = 255, qmax = 0;
   for (uint32_t o = 0; o < part; o += kWave) {
     const uint32_t c = p[o + lane];
@@ -176,12 +177,18 @@ struct Piece32 {
 __device__ __forceinline__ uint32_t lds_chunk_addr(uint32_t o) {  // byte o of the chunk -> its place in the copy
   return (o & 0x800u) | ((o & 0x10u) << 6) | ((o >> 1) & 0x3F0u) | (o & 0xFu);
 }
+// The name-capturing instantiation keeps the copy in image order instead (header lines are read from it 8 bytes at a
+// time at any alignment), kCopyFront bytes of slack in front of it and kCopyBack behind: a header's 64-byte window
+// starts 3 bytes before its '@' and may reach past the chunk.  (Its 16-byte stores then meet two-way bank conflicts,
+// which the store's own issue time covers.)
+constexpr uint32_t kCopyFront = 16, kCopyBack = 64;
+constexpr uint32_t kCopyRow = kCopyFront + kChunkBytes + kCopyBack;
 
 __device__ __forceinline__ uint32_t stage_entry(uint32_t ent, uint32_t c1) {
   return ent | ((c1 == '@' ? kClsAt : (c1 == '+' ? kClsPlus : 0u)) << 12);
 }
 
-template <uint32_t ABL>
+template <uint32_t ABL, bool LINEAR>
 __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
                                             const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
                                             const uint32_t (&ex)[kHalves], uint32_t tot,
@@ -206,7 +213,7 @@ __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uin
     const uint32_t o = (ent & 0xFFFu) + 1;  // the byte after the '\n'
     uint32_t c1 = 0;
     if (!(ABL & 4u)) {
-      if (interior) c1 = o < (uint32_t)kChunkBytes ? (uint32_t)copy[lds_chunk_addr(o)] : (tail & 0xFFu);
+      if (interior) c1 = o < (uint32_t)kChunkBytes ? (uint32_t)copy[LINEAR ? o : lds_chunk_addr(o)] : (tail & 0xFFu);
       else c1 = cb + o < n ? (uint32_t)img[cb + o] : 0u;
     }
     dst[i] = (uint16_t)stage_entry(ent, c1);
@@ -215,15 +222,18 @@ __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uin
 
 // ABL: ablation mask for tools/kbench (product code instantiates 0): 1 = no byte-class checks,
 // 2 = no staging, 4 = no fetch of the byte after a newline, 8 = no base check, 16 = no quality test
-template <uint32_t ABL>
+// NAMES: also capture the header lines that begin in the chunk (NameCapture, fqg_device.h)
+template <uint32_t ABL, bool NAMES = false>
 __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restrict__ img, uint64_t n,
                                                          uint32_t n_chunks, StreamOut o,
-                                                         CallState* __restrict__ cs) {
+                                                         CallState* __restrict__ cs, NameCapture nc = NameCapture{}) {
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
+  static_assert(!NAMES || !(ABL & 7u), "the name capture needs the speculation, the staged entries and the copy");
   __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
-  __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][kChunkBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][NAMES ? kCopyRow : (uint32_t)kChunkBytes];
   // (the wave index is uniform: telling the compiler keeps chunk-level values in scalar registers)
   const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* const copy = s_copy[wv] + (NAMES ? kCopyFront : 0u);
   const uint32_t chunk = blockIdx.x * (kBlock / kWave) + wv;
   if (chunk >= n_chunks) return;
   const uint64_t cb = (uint64_t)chunk * kChunkBytes;
@@ -234,9 +244,11 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
   uint32_t flags = 0;
 
   uint32_t tail = 0;  // the 4 bytes after the chunk (look-ahead of the last lane)
+  uint32_t prev = '\n';  // NAMES: the byte in front of the chunk (the image starts behind a virtual newline)
   const uint32_t boot_lo = cs->boot_qmin, boot_hi = cs->boot_qmax;
   if (interior) {
     tail = *reinterpret_cast<const uint32_t*>(img + cb + kChunkBytes);
+    if (NAMES && chunk) prev = *reinterpret_cast<const uint32_t*>(img + cb - 4) >> 24;
 #pragma unroll
     for (int k = 0; k < kHalves; ++k) {
       v[k].a = *reinterpret_cast<const uint4*>(img + wb + (uint64_t)k * kHalfBytes);
@@ -245,8 +257,13 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     if (!(ABL & 6u)) {
 #pragma unroll
       for (int k = 0; k < kHalves; ++k) {
-        *reinterpret_cast<uint4*>(&s_copy[wv][k * kHalfBytes + lane * 16]) = v[k].a;
-        *reinterpret_cast<uint4*>(&s_copy[wv][k * kHalfBytes + kHalfBytes / 2 + lane * 16]) = v[k].b;
+        if (NAMES) {
+          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes]) = v[k].a;
+          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes + 16]) = v[k].b;
+        } else {
+          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * 16]) = v[k].a;
+          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + kHalfBytes / 2 + lane * 16]) = v[k].b;
+        }
       }
     }
     uint32_t okacc = kH, hiacc = 0;
@@ -330,10 +347,10 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
   const uint32_t tot = total < (uint32_t)kStageCap ? total : (uint32_t)kStageCap;
 
   uint32_t info = kInfoUnknown;
+  bool found = false;  // a line type was speculated
+  uint32_t t0 = 0;     // ... for the chunk's first byte
   if (!(ABL & 1u) && interior && !(flags & kFlagHigh)) {
     // ---- speculation: the first line of exactly one byte is taken for a "+" line (type 2) ----
-    bool found = false;
-    uint32_t t0 = 0;
 #pragma unroll
     for (int k = 0; k < kHalves; ++k) {
       const uint64_t bal = __ballot(cand[k] != 0);
@@ -435,7 +452,51 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     }
   }
 
-  if (!(ABL & 2u)) stage_chunk<ABL>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], s_copy[wv], tail, o.stage, interior);
+  if (!(ABL & 2u)) stage_chunk<ABL, NAMES>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], copy, tail, o.stage, interior);
+  if constexpr (NAMES) {
+    // ---- header lines that begin in this chunk -> 64-byte records (NameCapture) ----
+    // Line starts: the chunk's first byte when the byte in front of it is a '\n' (v = 0), and the byte behind the
+    // chunk's v-th newline unless that newline is the chunk's last byte; the line that starts at v has type t0 + v.
+    uint32_t hc = kNoCapture;
+    if (found && total <= (uint32_t)kStageCap) {
+      hc = 0;
+      const uint16_t* slots = s_slots[wv];
+      const bool first_is_start = prev == '\n';
+      for (uint32_t base = 0; base <= tot; base += kWave) {
+        const uint32_t vv = base + (uint32_t)lane;
+        bool is_hdr = vv <= tot && ((t0 + vv) & 3u) == 0u && (vv > 0 || first_is_start);
+        uint32_t at = 0;
+        if (is_hdr && vv > 0) {
+          at = (slots[vv - 1] & 0xFFFu) + 1u;
+          is_hdr = at < (uint32_t)kChunkBytes;
+        }
+        const unsigned long long hm = __ballot(is_hdr);
+        const uint32_t j = hc + (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
+        hc += (uint32_t)__builtin_popcountll(hm);
+        if (is_hdr && j < nc.K) {
+          const bool end_known = vv < tot;
+          uint32_t len = (end_known ? (uint32_t)(slots[vv] & 0xFFFu) : (uint32_t)kChunkBytes) - at;
+          len = len > 1023u ? 1023u : len;
+          unsigned long long w[kNameRecWords];
+#pragma unroll
+          for (uint32_t k = 0; k < kNameRecWords; ++k) __builtin_memcpy(&w[k], copy + at + 8u * k - 3u, 8);  // byte 3 = the line's first byte
+          const uint32_t meta = len | (vv << 10) | (end_known ? 1u << 19 : 0u) | (((w[0] >> 24) & 0xFFu) == '@' ? 1u << 20 : 0u);
+          w[0] = (w[0] & 0xFFFFFFFF00000000ull) | meta;
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          u64x2* dst = reinterpret_cast<u64x2*>(nc.recs + ((uint64_t)chunk * nc.K + j) * kNameRecWords);
+#pragma unroll
+          for (uint32_t k = 0; k < kNameRecWords / 2; ++k) {
+            u64x2 x;
+            x.x = w[2 * k];
+            x.y = w[2 * k + 1];
+            dst[k] = x;
+          }
+        }
+      }
+      if (hc >= kNoCapture) hc = kNoCapture - 1u;
+    }
+    if (lane == 0) nc.hcount[chunk] = (uint16_t)hc;
+  }
   if (lane == 0) {
     o.counts[chunk] = total;
     o.cinfo[chunk] = info;

@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
     probe_piece(pr2, in2.data(), in2.size(), 1);
     fqg_validate_result r2;
     LIB(fqg_validate(g_ctx, nullptr, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st,
-                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS, &r2));
+                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | FQG_VALIDATE_NAMES, &r2));
     if (r2.code == FQG_E_LINE_TOO_LONG) fail_too_long(path2, r2.record);
     const uint64_t n2 = r2.n_records;
     std::vector<uint64_t> match(n2 ? n2 : 1), p1, p2, u2;

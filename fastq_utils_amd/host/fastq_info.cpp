@@ -221,7 +221,7 @@ void run_pair_second_file(const char* path1, const char* path2, Stats& S, Indexe
     probe_piece(pr2, in.data(), in.size(), 1);
     fqg_validate_result r;
     // file-2 records are validated against file 1's state and counters (src/fastq_info.c:345)
-    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &F.st, 0, &r));
+    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &F.st, FQG_VALIDATE_NAMES, &r));
     fqg_index_result ir{};
     ir.n_entries = F.entries;
     if (r.n_records > 0) LIB(fqg_index_match_delete(g_ctx, F.index, &pr2.st, &ir));

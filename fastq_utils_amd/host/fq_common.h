@@ -240,7 +240,7 @@ void run_index_input(Input& in, const char* path, int is_pe, Stats& S, IndexedFi
     probe_piece(pr, in.data(), in.size(), is_pe);
     fqg_validate_result r;
     LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st,
-                     FQG_VALIDATE_COUNT_TWICE, &r));
+                     FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES, &r));
     fqg_index_result ir{};
     if (r.n_records > 0) LIB(fqg_index_insert_unique(g_ctx, F.index, &pr.st, &ir));
     // which finding does the serial loop hit first?  per record: read (truncation), name

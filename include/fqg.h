@@ -139,6 +139,11 @@ typedef struct {
 #define FQG_VALIDATE_FRAME_ONLY 8u  /* build the line index only: no checks, no statistics (inputs that the
                                        caller vouches for, src/fastq_pre_barcodes.c:541-543) */
 #define FQG_VALIDATE_TWO_PASS 16u    /* never take the single-pass (streaming) framing path */
+#define FQG_VALIDATE_NAMES 32u      /* the names of this image go to an index next (fqg_index_insert_unique,
+                                       fqg_index_match_delete, fqg_index_probe_delete on the frame this call leaves): the
+                                       single-pass framing also copies every header line into a 64-byte record while the
+                                       bytes are on the chip, and the index calls work from those records instead of going
+                                       back to the image.  Results are the same with or without it. */
 #define FQG_VALIDATE_COUNT_TWICE 4u /* every record counts twice in acc: the index loop runs
                                        fastq_new_entry_stats in both fastq_read_next_entry and
                                        fastq_validate_entry (src/fastq.c:415,432) */
@@ -213,6 +218,10 @@ int fqg_index_probe_delete(fqg_ctx *ctx, fqg_index *index, const fqg_file_state 
 /* alive[g] = 1 for every inserted record g (insertion order) whose entry nobody has taken yet: what a lookup of
  * the file's own names finds after the pairing loop (src/fastq_filterpair.c:196-216); cap >= records inserted */
 int fqg_index_alive(fqg_ctx *ctx, fqg_index *index, uint8_t *alive, uint64_t cap);
+/* Of the last fqg_index_insert_unique / _match_delete / _probe_delete call on this context: how many records had their
+ * name taken straight from a capture record of the streaming pass (FQG_VALIDATE_NAMES); the rest went through the line
+ * index.  A measurement / test aid: results do not depend on it. */
+uint64_t fqg_index_names_captured(const fqg_ctx *ctx);
 /* the frames an index has retained, in insertion order (borrowed: they live as long as the index) */
 uint64_t fqg_index_n_frames(const fqg_index *index);
 const fqg_frame *fqg_index_frame(const fqg_index *index, uint64_t k);

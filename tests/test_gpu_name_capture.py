@@ -1,0 +1,218 @@
+"""The read-name kernels work from the header records that the streaming pass captures (FQG_VALIDATE_NAMES:
+k_stream_pass1<names> -> k_names_pass, fqg_index_kernels.hip) and go through the line index for every header the
+capture cannot vouch for.  Both ways must give what the reference's serial loops give (src/fastq.c:396-439,
+src/fastq_info.c:333-362, src/fastq_filterpair.c:108-216).  Small files do not reach the streaming pass on their own, so
+everything here runs with FQGPU_STREAM_MIN=256; inputs are built to land on each seam of the capture: chunks whose
+speculated line type is wrong, chunks with more headers than record slots, header lines that straddle a chunk, lines
+longer than a record holds, names of 48 bytes and more (the bucket carries 48), duplicates whose copies arrive by
+different ways, a name asked for twice across two pieces of the second file."""
+import gzip
+import os
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import fastq_utils_amd as fq
+from oracle import loader as orc
+from tests import fuzz
+from tests.test_gpu_cli import GOLDEN, compare_with_oracle, run_cli
+from tests.util import GOLD, REPO, strip_progress
+
+pytestmark = pytest.mark.gpu
+STREAM = {"FQGPU_STREAM_MIN": "256"}
+PIECES = {"FQGPU_STREAM_MIN": "256", "FQGPU_CHUNK_MB": "1"}
+FILTERPAIR = os.path.join(REPO, "bin", "fastq_filterpair")
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rec(name, rng, ln):
+    s = BASES[rng.integers(0, 4, ln)].tobytes()
+    q = (rng.integers(5, 40, ln) + 33).astype(np.uint8).tobytes()
+    return b"@" + name + b"\n" + s + b"\n+\n" + q + b"\n"
+
+
+def write(tmp, files):
+    for k, v in files.items():
+        with open(os.path.join(tmp, k), "wb") as f:
+            f.write(v)
+
+
+def test_golden_index_and_pairing_invocations_with_the_capture():
+    """every golden invocation that builds an index (no -r), streamed"""
+    cases = [c for c in GOLDEN if "-r" not in c["args"]]
+    assert len(cases) > 200
+
+    def one(case):
+        rc, out, err = run_cli(case["args"], GOLD, STREAM)
+        ok = (rc == case["exit"] and out == case["stdout"] and strip_progress(err) == strip_progress(case["stderr"]))
+        return None if ok else (case["args"], rc, case["exit"], err[-400:], case["stderr"][-400:])
+
+    with ThreadPoolExecutor(8) as ex:
+        bad = [b for b in ex.map(one, cases) if b]
+    assert not bad, f"{len(bad)} of {len(cases)} differ; first: {bad[:3]}"
+
+
+@pytest.mark.parametrize("kind", fuzz.MUTATIONS)
+def test_mutated_files(kind):
+    rng = np.random.default_rng(abs(hash("cap" + kind)) % 100000)
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(4):
+            style = ["casava", "slash", "int", "nosuffix"][trial % 4]
+            img = fuzz.make_fastq(rng, int(rng.integers(40, 600)), 1, 120, style, hdr2_names=bool(trial & 1), rna=(trial == 2))
+            img = fuzz.mutate(rng, img, kind)
+            write(tmp, {"f.fastq": img})
+            for args in (["f.fastq"], ["f.fastq", "pe"]):
+                compare_with_oracle(tmp, args, {"f.fastq": img}, STREAM)
+
+
+def test_duplicates_and_pairs():
+    rng = np.random.default_rng(55)
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(10):
+            style = ["casava", "slash"][trial % 2]
+            n = int(rng.integers(200, 3000))
+            a = fuzz.make_fastq(np.random.default_rng(trial), n, 1, 90, style, mate=1)
+            b = fuzz.make_fastq(np.random.default_rng(trial), n, 1, 90, style, mate=2)
+            la, lb = a.split(b"\n"), b.split(b"\n")
+            k = int(rng.integers(0, n))
+            if trial % 5 == 1:  # a record of file 1 three times ("earliest repeat")
+                la = la[:-1] + la[4 * k:4 * k + 4] + la[4 * k:4 * k + 4] + [b""]
+            if trial % 5 == 2:  # a record missing from file 2
+                lb = lb[:4 * k] + lb[4 * k + 4:]
+            if trial % 5 == 3:  # file 2 in another order (still paired)
+                recs = [lb[4 * i:4 * i + 4] for i in range(n)]
+                lb = [x for i in rng.permutation(n) for x in recs[i]] + [b""]
+            if trial % 5 == 4:  # a name twice in file 2
+                lb = lb[:-1] + lb[4 * k:4 * k + 4] + [b""]
+            files = {"a.fastq": b"\n".join(la), "b.fastq": b"\n".join(lb)}
+            write(tmp, files)
+            for args in (["a.fastq"], ["a.fastq", "b.fastq"], ["b.fastq", "a.fastq"]):
+                compare_with_oracle(tmp, args, files, STREAM)
+                compare_with_oracle(tmp, args, files, PIECES)
+
+
+def names_of_every_kind(rng, n, mate=1):
+    """records whose headers land on every branch of the capture: short and 50-70 byte names (the bucket holds 48, the
+    record 60), Casava headers whose blank lies beyond the record, headers of several hundred bytes, reads of one base
+    (their sequence line looks like a '+' line: the chunk's speculated type is wrong) and runs of very short records (more
+    headers in a chunk than record slots)"""
+    out = []
+    for i in range(n):
+        kind = i % 11
+        if kind == 0:
+            name = b"N%d:%s %d:N:0:A" % (i, b"x" * int(rng.integers(30, 70)), mate)   # name of 32..72 bytes, then the blank
+        elif kind == 1:
+            name = b"L%d:%s %d:N:0:A" % (i, b"y" * int(rng.integers(100, 400)), mate)  # beyond the register path too
+        elif kind == 2:
+            name = b"S%d %d:N:0:%s" % (i, mate, b"C" * int(rng.integers(0, 200)))      # short name, long comment
+        elif kind == 3:
+            name = b"T%d:%s/%d %d:N:0:A" % (i, b"z" * int(rng.integers(0, 50)), mate, mate)  # Casava with a /1 in front of the blank
+        else:
+            name = b"R:%d:%d %d:N:0:ACGT" % (i % 7, i, mate)
+        ln = 1 if (i % 97) == 5 else (int(rng.integers(1, 6)) if (i // 200) % 3 == 1 else int(rng.integers(20, 160)))
+        out.append(rec(name, rng, ln))
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_every_seam_of_the_capture(seed):
+    rng = np.random.default_rng(seed)
+    n = 6000
+    r1 = names_of_every_kind(np.random.default_rng(seed), n, 1)
+    r2 = names_of_every_kind(np.random.default_rng(seed), n, 2)
+    dup = list(r1)
+    k = int(rng.integers(0, n))
+    dup.insert(int(rng.integers(k + 1, n)), r1[k])
+    perm = rng.permutation(n)
+    files = {"a.fastq": b"".join(r1), "b.fastq": b"".join(r2), "d.fastq": b"".join(dup),
+             "s.fastq": b"".join(r2[i] for i in perm), "m.fastq": b"".join(r2[:k] + r2[k + 1:])}
+    with tempfile.TemporaryDirectory() as tmp:
+        write(tmp, files)
+        for env in (STREAM, PIECES):
+            for args in (["a.fastq"], ["d.fastq"], ["a.fastq", "b.fastq"], ["a.fastq", "s.fastq"], ["a.fastq", "m.fastq"],
+                         ["m.fastq", "a.fastq"]):
+                compare_with_oracle(tmp, args, files, env)
+
+
+@pytest.mark.parametrize("style", ["slash", "nosuffix", "int"])
+def test_names_that_are_the_whole_line(style):
+    """not Casava: the name runs to the end of the line, so a line longer than the record goes through the line index"""
+    n = 4000
+    pad = lambda i: b"p" * (0 if i % 3 else 40 + (i * 7919) % 50)  # noqa: E731  (the same for both mates of a read)
+
+    def name(i, mate):
+        if style == "slash":
+            return b"read%s.%d/%d" % (pad(i), i, mate)
+        if style == "int":
+            return b"%d" % (10 ** 70 + i if i % 5 == 0 else i)
+        return b"read%s_%d_x" % (pad(i), i)
+
+    rngs = [np.random.default_rng(3), np.random.default_rng(3)]
+    a = b"".join(rec(name(i, 1), rngs[0], int(rngs[0].integers(10, 120))) for i in range(n))
+    b = b"".join(rec(name(i, 2), rngs[1], int(rngs[1].integers(10, 120))) for i in range(n))
+    files = {"a.fastq": a, "b.fastq": b}
+    with tempfile.TemporaryDirectory() as tmp:
+        write(tmp, files)
+        for args in (["a.fastq"], ["a.fastq", "b.fastq"]):
+            compare_with_oracle(tmp, args, files, PIECES)
+
+
+def test_a_file2_name_asked_twice_across_two_pieces():
+    """the second copy of a file-2 record arrives in a later 1 MiB piece than the first: the entry was taken by an asker
+    of an earlier piece, so the later one is the record the serial loop stops at (src/fastq_info.c:338)"""
+    a = fuzz.make_fastq(np.random.default_rng(1), 30000, 50, 150, "casava", mate=1)
+    b = fuzz.make_fastq(np.random.default_rng(1), 30000, 50, 150, "casava", mate=2)
+    lb = b.split(b"\n")
+    twice = lb[4 * 100:4 * 100 + 4]
+    d2 = b"\n".join(lb[:4 * 25000] + twice + lb[4 * 25000:])   # record 100 again as record 25000 (piece 6 or so)
+    files = {"a.fastq": a, "d2.fastq": d2}
+    with tempfile.TemporaryDirectory() as tmp:
+        write(tmp, files)
+        for env in ({"FQGPU_CHUNK_MB": "1"}, PIECES):
+            compare_with_oracle(tmp, ["a.fastq", "d2.fastq"], files, env)
+            want = orc.fastq_filterpair(a, "a.fastq", d2, "d2.fastq")
+            p = subprocess.run([FILTERPAIR, "a.fastq", "d2.fastq", "p1.fastq.gz", "p2.fastq.gz", "up.fastq.gz"], cwd=tmp,
+                               capture_output=True, timeout=300, env=dict(os.environ, **env))
+            assert p.returncode == want["exit"], p.stderr[-400:]
+            assert strip_progress(p.stderr.decode("latin-1")) == strip_progress(want["stderr"])
+            for k, name in enumerate(("p1", "p2", "up")):
+                assert gzip.decompress(open(os.path.join(tmp, name + ".fastq.gz"), "rb").read()) == want["files"][k], name
+
+
+def test_the_capture_is_what_runs():
+    """on regular reads nearly every name comes from a capture record (the exceptions: headers that straddle a chunk),
+    and the finding is the oracle's either way"""
+    os.environ["FQGPU_STREAM_MIN"] = "256"
+    try:
+        rng = np.random.default_rng(8)
+        n = 20000
+        img = fuzz.make_fastq(rng, n, 100, 150, "casava")
+        lines = img.split(b"\n")
+        dup = b"\n".join(lines[:-1] + lines[4 * 4321:4 * 4321 + 4] + [b""])
+        with fq.Context(0) as ctx:
+            for image, want_code in ((img, 0), (dup, 3)):  # 3 = FQG_E_DUP_NAME
+                st = fq.abi.probe_first_record(image, False)
+                for flags, captured in ((fq.abi.VALIDATE_NAMES, True), (0, False)):
+                    acc = ctx.accumulator()
+                    r = ctx.validate(image, acc, st, flags=fq.abi.VALIDATE_COUNT_TWICE | flags)
+                    assert r["code"] == 0 and r["path"] == 3
+                    idx = ctx.name_index(1024)  # (grows: the earlier frames are re-inserted through the line index)
+                    ir = idx.insert_unique(st)
+                    assert ir["code"] == want_code, ir
+                    if want_code:
+                        assert ir["record"] == n
+                    else:
+                        assert ir["n_entries"] == n
+                    got = idx.names_captured()
+                    assert (got > 0.95 * n) if captured else got == 0, (got, n)
+                    # the same names as a second file: all of them found, nothing left
+                    r2 = ctx.validate(img, None, st, flags=fq.abi.VALIDATE_NO_STATS | flags)
+                    mr = idx.match_delete(st)
+                    assert mr["code"] == 0 and mr["n_entries"] == 0, mr
+                    idx.close()
+                    acc.close()
+    finally:
+        os.environ.pop("FQGPU_STREAM_MIN", None)
