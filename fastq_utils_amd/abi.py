@@ -32,7 +32,7 @@ EXPORTS = [
     "fqg_profile_reset", "fqg_profile_read", "fqg_synth_record_bytes", "fqg_synth_fastq",
     "fqg_frame_retain", "fqg_frame_release", "fqg_frame_n_records", "fqg_frame_make_current", "fqg_index_create",
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_index_probe_delete",
-    "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_index_names_captured", "fqg_records_gather",
+    "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_index_names_captured", "fqg_index_expect_lookups", "fqg_records_gather",
     "fqg_records_gather_output", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
@@ -221,6 +221,7 @@ def load():
     L.fqg_index_match_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(IndexResult)]
     L.fqg_index_probe_delete.argtypes = [vp, vp, C.POINTER(FileState), C.POINTER(u64), C.POINTER(IndexResult)]
     L.fqg_index_alive.argtypes = [vp, vp, C.POINTER(C.c_uint8), u64]
+    L.fqg_index_expect_lookups.argtypes = [vp, C.c_int]
     L.fqg_index_names_captured.argtypes = [vp]
     L.fqg_index_names_captured.restype = u64
     L.fqg_records_gather.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
@@ -426,6 +427,10 @@ class NameIndex:
         a = np.empty(max(1, n_inserted), dtype=np.uint8)
         self.ctx._check(load().fqg_index_alive(self.ctx.h, self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), n_inserted))
         return a[:n_inserted]
+
+    def expect_lookups(self, yes):
+        """before the first insert: False = the index is only a uniqueness test (it keeps no name records)"""
+        self.ctx._check(load().fqg_index_expect_lookups(self.h, 1 if yes else 0))
 
     def names_captured(self):
         """of the last insert / match call: records whose name came from a capture record of the streaming pass"""

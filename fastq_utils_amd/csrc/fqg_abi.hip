@@ -71,6 +71,7 @@ struct fqg_ctx {
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
   DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
   DevBuf name_hcount; // ... and the headers every chunk saw
+  DevBuf name_redo, name_redo_chunks;  // what the capture-fed name kernel leaves to the line-index one
   NamesView names{};            // what the name kernels need of the last capture
   uint64_t last_names_captured = 0;    // of the last index call: records whose name came straight from a capture record
   const uint8_t* names_img = nullptr;  // the image it belongs to (null: no capture) - the current frame's, or the
@@ -275,6 +276,8 @@ void fqg_close(fqg_ctx* c) {
   release(c->redo);
   release(c->name_recs);
   release(c->name_hcount);
+  release(c->name_redo);
+  release(c->name_redo_chunks);
   release(c->umi_arena);
   release(c->umi_names);
   release(c->umi_cells);
@@ -1025,8 +1028,10 @@ uint64_t fqg_frame_n_records(const fqg_frame* f) { return f ? f->fv.n_records : 
 // ---- read-name index ------------------------------------------------------------------------
 struct fqg_index {
   fqg_ctx* ctx = nullptr;
-  DevBuf buckets, segs_dev, slot_of, match;
+  DevBuf slots, names, claims, segs_dev, found, match;
   uint64_t capacity = 0;
+  uint64_t rec_cap = 0;          // records names[] / claims[] have room for
+  bool keep_names = true;        // false: nobody will look names up in this index (fqg_index_expect_lookups)
   std::vector<fqg_frame*> frames;
   std::vector<IndexSeg> segs;
   uint64_t n_records_total = 0;  // records fed so far = global index of the next frame's first record
@@ -1041,15 +1046,17 @@ namespace {
 int index_alloc_table(fqg_index* ix, uint64_t capacity) {
   fqg_ctx* c = ix->ctx;
   int rc;
-  if ((rc = ensure(c, ix->buckets, (size_t)capacity * sizeof(NameBucket)))) return rc;
-  HIP_TRY(c, hipMemsetAsync(ix->buckets.p, 0xFF, (size_t)capacity * sizeof(NameBucket), c->stream));  // empty keys, no claims
+  if ((rc = ensure(c, ix->slots, (size_t)capacity * 8))) return rc;
+  HIP_TRY(c, hipMemsetAsync(ix->slots.p, 0xFF, (size_t)capacity * 8, c->stream));
   ix->capacity = capacity;
   return 0;
 }
 
 IndexView index_view(fqg_index* ix) {
   IndexView v;
-  v.buckets = (NameBucket*)ix->buckets.p;
+  v.slots = (unsigned long long*)ix->slots.p;
+  v.names = ix->keep_names ? (NameRec*)ix->names.p : nullptr;
+  v.claims = (unsigned long long*)ix->claims.p;
   v.mask = ix->capacity - 1;
   v.segs = (const IndexSeg*)ix->segs_dev.p;
   v.n_segs = (int)ix->segs.size();
@@ -1057,6 +1064,35 @@ IndexView index_view(fqg_index* ix) {
   v.is_pe = ix->is_pe;
   v.may_have_nul = (ix->flags & kFlagNul) ? 1 : 0;
   return v;
+}
+
+// room in names[] / claims[] for `total` inserted records (kept across growth: record-ordered arrays)
+int index_reserve_records(fqg_index* ix, uint64_t total) {
+  fqg_ctx* c = ix->ctx;
+  if (total <= ix->rec_cap) return 0;
+  const uint64_t cap = std::max<uint64_t>(total + total / 8 + 1024, 2 * ix->rec_cap);
+  DevBuf names, claims;
+  hipError_t e = hipSuccess;
+  if (ix->keep_names) e = hipMalloc(&names.p, (size_t)cap * sizeof(NameRec));
+  if (e == hipSuccess) e = hipMalloc(&claims.p, (size_t)cap * 8);
+  if (e != hipSuccess) {
+    if (names.p) (void)hipFree(names.p);
+    return fail(c, FQG_ERR_NOMEM, "name index: hipMalloc", e);
+  }
+  names.cap = (size_t)cap * sizeof(NameRec);
+  claims.cap = (size_t)cap * 8;
+  const uint64_t used = ix->n_records_total;
+  if (used && ix->names.p && names.p)
+    (void)hipMemcpyAsync(names.p, ix->names.p, (size_t)used * sizeof(NameRec), hipMemcpyDeviceToDevice, c->stream);
+  if (used && ix->claims.p) (void)hipMemcpyAsync(claims.p, ix->claims.p, (size_t)used * 8, hipMemcpyDeviceToDevice, c->stream);
+  (void)hipMemsetAsync((char*)claims.p + (size_t)used * 8, 0xFF, (size_t)(cap - used) * 8, c->stream);  // nobody has asked yet
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  release(ix->names);
+  release(ix->claims);
+  ix->names = names;
+  ix->claims = claims;
+  ix->rec_cap = cap;
+  return 0;
 }
 
 int index_upload_segs(fqg_index* ix) {
@@ -1093,9 +1129,46 @@ bool names_usable(const fqg_ctx* c, const FrameView& fv) {
   static const bool off = getenv("FQGPU_NO_NAME_CAPTURE") != nullptr;  // (A/B: always go through the line index)
   return !off && c->names_img && c->names_img == fv.img && c->names_nbytes == fv.nbytes;
 }
-unsigned names_grid(fqg_ctx* c) {
+// the lists k_names_pass fills for k_names_rest
+int env_int(const char* name, int dflt);
+int names_prepare(fqg_ctx* c, const FrameView& fv) {
+  int rc;
+  (void)fv;
   const uint64_t n_slots = (uint64_t)c->names.cr.n_chunks << c->names.k_shift;
-  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_slots + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 16));
+  if ((rc = ensure(c, c->name_redo, ((n_slots + 63) / 64 + 1) * 8))) return rc;
+  if ((rc = ensure(c, c->name_redo_chunks, (size_t)std::max<uint32_t>(c->names.cr.n_chunks, 1)))) return rc;
+  c->names.redo_bits = (unsigned long long*)c->name_redo.p;
+  c->names.chunk_redo = (uint8_t*)c->name_redo_chunks.p;
+  static const int abl = env_int("FQGPU_NAMES_ABL", 0);
+  c->names.ablate = abl;
+  return 0;
+}
+// (measurement knobs: FQGPU_NAMES_BLOCKS_PER_CU, FQGPU_NAMES_DYN_LDS - bytes of unused LDS per workgroup, which caps the
+// workgroups a CU holds -, FQGPU_NAMES_NT=0 for plain instead of non-temporal loads of the capture records)
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+unsigned names_grid(fqg_ctx* c) {
+  static const int per_cu = std::max(1, env_int("FQGPU_NAMES_BLOCKS_PER_CU", 16));
+  const uint64_t n_slots = (uint64_t)c->names.cr.n_chunks << c->names.k_shift;
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_slots + kBlock - 1) / kBlock, (uint64_t)c->cu_count * per_cu));
+}
+void launch_names_pass(fqg_ctx* c, bool match, const FrameView& fv, const IndexView& iv, const fqg_file_state* st,
+                       uint64_t base, unsigned long long* found) {
+  static const unsigned dyn_lds = (unsigned)std::max(0, env_int("FQGPU_NAMES_DYN_LDS", 0));
+  static const bool nt = env_int("FQGPU_NAMES_NT", 1) != 0;
+#define FQG_NAMES_PASS(M, N)                                                                                             \
+  hipLaunchKernelGGL((k_names_pass<M, N>), dim3(names_grid(c)), dim3(kBlock), dyn_lds, c->stream, fv, c->names, iv,       \
+                     st->readname_format, st->is_pe, base, found, c->d_icall)
+  if (match) {
+    if (nt) FQG_NAMES_PASS(true, true);
+    else FQG_NAMES_PASS(true, false);
+  } else {
+    if (nt) FQG_NAMES_PASS(false, true);
+    else FQG_NAMES_PASS(false, false);
+  }
+#undef FQG_NAMES_PASS
 }
 
 // rebuild the table at a larger capacity from the retained segments
@@ -1112,8 +1185,10 @@ int index_grow(fqg_index* ix, uint64_t need_names) {
     if ((rc = index_reset_call(c))) return rc;
     FrameView fv = ix->frames[s]->fv;
     ProfScope ps(c, "k_index_insert(regrow)");
-    hipLaunchKernelGGL(k_index_insert, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv,
-                       index_view(ix), ix->segs[s].record_base, c->d_icall);
+    IndexView v = index_view(ix);
+    v.names = nullptr;  // (the name records of these frames are in place)
+    hipLaunchKernelGGL(k_index_insert, dim3(index_grid(c, fv.n_records)), dim3(kBlock), 0, c->stream, fv, v,
+                       ix->segs[s].record_base, c->d_icall);
   }
   return 0;
 }
@@ -1136,13 +1211,22 @@ int fqg_index_create(fqg_ctx* c, uint64_t expected_names, fqg_index** out) {
   return 0;
 }
 
+int fqg_index_expect_lookups(fqg_index* ix, int yes) {
+  if (!ix) return FQG_ERR_ARG;
+  if (ix->n_records_total) return fail(ix->ctx, FQG_ERR_STATE, "fqg_index_expect_lookups: the index is not empty");
+  ix->keep_names = yes != 0;
+  return 0;
+}
+
 void fqg_index_destroy(fqg_index* ix) {
   if (!ix) return;
   (void)hipStreamSynchronize(ix->ctx->stream);
   for (auto* f : ix->frames) fqg_frame_release(f);
-  release(ix->buckets);
+  release(ix->slots);
+  release(ix->names);
+  release(ix->claims);
   release(ix->segs_dev);
-  release(ix->slot_of);
+  release(ix->found);
   release(ix->match);
   delete ix;
 }
@@ -1186,12 +1270,18 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
     ix->segs.back().n_records = 0;  // (kept for ownership only)
     return code;
   };
+  if ((rc = index_reserve_records(ix, ix->n_records_total + sg.n_records))) return drop(rc);
   if ((rc = index_upload_segs(ix))) return drop(rc);
   if ((rc = index_reset_call(c))) return drop(rc);
   const bool captured = names_usable(c, fr->fv);
   if (sg.n_records && captured) {
-    ProfScope ps(c, "k_names_insert");
-    hipLaunchKernelGGL(k_names_pass<false>, dim3(names_grid(c)), dim3(kBlock), 0, c->stream, fr->fv, c->names, index_view(ix),
+    if ((rc = names_prepare(c, fr->fv))) return drop(rc);
+    {
+      ProfScope ps(c, "k_names_insert");
+      launch_names_pass(c, false, fr->fv, index_view(ix), st, sg.record_base, nullptr);
+    }
+    ProfScope ps(c, "k_names_rest");
+    hipLaunchKernelGGL(k_names_rest<false>, dim3(c->cu_count * 4), dim3(kBlock), 0, c->stream, fr->fv, c->names, index_view(ix),
                        st->readname_format, st->is_pe, sg.record_base, (unsigned long long*)nullptr, c->d_icall);
   } else if (sg.n_records) {
     ProfScope ps(c, "k_index_insert");
@@ -1201,7 +1291,7 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   if ((rc = index_fetch_call(c))) return drop(rc);
   if (hipGetLastError() != hipSuccess) return drop(fail(c, FQG_ERR_HIP, "k_index_insert"));
   if (c->h_icall->table_full) return drop(fail(c, FQG_ERR_STATE, "name index full"));
-  if (sg.n_records && c->h_icall->seen != sg.n_records) return drop(fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once"));
+  if (sg.n_records && c->h_icall->seen != sg.n_records && !(captured && c->names.ablate)) return drop(fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once"));
   c->last_names_captured = c->h_icall->captured;
   ix->n_records_total += sg.n_records;
   ix->inserted += c->h_icall->inserted;
@@ -1227,20 +1317,26 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   memset(out, 0, sizeof(*out));
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
+  if (!ix->claims.p && (rc = index_reserve_records(ix, std::max<uint64_t>(ix->n_records_total, 1)))) return rc;
   if ((rc = index_upload_segs(ix))) return rc;
   if ((rc = index_reset_call(c))) return rc;
   const FrameView fv = c->frame;
   unsigned long long *d_slot = nullptr, *d_match = nullptr;
   if (match && fv.n_records) {
-    if ((rc = ensure(c, ix->slot_of, fv.n_records * 8))) return rc;
+    if ((rc = ensure(c, ix->found, fv.n_records * 8))) return rc;
     if ((rc = ensure(c, ix->match, fv.n_records * 8))) return rc;
-    d_slot = (unsigned long long*)ix->slot_of.p;
+    d_slot = (unsigned long long*)ix->found.p;
     d_match = (unsigned long long*)ix->match.p;
   }
   if (fv.n_records) {
     if (names_usable(c, fv)) {
-      ProfScope ps(c, "k_names_match");
-      hipLaunchKernelGGL(k_names_pass<true>, dim3(names_grid(c)), dim3(kBlock), 0, c->stream, fv, c->names, index_view(ix),
+      if ((rc = names_prepare(c, fv))) return rc;
+      {
+        ProfScope ps(c, "k_names_match");
+        launch_names_pass(c, true, fv, index_view(ix), st, ix->n_askers_total, d_slot);
+      }
+      ProfScope ps(c, "k_names_rest");
+      hipLaunchKernelGGL(k_names_rest<true>, dim3(c->cu_count * 4), dim3(kBlock), 0, c->stream, fv, c->names, index_view(ix),
                          st->readname_format, st->is_pe, ix->n_askers_total, d_slot, c->d_icall);
     } else {
       ProfScope ps(c, "k_index_match_delete");
@@ -1258,7 +1354,7 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   }
   if ((rc = index_fetch_call(c))) return rc;
   HIP_TRY(c, hipGetLastError());
-  if (fv.n_records && c->h_icall->seen != fv.n_records) return fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once");
+  if (fv.n_records && c->h_icall->seen != fv.n_records && !c->names.ablate) return fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once");
   c->last_names_captured = c->h_icall->captured;
   ix->matched += c->h_icall->matched;
   ix->n_askers_total += fv.n_records;

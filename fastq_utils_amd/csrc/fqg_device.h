@@ -51,15 +51,17 @@ __host__ __device__ inline bool chunk_info_range(uint32_t info, uint32_t rank0) 
 //     bytes 0..3   meta: bits 0..9  bytes of the line in front of its '\n', the '@' included (1023 = that or more)
 //                        bits 10..18 v: the line starts behind the chunk's v-th newline (v = 0: at the chunk's
 //                                    first byte) - with the chunk's first rank this gives the record index
-//                        bit 19      the line's '\n' lies in the chunk (its length is known)
+//                        bit 19      the length is known (the line's '\n' was seen)
 //                        bit 20      the line starts with '@'
+//                        bit 21      the length is not known, but every text byte of the record is the line's (a
+//                                    header that runs into the next chunk and has no '\n' in its first 61 bytes)
 //     bytes 4..63  the 60 bytes behind the '@' (whatever follows the line when it is shorter)
 // Records sit at [chunk * K + ordinal of the header in the chunk]; hcount[chunk] = headers the chunk saw
 // (kNoCapture: none captured - no speculation in this chunk).  A consumer trusts a chunk's records only when the
 // speculated type was the true one and hcount <= K; every other header is found through the line index.
 constexpr uint32_t kNameRecWords = 8;       // 64-bit words per record
 constexpr uint32_t kNameRecText = 60;       // header bytes behind the '@' in a record
-constexpr uint32_t kNameInline = 48;        // name bytes an index bucket carries
+constexpr uint32_t kNameInline = 56;        // name bytes the index keeps per record (NameRec)
 constexpr uint32_t kNoCapture = 0xFFFFu;
 struct NameCapture {
   unsigned long long* recs;  // n_chunks * K records

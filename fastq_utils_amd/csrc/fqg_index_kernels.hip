@@ -2,29 +2,33 @@
 // fastq_index_readnames (reference src/fastq.c:396-439, :577-611) and by the file-2 pairing
 // loop of fastq_info (reference src/fastq_info.c:333-356).
 //
-// Table: open addressing, linear probing, one 64-BYTE BUCKET per name - a cache line that holds everything a
-// look-up needs, so that finding a name, confirming it on its bytes and taking it is ONE memory access:
-//     key    { tag : 24 | record : 40 }   (all ones = empty)   the word the insert claims with a CAS
-//     claim  smallest record of the asking file that took the entry (all ones = nobody)
-//     name   the first 48 bytes of the canonical name, zero padded
+// Three arrays (what each costs per access is measured in tools/kbench/rmwbench.hip: on MI355X a random 8-byte load
+// runs at 50 G/s, a random 64-byte load at 20 G/s, an atomic at 19 G/s wherever it goes - but atomics to neighbouring
+// words at 100 G/s):
+//   slots[2^k >= 2 * names]  open addressing, linear probing, ONE 8-byte word per slot
+//         { tag : 24 | record : 40 }   (all ones = empty)      the insert claims it with a CAS: its one random access
+//   names[record]            64 bytes per inserted record, in RECORD order: length + the first 56 bytes of the
+//                            canonical name.  Written by the insert as a sequential stream; a look-up that found a
+//                            tag reads names[record] to decide on the BYTES - and when the second file comes in the
+//                            first one's order (the usual case) neighbouring lanes read neighbouring records
+//   claims[record]           smallest record of the asking file that took the entry (all ones = nobody), in record
+//                            order for the same reason: the atomicMin of neighbouring lanes fall into one line
 // `record` is the global index of the record that owns the name, `tag` 24 further bits of the name's 64-bit hash.
-// Equality is decided on the name BYTES: a name shorter than 48 bytes is compared inside the bucket (names hold no
-// NUL byte, so equal padded words mean equal lengths too); for longer names the index keeps references to the framed
-// images it was fed (segments) and the record index leads back to the header bytes.  Hash collisions can neither
-// fake nor hide a duplicate.
+// Equality is always decided on the name bytes (names beyond 56 bytes, and tag matches while the insert is still
+// running, through the images the index keeps references to), so hash collisions can neither fake nor hide a duplicate.
 //
 // Where the names come from: the streaming pass copies every header line it sees into a 64-byte record while the
-// chunk is in LDS (NameCapture, fqg_device.h), and k_names_insert / k_names_match work from those records - a
-// sequential read instead of one header line per 349-byte stride.  Headers the capture could not vouch for
-// (mis-speculated chunks, lines that straddle a chunk, lines longer than a record) and frames that were not
-// streamed go through the line index and the image (k_index_insert / k_index_match_delete: same table, same results).
+// chunk is in LDS (NameCapture, fqg_device.h), and k_names_pass works from those records - a sequential read instead
+// of one header line per 349-byte stride.  Headers the capture could not vouch for (mis-speculated chunks, lines that
+// straddle a chunk, lines longer than a record) and frames that were not streamed go through the line index and the
+// image (k_index_insert / k_index_match_delete: same arrays, same results).
 //
 // Serial semantics in a parallel insert: the reference stops at the first record (file order)
 // whose name is already present.  Every thread that meets its own name in the table does
-// atomicMin(key, tag|me) and reports max(previous owner, me); the minimum over all reports is
+// atomicMin(slot, tag|me) and reports max(previous owner, me); the minimum over all reports is
 // exactly the second-smallest index of the earliest repeated name, i.e. the record the serial
 // loop would have stopped at.  The same argument gives the first unpaired record in the
-// match-and-delete pass (claim holds the smallest file-2 record that asked for the entry).
+// match-and-delete pass (claims[] holds the smallest file-2 record that asked for the entry).
 #include "fqg_device.h"
 
 namespace fqg {
@@ -40,14 +44,16 @@ struct IndexSeg {
   uint64_t record_base;  // global index of the segment's first record
 };
 
-struct NameBucket {
-  unsigned long long key, claim;
-  unsigned long long name[kNameInline / 8];
+struct NameRec {
+  unsigned long long n;  // length of the canonical name
+  unsigned long long name[kNameInline / 8];  // its first 56 bytes, zero padded
 };
-static_assert(sizeof(NameBucket) == 64, "a bucket is one 64-byte line");
+static_assert(sizeof(NameRec) == 64, "a name record is one 64-byte line");
 
 struct IndexView {
-  NameBucket* buckets;
+  unsigned long long* slots;
+  NameRec* names;              // per inserted record (global index); null: not kept (an index nobody will ask)
+  unsigned long long* claims;  // per inserted record, match-and-delete only (may be null)
   uint64_t mask;               // capacity - 1 (capacity is a power of two)
   const IndexSeg* segs;
   int n_segs;
@@ -246,9 +252,11 @@ __device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n,
   return h;
 }
 // name (length, hash) of the header line at img + b; the fast path when the line allows it
+// (nm, optional: the first kNameInline bytes of the name as zero-padded words)
 __device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ img, uint64_t nbytes, uint64_t b, uint64_t e,
                                                   int fmt, int is_pe, int may_have_nul, uint32_t* acct, uint64_t* h,
-                                                  bool* at_sign, uint64_t* second = nullptr) {
+                                                  bool* at_sign, uint64_t* second = nullptr,
+                                                  unsigned long long* nm = nullptr) {
   const uint8_t* line = img + b;
   const uint32_t len = (uint32_t)(e - b), has_nl = e < nbytes ? 1u : 0u;
   if (!may_have_nul && len + has_nl <= kHdrBytes - 1 && b + kHdrBytes <= nbytes) {
@@ -259,31 +267,38 @@ __device__ __forceinline__ uint32_t name_and_hash(const uint8_t* __restrict__ im
     if (ok) {
       *at_sign = (H.w[0] & 0xFF) == '@';
       *h = hash_name_regs(H, n, second);
+      if (nm) {
+#pragma unroll
+        for (uint32_t k = 0; k < kNameInline / 8; ++k) {
+          const uint64_t nw = (H.w[k] >> 8) | (H.w[k + 1] << 56);  // bytes 8k .. 8k+7 of the name
+          nm[k] = 8u * k + 8u <= n ? nw : (8u * k < n ? nw & ((1ull << (8 * (n - 8u * k))) - 1ull) : 0ull);
+        }
+      }
       return n;
     }
   }
   *at_sign = line[0] == '@';
   const uint32_t n = canon_name(line, len, has_nl, fmt, is_pe, may_have_nul, acct);
   *h = hash_name(line + 1, n, second);
+  if (nm) {
+    const uint32_t m = n < kNameInline ? n : kNameInline;
+    for (uint32_t k = 0; k < kNameInline / 8; ++k) {
+      unsigned long long w = 0;
+      for (uint32_t i = 0; i < 8 && 8 * k + i < m; ++i) w |= (unsigned long long)line[1 + 8 * k + i] << (8 * i);
+      nm[k] = w;
+    }
+  }
   return n;
 }
 
-// ---- buckets -----------------------------------------------------------------------------------
+// ---- names as keys ------------------------------------------------------------------------------
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 
 struct NameKey {
   uint32_t n, acct;  // canonical name length; the `len` the reference accounts for it (src/fastq.c:609)
   uint64_t h;
-  unsigned long long nm[kNameInline / 8];  // first 48 name bytes, zero padded
+  unsigned long long nm[kNameInline / 8];  // first 56 name bytes, zero padded
 };
-
-// the first 48 bytes of the name at p (n bytes, no NUL inside) as padded words; byte-wise - the slow path only
-__device__ inline void name_words_from_image(const uint8_t* __restrict__ p, uint32_t n, unsigned long long (&nm)[kNameInline / 8]) {
-#pragma unroll
-  for (uint32_t k = 0; k < kNameInline / 8; ++k) nm[k] = 0;
-  const uint32_t m = n < kNameInline ? n : kNameInline;
-  for (uint32_t i = 0; i < m; ++i) nm[i >> 3] |= (unsigned long long)p[i] << (8 * (i & 7));
-}
 
 // Name of a captured header line (NameCapture record in w[]).  false: the record cannot give it - the line's end is
 // not in the chunk, the line is longer than the record holds, a Casava header has no blank - and the caller goes
@@ -294,14 +309,16 @@ __device__ __forceinline__ bool name_from_record(const unsigned long long (&w)[k
   const uint32_t L = meta & 1023u;  // strlen(&hdr[1]): the bytes behind the '@' and the '\n'
   *v = (meta >> 10) & 511u;
   *at_sign = ((meta >> 20) & 1u) != 0;
-  if (!((meta >> 19) & 1u) || L >= (uint32_t)FQG_MAX_LABEL_LENGTH) return false;
+  const bool end_known = ((meta >> 19) & 1u) != 0;
+  // (length unknown: only a Casava name, which ends at a blank, can still be read - when the record's bytes are the line's)
+  if (end_known ? L >= (uint32_t)FQG_MAX_LABEL_LENGTH : !(((meta >> 21) & 1u) && fmt == FQG_NAME_CASAVA18)) return false;
   uint64_t t[kNameRecWords];  // the bytes behind the '@'
 #pragma unroll
   for (uint32_t i = 0; i + 1 < kNameRecWords; ++i) t[i] = (w[i] >> 32) | (w[i + 1] << 32);
   t[kNameRecWords - 1] = w[kNameRecWords - 1] >> 32;
   uint32_t n, acct;
   if (fmt == FQG_NAME_CASAVA18) {
-    const uint32_t lim = L < kNameRecText ? L : kNameRecText;
+    const uint32_t lim = end_known && L < kNameRecText ? L : kNameRecText;
     uint32_t first = ~0u, two_before = 0;
 #pragma unroll
     for (int i = (int)kNameRecWords - 1; i >= 0; --i) {
@@ -356,12 +373,11 @@ __device__ inline void name_from_image(const FrameView& f, uint64_t r, int fmt, 
                                        bool* at_sign) {
   const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
   const uint64_t e = f.line_end[4 * r];
-  k.n = name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &k.acct, &k.h, at_sign);
-  name_words_from_image(f.img + b + 1, k.n, k.nm);
+  k.n = name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &k.acct, &k.h, at_sign, nullptr, k.nm);
 }
 
-// Is the canonical name of the stored record g the n bytes at `mine`?  Byte-wise: only names of 48 bytes or more, and
-// tag matches during an insert, come here.
+// Is the canonical name of the stored record g the n bytes at `mine`?  Byte-wise, through the images: names beyond 56
+// bytes, tag matches during an insert, indexes that keep no name records.
 __device__ inline bool stored_name_is(const IndexView& ix, uint64_t g, const uint8_t* __restrict__ mine, uint32_t n) {
   const uint8_t* other;
   uint32_t on;
@@ -377,33 +393,39 @@ struct IndexTally {  // per-thread findings and counts of the name kernels
 __device__ __forceinline__ void insert_name(const IndexView& ix, const NameKey& k, bool at_sign, const FrameView& f, uint64_t r,
                                             uint64_t record_base, IndexTally& t, IndexCall* __restrict__ call) {
   ++t.seen;
+  const unsigned long long g = record_base + r;
+  if (ix.names) {
+    // the record's name for later look-ups: neighbouring lanes, neighbouring 64-byte lines (a record without '@' or
+    // with a repeated name gets one too - nothing will ever point at it)
+    u64x2_t* dst = reinterpret_cast<u64x2_t*>(ix.names + g);
+    u64x2_t x;
+    x.x = k.n;
+    x.y = k.nm[0];
+    __builtin_nontemporal_store(x, dst);
+#pragma unroll
+    for (uint32_t i = 1; i < 4; ++i) {
+      x.x = k.nm[2 * i - 1];
+      x.y = k.nm[2 * i];
+      __builtin_nontemporal_store(x, dst + i);
+    }
+  }
   if (!at_sign) {  // fastq_get_readname refuses it (src/fastq.c:448)
     t.first_wrong = r < t.first_wrong ? r : t.first_wrong;
     return;
   }
-  const unsigned long long g = record_base + r;
   const unsigned long long me = ((k.h >> 40) << 40) | g;
   uint64_t at = k.h & ix.mask;
   for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
-    NameBucket* bk = ix.buckets + at;
-    // one round trip when the bucket is free (most are: the table is at most half full)
-    const unsigned long long cur = atomicCAS(&bk->key, kSlotEmpty, me);
+    // one round trip when the slot is free (most are: the table is at most half full)
+    const unsigned long long cur = atomicCAS(&ix.slots[at], kSlotEmpty, me);
     if (cur == kSlotEmpty) {
-      // (nobody reads these words before the kernel has ended: a tag match inside an insert is confirmed on the images)
-      u64x2_t* dst = reinterpret_cast<u64x2_t*>(bk->name);
-#pragma unroll
-      for (uint32_t i = 0; i < kNameInline / 16; ++i) {
-        u64x2_t x;
-        x.x = k.nm[2 * i];
-        x.y = k.nm[2 * i + 1];
-        dst[i] = x;
-      }
       ++t.inserted;
       t.name_bytes += k.acct;
       return;
     }
+    // (the other record's name record may not be written yet - it belongs to this very launch: compare on the images)
     if ((cur >> 40) == (me >> 40) && stored_name_is(ix, cur & kIdxMask, NameAt{f, r}(), k.n)) {
-      const unsigned long long prev = atomicMin(&bk->key, me);
+      const unsigned long long prev = atomicMin(&ix.slots[at], me);
       const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
       t.first_dup = late < t.first_dup ? late : t.first_dup;
       return;
@@ -412,12 +434,13 @@ __device__ __forceinline__ void insert_name(const IndexView& ix, const NameKey& 
   atomicOr(&call->table_full, 1u);
 }
 
-// Find the name of frame-local record r of the asking file and take its entry.  The whole bucket is fetched at once:
-// key, claim and name bytes arrive in one round trip.  slot_of[r] (optional) remembers where the name was found.
+// Find the name of frame-local record r of the asking file and take its entry: slot -> the stored record's name
+// record (bytes decide) -> atomicMin on its claim.  found[r] (optional) = the record whose entry was found
+// (kSlotEmpty: none, kSlotEmpty - 1: no '@').
 __device__ __forceinline__ void match_name(const IndexView& ix, const NameKey& k, bool at_sign, const FrameView& f, uint64_t r,
-                                           uint64_t asker_base, unsigned long long* __restrict__ slot_of, IndexTally& t) {
+                                           uint64_t asker_base, unsigned long long* __restrict__ found, IndexTally& t) {
   ++t.seen;
-  if (slot_of) slot_of[r] = at_sign ? kSlotEmpty : kSlotEmpty - 1;
+  if (found) found[r] = at_sign ? kSlotEmpty : kSlotEmpty - 1;
   if (!at_sign) {
     t.first_wrong = r < t.first_wrong ? r : t.first_wrong;
     return;
@@ -425,26 +448,31 @@ __device__ __forceinline__ void match_name(const IndexView& ix, const NameKey& k
   const unsigned long long g2 = asker_base + r;
   uint64_t at = k.h & ix.mask;
   for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
-    NameBucket* bk = ix.buckets + at;
-    const u64x2_t* src = reinterpret_cast<const u64x2_t*>(bk);
-    const u64x2_t a = src[0], b = src[1], c = src[2], d = src[3];
-    if (a.x == kSlotEmpty) break;
-    if ((a.x >> 40) != (k.h >> 40)) continue;
-    const unsigned long long diff =
-        (b.x ^ k.nm[0]) | (b.y ^ k.nm[1]) | (c.x ^ k.nm[2]) | (c.y ^ k.nm[3]) | (d.x ^ k.nm[4]) | (d.y ^ k.nm[5]);
-    if (diff) continue;
-    // (names hold no NUL byte: equal padded words of a name shorter than 48 bytes mean equal names)
-    if (k.n >= kNameInline && !stored_name_is(ix, a.x & kIdxMask, NameAt{f, r}(), k.n)) continue;
+    const unsigned long long cur = ix.slots[at];
+    if (cur == kSlotEmpty) break;
+    if ((cur >> 40) != (k.h >> 40)) continue;
+    const unsigned long long g = cur & kIdxMask;
+    bool same;
+    if (ix.names) {
+      const u64x2_t* src = reinterpret_cast<const u64x2_t*>(ix.names + g);
+      const u64x2_t a = src[0], b = src[1], c = src[2], d = src[3];
+      same = a.x == k.n && !((a.y ^ k.nm[0]) | (b.x ^ k.nm[1]) | (b.y ^ k.nm[2]) | (c.x ^ k.nm[3]) | (c.y ^ k.nm[4]) |
+                             (d.x ^ k.nm[5]) | (d.y ^ k.nm[6]));
+      if (same && k.n > kNameInline) same = stored_name_is(ix, g, NameAt{f, r}(), k.n);
+    } else {
+      same = stored_name_is(ix, g, NameAt{f, r}(), k.n);
+    }
+    if (!same) continue;
     // the smallest asker gets the entry; every other asker is what the serial loop would have found missing
     // after the delete.  An asker of an EARLIER piece is smaller than every record of this one, so `late`
     // always lies in this piece.
-    const unsigned long long prev = atomicMin(&bk->claim, g2);
+    const unsigned long long prev = atomicMin(&ix.claims[g], g2);
     if (prev == kSlotEmpty) ++t.matched;
     else {
       const unsigned long long late = (prev > g2 ? prev : g2) - asker_base;
       t.first_missing = late < t.first_missing ? late : t.first_missing;
     }
-    if (slot_of) slot_of[r] = at;
+    if (found) found[r] = g;
     return;
   }
   t.first_missing = r < t.first_missing ? r : t.first_missing;
@@ -493,11 +521,11 @@ __global__ __launch_bounds__(kBlock) void k_index_insert(FrameView f, IndexView 
 }
 
 // One thread per record of the (file-2) frame: find the name, claim its entry.  claim holds the GLOBAL index
-// (asker_base + r: the pieces of the asking file share the index) of the smallest asker; slot_of[r] (optional)
-// remembers where record r found its name (kSlotEmpty: nowhere) for k_index_probe_resolve.
+// (asker_base + r: the pieces of the asking file share the index) of the smallest asker; found[r] (optional)
+// remembers whose entry record r found (kSlotEmpty: nobody's) for k_index_probe_resolve.
 __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, IndexView ix, int fmt2, int is_pe2,
                                                                int may_have_nul2, uint64_t asker_base,
-                                                               unsigned long long* __restrict__ slot_of,
+                                                               unsigned long long* __restrict__ found,
                                                                IndexCall* __restrict__ call) {
   IndexTally t;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -505,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, Inde
     NameKey k;
     bool at_sign;
     name_from_image(f, r, fmt2, is_pe2, may_have_nul2, k, &at_sign);
-    match_name(ix, k, at_sign, f, r, asker_base, slot_of, t);
+    match_name(ix, k, at_sign, f, r, asker_base, found, t);
   }
   tally_flush(t, call);
 }
@@ -521,54 +549,111 @@ struct NamesView {
   const uint32_t* cinfo;
   ChunkRanks cr;
   uint32_t K, k_shift;  // K = 1 << k_shift record slots per chunk
+  // what k_names_pass leaves to k_names_rest - written with plain stores, one owner per word (a list with ONE counter
+  // was the whole cost of this pass: a million appends to one address take 12 ms):
+  unsigned long long* redo_bits;  // per 64 record slots: the slots whose record cannot give the name
+  uint8_t* chunk_redo;            // per chunk: 1 = its records cannot be trusted, its headers are enumerated by rank
+  int ablate;  // measurement only (FQGPU_NAMES_ABL): 1 = no table access, 8 = no decoding
 };
 
-template <bool MATCH>
+template <bool MATCH, bool NT = true>
 __global__ __launch_bounds__(kBlock) void k_names_pass(FrameView f, NamesView nv, IndexView ix, int fmt, int is_pe,
                                                        uint64_t base /* record_base or asker_base */,
-                                                       unsigned long long* __restrict__ slot_of,
+                                                       unsigned long long* __restrict__ found,
                                                        IndexCall* __restrict__ call) {
   IndexTally t;
   const uint64_t n_slots = (uint64_t)nv.cr.n_chunks << nv.k_shift;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < n_slots; s += stride) {
+  const uint32_t lane = threadIdx.x & 63u;
+  // a wavefront owns 64 consecutive slots per step (K is a power of two >= 8: whole chunks or an aligned part of one)
+  for (uint64_t s0 = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u); s0 < n_slots; s0 += stride) {
+    const uint64_t s = s0 + lane;
     const uint32_t c = (uint32_t)(s >> nv.k_shift), j = (uint32_t)s & (nv.K - 1u);
-    const uint32_t hc = nv.hcount[c], info = nv.cinfo[c];
-    const uint64_t rank0 = nv.cr.rank0(c);
-    const bool trusted = hc != kNoCapture && hc <= nv.K && !(info & (kInfoUnknown | kInfoOneLine)) && (info & 3u) == ((uint32_t)rank0 & 3u);
-    if (trusted) {
-      if (j >= hc) continue;
-      unsigned long long w[kNameRecWords];
-      const u64x2_t* src = reinterpret_cast<const u64x2_t*>(nv.recs + s * kNameRecWords);
+    bool live = s < n_slots, redo = false;
+    uint64_t r = 0;
+    NameKey k;
+    bool at_sign = false;
+    if (live) {
+      const uint32_t hc = nv.hcount[c], info = nv.cinfo[c];
+      const uint64_t rank0 = nv.cr.rank0(c);
+      const bool trusted = hc != kNoCapture && hc <= nv.K && !(info & (kInfoUnknown | kInfoOneLine)) && (info & 3u) == ((uint32_t)rank0 & 3u);
+      if (j == 0) nv.chunk_redo[c] = trusted ? 0 : 1;
+      live = trusted && j < hc;
+      if (live) {
+        unsigned long long w[kNameRecWords];
+        const u64x2_t* src = reinterpret_cast<const u64x2_t*>(nv.recs + s * kNameRecWords);
 #pragma unroll
-      for (uint32_t i = 0; i < kNameRecWords / 2; ++i) {
-        const u64x2_t x = __builtin_nontemporal_load(src + i);
-        w[2 * i] = x.x;
-        w[2 * i + 1] = x.y;
+        for (uint32_t i = 0; i < kNameRecWords / 2; ++i) {
+          const u64x2_t x = NT ? __builtin_nontemporal_load(src + i) : src[i];
+          w[2 * i] = x.x;
+          w[2 * i + 1] = x.y;
+        }
+        uint32_t v;
+        bool ok;
+        if (nv.ablate & 8) {
+          ok = true;
+          v = ((uint32_t)w[0] >> 10) & 511u;
+          k.h = mix_hash(w[1] ^ w[3], w[2] ^ w[4]);
+          k.n = k.acct = 20;
+          at_sign = true;
+#pragma unroll
+          for (uint32_t i = 0; i < kNameInline / 8; ++i) k.nm[i] = w[i + 1];
+        } else ok = name_from_record(w, fmt, is_pe, k, &at_sign, &v);
+        r = (rank0 + v) >> 2;  // (rank0 + v = 4 r: the line behind newline 4 r - 1)
+        if (r >= f.n_records) live = false;  // a header of the incomplete tail
+        else if (!ok) {
+          redo = true;
+          live = false;
+        }
       }
-      NameKey k;
-      bool at_sign;
-      uint32_t v;
-      const bool ok = name_from_record(w, fmt, is_pe, k, &at_sign, &v);
-      const uint64_t r = (rank0 + v) >> 2;  // (rank0 + v = 4 r: the line behind newline 4 r - 1)
-      if (r >= f.n_records) continue;        // a header of the incomplete tail
-      if (ok) ++t.captured;
-      else name_from_image(f, r, fmt, is_pe, 0, k, &at_sign);
-      if (MATCH) match_name(ix, k, at_sign, f, r, base, slot_of, t);
+    }
+    const unsigned long long rm = __ballot(redo);
+    if (lane == 0) nv.redo_bits[s0 >> 6] = rm;
+    if (live) {
+      ++t.captured;
+      if (nv.ablate & 1) t.seen += (k.h & 1) + 1;
+      else if (MATCH) match_name(ix, k, at_sign, f, r, base, found, t);
       else insert_name(ix, k, at_sign, f, r, base, t, call);
-    } else {
-      // records r with 4 r in [rank0, rank0 + count]: their header starts behind a newline of this chunk or behind the
-      // last byte of the chunk before; the one that starts in THIS chunk is this chunk's
-      const uint64_t r_lo = (rank0 + 3) >> 2, r_hi = (rank0 + nv.cr.counts[c]) >> 2;
-      for (uint64_t r = r_lo + j; r <= r_hi && r < f.n_records; r += nv.K) {
-        const uint64_t start = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
-        if ((uint32_t)(start / kChunkBytes) != c) continue;
-        NameKey k;
-        bool at_sign;
-        name_from_image(f, r, fmt, is_pe, 0, k, &at_sign);
-        if (MATCH) match_name(ix, k, at_sign, f, r, base, slot_of, t);
-        else insert_name(ix, k, at_sign, f, r, base, t, call);
-      }
+    }
+  }
+  tally_flush(t, call);
+}
+
+// What k_names_pass left, all of it through the line index: the flagged record slots, and the records whose header
+// starts in a flagged chunk - those r with 4 r in [rank0, rank0 + count], i.e. behind one of the chunk's newlines or
+// behind the last byte of the chunk before; the one that starts in THIS chunk is this chunk's.
+template <bool MATCH>
+__global__ __launch_bounds__(kBlock) void k_names_rest(FrameView f, NamesView nv, IndexView ix, int fmt, int is_pe,
+                                                       uint64_t base, unsigned long long* __restrict__ found,
+                                                       IndexCall* __restrict__ call) {
+  IndexTally t;
+  const uint64_t n_slots = (uint64_t)nv.cr.n_chunks << nv.k_shift, n_words = (n_slots + 63) >> 6;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock, tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  auto one = [&](uint64_t r) {
+    NameKey k;
+    bool at_sign;
+    name_from_image(f, r, fmt, is_pe, 0, k, &at_sign);
+    if (MATCH) match_name(ix, k, at_sign, f, r, base, found, t);
+    else insert_name(ix, k, at_sign, f, r, base, t, call);
+  };
+  for (uint64_t wd = tid; wd < n_words; wd += stride) {
+    unsigned long long m = nv.redo_bits[wd];
+    while (m) {
+      const uint64_t s = (wd << 6) + (uint64_t)__builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t c = (uint32_t)(s >> nv.k_shift);
+      const uint32_t v = ((uint32_t)nv.recs[s * kNameRecWords] >> 10) & 511u;
+      one((nv.cr.rank0(c) + v) >> 2);
+    }
+  }
+  // a flagged chunk: 16 lanes share its candidates
+  for (uint64_t c = tid >> 4; c < nv.cr.n_chunks; c += stride >> 4) {
+    if (!nv.chunk_redo[c]) continue;
+    const uint64_t rank0 = nv.cr.rank0((uint32_t)c);
+    const uint64_t r_lo = (rank0 + 3) >> 2, r_hi = (rank0 + nv.cr.counts[c]) >> 2;
+    for (uint64_t r = r_lo + (tid & 15u); r <= r_hi && r < f.n_records; r += 16) {
+      const uint64_t start = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+      if (start / kChunkBytes == c) one(r);
     }
   }
   tally_flush(t, call);
@@ -577,23 +662,23 @@ __global__ __launch_bounds__(kBlock) void k_names_pass(FrameView f, NamesView nv
 // After a matching pass: match[r] = global index (insertion order) of the entry record r took, or kNoRecord
 // when its name is not in the index or an earlier asker took it (src/fastq_filterpair.c:150-170: lookup, then
 // fastq_index_delete)
-__global__ __launch_bounds__(kBlock) void k_index_probe_resolve(uint64_t n, const unsigned long long* __restrict__ slot_of,
+__global__ __launch_bounds__(kBlock) void k_index_probe_resolve(uint64_t n, const unsigned long long* __restrict__ found,
                                                                 IndexView ix, uint64_t asker_base,
                                                                 unsigned long long* __restrict__ match) {
   const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= n) return;
-  const unsigned long long at = slot_of[r];
-  if (at >= kSlotEmpty - 1) match[r] = at;  // not in the index / no '@' (FQG_NO_MATCH / FQG_MATCH_WRONG_HEADER)
-  else match[r] = ix.buckets[at].claim == asker_base + r ? (ix.buckets[at].key & kIdxMask) : kNoRecord;
+  const unsigned long long g = found[r];
+  if (g >= kSlotEmpty - 1) match[r] = g;  // not in the index / no '@' (FQG_NO_MATCH / FQG_MATCH_WRONG_HEADER)
+  else match[r] = ix.claims[g] == asker_base + r ? g : kNoRecord;
 }
 // alive[g] = 1 for every inserted record g whose entry nobody has taken (the table still holds it)
 __global__ __launch_bounds__(kBlock) void k_index_alive(IndexView ix, uint64_t n_records, uint8_t* __restrict__ alive) {
   const uint64_t at = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (at > ix.mask) return;
-  const u64x2_t kc = *reinterpret_cast<const u64x2_t*>(ix.buckets + at);
-  if (kc.x == kSlotEmpty) return;
-  const unsigned long long g = kc.x & kIdxMask;
-  if (g < n_records) alive[g] = kc.y == kSlotEmpty ? 1 : 0;
+  const unsigned long long cur = ix.slots[at];
+  if (cur == kSlotEmpty) return;
+  const unsigned long long g = cur & kIdxMask;
+  if (g < n_records) alive[g] = (!ix.claims || ix.claims[g] == kSlotEmpty) ? 1 : 0;
 }
 
 // Names of paired records must be equal: record 2k against 2k+1 of one frame (interleaved

@@ -474,13 +474,36 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         const uint32_t j = hc + (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
         hc += (uint32_t)__builtin_popcountll(hm);
         if (is_hdr && j < nc.K) {
-          const bool end_known = vv < tot;
+          bool end_known = vv < tot, real = false;
           uint32_t len = (end_known ? (uint32_t)(slots[vv] & 0xFFFu) : (uint32_t)kChunkBytes) - at;
-          len = len > 1023u ? 1023u : len;
           unsigned long long w[kNameRecWords];
+          if (end_known || cb + at + kNameRecText + 1 > n) {
 #pragma unroll
-          for (uint32_t k = 0; k < kNameRecWords; ++k) __builtin_memcpy(&w[k], copy + at + 8u * k - 3u, 8);  // byte 3 = the line's first byte
-          const uint32_t meta = len | (vv << 10) | (end_known ? 1u << 19 : 0u) | (((w[0] >> 24) & 0xFFu) == '@' ? 1u << 20 : 0u);
+            for (uint32_t k = 0; k < kNameRecWords; ++k) __builtin_memcpy(&w[k], copy + at + 8u * k - 3u, 8);  // byte 3 = the line's first byte
+          } else {
+            // the line runs into the next chunk (one header in eight does at 150 bp): its bytes from the image - the
+            // wavefront next door is loading them anyway - and its length from the '\n' among them, if there is one
+            const uint8_t* g = img + cb + at - 3u;
+            unsigned long long nlm[kNameRecWords];
+#pragma unroll
+            for (uint32_t k = 0; k < kNameRecWords; ++k) {
+              __builtin_memcpy(&w[k], g + 8u * k, 8);
+              const unsigned long long y = w[k] ^ 0x0A0A0A0A0A0A0A0Aull;
+              nlm[k] = ~(((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y | 0x7F7F7F7F7F7F7F7Full);
+            }
+            nlm[0] &= ~0xFFFFFFull;  // (the three bytes in front of the line)
+            real = true;
+            len = kNameRecText + 1;  // at least: no '\n' among the bytes of the record
+#pragma unroll
+            for (int k = (int)kNameRecWords - 1; k >= 0; --k)
+              if (nlm[k]) {
+                len = 8u * (uint32_t)k + ((uint32_t)__builtin_ctzll(nlm[k]) >> 3) - 3u;
+                end_known = true;
+              }
+          }
+          len = len > 1023u ? 1023u : len;
+          const uint32_t meta = len | (vv << 10) | (end_known ? 1u << 19 : 0u) | (((w[0] >> 24) & 0xFFu) == '@' ? 1u << 20 : 0u) |
+                                (real ? 1u << 21 : 0u);
           w[0] = (w[0] & 0xFFFFFFFF00000000ull) | meta;
           typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
           u64x2* dst = reinterpret_cast<u64x2*>(nc.recs + ((uint64_t)chunk * nc.K + j) * kNameRecWords);

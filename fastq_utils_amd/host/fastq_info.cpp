@@ -503,6 +503,7 @@ int main(int argc, char** argv) {
   } else {
     fprintf(stderr, "DEFAULT_HASHSIZE=%lu\n", 39000001ul);
     fprintf(stderr, "Scanning and indexing all reads from %s\n", file1);
+    F.lookups = is_paired_data && file2 != nullptr;  // (one file, or "pe": the index is only the uniqueness test)
     run_index_file(file1, is_paired_data, S, F);
     fprintf(stderr, "Scanning complete.\n");
     S.num_reads1 = F.entries;

@@ -222,6 +222,7 @@ struct IndexedFile {
   fqg_file_state st{};
   uint64_t n_records = 0;
   uint64_t entries = 0, index_mem = 0;
+  bool lookups = true;  // a second file will be looked up in it (false: the index is only the uniqueness test)
 };
 
 // (`in`: the opened file; whole: the file as one image - one retained frame - instead of pieces)
@@ -234,13 +235,21 @@ void run_index_input(Input& in, const char* path, int is_pe, Stats& S, IndexedFi
   Probe pr;
   uint64_t base = 0;
   bool info_pending = true;
-  LIB(fqg_index_create(g_ctx, 1 << 20, &F.index));
   F.index_mem = 8;
   while (whole ? in.next(true) : in.next()) {
     probe_piece(pr, in.data(), in.size(), is_pe);
     fqg_validate_result r;
     LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st,
                      FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES, &r));
+    if (!F.index) {
+      // sized from the first piece: a plain file holds about (its bytes / this piece's mean record) names - the table
+      // then never has to be rebuilt at twice the size
+      uint64_t expect = 1 << 20;
+      if (r.n_records && r.consumed && in.plain_bytes() > in.size())
+        expect = (uint64_t)((double)in.plain_bytes() / ((double)r.consumed / (double)r.n_records) * 1.05) + 1024;
+      LIB(fqg_index_create(g_ctx, expect, &F.index));
+      if (!F.lookups) LIB(fqg_index_expect_lookups(F.index, 0));
+    }
     fqg_index_result ir{};
     if (r.n_records > 0) LIB(fqg_index_insert_unique(g_ctx, F.index, &pr.st, &ir));
     // which finding does the serial loop hit first?  per record: read (truncation), name
@@ -288,6 +297,7 @@ void run_index_input(Input& in, const char* path, int is_pe, Stats& S, IndexedFi
     if (r.stopped) break;
     if (!in.final()) in.carry_from(r.consumed);
   }
+  if (!F.index) LIB(fqg_index_create(g_ctx, 1024, &F.index));  // an empty file: an empty index
   F.st = pr.st;
   F.n_records = base;
 }

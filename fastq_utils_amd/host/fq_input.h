@@ -152,6 +152,8 @@ class Input {
   const char* data() const { return data_; }
   size_t size() const { return len_; }
   bool final() const { return eof_; }
+  // bytes of a plain (uncompressed, seekable) input, 0 when unknown: a size hint for whoever sizes tables from it
+  uint64_t plain_bytes() const { return plain_fd_ >= 0 ? plain_size_ : 0; }
   const std::string& path() const { return path_; }
 
  private:

@@ -196,6 +196,10 @@ typedef struct {
 
 int fqg_index_create(fqg_ctx *ctx, uint64_t expected_names, fqg_index **out);
 void fqg_index_destroy(fqg_index *index);
+/* Before the first insert: yes = 0 tells the index that nobody will look names up in it (fastq_info on ONE file only
+ * tests the names for uniqueness, src/fastq_info.c:289-300) - it then keeps no name record per entry (64 bytes each,
+ * which the look-ups of a second file are decided on).  Look-ups still work without them, through the images. */
+int fqg_index_expect_lookups(fqg_index *index, int yes);
 /* Insert the name of every record of the context's current frame (the frame is retained by the
  * index).  Finding: the first record whose header does not start with '@' (FQG_E_WRONG_HEADER,
  * src/fastq.c:448) or whose name is already in the index (FQG_E_DUP_NAME, src/fastq.c:422),
