@@ -55,6 +55,7 @@ struct fqg_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   int cu_count = 256;
+  int lines_per_cu = 0;  // workgroups of k_stream_lines a CU holds (asked once)
   uint64_t stream_min = 1ull << 20;  // images at least this large take the single-pass framing path (FQGPU_STREAM_MIN)
 
   DevBuf image;       // staging for host images
@@ -713,14 +714,13 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
       const uint64_t groups = (n_lines_all + 4 * kWave - 1) / (4 * kWave);
       // a persistent grid: every workgroup must be resident from the start (one that is not would do its whole
       // share after the others have finished)
-      static int per_cu = 0;
-      if (!per_cu) {
+      if (!c->lines_per_cu) {  // (per context: a context is one device, and contexts run on threads of their own)
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines), kBlock, 0) != hipSuccess || nb < 1)
           nb = 4;
-        per_cu = nb;
+        c->lines_per_cu = nb;
       }
-      const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)c->cu_count * per_cu));
+      const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)c->cu_count * c->lines_per_cu));
       hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A);
     }
     out->records_done = true;

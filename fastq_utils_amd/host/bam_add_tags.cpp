@@ -154,6 +154,10 @@ int main(int argc, char* argv[]) {
   std::vector<uint64_t> offsets(n_rec ? n_rec : 1);
   fqg_bam_index_records(stream.data(), stream.size(), offsets.data(), n_rec, &n_rec, &used);
   const uint64_t header_end = n_rec ? offsets[0] : used;
+  if (header_end > stream.size()) {
+    PRINT_ERROR("%s is not a BAM file", inbam_file);
+    return 2;
+  }
 
   // the references of the header (bam_header_read): names as C strings
   std::string names;
@@ -168,6 +172,11 @@ int main(int argc, char* argv[]) {
     const int32_t n_ref = rd32(p);
     p += 4;
     for (int32_t i = 0; i < n_ref; ++i) {
+      // (fqg_bam_index_records vouches for the walk as a whole; each name is checked again where it is used)
+      if (p + 8 > stream.size() || p + 8 + (uint64_t)(uint32_t)rd32(p) > stream.size()) {
+        PRINT_ERROR("%s: truncated BAM header (reference %d)", inbam_file, i);
+        return 2;
+      }
       const uint32_t l_name = (uint32_t)rd32(p);
       const char* nm = (const char*)&stream[p + 4];
       const size_t len = strnlen(nm, l_name);

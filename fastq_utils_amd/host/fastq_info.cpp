@@ -132,6 +132,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
     for (size_t i = 0; i < devs.size(); ++i) th.emplace_back(work, i);
     auto join_all = [&] {
       stop = true;
+      src.abort();  // (a worker may be waiting for a piece, the producer for a slot that stays held after a finding)
       for (auto& t : th)
         if (t.joinable()) t.join();
     };

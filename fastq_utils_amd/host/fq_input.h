@@ -263,6 +263,9 @@ class Input {
   bool next_whole() {
     whole_mode_ = true;
     size_t cap = std::max<size_t>(cap_, 4096), len = whole_carry_;
+    // a plain file's size is known: one allocation of exactly what is left (growing by doubling would hold the old and
+    // the new pinned buffer at once and copy a 32 GB file seven times); gz input and stdin grow as they go
+    if (plain_fd_ >= 0 && plain_size_ >= plain_off_) cap = std::max<size_t>((size_t)(plain_size_ - plain_off_) + len + 1, 4096);
     char* buf = alloc(cap + 1);
     if (len) memcpy(buf, data_ + carry_at_, len);
     whole_carry_ = 0;

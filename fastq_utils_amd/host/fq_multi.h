@@ -69,7 +69,8 @@ class AlignedPieces {
   // next piece in file order; false when the file is exhausted.  Thread-safe.
   bool next(Piece* out) {
     std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [&] { return !ready_.empty() || done_ || failed_; });
+    cv_.wait(lk, [&] { return !ready_.empty() || done_ || failed_ || quit_; });
+    if (quit_) return false;
     if (failed_) {
       FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
       exit(kExitSys);
@@ -82,6 +83,16 @@ class AlignedPieces {
   void release(const Piece& p) {
     std::lock_guard<std::mutex> lk(mu_);
     slots_[(size_t)p.slot].busy = false;
+    cv_.notify_all();
+  }
+  // Stop handing out pieces: wakes the producer (which may be waiting for a free slot that nobody will release any
+  // more) and every consumer waiting in next(), which then returns false.  For the error paths of the consumers: they
+  // stop with pieces still held, and joining them without this would wait forever.
+  void abort() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
     cv_.notify_all();
   }
 

@@ -7,7 +7,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <chrono>
 #include <map>
+#include <thread>
 
 #include "../../fastq_utils_amd/host/fq_multi.h"
 
@@ -34,6 +37,28 @@ int main(int argc, char** argv) {
   };
   std::map<uint64_t, Seen> seen;
   std::mutex mu;
+  {
+    // the error path of the program (fastq_info.cpp: join_all after a finding): consumers stop with pieces still held -
+    // one of them blocked in next() under the fetch lock, the producer waiting for a slot nobody will release.
+    // abort() must let all of them go (this block would hang without it).
+    fqhost::AlignedPieces src(nullptr, argv[1], piece, 3);
+    std::mutex fetch;
+    std::atomic<int> held{0};
+    auto hoard = [&] {
+      fqhost::Piece p;
+      for (;;) {
+        std::lock_guard<std::mutex> lk(fetch);
+        if (!src.next(&p)) return;
+        ++held;  // never released
+        if (p.final) return;
+      }
+    };
+    std::thread a(hoard), b(hoard);
+    for (int spin = 0; spin < 2000 && held.load() < 3; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    src.abort();
+    a.join();
+    b.join();
+  }
   {
     fqhost::AlignedPieces src(nullptr, argv[1], piece, 2 * n_cons + 2);
     auto work = [&] {
