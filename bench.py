@@ -136,6 +136,22 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs):
     ctx.synth_fastq(img1.data_ptr(), n_pairs, 26, first_index=0, seed=777, mate=1)
     ctx.synth_fastq(img2.data_ptr(), n_pairs, 150, first_index=0, seed=778, mate=2)
     ctx.synchronize()
+    # cell barcodes as SURVEY 8d(3) asks: drawn from a list of 10 000, one random base changed in about 1 % of the reads
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(4321)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    wl_codes = torch.randint(0, 4, (10_000, 16), generator=g0, device=dev)
+    cb = img1.view(n_pairs, R1)[:, 45:45 + 16]
+    step_rows = 25_000_000
+    for a in range(0, n_pairs, step_rows):
+        b = min(n_pairs, a + step_rows)
+        pick = torch.randint(0, 10_000, (b - a,), generator=g0, device=dev)
+        codes = wl_codes[pick]
+        err = torch.nonzero(torch.rand(b - a, generator=g0, device=dev) < 0.01).squeeze(1)
+        codes[err, torch.randint(0, 16, (err.numel(),), generator=g0, device=dev)] = torch.randint(0, 4, (err.numel(),), generator=g0, device=dev)
+        cb[a:b] = acgt[codes]
+        del pick, codes, err
+    torch.cuda.synchronize()
     # barcode qualities as SURVEY 8d(3) asks: Phred 12..40, and one base below Phred 10 in about 5 % of the reads
     q = img1.view(n_pairs, R1)[:, 45 + 26 + 3: 45 + 26 + 3 + 26]
     q.clamp_(min=33 + 12)
@@ -197,6 +213,40 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs):
         "properties_hold": bool(ok), "expected_discarded": want_disc, "sam_bytes_per_kept_pair": r["out_bytes"][0] / max(1, kept),
         "first_2000_pairs_identical_to_oracle": got == body and want["exit"] == 0,
     }
+    # the whitelist stage, on its own ("report a whitelist-membership stage separately"): the 16 cell-barcode
+    # characters of every index read packed as bam_umi_count packs them and looked up in the set its --known_cells file
+    # gives (valid_barcode, src/bam_umi_count.c:523-535); the count is recomputed with torch from the same bytes
+    try:
+        wl_bytes = acgt[wl_codes].cpu().numpy()
+        wl = A.Whitelist.from_lines(ctx, b"".join(bytes(row) + b"\n" for row in wl_bytes))
+        ctx.barcodes_whitelist(frames[A.INDEX1], wl, 0, 16, n_records=n_pairs)
+        ctx.profile(True)
+        ctx.profile_reset()
+        wr = ctx.barcodes_whitelist(frames[A.INDEX1], wl, 0, 16, n_records=n_pairs)
+        ctx.synchronize()
+        wms = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_bc_whitelist") and v[0] > 0}
+        ctx.profile(False)
+        pw = torch.tensor([10 ** k for k in range(16)], dtype=torch.int64, device=dev)  # (the string is packed from its end)
+        lut = torch.zeros(256, dtype=torch.int64, device=dev)
+        for ch, dgt in zip(b"ACGTN", range(1, 6)):
+            lut[ch] = dgt
+        wl_packed = ((wl_codes + 1) * pw).sum(dim=1)
+        want_valid = 0
+        for a in range(0, n_pairs, step_rows):
+            b = min(n_pairs, a + step_rows)
+            want_valid += int(torch.isin((lut[cb[a:b].long()] * pw).sum(dim=1), wl_packed).sum().item())
+        kms = sum(wms.values())
+        out["whitelist_stage"] = {
+            "what": "valid_barcode on the 16 cell-barcode characters of every index read against a 10 000-entry whitelist (fqg_barcodes_whitelist)",
+            "whitelist_entries": 10_000, "reads": n_pairs, "valid": wr["n_valid"], "expected_valid": want_valid,
+            "short": wr["n_short"], "ok": wr["n_valid"] == want_valid and wr["n_short"] == 0, "kernel_ms": kms,
+            "Mreads_per_s": n_pairs / (kms * 1e-3) / 1e6 if kms else None,
+            "algorithmic_bytes_per_read": 16 + 16,  # the barcode + the two line ends that locate it
+            "achieved_GBps": 32.0 * n_pairs / (kms * 1e-3) / 1e9 if kms else None,
+        }
+        wl.close()
+    except Exception as e:
+        out["whitelist_stage"] = {"error": repr(e)[:300]}
     for f in frames.values():
         f.release()
     ref = os.path.join(REPO, "oracle", "_ref", "fastq_pre_barcodes")

@@ -35,6 +35,7 @@ EXPORTS = [
     "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_index_names_captured", "fqg_index_expect_lookups", "fqg_records_gather",
     "fqg_records_gather_output", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
+    "fqg_whitelist_create", "fqg_whitelist_destroy", "fqg_barcodes_whitelist",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
     "fqg_umi_count", "fqg_umi_features",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
@@ -246,6 +247,11 @@ def load():
     L.fqg_fpset_pair_runs.argtypes = [vp, vp, C.POINTER(PairSummary), C.POINTER(u64), u64]
     L.fqg_frame_name.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_char_p, u64]
     L.fqg_frame_name.restype = C.c_int64
+    L.fqg_whitelist_create.argtypes = [vp, C.POINTER(u64), u64, C.POINTER(vp)]
+    L.fqg_whitelist_destroy.argtypes = [vp]
+    L.fqg_whitelist_destroy.restype = None
+    L.fqg_barcodes_whitelist.argtypes = [vp, vp, u64, u64, u64, C.c_int64, C.c_int64, vp, C.POINTER(C.c_uint8),
+                                         C.POINTER(WhitelistResult)]
     L.fqg_pack_barcode.argtypes = [C.c_char_p]
     L.fqg_pack_barcode.restype = u64
     L.fqg_unpack_barcode.argtypes = [u64, C.c_char_p]
@@ -317,6 +323,34 @@ class Accumulator:
 
     def merge(self, blob: bytes):
         self.ctx._check(load().fqg_acc_merge(self.h, blob, len(blob)))
+
+
+class WhitelistResult(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_valid", C.c_uint64), ("n_short", C.c_uint64)]
+
+
+class Whitelist:
+    """Device set of packed barcodes (fqg_whitelist): what load_whitelist builds from a --known_cells file."""
+
+    def __init__(self, ctx, packed):
+        self.ctx = ctx
+        arr = (C.c_uint64 * max(1, len(packed)))(*packed)
+        h = C.c_void_p()
+        ctx._check(load().fqg_whitelist_create(ctx.h, arr, len(packed), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_lines(cls, ctx, text):
+        """the lines of a whitelist file as the reference reads them (fgets + char2uint_64 per non-empty line)"""
+        lines = text.split(b"\n")
+        if lines and lines[-1] == b"":
+            lines.pop()
+        return cls(ctx, [int(load().fqg_pack_barcode(ln + b"\n")) for ln in lines])
+
+    def close(self):
+        if self.h:
+            load().fqg_whitelist_destroy(self.h)
+            self.h = None
 
 
 class Frame:
@@ -548,6 +582,21 @@ class Context:
         buf = C.create_string_buffer(max(1, nbytes))
         self._check(load().fqg_records_filter_output(self.h, buf, nbytes))
         return buf.raw[:nbytes]
+
+    def barcodes_whitelist(self, frame, whitelist, offset, size, n_records=None, first_record=0, step=1, want_flags=False):
+        """valid_barcode (src/bam_umi_count.c:523-535) on the `size` characters at `offset` of every record's sequence;
+        returns the counts (and one byte per record when want_flags)"""
+        import numpy as np
+        n = frame.n_records if n_records is None else n_records
+        r = WhitelistResult()
+        flags = np.zeros(max(1, n), dtype=np.uint8) if want_flags else None
+        self._check(load().fqg_barcodes_whitelist(self.h, frame.h, first_record, step, n, offset, size, whitelist.h,
+                                                  flags.ctypes.data_as(C.POINTER(C.c_uint8)) if want_flags else None,
+                                                  C.byref(r)))
+        d = {k: int(getattr(r, k)) for k, _ in WhitelistResult._fields_}
+        if want_flags:
+            d["valid"] = flags[:n]
+        return d
 
     def barcodes_output(self, which, nbytes):
         buf = C.create_string_buffer(max(1, nbytes))

@@ -1656,6 +1656,81 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   return 0;
 }
 
+// ---- whitelist membership ---------------------------------------------------------------------
+struct fqg_whitelist {
+  fqg_ctx* ctx = nullptr;
+  DevBuf set;
+  uint64_t capacity = 0;
+};
+
+int fqg_whitelist_create(fqg_ctx* c, const uint64_t* packed, uint64_t n, fqg_whitelist** out) {
+  if (!c || !out || (!packed && n)) return FQG_ERR_ARG;
+  *out = nullptr;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint64_t cap = 1024;
+  while (cap < 4 * n) cap <<= 1;
+  std::vector<WlSlot> host(cap, WlSlot{0, 0});
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t at = wl_hash(packed[i]) & (cap - 1);
+    while (host[at].used && host[at].key != packed[i]) at = (at + 1) & (cap - 1);
+    host[at] = WlSlot{packed[i], 1};
+  }
+  std::unique_ptr<fqg_whitelist> w(new fqg_whitelist());
+  w->ctx = c;
+  w->capacity = cap;
+  int rc;
+  if ((rc = ensure(c, w->set, cap * sizeof(WlSlot)))) return rc;
+  HIP_TRY(c, hipMemcpy(w->set.p, host.data(), cap * sizeof(WlSlot), hipMemcpyHostToDevice));
+  *out = w.release();
+  return 0;
+}
+
+void fqg_whitelist_destroy(fqg_whitelist* w) {
+  if (!w) return;
+  (void)hipStreamSynchronize(w->ctx->stream);
+  release(w->set);
+  delete w;
+}
+
+int fqg_barcodes_whitelist(fqg_ctx* c, const fqg_frame* frame, uint64_t first, uint64_t step, uint64_t n, int64_t offset,
+                           int64_t size, const fqg_whitelist* wl, uint8_t* valid, fqg_whitelist_result* out) {
+  if (!c || !frame || !wl || !out || wl->ctx != c || frame->ctx != c) return FQG_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  if (offset < 0 || size < 1 || size > kWlMaxSize) return fail(c, FQG_ERR_ARG, "fqg_barcodes_whitelist: offset >= 0 and 1 <= size <= 56");
+  if (frame->flags & kFlagNul) return fail(c, FQG_ERR_ARG, "fqg_barcodes_whitelist: input holds NUL bytes");
+  if (step < 1 || (n && first + (n - 1) * step >= frame->fv.n_records)) return fail(c, FQG_ERR_ARG, "fqg_barcodes_whitelist: records beyond the frame");
+  out->n_records = n;
+  if (!n) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  uint8_t* d_valid = nullptr;
+  if (valid) {
+    if ((rc = ensure(c, c->bc_status, n))) return rc;
+    d_valid = (uint8_t*)c->bc_status.p;
+  }
+  WlCall* d_call = reinterpret_cast<WlCall*>(c->d_bcall);
+  HIP_TRY(c, hipMemsetAsync(d_call, 0, sizeof(WlCall), c->stream));
+  {
+    ProfScope ps(c, "k_bc_whitelist");
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 32));
+#define FQG_WL(W)                                                                                                       \
+  hipLaunchKernelGGL(k_bc_whitelist<W>, dim3(grid), dim3(kBlock), 0, c->stream, frame->fv, first, step, n, (uint32_t)offset, \
+                     (uint32_t)size, (const WlSlot*)wl->set.p, wl->capacity - 1, d_valid, d_call)
+    if (size <= 16) FQG_WL(2);
+    else if (size <= 32) FQG_WL(4);
+    else FQG_WL(7);
+#undef FQG_WL
+  }
+  WlCall* h_call = reinterpret_cast<WlCall*>(c->h_bcall);
+  HIP_TRY(c, hipMemcpyAsync(h_call, d_call, sizeof(WlCall), hipMemcpyDeviceToHost, c->stream));
+  if (valid) HIP_TRY(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  out->n_valid = h_call->n_valid;
+  out->n_short = h_call->n_short;
+  return 0;
+}
+
 // ---- per-record filters ---------------------------------------------------------------------
 int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record, uint64_t n_rec,
                        const fqg_filter_params* fp, fqg_filter_result* out) {

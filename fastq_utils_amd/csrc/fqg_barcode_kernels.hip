@@ -1068,4 +1068,89 @@ __global__ __launch_bounds__(kBlock) void k_bc_emit_direct(BcParams P, BcTile tc
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// whitelist membership of a barcode cut out of the reads (BASELINE configs[2]: "known_cells whitelist"): the cell
+// barcode that fastq_pre_barcodes puts into the read name is what bam_umi_count later packs with char2uint_64
+// (src/bam_umi_count.c:364-382: base 10, A C G T N -> 1..5, from the END of the string, stopping at the first other
+// character) and looks up with valid_barcode (:523-535) in the table load_whitelist (:543-579) filled.  One thread
+// per record: the `size` characters at `offset` of the sequence line (get_barcode's bounds, src/fastq_pre_barcodes.c:232:
+// a read too short for them has no barcode), packed in registers, looked up in a small open-addressing set that the
+// L2 keeps (ten thousand entries).
+// ------------------------------------------------------------------------------------------
+struct WlSlot {
+  unsigned long long key, used;
+};
+struct WlCall {
+  unsigned long long n_valid, n_short;
+};
+__host__ __device__ inline uint64_t wl_hash(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+constexpr int kWlMaxSize = 56;  // barcode characters (the reference's arrays hold 49)
+
+template <int WORDS>  // 8-byte words that hold the barcode
+__global__ __launch_bounds__(kBlock) void k_bc_whitelist(FrameView f, uint64_t first, uint64_t step, uint64_t n, uint32_t offset,
+                                                         uint32_t size, const WlSlot* __restrict__ set, uint64_t mask,
+                                                         uint8_t* __restrict__ valid, WlCall* __restrict__ call) {
+  unsigned long long n_valid = 0, n_short = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) {
+    const uint64_t r = first + k * step;
+    const uint64_t b = f.line_end[4 * r] + 1, e = f.line_end[4 * r + 1];  // the sequence line
+    bool ok = false;
+    if ((uint64_t)offset + size > e - b) ++n_short;  // (offset + size > read_len - 1, read_len = strlen(seq) with its '\n')
+    else {
+      const uint8_t* p = f.img + b + offset;
+      uint64_t w[WORDS];
+#pragma unroll
+      for (int i = 0; i < WORDS; ++i) {
+        w[i] = 0;
+        // (whole words while they lie inside the image; the last bytes of an image one by one)
+        if (8u * i < size) {
+          if (b + offset + 8u * i + 8u <= f.nbytes) __builtin_memcpy(&w[i], p + 8 * i, 8);
+          else
+            for (uint32_t q = 0; q < 8 && 8u * i + q < size; ++q) w[i] |= (uint64_t)p[8 * i + q] << (8 * q);
+        }
+      }
+      uint64_t v = 0;
+      bool stopped = false;
+#pragma unroll
+      for (int pos = 8 * WORDS - 1; pos >= 0; --pos) {
+        const uint32_t c = (uint32_t)(w[pos >> 3] >> (8 * (pos & 7))) & 0xFFu;
+        // A C G T N (either case) -> 1 2 3 4 5: c & 0xDF folds the case
+        const uint32_t u = c & 0xDFu;
+        const uint32_t base = u == 'A' ? 1u : u == 'C' ? 2u : u == 'G' ? 3u : u == 'T' ? 4u : u == 'N' ? 5u : 0u;
+        if ((uint32_t)pos < size && !stopped) {
+          if (!base) stopped = true;
+          else v = v * 10 + base;
+        }
+      }
+      for (uint64_t at = wl_hash(v) & mask;; at = (at + 1) & mask) {
+        const WlSlot s = set[at];
+        if (!s.used) break;
+        if (s.key == v) {
+          ok = true;
+          break;
+        }
+      }
+    }
+    if (valid) valid[k] = ok ? 1 : 0;
+    n_valid += ok ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    n_valid += __shfl_down(n_valid, d, 64);
+    n_short += __shfl_down(n_short, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_valid) atomicAdd(&call->n_valid, n_valid);
+    if (n_short) atomicAdd(&call->n_short, n_short);
+  }
+}
+
 }  // namespace fqg

@@ -316,6 +316,24 @@ int fqg_barcodes_transform(fqg_ctx *ctx, const fqg_frame *const frames[6], const
 /* copy output `which` (0 SAM, 1, 2) of the last transform to host memory */
 int fqg_barcodes_output(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
 
+/* ---- whitelist membership of a barcode (BASELINE configs[2]: "known_cells whitelist") ------------------
+ * The cell barcode that fastq_pre_barcodes cuts out of a read is what bam_umi_count later packs with char2uint_64
+ * (src/bam_umi_count.c:364-382) and tests with valid_barcode (:523-535) against the table load_whitelist (:543-579)
+ * filled from the --known_cells file.  fqg_whitelist_create takes the packed lines of such a file (fqg_pack_barcode
+ * on every line that fgets returns non-empty, in any order; repeats are fine); fqg_barcodes_whitelist answers, for
+ * records first_record, first_record + step, ... of a retained frame, whether the `size` characters at `offset` of
+ * the sequence line are a member.  A read too short for them (get_barcode's bounds, src/fastq_pre_barcodes.c:232)
+ * has no barcode: not valid, counted in n_short.  valid (host memory, one byte per record) may be NULL. */
+typedef struct fqg_whitelist fqg_whitelist;
+typedef struct {
+  uint64_t n_records, n_valid, n_short;
+} fqg_whitelist_result;
+int fqg_whitelist_create(fqg_ctx *ctx, const uint64_t *packed, uint64_t n, fqg_whitelist **out);
+void fqg_whitelist_destroy(fqg_whitelist *wl);
+int fqg_barcodes_whitelist(fqg_ctx *ctx, const fqg_frame *frame, uint64_t first_record, uint64_t step, uint64_t n_records,
+                           int64_t offset, int64_t size, const fqg_whitelist *wl, uint8_t *valid,
+                           fqg_whitelist_result *out);
+
 /* ---- per-record filters (fastq_filter_n, fastq_trim_poly_at) ------------------------------------
  * Replaces the record loops of fastq_filter_n (src/fastq_filter_n.c:75-91: count N/n in the sequence,
  * drop the record when there are more than read_len * max_n / 100) and of fastq_trim_poly_at
