@@ -392,12 +392,24 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
                 assert p.returncode == 0, p.stderr[-300:]
                 assert ("Number of reads: %d" % n).encode() in p.stderr, p.stderr[-300:]
             med = sorted(runs)[1]
-            threads = min(32, os.cpu_count() or 1)
+            threads = min(12, os.cpu_count() or 1)
+            # where the time goes (FQGPU_TIMING=1 makes the program say), and two other stager shapes
+            variants = {}
+            for label, env in (("timing", {"FQGPU_TIMING": "1"}), ("32_threads", {"FQGPU_HOST_THREADS": "32", "FQGPU_TIMING": "1"}),
+                               ("256MiB_slots", {"FQGPU_CHUNK_MB": "256", "FQGPU_TIMING": "1"}),
+                               ("two_contexts_one_gpu", {"FQGPU_DEVICES": "0,0"})):
+                t0 = time.perf_counter()
+                p = subprocess.run([exe, "-r", path], capture_output=True, env=dict(os.environ, **env))
+                dt = time.perf_counter() - t0
+                err = p.stderr.decode("latin-1")
+                variants[label] = {"seconds": dt, "Mreads_per_s": n / dt / 1e6, "ok": p.returncode == 0,
+                                   "says": [ln[ln.find("fqgpu timing"):] for ln in err.splitlines() if "fqgpu timing" in ln]}
             out["negative_controls"] = negative_controls(exe, path, arr, n, R)
             out["cli_fastq_info_r_tmpfs_file"] = {
                 "seconds_median_of_3": med, "seconds": runs, "Mreads_per_s": n / med / 1e6, "GBps": nbytes / med / 1e9,
-                "stager": f"3 pinned slots of 256 MiB, {threads} pread threads per slot (FQGPU_CHUNK_MB / FQGPU_HOST_THREADS)",
-                "includes": "process start, HIP initialisation, pinned allocation, read, H2D, kernels, summary"}
+                "stager": f"3 pinned slots of 128 MiB, a pool of {threads} pread threads (FQGPU_CHUNK_MB / FQGPU_HOST_THREADS)",
+                "includes": "process start, HIP initialisation, pinned allocation, read, H2D, kernels, summary",
+                "variants": variants}
         finally:
             if os.path.exists(path):
                 os.unlink(path)

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
 #include <map>
 
 #include "fq_common.h"
@@ -32,16 +33,46 @@ void print_usage(int verbose) {
   }
 }
 
+static const std::chrono::steady_clock::time_point g_t_start = std::chrono::steady_clock::now();
+static double since_start() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t_start).count(); }
+
 // ---- -r, one file: validate_single_fastq_file (src/fastq_info.c:155-176) ------------------
 void run_single_noindex(const char* path, Stats& S) {
   Input in(g_ctx, path, piece_bytes());
   Probe pr;
   uint64_t base = 0;
   bool info_pending = true;
-  while (in.next()) {
+  // FQGPU_TIMING=1: where the wall time of the loop goes (waiting for the reader / copying + validating), on stderr
+  const bool timing = getenv("FQGPU_TIMING") != nullptr;
+  double t_wait = 0, t_gpu = 0;
+  uint64_t n_pieces = 0, n_bytes = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  struct Report {
+    const bool on;
+    const double& w;
+    const double& g;
+    const uint64_t& p;
+    const uint64_t& b;
+    ~Report() {
+      if (on) fprintf(stderr, "\nfqgpu timing: %llu pieces, %.3f GB; waiting for the reader %.3f s, copy + validate %.3f s; %.3f s since the program started\n",
+                      (unsigned long long)p, b / 1e9, w, g, (double)clock() / CLOCKS_PER_SEC >= 0 ? since_start() : 0.0);
+    }
+  } report{timing, t_wait, t_gpu, n_pieces, n_bytes};
+  for (;;) {
+    const double t0 = timing ? now() : 0;
+    if (!in.next()) break;
+    const double t1 = timing ? now() : 0;
     probe_piece(pr, in.data(), in.size(), 1);
     fqg_validate_result r;
     LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st, 0, &r));
+    if (timing) {
+      if (!n_pieces) fprintf(stderr, "fqgpu timing: first piece in hand %.3f s, validated %.3f s after the program started\n",
+                             since_start() - (now() - t1), since_start());
+      t_wait += t1 - t0;
+      t_gpu += now() - t1;
+      ++n_pieces;
+      n_bytes += in.size();
+    }
     if (info_pending && base == 0 && r.n_records > 0) {
       if (!(r.code && r.record == 0 && is_early_code(r.code))) print_probe(pr);
       info_pending = false;
@@ -479,7 +510,9 @@ int main(int argc, char** argv) {
 
   const char* dev = getenv("FQGPU_DEVICE");
   const std::vector<int> devices = devices_from_env();  // FQGPU_DEVICES=0,1,..: the -r pass over several GPUs
+  fqhost::keep_slots_until_exit() = true;
   int rc = fqg_open(!devices.empty() ? devices[0] : dev ? atoi(dev) : 0, &g_ctx);
+  if (getenv("FQGPU_TIMING")) fprintf(stderr, "fqgpu timing: context open %.3f s after the program started\n", since_start());
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
     exit(kExitSys);
@@ -562,5 +595,9 @@ int main(int argc, char** argv) {
   LIB(fqg_acc_median(S.acc1, S.acc2, &med));
   fprintf(stderr, "Read length: %lu %lu %u\n", min_rl - 1, max_rl - 1, (unsigned)(med - 1));
   fprintf(stderr, "OK\n");
-  exit(0);
+  if (getenv("FQGPU_TIMING")) fprintf(stderr, "fqgpu timing: summary printed %.3f s after the program started\n", since_start());
+  // everything is said and nothing is open for writing: leave without the HIP runtime's tear-down (0.1 s)
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

@@ -28,7 +28,7 @@ fqg_ctx* g_ctx = nullptr;
 
 size_t piece_bytes() {
   const char* e = getenv("FQGPU_CHUNK_MB");
-  size_t mb = e ? strtoull(e, nullptr, 10) : 256;  // (3 pinned slots of this size: fq_input.h)
+  size_t mb = e ? strtoull(e, nullptr, 10) : 128;  // (3 pinned slots of this size: fq_input.h; pinning them is part of the start-up)
   if (mb < 1) mb = 1;
   return mb << 20;
 }

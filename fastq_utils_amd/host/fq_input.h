@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -42,11 +44,87 @@ namespace fqhost {
   } while (0)
 constexpr int kExitParams = 1, kExitSys = 2, kExitFormat = 3;
 
+// The programs run one job and exit: un-pinning hundreds of megabytes of staging slots first (0.1 - 0.2 s) buys nothing -
+// the operating system takes the memory back.  Set once by a program's main(); library-style users leave it alone.
+inline bool& keep_slots_until_exit() {
+  static bool v = false;
+  return v;
+}
+
 inline unsigned host_read_threads() {
   if (const char* e = getenv("FQGPU_HOST_THREADS")) return (unsigned)std::max(1L, strtol(e, nullptr, 10));
   const unsigned hw = std::thread::hardware_concurrency();
-  return std::max(1u, std::min(32u, hw ? hw : 1u));
+  // (a dozen copy a tmpfs file faster than PCIe takes it; more of them only compete with the DMA for host memory:
+  // 8 / 16 / 32 / 64 threads -> 1.06 / 1.16 / 1.24 / 1.46 s for the 100 M-read file of the bench)
+  return std::max(1u, std::min(12u, hw ? hw : 1u));
 }
+
+// A few reader threads that stay around: every slot of a plain file is read by all of them at once, and starting
+// thirty threads per 256 MiB slot cost a quarter of the time the slot's copy to the GPU takes.
+class ReaderPool {
+ public:
+  explicit ReaderPool(unsigned n) : n_(std::max(1u, n)) {
+    for (unsigned t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
+  }
+  ~ReaderPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  unsigned size() const { return n_; }
+  // fn(t) for t in [0, parts), parts <= size(); the caller runs part 0 and returns when all are done
+  template <class F>
+  void run(unsigned parts, F&& fn) {
+    if (parts <= 1) {
+      fn(0u);
+      return;
+    }
+    std::function<void(unsigned)> f = fn;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &f;
+      parts_ = parts;
+      left_ = parts - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    fn(0u);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return left_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void loop(unsigned t) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)>* f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+        if (t < parts_) f = fn_;
+      }
+      if (!f) continue;
+      (*f)(t);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  unsigned n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned)>* fn_ = nullptr;
+  unsigned parts_ = 0, left_ = 0;
+  unsigned long gen_ = 0;
+  bool quit_ = false;
+};
 
 class Input {
  public:
@@ -86,6 +164,7 @@ class Input {
     if (producer_.joinable()) producer_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
+    if (keep_slots_until_exit()) return;
     for (Slot& s : slots_)
       if (s.buf) fqg_host_free(ctx_, s.buf);
     if (whole_) fqg_host_free(ctx_, whole_);
@@ -162,7 +241,7 @@ class Input {
   struct Slot {
     char* buf = nullptr;
     size_t head = 0, len = 0;
-    bool ready = false, last = false;
+    bool ready = false, last = false, allocated = false;
   };
 
   char* alloc(size_t n) {
@@ -203,6 +282,7 @@ class Input {
     const uint64_t left = plain_size_ - plain_off_;
     const size_t len = (size_t)std::min<uint64_t>(want, left);
     const unsigned T = (unsigned)std::min<uint64_t>(host_read_threads(), std::max<uint64_t>(1, len >> 22));
+    if (T > 1 && !pool_) pool_.reset(new ReaderPool(host_read_threads()));
     std::atomic<bool> bad{false};
     auto part = [&](unsigned t) {
       const size_t a = (len * t / T) & ~(size_t)4095, b = t + 1 == T ? len : (len * (t + 1) / T) & ~(size_t)4095;
@@ -217,12 +297,7 @@ class Input {
       }
     };
     if (T <= 1) part(0);
-    else {
-      std::vector<std::thread> th;
-      for (unsigned t = 1; t < T; ++t) th.emplace_back(part, t);
-      part(0);
-      for (auto& x : th) x.join();
-    }
+    else pool_->run(T, part);
     if (bad) {
       std::lock_guard<std::mutex> lk(mu_);
       fail_msg_ = "read error";
@@ -235,17 +310,46 @@ class Input {
   }
 
   void produce() {
+    // pinning a slot takes as long as filling it: the slots behind the first are allocated by a helper while the first
+    // is being read (the file may well end inside the first)
+    const size_t head = std::min(kHead, std::max<size_t>(cap_, 4096));  // (tiny files: tiny slots)
+    std::thread helper;
+    const bool more = plain_fd_ < 0 || plain_size_ > cap_;
+    if (more)
+      helper = std::thread([this, head] {
+        for (int i = 1; i < kSlots; ++i) {
+          char* b = static_cast<char*>(fqg_host_alloc(ctx_, head + cap_ + 1));
+          std::lock_guard<std::mutex> lk(mu_);
+          slots_[i].buf = b;
+          slots_[i].allocated = true;
+          cv_.notify_all();
+          if (!b || quit_) return;
+        }
+      });
+    struct Join {
+      std::thread& t;
+      ~Join() {
+        if (t.joinable()) t.join();
+      }
+    } join{helper};
     for (int i = 0;; i = (i + 1) % kSlots) {
       Slot& s = slots_[i];
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return !s.ready || quit_; });
+        cv_.wait(lk, [&] { return (!s.ready && (i == 0 || !more || s.allocated)) || quit_; });
         if (quit_) return;
       }
       if (!s.buf) {
-        s.head = std::min(kHead, std::max<size_t>(cap_, 4096));  // (tiny files: tiny slots)
-        s.buf = alloc(s.head + cap_ + 1);
+        if (i > 0 && more) {
+          std::lock_guard<std::mutex> lk(mu_);
+          fail_msg_ = "unable to allocate pinned memory";
+          failed_ = true;
+          cv_.notify_all();
+          return;
+        }
+        s.buf = alloc(head + cap_ + 1);
       }
+      s.head = head;
       bool at_end = false;
       const size_t len = plain_fd_ >= 0 ? read_plain(s.buf + s.head, cap_, &at_end) : read_gz(s.buf + s.head, cap_, &at_end);
       {
@@ -310,6 +414,7 @@ class Input {
   uint64_t plain_size_ = 0, plain_off_ = 0;
   size_t cap_;
   Slot slots_[kSlots];
+  std::unique_ptr<ReaderPool> pool_;
   std::thread producer_;
   std::mutex mu_;
   std::condition_variable cv_;

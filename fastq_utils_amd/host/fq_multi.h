@@ -63,6 +63,7 @@ class AlignedPieces {
     if (producer_.joinable()) producer_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
+    if (keep_slots_until_exit()) return;
     for (auto& s : slots_)
       if (s.buf) fqg_host_free(ctx_, s.buf);
   }
@@ -128,10 +129,8 @@ class AlignedPieces {
       };
       if (T <= 1) part(0);
       else {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(part, t);
-        part(0);
-        for (auto& x : th) x.join();
+        if (!pool_) pool_.reset(new ReaderPool(host_read_threads()));
+        pool_->run(T, part);
       }
       if (bad) {
         fail("read error");
@@ -286,6 +285,7 @@ class AlignedPieces {
   std::thread producer_;
   std::mutex mu_;
   std::condition_variable cv_;
+  std::unique_ptr<ReaderPool> pool_;
   bool quit_ = false, failed_ = false, done_ = false;
   std::string fail_msg_;
 };
