@@ -37,7 +37,7 @@ EXPORTS = [
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_whitelist_create", "fqg_whitelist_destroy", "fqg_barcodes_whitelist",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
-    "fqg_umi_count", "fqg_umi_features",
+    "fqg_umi_count", "fqg_umi_features", "fqg_umi_record_features", "fqg_umi_replayed_features", "fqg_umi_umis",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
     "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
     "fqg_fpset_candidates", "fqg_fpset_pair_runs", "fqg_frame_name",
@@ -94,7 +94,9 @@ class UmiParams(C.Structure):
                 ("max_cells", C.c_uint32), ("max_features", C.c_uint32), ("min_reads", C.c_uint32),
                 ("min_umis", C.c_uint32), ("known_umis", C.POINTER(C.c_uint64)),
                 ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64),
-                ("defer_output", C.c_int32), ("strict_set", C.c_int32)]
+                ("defer_output", C.c_int32), ("strict_set", C.c_int32),
+                ("umi_table_keys", C.POINTER(C.c_uint64)), ("umi_table_ids", C.POINTER(C.c_uint32)),
+                ("n_umi_table", C.c_uint64)]
 
 
 class BamTagsParams(C.Structure):
@@ -670,7 +672,7 @@ class Context:
     def umi_count(self, stream, offsets=None, sorted_by_cell=True, uniq_mapped_only=False, feat_tag=b"GX",
                   cell_tag=b"CR", umi_tag=b"RX", max_cells=None, max_features=100000, min_reads=0, min_umis=0,
                   known_umis=None, known_cells=None, nbytes=None, want_entries=True, defer_output=False,
-                  strict_set=False):
+                  strict_set=False, umi_table=None):
         """bam_umi_count's alignment loop on an inflated BAM stream: bytes (host) or an int device pointer
         (then `nbytes` and `offsets` are required).  Returns the result fields plus, when the call
         succeeded, feature names / packed cells in id order and the (row, col, value) lines."""
@@ -705,6 +707,12 @@ class Context:
                 keep.append(arr)
                 setattr(p, name, arr)
                 setattr(p, "n_" + name, len(vals))
+        if umi_table is not None:  # (sorted packed UMIs, their ids in the whole file): numpy uint64 / uint32 arrays
+            tk, ti = umi_table
+            keep += [tk, ti]
+            p.umi_table_keys = tk.ctypes.data_as(C.POINTER(C.c_uint64))
+            p.umi_table_ids = ti.ctypes.data_as(C.POINTER(C.c_uint32))
+            p.n_umi_table = len(tk)
         r = UmiResult()
         self._check(L.fqg_umi_count(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
                                     MEM_HOST if host else MEM_DEVICE, offs, n_rec, C.byref(p), C.byref(r)))
@@ -719,6 +727,35 @@ class Context:
             if not defer_output:
                 out["entries"] = self._umi_entries(r)
         return out
+
+    def umi_umis(self):
+        """the packed UMIs of the last umi_count that are not whitelisted, in order of first appearance (numpy uint64)"""
+        import numpy as np
+        L = load()
+        L.fqg_umi_umis.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        n = C.c_uint64()
+        self._check(L.fqg_umi_umis(self.h, None, 0, C.byref(n)))
+        a = np.zeros(max(1, n.value), dtype=np.uint64)
+        self._check(L.fqg_umi_umis(self.h, a.ctypes.data, n.value, C.byref(n)))
+        return a[:n.value]
+
+    def umi_record_features(self, n_records):
+        """after umi_count(defer_output=True): the feature id of every alignment (0: not counted), numpy uint32"""
+        import numpy as np
+        a = np.zeros(max(1, n_records), dtype=np.uint32)
+        L = load()
+        L.fqg_umi_record_features.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(L.fqg_umi_record_features(self.h, a.ctypes.data, n_records))
+        return a[:n_records]
+
+    def umi_replayed_features(self, n_features):
+        """after umi_count(defer_output=True): per feature id (index 0 unused) whether one of its sets was replayed"""
+        import numpy as np
+        a = np.zeros(n_features + 1, dtype=np.uint8)
+        L = load()
+        L.fqg_umi_replayed_features.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(L.fqg_umi_replayed_features(self.h, a.ctypes.data, n_features + 1))
+        return a
 
     def bam_add_tags(self, stream, tenx=False, tx_tag=False, targets=(), genes=None, offsets=None, nbytes=None,
                      want_output=True):

@@ -77,7 +77,8 @@ struct fqg_ctx {
   uint64_t last_names_captured = 0;    // of the last index call: records whose name came straight from a capture record
   const uint8_t* names_img = nullptr;  // the image it belongs to (null: no capture) - the current frame's, or the
   uint64_t names_nbytes = 0;           // capture is not used
-  DevBuf umi_names, umi_cells, umi_entries[2];  // results of the last fqg_umi_count
+  DevBuf umi_names, umi_cells, umi_umis, umi_entries[2];  // results of the last fqg_umi_count
+  uint64_t umi_n_umis = 0;
   uint64_t umi_n_features = 0, umi_n_cells = 0, umi_n_entries[2] = {0, 0};
   void* umi_state = nullptr;  // UmiState of a deferred fqg_umi_count (fqg_umi_abi.inc)
   DevBuf umi_arena;           // scratch memory of fqg_umi_count, kept between calls
@@ -282,6 +283,7 @@ void fqg_close(fqg_ctx* c) {
   release(c->umi_arena);
   release(c->umi_names);
   release(c->umi_cells);
+  release(c->umi_umis);
   release(c->umi_entries[0]);
   release(c->umi_entries[1]);
   release(c->bc_status);

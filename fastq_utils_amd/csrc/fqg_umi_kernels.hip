@@ -57,6 +57,11 @@ struct UmiParams {
   const unsigned long long* known_cells_sorted;
   uint32_t n_known_cells;
   int have_known_umis, have_known_cells;
+  // shards of one file: the file's numbering of the UMIs that are not whitelisted (sorted keys -> 1-based ids); null:
+  // numbered in order of first appearance in this call
+  const unsigned long long* umi_table_keys;
+  const uint32_t* umi_table_ids;
+  uint32_t n_umi_table;
 };
 
 struct UmiRec {            // per record, after parsing
@@ -663,7 +668,20 @@ __global__ __launch_bounds__(kBlock) void k_umi_assign(uint32_t n, UmiParams P, 
   if (st == kStCounted) {
     const UmiRec r = rec[i];
     const uint32_t us = uslot[i];
-    if (us != kNoIdx) uid = (us & kWhiteBit) ? (us & ~kWhiteBit) + 1u : P.n_known_umis + pu.at(U.first[us]) + 1u;
+    if (us != kNoIdx) {
+      if (us & kWhiteBit) uid = (us & ~kWhiteBit) + 1u;
+      else if (!P.umi_table_keys) uid = P.n_known_umis + pu.at(U.first[us]) + 1u;
+      else {  // the id the whole file gives this UMI
+        uint32_t lo = 0, hi = P.n_umi_table;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (P.umi_table_keys[mid] < r.umi_i) lo = mid + 1;
+          else hi = mid;
+        }
+        if (lo < P.n_umi_table && P.umi_table_keys[lo] == r.umi_i) uid = P.n_known_umis + P.umi_table_ids[lo];
+        else atomicOr(&call->table_full, 2u);  // (not in the table: the caller's table does not cover this shard)
+      }
+    }
     const uint32_t cs = cslot[i];
     if (cs != kNoIdx) cid = pc.at(C.first[cs]) + 1u;
     unsigned long long key = kKeyEmpty;

@@ -399,32 +399,139 @@ def unit_float(count):
     return float(min(count, 1 << 24))
 
 
+def bam_split(stream):
+    """(header bytes, offsets of the alignment records as a numpy array, end of the last complete record) of an
+    inflated BAM stream"""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import abi as A
+
+    L = A.load()
+    buf = (C.c_char * len(stream)).from_buffer_copy(stream)
+    n, used = C.c_uint64(), C.c_uint64()
+    if L.fqg_bam_index_records(buf, len(stream), None, 0, C.byref(n), C.byref(used)) != 0:
+        raise ValueError("not a BAM stream")
+    offs = np.zeros(max(1, n.value), dtype=np.uint64)
+    L.fqg_bam_index_records(buf, len(stream), offs.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n), C.byref(used))
+    offs = offs[:n.value]
+    return stream[:int(offs[0]) if n.value else used.value], offs, used.value
+
+
+def umi_replayed_names(ctx, info):
+    """names of the features one of whose (cell, feature) sets the last umi_count(defer_output=True) replayed as the
+    reference's RL_Tree behaves: their trees carry state from cell to cell (src/range_list.c:187-198)"""
+    flags = ctx.umi_replayed_features(len(info["features"]))
+    return [info["features"][f - 1] for f in range(1, len(info["features"]) + 1) if flags[f]]
+
+
+def umi_records_of(ctx, stream, info, names):
+    """the alignment records of the shard just counted (umi_count(defer_output=True) on `stream`) whose feature is one of
+    `names`, in file order, as bytes: what a later shard puts in front of its own records so that the trees of these
+    features arrive in the state the serial loop would have left them in (src/bam_umi_count.c:418-441: quick_reset_db
+    keeps the tree arrays)"""
+    import numpy as np
+
+    want = {n for n in names}
+    ids = [f for f in range(1, len(info["features"]) + 1) if info["features"][f - 1] in want]
+    if not ids:
+        return b""
+    _, offs, used = bam_split(stream)
+    feat = ctx.umi_record_features(len(offs))
+    pick = np.nonzero(np.isin(feat, np.array(ids, dtype=np.uint32)))[0]
+    ends = np.append(offs[1:], np.uint64(used))
+    return b"".join(stream[int(offs[i]):int(ends[i])] for i in pick)
+
+
+def umi_global_table(umi_lists):
+    """umi_lists: per rank, in rank order, the packed UMIs its shard saw in order of first appearance (ctx.umi_umis()).
+    The reference numbers UMIs 1, 2, .. in order of first appearance in the WHOLE file (blabel2id, src/bam_umi_count.c:
+    225-260) and keeps those NUMBERS in its RL_Tree, so where the tree is not a set the result depends on them: every
+    shard must use the file's numbering.  Returns (sorted packed UMIs, their ids) for umi_count(umi_table=...)."""
+    import numpy as np
+
+    allv = np.concatenate([np.asarray(x, dtype=np.uint64) for x in umi_lists]) if umi_lists else np.zeros(0, np.uint64)
+    if allv.size == 0:
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+    keys, first = np.unique(allv, return_index=True)      # first position of every value in rank-then-local order
+    ids = np.empty(len(keys), dtype=np.uint32)
+    ids[np.argsort(first, kind="stable")] = np.arange(1, len(keys) + 1, dtype=np.uint32)
+    return np.ascontiguousarray(keys), np.ascontiguousarray(ids)
+
+
+def umi_count_behind(ctx, stream, history, **kw):
+    """Count a shard with `history` (alignment records of earlier shards, umi_records_of) in front of its own records.
+    Returns the counted info, the number of cells the history brought (they come first), and the counters of the
+    history alone (to be taken off the totals)."""
+    hdr, offs, used = bam_split(stream)
+    if not history:
+        return ctx.umi_count(stream, defer_output=True, **kw), 0, {"n_new": 0, "n_counted": 0}
+    alone = ctx.umi_count(hdr + history, defer_output=True, **kw)
+    both = ctx.umi_count(hdr + history + stream[len(hdr):used], defer_output=True, **kw)
+    return both, len(alone["cells"]) if alone["code"] == 0 else 0, alone
+
+
+def umi_finish_shard(ctx, counted, n_history_cells, history_counters, global_ids, cell_offset):
+    """output rules for a shard counted by umi_count_behind: feature ids by name from `global_ids`, the cells of the
+    history dropped, cell ids continuing at cell_offset + 1"""
+    remap = [0] + [global_ids[name] for name in counted["features"]]
+    e = ctx.umi_emit(remap, cell_offset - n_history_cells)
+    entries = [[t for t in e["entries"][w] if t[1] > cell_offset] for w in range(2)]
+    return {"entries": entries, "n_entries": [len(x) for x in entries], "total": [sum(t[2] for t in x) for x in entries],
+            "n_new": counted["n_new"] - history_counters["n_new"], "n_counted": counted["n_counted"] - history_counters["n_counted"],
+            "rl_undefined": counted.get("rl_undefined", 0) - history_counters.get("rl_undefined", 0)}
+
+
 def umi_count_sharded(ctx, stream, group=None, **kw):
     """Every rank calls this with ITS shard (an inflated BAM stream holding whole cells, in file order
-    over the ranks).  Counts locally, agrees on global feature / cell ids (one all_gather_object of the
-    name lists - kilobytes), applies the output rules with the global ids.  Returns this rank's lines
-    plus the merged header fields; concatenating the lines of the ranks in order gives the file."""
+    over the ranks).
+      round 1: every rank counts its shard; the ranks agree on the file's numbering of features, cells and UMIs (one
+               all_gather_object of the name / barcode lists: first appearance over the ranks in order);
+      round 2: every rank counts again with the file's UMI numbers (the reference's RL_Tree holds those numbers) and
+               reports the features one of whose sets is replayed as the tree behaves - a tree carries state from
+               cell to cell;
+      round 3: every rank puts the alignments of those features from all EARLIER shards (kilobytes per feature) in
+               front of its own and counts a last time: each rank then replays exactly what the serial loop replays,
+               without waiting for another rank.
+    Rounds 2 and 3 only run when some set is replayed at all.  Returns this rank's lines plus the merged header
+    fields; concatenating the lines of the ranks in order gives the file."""
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     local = ctx.umi_count(stream, defer_output=True, **kw)
     infos = [None] * world
-    dist.all_gather_object(infos, {k: local.get(k) for k in ("code", "record", "aux", "features", "cells", "n_alignments",
-                                                           "n_tags_found", "n_umis_discarded", "n_cells_discarded",
-                                                           "n_counted", "n_new", "unit_increments")}, group=group)
+    dist.all_gather_object(infos, dict({k: local.get(k) for k in ("code", "record", "aux", "features", "cells", "n_alignments",
+                                                                "n_tags_found", "n_umis_discarded", "n_cells_discarded",
+                                                                "n_counted", "n_new", "unit_increments", "rl_replayed")},
+                                       umis=ctx.umi_umis() if local["code"] == 0 else None), group=group)
     m = merge_umi_shards(infos)
     if m["finding"] is not None:
         return {"finding": m["finding"]}
     if not all(i["unit_increments"] for i in infos):
         raise NotImplementedError("fractional increments (NH > 1, several genes) add up in file order in float32: "
                                   "count such files on one GPU")
-    mine = ctx.umi_emit(m["remap"][rank], m["cell_offset"][rank])
+    global_ids = {name: k + 1 for k, name in enumerate(m["features"])}
+    counted, n_hist, hist = local, 0, {"n_new": 0, "n_counted": 0}
+    if world > 1 and not kw.get("strict_set"):
+        table = umi_global_table([i["umis"] for i in infos])
+        numbered = ctx.umi_count(stream, defer_output=True, umi_table=table, **kw)
+        replayed = [None] * world
+        dist.all_gather_object(replayed, umi_replayed_names(ctx, numbered) if numbered["code"] == 0 else [], group=group)
+        carried = sorted({n for r in replayed for n in r})
+        counted = numbered
+        if carried:
+            blobs = [None] * world
+            dist.all_gather_object(blobs, umi_records_of(ctx, stream, numbered, carried), group=group)
+            counted, n_hist, hist = umi_count_behind(ctx, stream, b"".join(blobs[:rank]), umi_table=table, **kw)
+    mine = umi_finish_shard(ctx, counted, n_hist, hist, global_ids, m["cell_offset"][rank])
     sums = [None] * world
-    dist.all_gather_object(sums, (mine["n_entries"], mine["total"]), group=group)
+    dist.all_gather_object(sums, (mine["n_entries"], mine["total"], mine["n_new"], mine["n_counted"], mine["rl_undefined"]), group=group)
     return {"finding": None, "entries": mine["entries"], "features": m["features"], "cells": m["cells"],
             "n_entries": [sum(s[0][w] for s in sums) for w in range(2)],
             "total": [sum(s[1][w] for s in sums) for w in range(2)],
-            "tot_reads": unit_float(sum(i["n_counted"] for i in infos)),
-            "tot_umi": unit_float(sum(i["n_new"] for i in infos)),
+            "tot_reads": unit_float(sum(s[3] for s in sums)),
+            "tot_umi": unit_float(sum(s[2] for s in sums)),
+            "rl_undefined": sum(s[4] for s in sums),
             "n_alignments": sum(i["n_alignments"] for i in infos),
             "n_tags_found": sum(i["n_tags_found"] for i in infos)}

@@ -383,6 +383,14 @@ typedef struct {
   int32_t strict_set;     /* 0 (default): the UMIs of a (cell, feature) are kept as the reference's RL_Tree keeps them
                              (src/range_list.c), which loses / invents members in rare arrival orders - bit-exact with
                              the reference program; 1: the set src/range_list.h:150-162 documents (an extra) */
+  /* Shards of one file (several GPUs): what the RL_Tree holds are the UMIs' IDS - dense, in order of first appearance
+   * in the WHOLE file (blabel2id, src/bam_umi_count.c:225-260) - so a shard must number its UMIs as the file does.
+   * umi_table_keys: packed UMIs (not in --known_umi), sorted ascending; umi_table_ids[i]: 1 + how many such UMIs the
+   * file saw before keys[i] first appears.  NULL: number them in order of first appearance in this call.  A UMI of
+   * the call that is missing from the table is FQG_ERR_ARG. */
+  const uint64_t *umi_table_keys;
+  const uint32_t *umi_table_ids;
+  uint64_t n_umi_table;
 } fqg_umi_params;
 
 typedef struct {
@@ -425,9 +433,19 @@ int fqg_umi_count(fqg_ctx *ctx, const void *stream, uint64_t nbytes, int mem, co
  * Fills n_entries / total of *out; the lines are read with fqg_umi_entries as usual. */
 int fqg_umi_emit(fqg_ctx *ctx, const uint32_t *feat_remap, uint64_t n_remap, uint32_t cell_offset,
                  fqg_umi_result *out);
+/* After fqg_umi_count(defer_output = 1), for a file whose cells are sharded over several GPUs: feat[i] = feature id of
+ * alignment i (0: not counted); flags[f] = 1 when a (cell, feature f) set was replayed as the reference's RL_Tree
+ * behaves (strict_set = 0) - the tree of such a feature carries state from one cell to the next
+ * (src/range_list.c:187-198, src/bam_umi_count.c:418-441), so a later shard must see that feature's earlier
+ * alignments to reproduce it (fastq_utils_amd/dist.py: umi_count_sharded).  flags needs n_features + 1 bytes. */
+int fqg_umi_record_features(fqg_ctx *ctx, uint32_t *feat, uint64_t cap);
+int fqg_umi_replayed_features(fqg_ctx *ctx, uint8_t *flags, uint64_t cap);
 /* results of the last fqg_umi_count on this context */
 int fqg_umi_features(fqg_ctx *ctx, char *names, uint64_t cap);       /* n_features x 25 bytes, NUL padded, id order */
 int fqg_umi_cells(fqg_ctx *ctx, uint64_t *packed, uint64_t cap);     /* n_cells packed barcodes, id order */
+/* the packed UMIs the call saw that are not in --known_umi, in order of first appearance; *n = how many (call with
+ * packed = NULL, cap = 0 for the count) */
+int fqg_umi_umis(fqg_ctx *ctx, uint64_t *packed, uint64_t cap, uint64_t *n);
 int fqg_umi_entries(fqg_ctx *ctx, int which, fqg_umi_entry *out, uint64_t cap); /* which: 0 UMI counts, 1 read counts */
 
 /* ---- measurement ------------------------------------------------------------------------

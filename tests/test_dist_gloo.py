@@ -137,3 +137,21 @@ def test_umi_shard_merge_gives_first_appearance_ids_over_the_ranks():
     infos[1].update(code=18, record=5, aux=30)
     assert fdist.merge_umi_shards(infos)["finding"] == (1, 18, 5, 30)
     assert fdist.unit_float(5) == 5.0 and fdist.unit_float(1 << 30) == float(1 << 24)
+
+
+def test_the_files_umi_numbers_from_the_shards_lists():
+    """umi_global_table: ids in order of first appearance over the ranks in order = over the file (blabel2id,
+    src/bam_umi_count.c:225-260); the table is sorted by packed UMI for the device's look-up"""
+    import numpy as np
+
+    from fastq_utils_amd import dist as fdist
+
+    shard0 = np.array([50, 7, 900, 3], dtype=np.uint64)        # first appearance in shard 0: ids 1..4
+    shard1 = np.array([7, 11, 50, 2], dtype=np.uint64)         # 11 -> 5, 2 -> 6 (7 and 50 are known)
+    shard2 = np.array([], dtype=np.uint64)
+    shard3 = np.array([2, 1000, 3], dtype=np.uint64)           # 1000 -> 7
+    keys, ids = fdist.umi_global_table([shard0, shard1, shard2, shard3])
+    assert list(keys) == sorted({50, 7, 900, 3, 11, 2, 1000})
+    assert dict(zip(keys.tolist(), ids.tolist())) == {50: 1, 7: 2, 900: 3, 3: 4, 11: 5, 2: 6, 1000: 7}
+    k0, i0 = fdist.umi_global_table([])
+    assert len(k0) == 0 and len(i0) == 0

@@ -274,6 +274,70 @@ def test_shards_at_cell_boundaries_give_the_file(ctx, n_shards):
     assert fdist.unit_float(sum(i["n_new"] for i in infos)) == whole["tot_umi"]
 
 
+@pytest.mark.parametrize("n_shards", [2, 3, 7])
+@pytest.mark.parametrize("seed", range(4))
+def test_shards_reproduce_the_tree_state_across_cuts(ctx, n_shards, seed):
+    """Few UMI values, many reads per (cell, gene): most sets hit the RL_Tree's overwrite and read slots that only an
+    EARLIER cell of the same gene wrote - cells that lie on another shard once the file is cut.  The sharded protocol
+    (dist.umi_count_sharded's steps, run here as virtual ranks on one GPU) must give the reference's file: every shard
+    gets the earlier alignments of the replayed features in front of its own (src/bam_umi_count.c:418-441 keeps the
+    tree arrays from cell to cell, src/range_list.c:187-198 clears only the root)."""
+    from fastq_utils_amd import dist as fdist
+
+    rng = np.random.default_rng(7000 + 10 * seed + n_shards)
+    n = int(rng.integers(4000, 40000))
+    n_cells, n_genes = int(rng.integers(2 * n_shards, 90)), int(rng.integers(1, 25))
+    cell = np.sort(rng.integers(0, n_cells, n))
+    gene = rng.zipf(1.5, n) % n_genes
+    space = int(rng.choice([300, 5000]))
+    umi = (rng.integers(0, space, n) * int(rng.choice([1, 7, 64]))) % (4 ** 10)
+    cells_code = rng.choice(np.uint64(1) << np.uint64(32), size=n_cells, replace=False).astype(np.uint64)
+    rec = bamgen.fixed_records(cells_code[cell], gene, umi.astype(np.uint64))
+    hdr = bamgen.header()
+    lu, lr, tu, tr, nc, ng, stats = bamgen.expected_matrix_reference(cell, gene, umi)
+    whole = ctx.umi_count(hdr + rec.tobytes())
+    assert whole["code"] == 0 and whole["entries"][0] == lu and whole["entries"][1] == lr and whole["rl_replayed"] >= 1
+    # cut at cell boundaries
+    starts = np.nonzero(np.diff(cell, prepend=-1))[0]
+    cuts = [int(starts[(len(starts) * k) // n_shards]) for k in range(n_shards)] + [n]
+    shards = [hdr + rec[cuts[k]:cuts[k + 1]].tobytes() for k in range(n_shards)]
+    infos, umis = [], []
+    for s_ in shards:
+        i = ctx.umi_count(s_, defer_output=True)
+        assert i["code"] == 0
+        infos.append(i)
+        umis.append(ctx.umi_umis())
+    m = fdist.merge_umi_shards(infos)
+    assert m["finding"] is None
+    table = fdist.umi_global_table(umis)          # the file's UMI numbers: the tree holds numbers, not barcodes
+    carried = set()
+    for s_ in shards:
+        i = ctx.umi_count(s_, defer_output=True, umi_table=table)
+        carried |= set(fdist.umi_replayed_names(ctx, i))
+    carried = sorted(carried)
+    assert carried
+    blobs = []
+    for s_ in shards:
+        i = ctx.umi_count(s_, defer_output=True, umi_table=table)
+        blobs.append(fdist.umi_records_of(ctx, s_, i, carried))
+    gid = {name: k + 1 for k, name in enumerate(m["features"])}
+    got_u, got_r, tot, n_new, n_counted, undefined, with_history = [], [], [0, 0], 0, 0, 0, 0
+    for k, s_ in enumerate(shards):
+        counted, n_hist, hist = fdist.umi_count_behind(ctx, s_, b"".join(blobs[:k]), umi_table=table)
+        with_history += 1 if (n_hist and counted["rl_replayed"]) else 0
+        mine = fdist.umi_finish_shard(ctx, counted, n_hist, hist, gid, m["cell_offset"][k])
+        got_u += mine["entries"][0]
+        got_r += mine["entries"][1]
+        tot = [tot[0] + mine["total"][0], tot[1] + mine["total"][1]]
+        n_new += mine["n_new"]
+        n_counted += mine["n_counted"]
+        undefined += mine["rl_undefined"]
+    assert with_history >= 1                      # the cuts do separate replayed sets from their history
+    assert got_u == lu and got_r == lr and tot == [tu, tr]
+    assert undefined == whole["rl_undefined"]     # (what the whole file reads of never-written memory, no more)
+    assert fdist.unit_float(n_counted) == whole["tot_reads"] and fdist.unit_float(n_new) == whole["tot_umi"]
+
+
 def test_sharded_protocol_through_a_one_rank_group(ctx):
     import torch
     import torch.distributed as dist
