@@ -96,7 +96,8 @@ class UmiParams(C.Structure):
                 ("known_cells", C.POINTER(C.c_uint64)), ("n_known_umis", C.c_uint64), ("n_known_cells", C.c_uint64),
                 ("defer_output", C.c_int32), ("strict_set", C.c_int32),
                 ("umi_table_keys", C.POINTER(C.c_uint64)), ("umi_table_ids", C.POINTER(C.c_uint32)),
-                ("n_umi_table", C.c_uint64)]
+                ("n_umi_table", C.c_uint64), ("db_start_reads", C.c_float), ("db_start_umi", C.c_float),
+                ("db_skip", C.c_uint64)]
 
 
 class BamTagsParams(C.Structure):
@@ -672,7 +673,7 @@ class Context:
     def umi_count(self, stream, offsets=None, sorted_by_cell=True, uniq_mapped_only=False, feat_tag=b"GX",
                   cell_tag=b"CR", umi_tag=b"RX", max_cells=None, max_features=100000, min_reads=0, min_umis=0,
                   known_umis=None, known_cells=None, nbytes=None, want_entries=True, defer_output=False,
-                  strict_set=False, umi_table=None):
+                  strict_set=False, umi_table=None, db_start=None, db_skip=0):
         """bam_umi_count's alignment loop on an inflated BAM stream: bytes (host) or an int device pointer
         (then `nbytes` and `offsets` are required).  Returns the result fields plus, when the call
         succeeded, feature names / packed cells in id order and the (row, col, value) lines."""
@@ -707,6 +708,8 @@ class Context:
                 keep.append(arr)
                 setattr(p, name, arr)
                 setattr(p, "n_" + name, len(vals))
+        if db_start is not None:  # a shard continues the file's float32 chain of totals (fractional increments)
+            p.db_start_reads, p.db_start_umi, p.db_skip = float(db_start[0]), float(db_start[1]), int(db_skip)
         if umi_table is not None:  # (sorted packed UMIs, their ids in the whole file): numpy uint64 / uint32 arrays
             tk, ti = umi_table
             keep += [tk, ti]

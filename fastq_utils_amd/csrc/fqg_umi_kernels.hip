@@ -835,12 +835,13 @@ __global__ __launch_bounds__(kBlock) void k_umi_sort_keys(uint32_t n, const uint
 }
 
 // db->tot_reads_obs / tot_umi_obs: one float32 chain over all records in order
+// (a shard of a file continues the chain of the shards before it: start values, and `skip` records in front that are not its own)
 __global__ void k_umi_db_totals(uint32_t n, uint32_t limit, const UmiRec* __restrict__ rec,
                                 const uint32_t* __restrict__ tslot, const uint8_t* __restrict__ is_new,
-                                UmiCall* __restrict__ call) {
+                                UmiCall* __restrict__ call, float start_reads, float start_umi, uint32_t skip) {
   if (blockIdx.x || threadIdx.x) return;
-  float r = 0.0f, u = 0.0f;
-  for (uint32_t i = 0; i < n && i < limit; ++i) {
+  float r = start_reads, u = start_umi;
+  for (uint32_t i = skip; i < n && i < limit; ++i) {
     if (tslot[i] == kNoIdx) continue;
     const float incr = rec[i].incr;
     if (is_new[i]) u += incr;
@@ -848,6 +849,14 @@ __global__ void k_umi_db_totals(uint32_t n, uint32_t limit, const UmiRec* __rest
   }
   call->db_reads = r;
   call->db_umi = u;
+}
+
+// features that have a replayed (cell, feature) set (hash path): pair key = cell << 32 | feature
+__global__ __launch_bounds__(kBlock) void k_umi_mark_replayed(uint32_t n_flagged, const uint32_t* __restrict__ flagged,
+                                                              const uint32_t* __restrict__ run_pslot, PairTable Pt,
+                                                              uint8_t* __restrict__ feat_flag) {
+  const uint32_t fi = blockIdx.x * kBlock + threadIdx.x;
+  if (fi < n_flagged) feat_flag[(uint32_t)Pt.t.s[run_pslot[flagged[fi]]].key] = 1;
 }
 
 // ---- output ---------------------------------------------------------------------------------------

@@ -494,8 +494,11 @@ def umi_count_sharded(ctx, stream, group=None, **kw):
       round 3: every rank puts the alignments of those features from all EARLIER shards (kilobytes per feature) in
                front of its own and counts a last time: each rank then replays exactly what the serial loop replays,
                without waiting for another rank.
-    Rounds 2 and 3 only run when some set is replayed at all.  Returns this rank's lines plus the merged header
-    fields; concatenating the lines of the ranks in order gives the file."""
+    Rounds 2 and 3 only run when there is more than one rank.  A file with fractional increments (NH > 1, several
+    genes per alignment) has one more dependence: db->tot_reads_obs / tot_umi_obs are ONE float32 chain over the file
+    (src/bam_umi_count.c:490-507), so the last count runs rank after rank, each starting from the totals of the one
+    before.  Returns this rank's lines plus the merged header fields; concatenating the lines of the ranks in order
+    gives the file."""
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -503,35 +506,57 @@ def umi_count_sharded(ctx, stream, group=None, **kw):
     infos = [None] * world
     dist.all_gather_object(infos, dict({k: local.get(k) for k in ("code", "record", "aux", "features", "cells", "n_alignments",
                                                                 "n_tags_found", "n_umis_discarded", "n_cells_discarded",
-                                                                "n_counted", "n_new", "unit_increments", "rl_replayed")},
+                                                                "n_counted", "n_new", "unit_increments", "rl_replayed",
+                                                                "tot_reads", "tot_umi")},
                                        umis=ctx.umi_umis() if local["code"] == 0 else None), group=group)
     m = merge_umi_shards(infos)
     if m["finding"] is not None:
         return {"finding": m["finding"]}
-    if not all(i["unit_increments"] for i in infos):
-        raise NotImplementedError("fractional increments (NH > 1, several genes) add up in file order in float32: "
-                                  "count such files on one GPU")
+    unit = all(i["unit_increments"] for i in infos)
     global_ids = {name: k + 1 for k, name in enumerate(m["features"])}
     counted, n_hist, hist = local, 0, {"n_new": 0, "n_counted": 0}
-    if world > 1 and not kw.get("strict_set"):
-        table = umi_global_table([i["umis"] for i in infos])
-        numbered = ctx.umi_count(stream, defer_output=True, umi_table=table, **kw)
-        replayed = [None] * world
-        dist.all_gather_object(replayed, umi_replayed_names(ctx, numbered) if numbered["code"] == 0 else [], group=group)
-        carried = sorted({n for r in replayed for n in r})
-        counted = numbered
-        if carried:
-            blobs = [None] * world
-            dist.all_gather_object(blobs, umi_records_of(ctx, stream, numbered, carried), group=group)
-            counted, n_hist, hist = umi_count_behind(ctx, stream, b"".join(blobs[:rank]), umi_table=table, **kw)
+    chain = None
+    if world > 1:
+        kw2 = dict(kw)
+        history = b""
+        if not kw.get("strict_set"):
+            kw2["umi_table"] = umi_global_table([i["umis"] for i in infos])
+            counted = ctx.umi_count(stream, defer_output=True, **kw2)
+            replayed = [None] * world
+            dist.all_gather_object(replayed, umi_replayed_names(ctx, counted) if counted["code"] == 0 else [], group=group)
+            carried = sorted({n for r in replayed for n in r})
+            if carried:
+                blobs = [None] * world
+                dist.all_gather_object(blobs, umi_records_of(ctx, stream, counted, carried), group=group)
+                history = b"".join(blobs[:rank])
+        hdr, _, used = bam_split(stream)
+        augmented = hdr + history + stream[len(hdr):used] if history else stream
+        if history:
+            hist = ctx.umi_count(hdr + history, defer_output=True, **kw2)
+            n_hist = len(hist["cells"]) if hist["code"] == 0 else 0
+        if unit:
+            if history:
+                counted = ctx.umi_count(augmented, defer_output=True, **kw2)
+        else:
+            chain = (0.0, 0.0)
+            for r in range(world):  # rank after rank: the chain of totals
+                box = [None]
+                if rank == r:
+                    counted = ctx.umi_count(augmented, defer_output=True, db_start=chain,
+                                            db_skip=hist.get("n_alignments", 0) if history else 0, **kw2)
+                    box = [(counted["tot_reads"], counted["tot_umi"])]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+                chain = box[0]
+    elif not unit:
+        chain = (local["tot_reads"], local["tot_umi"])
     mine = umi_finish_shard(ctx, counted, n_hist, hist, global_ids, m["cell_offset"][rank])
     sums = [None] * world
     dist.all_gather_object(sums, (mine["n_entries"], mine["total"], mine["n_new"], mine["n_counted"], mine["rl_undefined"]), group=group)
     return {"finding": None, "entries": mine["entries"], "features": m["features"], "cells": m["cells"],
             "n_entries": [sum(s[0][w] for s in sums) for w in range(2)],
             "total": [sum(s[1][w] for s in sums) for w in range(2)],
-            "tot_reads": unit_float(sum(s[3] for s in sums)),
-            "tot_umi": unit_float(sum(s[2] for s in sums)),
+            "tot_reads": unit_float(sum(s[3] for s in sums)) if unit else chain[0],
+            "tot_umi": unit_float(sum(s[2] for s in sums)) if unit else chain[1],
             "rl_undefined": sum(s[4] for s in sums),
             "n_alignments": sum(i["n_alignments"] for i in infos),
             "n_tags_found": sum(i["n_tags_found"] for i in infos)}

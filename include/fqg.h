@@ -391,6 +391,12 @@ typedef struct {
   const uint64_t *umi_table_keys;
   const uint32_t *umi_table_ids;
   uint64_t n_umi_table;
+  /* ... and db->tot_reads_obs / tot_umi_obs (src/bam_umi_count.c:490-507) are ONE float32 chain over the file: a shard
+   * continues it from where the shards before it ended (db_start_*), beginning at its own first alignment (db_skip
+   * alignments in front of that are history of earlier shards, see fastq_utils_amd/dist.py).  Only read when the call
+   * has fractional increments (unit increments give min(count, 2^24)). */
+  float db_start_reads, db_start_umi;
+  uint64_t db_skip;
 } fqg_umi_params;
 
 typedef struct {

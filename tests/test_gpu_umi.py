@@ -338,6 +338,56 @@ def test_shards_reproduce_the_tree_state_across_cuts(ctx, n_shards, seed):
     assert fdist.unit_float(n_counted) == whole["tot_reads"] and fdist.unit_float(n_new) == whole["tot_umi"]
 
 
+@pytest.mark.parametrize("n_shards", [2, 5])
+@pytest.mark.parametrize("seed", range(3))
+def test_shards_with_fractional_increments_continue_the_float_chain(ctx, n_shards, seed):
+    """NH > 1 and several genes per alignment: increments are fractions, and db->tot_reads_obs / tot_umi_obs are ONE
+    float32 chain over the file (src/bam_umi_count.c:490-507).  Shards count rank after rank, each starting from the
+    totals of the one before (db_start / db_skip); everything else as in the unit case."""
+    from fastq_utils_amd import dist as fdist
+
+    rng = np.random.default_rng(8100 + 10 * seed + n_shards)
+    bam, stream = bamgen.tagged_bam(rng, n_cells=30, genes=25, reads_per_cell=(20, 300), umi_len=4, nh=True, multi_gx=True)
+    want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"], {"in.bam": bam}.get)
+    assert want["exit"] == 0
+    whole = ctx.umi_count(stream)
+    assert whole["code"] == 0 and not whole["unit_increments"]
+    assert whole["entries"][0] == lines_of(want["files"]["u"]) and whole["entries"][1] == lines_of(want["files"]["r"])
+    shards = split_at_cell_boundaries(stream, n_shards)
+    infos, umis = [], []
+    for s_ in shards:
+        infos.append(ctx.umi_count(s_, defer_output=True))
+        umis.append(ctx.umi_umis())
+    m = fdist.merge_umi_shards(infos)
+    assert m["finding"] is None
+    table = fdist.umi_global_table(umis)
+    carried, numbered = set(), []
+    for s_ in shards:
+        i = ctx.umi_count(s_, defer_output=True, umi_table=table)
+        carried |= set(fdist.umi_replayed_names(ctx, i))
+    blobs = []
+    for s_ in shards:
+        i = ctx.umi_count(s_, defer_output=True, umi_table=table)
+        blobs.append(fdist.umi_records_of(ctx, s_, i, sorted(carried)) if carried else b"")
+    gid = {name: k + 1 for k, name in enumerate(m["features"])}
+    got_u, got_r, chain = [], [], (0.0, 0.0)
+    for k, s_ in enumerate(shards):
+        hdr, _, used = fdist.bam_split(s_)
+        history = b"".join(blobs[:k])
+        hist, n_hist = {"n_new": 0, "n_counted": 0}, 0
+        if history:
+            hist = ctx.umi_count(hdr + history, defer_output=True, umi_table=table)
+            n_hist = len(hist["cells"])
+        counted = ctx.umi_count(hdr + history + s_[len(hdr):used], defer_output=True, umi_table=table, db_start=chain,
+                                db_skip=hist.get("n_alignments", 0) if history else 0)
+        chain = (counted["tot_reads"], counted["tot_umi"])
+        mine = fdist.umi_finish_shard(ctx, counted, n_hist, hist, gid, m["cell_offset"][k])
+        got_u += mine["entries"][0]
+        got_r += mine["entries"][1]
+    assert got_u == whole["entries"][0] and got_r == whole["entries"][1]
+    assert chain == (whole["tot_reads"], whole["tot_umi"])
+
+
 def test_sharded_protocol_through_a_one_rank_group(ctx):
     import torch
     import torch.distributed as dist
