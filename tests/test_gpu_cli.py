@@ -166,3 +166,23 @@ def test_several_devices_many_pieces(kind):
                 rc, out, err = run_cli(["-r", "g.fastq.gz"], tmp, env)
                 want = oracle_run(["-r", "g.fastq.gz"], {"g.fastq.gz": img})
                 assert (rc, out, strip_progress(err)) == (want["exit"], want["stdout"], strip_progress(want["stderr"])), err[-500:]
+
+
+@pytest.mark.parametrize("which", ["header_1500", "header_1500_first", "read_2.6M", "hdr2_1200"])
+def test_overlong_lines_are_refused(which):
+    """The one input class where bin/fastq_info does NOT print what the reference prints: a line beyond
+    the reference's gzgets buffers (src/fastq.c:249-253) is read in pieces there, which puts every later line out of
+    step - the reference then reports whatever the shifted framing trips over (pinned, with the oracle, in
+    tests/test_oracle_vs_ref_fuzz.py::test_lines_beyond_the_gzgets_buffers).  Here the record is named and the program
+    exits with status 2."""
+    from tests.test_oracle_vs_ref_fuzz import overlong_images
+
+    img = overlong_images()[which]
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "f.fastq"), "wb") as f:
+            f.write(img)
+        for args in (["-r", "f.fastq"], ["f.fastq"]):
+            rc, out, err = run_cli(args, tmp)
+            want = oracle_run(args, {"f.fastq": img})
+            assert rc == 2 and "has a line longer than the reference's line buffers" in err, err[-300:]
+            assert want["exit"] != 0   # the reference does not accept these files either: it fails further on, out of step

@@ -82,3 +82,23 @@ def test_paired_and_interleaved_modes():
             got = orc.fastq_info(img, "i.fastq", None, "pe", orc.ARG2_PE, 0)
             assert (got["exit"], got["stdout"]) == (rc, out), (err, got["stderr"])
             assert strip_progress(got["stderr"]) == strip_progress(err)
+
+
+def overlong_images():
+    """lines beyond the reference's gzgets buffers (src/fastq.c:249-253: 1000 bytes for the header lines, 2 500 000 for
+    sequence and quality): the reference reads them in pieces, so every later `line` is out of step"""
+    rng = np.random.default_rng(4)
+    ok = fuzz.make_fastq(rng, 5, 30, 60, "casava")
+    long_hdr = b"@" + b"h" * 1500 + b" 1:N:0:A\nACGT\n+\nIIII\n"
+    n = 2_600_000
+    long_read = b"@ultra 1:N:0:A\n" + b"ACGT" * (n // 4) + b"\n+\n" + b"I" * n + b"\n"
+    return {"header_1500": ok + long_hdr + ok, "header_1500_first": long_hdr + ok, "read_2.6M": ok + long_read + ok,
+            "hdr2_1200": b"@r 1:N:0:A\nACGT\n+" + b"x" * 1200 + b"\nIIII\n" + ok}
+
+
+@pytest.mark.parametrize("which", sorted(overlong_images()))
+def test_lines_beyond_the_gzgets_buffers(which):
+    """pins what the REFERENCE does with such input (the oracle restates its gzgets calls); the GPU programs refuse it
+    with FQG_E_LINE_TOO_LONG instead - tests/test_gpu_cli.py::test_overlong_lines_are_refused, DESIGN.md 7.1"""
+    with tempfile.TemporaryDirectory() as tmp:
+        compare(tmp, overlong_images()[which])
