@@ -39,7 +39,8 @@ EXPORTS = [
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
     "fqg_umi_count", "fqg_umi_features", "fqg_umi_record_features", "fqg_umi_replayed_features", "fqg_umi_umis",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
-    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
+    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_names_fingerprints_acct", "fqg_device_alloc", "fqg_device_free",
+    "fqg_device_copy", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
     "fqg_fpset_candidates", "fqg_fpset_pair_runs", "fqg_frame_name",
 ]
 

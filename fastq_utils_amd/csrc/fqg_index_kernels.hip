@@ -773,6 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
   FpRec me[kFpPerThread];
   uint32_t owner[kFpPerThread], slot[kFpPerThread];
   bool have[kFpPerThread];
+  unsigned long long name_bytes = 0;  // PASS 0: sum of the `len` the reference accounts per name (src/fastq.c:609) -> cursor[kMaxOwners]
 #pragma unroll
   for (int j = 0; j < kFpPerThread; ++j) {
     const uint64_t r = ((uint64_t)blockIdx.x * kFpPerThread + j) * kBlock + threadIdx.x;
@@ -787,6 +788,7 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
       bool at_sign;
       (void)name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign, &h2);
       if (at_sign) {  // (a wrong header is the local pass's finding, src/fastq.c:448)
+        if (PASS == 0) name_bytes += acct;
         unsigned long long h = h64;
         if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
         me[j].fp = h;
@@ -801,7 +803,12 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
   // one reservation per owner and workgroup (many more of them on one address would cost more than the hashing)
   if (threadIdx.x < n_owners && s_cnt[threadIdx.x])
     s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-  if (PASS == 0) return;
+  if (PASS == 0) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) name_bytes += __shfl_down(name_bytes, d, 64);
+    if ((threadIdx.x & 63) == 0 && name_bytes) atomicAdd(&cursor[kMaxOwners], name_bytes);
+    return;
+  }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kFpPerThread; ++j)

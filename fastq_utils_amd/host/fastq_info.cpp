@@ -19,6 +19,7 @@
 
 #include "fq_common.h"
 #include "fq_multi.h"
+#include "fq_names_multi.h"
 
 namespace {
 
@@ -239,6 +240,281 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
     fqg_file_stats fs;
     LIB(fqg_acc_read(S.acc1, &fs));
     S.num_reads1 = fs.num_rds;
+  }
+}
+
+// ---- default and paired modes over several GPUs (FQGPU_DEVICES=0,1,..) --------------------------------------------
+// The index modes with the records of a file spread over several contexts: every piece is validated (and its frame
+// kept) by whichever context is free, and the names are tested ACROSS the contexts by the fingerprint exchange of
+// fq_names_multi.h instead of one device's index.  Findings are ordered as the serial loops order them: per record
+// read (truncation), name (wrong header), duplicate / unpaired, validation.
+struct MultiDev {
+  fqg_ctx* ctx = nullptr;
+  fqg_acc* acc = nullptr;
+};
+struct MultiPass {
+  bool stopped = false;       // a NUL at a record start ends the file there: the caller runs the one-device loop instead
+  uint64_t n_records = 0;     // records of the pieces looked at
+  bool have = false;          // a finding of the validation side (stages 0, 1, 3) - the first in file order
+  uint64_t rec = 0;
+  int stage = 0;
+  fqg_validate_result r{};
+  RecordText text;
+  Probe pr;
+  std::vector<fqhost::NameShard> shards;  // per device: the frames it kept
+};
+
+// one pass of all devices over a file.  validate_as: the state the records are validated under (null: the file's
+// own, decided from its first record); acc_of_first: the accumulator device 0 adds to
+MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint32_t flags, const fqg_file_state* validate_as) {
+  MultiPass out;
+  out.shards.resize(D.size());
+  for (size_t i = 0; i < D.size(); ++i) out.shards[i].ctx = D[i].ctx;
+  const size_t piece = getenv("FQGPU_CHUNK_MB") ? piece_bytes() : (size_t)128 << 20;
+  struct Done {
+    Piece p;
+    fqg_validate_result r{};
+    int rc = 0;
+    std::string err;
+  };
+  std::map<uint64_t, Done> done;
+  std::mutex mu, fetch_mu, shard_mu;
+  std::condition_variable cv;
+  std::atomic<bool> stop{false};
+  bool exhausted = false;        // (under fetch_mu)
+  uint64_t n_pieces = ~0ull;     // known once the final piece was handed out (under mu)
+  AlignedPieces src(g_ctx, path, piece, (int)(2 * D.size() + 2));
+  auto work = [&](size_t di) {
+    for (;;) {
+      Done d;
+      fqg_file_state st;
+      {
+        std::lock_guard<std::mutex> lk(fetch_mu);
+        if (exhausted || stop || !src.next(&d.p)) {
+          exhausted = true;
+          return;
+        }
+        if (d.p.final) exhausted = true;
+        probe_piece(out.pr, d.p.data, d.p.size, is_pe);  // piece 0 is handed out first: the state is the first record's
+        st = validate_as ? *validate_as : out.pr.st;
+      }
+      d.rc = fqg_validate(D[di].ctx, D[di].acc, d.p.data, d.p.size, FQG_MEM_HOST, d.p.final ? 1 : 0, &st, flags, &d.r);
+      if (d.rc) d.err = fqg_last_error(D[di].ctx);
+      else if (!d.p.final && d.r.code == FQG_OK && !d.r.stopped && d.r.consumed != d.p.size) {
+        d.rc = FQG_ERR_ARG;
+        d.err = "a piece cut at a record boundary was not consumed whole";
+      } else if (d.r.n_records) {
+        fqg_frame* fr = nullptr;
+        d.rc = fqg_frame_retain(D[di].ctx, &fr);
+        if (d.rc) d.err = fqg_last_error(D[di].ctx);
+        else {
+          std::lock_guard<std::mutex> lk(shard_mu);
+          out.shards[di].pieces.push_back(fqhost::NameShard::Piece{fr, d.p.first_record, d.r.n_records});
+        }
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (d.p.final) n_pieces = d.p.seq + 1;
+      done.emplace(d.p.seq, std::move(d));
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < D.size(); ++i) th.emplace_back(work, i);
+  auto join_all = [&] {
+    stop = true;
+    src.abort();
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+  };
+  bool info_pending = true;
+  for (uint64_t k = 0;; ++k) {
+    Done d;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return done.count(k) || k >= n_pieces; });
+      if (!done.count(k)) break;
+      d = std::move(done[k]);
+      done.erase(k);
+    }
+    const uint64_t base = d.p.first_record;
+    const fqg_validate_result& r = d.r;
+    if (d.rc) {
+      join_all();
+      FQ_PRINT_ERROR("GPU library failure in fqg_validate (%d): %s", d.rc, d.err.c_str());
+      exit(kExitSys);
+    }
+    int stage = -1;
+    if (r.code == FQG_E_TRUNCATED || r.code == FQG_E_LINE_TOO_LONG) stage = 0;
+    else if (r.code == FQG_E_HDR1_AT) stage = 1;
+    else if (r.code) stage = 3;
+    if (info_pending && base == 0 && r.n_records > 0) {
+      if (!(stage >= 0 && stage <= 1 && r.record == 0)) print_probe(out.pr);
+      info_pending = false;
+    }
+    if (r.stopped) {
+      join_all();
+      out.stopped = true;
+      return out;
+    }
+    if (stage >= 0) {
+      join_all();
+      out.have = true;
+      out.rec = base + r.record;
+      out.stage = stage;
+      out.r = r;
+      out.text = locate_record(d.p.data, d.p.size, r.record);
+      out.n_records = base + r.n_records;
+      return out;
+    }
+    out.n_records = base + r.n_records;
+    src.release(d.p);
+    if (d.p.final) break;
+  }
+  join_all();
+  return out;
+}
+
+void merge_device_stats(std::vector<MultiDev>& D, Stats& S) {
+  std::vector<char> buf;
+  for (size_t i = 1; i < D.size(); ++i) {
+    size_t used = 0;
+    if (fqg_acc_export(D[i].acc, nullptr, 0, &used) != 0) die_lib("fqg_acc_export", -1);
+    buf.resize(used);
+    if (fqg_acc_export(D[i].acc, buf.data(), buf.size(), &used) != 0) die_lib("fqg_acc_export", -1);
+    LIB(fqg_acc_merge(S.acc1, buf.data(), used));
+    if (fqg_acc_reset(D[i].acc) != 0) die_lib("fqg_acc_reset", -1);
+  }
+}
+
+void release_shards(std::vector<fqhost::NameShard>& sh) {
+  for (auto& s : sh)
+    for (auto& p : s.pieces) fqg_frame_release(const_cast<fqg_frame*>(p.frame));
+  sh.clear();
+}
+
+struct MultiIndexed {
+  std::vector<MultiDev> D;
+  fqhost::NamesOfFile f1;
+};
+
+// file 1 of the default / paired mode.  false: the file holds a NUL at a record start - run the one-device loop.
+bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, MultiIndexed& M, const std::vector<int>& devs) {
+  M.D.resize(devs.size());
+  M.D[0].ctx = g_ctx;
+  M.D[0].acc = S.acc1;
+  for (size_t i = 1; i < devs.size(); ++i) {
+    const int rc = fqg_open(devs[i], &M.D[i].ctx);
+    if (rc != 0) {
+      FQ_PRINT_ERROR("FQGPU_DEVICES: device %d is not a usable MI355X GPU (fqg_open: %d)", devs[i], rc);
+      exit(kExitSys);
+    }
+    if (fqg_acc_create(M.D[i].ctx, &M.D[i].acc) != 0) die_lib("fqg_acc_create", -1);
+  }
+  MultiPass pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE, nullptr);
+  if (pass.stopped) {
+    release_shards(pass.shards);
+    for (size_t i = 1; i < M.D.size(); ++i) {
+      fqg_acc_destroy(M.D[i].acc);
+      fqg_close(M.D[i].ctx);
+    }
+    M.D.clear();
+    LIB(fqg_acc_reset(S.acc1));
+    return false;
+  }
+  M.f1.shards = std::move(pass.shards);
+  M.f1.st = pass.pr.st;
+  M.f1.flag = 0;
+  fqhost::NamesExchange ex;
+  bool dup = false;
+  uint64_t dup_rec = 0, name_bytes = 0;
+  std::string dup_name;
+  if (!ex.first_duplicate(M.f1, &dup, &dup_rec, &dup_name, &name_bytes)) {
+    FQ_PRINT_ERROR("GPU library failure in the read-name exchange: %s", ex.error.c_str());
+    exit(kExitSys);
+  }
+  // which finding does the serial loop hit first?  per record: read (0), name (1), duplicate (2), validation (3)
+  uint64_t best = ~0ull;
+  int stage = 9;
+  if (pass.have) {
+    best = pass.rec;
+    stage = pass.stage;
+  }
+  if (dup && (dup_rec < best || (dup_rec == best && 2 < stage))) {
+    best = dup_rec;
+    stage = 2;
+  }
+  if (best != ~0ull) {
+    ticker(1, best, 100000);
+    if (stage == 0) {
+      if (pass.r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, best);
+      fail_truncated(path, 4 * best);
+    }
+    if (stage == 1) fail_wrong_header(path, 4 * (best + 1), pass.text.l[0]);
+    if (stage == 2) {
+      FQ_PRINT_ERROR("Error in file %s: line %lu: duplicated sequence %s", path, (unsigned long)(4 * (best + 1)), dup_name.c_str());
+      exit(kExitFormat);
+    }
+    print_validation_error(path, 4 * (best + 1), pass.r, pass.text);
+    exit(kExitFormat);
+  }
+  ticker(1, pass.n_records, 100000);
+  merge_device_stats(M.D, S);
+  F.st = pass.pr.st;
+  F.n_records = pass.n_records;
+  F.entries = pass.n_records;
+  F.index_mem = 8 + pass.n_records * (16 + 1 + 24) + name_bytes;  // what the reference adds up (src/fastq.c:609, src/fastq_info.c:293)
+  return true;
+}
+
+// the second file of a pair over the same devices (src/fastq_info.c:322-362)
+void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, IndexedFile& F, MultiIndexed& M) {
+  const unsigned long cline1 = 4 * F.n_records;  // fd1->cline stays where indexing left it
+  // file-2 records are validated against file 1's state and counters (src/fastq_info.c:345); names under file 2's own
+  MultiPass pass = multi_pass(path2, M.D, 1, 0, &F.st);
+  if (pass.stopped) {
+    FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES: use one device", path2);
+    exit(kExitSys);
+  }
+  fqhost::NamesOfFile f2;
+  f2.shards = std::move(pass.shards);
+  f2.st = pass.pr.st;
+  f2.flag = FQG_FP_FILE2;
+  fqhost::NamesExchange ex;
+  fqhost::PairingOutcome po;
+  if (!ex.pairing(M.f1, f2, &po)) {
+    FQ_PRINT_ERROR("GPU library failure in the read-name exchange: %s", ex.error.c_str());
+    exit(kExitSys);
+  }
+  uint64_t best = ~0ull;
+  int stage = 9;
+  if (pass.have) {
+    best = pass.rec;
+    stage = pass.stage;
+  }
+  if (po.has_first && (po.first_unpaired < best || (po.first_unpaired == best && 2 < stage))) {
+    best = po.first_unpaired;
+    stage = 2;
+  }
+  if (best != ~0ull) {
+    ticker(1, best, 100000);
+    if (stage == 0) {
+      if (pass.r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path2, best);
+      fail_truncated(path2, 4 * best);
+    }
+    if (stage == 1) fail_wrong_header(path2, 4 * (best + 1), pass.text.l[0]);
+    if (stage == 2) {
+      FQ_PRINT_ERROR("Error in file %s: line %lu: unpaired read - %s", path2, (unsigned long)(4 * (best + 1)), po.first_name.c_str());
+      exit(kExitFormat);
+    }
+    print_validation_error(path1, cline1, pass.r, pass.text);  // named after file 1, like the reference
+    exit(kExitFormat);
+  }
+  ticker(1, pass.n_records, 100000);
+  merge_device_stats(M.D, S);
+  printf("\n");
+  if (po.leftover > 0) {
+    FQ_PRINT_ERROR("Error in file %s: found %llu unpaired reads", path1, (unsigned long long)po.leftover);
+    exit(kExitFormat);
   }
 }
 
@@ -520,6 +796,7 @@ int main(int argc, char** argv) {
   Stats S;
   LIB(fqg_acc_create(g_ctx, &S.acc1));
   IndexedFile F;
+  MultiIndexed multi;
   bool merged_second_file = false;
 
   if (is_interleaved) {
@@ -538,7 +815,10 @@ int main(int argc, char** argv) {
     fprintf(stderr, "DEFAULT_HASHSIZE=%lu\n", 39000001ul);
     fprintf(stderr, "Scanning and indexing all reads from %s\n", file1);
     F.lookups = is_paired_data && file2 != nullptr;  // (one file, or "pe": the index is only the uniqueness test)
-    run_index_file(file1, is_paired_data, S, F);
+    if (!(devices.size() > 1 && run_index_multi(file1, is_paired_data, S, F, multi, devices))) {
+      multi.D.clear();
+      run_index_file(file1, is_paired_data, S, F);
+    }
     fprintf(stderr, "Scanning complete.\n");
     S.num_reads1 = F.entries;
     fprintf(stderr, "\n");
@@ -563,7 +843,8 @@ int main(int argc, char** argv) {
   if (is_paired_data && !is_interleaved && !is_sorted) {
     fprintf(stderr, "File %s processed\n", file1);
     fprintf(stderr, "Next file %s\n", file2);
-    run_pair_second_file(file1, file2, S, F);
+    if (!multi.D.empty()) run_pair_second_file_multi(file1, file2, S, F, multi);
+    else run_pair_second_file(file1, file2, S, F);
     // fd2's own counters are never touched (file-2 records went through fd1): an untouched
     // accumulator stands in for it in min/max and in median_rl()
     LIB(fqg_acc_create(g_ctx, &S.acc2));

@@ -1,0 +1,346 @@
+// fq_names_multi.h - read names across the GPUs of ONE process (the drop-in programs with FQGPU_DEVICES=0,1,..):
+// the unique-name test of fastq_index_readnames (reference src/fastq.c:396-439) and the file-2 loop of fastq_info
+// (src/fastq_info.c:333-362) when the records of a file are spread over several contexts.  The protocol is
+// SURVEY 8e's, the same that fastq_utils_amd/dist.py runs between processes over RCCL - here the "all-to-all" is a
+// set of peer copies (fqg_device_copy: xGMI between two GPUs), since all contexts live in this process:
+//   1. every context turns the canonical names of its frames into 16-byte (fingerprint, global record index) pairs,
+//      bucketed by owner (fqg_names_fingerprints_acct; owner = high bits of the fingerprint);
+//   2. bucket (d -> o) is copied into owner o's receive buffer;
+//   3. every owner sorts what it received and classifies runs of equal fingerprints on its device
+//      (fqg_fpset_candidates / fqg_fpset_pair_runs);
+//   4. what a fingerprint cannot decide is decided on the name BYTES, fetched from the context that holds the record
+//      (fqg_frame_name) - a hash collision can neither fake nor hide a finding.
+// One thread per context for steps 1 and 3 (a context is not thread-safe, different contexts are independent).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fqg.h"
+
+namespace fqhost {
+
+struct NameShard {  // what one context holds of one file
+  fqg_ctx* ctx = nullptr;
+  struct Piece {
+    const fqg_frame* frame;
+    uint64_t first_record, n_records;  // global index of the frame's first record, records in it
+  };
+  std::vector<Piece> pieces;
+};
+
+struct NamesOfFile {
+  std::vector<NameShard> shards;  // one per context, in any order
+  fqg_file_state st{};
+  uint64_t flag = 0;  // FQG_FP_FILE2 for the asking file of a pairing
+};
+
+struct PairingOutcome {
+  uint64_t matched = 0, leftover = 0, unpaired = 0;
+  bool has_first = false;
+  uint64_t first_unpaired = 0;  // record index in file 2
+  std::string first_name;
+};
+
+class NamesExchange {
+ public:
+  // error text of the last failure ("" when none); every call returns false on failure
+  std::string error;
+
+  // smallest global record index whose name already occurred at a smaller index, if any; name_bytes = the sum the
+  // reference accounts for the names (src/fastq.c:609)
+  bool first_duplicate(const NamesOfFile& f, bool* found, uint64_t* record, std::string* name, uint64_t* name_bytes) {
+    *found = false;
+    *name_bytes = 0;
+    std::vector<const NamesOfFile*> files{&f};
+    Exchanged x;
+    if (!exchange(files, x)) return false;
+    *name_bytes = x.name_bytes;
+    // candidates of every owner
+    std::vector<std::pair<uint64_t, uint64_t>> cand;
+    std::vector<std::string> errs(x.owners.size());
+    std::vector<std::vector<uint64_t>> per(x.owners.size());
+    run_per_owner(x, [&](size_t o) {
+      Owner& ow = x.owners[o];
+      if (!ow.n) return;
+      fqg_fpset* set = nullptr;
+      if (fqg_fpset_create(ow.ctx, ow.n, &set) != 0 || fqg_fpset_insert(ow.ctx, set, ow.recv, ow.n) != 0) {
+        errs[o] = fqg_last_error(ow.ctx);
+        if (set) fqg_fpset_destroy(set);
+        return;
+      }
+      uint64_t cap = 1 << 16, n_found = 0;
+      std::vector<uint64_t> pairs(2 * cap);
+      int rc = fqg_fpset_candidates(ow.ctx, set, pairs.data(), cap, &n_found);
+      if (rc == 0 && n_found > cap) {
+        cap = n_found;
+        pairs.resize(2 * cap);
+        rc = fqg_fpset_candidates(ow.ctx, set, pairs.data(), cap, &n_found);
+      }
+      if (rc != 0) errs[o] = fqg_last_error(ow.ctx);
+      else per[o].assign(pairs.begin(), pairs.begin() + 2 * n_found);
+      fqg_fpset_destroy(set);
+    });
+    release(x);
+    for (auto& e : errs)
+      if (!e.empty()) return fail(e);
+    for (auto& p : per)
+      for (size_t k = 0; k + 1 < p.size(); k += 2) cand.emplace_back(p[k], p[k + 1]);
+    if (cand.empty()) return true;
+    // all holders of one fingerprint are compared with each other: the smallest index whose name equals the name
+    // of an earlier holder is the record the serial loop stops at
+    std::map<uint64_t, std::set<uint64_t>> groups;
+    for (auto& c : cand) groups[c.first].insert(c.second);
+    bool have = false;
+    uint64_t best = 0;
+    std::string best_name;
+    for (auto& g : groups) {
+      std::string nm;
+      if (!name_of(f, g.first, &nm)) return false;
+      std::set<std::string> seen{nm};
+      for (uint64_t later : g.second) {
+        if (have && later >= best) break;
+        if (!name_of(f, later, &nm)) return false;
+        if (seen.count(nm)) {
+          have = true;
+          best = later;
+          best_name = nm;
+          break;
+        }
+        seen.insert(nm);
+      }
+    }
+    *found = have;
+    *record = best;
+    *name = best_name;
+    return true;
+  }
+
+  // the file-2 loop: every name of f2 (flag FQG_FP_FILE2) looks for its holder in f1
+  bool pairing(const NamesOfFile& f1, const NamesOfFile& f2, PairingOutcome* out) {
+    *out = PairingOutcome();
+    std::vector<const NamesOfFile*> files{&f1, &f2};
+    Exchanged x;
+    if (!exchange(files, x)) return false;
+    struct Part {
+      fqg_pair_summary s{};
+      std::vector<uint64_t> entries;  // (run, index) pairs
+      std::string err;
+    };
+    std::vector<Part> parts(x.owners.size());
+    run_per_owner(x, [&](size_t o) {
+      Owner& ow = x.owners[o];
+      parts[o].s.first_unpaired = ~0ull;
+      if (!ow.n) return;
+      fqg_fpset* set = nullptr;
+      if (fqg_fpset_create(ow.ctx, ow.n, &set) != 0 || fqg_fpset_insert(ow.ctx, set, ow.recv, ow.n) != 0) {
+        parts[o].err = fqg_last_error(ow.ctx);
+        if (set) fqg_fpset_destroy(set);
+        return;
+      }
+      uint64_t cap = 1 << 16;
+      parts[o].entries.resize(2 * cap);
+      int rc = fqg_fpset_pair_runs(ow.ctx, set, &parts[o].s, parts[o].entries.data(), cap);
+      if (rc == 0 && parts[o].s.n_complex > cap) {
+        cap = parts[o].s.n_complex;
+        parts[o].entries.resize(2 * cap);
+        rc = fqg_fpset_pair_runs(ow.ctx, set, &parts[o].s, parts[o].entries.data(), cap);
+      }
+      if (rc != 0) parts[o].err = fqg_last_error(ow.ctx);
+      else parts[o].entries.resize(2 * parts[o].s.n_complex);
+      fqg_fpset_destroy(set);
+    });
+    release(x);
+    bool have = false;
+    uint64_t first = 0;
+    auto offer_first = [&](uint64_t idx) {
+      if (!have || idx < first) {
+        have = true;
+        first = idx;
+      }
+    };
+    for (auto& p : parts) {
+      if (!p.err.empty()) return fail(p.err);
+      out->matched += p.s.matched;
+      out->leftover += p.s.leftover;
+      out->unpaired += p.s.unpaired;
+      if (p.s.first_unpaired != ~0ull) offer_first(p.s.first_unpaired);
+      // runs the device could not classify (a name asked for twice, a collision): per NAME the holder pairs with the
+      // smallest asker; later askers, and askers of a name without holder, are unpaired; holders nobody asked for
+      // are left over.  Run ids are owner-local.
+      std::map<uint64_t, std::vector<uint64_t>> runs;
+      for (size_t k = 0; k + 1 < p.entries.size(); k += 2) runs[p.entries[k]].push_back(p.entries[k + 1]);
+      for (auto& r : runs) {
+        std::map<std::string, std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> by_name;
+        for (uint64_t g : r.second) {
+          std::string nm;
+          const bool asker = (g & FQG_FP_FILE2) != 0;
+          if (!name_of(asker ? f2 : f1, g & ~FQG_FP_FILE2, &nm)) return false;
+          auto& e = by_name[nm];
+          (asker ? e.second : e.first).push_back(g & ~FQG_FP_FILE2);
+        }
+        for (auto& e : by_name) {
+          auto& holders = e.second.first;
+          auto& askers = e.second.second;
+          std::sort(askers.begin(), askers.end());
+          size_t bad_from = 0;
+          if (!holders.empty()) {
+            if (!askers.empty()) {
+              out->matched += 1;
+              out->leftover += holders.size() - 1;
+              bad_from = 1;
+            } else {
+              out->leftover += holders.size();
+              bad_from = askers.size();
+            }
+          }
+          out->unpaired += askers.size() - bad_from;
+          if (bad_from < askers.size()) offer_first(askers[bad_from]);
+        }
+      }
+    }
+    if (have) {
+      out->has_first = true;
+      out->first_unpaired = first;
+      if (!name_of(f2, first, &out->first_name)) return false;
+    }
+    return true;
+  }
+
+ private:
+  struct Owner {
+    fqg_ctx* ctx = nullptr;
+    void* recv = nullptr;
+    uint64_t n = 0;
+  };
+  struct Exchanged {
+    std::vector<Owner> owners;
+    uint64_t name_bytes = 0;
+  };
+  bool fail(const std::string& e) {
+    error = e;
+    return false;
+  }
+  template <class F>
+  static void run_per_owner(Exchanged& x, F fn) {
+    std::vector<std::thread> th;
+    for (size_t o = 1; o < x.owners.size(); ++o) th.emplace_back(fn, o);
+    if (!x.owners.empty()) fn(0);
+    for (auto& t : th) t.join();
+  }
+  static void release(Exchanged& x) {
+    for (auto& o : x.owners)
+      if (o.recv) fqg_device_free(o.ctx, o.recv);
+    x.owners.clear();
+  }
+
+  // canonical name of global record `idx` of file f, from the context that holds it
+  bool name_of(const NamesOfFile& f, uint64_t idx, std::string* out) {
+    for (auto& sh : f.shards)
+      for (auto& p : sh.pieces)
+        if (idx >= p.first_record && idx < p.first_record + p.n_records) {
+          char buf[FQG_MAX_LABEL_LENGTH + 8];
+          const int64_t n = fqg_frame_name(sh.ctx, p.frame, &f.st, idx - p.first_record, buf, sizeof buf);
+          if (n < 0) return fail(fqg_last_error(sh.ctx));
+          out->assign(buf, (size_t)n);
+          return true;
+        }
+    return fail("a record index that no context holds");
+  }
+
+  // steps 1 and 2: fingerprints of all files on all contexts, every bucket copied to its owner.  The owners are the
+  // contexts of files[0] (every file has a shard on every context, possibly without pieces).
+  bool exchange(const std::vector<const NamesOfFile*>& files, Exchanged& x) {
+    const size_t D = files[0]->shards.size();
+    if (D == 0 || D > FQG_MAX_OWNERS) return fail("between 1 and 64 contexts");
+    for (auto* f : files)
+      if (f->shards.size() != D) return fail("every file needs a shard per context");
+    struct Bucket {
+      const void* src;
+      uint64_t n;
+    };
+    struct Local {
+      void* buf = nullptr;
+      std::vector<std::vector<Bucket>> to;  // per owner
+      uint64_t name_bytes = 0;
+      std::string err;
+    };
+    std::vector<Local> loc(D);
+    auto produce = [&](size_t d) {
+      Local& L = loc[d];
+      L.to.resize(D);
+      fqg_ctx* ctx = files[0]->shards[d].ctx;
+      uint64_t total = 0;
+      for (auto* f : files)
+        for (auto& p : f->shards[d].pieces) total += p.n_records;
+      if (!total) return;
+      L.buf = fqg_device_alloc(ctx, total * sizeof(fqg_fp));
+      if (!L.buf) {
+        L.err = "device allocation failed";
+        return;
+      }
+      uint64_t off = 0;
+      for (auto* f : files)
+        for (auto& p : f->shards[d].pieces) {
+          if (f->shards[d].ctx != ctx) {
+            L.err = "the shards of a context must belong to it";
+            return;
+          }
+          uint64_t counts[FQG_MAX_OWNERS], nb = 0;
+          if (fqg_names_fingerprints_acct(ctx, p.frame, &f->st, p.first_record | f->flag, (uint32_t)D,
+                                          (char*)L.buf + off * sizeof(fqg_fp), counts, &nb) != 0) {
+            L.err = fqg_last_error(ctx);
+            return;
+          }
+          if (!f->flag) L.name_bytes += nb;
+          for (size_t o = 0; o < D; ++o) {
+            if (counts[o]) L.to[o].push_back(Bucket{(char*)L.buf + off * sizeof(fqg_fp), counts[o]});
+            off += counts[o];
+          }
+        }
+    };
+    {
+      std::vector<std::thread> th;
+      for (size_t d = 1; d < D; ++d) th.emplace_back(produce, d);
+      produce(0);
+      for (auto& t : th) t.join();
+    }
+    bool ok = true;
+    for (auto& L : loc)
+      if (!L.err.empty()) ok = fail(L.err);
+    x.owners.assign(D, Owner());
+    for (size_t o = 0; o < D && ok; ++o) {
+      Owner& ow = x.owners[o];
+      ow.ctx = files[0]->shards[o].ctx;
+      for (size_t d = 0; d < D; ++d)
+        for (auto& b : loc[d].to[o]) ow.n += b.n;
+      if (!ow.n) continue;
+      ow.recv = fqg_device_alloc(ow.ctx, ow.n * sizeof(fqg_fp));
+      if (!ow.recv) {
+        ok = fail("device allocation failed");
+        break;
+      }
+      uint64_t at = 0;
+      for (size_t d = 0; d < D && ok; ++d)
+        for (auto& b : loc[d].to[o]) {
+          if (fqg_device_copy(ow.ctx, (char*)ow.recv + at * sizeof(fqg_fp), files[0]->shards[d].ctx, b.src, b.n * sizeof(fqg_fp)) != 0) {
+            ok = fail(fqg_last_error(ow.ctx));
+            break;
+          }
+          at += b.n;
+        }
+    }
+    for (size_t d = 0; d < D; ++d) {
+      x.name_bytes += loc[d].name_bytes;
+      if (loc[d].buf) fqg_device_free(files[0]->shards[d].ctx, loc[d].buf);
+    }
+    if (!ok) release(x);
+    return ok;
+  }
+};
+
+}  // namespace fqhost

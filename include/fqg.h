@@ -256,6 +256,17 @@ uint32_t fqg_fp_owner(uint64_t fp, uint32_t n_owners);
  * header does not start with '@' are left out. */
 int fqg_names_fingerprints(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t record_base,
                            uint32_t n_owners, void *out_device, uint64_t *counts);
+/* the same, and *name_bytes = sum over the frame's records of the `len` the reference accounts per indexed name
+ * (src/fastq.c:609: what "Memory used in indexing" is made of) */
+int fqg_names_fingerprints_acct(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t record_base,
+                                uint32_t n_owners, void *out_device, uint64_t *counts, uint64_t *name_bytes);
+/* Device buffers for the exchange, and the exchange itself when the owners are contexts of ONE process (the drop-in
+ * programs with FQGPU_DEVICES=0,1,..: fastq_utils_amd/host/fq_names_multi.h): a copy from a buffer of one context
+ * into a buffer of another - over xGMI between two GPUs - that has arrived when the call returns.  Ranks in
+ * different processes use RCCL instead (fastq_utils_amd/dist.py). */
+void *fqg_device_alloc(fqg_ctx *ctx, uint64_t bytes);
+void fqg_device_free(fqg_ctx *ctx, void *p);
+int fqg_device_copy(fqg_ctx *dst_ctx, void *dst, fqg_ctx *src_ctx, const void *src, uint64_t bytes);
 int fqg_fpset_create(fqg_ctx *ctx, uint64_t expected, fqg_fpset **out);
 void fqg_fpset_destroy(fqg_fpset *set);
 /* fps: DEVICE memory, n fqg_fp */

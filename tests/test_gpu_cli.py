@@ -186,3 +186,64 @@ def test_overlong_lines_are_refused(which):
             want = oracle_run(args, {"f.fastq": img})
             assert rc == 2 and "has a line longer than the reference's line buffers" in err, err[-300:]
             assert want["exit"] != 0   # the reference does not accept these files either: it fails further on, out of step
+
+
+# ---- FQGPU_DEVICES in the index modes: names across contexts (host/fq_names_multi.h) ----------------------------------
+def test_several_devices_golden_index_and_pairing_invocations():
+    """every golden invocation that tests names (no -r, not interleaved "pe"): records spread over three contexts, names
+    tested across them by the fingerprint exchange - same exit status, stdout and stderr as the reference binary"""
+    cases = [c for c in GOLDEN if "-r" not in c["args"] and "pe" not in c["args"]]
+    assert len(cases) > 150
+
+    def one(case):
+        rc, out, err = run_cli(case["args"], GOLD, MULTI)
+        ok = (rc == case["exit"] and out == case["stdout"]
+              and strip_progress(err) == strip_progress(case["stderr"]))
+        return None if ok else (case["args"], rc, case["exit"], err[-400:], case["stderr"][-400:])
+
+    with ThreadPoolExecutor(4) as ex:
+        bad = [b for b in ex.map(one, cases) if b]
+    assert not bad, f"{len(bad)} of {len(cases)} differ; first: {bad[:3]}"
+
+
+def test_several_devices_duplicates_and_pairs_in_many_pieces():
+    """1 MiB pieces over three contexts: a name repeated pieces apart, a missing mate, mates in another order, a name asked
+    for twice - what the serial loops print"""
+    rng = np.random.default_rng(23)
+    env = dict(MULTI, FQGPU_CHUNK_MB="1")
+    with tempfile.TemporaryDirectory() as tmp:
+        n = 30000
+        a = fuzz.make_fastq(np.random.default_rng(3), n, 50, 150, "casava", mate=1)
+        b = fuzz.make_fastq(np.random.default_rng(3), n, 50, 150, "casava", mate=2)
+        la, lb = a.split(b"\n"), b.split(b"\n")
+        recs_b = [lb[4 * i:4 * i + 4] for i in range(n)]
+        dup = b"\n".join(la[:4 * 20000] + la[4 * 77:4 * 78] + la[4 * 20000:])              # record 77 again as record 20000
+        missing = b"\n".join(lb[:4 * 12345] + lb[4 * 12346:])                               # a mate less in file 2
+        shuffled = b"\n".join([x for i in rng.permutation(n) for x in recs_b[i]] + [b""])   # still paired
+        twice = b"\n".join(lb[:4 * 25000] + lb[4 * 100:4 * 101] + lb[4 * 25000:])           # a name asked for twice
+        bad_base = bytearray(a)
+        bad_base[len(a) // 2 + a[len(a) // 2:].index(b"\n+\n") - 3] = ord("X")              # a validation finding mid-file
+        files = {"a.fastq": a, "b.fastq": b, "d.fastq": dup, "m.fastq": missing, "s.fastq": shuffled, "t.fastq": twice,
+                 "x.fastq": bytes(bad_base)}
+        for name, img in files.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(img)
+        for args in (["a.fastq"], ["d.fastq"], ["x.fastq"], ["a.fastq", "b.fastq"], ["a.fastq", "m.fastq"], ["m.fastq", "a.fastq"],
+                     ["a.fastq", "s.fastq"], ["a.fastq", "t.fastq"], ["x.fastq", "b.fastq"], ["a.fastq", "x.fastq"], ["d.fastq", "b.fastq"]):
+            compare_with_oracle(tmp, args, files, env)
+
+
+@pytest.mark.parametrize("kind", fuzz.MUTATIONS)
+def test_several_devices_mutated_files_in_index_mode(kind):
+    rng = np.random.default_rng(abs(hash("multi-index" + kind)) % 100000)
+    env = dict(MULTI, FQGPU_CHUNK_MB="1")
+    with tempfile.TemporaryDirectory() as tmp:
+        img = fuzz.make_fastq(rng, 30000, 20, 120, "casava")
+        img = fuzz.mutate(rng, img, kind)
+        mate = fuzz.make_fastq(np.random.default_rng(5), 2000, 20, 120, "casava", mate=2)
+        files = {"f.fastq": img, "g.fastq": mate}
+        for name, data in files.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(data)
+        compare_with_oracle(tmp, ["f.fastq"], files, env)
+        compare_with_oracle(tmp, ["g.fastq", "f.fastq"], files, env)
