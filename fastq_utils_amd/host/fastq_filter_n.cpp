@@ -22,11 +22,11 @@ int main(int argc, char** argv) {
       default:
         ++nopt;
         FQ_PRINT_ERROR("Option -%c invalid", optopt);
-        exit(kExitParams);
+        fqhost::leave(kExitParams);
     }
   if (argc - nopt < 2 || argc - nopt > 3) {
     FQ_PRINT_ERROR("Usage: fastq_filter_n [ -n 0 ] fastq1");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   if (max_n > 0) fprintf(stderr, "Discard reads with more than %d%% of Ns\n", max_n);
   else fprintf(stderr, "Discard reads with at least one N\n");
@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
   const int rc = fqg_open(dev ? atoi(dev) : 0, &ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   fqg_filter_params fp;
   memset(&fp, 0, sizeof(fp));
@@ -54,5 +54,5 @@ int main(int argc, char** argv) {
       });
   fflush(stdout);
   fqg_close(ctx);
-  exit(0);
+  fqhost::leave(0);
 }

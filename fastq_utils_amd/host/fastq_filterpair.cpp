@@ -26,7 +26,7 @@ gzFile open_out(const char* path) {  // fastq_new(path, FALSE, "w3") -> fastq_op
   else g = gzopen(path, "w3");
   if (!g) {
     FQ_PRINT_ERROR("Unable to open %s", path);
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   gzbuffer(g, 128000);
   return g;
@@ -44,7 +44,7 @@ void emit(const fqg_frame* frame, const std::vector<uint64_t>& list, gzFile out,
     if (gzwrite(out, host.data() + o, n) != (int)n) {
       int en = 0;
       FQ_PRINT_ERROR("%s.\n", gzerror(out, &en));  // GZ_WRITE, src/fastq.c:211-235
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
     o += n;
   }
@@ -53,7 +53,7 @@ void emit(const fqg_frame* frame, const std::vector<uint64_t>& list, gzFile out,
 void close_out(gzFile g) {  // fastq_destroy -> fastq_close (src/fastq.c:615-629)
   if (gzclose(g) != Z_OK) {
     FQ_PRINT_ERROR("unable to close file descriptor");
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
 }
 
@@ -63,14 +63,14 @@ int main(int argc, char** argv) {
   fprintf(stderr, "fastq_utils %s\n", "0.25.3");  // fastq_print_version
   if (argc != 6 && argc != 7) {
     fprintf(stderr, "Usage: filterpair fastq1 fastq2 paired1 paired2 unpaired [sorted]\n");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   fprintf(stderr, "%d", argc);
   const char* dev = getenv("FQGPU_DEVICE");
   int rc = fqg_open(dev ? atoi(dev) : 0, &g_ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X device (fqg_open: %d); this program has no CPU path", rc);
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   const char *path1 = argv[1], *path2 = argv[2];
   Input in1(g_ctx, path1, piece_bytes());
@@ -225,7 +225,7 @@ int main(int argc, char** argv) {
   close_out(w3);
   if (paired == 0) {
     fprintf(stderr, "!!!WARNING!!! 0 paired reads! are the headers ok?\n");
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
-  exit(0);
+  fqhost::leave(0);
 }

@@ -84,7 +84,7 @@ void run_single_noindex(const char* path, Stats& S) {
       if (r.code == FQG_E_TRUNCATED) fail_truncated(path, 4 * R);
       if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, R);
       print_validation_error(path, 4 * (R + 1), r, locate_record(in.data(), in.size(), r.record));
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     }
     ticker(base + 1, base + r.n_records, 100000);
     base += r.n_records;
@@ -113,7 +113,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
     const int rc = fqg_open(devs[i], &D[i].ctx);
     if (rc != 0) {
       FQ_PRINT_ERROR("FQGPU_DEVICES: device %d is not a usable MI355X GPU (fqg_open: %d)", devs[i], rc);
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
     if (fqg_acc_create(D[i].ctx, &D[i].acc) != 0) die_lib("fqg_acc_create", -1);
   }
@@ -183,7 +183,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
       if (d.rc) {
         join_all();
         FQ_PRINT_ERROR("GPU library failure in fqg_validate (%d): %s", d.rc, d.err.c_str());
-        exit(kExitSys);
+        fqhost::leave(kExitSys);
       }
       if (info_pending && base == 0 && r.n_records > 0) {
         if (!(r.code && r.record == 0 && is_early_code(r.code))) print_probe(pr);
@@ -196,7 +196,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
         if (r.code == FQG_E_TRUNCATED) fail_truncated(path, 4 * R);
         if (r.code == FQG_E_LINE_TOO_LONG) fail_too_long(path, R);
         print_validation_error(path, 4 * (R + 1), r, locate_record(d.p.data, d.p.size, r.record));
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       }
       if (r.stopped) {
         // a NUL at a record start ends the file here (src/fastq.c:250): what later pieces added to the accumulators
@@ -219,7 +219,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
     if (strcmp(path, "-") == 0) {
       FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES on a stream: use one device",
                      path);
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
     LIB(fqg_acc_reset(S.acc1));
     run_single_noindex(path, S);
@@ -341,7 +341,7 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
     if (d.rc) {
       join_all();
       FQ_PRINT_ERROR("GPU library failure in fqg_validate (%d): %s", d.rc, d.err.c_str());
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
     int stage = -1;
     if (r.code == FQG_E_TRUNCATED || r.code == FQG_E_LINE_TOO_LONG) stage = 0;
@@ -406,7 +406,7 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
     const int rc = fqg_open(devs[i], &M.D[i].ctx);
     if (rc != 0) {
       FQ_PRINT_ERROR("FQGPU_DEVICES: device %d is not a usable MI355X GPU (fqg_open: %d)", devs[i], rc);
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
     if (fqg_acc_create(M.D[i].ctx, &M.D[i].acc) != 0) die_lib("fqg_acc_create", -1);
   }
@@ -430,7 +430,7 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
   std::string dup_name;
   if (!ex.first_duplicate(M.f1, &dup, &dup_rec, &dup_name, &name_bytes)) {
     FQ_PRINT_ERROR("GPU library failure in the read-name exchange: %s", ex.error.c_str());
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   // which finding does the serial loop hit first?  per record: read (0), name (1), duplicate (2), validation (3)
   uint64_t best = ~0ull;
@@ -452,10 +452,10 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
     if (stage == 1) fail_wrong_header(path, 4 * (best + 1), pass.text.l[0]);
     if (stage == 2) {
       FQ_PRINT_ERROR("Error in file %s: line %lu: duplicated sequence %s", path, (unsigned long)(4 * (best + 1)), dup_name.c_str());
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     }
     print_validation_error(path, 4 * (best + 1), pass.r, pass.text);
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
   ticker(1, pass.n_records, 100000);
   merge_device_stats(M.D, S);
@@ -473,7 +473,7 @@ void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, 
   MultiPass pass = multi_pass(path2, M.D, 1, 0, &F.st);
   if (pass.stopped) {
     FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES: use one device", path2);
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   fqhost::NamesOfFile f2;
   f2.shards = std::move(pass.shards);
@@ -483,7 +483,7 @@ void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, 
   fqhost::PairingOutcome po;
   if (!ex.pairing(M.f1, f2, &po)) {
     FQ_PRINT_ERROR("GPU library failure in the read-name exchange: %s", ex.error.c_str());
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   uint64_t best = ~0ull;
   int stage = 9;
@@ -504,17 +504,17 @@ void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, 
     if (stage == 1) fail_wrong_header(path2, 4 * (best + 1), pass.text.l[0]);
     if (stage == 2) {
       FQ_PRINT_ERROR("Error in file %s: line %lu: unpaired read - %s", path2, (unsigned long)(4 * (best + 1)), po.first_name.c_str());
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     }
     print_validation_error(path1, cline1, pass.r, pass.text);  // named after file 1, like the reference
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
   ticker(1, pass.n_records, 100000);
   merge_device_stats(M.D, S);
   printf("\n");
   if (po.leftover > 0) {
     FQ_PRINT_ERROR("Error in file %s: found %llu unpaired reads", path1, (unsigned long long)po.leftover);
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
 }
 
@@ -562,10 +562,10 @@ void run_pair_second_file(const char* path1, const char* path2, Stats& S, Indexe
       if (best_stage == 2) {
         FQ_PRINT_ERROR("Error in file %s: line %lu: unpaired read - %s", path2, (unsigned long)(4 * (R + 1)),
                        canonical_name(t.l[0], pr2.st).c_str());
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       }
       print_validation_error(path1, cline1, r, t);  // named after file 1, like the reference
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     }
     ticker(base + 1, base + r.n_records, 100000);
     base += r.n_records;
@@ -576,7 +576,7 @@ void run_pair_second_file(const char* path1, const char* path2, Stats& S, Indexe
   printf("\n");
   if (F.entries > 0) {
     FQ_PRINT_ERROR("Error in file %s: found %llu unpaired reads", path1, (unsigned long long)F.entries);
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
 }
 
@@ -635,7 +635,7 @@ void run_interleaved(const char* path, Stats& S) {
         fail_truncated(path, 4 * (best_pair * 2 + (best_stage == 2 ? 1 : 0)));
       case 1:
         FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated?", path, (unsigned long)(4 * n));
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       case 3:
         fail_wrong_header(path, cline_pair, locate_record(in.data(), in.size(), 2 * k).l[0]);
       case 4:
@@ -643,10 +643,10 @@ void run_interleaved(const char* path, Stats& S) {
       case 5:
         FQ_PRINT_ERROR("Error in file %s: line %lu: unpaired read - %s", path, cline_pair,
                        canonical_name(locate_record(in.data(), in.size(), 2 * k).l[0], pr.st).c_str());
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       default:
         print_validation_error(path, cline_pair, r, locate_record(in.data(), in.size(), r.record));
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
     }
   }
   ticker(1, n / 2, 50000, 2);
@@ -715,21 +715,21 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
       fail_truncated(p1, 4 * k);
     case VAL1:
       print_validation_error(p1, 4 * (k + 1), r1, locate_record(in1.data(), in1.size(), k));
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     case READ2:
       if (r2.code == FQG_E_LINE_TOO_LONG) fail_too_long(p2, k);
       fail_truncated(p2, 4 * k);
     case VAL2:
       print_validation_error(p2, 4 * (k + 1), r2, locate_record(in2.data(), in2.size(), k));
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     case NAMES:
       FQ_PRINT_ERROR("Readnames do not match across files (read #%ld)", (long)(k + 1 + 1));
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     case END1:
       // file 1 is exhausted at record n1; anything left in file 2?
       if (n2 > n1) {
         FQ_PRINT_ERROR("Premature end of file1");
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       }
       if (tail2 && n2 == n1) fail_truncated(p2, 4 * n1);
       break;
@@ -737,7 +737,7 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
       // file 2 is exhausted at record n2 (record n2 of file 1 has been read and validated)
       if (n1 >= n2 + 2) {
         FQ_PRINT_ERROR("Premature end of file2");
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       }
       if (tail1 && n1 == n2 + 1) fail_truncated(p1, 4 * (n2 + 1));
       break;
@@ -762,20 +762,20 @@ int main(int argc, char** argv) {
       case 'e': empty_ok = 1; ++nopt; break;
       case 's': is_sorted = 1; ++nopt; break;
       case 'r': skip_readname_check = 1; ++nopt; break;
-      case 'h': print_usage(1); exit(0);
+      case 'h': print_usage(1); fqhost::leave(0);
       case 'f':
         fprintf(stderr, "Fixing (-f) enabled: Replacing . by N (creating .fix.gz files)\n");
         FQ_PRINT_ERROR("-f option is no longer valid.");
-        exit(kExitParams);
+        fqhost::leave(kExitParams);
       default:
         ++nopt;
         FQ_PRINT_ERROR("Option -%c invalid", optopt);
-        exit(kExitParams);
+        fqhost::leave(kExitParams);
     }
   if (argc - nopt < 2 || argc - nopt > 3) {
     FQ_PRINT_ERROR("Invalid number of arguments");
     print_usage(0);
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   if (argc - nopt == 3) {
     is_paired_data = 1;
@@ -791,7 +791,7 @@ int main(int argc, char** argv) {
   if (getenv("FQGPU_TIMING")) fprintf(stderr, "fqgpu timing: context open %.3f s after the program started\n", since_start());
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   Stats S;
   LIB(fqg_acc_create(g_ctx, &S.acc1));
@@ -831,10 +831,10 @@ int main(int argc, char** argv) {
       fprintf(stdout, "Quality encoding range: %lu %lu\n", 0L, 0L);
       fprintf(stdout, "Quality encoding: %s\n", "");
       fprintf(stdout, "Read length: %lu %lu %u\n", 0L, 0L, 0);
-      exit(0);
+      fqhost::leave(0);
     }
     FQ_PRINT_ERROR("No reads found in %s.", file1);
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
   // min/max lengths and qualities are taken BEFORE the second file goes through fd1
   // (src/fastq_info.c:316-319); only the length histogram keeps growing
@@ -867,7 +867,7 @@ int main(int argc, char** argv) {
       FQ_PRINT_ERROR("Unable to determine quality encoding - unknown range [%lu,>%u]", min_qual, FQG_MAX_PHRED_QUAL);
     else
       FQ_PRINT_ERROR("Unable to determine quality encoding - unknown range [%lu,%lu]", min_qual, max_qual);
-    exit(kExitFormat);
+    fqhost::leave(kExitFormat);
   }
   fprintf(stderr, "Quality encoding range: %lu %lu\n", min_qual, max_qual);
   if (!enc) fprintf(stderr, "Quality encoding: NA\n");

@@ -23,7 +23,7 @@ namespace {
 fqg_ctx* g_ctx = nullptr;
 [[noreturn]] void die_lib(const char* what, int rc) {
   FQ_PRINT_ERROR("GPU library failure in %s (%d): %s", what, rc, g_ctx ? fqg_last_error(g_ctx) : "no context");
-  exit(kExitSys);
+  fqhost::leave(kExitSys);
 }
 #define LIB(call)                        \
   do {                                   \
@@ -53,7 +53,7 @@ int read_index2read_idx(const char* s) {  // src/fastq_pre_barcodes.c:79-89
   if (!strcmp(s, "index2")) return INDEX2;
   if (!strcmp(s, "index3")) return INDEX3;
   FQ_PRINT_ERROR("invalid file reference %s (valid values are read1,read2, index1,index2,index3)\n", s);
-  exit(1);
+  fqhost::leave(1);
 }
 
 void print_usage() {  // src/fastq_pre_barcodes.c:311-346
@@ -235,7 +235,7 @@ int main(int argc, char** argv) {
         }
         if (xx != 2) {
           FQ_PRINT_ERROR("two file references should be passed to --interleaved");
-          exit(1);
+          fqhost::leave(1);
         }
         P.interleaved[0] = refs[0];
         P.interleaved[1] = refs[1];
@@ -269,20 +269,20 @@ int main(int argc, char** argv) {
   }
   if (help) {
     print_usage();
-    exit(0);
+    fqhost::leave(0);
   }
   FQ_PRINT_INFO("Validating options...");
   if (!file[READ1]) {  // validate_options, src/fastq_pre_barcodes.c:91-107
     FQ_PRINT_ERROR("missing input file (-read1)");
-    exit(1);
+    fqhost::leave(1);
   }
   if (paired && !file[READ2]) {
     FQ_PRINT_ERROR("if paired_end is used then two fastq files should be provided - missing input file (-read2)");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   if (!outfile[READ1]) {
     FQ_PRINT_ERROR("if single_end then -outfile1 should be provided");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   FQ_PRINT_INFO("Options OK.");
   FQ_PRINT_INFO("input files %d", num_input_files);
@@ -291,7 +291,7 @@ int main(int argc, char** argv) {
   int rc = fqg_open(dev ? atoi(dev) : 0, &g_ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   P.out_sam = out_sam;
   P.tenx = tenx;
@@ -304,7 +304,7 @@ int main(int argc, char** argv) {
     }
   if (has_interleaved && (!file[P.interleaved[0]] || !file[P.interleaved[1]])) {
     FQ_PRINT_ERROR("--interleaved refers to an input that was not given");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   GzipMembers outgz[3];  // gzip level 4 like the reference's "w4", one member per 4 MiB block, all cores
   bool out_open[3] = {false, false, false};
@@ -313,13 +313,13 @@ int main(int argc, char** argv) {
       if (outfile[x]) {
         if (!file[x]) {
           FQ_PRINT_ERROR("--outfile%d needs --read%d", x, x);
-          exit(kExitParams);
+          fqhost::leave(kExitParams);
         }
         P.emit[x] = 1;
         // ("-": the reference's gzdopen(stdout, "wb") compresses at the default level; "w4" otherwise)
         if (!outgz[x].open(outfile[x], (outfile[x][0] == '-' && outfile[x][1] == 0) ? Z_DEFAULT_COMPRESSION : 4)) {
           FQ_PRINT_ERROR("Unable to open %s", outfile[x]);
-          exit(kExitParams);
+          fqhost::leave(kExitParams);
         }
         out_open[x] = true;
       }
@@ -399,7 +399,7 @@ int main(int argc, char** argv) {
         else {
           if (!outgz[which].write(hostbuf.data(), r.out_bytes[which])) {
             FQ_PRINT_ERROR("%s.\n", "write error");
-            exit(kExitSys);
+            fqhost::leave(kExitSys);
           }
         }
       }
@@ -429,10 +429,10 @@ int main(int argc, char** argv) {
         const uint64_t reads_of_file = rec + 1;  // records this file has handed out so far
         FQ_PRINT_ERROR("Error in file %s: line %lu: wrong header %s", s.path, (unsigned long)(4 * reads_of_file),
                        hdr.c_str());
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       }
       FQ_PRINT_ERROR("Readnames do not match across files (read #%ld)", (long)(processed + 1));
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     }
     const bool ended_on_discard = has_interleaved && r.n_done < n;
     for (int x = READ1; x <= INDEX3; ++x)
@@ -452,7 +452,7 @@ int main(int argc, char** argv) {
                                (has_interleaved && x == P.interleaved[1] && s.use == (long)s.avail + 1))) {
         FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", s.path,
                        (unsigned long)(4 * (s.records_before + s.avail)));
-        exit(1);
+        fqhost::leave(1);
       }
       break;
     }
@@ -462,8 +462,8 @@ int main(int argc, char** argv) {
     for (int x = READ1; x <= READ2; ++x)
       if (out_open[x] && !outgz[x].close()) {
         FQ_PRINT_ERROR("unable to close file descriptor");
-        exit(kExitSys);
+        fqhost::leave(kExitSys);
       }
   fflush(stdout);
-  exit(0);
+  fqhost::leave(0);
 }

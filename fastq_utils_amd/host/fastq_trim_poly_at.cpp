@@ -56,16 +56,16 @@ int main(int argc, char** argv) {
   }
   if (help) {
     print_usage();
-    exit(0);
+    fqhost::leave(0);
   }
   FQ_PRINT_INFO("Validating options...");
   if (!file) {
     FQ_PRINT_ERROR("missing input file (--file)");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   if (!outfile) {
     FQ_PRINT_ERROR("missing output file name (--outfile)");
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
   FQ_PRINT_INFO("Options OK.");
 
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     if (!(file[0] == '-' && file[1] == 0)) {
       if (!probe) {
         FQ_PRINT_ERROR("Unable to open %s", file);
-        exit(kExitParams);
+        fqhost::leave(kExitParams);
       }
       gzclose(probe);
     }
@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
   GzipMembers out;
   if (!out.open(outfile, (outfile[0] == '-' && outfile[1] == 0) ? Z_DEFAULT_COMPRESSION : 4)) {
     FQ_PRINT_ERROR("Unable to open %s", outfile);
-    exit(kExitParams);
+    fqhost::leave(kExitParams);
   }
 
   fqg_ctx* ctx = nullptr;
@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
   const int rc = fqg_open(dev ? atoi(dev) : 0, &ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   fqg_filter_params fp;
   memset(&fp, 0, sizeof(fp));
@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
       [&](const char* text, size_t n) {
         if (!out.write(text, n)) {
           FQ_PRINT_ERROR("%s.\n", "write error");
-          exit(kExitSys);
+          fqhost::leave(kExitSys);
         }
       },
       [](unsigned long before, unsigned long after) {
@@ -120,8 +120,8 @@ int main(int argc, char** argv) {
   FQ_PRINT_INFO("Reads discarded: %ld", (long)t.discarded);
   if (!out.close()) {
     FQ_PRINT_ERROR("unable to close file descriptor");
-    exit(kExitSys);
+    fqhost::leave(kExitSys);
   }
   fqg_close(ctx);
-  exit(0);
+  fqhost::leave(0);
 }

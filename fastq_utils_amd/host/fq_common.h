@@ -18,7 +18,7 @@ fqg_ctx* g_ctx = nullptr;
 
 [[noreturn]] void die_lib(const char* what, int rc) {
   FQ_PRINT_ERROR("GPU library failure in %s (%d): %s", what, rc, g_ctx ? fqg_last_error(g_ctx) : "no context");
-  exit(kExitSys);
+  fqhost::leave(kExitSys);
 }
 #define LIB(call)                   \
   do {                              \
@@ -196,18 +196,18 @@ void print_validation_error(const char* fname, unsigned long cline, const fqg_va
 
 [[noreturn]] void fail_truncated(const char* fname, unsigned long cline) {
   FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", fname, cline);  // src/fastq.c:255
-  exit(1);
+  fqhost::leave(1);
 }
 [[noreturn]] void fail_too_long(const char* fname, uint64_t rec) {
   FQ_PRINT_ERROR(
       "Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes); the "
       "reference splits such lines silently, this program refuses them",
       fname, (unsigned long)(rec + 1), FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
-  exit(kExitSys);
+  fqhost::leave(kExitSys);
 }
 [[noreturn]] void fail_wrong_header(const char* fname, unsigned long cline, const std::string& hdr) {
   FQ_PRINT_ERROR("Error in file %s: line %lu: wrong header %s", fname, cline, hdr.c_str());  // src/fastq.c:449
-  exit(kExitFormat);
+  fqhost::leave(kExitFormat);
 }
 
 struct Stats {
@@ -283,10 +283,10 @@ void run_index_input(Input& in, const char* path, int is_pe, Stats& S, IndexedFi
       if (best_stage == 2) {
         FQ_PRINT_ERROR("Error in file %s: line %lu: duplicated sequence %s", path, (unsigned long)(4 * (R + 1)),
                        canonical_name(t.l[0], pr.st).c_str());
-        exit(kExitFormat);
+        fqhost::leave(kExitFormat);
       }
       print_validation_error(path, 4 * (R + 1), r, t);
-      exit(kExitFormat);
+      fqhost::leave(kExitFormat);
     }
     ticker(base + 1, base + r.n_records, 100000);
     base += r.n_records;

@@ -29,7 +29,7 @@ inline FilterTotals run_filter(fqg_ctx* ctx, const char* path, const fqg_filter_
   auto lib = [&](int rc, const char* what) {
     if (rc != 0) {
       FQ_PRINT_ERROR("GPU library failure in %s (%d): %s", what, rc, fqg_last_error(ctx));
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
   };
   Input in(ctx, path, piece_bytes_env());
@@ -65,7 +65,7 @@ inline FilterTotals run_filter(fqg_ctx* ctx, const char* path, const fqg_filter_
   if (tail_lines > 0) {
     FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", path, 4ul * t.processed);
     fflush(stdout);
-    exit(1);
+    fqhost::leave(1);
   }
   return t;
 }

@@ -51,6 +51,16 @@ inline bool& keep_slots_until_exit() {
   return v;
 }
 
+// How the programs leave: with everything they said flushed, and WITHOUT exit()'s hooks.  The HIP runtime tears itself
+// down in one of them, and it must not meet a thread of ours that is still inside a HIP call (a reader pinning its next
+// slot while the main thread has found the file's first error): that is a crash after the error message, i.e. a wrong
+// exit status.  Nothing is lost: outputs are closed by those who write them before they leave.
+[[noreturn]] inline void leave(int code) {
+  fflush(stdout);
+  fflush(stderr);
+  _exit(code);
+}
+
 inline unsigned host_read_threads() {
   if (const char* e = getenv("FQGPU_HOST_THREADS")) return (unsigned)std::max(1L, strtol(e, nullptr, 10));
   const unsigned hw = std::thread::hardware_concurrency();
@@ -150,7 +160,7 @@ class Input {
     }
     if (!gz_ && plain_fd_ < 0) {
       FQ_PRINT_ERROR("Unable to open %s", path);
-      exit(kExitParams);
+      leave(kExitParams);
     }
     if (gz_) gzbuffer(gz_, 1 << 20);
     if (plain_fd_ >= 0 && plain_size_ < cap_) cap_ = std::max<size_t>(plain_size_, 1);  // small file: one small slot
@@ -195,7 +205,7 @@ class Input {
       cv_.wait(lk, [&] { return s.ready || failed_; });
       if (failed_) {
         FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
-        exit(kExitSys);
+        leave(kExitSys);
       }
     }
     if (carry > s.head) {  // a tail longer than the headroom (a record of megabases): rebuild this one piece
@@ -248,7 +258,7 @@ class Input {
     char* p = static_cast<char*>(fqg_host_alloc(ctx_, n));
     if (!p) {
       FQ_PRINT_ERROR("unable to allocate %zu bytes of pinned memory", n);
-      exit(kExitSys);
+      leave(kExitSys);
     }
     return p;
   }
@@ -314,7 +324,7 @@ class Input {
     // is being read (the file may well end inside the first)
     const size_t head = std::min(kHead, std::max<size_t>(cap_, 4096));  // (tiny files: tiny slots)
     std::thread helper;
-    const bool more = plain_fd_ < 0 || plain_size_ > cap_;
+    const bool more = plain_fd_ >= 0 && plain_size_ > cap_;  // (gz input, stdin: unknown - the slots are pinned as they are needed)
     if (more)
       helper = std::thread([this, head] {
         for (int i = 1; i < kSlots; ++i) {
@@ -388,14 +398,14 @@ class Input {
         if (got < 0) {
           int en = 0;
           FQ_PRINT_ERROR("%s.\n", gzerror(gz_, &en));
-          exit(kExitSys);
+          leave(kExitSys);
         }
         if (got == 0) at_end = true;
         len += (size_t)got;
       }
       if (failed_) {
         FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
-        exit(kExitSys);
+        leave(kExitSys);
       }
     }
     if (whole_) fqg_host_free(ctx_, whole_);

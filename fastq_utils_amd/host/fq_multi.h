@@ -49,7 +49,7 @@ class AlignedPieces {
     }
     if (!gz_ && plain_fd_ < 0) {
       FQ_PRINT_ERROR("Unable to open %s", path);
-      exit(kExitParams);
+      fqhost::leave(kExitParams);
     }
     if (gz_) gzbuffer(gz_, 1 << 20);
     producer_ = std::thread([this] { produce(); });
@@ -74,7 +74,7 @@ class AlignedPieces {
     if (quit_) return false;
     if (failed_) {
       FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
-      exit(kExitSys);
+      fqhost::leave(kExitSys);
     }
     if (ready_.empty()) return false;
     *out = ready_.front();
