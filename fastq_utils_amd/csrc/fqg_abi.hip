@@ -1347,10 +1347,12 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
                          ix->n_askers_total, d_slot, c->d_icall);
     }
     if (match) {
-      ProfScope ps(c, "k_index_probe_resolve");
-      hipLaunchKernelGGL(k_index_probe_resolve, dim3((unsigned)((fv.n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                         c->stream, fv.n_records, (const unsigned long long*)d_slot, index_view(ix), ix->n_askers_total,
-                         d_match);
+      {
+        ProfScope ps(c, "k_index_probe_resolve");
+        hipLaunchKernelGGL(k_index_probe_resolve, dim3((unsigned)((fv.n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           c->stream, fv.n_records, (const unsigned long long*)d_slot, index_view(ix), ix->n_askers_total,
+                           d_match);
+      }
       HIP_TRY(c, hipMemcpyAsync(match, d_match, fv.n_records * 8, hipMemcpyDeviceToHost, c->stream));
     }
   }

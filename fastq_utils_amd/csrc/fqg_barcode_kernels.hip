@@ -622,9 +622,9 @@ __global__ __launch_bounds__(kBlock) void k_bc_count(const uint8_t* __restrict__
 
 // ---- 64-bit exclusive scan of u32 lengths: 2048 per workgroup ---------------------------------
 constexpr int kScan64Span = kBlock * 8;
-__global__ __launch_bounds__(kBlock) void k_scan64_a(const uint32_t* __restrict__ in, uint64_t n,
-                                                     unsigned long long* __restrict__ local,
-                                                     unsigned long long* __restrict__ sums) {
+__device__ __forceinline__ void scan64_a_body(const uint32_t* __restrict__ in, uint64_t n,
+                                              unsigned long long* __restrict__ local,
+                                              unsigned long long* __restrict__ sums) {
   __shared__ unsigned long long s_w[kBlock / kWave];
   const uint64_t first = (uint64_t)blockIdx.x * kScan64Span + threadIdx.x * 8;
   unsigned long long v[8], sum = 0;
@@ -656,8 +656,14 @@ __global__ __launch_bounds__(kBlock) void k_scan64_a(const uint32_t* __restrict_
   if (threadIdx.x == 0) sums[blockIdx.x] = all;
 }
 // one workgroup: exclusive prefix over the span sums, total into *total
-__global__ __launch_bounds__(kBlock) void k_scan64_b(unsigned long long* __restrict__ sums, uint64_t nb,
-                                                     unsigned long long* __restrict__ total) {
+__global__ __launch_bounds__(kBlock) void k_scan64_a(const uint32_t* __restrict__ in, uint64_t n,
+                                                     unsigned long long* __restrict__ local,
+                                                     unsigned long long* __restrict__ sums) {
+  scan64_a_body(in, n, local, sums);
+}
+
+__device__ __forceinline__ void scan64_b_body(unsigned long long* __restrict__ sums, uint64_t nb,
+                                              unsigned long long* __restrict__ total) {
   __shared__ unsigned long long s_part[kBlock];
   __shared__ unsigned long long s_carry;
   if (threadIdx.x == 0) s_carry = 0;
@@ -680,6 +686,25 @@ __global__ __launch_bounds__(kBlock) void k_scan64_b(unsigned long long* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(kBlock) void k_scan64_b(unsigned long long* __restrict__ sums, uint64_t nb,
+                                                     unsigned long long* __restrict__ total) {
+  scan64_b_body(sums, nb, total);
+}
+// the same for three arrays in one launch (blockIdx.y picks the array): bam_umi_count numbers UMIs, cells and features
+// by three such scans, and a launch costs more than the scan of a few million flags
+struct Scan3 {
+  const uint32_t* first[3];          // k_umi_flag3: table -> first record of the key in the slot
+  uint32_t* flag[3];
+  unsigned long long* local[3];
+  unsigned long long* sums[3];
+  unsigned long long* total;         // [3]
+};
+__global__ __launch_bounds__(kBlock) void k_scan64_a3(Scan3 t, uint64_t n) {
+  scan64_a_body(t.flag[blockIdx.y], n, t.local[blockIdx.y], t.sums[blockIdx.y]);
+}
+__global__ __launch_bounds__(kBlock) void k_scan64_b3(Scan3 t, uint64_t nb) {
+  scan64_b_body(t.sums[blockIdx.y], nb, t.total + blockIdx.y);
 }
 
 // ---- emit -----------------------------------------------------------------------------------

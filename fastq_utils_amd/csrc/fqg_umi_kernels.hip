@@ -642,6 +642,13 @@ __global__ __launch_bounds__(kBlock) void k_umi_flag(const uint32_t* __restrict_
   if (f != kNoIdx) flag[f] = 1u;
 }
 
+__global__ __launch_bounds__(kBlock) void k_umi_flag3(Scan3 t, uint64_t n_slots) {
+  const uint64_t h = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (h >= n_slots) return;
+  const uint32_t f = t.first[blockIdx.y][h];
+  if (f != kNoIdx) t.flag[blockIdx.y][f] = 1u;
+}
+
 // exclusive prefix over u32 flags: local (per span of kUmiSpan) + span sums (scanned by k_scan64_b)
 constexpr int kUmiSpan = kBlock * 8;
 struct Prefix {

@@ -4,7 +4,9 @@
 #   traffic  FETCH_SIZE / WRITE_SIZE in separate passes on the headline workload (+ a --two-pass run: k_count_nl, the
 #            kernel with a known byte count the read correction is checked on) -> <tag>_traffic_100M_150bp.json
 #   umi      FETCH_SIZE / WRITE_SIZE / SQ counters of the bam_umi_count kernels on configs[3]
-#   index    FETCH_SIZE / WRITE_SIZE of the default-mode extra (k_index_insert) -> traffic_index_100M.json
+#   index    FETCH_SIZE / WRITE_SIZE of the default-mode extra (the name kernels) -> traffic_index_100M.json
+#   pass1sq  SQ counters of the streaming kernels (headline workload) -> pass1_sq_counters.json
+#   micro    the random-access and decode microbenchmarks -> rmwbench.txt, decbench.txt
 # Counter passes never carry another trace domain than --kernel-trace.  Summaries land in gpurun_out/<tag>/; copy what
 # is to be judged into profiles/.
 set -u
@@ -47,6 +49,23 @@ for w in $WHAT; do
     done
     python3 $R/tools/pmc_traffic.py $(find $O/idx_pmc_FETCH_SIZE -name '*counter_collection.csv') $(find $O/idx_pmc_WRITE_SIZE -name '*counter_collection.csv') \
         34900000000 > $O/traffic_index_100M.json 2>$O/traffic_index.err || true
+    ;;
+  pass1sq)
+    # issue-side counters of the dominant kernel (k_stream_pass1<0>): is it the VALU that bounds it?
+    i=0
+    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+               "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+      i=$((i+1))
+      rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p1sq/p$i -o pmc -- python3 $R/bench.py --steps 2 $ONLY_HEADLINE > $O/p1sq_$i.json 2> $O/p1sq_$i.err
+      find $O/p1sq/p$i -name '*kernel_trace.csv' -delete
+    done
+    python3 $R/tools/pmc_sum.py $O/p1sq k_stream > $O/pass1_sq_counters.json
+    find $O/p1sq -name '*counter_collection.csv' -delete
+    ;;
+  micro)
+    # what one random access costs on this GPU (tools/kbench/rmwbench.hip), and what decoding a capture record costs
+    (cd $R/tools/kbench && timeout 300 ./rmwbench 100 30 35) > $O/rmwbench.txt 2>&1
+    (cd $R/tools/kbench && timeout 120 ./decbench) > $O/decbench.txt 2>&1
     ;;
   umistats)
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/umi_stats -o stats -- python3 $R/bench.py $ONLY_UMI > $O/umi_under_rocprof.json 2> $O/umi_under_rocprof.err
