@@ -10,10 +10,13 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
+#include "fq_blocks.h"
 #include "fq_input.h"
+#include "fq_multi.h"
 #include "fq_parallel.h"
 
 using namespace fqhost;
@@ -109,24 +112,28 @@ struct Source {
   size_t carry_at = 0;      // bytes of the current piece covered by complete records
 };
 
-void probe(Source& s) {
-  if (s.probed || s.in->size() == 0) return;
-  s.st.is_pe = 1;
-  if (fqg_probe_first_record(s.in->data(), s.in->size(), 1, &s.st) != 0) return;
-  s.probed = true;
-  if (s.st.readname_format == FQG_NAME_CASAVA18) s.format_line = "CASAVA=1.8\n";
-  else if (s.st.readname_format == FQG_NAME_INTEGER) {
+// state of the first record + the line fastq_get_readname prints on its first call for the file
+bool probe_bytes(const char* data, size_t size, fqg_file_state* st, std::string* format_line) {
+  st->is_pe = 1;
+  if (fqg_probe_first_record(data, size, 1, st) != 0) return false;
+  if (st->readname_format == FQG_NAME_CASAVA18) *format_line = "CASAVA=1.8\n";
+  else if (st->readname_format == FQG_NAME_INTEGER) {
     // INTEGERNAME and NOP share a value; the text differs (src/fastq.c:465-474)
-    const char* b = s.in->data();
-    const char* nl = static_cast<const char*>(memchr(b, '\n', s.in->size()));
-    std::string h(b + 1, nl ? (size_t)(nl - b) : s.in->size() - 1);
+    const char* nl = static_cast<const char*>(memchr(data, '\n', size));
+    std::string h(data + 1, nl ? (size_t)(nl - data) : size - 1);
     const std::string name = h.c_str();
     size_t i = 0;
     while (i < name.size() && name[i] >= '0' && name[i] <= '9') ++i;
     const std::string rest = name.substr(i);
     const bool all_digits = i > 0 && (rest.empty() || rest == "\n" || rest == "\r");
-    s.format_line = all_digits ? "Read name provided as an integer\n" : "Read name provided with no suffix\n";
+    *format_line = all_digits ? "Read name provided as an integer\n" : "Read name provided with no suffix\n";
   }
+  return true;
+}
+
+void probe(Source& s) {
+  if (s.probed || s.in->size() == 0) return;
+  s.probed = probe_bytes(s.in->data(), s.in->size(), &s.st, &s.format_line);
 }
 
 // frame the next piece of `s`; false when the input is used up
@@ -160,6 +167,257 @@ bool refill(Source& s) {
     s.carry_at = r.consumed;
   } else s.exhausted = true;
   return r.n_records > 0 || !s.exhausted;
+}
+
+// ---- several GPUs (FQGPU_DEVICES=0,1,..): every input is cut into blocks of the same B records (fq_blocks.h), block j
+// of all inputs is one unit, whichever device is free takes the next unit, and this thread takes the results in unit
+// order - what the serial loop prints and writes, in its order.  Not for --interleaved input (a discarded read leaves
+// the reference's file pointers out of step from there on, src/fastq_pre_barcodes.c:653 vs :722: a serial dependence).
+struct BlockRun {
+  const char* const* file;
+  const fqg_barcode_params* P;
+  GzipMembers* outgz;
+  int out_sam, num_input_files;
+};
+
+[[noreturn]] void run_blocks(const BlockRun& A, const std::vector<int>& devs) {
+  const size_t nd = devs.size();
+  std::vector<fqg_ctx*> ctx(nd, nullptr);
+  ctx[0] = g_ctx;  // (opened on devs[0])
+  for (size_t i = 1; i < nd; ++i) {
+    const int rc = fqg_open(devs[i], &ctx[i]);
+    if (rc != 0) {
+      FQ_PRINT_ERROR("FQGPU_DEVICES: device %d is not a usable MI355X GPU (fqg_open: %d)", devs[i], rc);
+      fqhost::leave(kExitSys);
+    }
+  }
+  RecordBlocks* cut[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  fqg_file_state st0[6];
+  memset(st0, 0, sizeof(st0));
+  std::string format_line[6];
+  double record_bytes = 64;
+  for (int x = READ1; x <= INDEX3; ++x)
+    if (A.file[x]) {
+      cut[x] = new RecordBlocks(g_ctx, A.file[x], (int)nd + 2);
+      if (cut[x]->peek_size()) probe_bytes(cut[x]->peek(), cut[x]->peek_size(), &st0[x], &format_line[x]);
+      else st0[x].is_pe = 1;
+      const double rb = cut[x]->peek_lines() >= 4 ? 4.0 * (double)cut[x]->peek_size() / (double)cut[x]->peek_lines()
+                                                  : (double)std::max<size_t>(cut[x]->peek_size(), 64);
+      record_bytes = std::max(record_bytes, rb);
+    }
+  const size_t piece = getenv("FQGPU_CHUNK_MB") ? piece_bytes() : (size_t)128 << 20;
+  uint64_t B = std::max<uint64_t>(1, (uint64_t)((double)piece / record_bytes));
+  if (const char* e = getenv("FQGPU_BLOCK_RECORDS")) B = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // (tests: tiny blocks)
+  for (int x = READ1; x <= INDEX3; ++x)
+    if (cut[x]) cut[x]->start(B);
+
+  struct Unit {
+    uint64_t seq = 0;
+    int rc = 0;
+    std::string err;
+    fqg_barcode_result r{};
+    uint64_t n = 0;                               // iterations the unit had to offer
+    uint64_t records[6] = {0, 0, 0, 0, 0, 0};     // complete records of every input's block
+    int tail_lines[6] = {0, 0, 0, 0, 0, 0};
+    bool final[6] = {false, false, false, false, false, false};
+    std::vector<char> out[3];
+    std::string wrong_header;                     // the text of the header line of a FQG_E_WRONG_HEADER finding
+  };
+  std::map<uint64_t, Unit> done;
+  std::mutex mu, fetch_mu;
+  std::condition_variable cv;
+  std::atomic<bool> stop{false};
+  bool exhausted = false;     // (under fetch_mu)
+  uint64_t next_seq = 0;      // (under fetch_mu)
+  uint64_t n_units = ~0ull;   // known once a unit with the end of an input was handed out (under mu)
+
+  auto work = [&](size_t di) {
+    fqg_ctx* c = ctx[di];
+    for (;;) {
+      Unit u;
+      Block b[6];
+      {
+        std::lock_guard<std::mutex> lk(fetch_mu);
+        if (exhausted || stop) return;
+        bool all = true;
+        for (int x = READ1; x <= INDEX3 && all; ++x)
+          if (cut[x] && !cut[x]->next(&b[x])) all = false;
+        if (!all) {  // (only after an abort: a unit that holds the end of an input is the last one handed out)
+          exhausted = true;
+          return;
+        }
+        u.seq = next_seq++;
+        for (int x = READ1; x <= INDEX3; ++x)
+          if (cut[x] && b[x].final) exhausted = true;
+        if (exhausted) {
+          std::lock_guard<std::mutex> lk2(mu);
+          n_units = u.seq + 1;
+        }
+      }
+      const fqg_frame* frames[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      fqg_frame* held[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      fqg_file_state states[6];
+      memcpy(states, st0, sizeof(states));
+      uint64_t first[6] = {0, 0, 0, 0, 0, 0};
+      auto lib_fail = [&](const char* what, int rc) {
+        u.rc = rc;
+        u.err = std::string(what) + ": " + fqg_last_error(c);
+      };
+      u.n = ~0ull;
+      for (int x = READ1; x <= INDEX3 && !u.rc; ++x)
+        if (cut[x]) {
+          fqg_validate_result r;
+          const int rc = fqg_validate(c, nullptr, b[x].data, b[x].size, FQG_MEM_HOST, b[x].final ? 1 : 0, &states[x],
+                                      FQG_VALIDATE_FRAME_ONLY, &r);
+          if (rc) {
+            lib_fail("fqg_validate", rc);
+            break;
+          }
+          if (!b[x].final && (r.n_records != B || r.consumed != b[x].size)) {
+            // (a NUL byte that ends the file early for the reference's C strings, src/fastq.c:250: not a case for blocks)
+            u.rc = FQG_ERR_ARG;
+            u.err = std::string("a block of ") + A.file[x] + " cut at a record boundary was not consumed whole (FQGPU_DEVICES): use one device";
+            break;
+          }
+          u.records[x] = r.n_records;
+          u.tail_lines[x] = r.tail_lines;
+          u.final[x] = b[x].final;
+          u.n = std::min<uint64_t>(u.n, r.n_records);
+          if (r.n_records) {
+            const int rc2 = fqg_frame_retain(c, &held[x]);
+            if (rc2) {
+              lib_fail("fqg_frame_retain", rc2);
+              break;
+            }
+            frames[x] = held[x];
+          }
+        }
+      if (!u.rc && u.n > 0) {
+        fqg_barcode_params Pb = *A.P;
+        const int rc = fqg_barcodes_transform(c, frames, states, first, &Pb, u.n, u.seq * B, &u.r);
+        if (rc) lib_fail("fqg_barcodes_transform", rc);
+        for (int which = 0; which < 3 && !u.rc; ++which)
+          if (u.r.out_bytes[which]) {
+            u.out[which].resize(u.r.out_bytes[which]);
+            const int rc2 = fqg_barcodes_output(c, which, u.out[which].data(), u.r.out_bytes[which]);
+            if (rc2) lib_fail("fqg_barcodes_output", rc2);
+          }
+        if (!u.rc && u.r.code == FQG_E_WRONG_HEADER) {
+          const Block& bb = b[u.r.file];
+          const char *p = bb.data, *end = bb.data + bb.size;
+          for (uint64_t line = 0; p < end && line < 4 * u.r.n_done; ++line) {
+            const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            p = nl ? nl + 1 : end;
+          }
+          const char* nl = p < end ? static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))) : nullptr;
+          u.wrong_header.assign(p, nl ? nl + 1 : end);
+        }
+      } else if (!u.rc) u.n = 0;
+      for (int x = READ1; x <= INDEX3; ++x)
+        if (cut[x]) {
+          if (held[x]) fqg_frame_release(held[x]);
+          cut[x]->release(b[x]);
+        }
+      std::lock_guard<std::mutex> lk(mu);
+      const uint64_t seq = u.seq;
+      done.emplace(seq, std::move(u));
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < nd; ++i) th.emplace_back(work, i);
+  auto join_all = [&] {
+    stop = true;
+    for (int x = READ1; x <= INDEX3; ++x)
+      if (cut[x]) cut[x]->abort();
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+  };
+
+  unsigned long processed = 0, discarded = 0;
+  bool first_batch = true;
+  Unit last;
+  bool have_last = false;
+  for (uint64_t k = 0;; ++k) {
+    Unit u;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return done.count(k) || k >= n_units; });
+      if (!done.count(k)) break;
+      u = std::move(done[k]);
+      done.erase(k);
+    }
+    if (u.rc) {
+      join_all();
+      FQ_PRINT_ERROR("GPU library failure in %s (%d)", u.err.c_str(), u.rc);
+      fqhost::leave(kExitSys);
+    }
+    if (u.n > 0) {
+      const fqg_barcode_result& r = u.r;
+      if (first_batch && A.num_input_files > 1) {
+        // format lines of the first fastq_get_readname call per file, in file order (src/fastq.c:459-485)
+        for (int x = READ1; x <= INDEX3; ++x)
+          if (A.file[x]) {
+            if (r.code == FQG_E_WRONG_HEADER && r.iteration == 0 && r.file == x) break;
+            fputs(format_line[x].c_str(), stderr);
+            if (st0[x].space == FQG_SPACE_COLOUR) fputs("Color space\n", stderr);
+          }
+      }
+      first_batch = false;
+      for (uint64_t w = 0; w < r.n_short; ++w) fputs("Warning: Read too short - barcode not found\n", stderr);
+      if (r.out_bytes[0]) fwrite(u.out[0].data(), 1, r.out_bytes[0], stdout);
+      for (int which = 1; which < 3; ++which)
+        if (r.out_bytes[which] && !A.outgz[which].write(u.out[which].data(), r.out_bytes[which])) {
+          join_all();
+          FQ_PRINT_ERROR("%s.\n", "write error");
+          fqhost::leave(kExitSys);
+        }
+      const unsigned long before = processed;
+      processed += r.n_done;
+      discarded += r.n_discarded;
+      for (unsigned long c = (before / 100000 + 1) * 100000; c <= processed; c += 100000) {
+        fprintf(stderr, "\b\b\b\b\b\b\b\b\b\b\b\b\b\b\b%lu", c);
+        fflush(stderr);
+      }
+      if (r.code != FQG_OK) {
+        join_all();
+        if (r.code == FQG_E_WRONG_HEADER) {  // src/fastq.c:448-451, with the file's own line counter
+          const uint64_t reads_of_file = u.seq * B + r.n_done + 1;
+          FQ_PRINT_ERROR("Error in file %s: line %lu: wrong header %s", A.file[r.file], (unsigned long)(4 * reads_of_file),
+                         u.wrong_header.c_str());
+          fqhost::leave(kExitFormat);
+        }
+        FQ_PRINT_ERROR("Readnames do not match across files (read #%ld)", (long)(processed + 1));
+        fqhost::leave(kExitFormat);
+      }
+    }
+    last = std::move(u);
+    have_last = true;
+  }
+  join_all();
+  // an incomplete record where the next read would have happened is a truncated file (src/fastq.c:254-257); a clean
+  // end of any input just ends the loop.  The first input, in file order, that has nothing left decides.
+  if (have_last)
+    for (int x = READ1; x <= INDEX3; ++x)
+      if (A.file[x]) {
+        if (!(last.final[x] && last.records[x] == last.n)) continue;
+        if (last.tail_lines[x] > 0) {
+          FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", A.file[x],
+                         (unsigned long)(4 * (last.seq * B + last.records[x])));
+          fqhost::leave(1);
+        }
+        break;
+      }
+  FQ_PRINT_INFO("Reads processed: %ld", (long)processed);
+  FQ_PRINT_INFO("Reads discarded: %ld", (long)discarded);
+  if (!A.out_sam)
+    for (int x = READ1; x <= READ2; ++x)
+      if (A.P->emit[x] && !A.outgz[x].close()) {
+        FQ_PRINT_ERROR("unable to close file descriptor");
+        fqhost::leave(kExitSys);
+      }
+  fflush(stdout);
+  fqhost::leave(0);
 }
 
 }  // namespace
@@ -288,7 +546,10 @@ int main(int argc, char** argv) {
   FQ_PRINT_INFO("input files %d", num_input_files);
 
   const char* dev = getenv("FQGPU_DEVICE");
-  int rc = fqg_open(dev ? atoi(dev) : 0, &g_ctx);
+  std::vector<int> devices = devices_from_env();  // FQGPU_DEVICES=0,1,..: record blocks over several GPUs
+  if (has_interleaved) devices.clear();
+  const bool multi = devices.size() > 1;
+  int rc = fqg_open(multi ? devices[0] : (dev ? atoi(dev) : 0), &g_ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
     fqhost::leave(kExitSys);
@@ -300,7 +561,7 @@ int main(int argc, char** argv) {
     if (file[x]) {
       P.present[x] = 1;
       src[x].path = file[x];
-      src[x].in = new Input(g_ctx, file[x], piece_bytes());
+      if (!multi) src[x].in = new Input(g_ctx, file[x], piece_bytes());
     }
   if (has_interleaved && (!file[P.interleaved[0]] || !file[P.interleaved[1]])) {
     FQ_PRINT_ERROR("--interleaved refers to an input that was not given");
@@ -330,6 +591,10 @@ int main(int argc, char** argv) {
     printf("\n");
   }
 
+  if (multi) {
+    BlockRun A{file, &P, outgz, out_sam, num_input_files};
+    run_blocks(A, devices);
+  }
   unsigned long processed = 0, discarded = 0;
   bool first_batch = true;
   std::vector<char> hostbuf;

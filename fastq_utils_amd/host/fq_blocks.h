@@ -1,0 +1,336 @@
+// fq_blocks.h - one (gz) FASTQ input cut into BLOCKS OF EXACTLY B RECORDS (the last block: what is left), without
+// looking at a GPU.  For programs that walk several inputs in lock step (fastq_pre_barcodes, reference
+// src/fastq_pre_barcodes.c:594-727: iteration k uses record k of every input): when every input is cut at the same
+// record numbers, block j of all inputs is a unit of work with no order among the units, and whichever device is free
+// takes the next one ("shards naturally" by record block).
+//
+// A record is four lines, so the cut behind record R is the byte behind the 4R-th newline.  The reader threads count
+// the newlines of what they read while the bytes are in their cache (as host/fq_multi.h does); the cut is then
+// searched only inside the one part whose count crosses 4R.  Bytes read beyond a cut are carried into the next block.
+#pragma once
+#include <deque>
+
+#include "fq_input.h"
+
+namespace fqhost {
+
+struct Block {
+  char* data = nullptr;  // pinned
+  size_t size = 0;
+  uint64_t first_record = 0;  // == seq * B
+  uint64_t lines = 0;         // newlines among the bytes (4 * B in every block but the last)
+  bool final = false;
+  int slot = -1;
+  uint64_t seq = 0;
+};
+
+class RecordBlocks {
+ public:
+  static constexpr size_t kPeek = 1u << 20;
+
+  RecordBlocks(fqg_ctx* ctx, const char* path, int n_slots) : ctx_(ctx), path_(path), slots_((size_t)n_slots) {
+    if (path_ == "-") gz_ = gzdopen(fileno(stdin), "rb");
+    else {
+      const int fd = open(path, O_RDONLY);
+      struct stat sb;
+      if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = pread(fd, magic, 2, 0);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+          plain_fd_ = fd;
+          plain_size_ = (uint64_t)sb.st_size;
+        }
+      }
+      if (plain_fd_ < 0) {
+        if (fd >= 0) close(fd);
+        gz_ = gzopen(path, "r");
+      }
+    }
+    if (!gz_ && plain_fd_ < 0) {
+      FQ_PRINT_ERROR("Unable to open %s", path);
+      leave(kExitParams);
+    }
+    if (gz_) gzbuffer(gz_, 1 << 20);
+    // the first bytes, read here: the caller probes the first record in them and sizes the blocks from their lines
+    carry_.resize(kPeek);
+    uint64_t nl = 0;
+    std::vector<Seg> segs;
+    const size_t got = read_some(carry_.data(), kPeek, &at_end_, &nl, 0, &segs);
+    if (failed_) {
+      FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
+      leave(kExitSys);
+    }
+    carry_.resize(got);
+    carry_lines_ = nl;
+  }
+  ~RecordBlocks() {
+    abort();
+    if (producer_.joinable()) producer_.join();
+    if (gz_) gzclose(gz_);
+    if (plain_fd_ >= 0) close(plain_fd_);
+    if (keep_slots_until_exit()) return;
+    for (auto& s : slots_)
+      if (s.buf) fqg_host_free(ctx_, s.buf);
+  }
+  RecordBlocks(const RecordBlocks&) = delete;
+  RecordBlocks& operator=(const RecordBlocks&) = delete;
+
+  const char* peek() const { return carry_.data(); }
+  size_t peek_size() const { return carry_.size(); }
+  uint64_t peek_lines() const { return carry_lines_; }
+  const std::string& path() const { return path_; }
+
+  // blocks of `records` records from now on (call once, before the first next())
+  void start(uint64_t records) {
+    per_block_ = std::max<uint64_t>(records, 1);
+    // (bytes per line so far; a file without a newline in its first bytes is one long line)
+    bytes_per_line_ = carry_lines_ ? (double)carry_.size() / (double)carry_lines_ : (double)std::max<size_t>(carry_.size(), 64);
+    producer_ = std::thread([this] { produce(); });
+  }
+  // next block in file order; false when the input is used up.  Thread-safe.
+  bool next(Block* out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !ready_.empty() || done_ || failed_ || quit_; });
+    if (quit_) return false;
+    if (failed_) {
+      FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
+      leave(kExitSys);
+    }
+    if (ready_.empty()) return false;
+    *out = ready_.front();
+    ready_.pop_front();
+    return true;
+  }
+  void release(const Block& b) {
+    std::lock_guard<std::mutex> lk(mu_);
+    slots_[(size_t)b.slot].busy = false;
+    cv_.notify_all();
+  }
+  // stop handing out blocks (error paths: consumers stop with blocks held)
+  void abort() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+  }
+
+ private:
+  struct Slot {
+    char* buf = nullptr;
+    size_t cap = 0;
+    bool busy = false;
+  };
+  struct Seg {  // a run of the block's bytes whose newline count is known
+    size_t begin, end;
+    uint64_t lines;
+  };
+
+  void fail(const char* msg) {
+    std::lock_guard<std::mutex> lk(mu_);
+    fail_msg_ = msg;
+    failed_ = true;
+    cv_.notify_all();
+  }
+  static uint64_t count_lines(const char* a, const char* b) {
+    uint64_t c = 0;
+    for (const char* p = a; (p = (const char*)memchr(p, '\n', (size_t)(b - p))) != nullptr; ++p) ++c;
+    return c;
+  }
+  // up to `want` bytes to dst (they will sit at offset `at` of their block); their newline counts part by part
+  size_t read_some(char* dst, size_t want, bool* at_end, uint64_t* newlines, size_t at, std::vector<Seg>* segs) {
+    size_t len = 0;
+    if (plain_fd_ >= 0) {
+      const uint64_t left = plain_size_ - plain_off_;
+      len = (size_t)std::min<uint64_t>(want, left);
+      const unsigned T = (unsigned)std::min<uint64_t>(host_read_threads(), std::max<uint64_t>(1, len >> 22));
+      std::vector<uint64_t> cnt(T, 0);
+      std::atomic<bool> bad{false};
+      auto bounds = [&](unsigned t, size_t* a, size_t* b) {
+        *a = len * t / T;
+        *b = t + 1 == T ? len : len * (t + 1) / T;
+      };
+      auto part = [&](unsigned t) {
+        size_t a, b;
+        bounds(t, &a, &b);
+        size_t done = a;
+        while (done < b) {
+          const ssize_t got = pread(plain_fd_, dst + done, b - done, (off_t)(plain_off_ + done));
+          if (got <= 0) {
+            bad = true;
+            return;
+          }
+          done += (size_t)got;
+        }
+        cnt[t] = count_lines(dst + a, dst + b);
+      };
+      if (T <= 1) part(0);
+      else {
+        if (!pool_) pool_.reset(new ReaderPool(host_read_threads()));
+        pool_->run(T, part);
+      }
+      if (bad) {
+        fail("read error");
+        return 0;
+      }
+      for (unsigned t = 0; t < T; ++t) {
+        size_t a, b;
+        bounds(t, &a, &b);
+        if (b > a) segs->push_back(Seg{at + a, at + b, cnt[t]});
+        *newlines += cnt[t];
+      }
+      plain_off_ += len;
+      if (plain_off_ >= plain_size_) *at_end = true;
+      return len;
+    }
+    while (len < want) {
+      const int got = gzread(gz_, dst + len, (unsigned)std::min<size_t>(want - len, 1u << 30));
+      if (got < 0) {
+        int en = 0;
+        fail(gzerror(gz_, &en));
+        return len;
+      }
+      if (got == 0) {
+        *at_end = true;
+        break;
+      }
+      len += (size_t)got;
+    }
+    if (!*at_end) {
+      const int c = gzgetc(gz_);
+      if (c < 0) *at_end = true;
+      else gzungetc(c, gz_);
+    }
+    const uint64_t c = count_lines(dst, dst + len);
+    if (len) segs->push_back(Seg{at, at + len, c});
+    *newlines += c;
+    return len;
+  }
+  int free_slot() {
+    std::unique_lock<std::mutex> lk(mu_);
+    int s = -1;
+    cv_.wait(lk, [&] {
+      if (quit_) return true;
+      for (size_t i = 0; i < slots_.size(); ++i)
+        if (!slots_[i].busy) {
+          s = (int)i;
+          return true;
+        }
+      return false;
+    });
+    if (s >= 0) slots_[(size_t)s].busy = true;
+    return s;
+  }
+  bool reserve(Slot& s, size_t keep, size_t want) {
+    if (want <= s.cap) return true;
+    const size_t cap = std::max(want, s.cap + s.cap / 2);
+    char* nb = static_cast<char*>(fqg_host_alloc(ctx_, cap + 1));
+    if (!nb) {
+      fail("unable to allocate pinned memory");
+      return false;
+    }
+    if (keep) memcpy(nb, s.buf, keep);
+    if (s.buf) fqg_host_free(ctx_, s.buf);
+    s.buf = nb;
+    s.cap = cap;
+    return true;
+  }
+
+  void produce() {
+    const uint64_t need = 4 * per_block_;
+    uint64_t seq = 0;
+    for (;;) {
+      if (at_end_ && carry_.empty() && seq > 0) break;
+      const int si = free_slot();
+      if (si < 0) return;
+      Slot& s = slots_[(size_t)si];
+      std::vector<Seg> segs;
+      size_t len = carry_.size();
+      uint64_t lines = carry_lines_;
+      if (!reserve(s, 0, std::max<size_t>((size_t)((double)need * bytes_per_line_ * 1.06) + (1u << 20), len))) return;
+      if (len) {
+        memcpy(s.buf, carry_.data(), len);
+        segs.push_back(Seg{0, len, lines});
+      }
+      carry_.clear();
+      carry_lines_ = 0;
+      while (lines < need && !at_end_) {
+        // what the missing lines should take, a little more than that: the surplus is carried, a shortfall reads again
+        const size_t est = (size_t)((double)(need - lines) * bytes_per_line_ * 1.03) + (64u << 10);
+        if (!reserve(s, len, len + est)) return;
+        uint64_t nl = 0;
+        const size_t got = read_some(s.buf + len, est, &at_end_, &nl, len, &segs);
+        if (failed_) return;
+        len += got;
+        lines += nl;
+        total_bytes_ += got;
+        total_lines_ += nl;
+        if (total_lines_ > 1000) bytes_per_line_ = (double)total_bytes_ / (double)total_lines_;
+        {
+          std::lock_guard<std::mutex> lk(mu_);
+          if (quit_) return;
+        }
+      }
+      size_t cut = len;
+      if (lines >= need) {
+        // the byte behind the need-th newline
+        uint64_t acc = 0;
+        for (const Seg& g : segs) {
+          if (acc + g.lines < need) {
+            acc += g.lines;
+            continue;
+          }
+          const char* p = s.buf + g.begin;
+          const char* e = s.buf + g.end;
+          for (uint64_t k = acc; k < need; ++k) p = (const char*)memchr(p, '\n', (size_t)(e - p)) + 1;
+          cut = (size_t)(p - s.buf);
+          break;
+        }
+        if (cut < len) {
+          carry_.assign(s.buf + cut, s.buf + len);
+          carry_lines_ = lines - need;
+        }
+        lines = need;
+      }
+      Block b;
+      b.data = s.buf;
+      b.size = cut;
+      b.first_record = seq * per_block_;
+      b.lines = lines;
+      b.final = at_end_ && carry_.empty();
+      b.slot = si;
+      b.seq = seq++;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        ready_.push_back(b);
+        cv_.notify_all();
+      }
+      if (b.final) break;
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    done_ = true;
+    cv_.notify_all();
+  }
+
+  fqg_ctx* ctx_;
+  std::string path_;
+  gzFile gz_ = nullptr;
+  int plain_fd_ = -1;
+  uint64_t plain_size_ = 0, plain_off_ = 0;
+  std::vector<Slot> slots_;
+  std::deque<Block> ready_;
+  std::vector<char> carry_;  // read, not handed out yet
+  uint64_t carry_lines_ = 0;
+  bool at_end_ = false;
+  uint64_t per_block_ = 1;
+  double bytes_per_line_ = 64;
+  uint64_t total_bytes_ = 0, total_lines_ = 0;
+  std::thread producer_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::unique_ptr<ReaderPool> pool_;
+  bool quit_ = false, failed_ = false, done_ = false;
+  std::string fail_msg_;
+};
+
+}  // namespace fqhost

@@ -124,3 +124,34 @@ def test_record_aligned_piece_cutter_runs_clean(tmpdir, san):
                                    env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"), capture_output=True, timeout=300)
                 out = p.stdout.decode().split()
                 assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, piece, consumers, p.stdout, p.stderr.decode()[-1500:])
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_record_block_cutter_runs_clean(tmpdir, san):
+    """fq_blocks.h (fastq_pre_barcodes with FQGPU_DEVICES): blocks of exactly B records cut on the host by counting lines
+    must tile the file and start at record k*B; several consumers, plain / gz / truncated / empty, blocks smaller and
+    larger than the first bytes the cutter peeks at, files that end exactly at a block boundary."""
+    flags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g", "-O1"]
+    exe = str(tmpdir / ("blocks_" + san.split(",")[0]))
+    subprocess.run(["g++", "-std=c++17", "-pthread"] + flags + ["-o", exe, os.path.join(CXX, "blocks_check.cpp"), "-lz"], check=True)
+    rng = np.random.default_rng(6)
+    recs = []
+    for i in range(6000):
+        n = int(rng.integers(1, 300))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).astype(np.uint8))
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * n + b"\n")
+    data = b"".join(recs)
+    files = {"full.fq": data, "full.fq.gz": gzip.compress(data, 1), "cut.fq": data[:-57], "nonl.fq": data[:-1],
+             "empty.fq": b"", "one.fq": recs[0], "blank.fq": b"\n" * 1001, "exact.fq": b"".join(recs[:3000]),
+             "small.fq": b"".join(recs[:50])}
+    for name, content in files.items():
+        (tmpdir / name).write_bytes(content)
+        size = len(data if name.endswith(".gz") else content)
+        for per_block in ("1", "7", "1000", "3000", "100000"):
+            if per_block in ("1", "7") and size > 100000:
+                continue
+            for consumers in ("1", "3"):
+                p = subprocess.run([exe, str(tmpdir / name), per_block, consumers],
+                                   env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"), capture_output=True, timeout=300)
+                out = p.stdout.decode().split()
+                assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, per_block, consumers, p.stdout, p.stderr.decode()[-1500:])
