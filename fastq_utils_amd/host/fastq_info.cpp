@@ -131,7 +131,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
   bool exhausted = false;  // (under fetch_mu)
   uint64_t n_pieces = ~0ull;  // known once the final piece was handed out (under mu)
   Probe pr;
-  bool rerun_serial = false;
+  bool rerun_serial = false, probe_printed = false;
   {
     AlignedPieces src(g_ctx, path, piece, (int)(2 * devs.size() + 2));
     auto work = [&](size_t di) {
@@ -186,7 +186,10 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
         fqhost::leave(kExitSys);
       }
       if (info_pending && base == 0 && r.n_records > 0) {
-        if (!(r.code && r.record == 0 && is_early_code(r.code))) print_probe(pr);
+        if (!(r.code && r.record == 0 && is_early_code(r.code))) {
+          print_probe(pr);
+          probe_printed = true;
+        }
         info_pending = false;
       }
       if (r.code) {
@@ -222,7 +225,9 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
       fqhost::leave(kExitSys);
     }
     LIB(fqg_acc_reset(S.acc1));
+    probe_line_is_out() = probe_printed;
     run_single_noindex(path, S);
+    probe_line_is_out() = false;
     return;
   }
   {
@@ -253,7 +258,9 @@ struct MultiDev {
   fqg_acc* acc = nullptr;
 };
 struct MultiPass {
-  bool stopped = false;       // a NUL at a record start ends the file there: the caller runs the one-device loop instead
+  bool stopped = false;       // a NUL at a record start ends the file there: the caller passes again with that limit
+  uint64_t stop_offset = 0;   // ... bytes of the (inflated) file in front of that record
+  bool probe_printed = false;
   uint64_t n_records = 0;     // records of the pieces looked at
   bool have = false;          // a finding of the validation side (stages 0, 1, 3) - the first in file order
   uint64_t rec = 0;
@@ -266,7 +273,8 @@ struct MultiPass {
 
 // one pass of all devices over a file.  validate_as: the state the records are validated under (null: the file's
 // own, decided from its first record); acc_of_first: the accumulator device 0 adds to
-MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint32_t flags, const fqg_file_state* validate_as) {
+MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint32_t flags, const fqg_file_state* validate_as,
+                     uint64_t limit = ~0ull, bool print_info = true) {
   MultiPass out;
   out.shards.resize(D.size());
   for (size_t i = 0; i < D.size(); ++i) out.shards[i].ctx = D[i].ctx;
@@ -283,7 +291,7 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
   std::atomic<bool> stop{false};
   bool exhausted = false;        // (under fetch_mu)
   uint64_t n_pieces = ~0ull;     // known once the final piece was handed out (under mu)
-  AlignedPieces src(g_ctx, path, piece, (int)(2 * D.size() + 2));
+  AlignedPieces src(g_ctx, path, piece, (int)(2 * D.size() + 2), limit);
   auto work = [&](size_t di) {
     for (;;) {
       Done d;
@@ -348,12 +356,16 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
     else if (r.code == FQG_E_HDR1_AT) stage = 1;
     else if (r.code) stage = 3;
     if (info_pending && base == 0 && r.n_records > 0) {
-      if (!(stage >= 0 && stage <= 1 && r.record == 0)) print_probe(out.pr);
+      if (!(stage >= 0 && stage <= 1 && r.record == 0)) {
+        if (print_info) print_probe(out.pr);
+        out.probe_printed = true;
+      }
       info_pending = false;
     }
-    if (r.stopped) {
+    if (r.stopped && stage < 0) {
       join_all();
       out.stopped = true;
+      out.stop_offset = d.p.stream_offset + r.consumed;
       return out;
     }
     if (stage >= 0) {
@@ -412,14 +424,20 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
   }
   MultiPass pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE, nullptr);
   if (pass.stopped) {
+    // a NUL byte at a record start ends the file there (src/fastq.c:250): what later pieces added to the accumulators
+    // and to the shards does not belong to it - once more, with the file ending where the reference stops reading
     release_shards(pass.shards);
-    for (size_t i = 1; i < M.D.size(); ++i) {
-      fqg_acc_destroy(M.D[i].acc);
-      fqg_close(M.D[i].ctx);
+    if (strcmp(path, "-") == 0) {
+      FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES on a stream: use one device", path);
+      fqhost::leave(kExitSys);
     }
-    M.D.clear();
-    LIB(fqg_acc_reset(S.acc1));
-    return false;
+    for (auto& d : M.D)
+      if (fqg_acc_reset(d.acc) != 0) die_lib("fqg_acc_reset", -1);
+    pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE, nullptr, pass.stop_offset, !pass.probe_printed);
+    if (pass.stopped) {
+      FQ_PRINT_ERROR("Error in file %s: the file changed while it was read", path);
+      fqhost::leave(kExitSys);
+    }
   }
   M.f1.shards = std::move(pass.shards);
   M.f1.st = pass.pr.st;
@@ -470,10 +488,30 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
 void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, IndexedFile& F, MultiIndexed& M) {
   const unsigned long cline1 = 4 * F.n_records;  // fd1->cline stays where indexing left it
   // file-2 records are validated against file 1's state and counters (src/fastq_info.c:345); names under file 2's own
+  // (the accumulators as file 1 left them: a second file that ends at a NUL byte is passed over twice)
+  std::vector<std::vector<char>> before(M.D.size());
+  for (size_t i = 0; i < M.D.size(); ++i) {
+    size_t used = 0;
+    if (fqg_acc_export(M.D[i].acc, nullptr, 0, &used) != 0) die_lib("fqg_acc_export", -1);
+    before[i].resize(used);
+    if (fqg_acc_export(M.D[i].acc, before[i].data(), before[i].size(), &used) != 0) die_lib("fqg_acc_export", -1);
+  }
   MultiPass pass = multi_pass(path2, M.D, 1, 0, &F.st);
   if (pass.stopped) {
-    FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES: use one device", path2);
-    fqhost::leave(kExitSys);
+    release_shards(pass.shards);
+    if (strcmp(path2, "-") == 0) {
+      FQ_PRINT_ERROR("Error in file %s: a NUL byte at a record start with FQGPU_DEVICES on a stream: use one device", path2);
+      fqhost::leave(kExitSys);
+    }
+    for (size_t i = 0; i < M.D.size(); ++i) {
+      if (fqg_acc_reset(M.D[i].acc) != 0) die_lib("fqg_acc_reset", -1);
+      if (fqg_acc_merge(M.D[i].acc, before[i].data(), before[i].size()) != 0) die_lib("fqg_acc_merge", -1);
+    }
+    pass = multi_pass(path2, M.D, 1, 0, &F.st, pass.stop_offset, !pass.probe_printed);
+    if (pass.stopped) {
+      FQ_PRINT_ERROR("Error in file %s: the file changed while it was read", path2);
+      fqhost::leave(kExitSys);
+    }
   }
   fqhost::NamesOfFile f2;
   f2.shards = std::move(pass.shards);

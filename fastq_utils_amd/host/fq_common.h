@@ -129,7 +129,17 @@ void probe_piece(Probe& pr, const char* buf, size_t n, int is_pe) {
   }
 }
 
+// set by a several-device pass that printed the line and then hands the file to a one-device loop (a NUL byte at a
+// record start): that loop's first print_probe is the same line again
+inline bool& probe_line_is_out() {
+  static bool v = false;
+  return v;
+}
 void print_probe(const Probe& pr) {
+  if (probe_line_is_out()) {
+    probe_line_is_out() = false;
+    return;
+  }
   fputs(pr.format_line.c_str(), stderr);
   if (pr.st.space == FQG_SPACE_COLOUR) fputs("Color space\n", stderr);
 }

@@ -20,6 +20,7 @@ struct Piece {
   char* data = nullptr;        // record-aligned image (points into a slot)
   size_t size = 0;
   uint64_t first_record = 0;   // records of the file before it
+  uint64_t stream_offset = 0;  // bytes of the (inflated) file before it
   bool final = false;
   int slot = -1;
   uint64_t seq = 0;            // position in file order
@@ -27,8 +28,9 @@ struct Piece {
 
 class AlignedPieces {
  public:
-  AlignedPieces(fqg_ctx* ctx, const char* path, size_t piece_bytes, int n_slots)
-      : ctx_(ctx), cap_(piece_bytes), slots_((size_t)n_slots) {
+  // limit: the file is taken to end after this many (inflated) bytes
+  AlignedPieces(fqg_ctx* ctx, const char* path, size_t piece_bytes, int n_slots, uint64_t limit = ~0ull)
+      : ctx_(ctx), cap_(piece_bytes), slots_((size_t)n_slots), limit_(limit) {
     path_ = path;
     if (path_ == "-") gz_ = gzdopen(fileno(stdin), "rb");
     else {
@@ -39,7 +41,7 @@ class AlignedPieces {
         const ssize_t got = pread(fd, magic, 2, 0);
         if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
           plain_fd_ = fd;
-          plain_size_ = (uint64_t)sb.st_size;
+          plain_size_ = std::min<uint64_t>((uint64_t)sb.st_size, limit_);
         }
       }
       if (plain_fd_ < 0) {
@@ -141,6 +143,7 @@ class AlignedPieces {
       if (plain_off_ >= plain_size_) *at_end = true;
       return len;
     }
+    want = (size_t)std::min<uint64_t>(want, limit_ - gz_total_);
     while (len < want) {
       const int got = gzread(gz_, dst + len, (unsigned)std::min<size_t>(want - len, 1u << 30));
       if (got < 0) {
@@ -154,6 +157,8 @@ class AlignedPieces {
       }
       len += (size_t)got;
     }
+    gz_total_ += len;
+    if (gz_total_ >= limit_) *at_end = true;
     if (!*at_end) {
       const int c = gzgetc(gz_);
       if (c < 0) *at_end = true;
@@ -193,6 +198,7 @@ class AlignedPieces {
     bool mid_line = false;      // the previous raw byte was not a newline
     bool at_end = false;
     uint64_t seq = 0;
+    uint64_t raw_before = 0;    // bytes of the file before the raw bytes being read
     while (!at_end) {
       const int si = free_slot();
       if (si < 0) return;
@@ -237,6 +243,7 @@ class AlignedPieces {
         held.data = s.buf + skip;
         held.size = len - skip;
         held.first_record = (lines_before + skip_lines) / 4;
+        held.stream_offset = raw_before + skip;
         held.slot = si;
         held.seq = seq++;
         held_tail = 0;
@@ -247,6 +254,7 @@ class AlignedPieces {
         s.busy = false;
       }
       lines_before += nl;
+      raw_before += len;
       if (len) mid_line = s.buf[len - 1] != '\n';
     }
     if (have_held) {
@@ -281,6 +289,7 @@ class AlignedPieces {
   uint64_t plain_size_ = 0, plain_off_ = 0;
   size_t cap_;
   std::vector<Slot> slots_;
+  uint64_t limit_ = ~0ull, gz_total_ = 0;
   std::deque<Piece> ready_;
   std::thread producer_;
   std::mutex mu_;

@@ -247,3 +247,28 @@ def test_several_devices_mutated_files_in_index_mode(kind):
                 f.write(data)
         compare_with_oracle(tmp, ["f.fastq"], files, env)
         compare_with_oracle(tmp, ["g.fastq", "f.fastq"], files, env)
+
+
+@pytest.mark.parametrize("n_reads", [300, 30000], ids=["one_piece", "many_pieces"])
+def test_several_devices_a_nul_byte_at_a_record_start_ends_the_file(n_reads):
+    """the reference reads C strings: a record whose first byte is NUL ends the file there (src/fastq.c:250).  Over several
+    devices the later pieces have been looked at by then - the file is passed over again up to that byte; what is printed
+    once by the serial loop is printed once (found by tools/fuzz_campaign.py, seeds 1000 and 1098)"""
+    a = fuzz.make_fastq(np.random.default_rng(3), n_reads, 20, 120, "int", mate=1)
+    b = fuzz.make_fastq(np.random.default_rng(3), n_reads, 20, 120, "int", mate=2)
+    cut = n_reads * 2 // 3
+
+    def nul_at(img, rec):
+        lines = img.split(b"\n")
+        lines[4 * rec] = b"\0" + lines[4 * rec][1:]
+        return b"\n".join(lines)
+
+    files = {"a.fastq": a, "b.fastq": b, "an.fastq": nul_at(a, cut), "bn.fastq": nul_at(b, cut), "a0.fastq": nul_at(a, 0)}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, data in files.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(data)
+        for env in (dict(MULTI, FQGPU_CHUNK_MB="1"), dict(MULTI, FQGPU_CHUNK_MB="1", FQGPU_STREAM_MIN="256"), {"FQGPU_CHUNK_MB": "1"}):
+            for args in (["-r", "an.fastq"], ["an.fastq"], ["an.fastq", "pe"], ["a.fastq", "bn.fastq"], ["an.fastq", "b.fastq"],
+                         ["an.fastq", "bn.fastq"], ["bn.fastq", "a.fastq"], ["-r", "a0.fastq"], ["a0.fastq"], ["a.fastq", "a0.fastq"]):
+                compare_with_oracle(tmp, args, files, env)
