@@ -176,16 +176,25 @@ __device__ __forceinline__ uint32_t dec_digits(unsigned long v) {
 }
 
 struct BcTags {
-  uint32_t n[3];  // umi, cell, sample lengths (0: absent)
+  uint32_t n[3];   // umi, cell, sample lengths (0: absent)
+  uint32_t qn[3];  // quality characters that go with them: the reference copies them with strncpy from the quality
+                   // STRING (src/fastq_pre_barcodes.c:250-252), which a malformed record may end before offset + size
   const uint8_t* s[3];
   const uint8_t* q[3];
 };
+// characters of a quality line (with its '\n', as gzgets leaves it) inside [off, off + size)
+__device__ __forceinline__ uint32_t bc_qual_chars(const BcLine& q, long off, long size) {
+  const long Lq = (long)(q.len + q.nl);
+  const long n = Lq - off;
+  return (uint32_t)(n < 0 ? 0 : (n < size ? n : size));
+}
 
 // get_barcode for one tag (src/fastq_pre_barcodes.c:218-259).  0 ok, 1 short, 2 low quality
 template <bool WIDE>
 __device__ __forceinline__ int bc_get(const BcLine (&ln)[4], long off, long size, int phred, int min_qual, uint32_t* n,
-                                      const uint8_t** s, const uint8_t** q) {
+                                      uint32_t* qn, const uint8_t** s, const uint8_t** q) {
   *n = 0;
+  *qn = 0;
   if (off == -1 || size == 0) return 0;
   const unsigned long rl1 = (unsigned long)(ln[1].len + ln[1].nl) - 1ul;
   if ((unsigned long)off > rl1 || (unsigned long)(off + size) > rl1) return 1;
@@ -208,6 +217,7 @@ __device__ __forceinline__ int bc_get(const BcLine (&ln)[4], long off, long size
     }
   }
   *n = (uint32_t)size;
+  *qn = bc_qual_chars(ln[3], off, size);
   *s = ln[1].p + off;
   *q = ln[3].p + off;
   return 0;
@@ -219,6 +229,7 @@ __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLi
                                                    uint32_t* finding) {
   *finding = 0;
   tags->n[0] = tags->n[1] = tags->n[2] = 0;
+  tags->qn[0] = tags->qn[1] = tags->qn[2] = 0;
   if (P.n_inputs > 1) {
     // names: every file against READ1 (src/fastq_pre_barcodes.c:606-635); '@' first (src/fastq.c:448)
 #pragma unroll
@@ -247,11 +258,11 @@ __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLi
   for (int x = 1; x < kBcFiles; ++x)
     if (bc_has<MASK>(P, x)) {
       int rc = 0;
-      if (P.umi_read == x) rc = bc_get<WIDE>(L[x], P.umi_off, P.umi_size, P.phred, P.min_qual, &tags->n[0], &tags->s[0], &tags->q[0]);
+      if (P.umi_read == x) rc = bc_get<WIDE>(L[x], P.umi_off, P.umi_size, P.phred, P.min_qual, &tags->n[0], &tags->qn[0], &tags->s[0], &tags->q[0]);
       if (!rc && P.sample_read == x)
-        rc = bc_get<WIDE>(L[x], P.sample_off, P.sample_size, P.phred, P.min_qual, &tags->n[2], &tags->s[2], &tags->q[2]);
+        rc = bc_get<WIDE>(L[x], P.sample_off, P.sample_size, P.phred, P.min_qual, &tags->n[2], &tags->qn[2], &tags->s[2], &tags->q[2]);
       if (!rc && P.cell_read == x)
-        rc = bc_get<WIDE>(L[x], P.cell_off, P.cell_size, P.phred, P.min_qual, &tags->n[1], &tags->s[1], &tags->q[1]);
+        rc = bc_get<WIDE>(L[x], P.cell_off, P.cell_size, P.phred, P.min_qual, &tags->n[1], &tags->qn[1], &tags->s[1], &tags->q[1]);
       if (rc) return rc == 1 ? kBcDiscardShort : kBcDiscardQual;
     }
   return kBcKeep;
@@ -262,6 +273,7 @@ __device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLi
 template <int MASK = 0>
 __device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine (&lines)[kBcFiles][4], BcTags* tags) {
   tags->n[0] = tags->n[1] = tags->n[2] = 0;
+  tags->qn[0] = tags->qn[1] = tags->qn[2] = 0;
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x)
     if (bc_has<MASK>(P, x) && (P.umi_read == x || P.sample_read == x || P.cell_read == x)) {
@@ -269,6 +281,7 @@ __device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine 
       auto take = [&](int slot, long off, long size) {
         if (off == -1 || size == 0) return;
         tags->n[slot] = (uint32_t)size;
+        tags->qn[slot] = bc_qual_chars(ln[3], off, size);
         tags->s[slot] = ln[1].p + off;
         tags->q[slot] = ln[3].p + off;
       };
@@ -326,9 +339,9 @@ __device__ __forceinline__ uint32_t bc_sam_line_len(unsigned long number, unsign
   uint32_t n = dec_digits(number) + 1 + dec_digits(flag);
   n += 15;  // "\t*\t0\t255\t*\t*\t0\t"
   n += dec_digits(g.shown) + 1 + g.seq_n + 1 + g.qual_n + 6 + g.name_n + 6 + g.qual_n;
-  if (t.n[0]) n += 12 + 2 * t.n[0];
-  if (t.n[1]) n += 12 + 2 * t.n[1];
-  if (t.n[2]) n += 12 + 2 * t.n[2];
+  if (t.n[0]) n += 12 + t.n[0] + t.qn[0];
+  if (t.n[1]) n += 12 + t.n[1] + t.qn[1];
+  if (t.n[2]) n += 12 + t.n[2] + t.qn[2];
   return n + 1;
 }
 __device__ __forceinline__ unsigned bc_sam_flag(bool se, bool mate1) {
@@ -917,20 +930,20 @@ __device__ __forceinline__ void bc_emit_sam_line(const BcParams& P, unsigned lon
     if (P.tenx) BC_LIT(w, "\tUB:Z:"); else BC_LIT(w, "\tRX:Z:");
     w.bytes(t.s[0], t.n[0]);
     if (P.tenx) BC_LIT(w, "\tUY:Z:"); else BC_LIT(w, "\tQX:Z:");
-    w.bytes(t.q[0], t.n[0]);
+    w.bytes(t.q[0], t.qn[0]);
   }
   if (t.n[1]) {
     w.ch(mate1 ? '\t' : ' ');  // the second mate gets a blank (src/fastq_pre_barcodes.c:705)
     BC_LIT(w, "CR:Z:");
     w.bytes(t.s[1], t.n[1]);
     BC_LIT(w, "\tCY:Z:");
-    w.bytes(t.q[1], t.n[1]);
+    w.bytes(t.q[1], t.qn[1]);
   }
   if (t.n[2]) {
     BC_LIT(w, "\tBC:Z:");
     w.bytes(t.s[2], t.n[2]);
     BC_LIT(w, "\tQT:Z:");
-    w.bytes(t.q[2], t.n[2]);
+    w.bytes(t.q[2], t.qn[2]);
   }
   w.ch('\n');
 }

@@ -694,6 +694,25 @@ void run_interleaved(const char* path, Stats& S) {
   S.num_reads1 = fs.num_rds;
 }
 
+// What fastq_read_entry (src/fastq.c:245-261) returns on the bytes BEHIND a line that started with a NUL byte.  That
+// line made the call before return 0 ("no entry"), which ends a loop - but not the file: the paired loop below reads
+// once more from each file afterwards (src/fastq_info.c:142-149), and that read starts at the next line.
+enum { kBehindNothing = 0, kBehindRecord = 1, kBehindTruncated = 2 };
+int read_behind_stop(const char* d, size_t n, size_t at) {
+  auto line = [&](size_t& p) {  // consumes a line; false when gzgets hands back an empty string (NUL first, or nothing left)
+    if (p >= n) return false;
+    const bool text = d[p] != 0;
+    const char* nl = static_cast<const char*>(memchr(d + p, '\n', n - p));
+    p = nl ? (size_t)(nl - d) + 1 : n;
+    return text;
+  };
+  size_t p = at;
+  line(p);  // the NUL line itself
+  if (!line(p)) return kBehindNothing;
+  const bool seq = line(p), hdr2 = line(p), qual = line(p);
+  return (seq && hdr2 && qual) ? kBehindRecord : kBehindTruncated;
+}
+
 // ---- -r -s, two files: validate_paired_sorted_fastq_file (src/fastq_info.c:108-152) ---------
 void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
   Input in1(g_ctx, p1, piece_bytes()), in2(g_ctx, p2, piece_bytes());
@@ -717,7 +736,7 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
   const bool t2 = r2.code == FQG_E_TRUNCATED || r2.code == FQG_E_LINE_TOO_LONG;
   const bool tail1 = r1.tail_lines > 0, tail2 = r2.tail_lines > 0;
   // per index k: read 1, validate 1, read 2, validate 2, names
-  enum { READ1 = 0, VAL1 = 1, READ2 = 2, VAL2 = 3, NAMES = 4, END1 = 5, END2 = 6 };
+  enum { READ1 = 0, VAL1 = 1, READ2 = 2, VAL2 = 3, NAMES = 4, END1 = 5, END2 = 6, STOP1 = 7, STOP2 = 8 };
   uint64_t best_k = ~0ull;
   int best_stage = 99, best_kind = -1;
   auto offer = [&](uint64_t k, int stage, int kind) {
@@ -732,9 +751,11 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
   if (t2) offer(r2.record, 2, READ2);
   else if (r2.code) offer(r2.record, 3, VAL2);
   if (cr.code == FQG_E_NAME_MISMATCH) offer(cr.record, 4, NAMES);
-  if (tail1) offer(n1, 0, READ1);
+  if (r1.stopped) offer(n1, 0, STOP1);  // a line that starts with a NUL byte: "no entry", the loop ends there
+  else if (tail1) offer(n1, 0, READ1);
   else offer(n1, 0, END1);  // clean end of file 1: the loop ends before reading file 2
-  if (tail2) offer(n2, 2, READ2);
+  if (r2.stopped) offer(n2, 2, STOP2);
+  else if (tail2) offer(n2, 2, READ2);
   else offer(n2, 2, END2);  // clean end of file 2, after record n2 of file 1 was handled
   // format lines come from inside validation (src/fastq.c:364) of each file's first record
   const bool reach1 = n1 > 0 && !(r1.code && r1.record == 0 && is_early_code(r1.code));
@@ -779,6 +800,36 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
       }
       if (tail1 && n1 == n2 + 1) fail_truncated(p1, 4 * (n2 + 1));
       break;
+    case STOP1: {
+      // the loop ended on the NUL line of file 1; the read after the loop goes on behind it
+      const int x = read_behind_stop(in1.data(), in1.size(), (size_t)r1.consumed);
+      if (x == kBehindRecord) {
+        FQ_PRINT_ERROR("Premature end of file2");
+        fqhost::leave(kExitFormat);
+      }
+      if (x == kBehindTruncated) fail_truncated(p1, 4 * n1);
+      if (n2 > n1) {  // ... and file 2 still has record n1
+        FQ_PRINT_ERROR("Premature end of file1");
+        fqhost::leave(kExitFormat);
+      }
+      if (tail2 && n2 == n1) fail_truncated(p2, 4 * n1);
+      break;
+    }
+    case STOP2: {
+      // record n2 of file 1 has been read and validated; the loop ended on the NUL line of file 2
+      if (n1 >= n2 + 2) {
+        FQ_PRINT_ERROR("Premature end of file2");
+        fqhost::leave(kExitFormat);
+      }
+      if (tail1 && n1 == n2 + 1) fail_truncated(p1, 4 * (n2 + 1));
+      const int y = read_behind_stop(in2.data(), in2.size(), (size_t)r2.consumed);
+      if (y == kBehindRecord) {
+        FQ_PRINT_ERROR("Premature end of file1");
+        fqhost::leave(kExitFormat);
+      }
+      if (y == kBehindTruncated) fail_truncated(p2, 4 * n2);
+      break;
+    }
   }
   finish_frames();
   printf("\n");

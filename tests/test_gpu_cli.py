@@ -272,3 +272,41 @@ def test_several_devices_a_nul_byte_at_a_record_start_ends_the_file(n_reads):
             for args in (["-r", "an.fastq"], ["an.fastq"], ["an.fastq", "pe"], ["a.fastq", "bn.fastq"], ["an.fastq", "b.fastq"],
                          ["an.fastq", "bn.fastq"], ["bn.fastq", "a.fastq"], ["-r", "a0.fastq"], ["a0.fastq"], ["a.fastq", "a0.fastq"]):
                 compare_with_oracle(tmp, args, files, env)
+
+
+def test_paired_sorted_mode_reads_on_behind_a_nul_line():
+    """-r -s: a line that starts with a NUL byte makes fastq_read_entry return "no entry", which ends the loop - and the two
+    reads after the loop (src/fastq_info.c:142-149) carry on BEHIND that line: a whole record there is "Premature end of
+    file2" / "file1", three lines are a truncated file, nothing is a clean end (tools/fuzz_campaign.py, seed 30415)"""
+    n = 60
+    a = fuzz.make_fastq(np.random.default_rng(8), n, 10, 60, "nosuffix", mate=1)
+    b = fuzz.make_fastq(np.random.default_rng(8), n, 10, 60, "nosuffix", mate=2)
+
+    def lines_of(img):
+        return img.split(b"\n")[:-1]
+
+    def with_nul(img, rec, keep_after):
+        """record `rec` starts with a NUL byte; only keep_after lines of the file follow that line (None: all)"""
+        ls = lines_of(img)
+        ls[4 * rec] = b"\0" + ls[4 * rec]
+        if keep_after is not None:
+            ls = ls[:4 * rec + 1 + keep_after]
+        return b"\n".join(ls) + b"\n"
+
+    shapes = {"a_mid": (with_nul(a, 20, None), b), "a_mid_b_short": (with_nul(a, 20, None), b"\n".join(lines_of(b)[:4 * 20]) + b"\n"),
+              "a_last_3_lines": (with_nul(a, 59, 3), b), "a_then_4_lines": (with_nul(a, 30, 4), b), "a_then_2_lines": (with_nul(a, 30, 2), b),
+              "a_then_nothing": (with_nul(a, 30, 0), b), "a_then_nothing_b_same": (with_nul(a, 30, 0), b"\n".join(lines_of(b)[:4 * 30]) + b"\n"),
+              "a_first": (with_nul(a, 0, None), b), "a_two_nul_lines": (with_nul(with_nul(a, 31, None), 30, 1), b),
+              "b_mid": (a, with_nul(b, 20, None)), "b_mid_a_short": (b"\n".join(lines_of(a)[:4 * 21]) + b"\n", with_nul(b, 20, None)),
+              "b_then_nothing": (a, with_nul(b, 20, 0)), "b_then_nothing_a_same": (b"\n".join(lines_of(a)[:4 * 21]) + b"\n", with_nul(b, 20, 0)),
+              "b_then_3_lines": (b"\n".join(lines_of(a)[:4 * 21]) + b"\n", with_nul(b, 20, 3)), "b_first": (a, with_nul(b, 0, None)),
+              "both_same_record": (with_nul(a, 25, None), with_nul(b, 25, None)), "a_before_b": (with_nul(a, 24, 0), with_nul(b, 25, None))}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, (fa, fb) in shapes.items():
+            files = {"a.fastq": fa, "b.fastq": fb}
+            for name, data in files.items():
+                with open(os.path.join(tmp, name), "wb") as f:
+                    f.write(data)
+            for env in ({}, {"FQGPU_STREAM_MIN": "256"}):
+                for args in (["-r", "-s", "a.fastq", "b.fastq"], ["-r", "-s", "b.fastq", "a.fastq"], ["-s", "a.fastq", "b.fastq"]):
+                    compare_with_oracle(tmp, args, files, env)

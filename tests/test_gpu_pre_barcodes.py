@@ -305,3 +305,35 @@ def test_several_devices_file_sets(name):
         assert res[0][0] == res[1][0] == 0, res[1][2]
         for i in range(1, 5):
             assert res[0][i] == res[1][i], (name, i)
+
+
+@pytest.mark.parametrize("extra", [["--sam", "--outfile1", "-"], ["--sam", "--10x", "--outfile1", "-"], ["--outfile1", "o.fastq.gz"]],
+                         ids=["sam", "sam10x", "fastq"])
+@pytest.mark.parametrize("env", [None, {"FQGPU_BC_LDS": "4096"}, {"FQGPU_DEVICES": "0,0", "FQGPU_BLOCK_RECORDS": "7"}],
+                         ids=["default", "tiny_tiles", "devices"])
+def test_quality_line_shorter_than_the_barcode_range(extra, env):
+    """a record of the barcode file whose quality line ends before offset + size (a damaged file: '+' twice, a quality
+    line cut short): the reference copies the quality characters with strncpy from a buffer that still holds the bytes of
+    EARLIER records behind the string's end; here and in the oracle the string ends where the line does
+    (tools/fuzz_campaign_programs.py, seed 20226: the kernel used to print whatever LDS held there)"""
+    rng = np.random.default_rng(20226)
+    r1, r2 = make_10x(rng, 300, 0.0, 0.0)
+    l1 = r1.split(b"\n")
+    l1[4 * 40 + 3] = b"+"                    # the quality line of record 40 is one character
+    l1[4 * 90 + 3] = l1[4 * 90 + 3][:18]     # ends inside the UMI range
+    l1[4 * 120 + 3] = l1[4 * 120 + 3][:16]   # ends where the UMI range begins
+    l1[4 * 150 + 3] = b""                    # empty
+    r1 = b"\n".join(l1)
+    files = {"r1.fastq": r1, "r2.fastq": r2}
+    args = V2[:V2.index("--min_qual")] + ["--min_qual", "0"] + extra
+    with tempfile.TemporaryDirectory() as d:
+        for name, img in files.items():
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img)
+        rc, out, err = run(BIN, args, d, env)
+        want = pbo.run_pre_barcodes(args, lambda n: files[n])
+        assert rc == want["exit"] == 0, err[-300:]
+        assert out == want["stdout"]
+        assert strip_progress(err) == strip_progress(want["stderr"])
+        if "o.fastq.gz" in args:
+            assert gunzip_file(os.path.join(d, "o.fastq.gz")) == want["files"][1].decode("latin-1")

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Differential campaign, fresh seeds: bin/bam_umi_count against the REFERENCE BINARY (oracle/_ref/bam_umi_count) on
+seeded BAM files - short UMIs (re-used across cells and genes: the reference's RL_Tree is not a set there), NH > 1,
+several genes per alignment, noisy tags, unsorted input, thresholds, whitelists.  `python tools/fuzz_campaign_bam.py
+<seed> <cases> [workers]` on the GPU box.  A run in which the reference dies of a signal is skipped (its tree reads and
+writes memory it does not own on some inputs: DESIGN 5.1)."""
+import os
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from tests import bamgen  # noqa: E402
+
+REF = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
+BIN = os.path.join(REPO, "bin", "bam_umi_count")
+
+
+def run(exe, args, cwd, tag):
+    try:
+        p = subprocess.run(["bam_umi_count"] + args + ["--ucounts", tag + "_u", "--rcounts", tag + "_r"], executable=exe, cwd=cwd,
+                           capture_output=True, timeout=180)
+    except subprocess.TimeoutExpired:
+        return None
+    out = {"rc": p.returncode, "stdout": p.stdout, "stderr": p.stderr.decode("latin-1").replace(tag + "_", "X_")}
+    for base in ("_u", "_r"):
+        for ext in ("", "_rows", "_cols"):
+            path = os.path.join(cwd, tag + base + ext)
+            out[base + ext] = open(path, "rb").read() if os.path.exists(path) else None
+    return out
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    kw = dict(n_cells=int(rng.integers(1, 80)), genes=int(rng.integers(1, 300)), umi_len=int(rng.integers(2, 9)),
+              reads_per_cell=(1, int(rng.integers(2, 400))))
+    kw["nh"] = bool(rng.random() < 0.4)
+    kw["multi_gx"] = bool(rng.random() < 0.3)
+    kw["noise"] = bool(rng.random() < 0.3)
+    kw["fresh_umis"] = bool(rng.random() < 0.2) and not kw["noise"]
+    unsorted = rng.random() < 0.2
+    if unsorted:
+        kw["sort_cells"] = False
+    bam, stream = bamgen.tagged_bam(rng, **kw)
+    args = ["--bam", "in.bam"]
+    if unsorted and rng.random() < 0.8:
+        args.append("--not_sorted_by_cell")
+    if rng.random() < 0.3:
+        args.append("--uniq_mapped")
+    elif rng.random() < 0.2:
+        args.append("--multi_mapped")
+    if rng.random() < 0.3:
+        args += ["--min_reads", str(int(rng.integers(0, 4)))]
+    if rng.random() < 0.3:
+        args += ["--min_umis", str(int(rng.integers(0, 4)))]
+    if rng.random() < 0.2:
+        args += ["--tag", "TX"]
+    if rng.random() < 0.15:
+        args.append("--10x")
+    files = {"in.bam": bam}
+    if rng.random() < 0.25:
+        import struct
+        cells = []
+        p = len(bamgen.header())
+        while p < len(stream):
+            (block,) = struct.unpack_from("<i", stream, p)
+            rec = stream[p + 4:p + 4 + block]
+            k = rec.find(b"CRZ")
+            if k >= 0:
+                c = rec[k + 3:rec.index(b"\0", k + 3)]
+                if c not in cells:
+                    cells.append(c)
+            p += 4 + block
+        keep = [c for c in cells if rng.random() < 0.6]
+        files["wl.txt"] = b"".join(c + b"\n" for c in keep)
+        args += ["--known_cells", "wl.txt"]
+    with tempfile.TemporaryDirectory() as d:
+        for fn, data in files.items():
+            with open(os.path.join(d, fn), "wb") as f:
+                f.write(data)
+        want = run(REF, args, d, "ref")
+        if want is None or want["rc"] < 0:
+            return []
+        got = run(BIN, args, d, "gpu")
+    if got != want:
+        keys = [k for k in want if got is None or got.get(k) != want[k]]
+        return [(seed, args, kw, want["rc"], None if got is None else got["rc"], keys, want["stderr"][-200:],
+                 "" if got is None else got["stderr"][-200:])]
+    return []
+
+
+def main():
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    workers = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    n_bad = 0
+    with ThreadPoolExecutor(workers) as ex:
+        for bad in ex.map(one_case, range(seed0, seed0 + cases)):
+            for b in bad:
+                n_bad += 1
+                if n_bad <= 30:
+                    print("DIFF", b, flush=True)
+    print(f"campaign (bam_umi_count) seeds {seed0}..{seed0 + cases - 1}: {n_bad} differing runs", flush=True)
+
+
+if __name__ == "__main__":
+    main()

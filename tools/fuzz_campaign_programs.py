@@ -46,11 +46,12 @@ def gunzip(path):
         return b"<broken gzip>"
 
 
-def damaged(rng, img, p_none):
+def damaged(rng, img, p_none, kinds=None):
+    kinds = kinds or KINDS
     what = []
     if rng.random() >= p_none:
         for _ in range(int(rng.integers(1, 3))):
-            kind = KINDS[int(rng.integers(0, len(KINDS)))]
+            kind = kinds[int(rng.integers(0, len(kinds)))]
             what.append(kind)
             img = fuzz.mutate(rng, img, kind)
     return img, what
@@ -139,7 +140,9 @@ def one_case(seed):
         q2 = (rng.integers(2, 41, l2) + 33).astype(np.uint8).tobytes()
         r1.append(b"@" + name + b" 1:N:0:ACGT\n" + s1 + b"\n+\n" + q1 + b"\n")
         r2.append(b"@" + name + b" 2:N:0:ACGT\n" + s2 + b"\n+\n" + q2 + b"\n")
-    i1, w1 = damaged(rng, b"".join(r1), 0.75)
+    # (the barcode file keeps its lines in step: a quality line shorter than the barcode range makes the reference copy
+    #  bytes of earlier records that are still in its buffer - DESIGN 7.1; seed 20226 of an earlier version found it)
+    i1, w1 = damaged(rng, b"".join(r1), 0.75, ["flip_seq", "bad_at", "empty_hdr", "strip_last_nl", "empty_seq"])
     i2, w2 = damaged(rng, b"".join(r2), 0.75)
     if rng.random() < 0.2:
         k = int(rng.integers(0, n + 1))
