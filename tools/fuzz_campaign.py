@@ -3,6 +3,7 @@
 seeded, mutated files - all four modes, one piece / 1 MiB pieces / several contexts, the streaming framing forced on
 small images.  Not a test: run it on the GPU box (`python tools/fuzz_campaign.py <seed> <cases> [workers]`), it prints
 every case that differs and a summary line.  Cases that differ become seeded tests."""
+import gzip
 import os
 import subprocess
 import sys
@@ -21,6 +22,10 @@ REF = os.path.join(REPO, "oracle", "_ref", "fastq_info")
 ENVS = [("default", {}), ("pieces", {"FQGPU_CHUNK_MB": "1"}), ("stream", {"FQGPU_STREAM_MIN": "256"}),
         ("devices", {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"}),
         ("devices_stream", {"FQGPU_DEVICES": "0,0,0", "FQGPU_CHUNK_MB": "1", "FQGPU_STREAM_MIN": "256"})]
+if os.environ.get("CAMPAIGN_COMPAT") == "1":
+    # the zero-change route: the reference's own fastq_info.c linked against libfastq_gpu.so (oracle/Makefile)
+    BIN = os.path.join(REPO, "oracle", "_ref", "fastq_info_on_libfastq_gpu")
+    ENVS = [("compat", {}), ("compat", {}), ("compat_stream", {"FQGPU_STREAM_MIN": "256"}), ("compat", {}), ("compat_stream", {"FQGPU_STREAM_MIN": "256"})]
 
 
 def run(binary, args, cwd, env=None):
@@ -83,16 +88,30 @@ def one_case(seed):
             k, at = int(rng.integers(0, na)), int(rng.integers(0, na))
             a = b"\n".join(la[:4 * at] + la[4 * k:4 * k + 4] + la[4 * at:])
             what.append("a:twice")
+    # an interleaved file from the (damaged) two: mates alternate as long as both have records
+    la, lb2 = a.split(b"\n"), b.split(b"\n")
+    ni = min(len(la), len(lb2)) // 4
+    inter = b"".join(b"\n".join(la[4 * i:4 * i + 4]) + b"\n" + b"\n".join(lb2[4 * i:4 * i + 4]) + b"\n" for i in range(ni))
+    if rng.random() < 0.3 and ni:
+        kind = fuzz.MUTATIONS[int(rng.integers(0, len(fuzz.MUTATIONS)))]
+        what.append("i:" + kind)
+        inter = fuzz.mutate(rng, inter, kind)
     bad = []
     with tempfile.TemporaryDirectory() as ref_dir, tempfile.TemporaryDirectory() as gpu_dir:
         for d in (ref_dir, gpu_dir):
-            for name, img in (("a.fastq", a), ("b.fastq", b)):
+            for name, img in (("a.fastq", a), ("b.fastq", b), ("i.fastq", inter)):
                 with open(os.path.join(d, name), "wb") as f:
                     f.write(img)
-        modes = [["-r", "a.fastq"], ["a.fastq"], ["a.fastq", "pe"], ["a.fastq", "b.fastq"], ["-s", "a.fastq", "b.fastq"]]
+            with open(os.path.join(d, "a.fastq.gz"), "wb") as f:
+                f.write(gzip.compress(a, 1))
+        modes = [["-r", "a.fastq"], ["a.fastq"], ["i.fastq", "pe"], ["a.fastq", "b.fastq"], ["-s", "a.fastq", "b.fastq"],
+                 ["a.fastq.gz", "b.fastq"]]
         if not big:
-            modes += [["-r", "-s", "a.fastq", "b.fastq"], ["b.fastq", "a.fastq"]]
+            modes += [["-r", "-s", "a.fastq", "b.fastq"], ["b.fastq", "a.fastq"], ["a.fastq", "pe"], ["-r", "a.fastq.gz"],
+                      ["-e", "-q", "a.fastq"], ["-f", "a.fastq"]]
         envs = ENVS if big else [ENVS[0], ENVS[2], ENVS[4]]
+        if os.environ.get("CAMPAIGN_COMPAT") == "1":
+            envs = [ENVS[0], ENVS[2]]
         for args in modes:
             want = run(REF, args, ref_dir)
             if want[0] in ("timeout", -11, -6):  # the reference itself crashed: not a case

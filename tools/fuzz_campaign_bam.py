@@ -93,7 +93,70 @@ def one_case(seed):
     return []
 
 
+def tags_case(seed):
+    """bam_add_tags: names as fastq_pre_barcodes writes them (and names it leaves alone), records of every size, --10x,
+    --tx, --tx_2_gx with a map that lacks some transcripts; the inflated output BAM, stderr and the exit status"""
+    import gzip
+    rng = np.random.default_rng(seed)
+    refs = int(rng.integers(1, 40))
+    names = [b"TX%04d.%d" % (i, i % 3) for i in range(refs)]
+    recs = []
+    for i in range(int(rng.integers(1, 3000))):
+        c = bamgen.barcode(rng, int(rng.choice([0, 8, 16, 30])))
+        u = bamgen.barcode(rng, int(rng.choice([0, 10, 12])))
+        sm = bamgen.barcode(rng, int(rng.choice([0, 0, 8])))
+        tail = b"M%d:%d" % (i, int(rng.integers(0, 10 ** 6)))
+        kind = int(rng.integers(0, 8))
+        if kind < 6:
+            name = b"STAGS_CELL=%s_UMI=%s_SAMPLE=%s_ETAGS_%s" % (c, u, sm, tail)
+        elif kind == 6:
+            name = tail
+        else:
+            name = b"STAGS_CELL=%s_UMX=%s_SAMPLE=%s_ETAGS_%s" % (c, u, sm, tail)
+        seq_len = int(rng.integers(0, 120)) if rng.random() < 0.98 else int(rng.integers(2000, 20000))
+        aux = bamgen.aux_z(b"XA", b"x" * int(rng.integers(0, 20))) if rng.random() < 0.5 else b""
+        tid = -1 if rng.random() < 0.1 else int(rng.integers(0, refs))
+        recs.append(bamgen.record(name[:254], aux, tid=tid, seq_len=seq_len))
+    stream = bamgen.header(tuple((nm, 1000) for nm in names)) + b"".join(recs)
+    args = ["--inbam", "in.bam", "--outbam", "o.bam"]
+    files = {"in.bam": bamgen.bgzf(stream, level=1)}
+    if rng.random() < 0.4:
+        args.append("--10x")
+    if rng.random() < 0.6:
+        args.append("--tx")
+        if rng.random() < 0.6:
+            files["map.tsv"] = b"".join(nm + b"\tGENE_%d\n" % (i // 2) for i, nm in enumerate(names) if rng.random() < 0.8)
+            args += ["--tx_2_gx", "map.tsv"]
+    res = []
+    for exe in (os.path.join(REPO, "oracle", "_ref", "bam_add_tags"), os.path.join(REPO, "bin", "bam_add_tags")):
+        with tempfile.TemporaryDirectory() as d:
+            for fn, data in files.items():
+                with open(os.path.join(d, fn), "wb") as f:
+                    f.write(data)
+            try:
+                p = subprocess.run(["bam_add_tags"] + args, executable=exe, cwd=d, capture_output=True, timeout=180)
+            except subprocess.TimeoutExpired:
+                return []
+            out = None
+            path = os.path.join(d, "o.bam")
+            if os.path.exists(path):
+                try:
+                    out = gzip.decompress(open(path, "rb").read())
+                except Exception:
+                    out = b"<broken>"
+            res.append((p.returncode, p.stdout, p.stderr.decode("latin-1"), out))
+        if res[0][0] < 0:
+            return []
+    if res[0] != res[1]:
+        return [(seed, "bam_add_tags", args, res[0][0], res[1][0], res[0][2][-200:], res[1][2][-200:],
+                 None if res[0][3] is None else len(res[0][3]), None if res[1][3] is None else len(res[1][3]))]
+    return []
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "tags":
+        global one_case
+        one_case = tags_case
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 6
@@ -104,7 +167,7 @@ def main():
                 n_bad += 1
                 if n_bad <= 30:
                     print("DIFF", b, flush=True)
-    print(f"campaign (bam_umi_count) seeds {seed0}..{seed0 + cases - 1}: {n_bad} differing runs", flush=True)
+    print(f"campaign ({one_case.__name__}) seeds {seed0}..{seed0 + cases - 1}: {n_bad} differing runs", flush=True)
 
 
 if __name__ == "__main__":
