@@ -1465,8 +1465,22 @@ static BcTile bc_tile_for(const BcParams& P) {
   tc.in_cap = ((unsigned)(1.06 * in * T + 48.0 * files + 48.0) + 15u) & ~15u;
   if (tc.in_cap + 1024u > budget) tc.in_cap = (budget / 2) & ~15u;
   tc.out_cap = (budget - tc.in_cap) & ~15u;
-  // the plan kernel: several tiles at once while one lane per iteration and 32 KiB of LDS allow it
-  tc.plan_m = std::max(1u, std::min(std::min(64u / tc.T, 32768u / std::max(tc.in_cap, 1u)), 4u));
+  // the plan kernel: several tiles at once while one lane per iteration allows it.  It stages only the files a
+  // barcode is cut from, and only when a minimum quality makes it read their bytes (bc_staged<PLAN>)
+  tc.plan_m = std::max(1u, std::min(64u / tc.T, 4u));
+  double plan_in = 0;
+  int plan_files = 0;
+  for (int x = 1; x < kBcFiles; ++x)
+    if (P.f[x].present && P.min_qual > 0 && (P.umi_read == x || P.cell_read == x || P.sample_read == x)) {
+      plan_in += (P.f[x].fv.n_records ? (double)P.f[x].fv.nbytes / (double)P.f[x].fv.n_records : 0.0) * P.f[x].step;
+      ++plan_files;
+    }
+  tc.plan_cap = ((unsigned)(1.06 * plan_in * T * tc.plan_m + 48.0 * plan_files + 64.0) + 15u) & ~15u;
+  while (tc.plan_m > 1 && tc.plan_cap > 32768u) {  // (long reads in a barcode file)
+    tc.plan_cap = (tc.plan_cap / tc.plan_m * (tc.plan_m - 1) + 15u) & ~15u;
+    --tc.plan_m;
+  }
+  tc.plan_cap = std::min(tc.plan_cap, 65536u - 256u);
   return tc;
 }
 
@@ -1558,7 +1572,7 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
     ProfScope ps(c, "k_bc_plan");
 #define FQG_PLAN_TILE(MASK)                                                                                       \
   do {                                                                                                            \
-    const unsigned plan_lds = tc.in_cap * tc.plan_m;                                                              \
+    const unsigned plan_lds = tc.plan_cap;                                                                        \
     const uint64_t plan_tiles = (n_tiles + tc.plan_m - 1) / tc.plan_m;                                            \
     const unsigned grid = (unsigned)std::min<uint64_t>(plan_tiles, resident((const void*)k_bc_plan_tile<MASK>, plan_lds)); \
     hipLaunchKernelGGL(k_bc_plan_tile<MASK>, dim3(grid), dim3(kWave), plan_lds, c->stream, P, tc, n_iter,          \
@@ -1578,21 +1592,10 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   uint64_t n_done = n_iter;
   const uint64_t n_big = c->h_bcall->big;
-  if (c->h_bcall->first_finding != ~0ull) {
-    const uint64_t k = c->h_bcall->first_finding >> 8;
-    n_done = k;
-    out->iteration = k;
-    out->code = (int32_t)((c->h_bcall->first_finding & 0xFF) >> 3);
-    out->file = (int32_t)(c->h_bcall->first_finding & 7);
-  }
-  if (inter && c->h_bcall->first_discard < n_done) {
-    n_done = c->h_bcall->first_discard + 1;
-    out->code = FQG_OK;  // a finding beyond the re-synchronisation point is not reached in this batch
-    out->file = 0;
-    out->iteration = 0;
-  }
+  // interleaved input re-synchronises behind the first discard: nothing beyond it is reached in this batch (a name
+  // finding - the emit kernels look for those - can only lie in what is emitted)
+  if (inter && c->h_bcall->first_discard < n_done) n_done = c->h_bcall->first_discard + 1;
   out->n_done = n_done;
-  if (!n_done) return 0;
   unsigned long long* d_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_bcall) + sizeof(BcCall));
   unsigned long long* h_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_bcall) + sizeof(BcCall));
   const uint64_t nb_done = (n_done + kScan64Span - 1) / kScan64Span;
@@ -1631,7 +1634,8 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   do {                                                                                                            \
     grid_t = (unsigned)std::min<uint64_t>(n_tiles_done, resident((const void*)k_bc_emit_tile<SAM, MASK>, lds));    \
     hipLaunchKernelGGL((k_bc_emit_tile<SAM, MASK>), dim3(grid_t), dim3(kWave), lds, c->stream, P, tc, n_done,      \
-                       (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);     \
+                       (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2],      \
+                       c->d_bcall);                                                                                \
   } while (0)
 #define FQG_EMIT_TILE_MASKS(SAM)                  \
   switch (file_mask) {                            \
@@ -1652,11 +1656,42 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
       const unsigned grid_e =
           (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + 3) / 4, (uint64_t)c->cu_count * 8));
       hipLaunchKernelGGL(k_bc_emit_direct, dim3(grid_e), dim3(kBlock), 0, c->stream, P, tc, n_done,
-                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2]);
+                         (const uint8_t*)c->bc_status.p, (const uint8_t*)c->bc_tile_big.p, eo[0], eo[1], eo[2], c->d_bcall);
     }
   }
+  HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
+  if (c->h_bcall->first_finding != ~0ull) {
+    // Names that do not agree (or a header without '@') at iteration k: the reference stops there, before it looks at
+    // the iteration's barcodes.  What the batch yields is what lies in front of k: the text up to k's place in every
+    // output, the discards among the first k iterations.
+    const uint64_t k = c->h_bcall->first_finding >> 8;
+    out->iteration = k;
+    out->code = (int32_t)((c->h_bcall->first_finding & 0xFF) >> 3);
+    out->file = (int32_t)(c->h_bcall->first_finding & 7);
+    out->n_done = k;
+    out->n_discarded = out->n_short = 0;
+    for (int i = 0; i < 3; ++i) {
+      if (P.out_sam ? i != 0 : !P.emit[i]) continue;
+      unsigned long long off = 0, sum = 0;
+      if (k) {  // (k < n_done: both entries exist)
+        HIP_TRY(c, hipMemcpy(&off, (const unsigned long long*)c->bc_off[i].p + k, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(&sum, (const unsigned long long*)c->bc_sum[i].p + k / kScan64Span, 8, hipMemcpyDeviceToHost));
+      }
+      out->out_bytes[i] = off + sum;
+      c->bc_out_bytes[i] = off + sum;
+    }
+    if (k) {
+      HIP_TRY(c, hipMemsetAsync(&c->d_bcall->discarded, 0, 2 * sizeof(unsigned long long), c->stream));
+      hipLaunchKernelGGL(k_bc_count, dim3((unsigned)std::min<uint64_t>((k + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0,
+                         c->stream, (const uint8_t*)c->bc_status.p, k, c->d_bcall);
+      HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      out->n_discarded = c->h_bcall->discarded;
+      out->n_short = c->h_bcall->short_warnings;
+    }
+  }
   return 0;
 }
 

@@ -29,6 +29,7 @@ struct BcTile {
   uint32_t in_cap;   // LDS bytes for the staged records
   uint32_t out_cap;  // LDS bytes for the output text (emit only)
   uint32_t plan_m;   // the plan kernel works on plan_m tiles at once (one lane per iteration: T * plan_m <= 64)
+  uint32_t plan_cap; // LDS bytes for what the plan stages of T * plan_m iterations (bc_staged<PLAN>)
 };
 
 struct BcFile {
@@ -223,37 +224,106 @@ __device__ __forceinline__ int bc_get(const BcLine (&ln)[4], long off, long size
   return 0;
 }
 
-// status + tags of one iteration from the lines of its records (in an image or in LDS)
+// Do two header lines (in LDS, 8 bytes of slack behind them) surely have the same canonical name?  One pass over the
+// words of both until they differ - no search for the end of either name:
+//   * no difference up to and including the '\n' of the shorter line: the lines are the same line, and so are their
+//     names when both files have the same name format;
+//   * CASAVA 1.8 (the name ends at the first blank, src/fastq.c:502-511): the byte in front of the first difference is
+//     a blank - the first blank of both lines lies in what they share ("... 1:N:0" against "... 2:N:0": the usual case);
+//   * DEFAULT with is_pe (the name is the line without its last character, :489-495): lines of one length that differ
+//     in that last character first.
+// Anything else - and an unterminated last line - is decided by the exact comparison (bc_names_differ).
+// The first 32 bytes of both lines are fetched at once when the lines are that long (BcHead: READ1's are fetched once
+// for all files): the kernel that makes this test waits for every LDS round trip, so four of them cost what one does.
+struct BcHead {
+  uint64_t w[4];  // bytes 0..31 of the line
+  bool wide;      // ... when it has them
+};
+__device__ __forceinline__ BcHead bc_head(const BcLine& a) {
+  BcHead h;
+  h.wide = a.len >= 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h.w[j] = h.wide ? ld8(a.p + 8 * j) : 0ull;
+  return h;
+}
+__device__ __forceinline__ bool bc_names_agree_fast(const BcLine& a, const BcHead& ha, int fa, const BcLine& b, int fb) {
+  if (fa != fb || !(a.nl & b.nl)) return false;
+  const uint32_t lmin = a.len < b.len ? a.len : b.len;  // position of the shorter line's '\n'
+  uint32_t i = 1, at = 0;
+  uint64_t d = 0;
+  uint32_t before = 0x100u;  // the byte in front of the first difference, when it is known already
+  if (ha.wide && b.len >= 32) {
+    uint64_t x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = ha.w[j] ^ ld8(b.p + 8 * j);
+    x[0] &= ~0xFFull;  // (byte 0: the '@' of both, checked by the caller)
+    if (x[0] | x[1] | x[2] | x[3]) {
+      const int j = x[0] ? 0 : (x[1] ? 1 : (x[2] ? 2 : 3));
+      d = x[0] ? x[0] : (x[1] ? x[1] : (x[2] ? x[2] : x[3]));
+      at = 8u * (uint32_t)j + ((uint32_t)__builtin_ctzll(d) >> 3);  // >= 1, < 32 <= lmin
+      const uint32_t q = at - 1;
+      const uint64_t wq = (q >> 3) == 0 ? ha.w[0] : ((q >> 3) == 1 ? ha.w[1] : ((q >> 3) == 2 ? ha.w[2] : ha.w[3]));
+      before = (uint32_t)(wq >> (8u * (q & 7u))) & 0xFFu;
+    } else {
+      i = 32;
+    }
+  }
+  if (!d) {
+    for (; i <= lmin; i += 8) {
+      d = ld8(a.p + i) ^ ld8(b.p + i);
+      if (d) break;
+    }
+    if (!d) return true;  // every byte up to that '\n' is the same (lmin = 0: two empty names)
+    at = i + ((uint32_t)__builtin_ctzll(d) >> 3);  // the first byte that differs
+    if (at > lmin) return true;
+  }
+  if (fa == FQG_NAME_CASAVA18) return at >= 2 && (before < 0x100u ? before : (uint32_t)a.p[at - 1]) == ' ';
+  if (fa == FQG_NAME_DEFAULT) return a.len == b.len && at + 1 == a.len && at >= 2;
+  return false;
+}
+
+// canonical names: file x against READ1, exactly (src/fastq_pre_barcodes.c:606-635)
+template <bool WIDE>
+__device__ __forceinline__ bool bc_names_differ(const BcLine& h1, int f1, const BcLine& hx, int fx) {
+  const uint32_t n1 = bc_name_len<WIDE>(h1, f1), nx = bc_name_len<WIDE>(hx, fx);
+  bool same = nx == n1;
+  if (WIDE) same = same && bc_same_bytes_wide(h1.p + 1, hx.p + 1, n1);
+  else
+    for (uint32_t i = 0; same && i < n1; ++i) same = h1.p[1 + i] == hx.p[1 + i];
+  return !same;
+}
+
+// The name checks of one iteration: '@' first in every header (fastq_get_readname, src/fastq.c:448), then every file's
+// canonical name against READ1's.  0, or (code << 3) | file of the first check that fails.  These checks come before
+// anything else the reference does with an iteration (discards included), but nothing the plan computes depends on
+// them: the EMIT kernels make them, on the header bytes they stage anyway (the plan then needs the bytes of the
+// barcode-carrying files only).
 template <bool WIDE, int MASK = 0>
-__device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLine (&L)[kBcFiles][4], BcTags* tags,
-                                                   uint32_t* finding) {
-  *finding = 0;
+__device__ __forceinline__ uint32_t bc_check_names(const BcParams& P, const BcLine (&L)[kBcFiles][4]) {
+  if (P.n_inputs <= 1) return 0;
+  uint32_t bad = 0;
+#pragma unroll
+  for (int x = kBcFiles - 1; x >= 1; --x)  // (all first bytes are fetched before any is looked at; the first file wins)
+    if (bc_has<MASK>(P, x) && L[x][0].p[0] != '@') bad = (FQG_E_WRONG_HEADER << 3) | x;
+  if (bad) return bad;
+  BcHead h1;
+  if (WIDE) h1 = bc_head(L[1][0]);
+#pragma unroll
+  for (int x = 2; x < kBcFiles; ++x)
+    if (bc_has<MASK>(P, x)) {
+      if (WIDE && bc_names_agree_fast(L[1][0], h1, P.f[1].fmt, L[x][0], P.f[x].fmt)) continue;
+      if (bc_names_differ<WIDE>(L[1][0], P.f[1].fmt, L[x][0], P.f[x].fmt)) return (FQG_E_NAME_MISMATCH << 3) | x;
+    }
+  return 0;
+}
+
+// status + tags of one iteration from the lines of its records (in an image or in LDS): extract_info for each file in
+// order - umi, sample, cell (src/fastq_pre_barcodes.c:262-285).  Only the lines of the barcode-carrying files are
+// looked at, and their BYTES only when a minimum quality is asked for (bc_plan_staged).
+template <bool WIDE, int MASK = 0>
+__device__ __forceinline__ uint8_t bc_decide_lines(const BcParams& P, const BcLine (&L)[kBcFiles][4], BcTags* tags) {
   tags->n[0] = tags->n[1] = tags->n[2] = 0;
   tags->qn[0] = tags->qn[1] = tags->qn[2] = 0;
-  if (P.n_inputs > 1) {
-    // names: every file against READ1 (src/fastq_pre_barcodes.c:606-635); '@' first (src/fastq.c:448)
-#pragma unroll
-    for (int x = 1; x < kBcFiles; ++x)
-      if (bc_has<MASK>(P, x) && L[x][0].p[0] != '@') {
-        *finding = (FQG_E_WRONG_HEADER << 3) | x;
-        return kBcFinding;
-      }
-    const uint32_t n1 = bc_name_len<WIDE>(L[1][0], P.f[1].fmt);
-#pragma unroll
-    for (int x = 2; x < kBcFiles; ++x)
-      if (bc_has<MASK>(P, x)) {
-        const uint32_t nx = bc_name_len<WIDE>(L[x][0], P.f[x].fmt);
-        bool same = nx == n1;
-        if (WIDE) same = same && bc_same_bytes_wide(L[1][0].p + 1, L[x][0].p + 1, n1);
-        else
-          for (uint32_t i = 0; same && i < n1; ++i) same = L[1][0].p[1 + i] == L[x][0].p[1 + i];
-        if (!same) {
-          *finding = (FQG_E_NAME_MISMATCH << 3) | x;
-          return kBcFinding;
-        }
-      }
-  }
-  // extract_info for each file in order: umi, sample, cell (src/fastq_pre_barcodes.c:262-285)
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x)
     if (bc_has<MASK>(P, x)) {
@@ -411,6 +481,7 @@ struct BcGeo {
 struct TileGeo {
   BcGeo f[kBcFiles];
   unsigned long long where[3];  // emit: the iteration's place in each output
+  uint32_t olen[3];             // emit: ... and the bytes it has there (what the plan computed)
   uint8_t st;                   // emit: status
   uint8_t big;                  // emit: tile flag
 };
@@ -421,17 +492,19 @@ __device__ __forceinline__ void bc_geo_load(const BcFile& f, uint64_t k, BcGeo& 
 #pragma unroll
   for (int i = 0; i < 4; ++i) g.e[i] = le[i];
 }
-// which files a kernel stages: the plan all of them, the SAM emit only what it prints or tags with
-template <bool SAM_EMIT, int MASK>
+// which files a kernel stages.  The emit kernels (and the record filters): every input - they print the records and
+// compare the names.  PLAN: only the files a barcode is cut from, and those only when a minimum quality is asked for
+// (get_barcode reads quality characters then); everything else the plan needs - line lengths - is in the line index.
+template <bool PLAN, int MASK>
 __device__ __forceinline__ bool bc_staged(const BcParams& P, int x) {
   if (!bc_has<MASK>(P, x)) return false;
-  if (SAM_EMIT && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) return false;
+  if (PLAN && (P.min_qual <= 0 || (P.umi_read != x && P.cell_read != x && P.sample_read != x))) return false;
   return true;
 }
 
 // Copies the spans into s_in and gives the lane its lines (pointers into LDS).  Returns false
 // (uniformly, before copying anything) when the spans do not fit in_cap.
-template <bool SAM_EMIT, int MASK>
+template <bool PLAN, int MASK>
 __device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& tg, int last_lane, int lane, uint8_t* s_in,
                                               uint32_t in_cap, BcLine (&L)[kBcFiles][4]) {
   const uint8_t* gbase[kBcFiles];  // address of the file's unit 0 minus 16 * its first unit number
@@ -443,7 +516,7 @@ __device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& 
   for (int x = 1; x < kBcFiles; ++x) {
     first_unit[x] = 0xFFFFFFFFu;  // never selected
     gbase[x] = P.f[1].fv.img;
-    if (!bc_staged<SAM_EMIT, MASK>(P, x)) continue;
+    if (!bc_staged<PLAN, MASK>(P, x)) continue;
     const BcFile& f = P.f[x];
     s0[x] = rfl64(tg.f[x].prev + 1);
     const uint64_t e3l = rl64(tg.f[x].e[3], last_lane);
@@ -476,10 +549,13 @@ __device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& 
   }
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x) {
-    if (!bc_staged<SAM_EMIT, MASK>(P, x)) continue;
+    if (!bc_has<MASK>(P, x)) continue;
     const BcGeo& g = tg.f[x];
     const uint64_t nb = P.f[x].fv.nbytes;
-    uint8_t* b = s_in + 16u * first_unit[x] + skew[x];
+    // (a file that is not staged: the lengths of its lines, no bytes - pointers that are never followed)
+    const bool st = bc_staged<PLAN, MASK>(P, x);
+    uint8_t* b = st ? s_in + 16u * first_unit[x] + skew[x] : s_in;
+    if (!st) s0[x] = g.prev + 1;
     L[x][0] = BcLine{b + (uint32_t)(g.prev + 1 - s0[x]), (uint32_t)(g.e[0] - g.prev - 1), g.e[0] < nb ? 1u : 0u};
     L[x][1] = BcLine{b + (uint32_t)(g.e[0] + 1 - s0[x]), (uint32_t)(g.e[1] - g.e[0] - 1), g.e[1] < nb ? 1u : 0u};
     L[x][2] = BcLine{b + (uint32_t)(g.e[1] + 1 - s0[x]), (uint32_t)(g.e[2] - g.e[1] - 1), g.e[2] < nb ? 1u : 0u};
@@ -489,16 +565,15 @@ __device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& 
 }
 
 // Would the records of the iterations held by lanes first_lane .. last_lane fit the input area of ONE emit
-// tile?  The same unit count as bc_stage_tile makes for that tile (sam: the emit kernel's staging rule).
+// tile?  The same unit count as bc_stage_tile makes for that tile (the emit kernels stage every input).
 template <int MASK>
 __device__ __forceinline__ bool bc_emit_tile_fits(const BcParams& P, const TileGeo& tg, int first_lane, int last_lane,
-                                                  bool sam, uint32_t in_cap) {
+                                                  uint32_t in_cap) {
   uint32_t units = 0;
   bool fit = true;
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x) {
     if (!bc_has<MASK>(P, x)) continue;
-    if (sam && x > 2 && P.umi_read != x && P.cell_read != x && P.sample_read != x) continue;
     const BcFile& f = P.f[x];
     const uint64_t s0 = rl64(tg.f[x].prev + 1, first_lane);
     const uint64_t e3l = rl64(tg.f[x].e[3], last_lane);
@@ -518,10 +593,12 @@ __device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLi
     if (bc_has<MASK>(P, x)) bc_lines(P.f[x], k, L[x]);
 }
 
-// One wavefront per PLAN tile = plan_m consecutive tiles of the emit kernel, one lane per iteration: the plan
-// needs LDS only for the records, so more iterations fit, and its per-lane work (names, qualities) then runs on
-// three times as many lanes.  What it decides per emit tile - does the tile fit the emit kernel's LDS areas -
-// is worked out per group of T lanes.  MASK: see bc_has.
+// One wavefront per PLAN tile = plan_m consecutive tiles of the emit kernel, one lane per iteration.  The plan decides
+// what the iteration's output is made of - keep / discard (get_barcode's bounds and minimum quality) and the byte count
+// of every output - from the line index and the bytes of the barcode-carrying files alone (bc_staged<PLAN>): its LDS
+// holds little, so many wavefronts are resident.  The name checks, which need the header bytes of every file, are made
+// by the emit kernels on the records they stage anyway (bc_check_names).  What the plan decides per emit tile - does
+// the tile fit the emit kernel's LDS areas - is worked out per group of T lanes.  MASK: see bc_has.
 template <int MASK>
 __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
                                                         uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
@@ -529,7 +606,7 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
                                                         BcCall* __restrict__ call) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
   const int lane = (int)threadIdx.x;
-  const uint32_t Tp = tc.T * tc.plan_m, plan_cap = tc.in_cap * tc.plan_m;
+  const uint32_t Tp = tc.T * tc.plan_m, plan_cap = tc.plan_cap;
   const uint64_t n_tiles = (n_iter + Tp - 1) / Tp;
   auto tile_size = [&](uint64_t tile) {
     const uint64_t left = n_iter - tile * Tp;
@@ -551,19 +628,19 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
     BcLine L[kBcFiles][4];
     if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);  // the next tile's index: in flight during this tile
-    const bool fit = bc_stage_tile<false, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
+    const bool fit = bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BcTags t;
-    uint32_t finding = 0, a = 0, b = 0, c = 0;
+    uint32_t a = 0, b = 0, c = 0;
     uint8_t st;
     if (fit) {
-      st = bc_decide_lines<true, MASK>(P, L, &t, &finding);
+      st = bc_decide_lines<true, MASK>(P, L, &t);
       if (st == kBcKeep) bc_out_lens(P, k, L, t, &a, &b, &c);
     } else {  // long reads: from the images
       BcLine G[kBcFiles][4];
       bc_lines_all<MASK>(P, k, G);
-      st = bc_decide_lines<false, MASK>(P, G, &t, &finding);
+      st = bc_decide_lines<false, MASK>(P, G, &t);
       if (st == kBcKeep) bc_out_lens(P, k, G, t, &a, &b, &c);
     }
     if (valid) {
@@ -577,7 +654,6 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
       a = b = c = 0;
     }
     const unsigned long long none = ~0ull;
-    const unsigned long long fnd = wave_min64(valid && st == kBcFinding ? (unsigned long long)((k << 8) | finding) : none);
     const unsigned long long dsc =
         wave_min64(valid && (st == kBcDiscardShort || st == kBcDiscardQual) ? (unsigned long long)k : none);
     // the emit tiles inside this plan tile
@@ -585,21 +661,27 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
       const uint32_t first = j * tc.T, last = (first + tc.T < Tn ? first + tc.T : Tn) - 1;
       const bool mine = (uint32_t)lane >= first && (uint32_t)lane <= last;
       const uint32_t sa = wave_sum32(mine ? a : 0u), sb = wave_sum32(mine ? b : 0u), sc = wave_sum32(mine ? c : 0u);
-      const bool fits_in = bc_emit_tile_fits<MASK>(P, cur, (int)first, (int)last, P.out_sam != 0, tc.in_cap);
+      const bool fits_in = bc_emit_tile_fits<MASK>(P, cur, (int)first, (int)last, tc.in_cap);
       if (lane == 0) {
         const bool big = !fits_in || sa + 32 > tc.out_cap || sb + 32 > tc.out_cap || sc + 32 > tc.out_cap;
         tile_big[tile * tc.plan_m + j] = big ? 1 : 0;
         if (big) atomicAdd(&call->big, 1ull);
       }
     }
-    if (lane == 0) {
-      // tiles run roughly in order: look before the atomic, almost every later tile has nothing to add
-      if (fnd != none && fnd < __atomic_load_n(&call->first_finding, __ATOMIC_RELAXED)) atomicMin(&call->first_finding, fnd);
-      if (dsc != none && dsc < __atomic_load_n(&call->first_discard, __ATOMIC_RELAXED)) atomicMin(&call->first_discard, dsc);
-    }
+    // tiles run roughly in order: look before the atomic, almost every later tile has nothing to add
+    if (lane == 0 && dsc != none && dsc < __atomic_load_n(&call->first_discard, __ATOMIC_RELAXED))
+      atomicMin(&call->first_discard, dsc);
     __builtin_amdgcn_wave_barrier();
     cur = nxt;
   }
+}
+
+// a name finding of the emit kernels: the smallest (iteration << 8 | code << 3 | file) wins
+__device__ __forceinline__ void bc_report_finding(BcCall* __restrict__ call, bool active, uint64_t k, uint32_t finding) {
+  if (!__ballot(active && finding != 0)) return;  // (the usual case: one ballot)
+  const unsigned long long none = ~0ull;
+  const unsigned long long fnd = wave_min64(active && finding ? (unsigned long long)((k << 8) | finding) : none);
+  if ((threadIdx.x & 63) == 0 && fnd < __atomic_load_n(&call->first_finding, __ATOMIC_RELAXED)) atomicMin(&call->first_finding, fnd);
 }
 
 // discarded iterations among the first n_done: one atomic per workgroup
@@ -974,7 +1056,7 @@ template <bool SAM, int MASK>
 __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, uint64_t n_done,
                                                         const uint8_t* __restrict__ status,
                                                         const uint8_t* __restrict__ tile_big, EmitOut o0, EmitOut o1,
-                                                        EmitOut o2) {
+                                                        EmitOut o2, BcCall* __restrict__ call) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
   uint8_t* s_in = s_lds;
   uint8_t* s_out = s_lds + tc.in_cap;
@@ -995,11 +1077,13 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
     tg.st = status[k];
 #pragma unroll
     for (int x = 1; x < kBcFiles; ++x)
-      if (bc_staged<SAM, MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
-    if (SAM) tg.where[0] = o0.off[k] + o0.sum[k / kScan64Span];
-    else {
-      if (P.emit[1]) tg.where[1] = o1.off[k] + o1.sum[k / kScan64Span];
-      if (P.emit[2]) tg.where[2] = o2.off[k] + o2.sum[k / kScan64Span];
+      if (bc_has<MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
+    if (SAM) {
+      tg.where[0] = o0.off[k] + o0.sum[k / kScan64Span];
+      tg.olen[0] = o0.len[k];
+    } else {
+      if (P.emit[1]) tg.where[1] = o1.off[k] + o1.sum[k / kScan64Span], tg.olen[1] = o1.len[k];
+      if (P.emit[2]) tg.where[2] = o2.off[k] + o2.sum[k / kScan64Span], tg.olen[2] = o2.len[k];
     }
   };
   TileGeo cur, nxt;
@@ -1013,9 +1097,11 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
     const uint64_t k = k0 + (valid ? it_raw : Tn - 1);
     const int last_lane = (int)((Tn - 1) * lpi);
     BcLine L[kBcFiles][4];
-    (void)bc_stage_tile<SAM, MASK>(P, cur, last_lane, lane, s_in, tc.in_cap, L);  // fits: the plan checked
+    (void)bc_stage_tile<false, MASK>(P, cur, last_lane, lane, s_in, tc.in_cap, L);  // fits: the plan checked
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // the name checks of every iteration, kept or not (the reference makes them first, src/fastq_pre_barcodes.c:606-635)
+    bc_report_finding(call, valid && mate1, k, valid && mate1 ? bc_check_names<true, MASK>(P, L) : 0u);
     const bool keep = valid && cur.st == kBcKeep;
     BcTags t;
     bc_tags_of_kept<MASK>(P, L, &t);
@@ -1031,7 +1117,8 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
       const SamGeom g = bc_sam_geom(sliced, mate1 ? P.read_off[1] : P.read_off[2], mate1 ? P.read_size[1] : P.read_size[2],
                                     mate1, own);
       const unsigned long number = P.first_read_number + k + 1;
-      const uint32_t my_len = keep ? bc_sam_line_len(number, bc_sam_flag(se, mate1), g, t) : 0u;
+      // (single-end: the line's length is what the plan computed for the iteration; two mates share that number)
+      const uint32_t my_len = !keep ? 0u : (lpi == 1 ? cur.olen[0] : bc_sam_line_len(number, bc_sam_flag(se, mate1), g, t));
       const unsigned long long tile_at = rfl64(cur.where[0]);
       const uint32_t before = __shfl_up(my_len, 1, 64);
       const uint32_t start = (uint32_t)(cur.where[0] - tile_at) + (mate1 ? 0u : before);
@@ -1052,7 +1139,7 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
         if (!P.emit[which]) continue;
         const EmitOut& o = which == 1 ? o1 : o2;
         const bool sliced = bc_slices(P, which);
-        const uint32_t my_len = keep ? bc_fastq_len(sliced, P.read_off[which], P.read_size[which], L[which], t) : 0u;
+        const uint32_t my_len = keep ? cur.olen[which] : 0u;
         const unsigned long long tile_at = rfl64(cur.where[which]);
         const uint32_t start = (uint32_t)(cur.where[which] - tile_at);
         const uint32_t total = wave_max32(start + my_len);
@@ -1076,14 +1163,19 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
 __global__ __launch_bounds__(kBlock) void k_bc_emit_direct(BcParams P, BcTile tc, uint64_t n_done,
                                                            const uint8_t* __restrict__ status,
                                                            const uint8_t* __restrict__ tile_big, EmitOut o0, EmitOut o1,
-                                                           EmitOut o2) {
+                                                           EmitOut o2, BcCall* __restrict__ call) {
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const int lane = (int)(threadIdx.x & 63), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool se = !P.f[2].present;
   for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + wv; k < n_done; k += n_waves) {
-    if (!tile_big[k / tc.T] || status[k] != kBcKeep) continue;
+    if (!tile_big[k / tc.T]) continue;
     BcLine L[kBcFiles][4];
     bc_lines_all(P, k, L);
+    {  // the name checks (every lane the same bytes, from the images)
+      const uint32_t finding = bc_check_names<false>(P, L);
+      if (finding && lane == 0) atomicMin(&call->first_finding, (unsigned long long)((k << 8) | finding));
+    }
+    if (status[k] != kBcKeep) continue;
     BcTags t;
     bc_tags_of_kept(P, L, &t);
     if (P.out_sam) {

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, 
     for (uint32_t j = 0; j * tc.T < Tn; ++j) {  // the emit tiles inside this plan tile
       const uint32_t first = j * tc.T, last = (first + tc.T < Tn ? first + tc.T : Tn) - 1;
       const uint32_t sum = wave_sum32((uint32_t)lane >= first && (uint32_t)lane <= last ? n : 0u);
-      const bool fits_in = bc_emit_tile_fits<0x02>(F, cur, (int)first, (int)last, false, tc.in_cap);
+      const bool fits_in = bc_emit_tile_fits<0x02>(F, cur, (int)first, (int)last, tc.in_cap);
       if (lane == 0) {
         const bool big = !fits_in || sum + 32 > tc.out_cap;
         tile_big[tile * tc.plan_m + j] = big ? 1 : 0;

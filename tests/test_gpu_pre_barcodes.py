@@ -337,3 +337,110 @@ def test_quality_line_shorter_than_the_barcode_range(extra, env):
         assert strip_progress(err) == strip_progress(want["stderr"])
         if "o.fastq.gz" in args:
             assert gunzip_file(os.path.join(d, "o.fastq.gz")) == want["files"][1].decode("latin-1")
+
+
+# ---- the name checks (made by the emit kernels): what the word-wise agreement test accepts, and what it hands over to
+# the exact comparison ----
+def _pairs_with_names(rng, names):
+    """two files of 26 bp / 60 bp reads whose k-th headers are names[k] = (header of file 1, header of file 2)"""
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    f1, f2 = [], []
+    for h1, h2 in names:
+        s1 = bases[rng.integers(0, 4, 26)].tobytes()
+        s2 = bases[rng.integers(0, 4, 60)].tobytes()
+        q1 = (rng.integers(20, 41, 26) + 33).astype(np.uint8).tobytes()
+        q2 = (rng.integers(20, 41, 60) + 33).astype(np.uint8).tobytes()
+        f1.append(b"@" + h1 + b"\n" + s1 + b"\n+\n" + q1 + b"\n")
+        f2.append(b"@" + h2 + b"\n" + s2 + b"\n+\n" + q2 + b"\n")
+    return b"".join(f1), b"".join(f2)
+
+
+def _casava_names(n):
+    """names of every length 1..70 (differences and blanks at every place of an 8-byte word), all agreeing"""
+    out = []
+    for i in range(n):
+        stem = (b"N%dx" % i) + b"ABCDEFGHIJ" * 8
+        stem = stem[: 1 + i % 70]
+        kind = i % 7
+        if kind == 0:
+            out.append((stem + b" 1:N:0:AC", stem + b" 2:N:0:AC"))           # the usual pair
+        elif kind == 1:
+            out.append((stem + b" 1:N:0:AC", stem + b" 1:N:0:AC"))           # the same line
+        elif kind == 2:
+            out.append((stem + b" 1:N:0:AC", stem + b" 1:Y:0:AC"))           # they differ behind the first field
+        elif kind == 3:
+            out.append((stem + b" 1:N:0:AC", stem + b" 2"))                  # a short second header
+        elif kind == 4:
+            out.append((stem + b"/1 1:N:0:AC", stem + b"/2 2:N:0:AC"))       # "/x" in front of the blank is dropped
+        elif kind == 5:
+            out.append((stem + b" z 1:N:0", stem + b" y 1:N:0"))             # a blank, then a difference
+        else:
+            out.append((stem + b" 1:N:0:AC", stem + b"  2:N:0:AC"))          # two blanks
+    return out
+
+
+@pytest.mark.parametrize("env", [None, {"FQGPU_BC_LDS": "4096"}], ids=["default", "tiny_tiles"])
+@pytest.mark.parametrize("extra", [["--sam", "--outfile1", "-"], ["--outfile1", "o.fastq.gz"]], ids=["sam", "fastq"])
+def test_names_that_agree_in_every_shape(extra, env):
+    rng = np.random.default_rng(77)
+    names = _casava_names(1400)
+    r2, r1 = _pairs_with_names(rng, names)  # (file of --read1 first)
+    files = {"r1.fastq": r1, "r2.fastq": r2}
+    args = V2 + extra
+    with tempfile.TemporaryDirectory() as d:
+        for name, img in files.items():
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img)
+        rc, out, err = run(BIN, args, d, env)
+        want = pbo.run_pre_barcodes(args, lambda n: files[n])
+        assert rc == want["exit"] == 0, err[-300:]
+        assert out == want["stdout"]
+        assert strip_progress(err) == strip_progress(want["stderr"])
+        if "o.fastq.gz" in args:
+            assert gunzip_file(os.path.join(d, "o.fastq.gz")) == want["files"][1].decode("latin-1")
+
+
+MISMATCHES = {
+    "last_character_of_the_name": (b"RUN:7:12345 1:N:0:AC", b"RUN:7:12346 2:N:0:AC"),
+    "first_character": (b"RUN:7:12345 1:N:0:AC", b"SUN:7:12345 2:N:0:AC"),
+    "one_is_a_prefix": (b"RUN:7:12345 1:N:0:AC", b"RUN:7:1234 1:N:0:AC"),
+    "longer_second_name": (b"RUN:7:12345 1:N:0:AC", b"RUN:7:123456 1:N:0:AC"),
+    "ninth_character": (b"RUN:7:12345:AAAA 1:N:0:AC", b"RUN:7:12X45:AAAA 1:N:0:AC"),
+    "slash_suffix_differs_in_the_name": (b"RUN:7:12345/1 1:N:0:AC", b"RUN:7:12355/2 2:N:0:AC"),
+    "no_blank_in_either": (b"RUN:7:12345", b"RUN:7:12346"),
+    # (a header without a blank keeps its '\n' in the name, src/fastq.c:502-511: it never equals one with a blank)
+    "second_header_ends_with_the_name": (b"RUN:7:12345 1:N:0:AC", b"RUN:7:12345"),
+    "wrong_header_second_file": (b"RUN:7:12345 1:N:0:AC", None),
+}
+
+
+@pytest.mark.parametrize("env", [None, {"FQGPU_BC_LDS": "4096"}], ids=["default", "tiny_tiles"])
+@pytest.mark.parametrize("shape", sorted(MISMATCHES))
+def test_names_that_do_not_agree(shape, env):
+    """the first iteration whose names differ stops the program, discards in front of it are counted, what was printed
+    in front of it is printed"""
+    rng = np.random.default_rng(sum(map(ord, shape)))
+    names = _casava_names(700)
+    names[433] = MISMATCHES[shape] if MISMATCHES[shape][1] is not None else (MISMATCHES[shape][0], MISMATCHES[shape][0])
+    names[600] = (b"LATER:1 1:N:0:AC", b"LATER:2 1:N:0:AC")  # a later one does not matter
+    r2, r1 = _pairs_with_names(rng, names)
+    if MISMATCHES[shape][1] is None:
+        l1 = r1.split(b"\n")
+        l1[4 * 433] = b"RUN:7:12345 1:N:0:AC"  # no '@'
+        r1 = b"\n".join(l1)
+    # a low base quality in a barcode in front of the finding (a discard) and behind it
+    for rec in (100, 500):
+        l1 = r1.split(b"\n")
+        l1[4 * rec + 3] = b"!" + l1[4 * rec + 3][1:]
+        r1 = b"\n".join(l1)
+    files = {"r1.fastq": r1, "r2.fastq": r2}
+    args = V2 + ["--sam", "--outfile1", "-"]
+    with tempfile.TemporaryDirectory() as d:
+        for name, img in files.items():
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img)
+        rc, out, err = run(BIN, args, d, env)
+        want = pbo.run_pre_barcodes(args, lambda n: files[n])
+        assert rc == want["exit"] == 3, err[-300:]
+        assert out == want["stdout"]
+        assert strip_progress(err) == strip_progress(want["stderr"])
