@@ -842,6 +842,11 @@ struct Writer {
     for (uint32_t i = lane; i < n; i += kWave) p[i] = s[i] == ' ' ? (uint8_t)'@' : s[i];
     p += n;
   }
+  __device__ __forceinline__ void bytes_twice(const uint8_t* s, uint32_t n, uint32_t dist) {
+    for (uint32_t i = lane; i < n; i += kWave) p[i] = p[dist + i] = s[i];
+    p += n;
+  }
+  __device__ __forceinline__ void skip(uint32_t n) { p += n; }
 };
 
 // one lane writes one text (k_bc_emit_tile: sources and destination are LDS, at any alignment).
@@ -892,45 +897,59 @@ struct LaneWriter {
     const uint64_t z = bytes_eq(x, (uint8_t)' ');  // ' ' 0x20 -> '@' 0x40
     return x ^ ((z >> 1) | (z >> 2));
   }
-  template <bool NAME>
-  __device__ __forceinline__ void copy(const uint8_t* s, uint32_t n) {
+  // TWICE: the same bytes also go to p + dist (the SAM line prints the quality string twice)
+  template <bool NAME, bool TWICE = false>
+  __device__ __forceinline__ void copy(const uint8_t* s, uint32_t n, uint32_t dist = 0) {
+    auto st8 = [&](uint32_t at, uint64_t v) {
+      if (NAME) v = at_for_blank(v);
+      __builtin_memcpy(p + at, &v, 8);
+      if (TWICE) __builtin_memcpy(p + dist + at, &v, 8);
+    };
     if (n >= 8) {
       uint32_t i = 0;
-      for (; i + 16 <= n; i += 16) {
-        uint64_t a = ld8(s + i), b = ld8(s + i + 8);
-        if (NAME) a = at_for_blank(a), b = at_for_blank(b);
-        __builtin_memcpy(p + i, &a, 8);
-        __builtin_memcpy(p + i + 8, &b, 8);
+      // (the wavefront waits for every LDS round trip: four reads are in flight per trip while the piece is long)
+      for (; i + 32 <= n; i += 32) {
+        const uint64_t a = ld8(s + i), b = ld8(s + i + 8), c = ld8(s + i + 16), d = ld8(s + i + 24);
+        st8(i, a);
+        st8(i + 8, b);
+        st8(i + 16, c);
+        st8(i + 24, d);
+      }
+      if (i + 16 <= n) {
+        const uint64_t a = ld8(s + i), b = ld8(s + i + 8);
+        st8(i, a);
+        st8(i + 8, b);
+        i += 16;
       }
       if (i + 8 <= n) {
-        uint64_t a = ld8(s + i);
-        if (NAME) a = at_for_blank(a);
-        __builtin_memcpy(p + i, &a, 8);
+        st8(i, ld8(s + i));
         i += 8;
       }
-      if (i < n) {  // the last 8 bytes again: they overlap what is already there with the same values
-        uint64_t a = ld8(s + n - 8);
-        if (NAME) a = at_for_blank(a);
-        __builtin_memcpy(p + n - 8, &a, 8);
-      }
+      if (i < n) st8(n - 8, ld8(s + n - 8));  // the last 8 bytes again: they overlap what is already there with the same values
     } else if (n) {
       uint64_t a = ld8(s);  // the sources have 8 bytes of slack
       if (NAME) a = at_for_blank(a);
-      uint32_t done = 0;
-      if (n & 4) {
-        const uint32_t w = (uint32_t)a;
-        __builtin_memcpy(p, &w, 4);
-        done = 4;
+#pragma unroll
+      for (int rep = 0; rep < (TWICE ? 2 : 1); ++rep) {
+        uint8_t* q = p + (rep ? dist : 0u);
+        uint32_t done = 0;
+        if (n & 4) {
+          const uint32_t w = (uint32_t)a;
+          __builtin_memcpy(q, &w, 4);
+          done = 4;
+        }
+        if (n & 2) {
+          const uint16_t w = (uint16_t)(a >> (8 * done));
+          __builtin_memcpy(q + done, &w, 2);
+          done += 2;
+        }
+        if (n & 1) q[done] = (uint8_t)(a >> (8 * done));
       }
-      if (n & 2) {
-        const uint16_t w = (uint16_t)(a >> (8 * done));
-        __builtin_memcpy(p + done, &w, 2);
-        done += 2;
-      }
-      if (n & 1) p[done] = (uint8_t)(a >> (8 * done));
     }
     p += n;
   }
+  __device__ __forceinline__ void bytes_twice(const uint8_t* s, uint32_t n, uint32_t dist) { copy<false, true>(s, n, dist); }
+  __device__ __forceinline__ void skip(uint32_t n) { p += n; }
   __device__ __forceinline__ void bytes(const uint8_t* s, uint32_t n) { copy<false>(s, n); }
   __device__ __forceinline__ void name(const uint8_t* s, uint32_t n) { copy<true>(s, n); }
   __device__ __forceinline__ void ch(char c) {
@@ -1003,11 +1022,11 @@ __device__ __forceinline__ void bc_emit_sam_line(const BcParams& P, unsigned lon
   w.ch('\t');
   w.bytes(ln[1].p + g.cs.from, g.seq_n);
   w.ch('\t');
-  w.bytes(ln[3].p + g.cq.from, g.qual_n);
+  w.bytes_twice(ln[3].p + g.cq.from, g.qual_n, g.qual_n + 6 + g.name_n + 6);  // the QUAL column and the op:Z: value
   BC_LIT(w, "\ton:Z:");
   w.name(ln[0].p + 1, g.name_n);
   BC_LIT(w, "\top:Z:");
-  w.bytes(ln[3].p + g.cq.from, g.qual_n);
+  w.skip(g.qual_n);
   if (t.n[0]) {
     if (P.tenx) BC_LIT(w, "\tUB:Z:"); else BC_LIT(w, "\tRX:Z:");
     w.bytes(t.s[0], t.n[0]);
