@@ -475,12 +475,18 @@ __device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) {
 // while the current one is copied and processed); the second is one loop over the 16-byte units of
 // all files together, 8 loads in flight per lane.  Units are aligned on the image ADDRESS, so a unit
 // always holds at least one byte of the image and never leaves its page.
+// (Nothing is computed from the loaded values where they are requested - no select, no addition: an instruction that
+// reads them there is a wait for the memory round trip there.  The requests of a tile are made one tile ahead.)
 struct BcGeo {
-  uint64_t prev, e[4];  // line ends of the lane's record and of the line before it
+  uint64_t praw, e[4];  // line ends of the lane's record, and of the line before it (record 0: its own first line end, unused)
+  uint32_t r0;          // the lane's record is record 0 of its file
+  __device__ __forceinline__ uint64_t start() const { return r0 ? 0ull : praw + 1; }  // first byte of the record
 };
 struct TileGeo {
   BcGeo f[kBcFiles];
-  unsigned long long where[3];  // emit: the iteration's place in each output
+  // emit: the iteration's place in each output is off + sum (added where it is used: an addition inside the function
+  // that requests the loads would make the wavefront wait for them there)
+  unsigned long long off[3], sum[3];
   uint32_t olen[3];             // emit: ... and the bytes it has there (what the plan computed)
   uint8_t st;                   // emit: status
   uint8_t big;                  // emit: tile flag
@@ -488,7 +494,8 @@ struct TileGeo {
 __device__ __forceinline__ void bc_geo_load(const BcFile& f, uint64_t k, BcGeo& g) {
   const uint64_t r = f.first + k * f.step + f.add;
   const uint64_t* __restrict__ le = f.fv.line_end + 4 * r;
-  g.prev = r == 0 ? ~0ull : le[-1];
+  g.r0 = r == 0 ? 1u : 0u;
+  g.praw = le[r == 0 ? 0 : -1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) g.e[i] = le[i];
 }
@@ -502,66 +509,108 @@ __device__ __forceinline__ bool bc_staged(const BcParams& P, int x) {
   return true;
 }
 
-// Copies the spans into s_in and gives the lane its lines (pointers into LDS).  Returns false
-// (uniformly, before copying anything) when the spans do not fit in_cap.
-template <bool PLAN, int MASK>
-__device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& tg, int last_lane, int lane, uint8_t* s_in,
-                                              uint32_t in_cap, BcLine (&L)[kBcFiles][4]) {
+// Where the spans of a tile lie: the tile's records of every staged file are one byte span, cut into 16-byte units
+// aligned on the image ADDRESS; the units of all files are numbered through.
+struct SpanPlan {
   const uint8_t* gbase[kBcFiles];  // address of the file's unit 0 minus 16 * its first unit number
   uint32_t first_unit[kBcFiles], skew[kBcFiles];
   uint64_t s0[kBcFiles];
-  uint32_t units = 0;
-  bool fit = true;
+  uint32_t units;
+  bool fit;  // the spans fit in_cap
+};
+template <bool PLAN, int MASK>
+__device__ __forceinline__ void bc_span_plan(const BcParams& P, const TileGeo& tg, int last_lane, uint32_t in_cap, SpanPlan& sp) {
+  sp.units = 0;
+  sp.fit = true;
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x) {
-    first_unit[x] = 0xFFFFFFFFu;  // never selected
-    gbase[x] = P.f[1].fv.img;
+    sp.first_unit[x] = 0xFFFFFFFFu;  // never selected
+    sp.gbase[x] = P.f[1].fv.img;
+    sp.skew[x] = 0;
+    sp.s0[x] = 0;
     if (!bc_staged<PLAN, MASK>(P, x)) continue;
     const BcFile& f = P.f[x];
-    s0[x] = rfl64(tg.f[x].prev + 1);
+    sp.s0[x] = rfl64(tg.f[x].start());
     const uint64_t e3l = rl64(tg.f[x].e[3], last_lane);
-    const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - s0[x];
-    skew[x] = (uint32_t)((uintptr_t)(f.fv.img + s0[x]) & 15u);
-    first_unit[x] = units;
-    gbase[x] = f.fv.img + s0[x] - skew[x] - 16ull * units;
-    if (n > (uint64_t)in_cap) fit = false;
-    else units += (skew[x] + (uint32_t)n + 15u) >> 4;
-    if ((uint64_t)units * 16u + 32u > (uint64_t)in_cap) fit = false;
+    const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - sp.s0[x];
+    sp.skew[x] = (uint32_t)((uintptr_t)(f.fv.img + sp.s0[x]) & 15u);
+    sp.first_unit[x] = sp.units;
+    sp.gbase[x] = f.fv.img + sp.s0[x] - sp.skew[x] - 16ull * sp.units;
+    if (n > (uint64_t)in_cap) sp.fit = false;
+    else sp.units += (sp.skew[x] + (uint32_t)n + 15u) >> 4;
+    if ((uint64_t)sp.units * 16u + 32u > (uint64_t)in_cap) sp.fit = false;
   }
-  if (!fit) return false;
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  for (uint32_t u0 = 0; u0 < units; u0 += 8 * kWave) {
-    u32x4 v[8];
+}
+typedef uint32_t bc_u32x4 __attribute__((ext_vector_type(4)));
+// unit u of a tile (clamped to the tile's last unit: no branch, every load of a round in flight)
+__device__ __forceinline__ bc_u32x4 bc_span_unit(const SpanPlan& sp, uint32_t u) {
+  u = u < sp.units ? u : (sp.units ? sp.units - 1 : 0u);  // (no unit at all: unit 0 of READ1's image, never stored)
+  const uint8_t* base = sp.gbase[1];  // (the staged file that comes first has first_unit 0: READ1, or the loop finds it)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      uint32_t u = u0 + j * kWave + lane;
-      u = u < units ? u : units - 1;  // clamped: no branch, all 8 in flight
-      const uint8_t* base = gbase[1];  // file 1 is always there and always first
+  for (int x = 2; x < kBcFiles; ++x) base = u >= sp.first_unit[x] ? sp.gbase[x] : base;
+  return __builtin_nontemporal_load(reinterpret_cast<const bc_u32x4*>(base + 16ull * u));
+}
+// units from_unit .. of the tile -> s_in, 8 loads in flight per lane
+__device__ __forceinline__ void bc_span_copy(const SpanPlan& sp, uint32_t from_unit, int lane, uint8_t* s_in) {
+  for (uint32_t u0 = from_unit; u0 < sp.units; u0 += 8 * kWave) {
+    bc_u32x4 v[8];
 #pragma unroll
-      for (int x = 2; x < kBcFiles; ++x) base = u >= first_unit[x] ? gbase[x] : base;
-      v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + 16ull * u));
-    }
+    for (int j = 0; j < 8; ++j) v[j] = bc_span_unit(sp, u0 + j * kWave + lane);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t u = u0 + j * kWave + lane;
-      if (u < units) *reinterpret_cast<u32x4*>(s_in + 16u * u) = v[j];
+      if (u < sp.units) *reinterpret_cast<bc_u32x4*>(s_in + 16u * u) = v[j];
     }
   }
+}
+// the lane's lines: pointers into the staged spans (a file that is not staged: the lengths of its lines, no bytes -
+// pointers that are never followed)
+template <bool PLAN, int MASK>
+__device__ __forceinline__ void bc_span_lines(const BcParams& P, const TileGeo& tg, const SpanPlan& sp, uint8_t* s_in,
+                                              BcLine (&L)[kBcFiles][4]) {
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x) {
     if (!bc_has<MASK>(P, x)) continue;
     const BcGeo& g = tg.f[x];
     const uint64_t nb = P.f[x].fv.nbytes;
-    // (a file that is not staged: the lengths of its lines, no bytes - pointers that are never followed)
     const bool st = bc_staged<PLAN, MASK>(P, x);
-    uint8_t* b = st ? s_in + 16u * first_unit[x] + skew[x] : s_in;
-    if (!st) s0[x] = g.prev + 1;
-    L[x][0] = BcLine{b + (uint32_t)(g.prev + 1 - s0[x]), (uint32_t)(g.e[0] - g.prev - 1), g.e[0] < nb ? 1u : 0u};
-    L[x][1] = BcLine{b + (uint32_t)(g.e[0] + 1 - s0[x]), (uint32_t)(g.e[1] - g.e[0] - 1), g.e[1] < nb ? 1u : 0u};
-    L[x][2] = BcLine{b + (uint32_t)(g.e[1] + 1 - s0[x]), (uint32_t)(g.e[2] - g.e[1] - 1), g.e[2] < nb ? 1u : 0u};
-    L[x][3] = BcLine{b + (uint32_t)(g.e[2] + 1 - s0[x]), (uint32_t)(g.e[3] - g.e[2] - 1), g.e[3] < nb ? 1u : 0u};
+    uint8_t* b = st ? s_in + 16u * sp.first_unit[x] + sp.skew[x] : s_in;
+    const uint64_t s0 = st ? sp.s0[x] : g.start();
+    L[x][0] = BcLine{b + (uint32_t)(g.start() - s0), (uint32_t)(g.e[0] - g.start()), g.e[0] < nb ? 1u : 0u};
+    L[x][1] = BcLine{b + (uint32_t)(g.e[0] + 1 - s0), (uint32_t)(g.e[1] - g.e[0] - 1), g.e[1] < nb ? 1u : 0u};
+    L[x][2] = BcLine{b + (uint32_t)(g.e[1] + 1 - s0), (uint32_t)(g.e[2] - g.e[1] - 1), g.e[2] < nb ? 1u : 0u};
+    L[x][3] = BcLine{b + (uint32_t)(g.e[2] + 1 - s0), (uint32_t)(g.e[3] - g.e[2] - 1), g.e[3] < nb ? 1u : 0u};
   }
+}
+
+// Copies the spans into s_in and gives the lane its lines (pointers into LDS).  Returns false
+// (uniformly, before copying anything) when the spans do not fit in_cap.
+template <bool PLAN, int MASK>
+__device__ __forceinline__ bool bc_stage_tile(const BcParams& P, const TileGeo& tg, int last_lane, int lane, uint8_t* s_in,
+                                              uint32_t in_cap, BcLine (&L)[kBcFiles][4]) {
+  SpanPlan sp;
+  bc_span_plan<PLAN, MASK>(P, tg, last_lane, in_cap, sp);
+  if (!sp.fit) return false;
+  bc_span_copy(sp, 0, lane, s_in);
+  bc_span_lines<PLAN, MASK>(P, tg, sp, s_in, L);
   return true;
+}
+
+// The emit kernel requests the first kSpanPf * 64 units of a tile (10 KiB: every tile of the default LDS budget) as
+// straight-line code - a loop makes the compiler wait for every request in flight where the loop begins, the next
+// tile's index among them.
+constexpr int kSpanPf = 10;
+__device__ __forceinline__ void bc_span_fetch(const SpanPlan& sp, int lane, bc_u32x4 (&v)[kSpanPf]) {
+#pragma unroll
+  for (int j = 0; j < kSpanPf; ++j) v[j] = bc_span_unit(sp, (uint32_t)(j * kWave + lane));
+}
+__device__ __forceinline__ void bc_span_land(const SpanPlan& sp, int lane, const bc_u32x4 (&v)[kSpanPf], uint8_t* s_in) {
+#pragma unroll
+  for (int j = 0; j < kSpanPf; ++j) {
+    const uint32_t u = (uint32_t)(j * kWave + lane);
+    if (u < sp.units) *reinterpret_cast<bc_u32x4*>(s_in + 16u * u) = v[j];
+  }
+  bc_span_copy(sp, kSpanPf * kWave, lane, s_in);  // (larger tiles: the rest now)
 }
 
 // Would the records of the iterations held by lanes first_lane .. last_lane fit the input area of ONE emit
@@ -575,7 +624,7 @@ __device__ __forceinline__ bool bc_emit_tile_fits(const BcParams& P, const TileG
   for (int x = 1; x < kBcFiles; ++x) {
     if (!bc_has<MASK>(P, x)) continue;
     const BcFile& f = P.f[x];
-    const uint64_t s0 = rl64(tg.f[x].prev + 1, first_lane);
+    const uint64_t s0 = rl64(tg.f[x].start(), first_lane);
     const uint64_t e3l = rl64(tg.f[x].e[3], last_lane);
     const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - s0;
     const uint32_t skew = (uint32_t)((uintptr_t)(f.fv.img + s0) & 15u);
@@ -1098,25 +1147,37 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
     for (int x = 1; x < kBcFiles; ++x)
       if (bc_has<MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
     if (SAM) {
-      tg.where[0] = o0.off[k] + o0.sum[k / kScan64Span];
-      tg.olen[0] = o0.len[k];
+      tg.off[0] = o0.off[k], tg.sum[0] = o0.sum[k / kScan64Span], tg.olen[0] = o0.len[k];
     } else {
-      if (P.emit[1]) tg.where[1] = o1.off[k] + o1.sum[k / kScan64Span], tg.olen[1] = o1.len[k];
-      if (P.emit[2]) tg.where[2] = o2.off[k] + o2.sum[k / kScan64Span], tg.olen[2] = o2.len[k];
+      if (P.emit[1]) tg.off[1] = o1.off[k], tg.sum[1] = o1.sum[k / kScan64Span], tg.olen[1] = o1.len[k];
+      if (P.emit[2]) tg.off[2] = o2.off[k], tg.sum[2] = o2.sum[k / kScan64Span], tg.olen[2] = o2.len[k];
     }
   };
   TileGeo cur, nxt;
   if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur = nxt) {
-    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);  // in flight during this tile
-    if (__builtin_amdgcn_readfirstlane((int)cur.big)) continue;
     const uint64_t k0 = tile * tc.T;
     const uint32_t Tn = tile_size(tile);
     const bool valid = it_raw < Tn;
     const uint64_t k = k0 + (valid ? it_raw : Tn - 1);
     const int last_lane = (int)((Tn - 1) * lpi);
+    // Requests in this order, nothing but requests in between: the first 10 KiB of this tile's spans (registers), then
+    // the next tile's index (it stays in flight while this tile is written and is looked at when the tile is done).
+    // Both without a branch - a value that is loaded on one path only is copied where the paths meet, which is a wait
+    // for it there: a tile that does not fit fetches (and drops) what its clamped plan says, the last tile requests
+    // its own index again.
+    // (The kernel for any set of files, MASK 0, has no registers for this: it copies the spans in the loop.)
+    constexpr bool kStraight = MASK != 0;
+    SpanPlan sp;
+    bc_span_plan<false, MASK>(P, cur, last_lane, tc.in_cap, sp);
+    bc_u32x4 pf[kSpanPf];
+    if (kStraight) bc_span_fetch(sp, lane, pf);
+    geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);
+    if (__builtin_amdgcn_readfirstlane((int)cur.big)) continue;
     BcLine L[kBcFiles][4];
-    (void)bc_stage_tile<false, MASK>(P, cur, last_lane, lane, s_in, tc.in_cap, L);  // fits: the plan checked
+    if (kStraight) bc_span_land(sp, lane, pf, s_in);  // (fits: the plan checked)
+    else bc_span_copy(sp, 0, lane, s_in);
+    bc_span_lines<false, MASK>(P, cur, sp, s_in, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the name checks of every iteration, kept or not (the reference makes them first, src/fastq_pre_barcodes.c:606-635)
@@ -1138,9 +1199,10 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
       const unsigned long number = P.first_read_number + k + 1;
       // (single-end: the line's length is what the plan computed for the iteration; two mates share that number)
       const uint32_t my_len = !keep ? 0u : (lpi == 1 ? cur.olen[0] : bc_sam_line_len(number, bc_sam_flag(se, mate1), g, t));
-      const unsigned long long tile_at = rfl64(cur.where[0]);
+      const unsigned long long where = cur.off[0] + cur.sum[0];
+      const unsigned long long tile_at = rfl64(where);
       const uint32_t before = __shfl_up(my_len, 1, 64);
-      const uint32_t start = (uint32_t)(cur.where[0] - tile_at) + (mate1 ? 0u : before);
+      const uint32_t start = (uint32_t)(where - tile_at) + (mate1 ? 0u : before);
       const uint32_t total = wave_max32(start + my_len);
       uint8_t* dst = o0.out + tile_at;
       const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
@@ -1159,8 +1221,9 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
         const EmitOut& o = which == 1 ? o1 : o2;
         const bool sliced = bc_slices(P, which);
         const uint32_t my_len = keep ? cur.olen[which] : 0u;
-        const unsigned long long tile_at = rfl64(cur.where[which]);
-        const uint32_t start = (uint32_t)(cur.where[which] - tile_at);
+        const unsigned long long where = cur.off[which] + cur.sum[which];
+        const unsigned long long tile_at = rfl64(where);
+        const uint32_t start = (uint32_t)(where - tile_at);
         const uint32_t total = wave_max32(start + my_len);
         uint8_t* dst = o.out + tile_at;
         const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kWave) void k_rf_emit_tile(BcParams F, RfParams P, 
     tg.big = tile_big[tile];
     tg.st = status[k];
     bc_geo_load(F.f[1], k, tg.f[1]);
-    tg.where[1] = o.off[k] + o.sum[k / kScan64Span];
+    tg.off[1] = o.off[k], tg.sum[1] = o.sum[k / kScan64Span];  // (added where it is used, see TileGeo)
   };
   TileGeo cur, nxt;
   if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
@@ -249,8 +249,9 @@ __global__ __launch_bounds__(kWave) void k_rf_emit_tile(BcParams F, RfParams P, 
     const bool keep = valid && !(cur.st & kRfDiscard);
     const RfCut c = rf_decide<true>(P, L[1]);
     const uint32_t my_len = keep ? rf_out_len(L[1], c) : 0u;
-    const unsigned long long tile_at = rfl64(cur.where[1]);
-    const uint32_t start = (uint32_t)(cur.where[1] - tile_at);
+    const unsigned long long where = cur.off[1] + cur.sum[1];
+    const unsigned long long tile_at = rfl64(where);
+    const uint32_t start = (uint32_t)(where - tile_at);
     const uint32_t total = wave_max32(keep ? start + my_len : 0u);
     uint8_t* dst = o.out + tile_at;
     const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
