@@ -1121,7 +1121,7 @@ struct EmitOut {
 // One wavefront per tile.  SAM: one lane per line (two per iteration for paired reads); FASTQ: one
 // lane per record, one output after the other.
 template <bool SAM, int MASK>
-__global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, uint64_t n_done,
+__global__ __launch_bounds__(kWave, 2) void k_bc_emit_tile(BcParams P, BcTile tc, uint64_t n_done,
                                                         const uint8_t* __restrict__ status,
                                                         const uint8_t* __restrict__ tile_big, EmitOut o0, EmitOut o1,
                                                         EmitOut o2, BcCall* __restrict__ call) {
@@ -1153,31 +1153,52 @@ __global__ __launch_bounds__(kWave) void k_bc_emit_tile(BcParams P, BcTile tc, u
       if (P.emit[2]) tg.off[2] = o2.off[k], tg.sum[2] = o2.sum[k / kScan64Span], tg.olen[2] = o2.len[k];
     }
   };
-  TileGeo cur, nxt;
-  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur = nxt) {
+  // Three tiles are under way per wavefront: the current tile is written while the spans of the next one (registers)
+  // and the line index of the one after it are in flight.  Every request is made without a branch and nothing is
+  // computed from a loaded value before the tile it belongs to begins - a value that is loaded on one path only is
+  // copied where the paths meet, and an instruction that reads it is a wait for it: the tile behind the last one is the
+  // last one again, a tile that does not fit LDS fetches (and drops) what its clamped plan says.
+  // (The kernel for any set of files, MASK 0, has no registers for this: it copies the spans of a tile when it gets
+  // there.)
+  constexpr bool kAhead = MASK != 0;
+  const uint64_t stride = gridDim.x;
+  auto clamp_tile = [&](uint64_t t) { return t < n_tiles ? t : n_tiles - 1; };
+  auto last_lane_of = [&](uint64_t t) { return (int)((tile_size(t) - 1) * lpi); };
+  TileGeo cur, nxt, nx2;
+  bc_u32x4 pf[kSpanPf];
+  if (blockIdx.x < n_tiles) {
+    geo_of(blockIdx.x, cur);
+    if (kAhead) {
+      geo_of(clamp_tile(blockIdx.x + stride), nxt);
+      SpanPlan sp;
+      bc_span_plan<false, MASK>(P, cur, last_lane_of(blockIdx.x), tc.in_cap, sp);
+      bc_span_fetch(sp, lane, pf);
+    }
+  }
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += stride, cur = kAhead ? nxt : nx2, nxt = nx2) {
     const uint64_t k0 = tile * tc.T;
     const uint32_t Tn = tile_size(tile);
     const bool valid = it_raw < Tn;
     const uint64_t k = k0 + (valid ? it_raw : Tn - 1);
-    const int last_lane = (int)((Tn - 1) * lpi);
-    // Requests in this order, nothing but requests in between: the first 10 KiB of this tile's spans (registers), then
-    // the next tile's index (it stays in flight while this tile is written and is looked at when the tile is done).
-    // Both without a branch - a value that is loaded on one path only is copied where the paths meet, which is a wait
-    // for it there: a tile that does not fit fetches (and drops) what its clamped plan says, the last tile requests
-    // its own index again.
-    // (The kernel for any set of files, MASK 0, has no registers for this: it copies the spans in the loop.)
-    constexpr bool kStraight = MASK != 0;
-    SpanPlan sp;
-    bc_span_plan<false, MASK>(P, cur, last_lane, tc.in_cap, sp);
-    bc_u32x4 pf[kSpanPf];
-    if (kStraight) bc_span_fetch(sp, lane, pf);
-    geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);
-    if (__builtin_amdgcn_readfirstlane((int)cur.big)) continue;
+    const bool big = __builtin_amdgcn_readfirstlane((int)cur.big) != 0;
     BcLine L[kBcFiles][4];
-    if (kStraight) bc_span_land(sp, lane, pf, s_in);  // (fits: the plan checked)
-    else bc_span_copy(sp, 0, lane, s_in);
-    bc_span_lines<false, MASK>(P, cur, sp, s_in, L);
+    {
+      SpanPlan sp;
+      bc_span_plan<false, MASK>(P, cur, last_lane_of(tile), tc.in_cap, sp);
+      if (!big) {  // (fits: the plan checked)
+        if (kAhead) bc_span_land(sp, lane, pf, s_in);
+        else bc_span_copy(sp, 0, lane, s_in);
+      }
+      bc_span_lines<false, MASK>(P, cur, sp, s_in, L);
+    }
+    if (kAhead) {
+      const uint64_t tn = clamp_tile(tile + stride);
+      SpanPlan sp;
+      bc_span_plan<false, MASK>(P, nxt, last_lane_of(tn), tc.in_cap, sp);
+      bc_span_fetch(sp, lane, pf);
+    }
+    geo_of(clamp_tile(tile + (kAhead ? 2 : 1) * stride), nx2);
+    if (big) continue;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the name checks of every iteration, kept or not (the reference makes them first, src/fastq_pre_barcodes.c:606-635)
