@@ -668,6 +668,8 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
     for (int x = 1; x < kBcFiles; ++x)
       if (bc_has<MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
   };
+  // (Many wavefronts are resident here - little LDS, ~100 registers - and hide each other's round trips: the three-tile
+  // scheme of the emit kernel, which costs 70 registers, made this kernel slower, 7.7 -> 11.2 ms.)
   TileGeo cur, nxt;
   if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
     const bool valid = (uint32_t)lane < Tn;
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
     BcLine L[kBcFiles][4];
-    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);  // the next tile's index: in flight during this tile
+    geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);  // the next tile's index (requested without a branch)
     const bool fit = bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

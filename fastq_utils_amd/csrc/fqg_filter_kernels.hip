@@ -139,16 +139,39 @@ __global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, 
     const uint32_t Tn = tile_size(tile);
     bc_geo_load(F.f[1], tile * Tp + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1), tg.f[1]);
   };
-  TileGeo cur, nxt;
-  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // three tiles under way per wavefront, every request without a branch (see k_bc_emit_tile)
+  const uint64_t stride = gridDim.x;
+  auto clamp_tile = [&](uint64_t t) { return t < n_tiles ? t : n_tiles - 1; };
+  TileGeo cur, nxt, nx2;
+  bc_u32x4 pf[kSpanPf];
+  if (blockIdx.x < n_tiles) {
+    geo_of(blockIdx.x, cur);
+    geo_of(clamp_tile(blockIdx.x + stride), nxt);
+    SpanPlan sp;
+    bc_span_plan<false, 0x02>(F, cur, (int)tile_size(blockIdx.x) - 1, plan_cap, sp);
+    bc_span_fetch(sp, lane, pf);
+  }
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += stride, cur = nxt, nxt = nx2) {
     const uint64_t k0 = tile * Tp;
     const uint32_t Tn = tile_size(tile);
     const bool valid = (uint32_t)lane < Tn;
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
-    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);
     BcLine L[kBcFiles][4];
-    const bool fit = bc_stage_tile<false, 0x02>(F, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
+    bool fit;
+    {
+      SpanPlan sp;
+      bc_span_plan<false, 0x02>(F, cur, (int)Tn - 1, plan_cap, sp);
+      fit = sp.fit;
+      if (fit) bc_span_land(sp, lane, pf, s_lds);
+      bc_span_lines<false, 0x02>(F, cur, sp, s_lds, L);
+    }
+    {
+      const uint64_t tn = clamp_tile(tile + stride);
+      SpanPlan sp;
+      bc_span_plan<false, 0x02>(F, nxt, (int)tile_size(tn) - 1, plan_cap, sp);
+      bc_span_fetch(sp, lane, pf);
+    }
+    geo_of(clamp_tile(tile + 2 * stride), nx2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     RfCut c;
@@ -180,7 +203,6 @@ __global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, 
       }
     }
     __builtin_amdgcn_wave_barrier();
-    cur = nxt;
   }
 }
 
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_rf_count(const uint8_t* __restrict__
   }
 }
 
-__global__ __launch_bounds__(kWave) void k_rf_emit_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
+__global__ __launch_bounds__(kWave, 2) void k_rf_emit_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
                                                         const uint8_t* __restrict__ status,
                                                         const uint8_t* __restrict__ tile_big, EmitOut o) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
@@ -235,15 +257,37 @@ __global__ __launch_bounds__(kWave) void k_rf_emit_tile(BcParams F, RfParams P, 
     bc_geo_load(F.f[1], k, tg.f[1]);
     tg.off[1] = o.off[k], tg.sum[1] = o.sum[k / kScan64Span];  // (added where it is used, see TileGeo)
   };
-  TileGeo cur, nxt;
-  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur = nxt) {
-    if (tile + gridDim.x < n_tiles) geo_of(tile + gridDim.x, nxt);
-    if (__builtin_amdgcn_readfirstlane((int)cur.big)) continue;
+  // three tiles under way per wavefront, every request without a branch (see k_bc_emit_tile)
+  const uint64_t stride = gridDim.x;
+  auto clamp_tile = [&](uint64_t t) { return t < n_tiles ? t : n_tiles - 1; };
+  TileGeo cur, nxt, nx2;
+  bc_u32x4 pf[kSpanPf];
+  if (blockIdx.x < n_tiles) {
+    geo_of(blockIdx.x, cur);
+    geo_of(clamp_tile(blockIdx.x + stride), nxt);
+    SpanPlan sp;
+    bc_span_plan<false, 0x02>(F, cur, (int)tile_size(blockIdx.x) - 1, tc.in_cap, sp);
+    bc_span_fetch(sp, lane, pf);
+  }
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += stride, cur = nxt, nxt = nx2) {
     const uint32_t Tn = tile_size(tile);
     const bool valid = (uint32_t)lane < Tn;
+    const bool big = __builtin_amdgcn_readfirstlane((int)cur.big) != 0;
     BcLine L[kBcFiles][4];
-    (void)bc_stage_tile<false, 0x02>(F, cur, (int)Tn - 1, lane, s_in, tc.in_cap, L);  // fits: the plan checked
+    {
+      SpanPlan sp;
+      bc_span_plan<false, 0x02>(F, cur, (int)Tn - 1, tc.in_cap, sp);
+      if (!big) bc_span_land(sp, lane, pf, s_in);  // (fits: the plan checked)
+      bc_span_lines<false, 0x02>(F, cur, sp, s_in, L);
+    }
+    {
+      const uint64_t tn = clamp_tile(tile + stride);
+      SpanPlan sp;
+      bc_span_plan<false, 0x02>(F, nxt, (int)tile_size(tn) - 1, tc.in_cap, sp);
+      bc_span_fetch(sp, lane, pf);
+    }
+    geo_of(clamp_tile(tile + 2 * stride), nx2);
+    if (big) continue;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool keep = valid && !(cur.st & kRfDiscard);

@@ -731,11 +731,11 @@ struct LinesArgs {
   uint32_t weight;
   AccState* acc;              // null: no statistics
   unsigned long long* hist;
-  int ablate;                 // measurement only (FQGPU_LINES_ABL): 1 = no line-index stores, 2 = no staged-entry loads
+  int ablate;                 // measurement only (FQGPU_LINES_ABL): 1 = no line-index stores
 };
 
 constexpr int kLinesHist = 4096;
-constexpr int kLinesPer = 2;  // records per lane and step: their staged-entry loads are in flight together (2.07 -> 1.58 ms; 4: 1.86 ms - registers; 3 does not compile with ROCm 7.2)
+constexpr int kLinesPer = 2;  // records per lane and step: their staged-entry loads are in flight together
 __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
   __shared__ uint32_t s_hist[kLinesHist];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
@@ -752,22 +752,27 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
   unsigned long long n_ok = 0, min_rl = ~0ull, max_rl = 0;
-  uint64_t nx_r0 = ~0ull;
-  uint32_t nx_cnt = 0, nx_win = 0;
-  auto window_load = [&](uint64_t step) {
-    if (step >= n_steps) return;
-    const uint64_t g = step * kLinesPer;
+  // The window of the next step is REQUESTED here and looked at when that step begins: nothing is computed from the
+  // loaded values before (no sum, no select - an instruction that reads a loaded value is where the wavefront waits for
+  // it), and the request has no branch (a lane outside the chunk table asks for the last chunk; `nx_in` says so).
+  unsigned long long nx_se = 0;
+  uint32_t nx_loc = 0, nx_cnt = 0, nx_win = 0;
+  bool nx_in = false;
+  auto window_request = [&](uint64_t step) {
+    const uint64_t g = (step < n_steps ? step : n_steps - 1) * kLinesPer;
     const uint64_t Rw = g ? 4 * g * kWave - 1 : 0;
     const double est = (double)Rw * chunks_per_line;
     uint32_t cw = est > 2.0 ? (uint32_t)(est - 2.0) : 0u;
     if (cw + kWave > A.cr.n_chunks) cw = A.cr.n_chunks > (uint32_t)kWave ? A.cr.n_chunks - kWave : 0u;
     const uint32_t cm = cw + (uint32_t)lane;
-    const bool in = cm < A.cr.n_chunks;
-    nx_r0 = in ? A.cr.rank0(cm) : ~0ull;
-    nx_cnt = in ? A.cr.counts[cm] : 0u;
+    nx_in = cm < A.cr.n_chunks;
+    const uint32_t cl = nx_in ? cm : A.cr.n_chunks - 1;
+    nx_se = A.cr.span_excl[cl / kScanSpan];
+    nx_loc = A.cr.local[cl];
+    nx_cnt = A.cr.counts[cl];
     nx_win = cw;
   };
-  window_load(wave0);
+  if (wave0 < n_steps) window_request(wave0);
   for (uint64_t step = wave0; step < n_steps; step += n_waves) {
     // e[0] = end of the line before mine, e[1..4] = ends of my four lines; ent[] = their staged entries
     uint64_t e[kLinesPer][5];
@@ -775,15 +780,15 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
     bool have[kLinesPer][5];
     // The chunks this wavefront's ranks live in: a window of 64 chunks starting a little before the estimated
     // chunk of its first rank, loaded by all lanes at once into LDS.  A lane whose rank falls outside it (reads
-    // of kilobases: few newlines per chunk) searches the chunk prefix on its own.  The window of the NEXT step is
-    // requested before this step's work, so its memory round trip is hidden.
-    s_wr0[wv][lane] = nx_r0;
-    s_wcnt[wv][lane] = nx_cnt;
+    // of kilobases: few newlines per chunk) searches the chunk prefix on its own.
+    s_wr0[wv][lane] = nx_in ? nx_se + nx_loc : ~0ull;
+    s_wcnt[wv][lane] = nx_in ? nx_cnt : 0u;
     win0 = nx_win;
-    window_load(step + n_waves);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- phase 1: where the entries are, and their loads (all kLinesPer * 5 of a lane before any is looked at) ----
+    // ---- phase 1a: where the entries are (LDS only, but for lanes outside the window) ----
+    uint64_t at[kLinesPer][5];   // index into stage[] of the entry to fetch
+    bool ld[kLinesPer][5];       // ... when there is one
 #pragma unroll
     for (int q = 0; q < kLinesPer; ++q) {
       const uint64_t g = step * kLinesPer + q;
@@ -794,19 +799,20 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
       e[q][0] = ~0ull;                 // (record 0: the line before starts at -1)
       ent[q][0] = (kClsAt << 12);      // ... and the image's first byte is checked directly below
       have[q][0] = r == 0;
+      at[q][0] = 0;
+      ld[q][0] = false;
       uint32_t c = 0, i = 0, cnt = 0;
       bool windowed = false;  // c is an index INTO the window (then counts come from LDS)
       if (R < A.n_newlines) {
-        const uint64_t* w0 = s_wr0[wv];
-        if (R >= w0[0] && (R < w0[kWave - 1] + s_wcnt[wv][kWave - 1])) {
+        if (R >= s_wr0[wv][0] && (R < s_wr0[wv][kWave - 1] + s_wcnt[wv][kWave - 1])) {
           uint32_t lo = 0, hi = kWave;  // last window entry whose first rank is <= R
           while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (w0[mid] <= R) lo = mid;
+            if (s_wr0[wv][mid] <= R) lo = mid;
             else hi = mid;
           }
           c = lo;
-          i = (uint32_t)(R - w0[lo]);
+          i = (uint32_t)(R - s_wr0[wv][lo]);
           cnt = s_wcnt[wv][lo];
           windowed = true;
         } else {
@@ -818,6 +824,8 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         if (k < k0) continue;
+        at[q][k] = 0;
+        ld[q][k] = false;
         if (R < A.n_newlines) {
           while (i >= cnt) {  // next chunk that holds a newline
             ++c;
@@ -826,10 +834,13 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
               windowed = false;
               c += win0;
             }
-            cnt = windowed ? s_wcnt[wv][c] : A.cr.counts[c];
+            if (windowed) cnt = s_wcnt[wv][c];
+            else cnt = __builtin_nontemporal_load(&A.cr.counts[c]);  // (a plain load here: the compiler merges the two into a load through a generic pointer and fails on it)
           }
           const uint32_t cg = windowed ? win0 + c : c;
-          ent[q][k] = (A.ablate & 2) ? (i * 80u) : A.stage[(uint64_t)cg * kStageCap + i];
+          at[q][k] = (uint64_t)cg * kStageCap + i;
+          ld[q][k] = true;
+          ent[q][k] = 0;
           e[q][k] = (uint64_t)cg * kChunkBytes;  // (+ the entry's offset, below)
           have[q][k] = true;
           ++i;
@@ -845,6 +856,20 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
         ++R;
       }
     }
+    // ---- phase 1b: every request of the step, nothing else: the next step's window, then the kLinesPer * 5 staged
+    // entries of the lane (a lane without an entry asks for entry 0) ----
+    window_request(step + n_waves);
+    uint16_t raw[kLinesPer][5];
+#pragma unroll
+    for (int q = 0; q < kLinesPer; ++q)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) raw[q][k] = A.stage[at[q][k]];
+#pragma unroll
+      for (int q = 0; q < kLinesPer; ++q)
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (ld[q][k]) ent[q][k] = raw[q][k];
+
     __builtin_amdgcn_wave_barrier();  // (the window is rewritten by the next step)
     // ---- phase 2: the line index, the checks, the statistics ----
 #pragma unroll
