@@ -7,6 +7,8 @@
 #   index    FETCH_SIZE / WRITE_SIZE of the default-mode extra (the name kernels) -> traffic_index_100M.json
 #   pass1sq  SQ counters of the streaming kernels (headline workload) -> pass1_sq_counters.json
 #   micro    the random-access and decode microbenchmarks -> rmwbench.txt, decbench.txt
+#   tiles    FETCH_SIZE / WRITE_SIZE of the tile kernels (fastq_pre_barcodes on 50 M pairs, the record filters on
+#            100 M reads) -> traffic_tile_kernels.json
 # Counter passes never carry another trace domain than --kernel-trace.  Summaries land in gpurun_out/<tag>/; copy what
 # is to be judged into profiles/.
 set -u
@@ -66,6 +68,15 @@ for w in $WHAT; do
     # what one random access costs on this GPU (tools/kbench/rmwbench.hip), and what decoding a capture record costs
     (cd $R/tools/kbench && timeout 300 ./rmwbench 100 30 35) > $O/rmwbench.txt 2>&1
     (cd $R/tools/kbench && timeout 120 ./decbench) > $O/decbench.txt 2>&1
+    ;;
+  tiles)
+    ONLY_TILES="--steps 2 --barcode-pairs 50000000 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra"
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/tiles_pmc_$c -o pmc -- python3 $R/bench.py $ONLY_TILES > $O/tiles_pmc_$c.json 2> $O/tiles_pmc_$c.err
+      find $O/tiles_pmc_$c -name '*kernel_trace.csv' -delete
+    done
+    python3 $R/tools/pmc_traffic.py $(find $O/tiles_pmc_FETCH_SIZE -name '*counter_collection.csv') $(find $O/tiles_pmc_WRITE_SIZE -name '*counter_collection.csv') \
+        34900000000 > $O/traffic_tile_kernels.json 2>$O/traffic_tiles.err || true
     ;;
   umistats)
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/umi_stats -o stats -- python3 $R/bench.py $ONLY_UMI > $O/umi_under_rocprof.json 2> $O/umi_under_rocprof.err
