@@ -1528,6 +1528,13 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   P.min_qual = bp->min_qual;
   P.out_sam = bp->out_sam;
   P.tenx = bp->tenx;
+  {
+    static const int abl = [] {
+      const char* e = getenv("FQGPU_BC_ABL");
+      return e ? atoi(e) : 0;
+    }();
+    P.ablate = abl;
+  }
   P.umi_off = bp->umi_offset;
   P.umi_size = bp->umi_size;
   P.cell_off = bp->cell_offset;

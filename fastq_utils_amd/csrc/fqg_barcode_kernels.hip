@@ -47,6 +47,7 @@ struct BcParams {
   int32_t umi_read, cell_read, sample_read;
   int32_t phred, min_qual;
   int32_t out_sam, tenx;
+  int32_t ablate;  // measurement only (FQGPU_BC_ABL, SAM emit): 1 = no line is written, 2 = no flush, 4 = no name check, 8 = no landing of the spans
   int32_t emit[3];
   int64_t umi_off, umi_size, cell_off, cell_size, sample_off, sample_size;
   int64_t read_off[3], read_size[3];
@@ -1107,8 +1108,9 @@ __device__ __forceinline__ void emit_flush(const uint8_t* __restrict__ buf, uint
   const uint32_t end = skew + len;
   const uint32_t first_full = (skew + 15u) & ~15u, last_full = end & ~15u;
   for (uint32_t i = skew + lane; i < (first_full < end ? first_full : end); i += kWave) g0[i] = buf[i];
+  typedef uint32_t fl_u32x4 __attribute__((ext_vector_type(4)));
   for (uint32_t u = first_full + 16u * lane; u + 16u <= last_full; u += 16u * kWave)
-    *reinterpret_cast<uint4*>(g0 + u) = *reinterpret_cast<const uint4*>(buf + u);
+    __builtin_nontemporal_store(*reinterpret_cast<const fl_u32x4*>(buf + u), reinterpret_cast<fl_u32x4*>(g0 + u));
   if (last_full >= first_full)
     for (uint32_t i = last_full + lane; i < end; i += kWave) g0[i] = buf[i];
 }
@@ -1188,7 +1190,8 @@ __global__ __launch_bounds__(kWave, 2) void k_bc_emit_tile(BcParams P, BcTile tc
       SpanPlan sp;
       bc_span_plan<false, MASK>(P, cur, last_lane_of(tile), tc.in_cap, sp);
       if (!big) {  // (fits: the plan checked)
-        if (kAhead) bc_span_land(sp, lane, pf, s_in);
+        if (P.ablate & 8) {
+        } else if (kAhead) bc_span_land(sp, lane, pf, s_in);
         else bc_span_copy(sp, 0, lane, s_in);
       }
       bc_span_lines<false, MASK>(P, cur, sp, s_in, L);
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(kWave, 2) void k_bc_emit_tile(BcParams P, BcTile tc
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the name checks of every iteration, kept or not (the reference makes them first, src/fastq_pre_barcodes.c:606-635)
-    bc_report_finding(call, valid && mate1, k, valid && mate1 ? bc_check_names<true, MASK>(P, L) : 0u);
+    if (!(P.ablate & 4)) bc_report_finding(call, valid && mate1, k, valid && mate1 ? bc_check_names<true, MASK>(P, L) : 0u);
     const bool keep = valid && cur.st == kBcKeep;
     BcTags t;
     bc_tags_of_kept<MASK>(P, L, &t);
@@ -1229,13 +1232,13 @@ __global__ __launch_bounds__(kWave, 2) void k_bc_emit_tile(BcParams P, BcTile tc
       const uint32_t total = wave_max32(start + my_len);
       uint8_t* dst = o0.out + tile_at;
       const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
-      if (keep) {
+      if (keep && !(P.ablate & 1)) {
         LaneWriter w{s_out + skew + start};
         bc_emit_sam_line(P, number, se, mate1, own, g, t, w);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      emit_flush(s_out, skew, total, dst, lane);
+      if (!(P.ablate & 2)) emit_flush(s_out, skew, total, dst, lane);
       __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
