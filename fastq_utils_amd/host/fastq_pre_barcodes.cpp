@@ -107,6 +107,8 @@ struct Source {
   uint64_t records_before = 0;  // records in earlier frames
   bool final_piece = false;
   int tail_lines = 0;
+  bool open_end = false;    // the file's last line has no '\n' and closes its last complete record: gzgets reads it up
+                            // to the end of the file, and the file is at its end for gzeof from then on
   bool exhausted = false;   // no more data will come
   bool carry_pending = false;
   size_t carry_at = 0;      // bytes of the current piece covered by complete records
@@ -160,6 +162,7 @@ bool refill(Source& s) {
                    FQG_VALIDATE_FRAME_ONLY, &r));
   s.final_piece = s.in->final();
   s.tail_lines = r.tail_lines;
+  s.open_end = s.final_piece && r.tail_lines == 0 && r.n_records > 0 && s.in->size() > 0 && s.in->data()[s.in->size() - 1] != '\n';
   s.avail = r.n_records;
   if (r.n_records) LIB(fqg_frame_retain(g_ctx, &s.frame));
   if (!s.in->final()) {
@@ -220,6 +223,7 @@ struct BlockRun {
     uint64_t records[6] = {0, 0, 0, 0, 0, 0};     // complete records of every input's block
     int tail_lines[6] = {0, 0, 0, 0, 0, 0};
     bool final[6] = {false, false, false, false, false, false};
+    bool open_end[6] = {false, false, false, false, false, false};  // see Source::open_end
     std::vector<char> out[3];
     std::string wrong_header;                     // the text of the header line of a FQG_E_WRONG_HEADER finding
   };
@@ -282,6 +286,7 @@ struct BlockRun {
           u.records[x] = r.n_records;
           u.tail_lines[x] = r.tail_lines;
           u.final[x] = b[x].final;
+          u.open_end[x] = b[x].final && r.tail_lines == 0 && r.n_records > 0 && b[x].size > 0 && b[x].data[b[x].size - 1] != '\n';
           u.n = std::min<uint64_t>(u.n, r.n_records);
           if (r.n_records) {
             const int rc2 = fqg_frame_retain(c, &held[x]);
@@ -396,8 +401,14 @@ struct BlockRun {
   }
   join_all();
   // an incomplete record where the next read would have happened is a truncated file (src/fastq.c:254-257); a clean
-  // end of any input just ends the loop.  The first input, in file order, that has nothing left decides.
+  // end of any input just ends the loop.  The first input, in file order, that has nothing left decides - unless the
+  // loop's own condition ends it first (fastq_files_eof, src/fastq_pre_barcodes.c:288-297, :594): an input whose last
+  // line has no '\n' is at its end for gzeof once that line has been read, and no input is read again.
+  bool loop_condition_ends_it = false;
   if (have_last)
+    for (int x = READ1; x <= INDEX3; ++x)
+      if (A.file[x] && last.final[x] && last.open_end[x] && last.records[x] == last.n) loop_condition_ends_it = true;
+  if (have_last && !loop_condition_ends_it)
     for (int x = READ1; x <= INDEX3; ++x)
       if (A.file[x]) {
         if (!(last.final[x] && last.records[x] == last.n)) continue;
@@ -707,8 +718,16 @@ int main(int argc, char** argv) {
       }
   }
   // an incomplete record where the next read would have happened is a truncated file
-  // (src/fastq.c:254-257); a clean end of any input just ends the loop
+  // (src/fastq.c:254-257); a clean end of any input just ends the loop - and so does the loop's own condition
+  // (fastq_files_eof, src/fastq_pre_barcodes.c:288-297, :594), before any input is read again: an input whose last line
+  // has no '\n' is at its end for gzeof once that line has been read
+  bool loop_condition_ends_it = false;
   for (int x = READ1; x <= INDEX3; ++x)
+    if (file[x]) {
+      const Source& s = src[x];
+      if (s.exhausted && s.open_end && (!s.frame || s.use == (long)s.avail)) loop_condition_ends_it = true;
+    }
+  for (int x = READ1; x <= INDEX3 && !loop_condition_ends_it; ++x)
     if (file[x]) {
       Source& s = src[x];
       const bool drained = s.exhausted && (!s.frame || s.use >= (long)s.avail);

@@ -444,3 +444,32 @@ def test_names_that_do_not_agree(shape, env):
         assert rc == want["exit"] == 3, err[-300:]
         assert out == want["stdout"]
         assert strip_progress(err) == strip_progress(want["stderr"])
+
+
+@pytest.mark.parametrize("env", [None, {"FQGPU_DEVICES": "0,0", "FQGPU_BLOCK_RECORDS": "3"}], ids=["default", "devices"])
+@pytest.mark.parametrize("open_end", [True, False], ids=["no_last_newline", "last_newline"])
+@pytest.mark.parametrize("which", ["r1", "r2"])
+def test_loop_condition_ends_the_loop_before_a_truncated_record_is_read(which, open_end, env):
+    """fastq_files_eof (src/fastq_pre_barcodes.c:288-297, :594): an input whose last line has no newline is at its end for
+    gzeof once that line is read, so the incomplete record that follows in ANOTHER input is never read; with the newline
+    the next iteration reads it and the file is truncated (tools/fuzz_campaign_programs.py, seed 930035)"""
+    rng = np.random.default_rng(930035)
+    r1, r2 = make_10x(rng, 7, 0.0, 0.0)
+    extra = b"\n".join(r2.split(b"\n")[:2]) + b"\n"   # two lines of a record that never ends
+    if which == "r1":
+        short, long_ = r1, r2 + extra
+    else:
+        short, long_ = r2, r1 + b"\n".join(r1.split(b"\n")[:2]) + b"\n"
+    if open_end:
+        short = short[:-1]
+    files = {"r1.fastq": short if which == "r1" else long_, "r2.fastq": long_ if which == "r1" else short}
+    args = V2 + ["--sam", "--outfile1", "-"]
+    with tempfile.TemporaryDirectory() as d:
+        for name, img in files.items():
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img)
+        rc, out, err = run(BIN, args, d, env)
+        want = pbo.run_pre_barcodes(args, lambda n: files[n])
+        assert rc == want["exit"], (err[-300:], want["stderr"][-300:])
+        assert out == want["stdout"]
+        assert strip_progress(err) == strip_progress(want["stderr"])
