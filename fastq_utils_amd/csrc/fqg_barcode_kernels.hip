@@ -7,11 +7,12 @@
 // Three launches per batch of iterations; plan and emit work on TILES of T consecutive iterations,
 // one wavefront per tile, whose records (contiguous in every input image) are first copied into LDS
 // with 16-byte loads:
-//   k_bc_plan_tile  one lane per iteration, reading its records from LDS: status (keep / discarded /
-//                   finding) and the exact number of output bytes of every output
+//   k_bc_plan_tile  one lane per iteration: status (keep / discarded) and the exact number of output bytes of
+//                   every output - from the line index and the bytes of the barcode-carrying files alone
 //   scan            64-bit exclusive prefix of the byte counts -> where each iteration writes
-//   k_bc_emit_tile  one lane per output line (SAM) or record (FASTQ): the lane writes its text into the
-//                   tile's LDS output area, which then goes to the output image with 16-byte stores
+//   k_bc_emit_tile  the name checks (on the headers of every file, which it stages anyway), then one lane per
+//                   output line (SAM) or record (FASTQ): the lane writes its text into the tile's LDS output
+//                   area, which then goes to the output image with 16-byte stores; three tiles under way
 // T is chosen by the host from the mean record sizes so that a tile fits its LDS areas; a tile that
 // does not fit (long reads) is flagged by the plan and handled by the slower direct paths (records read
 // from the images, one wavefront per iteration in k_bc_emit_direct).
@@ -472,10 +473,10 @@ __device__ __forceinline__ unsigned long long wave_min64(unsigned long long v) {
 // ---- tiles: the records of T consecutive iterations of every file, copied into LDS ----------------
 // Two dependent round trips to memory per tile: the line index of the tile's records (what a lane
 // needs to know its iteration's lines, and lane 0 / the last lane to know the tile's byte span),
-// then the spans themselves.  The first is issued one tile AHEAD (TileGeo of the next tile is loaded
-// while the current one is copied and processed); the second is one loop over the 16-byte units of
-// all files together, 8 loads in flight per lane.  Units are aligned on the image ADDRESS, so a unit
-// always holds at least one byte of the image and never leaves its page.
+// then the spans themselves.  The emit kernels and the record filters keep three tiles under way (index of the
+// tile after next and spans of the next tile in flight while the current one is written); the plan kernel of
+// fastq_pre_barcodes requests the next tile's index with the current tile's spans.  Units are aligned on the
+// image ADDRESS, so a unit always holds at least one byte of the image and never leaves its page.
 // (Nothing is computed from the loaded values where they are requested - no select, no addition: an instruction that
 // reads them there is a wait for the memory round trip there.  The requests of a tile are made one tile ahead.)
 struct BcGeo {
