@@ -7,6 +7,7 @@
 #   index    FETCH_SIZE / WRITE_SIZE of the default-mode extra (the name kernels) -> traffic_index_100M.json
 #   pass1sq  SQ counters of the streaming kernels (headline workload) -> pass1_sq_counters.json
 #   micro    the random-access and decode microbenchmarks -> rmwbench.txt, decbench.txt
+#   tilessq  SQ counters of the tile kernels of fastq_pre_barcodes (50 M pairs) -> tiles_sq_counters.json
 #   tiles    FETCH_SIZE / WRITE_SIZE of the tile kernels (fastq_pre_barcodes on 50 M pairs, the record filters on
 #            100 M reads) -> traffic_tile_kernels.json
 # Counter passes never carry another trace domain than --kernel-trace.  Summaries land in gpurun_out/<tag>/; copy what
@@ -68,6 +69,18 @@ for w in $WHAT; do
     # what one random access costs on this GPU (tools/kbench/rmwbench.hip), and what decoding a capture record costs
     (cd $R/tools/kbench && timeout 300 ./rmwbench 100 30 35) > $O/rmwbench.txt 2>&1
     (cd $R/tools/kbench && timeout 120 ./decbench) > $O/decbench.txt 2>&1
+    ;;
+  tilessq)
+    ONLY_BC="--reads 4000000 --steps 2 --barcode-pairs 50000000 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-filters-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra"
+    i=0
+    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+               "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+      i=$((i+1))
+      rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/bcsq/p$i -o pmc -- python3 $R/bench.py $ONLY_BC > $O/bcsq_$i.json 2> $O/bcsq_$i.err
+      find $O/bcsq/p$i -name '*kernel_trace.csv' -delete
+    done
+    python3 $R/tools/pmc_sum.py $O/bcsq k_bc_ > $O/tiles_sq_counters.json
+    find $O/bcsq -name '*counter_collection.csv' -delete
     ;;
   tiles)
     ONLY_TILES="--steps 2 --barcode-pairs 50000000 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra"
