@@ -368,7 +368,16 @@ __global__ __launch_bounds__(kBlock) void k_gather_copy(FrameView f, const unsig
         const uint8_t* __restrict__ src = f.img + rfl64(s_off);
         uint8_t* __restrict__ dst = out + rfl64(d_off);
         const uint64_t total = rl64(d_off + len, cnt - 1) - rfl64(d_off);
-        for (uint64_t o = (uint64_t)lane * 16u; o < total; o += 16u * kWave) {
+        // four pieces per lane in flight (a loop of one load and one store waits for every piece on its own)
+        uint64_t o = (uint64_t)lane * 16u;
+        for (; o + 3u * 16u * kWave + 16u <= total; o += 4u * 16u * kWave) {
+          u32x4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(src + o + (uint64_t)q * 16u * kWave);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(dst + o + (uint64_t)q * 16u * kWave) = v[q];
+        }
+        for (; o < total; o += 16u * kWave) {
           if (o + 16u <= total) *reinterpret_cast<u32x4*>(dst + o) = *reinterpret_cast<const u32x4*>(src + o);
           else
             for (uint64_t q = o; q < total; ++q) dst[q] = src[q];
