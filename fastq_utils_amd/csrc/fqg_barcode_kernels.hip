@@ -1110,7 +1110,15 @@ __device__ __forceinline__ void emit_flush(const uint8_t* __restrict__ buf, uint
   const uint32_t first_full = (skew + 15u) & ~15u, last_full = end & ~15u;
   for (uint32_t i = skew + lane; i < (first_full < end ? first_full : end); i += kWave) g0[i] = buf[i];
   typedef uint32_t fl_u32x4 __attribute__((ext_vector_type(4)));
-  for (uint32_t u = first_full + 16u * lane; u + 16u <= last_full; u += 16u * kWave)
+  uint32_t u = first_full + 16u * lane;
+  for (; u + 3u * 16u * kWave + 16u <= last_full; u += 4u * 16u * kWave) {  // four LDS reads in flight per lane
+    fl_u32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const fl_u32x4*>(buf + u + (uint32_t)q * 16u * kWave);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(v[q], reinterpret_cast<fl_u32x4*>(g0 + u + (uint32_t)q * 16u * kWave));
+  }
+  for (; u + 16u <= last_full; u += 16u * kWave)
     __builtin_nontemporal_store(*reinterpret_cast<const fl_u32x4*>(buf + u), reinterpret_cast<fl_u32x4*>(g0 + u));
   if (last_full >= first_full)
     for (uint32_t i = last_full + lane; i < end; i += kWave) g0[i] = buf[i];
