@@ -830,8 +830,35 @@ def committed_traffic(kernel, n_reads, read_len, record_bytes):
     return None, None
 
 
+def launch_ranks(n_gpus):
+    """`python3 bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as CHILDREN (this process
+    has not touched the GPU - nothing that initialises HIP is imported before this point - and never execs), relay
+    what they print and leave with the launcher's status.  With FQGPU_BENCH_ONE_DEVICE=1 all ranks share GPU 0."""
+    import socket
+
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait()
+    except BaseException:  # interrupted: take the whole group of ranks down with us
+        import signal
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        raise
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -943,8 +970,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"fastq_info -r (frame + validate + stats) on {n} synthetic {a.read_len}bp single-end "
-                            f"reads per GPU, {R} B/record, uncompressed, HBM-resident (BASELINE.json configs[1])",
+                "workload": f"HBM-resident image (host-fed rates: see host_fed): fastq_info -r (frame + validate + "
+                            f"stats), {n} synthetic {a.read_len}bp SE reads per GPU, {R} B/record (BASELINE configs[1])",
                 "reads_per_gpu": n, "read_len": a.read_len, "record_bytes": R, "path": res["path"],
             },
             "roofline": {
@@ -1114,6 +1141,17 @@ def main():
                 out["e2e"] = e2e_block(ctx, fq, torch, dev, image, n, R, st)
             except Exception as e:
                 out["e2e"] = {"error": repr(e)[:300]}
+            # SURVEY 8(d) "report two rates": `value` above is the kernel-side (HBM-resident) rate; this is the
+            # configs[1] placement - the same reads "uncompressed in host RAM" - through the C-ABI and through the program
+            abi_leg = out["e2e"].get("abi_pinned_host_image") or {}
+            cli_leg = out["e2e"].get("cli_fastq_info_r_tmpfs_file") or {}
+            out["host_fed"] = {
+                "what": "configs[1] placement: the same reads uncompressed in host RAM, fed over PCIe",
+                "abi_Mreads_per_s": abi_leg.get("Mreads_per_s"), "abi_GBps": abi_leg.get("PCIe_GBps"),
+                "cli_Mreads_per_s": cli_leg.get("Mreads_per_s"), "cli_GBps": cli_leg.get("GBps"),
+                "ceiling": "PCIe 5 x16, 63 GB/s spec = 180 Mreads/s at this record size (MI355X_MICROARCH.md)",
+                "target_Mreads_per_s": 50.0, "details": "e2e",
+            }
         if world == 1 and not a.no_filters_extra:
             try:
                 out["filters_extra"] = filters_extra(ctx, fq, torch, dev, image, n, R, st, a.read_len)

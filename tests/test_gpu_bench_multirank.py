@@ -4,12 +4,11 @@ GPU 0 over gloo (FQGPU_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on one device)
 nothing here; the line must come out once, complete, with exit status 0."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
 
-from tests.util import REPO
+from tests.util import REPO, free_port, run_group
 
 pytestmark = pytest.mark.gpu
 
@@ -18,9 +17,22 @@ pytestmark = pytest.mark.gpu
 def test_two_ranks_on_one_device(ranks):
     env = dict(os.environ, FQGPU_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
-           "127.0.0.1", "--master-port", str(29720 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+           "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
            "--reads", "2000000"]
-    p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, timeout=600)
+    check_line(run_group(cmd, 600, cwd=REPO, env=env), ranks)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher around it (the shape of the driver's 1-GPU command): bench.py
+    starts the ranks itself, as children, before it touches the GPU."""
+    env = dict(os.environ, FQGPU_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "2000000"]
+    check_line(run_group(cmd, 600, cwd=REPO, env=env), 2)
+
+
+def check_line(p, ranks):
     assert p.returncode == 0, p.stderr.decode("latin-1")[-2000:]
     lines = [ln for ln in p.stdout.decode("latin-1").splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 fq = pytest.importorskip("fastq_utils_amd")
 torch = pytest.importorskip("torch")
 from fastq_utils_amd import dist as fdist  # noqa: E402
+from tests.util import free_port  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -114,7 +115,7 @@ def test_protocol_through_a_one_rank_rccl_group(ctx):
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29631")
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:

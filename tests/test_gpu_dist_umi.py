@@ -4,7 +4,6 @@ refuses several ranks on one device), against the single-GPU result of the whole
 pins on the oracle and the reference binary."""
 import json
 import os
-import subprocess
 import sys
 import tempfile
 
@@ -14,19 +13,19 @@ import pytest
 import fastq_utils_amd as fq
 from tests import bamgen
 from tests.test_gpu_umi import split_at_cell_boundaries
-from tests.util import REPO
+from tests.util import REPO, free_port, run_group
 
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(shards, port):
+def run_ranks(shards):
     with tempfile.TemporaryDirectory() as tmp:
         np.savez(os.path.join(tmp, "shards.npz"), **{"shard%d" % k: np.frombuffer(s, dtype=np.uint8) for k, s in enumerate(shards)})
         out = os.path.join(tmp, "out.json")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(len(shards)),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "tests", "umi_shard_worker.py"),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(REPO, "tests", "umi_shard_worker.py"),
                os.path.join(tmp, "shards.npz"), out]
-        p = subprocess.run(cmd, cwd=REPO, capture_output=True, timeout=600)
+        p = run_group(cmd, 600, cwd=REPO)
         assert p.returncode == 0, p.stderr.decode("latin-1")[-3000:]
         return json.load(open(out))
 
@@ -47,7 +46,7 @@ def test_replayed_sets_across_ranks(ranks):
     assert whole["code"] == 0 and whole["rl_replayed"] >= 1
     starts = np.nonzero(np.diff(cell, prepend=-1))[0]
     cuts = [int(starts[(len(starts) * k) // ranks]) for k in range(ranks)] + [n]
-    got = run_ranks([hdr + rec[cuts[k]:cuts[k + 1]].tobytes() for k in range(ranks)], 29760 + ranks)
+    got = run_ranks([hdr + rec[cuts[k]:cuts[k + 1]].tobytes() for k in range(ranks)])
     assert [tuple(e) for e in got["entries_u"]] == whole["entries"][0]
     assert [tuple(e) for e in got["entries_r"]] == whole["entries"][1]
     assert (got["n_entries"], got["total"], got["tot_reads"], got["tot_umi"], got["rl_undefined"]) == (
@@ -60,7 +59,7 @@ def test_fractional_increments_across_ranks():
     with fq.Context(0) as ctx:
         whole = ctx.umi_count(stream)
     assert whole["code"] == 0 and not whole["unit_increments"]
-    got = run_ranks(split_at_cell_boundaries(stream, 3), 29771)
+    got = run_ranks(split_at_cell_boundaries(stream, 3))
     assert [tuple(e) for e in got["entries_u"]] == whole["entries"][0]
     assert [tuple(e) for e in got["entries_r"]] == whole["entries"][1]
     assert (got["tot_reads"], got["tot_umi"]) == (whole["tot_reads"], whole["tot_umi"])

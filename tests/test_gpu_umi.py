@@ -13,7 +13,7 @@ import pytest
 from oracle import umi_oracle as uo
 from tests import bamgen
 from tests.test_oracle_umi import GOLDEN, comparable, golden_files, want_exit
-from tests.util import GOLD, REPO
+from tests.util import GOLD, REPO, free_port
 
 pytestmark = pytest.mark.gpu
 fq = pytest.importorskip("fastq_utils_amd")
@@ -394,7 +394,7 @@ def test_sharded_protocol_through_a_one_rank_group(ctx):
     from fastq_utils_amd import dist as fdist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = "29641"
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:

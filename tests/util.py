@@ -28,3 +28,32 @@ def load_fastq_info_golden():
 def strip_progress(s):
     """Drop the PRINT_READS_PROCESSED ticker (src/fastq.h:82): 15 backspaces + a count."""
     return _PROGRESS.sub("", s)
+
+
+def free_port():
+    """A TCP port nobody listens on right now (for torch.distributed rendezvous: fixed ports collide between
+    concurrent runs and with sockets in TIME_WAIT)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_group(cmd, timeout, **kw):
+    """subprocess.run(capture_output=True) for a launcher that starts ranks of its own: the launcher runs in its
+    own process group, and on a timeout the WHOLE group is killed (a hung rank must not outlive the test)."""
+    import signal
+    import subprocess
+
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, **kw)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        raise AssertionError("timed out after %d s: %s\n%s" % (timeout, " ".join(map(str, cmd)), err.decode("latin-1")[-2000:]))
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
