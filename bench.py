@@ -1085,7 +1085,7 @@ def main():
                     p2 = ctx.profile_read()
                     ctx.profile(False)
                     acc2.close()
-                    assert os.environ.get("FQGPU_NAMES_ABL") or (r2["code"] == 0 and ir["code"] == 0 and ir["n_entries"] == n), (r2, ir)
+                    assert r2["code"] == 0 and ir["code"] == 0 and ir["n_entries"] == n, (r2, ir)
                     kern = {k: v[1] / max(1, v[0]) for k, v in p2.items() if k.startswith("k_") and v[0] > 0}
                     ki = kern.get("k_names_insert", kern.get("k_index_insert", 0.0))
                     total = sum(kern.values())

@@ -243,6 +243,12 @@ def load():
     L.fqg_fp_owner.argtypes = [u64, C.c_uint32]
     L.fqg_fp_owner.restype = C.c_uint32
     L.fqg_names_fingerprints.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, C.POINTER(u64)]
+    L.fqg_names_fingerprints_acct.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.fqg_device_alloc.argtypes = [vp, u64]
+    L.fqg_device_alloc.restype = vp  # (a pointer: the ctypes default, c_int, would cut it to 32 bits)
+    L.fqg_device_free.argtypes = [vp, vp]
+    L.fqg_device_free.restype = None
+    L.fqg_device_copy.argtypes = [vp, vp, vp, vp, u64]
     L.fqg_fpset_create.argtypes = [vp, u64, C.POINTER(vp)]
     L.fqg_fpset_destroy.argtypes = [vp]
     L.fqg_fpset_destroy.restype = None

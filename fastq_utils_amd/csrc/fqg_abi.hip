@@ -47,6 +47,31 @@ struct ProfSlot {
   double ms = 0;
 };
 
+// Ablation switches (FQGPU_LINES_ABL, FQGPU_NAMES_ABL, FQGPU_BC_ABL, FQGPU_UMI_INSERT_ABL: kernels that skip a part
+// of their work and give knowingly WRONG results, for tools/*_abl.sh) exist only in a library built with
+// -DFQG_MEASURE (`make MEASURE=1`).  The shipped library does not read these variables at all: a drop-in program
+// that inherits one of them must not change what it computes.
+// (the "every record met once" self-checks are never bypassed in the shipped library)
+inline bool measured_wrong(int ablate) {
+#ifdef FQG_MEASURE
+  return ablate != 0;
+#else
+  (void)ablate;
+  return false;
+#endif
+}
+inline int measure_int(const char* name) {
+#ifdef FQG_MEASURE
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v) fprintf(stderr, "libfqgpu (FQG_MEASURE build): %s=%d - results of this call are NOT valid\n", name, v);
+  return v;
+#else
+  (void)name;
+  return 0;
+#endif
+}
+
 }  // namespace
 
 struct fqg_ctx {
@@ -709,7 +734,7 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     A.weight = rd.weight;
     A.acc = rd.acc;
     A.hist = rd.hist;
-    static const int lines_abl = getenv("FQGPU_LINES_ABL") ? atoi(getenv("FQGPU_LINES_ABL")) : 0;
+    static const int lines_abl = measure_int("FQGPU_LINES_ABL");
     A.ablate = lines_abl;
     {
       ProfScope ps(c, "k_stream_lines");
@@ -832,6 +857,20 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   fv.line_end = (const uint64_t*)c->line_end.p;
   fv.n_lines = n_lines_all;
   fv.n_records = n_records;
+  fv.reframed = (flags & FQG_VALIDATE_REFRAMED) ? 1u : 0u;
+  if (!fv.reframed) {
+    // the gzgets limits, where the record-wise checks do not look: every line of an image that is only framed, and the
+    // lines of an incomplete last record (the reference reads THOSE in pieces too before it finds the file truncated)
+    const uint64_t from = frame_only ? 0 : 4 * n_records;
+    const uint64_t upto = final ? n_lines_all : usable;
+    if (upto > from) {
+      ProfScope ps(c, "k_overlong");
+      FrameView lv = fv;
+      lv.n_lines = upto;
+      hipLaunchKernelGGL(k_overlong, dim3((unsigned)((upto - from + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, lv, from,
+                         c->d_cs);
+    }
+  }
 
   // a record that starts with NUL ends the file silently (src/fastq.c:250)
   bool tail_is_stop = false;
@@ -931,14 +970,16 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   if (c->h_cs->first_key != ~0ull) {
     out->record = c->h_cs->first_key >> 8;
     out->code = (int32_t)(c->h_cs->first_key & 0xFF);
-    hipLaunchKernelGGL(k_validate_exact, dim3(1), dim3(kBlock), 0, c->stream, fv, st->is_pe,
-                       st->readname_format, st->space, 1u, (AccState*)nullptr, (unsigned long long*)nullptr,
-                       c->d_cs, out->record, (const unsigned long long*)nullptr,
-                       (const unsigned long long*)nullptr);
-    HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    out->aux0 = c->h_cs->aux0;
-    out->aux1 = c->h_cs->aux1;
+    if (out->code != FQG_E_LINE_TOO_LONG) {  // (that one has no arguments, and its record may be the incomplete last one)
+      hipLaunchKernelGGL(k_validate_exact, dim3(1), dim3(kBlock), 0, c->stream, fv, st->is_pe,
+                         st->readname_format, st->space, 1u, (AccState*)nullptr, (unsigned long long*)nullptr,
+                         c->d_cs, out->record, (const unsigned long long*)nullptr,
+                         (const unsigned long long*)nullptr);
+      HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      out->aux0 = c->h_cs->aux0;
+      out->aux1 = c->h_cs->aux1;
+    }
   } else if (final && leftover && !out->stopped && !tail_is_stop) {
     // src/fastq.c:254-257: fewer than four lines left
     out->code = FQG_E_TRUNCATED;
@@ -1141,7 +1182,7 @@ int names_prepare(fqg_ctx* c, const FrameView& fv) {
   if ((rc = ensure(c, c->name_redo_chunks, (size_t)std::max<uint32_t>(c->names.cr.n_chunks, 1)))) return rc;
   c->names.redo_bits = (unsigned long long*)c->name_redo.p;
   c->names.chunk_redo = (uint8_t*)c->name_redo_chunks.p;
-  static const int abl = env_int("FQGPU_NAMES_ABL", 0);
+  static const int abl = measure_int("FQGPU_NAMES_ABL");
   c->names.ablate = abl;
   return 0;
 }
@@ -1293,7 +1334,7 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   if ((rc = index_fetch_call(c))) return drop(rc);
   if (hipGetLastError() != hipSuccess) return drop(fail(c, FQG_ERR_HIP, "k_index_insert"));
   if (c->h_icall->table_full) return drop(fail(c, FQG_ERR_STATE, "name index full"));
-  if (sg.n_records && c->h_icall->seen != sg.n_records && !(captured && c->names.ablate)) return drop(fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once"));
+  if (sg.n_records && c->h_icall->seen != sg.n_records && !measured_wrong(captured && c->names.ablate)) return drop(fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once"));
   c->last_names_captured = c->h_icall->captured;
   ix->n_records_total += sg.n_records;
   ix->inserted += c->h_icall->inserted;
@@ -1358,7 +1399,7 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   }
   if ((rc = index_fetch_call(c))) return rc;
   HIP_TRY(c, hipGetLastError());
-  if (fv.n_records && c->h_icall->seen != fv.n_records && !c->names.ablate) return fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once");
+  if (fv.n_records && c->h_icall->seen != fv.n_records && !measured_wrong(c->names.ablate)) return fail(c, FQG_ERR_STATE, "name index: the pass did not meet every record once");
   c->last_names_captured = c->h_icall->captured;
   ix->matched += c->h_icall->matched;
   ix->n_askers_total += fv.n_records;
@@ -1529,10 +1570,7 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   P.out_sam = bp->out_sam;
   P.tenx = bp->tenx;
   {
-    static const int abl = [] {
-      const char* e = getenv("FQGPU_BC_ABL");
-      return e ? atoi(e) : 0;
-    }();
+    static const int abl = measure_int("FQGPU_BC_ABL");
     P.ablate = abl;
   }
   P.umi_off = bp->umi_offset;

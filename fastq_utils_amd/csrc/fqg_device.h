@@ -107,6 +107,7 @@ struct FrameView {
   const uint64_t* line_end;  // per line: offset of its '\n', or nbytes for an unterminated last line
   uint64_t n_lines;
   uint64_t n_records;
+  uint32_t reframed = 0;  // FQG_VALIDATE_REFRAMED: lines are within the gzgets limits by construction
 };
 
 }  // namespace fqg

@@ -277,8 +277,9 @@ __device__ __forceinline__ RecOut validate_record(const FrameView& f, uint64_t r
   const Line &h1 = ln[0], &sq = ln[1], &h2 = ln[2], &ql = ln[3];
 
   // gzgets limits (src/fastq.c:249-253): a longer line would have been split by the reference
-  if (h1.len + h1.nl > FQG_MAX_LABEL_LENGTH - 1 || h2.len + h2.nl > FQG_MAX_LABEL_LENGTH - 1 ||
-      sq.len + sq.nl > FQG_MAX_READ_LENGTH - 1 || ql.len + ql.nl > FQG_MAX_READ_LENGTH - 1) {
+  if (!f.reframed &&
+      (h1.len + h1.nl > FQG_MAX_LABEL_LENGTH - 1 || h2.len + h2.nl > FQG_MAX_LABEL_LENGTH - 1 ||
+       sq.len + sq.nl > FQG_MAX_READ_LENGTH - 1 || ql.len + ql.nl > FQG_MAX_READ_LENGTH - 1)) {
     o.code = FQG_E_LINE_TOO_LONG;
     return o;
   }
@@ -861,6 +862,24 @@ __global__ __launch_bounds__(kBlock) void k_find_stop(FrameView f, CallState* __
   if (r >= f.n_records) return;
   const uint64_t s = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
   if (f.img[s] == 0) atomicMin(&cs->stop_record, (unsigned long long)r);
+}
+
+// lines [first, f.n_lines) against the gzgets limits of the reference (src/fastq.c:249-253): the record of the first
+// line that gzgets would not return whole.  For images nobody validates (FQG_VALIDATE_FRAME_ONLY) and for the lines of
+// an incomplete last record, which the record-wise checks never see.
+__global__ __launch_bounds__(kBlock) void k_overlong(FrameView f, uint64_t first, CallState* __restrict__ cs) {
+  const uint64_t i = first + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool bad = false;
+  if (i < f.n_lines) {
+    const uint64_t e = f.line_end[i], s = i == 0 ? 0 : f.line_end[i - 1] + 1;
+    const uint64_t total = e - s + (e < f.nbytes ? 1u : 0u);
+    bad = total > ((i & 1u) ? (uint64_t)FQG_MAX_READ_LENGTH - 1 : (uint64_t)FQG_MAX_LABEL_LENGTH - 1);
+  }
+  const unsigned long long m = __ballot(bad);
+  if (m && lane_id() == __builtin_ctzll(m)) {
+    const unsigned long long key = ((unsigned long long)(i >> 2) << 8) | (unsigned long long)FQG_E_LINE_TOO_LONG;
+    atomicMin(&cs->first_key, key);
+  }
 }
 
 // record descriptors (FASTQ_ENTRY geometry) for a range of records

@@ -52,6 +52,29 @@ __device__ __forceinline__ uint32_t nl_marks7(uint32_t w, uint32_t& okacc) {
   return t & kH;
 }
 
+// The same marks, with the control-character test as ONE three-input boolean instruction per word: `bad` collects bit 7
+// of every byte that is < 0x20 and no '\n'.  (x = byte ^ 0x0A keeps a byte on its side of 0x20; t = 0x80 - x has bit 7
+// where x == 0; t + 0x1F = 0x9F - x has bit 7 where x < 0x20.  No byte carries into its neighbour: t is 0x01..0x80.)
+// What an instruction costs on gfx950 decides the form (tools/kbench/valubench.hip, profiles/r04*_valubench.txt): a
+// two-operand VALU instruction on registers or a literal - and v_bitop3_b32 - issues in 2 cycles per wavefront, a
+// three-operand one (v_or3, v_and_or, v_perm, v_dot4, v_xad, v_lshl_or ..) or one that reads an SGPR in 4.
+__device__ __forceinline__ uint32_t nl_marks7b(uint32_t w, uint32_t& bad) {
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  const uint32_t t = kH - x;
+  const uint32_t c = t + 0x1F1F1F1Fu;
+  bad = __builtin_amdgcn_bitop3_b32(bad, c, t, 0xF4);  // bad | (c & ~t): truth table of A | (B & ~C) with A = 0xF0, B = 0xCC, C = 0xAA
+  return t & kH;
+}
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE); }
+
+// a wave-uniform value in a VECTOR register: v_sub / v_add on two vector registers issue in 2 cycles, with an SGPR
+// operand in 4 (the compiler would keep such a value in an SGPR)
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t x) {
+  uint32_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+  return v;
+}
+
 // 0x80 in every byte (< 0x80) that is not one of A C G T N
 __device__ __forceinline__ uint32_t not_acgtn7(uint32_t w) {
   // byte table indexed by (c & 7): 7F 'A' 7F 'C' 'T' 7F 'N' 'G'; 0x7F never matches (its low bits are 7)
@@ -60,8 +83,8 @@ __device__ __forceinline__ uint32_t not_acgtn7(uint32_t w) {
 }
 
 // 0x80 in every byte (< 0x80) inside [lo, hi]; lob = lo * 0x01010101, hihb = (hi | 0x80) * 0x01010101
-__device__ __forceinline__ uint32_t in_range7(uint32_t w, uint32_t lob, uint32_t hihb) {
-  return ((w | kH) - lob) & (hihb - w) & kH;
+__device__ __forceinline__ uint32_t in_range7(uint32_t w, uint32_t lob, uint32_t hihb, uint32_t kh = kH) {
+  return ((w | kH) - lob) & (hihb - w) & kh;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -220,6 +243,62 @@ __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uin
   }
 }
 
+// Staging without the slot table (V2): a lane writes the entries of its OWN newlines - it knows their ranks (ex + the
+// count below them in its mask) - straight to the chunk's place in `stage`; neighbouring ranks are neighbouring lanes,
+// so the 2-byte stores of an instruction fall into one or two lines.  The first two newlines of a lane's 32 bytes are
+// handled without a branch (their look-ups in the LDS copy are in flight together, for both slices); a third and later
+// ones - three line ends within 32 bytes: empty lines - take a loop that ordinary files never enter.  The first form
+// (stage_chunk) went through a per-wave table in LDS: two data-dependent loops, a barrier and two dependent LDS round
+// trips per chunk, 1.1 ms of the pass on 100 M reads although it is 60 of its 540 instructions.
+__device__ __forceinline__ uint32_t stage_one(uint32_t at, uint32_t j, uint32_t nl2, uint32_t c1) {
+  return stage_entry((at + j) | (((nl2 >> j) & 1u) << 14), c1);
+}
+template <uint32_t ABL>
+__device__ __forceinline__ void stage_chunk_direct(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
+                                                   const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
+                                                   const uint32_t (&ex)[kHalves], const uint8_t* __restrict__ copy,
+                                                   uint32_t tail, uint16_t* __restrict__ stage, bool interior) {
+  const int lane = lane_id();
+  uint16_t* dst = stage + (uint64_t)chunk * kStageCap;
+  auto next_byte = [&](uint32_t o) -> uint32_t {  // the byte at chunk offset o (the one behind a newline)
+    if (ABL & 4u) return 0u;
+    if (interior) return o < (uint32_t)kChunkBytes ? (uint32_t)copy[o] : (tail & 0xFFu);
+    return cb + o < n ? (uint32_t)img[cb + o] : 0u;
+  };
+  uint32_t j0[kHalves], j1[kHalves], c0[kHalves], c1[kHalves], rest[kHalves];
+#pragma unroll
+  for (int k = 0; k < kHalves; ++k) {
+    const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
+    const uint32_t m0 = nl[k], m1 = m0 & (m0 - 1u);
+    j0[k] = m0 ? (uint32_t)__builtin_ctz(m0) : 0u;
+    j1[k] = m1 ? (uint32_t)__builtin_ctz(m1) : 0u;
+    rest[k] = m1 & (m1 - 1u);
+    // (a lane without a newline looks at its own first bytes: any address of the copy will do)
+    c0[k] = next_byte(at + j0[k] + 1u);
+    c1[k] = next_byte(at + j1[k] + 1u);
+  }
+#pragma unroll
+  for (int k = 0; k < kHalves; ++k) {
+    const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
+    const uint32_t m0 = nl[k], m1 = m0 & (m0 - 1u), r = ex[k];
+    if (m0 && r < (uint32_t)kStageCap) dst[r] = (uint16_t)stage_one(at, j0[k], nl2[k], c0[k]);
+    if (m1 && r + 1u < (uint32_t)kStageCap) dst[r + 1u] = (uint16_t)stage_one(at, j1[k], nl2[k], c1[k]);
+  }
+  if (__ballot((rest[0] | rest[1]) != 0)) {  // rare: a third newline within 32 bytes
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) {
+      const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
+      uint32_t m = rest[k], r = ex[k] + 2u;
+      while (m) {
+        const uint32_t j = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        if (r < (uint32_t)kStageCap) dst[r] = (uint16_t)stage_one(at, j, nl2[k], next_byte(at + j + 1u));
+        ++r;
+      }
+    }
+  }
+}
+
 // ABL: ablation mask for tools/kbench (product code instantiates 0): 1 = no byte-class checks,
 // 2 = no staging, 4 = no fetch of the byte after a newline, 8 = no base check, 16 = no quality test
 // NAMES: also capture the header lines that begin in the chunk (NameCapture, fqg_device.h)
@@ -229,7 +308,12 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
                                                          CallState* __restrict__ cs, NameCapture nc = NameCapture{}) {
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
   static_assert(!NAMES || !(ABL & 7u), "the name capture needs the speculation, the staged entries and the copy");
-  __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
+  // (tools/kbench: the forms of round 4 against those of round 3 - 32: marks and range test, 64: staging without the slot
+  // table, 128: the LDS copy in image order for the slot-table staging too)
+  constexpr bool V2 = (ABL & 32u) != 0;
+  constexpr bool DIRECT = (ABL & 64u) != 0 && !NAMES;
+  constexpr bool LINEAR = NAMES || DIRECT || (ABL & 128u) != 0;  // the LDS copy in image order
+  __shared__ uint16_t s_slots[DIRECT ? 1 : kBlock / kWave][DIRECT ? 1 : kStageCap];
   __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][NAMES ? kCopyRow : (uint32_t)kChunkBytes];
   // (the wave index is uniform: telling the compiler keeps chunk-level values in scalar registers)
   const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -257,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     if (!(ABL & 6u)) {
 #pragma unroll
       for (int k = 0; k < kHalves; ++k) {
-        if (NAMES) {
+        if (LINEAR) {
           *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes]) = v[k].a;
           *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes + 16]) = v[k].b;
         } else {
@@ -266,9 +350,18 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         }
       }
     }
-    uint32_t okacc = kH, hiacc = 0;
+    uint32_t okacc = kH, hiacc = 0, badacc = 0;
 #pragma unroll
     for (int k = 0; k < kHalves; ++k) {
+      if (V2) {
+        hiacc = or3(or3(or3(or3(hiacc, v[k].a.x, v[k].a.y), v[k].a.z, v[k].a.w), v[k].b.x, v[k].b.y), v[k].b.z, v[k].b.w);
+        const uint32_t lo = pack_marks16(nl_marks7b(v[k].a.x, badacc), nl_marks7b(v[k].a.y, badacc),
+                                         nl_marks7b(v[k].a.z, badacc), nl_marks7b(v[k].a.w, badacc));
+        const uint32_t hi = pack_marks16(nl_marks7b(v[k].b.x, badacc), nl_marks7b(v[k].b.y, badacc),
+                                         nl_marks7b(v[k].b.z, badacc), nl_marks7b(v[k].b.w, badacc));
+        nl[k] = lo | (hi << 16);
+        continue;
+      }
       hiacc |= v[k].a.x | v[k].a.y | v[k].a.z | v[k].a.w | v[k].b.x | v[k].b.y | v[k].b.z | v[k].b.w;
       const uint32_t lo = pack_marks16(nl_marks7(v[k].a.x, okacc), nl_marks7(v[k].a.y, okacc),
                                        nl_marks7(v[k].a.z, okacc), nl_marks7(v[k].a.w, okacc));
@@ -277,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
       nl[k] = lo | (hi << 16);
     }
     const bool high = __ballot((hiacc & kH) != 0) != 0;
-    const bool ctrl = __ballot((okacc & kH) != kH) != 0;
+    const bool ctrl = __ballot(V2 ? (badacc & kH) != 0 : (okacc & kH) != kH) != 0;
     if (high) flags |= kFlagHigh;  // (the masks above are meaningless then; the host drops this pass)
     if (ctrl && !high) {
       // rare: a control byte other than '\n'.  Only NUL and CR change what a line is (C strings,
@@ -372,7 +465,9 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         lo = 127u;
         hi = 0u;
       }
-      const uint32_t lob = lo * 0x01010101u, hihb = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
+      const uint32_t lob_s = lo * 0x01010101u, hihb_s = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
+      const uint32_t lob = V2 ? in_vgpr(lob_s) : lob_s, hihb = V2 ? in_vgpr(hihb_s) : hihb_s;
+      const uint32_t khv = V2 ? in_vgpr(kH) : kH;  // (a three-operand instruction cannot hold a literal: the compiler would read an SGPR)
       QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
       bool any_viol = false;
 #pragma unroll
@@ -385,10 +480,10 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         const uint32_t bad = (ABL & 8u) ? 0u : inv & M1 & ~nl[k];
         if (bad) queue_suspect(o, cs, wb + (uint64_t)k * kHalfBytes + (uint32_t)__builtin_ctz(bad));
         const uint32_t okq =
-            pack_marks16(in_range7(a.x, lob, hihb), in_range7(a.y, lob, hihb), in_range7(a.z, lob, hihb),
-                         in_range7(a.w, lob, hihb)) |
-            (pack_marks16(in_range7(b.x, lob, hihb), in_range7(b.y, lob, hihb), in_range7(b.z, lob, hihb),
-                          in_range7(b.w, lob, hihb)) << 16);
+            pack_marks16(in_range7(a.x, lob, hihb, khv), in_range7(a.y, lob, hihb, khv), in_range7(a.z, lob, hihb, khv),
+                         in_range7(a.w, lob, hihb, khv)) |
+            (pack_marks16(in_range7(b.x, lob, hihb, khv), in_range7(b.y, lob, hihb, khv), in_range7(b.z, lob, hihb, khv),
+                          in_range7(b.w, lob, hihb, khv)) << 16);
         const uint32_t qm = (ABL & 16u) ? 0u : M3 & ~nl[k];
         if (__ballot((qm & ~okq) != 0)) {  // rare: exact range of this slice's quality bytes
           any_viol = true;
@@ -452,7 +547,10 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     }
   }
 
-  if (!(ABL & 2u)) stage_chunk<ABL, NAMES>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], copy, tail, o.stage, interior);
+  if (!(ABL & 2u)) {
+    if constexpr (DIRECT) stage_chunk_direct<ABL>(img, n, cb, chunk, nl, nl2, ex, copy, tail, o.stage, interior);
+    else stage_chunk<ABL, LINEAR>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], copy, tail, o.stage, interior);
+  }
   if constexpr (NAMES) {
     // ---- header lines that begin in this chunk -> 64-byte records (NameCapture) ----
     // Line starts: the chunk's first byte when the byte in front of it is a '\n' (v = 0), and the byte behind the

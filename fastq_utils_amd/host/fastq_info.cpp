@@ -65,7 +65,7 @@ void run_single_noindex(const char* path, Stats& S) {
     const double t1 = timing ? now() : 0;
     probe_piece(pr, in.data(), in.size(), 1);
     fqg_validate_result r;
-    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st, 0, &r));
+    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st, in.vflags(), &r));
     if (timing) {
       if (!n_pieces) fprintf(stderr, "fqgpu timing: first piece in hand %.3f s, validated %.3f s after the program started\n",
                              since_start() - (now() - t1), since_start());
@@ -409,7 +409,8 @@ struct MultiIndexed {
   fqhost::NamesOfFile f1;
 };
 
-// file 1 of the default / paired mode.  false: the file holds a NUL at a record start - run the one-device loop.
+// file 1 of the default / paired mode.  Always returns true (a file that holds a NUL at a record start is passed over
+// once more with the limit the first pass found, below; nothing falls back to the one-device loop any more).
 bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, MultiIndexed& M, const std::vector<int>& devs) {
   M.D.resize(devs.size());
   M.D[0].ctx = g_ctx;
@@ -567,7 +568,7 @@ void run_pair_second_file(const char* path1, const char* path2, Stats& S, Indexe
     probe_piece(pr2, in.data(), in.size(), 1);
     fqg_validate_result r;
     // file-2 records are validated against file 1's state and counters (src/fastq_info.c:345)
-    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &F.st, FQG_VALIDATE_NAMES, &r));
+    LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &F.st, FQG_VALIDATE_NAMES | in.vflags(), &r));
     fqg_index_result ir{};
     ir.n_entries = F.entries;
     if (r.n_records > 0) LIB(fqg_index_match_delete(g_ctx, F.index, &pr2.st, &ir));
@@ -626,7 +627,7 @@ void run_interleaved(const char* path, Stats& S) {
   Probe pr;
   probe_piece(pr, in.data(), in.size(), 1);
   fqg_validate_result r;
-  LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, 1, &pr.st, 0, &r));
+  LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, 1, &pr.st, in.vflags(), &r));
   const uint64_t n = r.n_records;
   fqg_index_result cr{};
   if (n >= 2) {
@@ -722,10 +723,10 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
   probe_piece(pr1, in1.data(), in1.size(), 1);
   probe_piece(pr2, in2.data(), in2.size(), 1);
   fqg_validate_result r1, r2;
-  LIB(fqg_validate(g_ctx, S.acc1, in1.data(), in1.size(), FQG_MEM_HOST, 1, &pr1.st, 0, &r1));
+  LIB(fqg_validate(g_ctx, S.acc1, in1.data(), in1.size(), FQG_MEM_HOST, 1, &pr1.st, in1.vflags(), &r1));
   fqg_frame *f1 = nullptr, *f2 = nullptr;
   if (r1.n_records) LIB(fqg_frame_retain(g_ctx, &f1));
-  LIB(fqg_validate(g_ctx, S.acc2, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st, 0, &r2));
+  LIB(fqg_validate(g_ctx, S.acc2, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st, in2.vflags(), &r2));
   if (r2.n_records) LIB(fqg_frame_retain(g_ctx, &f2));
   fqg_index_result cr{};
   if (f1 && f2) LIB(fqg_names_compare(g_ctx, f1, &pr1.st, f2, &pr2.st, &cr));
@@ -844,6 +845,7 @@ int main(int argc, char** argv) {
   int is_paired_data = 0, is_interleaved = 0, is_sorted = 0, empty_ok = 0, no_encoding_ok = 0, skip_readname_check = 0;
   int nopt = 0, c;
   opterr = 0;
+  fqhost::install_counted_output(argv);  // (fq_respawn.h: a run that has to start over does not print anything twice)
   fprintf(stderr, "fastq_utils %s\n", "0.25.3");  // fastq_print_version
   // option handling as in src/fastq_info.c:214-255 (nopt counts option letters)
   while ((c = getopt(argc, argv, "esfrhq")) != -1) switch (c) {

@@ -133,6 +133,15 @@ bool probe_bytes(const char* data, size_t size, fqg_file_state* st, std::string*
   return true;
 }
 
+// the reference reads a line beyond its gzgets buffers in pieces (src/fastq.c:249-253) and goes on out of step; this
+// program copies records, it does not reproduce that: refused, loudly
+[[noreturn]] void refuse_long_line(const char* path, uint64_t record) {
+  FQ_PRINT_ERROR("Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes)", path,
+                 (unsigned long)(record + 1), FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
+  fflush(stdout);
+  fqhost::leave(kExitSys);
+}
+
 void probe(Source& s) {
   if (s.probed || s.in->size() == 0) return;
   s.probed = probe_bytes(s.in->data(), s.in->size(), &s.st, &s.format_line);
@@ -160,12 +169,16 @@ bool refill(Source& s) {
   fqg_validate_result r;
   LIB(fqg_validate(g_ctx, nullptr, s.in->data(), s.in->size(), FQG_MEM_HOST, s.in->final() ? 1 : 0, &s.st,
                    FQG_VALIDATE_FRAME_ONLY, &r));
-  s.final_piece = s.in->final();
+  if (r.code == FQG_E_LINE_TOO_LONG) refuse_long_line(s.in->path().c_str(), s.records_before + r.record);
+  const bool ends_here = r.stopped != 0;  // a header line that starts with a NUL byte: "no entry" (src/fastq.c:250), the input ends
+  if (ends_here)  // the records in front of it, framed alone
+    LIB(fqg_validate(g_ctx, nullptr, s.in->data(), r.consumed, FQG_MEM_HOST, 1, &s.st, FQG_VALIDATE_FRAME_ONLY, &r));
+  s.final_piece = s.in->final() || ends_here;
   s.tail_lines = r.tail_lines;
-  s.open_end = s.final_piece && r.tail_lines == 0 && r.n_records > 0 && s.in->size() > 0 && s.in->data()[s.in->size() - 1] != '\n';
+  s.open_end = s.final_piece && !ends_here && r.tail_lines == 0 && r.n_records > 0 && s.in->size() > 0 && s.in->data()[s.in->size() - 1] != '\n';
   s.avail = r.n_records;
   if (r.n_records) LIB(fqg_frame_retain(g_ctx, &s.frame));
-  if (!s.in->final()) {
+  if (!s.in->final() && !ends_here) {
     s.carry_pending = true;
     s.carry_at = r.consumed;
   } else s.exhausted = true;
@@ -224,6 +237,7 @@ struct BlockRun {
     int tail_lines[6] = {0, 0, 0, 0, 0, 0};
     bool final[6] = {false, false, false, false, false, false};
     bool open_end[6] = {false, false, false, false, false, false};  // see Source::open_end
+    bool ends = false;                            // an input ends inside this unit although its block is not the last
     std::vector<char> out[3];
     std::string wrong_header;                     // the text of the header line of a FQG_E_WRONG_HEADER finding
   };
@@ -277,16 +291,33 @@ struct BlockRun {
             lib_fail("fqg_validate", rc);
             break;
           }
-          if (!b[x].final && (r.n_records != B || r.consumed != b[x].size)) {
-            // (a NUL byte that ends the file early for the reference's C strings, src/fastq.c:250: not a case for blocks)
+          if (r.code == FQG_E_LINE_TOO_LONG) {
             u.rc = FQG_ERR_ARG;
-            u.err = std::string("a block of ") + A.file[x] + " cut at a record boundary was not consumed whole (FQGPU_DEVICES): use one device";
+            u.err = std::string("fqg_validate: ") + A.file[x] + " has a line longer than the reference's line buffers (record " +
+                    std::to_string(u.seq * B + r.record + 1) + "); the reference reads such a line in pieces, this program refuses it";
+            break;
+          }
+          // a header line that starts with a NUL byte is "no entry" for the reference (src/fastq.c:250): this input ends
+          // HERE, cleanly, whatever follows - the unit is the last one the consumer looks at
+          const bool ends_here = r.stopped != 0;
+          if (ends_here) {
+            // frame the records in front of it once more, alone: what follows the NUL is not this file's any more
+            u.ends = true;
+            const int rc2 = fqg_validate(c, nullptr, b[x].data, r.consumed, FQG_MEM_HOST, 1, &states[x], FQG_VALIDATE_FRAME_ONLY, &r);
+            if (rc2) {
+              lib_fail("fqg_validate", rc2);
+              break;
+            }
+          }
+          if (!b[x].final && !ends_here && (r.n_records != B || r.consumed != b[x].size)) {
+            u.rc = FQG_ERR_STATE;
+            u.err = std::string("a block of ") + A.file[x] + " cut at a record boundary was not consumed whole";
             break;
           }
           u.records[x] = r.n_records;
-          u.tail_lines[x] = r.tail_lines;
-          u.final[x] = b[x].final;
-          u.open_end[x] = b[x].final && r.tail_lines == 0 && r.n_records > 0 && b[x].size > 0 && b[x].data[b[x].size - 1] != '\n';
+          u.tail_lines[x] = ends_here ? 0 : r.tail_lines;
+          u.final[x] = b[x].final || ends_here;
+          u.open_end[x] = b[x].final && !ends_here && r.tail_lines == 0 && r.n_records > 0 && b[x].size > 0 && b[x].data[b[x].size - 1] != '\n';
           u.n = std::min<uint64_t>(u.n, r.n_records);
           if (r.n_records) {
             const int rc2 = fqg_frame_retain(c, &held[x]);
@@ -396,8 +427,10 @@ struct BlockRun {
         fqhost::leave(kExitFormat);
       }
     }
+    const bool ends = u.ends;
     last = std::move(u);
     have_last = true;
+    if (ends) break;  // (later units, if any were handed out, are dropped)
   }
   join_all();
   // an incomplete record where the next read would have happened is a truncated file (src/fastq.c:254-257); a clean

@@ -68,9 +68,7 @@ class RecordBlocks {
     if (producer_.joinable()) producer_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
-    if (keep_slots_until_exit()) return;
-    for (auto& s : slots_)
-      if (s.buf) fqg_host_free(ctx_, s.buf);
+    for (auto& s : slots_) slot_release(ctx_, s.buf);
   }
   RecordBlocks(const RecordBlocks&) = delete;
   RecordBlocks& operator=(const RecordBlocks&) = delete;
@@ -224,13 +222,13 @@ class RecordBlocks {
   bool reserve(Slot& s, size_t keep, size_t want) {
     if (want <= s.cap) return true;
     const size_t cap = std::max(want, s.cap + s.cap / 2);
-    char* nb = static_cast<char*>(fqg_host_alloc(ctx_, cap + 1));
+    char* nb = slot_alloc(ctx_, cap + 1);
     if (!nb) {
       fail("unable to allocate pinned memory");
       return false;
     }
     if (keep) memcpy(nb, s.buf, keep);
-    if (s.buf) fqg_host_free(ctx_, s.buf);
+    slot_release(ctx_, s.buf);
     s.buf = nb;
     s.cap = cap;
     return true;

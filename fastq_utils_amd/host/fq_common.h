@@ -208,10 +208,16 @@ void print_validation_error(const char* fname, unsigned long cline, const fqg_va
   FQ_PRINT_ERROR("Error in file %s: line %lu: file truncated", fname, cline);  // src/fastq.c:255
   fqhost::leave(1);
 }
+// A line beyond the reference's gzgets limits (src/fastq.c:249-253).  Everything up to that record went the reference's
+// way; from there on the reference reads the file in pieces of its own.  The program runs itself again, as a child, on
+// input that is cut the same way while it is read (fq_respawn.h, fq_reframe.h), and leaves with the child's status.
+// Only a stream that several devices were asked to share cannot be read twice.
 [[noreturn]] void fail_too_long(const char* fname, uint64_t rec) {
+  if (fqhost::reframe_supported() && strcmp(fname, "-") != 0 && !fqhost::reframing()) fqhost::respawn_reframed();
   FQ_PRINT_ERROR(
-      "Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes); the "
-      "reference splits such lines silently, this program refuses them",
+      "Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes); the reference "
+      "reads such a line in pieces, this program refuses it (fastq_info reproduces the pieces, on files and on a stream "
+      "that one device reads)",
       fname, (unsigned long)(rec + 1), FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
   fqhost::leave(kExitSys);
 }
@@ -250,7 +256,7 @@ void run_index_input(Input& in, const char* path, int is_pe, Stats& S, IndexedFi
     probe_piece(pr, in.data(), in.size(), is_pe);
     fqg_validate_result r;
     LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st,
-                     FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES, &r));
+                     FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES | in.vflags(), &r));
     if (!F.index) {
       // sized from the first piece: a plain file holds about (its bytes / this piece's mean record) names - the table
       // then never has to be rebuilt at twice the size

@@ -42,6 +42,12 @@ inline FilterTotals run_filter(fqg_ctx* ctx, const char* path, const fqg_filter_
     fqg_validate_result r;
     lib(fqg_validate(ctx, nullptr, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &st, FQG_VALIDATE_FRAME_ONLY, &r),
         "fqg_validate");
+    if (r.code == FQG_E_LINE_TOO_LONG) {  // (the reference would read it in pieces, src/fastq.c:249-253: DESIGN.md 7.1)
+      FQ_PRINT_ERROR("Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes)", path,
+                     t.processed + (unsigned long)r.record + 1, FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
+      fflush(stdout);
+      fqhost::leave(kExitSys);
+    }
     tail_lines = r.tail_lines;
     if (r.n_records) {
       fqg_frame* frame = nullptr;

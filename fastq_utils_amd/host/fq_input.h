@@ -27,11 +27,14 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/fqg.h"
+#include "fq_reframe.h"
+#include "fq_respawn.h"
 
 namespace fqhost {
 
@@ -46,10 +49,69 @@ constexpr int kExitParams = 1, kExitSys = 2, kExitFormat = 3;
 
 // The programs run one job and exit: un-pinning hundreds of megabytes of staging slots first (0.1 - 0.2 s) buys nothing -
 // the operating system takes the memory back.  Set once by a program's main(); library-style users leave it alone.
+// A slot that outlives its owner this way is NOT lost: it goes to a process-wide pool and the next reader (the second
+// pass over a file, the second file of a pair, the one-device loop after a multi-device attempt) takes it over instead
+// of pinning a new one - a program holds as many pinned slots as its busiest reader needs, however many readers it
+// builds (the slots are portable pinned memory: any device's context may copy from them).
 inline bool& keep_slots_until_exit() {
   static bool v = false;
   return v;
 }
+
+class SlotPool {
+ public:
+  static SlotPool& get() {
+    static SlotPool* p = new SlotPool;  // (never destroyed: reader threads may still hold slots when the program leaves)
+    return *p;
+  }
+  // pinned memory of at least `bytes`; nullptr when the allocation fails
+  char* take(fqg_ctx* ctx, size_t bytes) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      size_t best = free_.size();
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].second >= bytes && free_[i].second <= bytes + bytes / 2 + (1u << 20) &&
+            (best == free_.size() || free_[i].second < free_[best].second))
+          best = i;
+      if (best != free_.size()) {
+        char* p = free_[best].first;
+        free_.erase(free_.begin() + (long)best);
+        return p;
+      }
+    }
+    char* p = static_cast<char*>(fqg_host_alloc(ctx, bytes));
+    if (p) {
+      std::lock_guard<std::mutex> lk(mu_);
+      size_[p] = bytes;
+    }
+    return p;
+  }
+  // the owner is done with it: back to the pool while the program keeps its slots, freed otherwise
+  void give(fqg_ctx* ctx, char* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = size_.find(p);
+    if (keep_slots_until_exit() && it != size_.end()) {
+      free_.emplace_back(p, it->second);
+      return;
+    }
+    if (it != size_.end()) size_.erase(it);
+    fqg_host_free(ctx, p);
+  }
+  size_t pinned_bytes() {  // (tests) everything this pool has handed out or holds
+    std::lock_guard<std::mutex> lk(mu_);
+    size_t t = 0;
+    for (auto& kv : size_) t += kv.second;
+    return t;
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<std::pair<char*, size_t>> free_;
+  std::map<char*, size_t> size_;
+};
+inline char* slot_alloc(fqg_ctx* ctx, size_t bytes) { return SlotPool::get().take(ctx, bytes); }
+inline void slot_release(fqg_ctx* ctx, char* p) { SlotPool::get().give(ctx, p); }
 
 // How the programs leave: with everything they said flushed, and WITHOUT exit()'s hooks.  The HIP runtime tears itself
 // down in one of them, and it must not meet a thread of ours that is still inside a HIP call (a reader pinning its next
@@ -146,24 +208,36 @@ class Input {
       const int fd = open(path, O_RDONLY);
       struct stat sb;
       if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
-        unsigned char magic[2] = {0, 0};
-        const ssize_t got = pread(fd, magic, 2, 0);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+        unsigned char magic[18];
+        memset(magic, 0, sizeof(magic));
+        const ssize_t got = pread(fd, magic, sizeof(magic), 0);
+        if (!(got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
           plain_fd_ = fd;
           plain_size_ = (uint64_t)sb.st_size;
+        } else if (got == 18 && bgzf_block_size(magic, 18) > 0 && !getenv("FQGPU_NO_PARALLEL_INFLATE")) {
+          // bgzip'd FASTQ: a sequence of small gzip members that say how long they are (SAM/BAM specification 4.1) -
+          // inflated on all cores (read_bgzf below) instead of by one zlib thread
+          bgzf_fd_ = fd;
+          bgzf_size_ = (uint64_t)sb.st_size;
         }
       }
-      if (plain_fd_ < 0) {
+      if (plain_fd_ < 0 && bgzf_fd_ < 0) {
         if (fd >= 0) close(fd);
         gz_ = gzopen(path, "r");
       }
     }
-    if (!gz_ && plain_fd_ < 0) {
+    if (!gz_ && plain_fd_ < 0 && bgzf_fd_ < 0) {
       FQ_PRINT_ERROR("Unable to open %s", path);
       leave(kExitParams);
     }
     if (gz_) gzbuffer(gz_, 1 << 20);
     if (plain_fd_ >= 0 && plain_size_ < cap_) cap_ = std::max<size_t>(plain_size_, 1);  // small file: one small slot
+    if (bgzf_fd_ >= 0) cap_ = std::max<size_t>(cap_, 1u << 17);  // (whole blocks of up to 64 KiB are inflated into a slot)
+    // The reference's gzgets limits (fq_reframe.h).  Inflated input and stdin pass through one thread anyway: it cuts
+    // as it goes (a memchr per line beside the inflate).  A plain file is read by many threads and handed over as it
+    // is; the GPU reports a line beyond the limits (FQG_E_LINE_TOO_LONG) and the program starts over with
+    // FQGPU_REFRAME set (fq_respawn.h), which brings it here.
+    reframe_ = ((gz_ != nullptr || bgzf_fd_ >= 0) && reframe_supported()) || reframing();
   }
   ~Input() {
     {
@@ -174,11 +248,10 @@ class Input {
     if (producer_.joinable()) producer_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
-    if (keep_slots_until_exit()) return;
-    for (Slot& s : slots_)
-      if (s.buf) fqg_host_free(ctx_, s.buf);
-    if (whole_) fqg_host_free(ctx_, whole_);
-    if (big_) fqg_host_free(ctx_, big_);
+    if (bgzf_fd_ >= 0) close(bgzf_fd_);
+    for (Slot& s : slots_) slot_release(ctx_, s.buf);
+    slot_release(ctx_, whole_);
+    slot_release(ctx_, big_);
   }
   Input(const Input&) = delete;
   Input& operator=(const Input&) = delete;
@@ -212,7 +285,7 @@ class Input {
       char* nb = alloc(carry + s.len + 1);
       memcpy(nb, carry_src, carry);
       memcpy(nb + carry, s.buf + s.head, s.len);
-      if (big_) fqg_host_free(ctx_, big_);
+      slot_release(ctx_, big_);
       big_ = nb;
       data_ = nb;
     } else {
@@ -241,6 +314,8 @@ class Input {
   const char* data() const { return data_; }
   size_t size() const { return len_; }
   bool final() const { return eof_; }
+  // what fqg_validate must be told about this input's pieces
+  uint32_t vflags() const { return reframe_ ? FQG_VALIDATE_REFRAMED : 0u; }
   // bytes of a plain (uncompressed, seekable) input, 0 when unknown: a size hint for whoever sizes tables from it
   uint64_t plain_bytes() const { return plain_fd_ >= 0 ? plain_size_ : 0; }
   const std::string& path() const { return path_; }
@@ -254,8 +329,16 @@ class Input {
     bool ready = false, last = false, allocated = false;
   };
 
+  // bytes a slot holds behind its headroom: the piece, and in re-framing mode the two bytes per cut on top of a piece
+  // of at least kReframeMin bytes (the bytes held back from one round to the next stay below the longest limit)
+  static constexpr size_t kReframeMin = 4u << 20;
+  size_t slot_room() const {
+    if (!reframe_) return cap_;
+    const size_t c = std::max(cap_, kReframeMin);
+    return c + c / 256 + 64;
+  }
   char* alloc(size_t n) {
-    char* p = static_cast<char*>(fqg_host_alloc(ctx_, n));
+    char* p = slot_alloc(ctx_, n);
     if (!p) {
       FQ_PRINT_ERROR("unable to allocate %zu bytes of pinned memory", n);
       leave(kExitSys);
@@ -319,6 +402,144 @@ class Input {
     return len;
   }
 
+  size_t read_some(char* dst, size_t want, bool* at_end) {
+    if (plain_fd_ >= 0) return read_plain(dst, want, at_end);
+    if (bgzf_fd_ >= 0) return read_bgzf(dst, want, at_end);
+    return read_gz(dst, want, at_end);
+  }
+
+  // ---- BGZF input (bgzip'd FASTQ; SAM/BAM specification 4.1) ------------------------------------------------------
+  // total size of the block that starts at p when p is a BGZF block header (gzip member, FEXTRA with the 'B' 'C'
+  // subfield), 0 otherwise
+  static size_t bgzf_block_size(const unsigned char* p, size_t avail) {
+    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = p[10] | ((size_t)p[11] << 8);
+    size_t q = 12;
+    while (q + 4 <= 12 + xlen && q + 4 <= avail) {
+      const size_t slen = p[q + 2] | ((size_t)p[q + 3] << 8);
+      if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= avail) {
+        const size_t bsize = (p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+        return bsize >= 12 + xlen + 8 ? bsize : 0;
+      }
+      q += 4 + slen;
+    }
+    return 0;
+  }
+  // up to `want` inflated bytes: compressed bytes are read in pieces of 32 MiB, the blocks in them are listed
+  // (their sizes are in their headers and trailers) and every block is inflated to its own place, many at a time.
+  // Whole blocks only: fewer than 64 KiB short of `want` is "full".
+  size_t read_bgzf(char* dst, size_t want, bool* at_end) {
+    struct Block {
+      size_t at, size, xlen, out_at, isize;
+    };
+    size_t len = 0;
+    auto fail = [&](const char* what) {
+      std::lock_guard<std::mutex> lk(mu_);
+      fail_msg_ = what;
+      failed_ = true;
+      cv_.notify_all();
+    };
+    for (;;) {
+      // refill the compressed window [bz_at_, bz_buf_.size())
+      if (bz_buf_.size() - bz_at_ < (1u << 17) && bgzf_off_ < bgzf_size_) {
+        bz_buf_.erase(bz_buf_.begin(), bz_buf_.begin() + (long)bz_at_);
+        bz_at_ = 0;
+        const size_t old = bz_buf_.size(), add = (size_t)std::min<uint64_t>(32u << 20, bgzf_size_ - bgzf_off_);
+        bz_buf_.resize(old + add);
+        size_t done = 0;
+        while (done < add) {
+          const ssize_t got = pread(bgzf_fd_, bz_buf_.data() + old + done, add - done, (off_t)(bgzf_off_ + done));
+          if (got <= 0) {
+            fail("read error");
+            return len;
+          }
+          done += (size_t)got;
+        }
+        bgzf_off_ += add;
+      }
+      if (bz_at_ == bz_buf_.size()) {
+        *at_end = true;
+        return len;
+      }
+      std::vector<Block> blocks;
+      size_t p = bz_at_, total = 0;
+      while (p < bz_buf_.size()) {
+        const size_t bsize = bgzf_block_size(bz_buf_.data() + p, bz_buf_.size() - p);
+        if (!bsize) {
+          if (bz_buf_.size() - p < 18 && bgzf_off_ < bgzf_size_) break;  // a header cut by the window: next round
+          fail("not a BGZF block where one was expected (a bgzip'd file followed by other data?)");
+          return len;
+        }
+        if (p + bsize > bz_buf_.size()) {
+          if (bgzf_off_ < bgzf_size_) break;
+          fail("truncated BGZF block");
+          return len;
+        }
+        const unsigned char* t = bz_buf_.data() + p + bsize - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        if (isize > 65536) {
+          fail("BGZF block larger than 64 KiB");
+          return len;
+        }
+        if (len + total + isize > want) break;
+        const size_t xlen = bz_buf_[p + 10] | ((size_t)bz_buf_[p + 11] << 8);
+        blocks.push_back({p, bsize, xlen, len + total, isize});
+        total += isize;
+        p += bsize;
+      }
+      if (blocks.empty()) {
+        if (p < bz_buf_.size() && bgzf_off_ >= bgzf_size_ && len + 65536 > want) return len;  // no room for the next block
+        if (p < bz_buf_.size() && len + 65536 > want) return len;
+        if (p >= bz_buf_.size() && bgzf_off_ >= bgzf_size_) {
+          *at_end = true;
+          return len;
+        }
+        if (bz_buf_.size() - bz_at_ >= (1u << 17)) return len;  // (cannot be: a window of 128 KiB holds a block)
+        continue;
+      }
+      if (!inflate_pool_) inflate_pool_.reset(new ReaderPool(std::max(1u, std::min(32u, std::thread::hardware_concurrency()))));
+      const unsigned T = (unsigned)std::min<size_t>(inflate_pool_->size(), std::max<size_t>(1, blocks.size() / 8));
+      std::atomic<bool> bad{false};
+      const unsigned char* src = bz_buf_.data();
+      inflate_pool_->run(T, [&](unsigned t) {
+        for (size_t i = blocks.size() * t / T; i < blocks.size() * (t + 1) / T; ++i) {
+          const Block& b = blocks[i];
+          if (b.isize == 0) continue;  // (the end-of-file marker, or an empty block)
+          z_stream zs;
+          memset(&zs, 0, sizeof(zs));
+          if (inflateInit2(&zs, -15) != Z_OK) {
+            bad = true;
+            return;
+          }
+          zs.next_in = const_cast<Bytef*>(src + b.at + 12 + b.xlen);
+          zs.avail_in = (uInt)(b.size - 12 - b.xlen - 8);
+          zs.next_out = reinterpret_cast<Bytef*>(dst + b.out_at);
+          zs.avail_out = (uInt)b.isize;
+          const int rc = inflate(&zs, Z_FINISH);
+          const bool good = rc == Z_STREAM_END && zs.total_out == b.isize;
+          inflateEnd(&zs);
+          const unsigned char* c = src + b.at + b.size - 8;
+          const uint32_t want_crc = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+          if (!good || (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(dst + b.out_at), (uInt)b.isize) != want_crc) {
+            bad = true;
+            return;
+          }
+        }
+      });
+      if (bad) {
+        fail("corrupt BGZF block (inflate or CRC-32 failed)");
+        return len;
+      }
+      len += total;
+      bz_at_ = p;
+      if (bz_at_ == bz_buf_.size() && bgzf_off_ >= bgzf_size_) {
+        *at_end = true;
+        return len;
+      }
+      if (len + 65536 > want) return len;
+    }
+  }
+
   void produce() {
     // pinning a slot takes as long as filling it: the slots behind the first are allocated by a helper while the first
     // is being read (the file may well end inside the first)
@@ -328,7 +549,7 @@ class Input {
     if (more)
       helper = std::thread([this, head] {
         for (int i = 1; i < kSlots; ++i) {
-          char* b = static_cast<char*>(fqg_host_alloc(ctx_, head + cap_ + 1));
+          char* b = slot_alloc(ctx_, head + slot_room() + 1);
           std::lock_guard<std::mutex> lk(mu_);
           slots_[i].buf = b;
           slots_[i].allocated = true;
@@ -357,11 +578,34 @@ class Input {
           cv_.notify_all();
           return;
         }
-        s.buf = alloc(head + cap_ + 1);
+        s.buf = alloc(head + slot_room() + 1);
       }
       s.head = head;
       bool at_end = false;
-      const size_t len = plain_fd_ >= 0 ? read_plain(s.buf + s.head, cap_, &at_end) : read_gz(s.buf + s.head, cap_, &at_end);
+      size_t len;
+      if (!reframe_) len = read_some(s.buf + s.head, cap_, &at_end);
+      else {
+        // raw bytes = what the last round held back + a fresh read; the cut form of what can be judged goes out
+        char* raw = s.buf + s.head;
+        const size_t held = rf_tail_.size(), want = std::max(cap_, kReframeMin) - held;
+        if (held) memcpy(raw, rf_tail_.data(), held);
+        const size_t n = held + read_some(raw + held, want, &at_end);
+        bool clean = true;
+        const size_t taken = rf_.run(raw, n, at_end, rf_out_, &clean);
+        rf_tail_.assign(raw + taken, n - taken);
+        len = taken;
+        if (!clean) {
+          if (rf_out_.size() > slot_room()) {  // (cannot be: two bytes per limit - 1 >= 999 bytes were allowed for)
+            std::lock_guard<std::mutex> lk(mu_);
+            fail_msg_ = "internal: a re-framed piece outgrew its slot";
+            failed_ = true;
+            cv_.notify_all();
+            return;
+          }
+          memcpy(raw, rf_out_.data(), rf_out_.size());
+          len = rf_out_.size();
+        }
+      }
       {
         std::lock_guard<std::mutex> lk(mu_);
         s.len = len;
@@ -385,14 +629,15 @@ class Input {
     whole_carry_ = 0;
     bool at_end = false;
     while (!at_end) {
-      if (len == cap) {
+      if (len == cap || (bgzf_fd_ >= 0 && cap - len < 65536)) {  // (read_bgzf fills whole blocks only)
         char* nb = alloc(cap * 2 + 1);
         memcpy(nb, buf, len);
-        fqg_host_free(ctx_, buf);
+        slot_release(ctx_, buf);
         buf = nb;
         cap *= 2;
       }
       if (plain_fd_ >= 0) len += read_plain(buf + len, cap - len, &at_end);
+      else if (bgzf_fd_ >= 0) len += read_bgzf(buf + len, cap - len, &at_end);
       else {
         const int got = gzread(gz_, buf + len, (unsigned)std::min<size_t>(cap - len, 1u << 30));
         if (got < 0) {
@@ -408,7 +653,18 @@ class Input {
         leave(kExitSys);
       }
     }
-    if (whole_) fqg_host_free(ctx_, whole_);
+    if (reframe_) {
+      bool clean = true;
+      rf_.run(buf, len, true, rf_out_, &clean);  // (the whole file at once: this object hands out nothing else)
+      if (!clean) {
+        char* nb = alloc(rf_out_.size() + 1);
+        memcpy(nb, rf_out_.data(), rf_out_.size());
+        slot_release(ctx_, buf);
+        buf = nb;
+        len = rf_out_.size();
+      }
+    }
+    slot_release(ctx_, whole_);
     whole_ = buf;
     data_ = buf;
     len_ = len;
@@ -422,6 +678,11 @@ class Input {
   gzFile gz_ = nullptr;
   int plain_fd_ = -1;
   uint64_t plain_size_ = 0, plain_off_ = 0;
+  int bgzf_fd_ = -1;  // bgzip'd input: blocks inflated on many threads (read_bgzf)
+  uint64_t bgzf_size_ = 0, bgzf_off_ = 0;
+  std::vector<unsigned char> bz_buf_;
+  size_t bz_at_ = 0;
+  std::unique_ptr<ReaderPool> inflate_pool_;
   size_t cap_;
   Slot slots_[kSlots];
   std::unique_ptr<ReaderPool> pool_;
@@ -437,6 +698,10 @@ class Input {
   size_t len_ = 0, carry_at_ = 0, whole_carry_ = 0;
   bool have_carry_ = false, whole_mode_ = false;
   bool eof_ = false, finished_ = false;
+  // the reference's gzgets limits (fq_reframe.h); the state belongs to whichever thread reads (producer or next_whole)
+  bool reframe_ = false;
+  Reframer rf_;
+  std::string rf_tail_, rf_out_;
 };
 
 }  // namespace fqhost

@@ -65,9 +65,7 @@ class AlignedPieces {
     if (producer_.joinable()) producer_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
-    if (keep_slots_until_exit()) return;
-    for (auto& s : slots_)
-      if (s.buf) fqg_host_free(ctx_, s.buf);
+    for (auto& s : slots_) slot_release(ctx_, s.buf);
   }
   // next piece in file order; false when the file is exhausted.  Thread-safe.
   bool next(Piece* out) {
@@ -204,7 +202,7 @@ class AlignedPieces {
       if (si < 0) return;
       Slot& s = slots_[(size_t)si];
       if (!s.buf) {
-        s.buf = static_cast<char*>(fqg_host_alloc(ctx_, cap_ + kTail + 1));
+        s.buf = slot_alloc(ctx_, cap_ + kTail + 1);
         if (!s.buf) {
           fail("unable to allocate pinned memory");
           return;
@@ -265,7 +263,7 @@ class AlignedPieces {
       const int si = free_slot();
       if (si < 0) return;
       Slot& s = slots_[(size_t)si];
-      if (!s.buf) s.buf = static_cast<char*>(fqg_host_alloc(ctx_, cap_ + kTail + 1));
+      if (!s.buf) s.buf = slot_alloc(ctx_, cap_ + kTail + 1);
       Piece p;
       p.data = s.buf;
       p.final = true;

@@ -144,6 +144,11 @@ typedef struct {
                                        single-pass framing also copies every header line into a 64-byte record while the
                                        bytes are on the chip, and the index calls work from those records instead of going
                                        back to the image.  Results are the same with or without it. */
+#define FQG_VALIDATE_REFRAMED 64u    /* the host has already cut the image at the reference's gzgets() limits
+                                       (src/fastq.c:249-253; fastq_utils_amd/host/fq_input.h, Reframer): a piece that gzgets
+                                       would return without its newline is followed by "\0\n" - the NUL the reference's
+                                       buffer holds behind it, and a newline that only frames.  No line is held against the
+                                       limits then (FQG_E_LINE_TOO_LONG is never reported). */
 #define FQG_VALIDATE_COUNT_TWICE 4u /* every record counts twice in acc: the index loop runs
                                        fastq_new_entry_stats in both fastq_read_next_entry and
                                        fastq_validate_entry (src/fastq.c:415,432) */

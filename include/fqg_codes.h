@@ -41,10 +41,11 @@ enum fqg_code {
   FQG_E_UNPAIRED = 13,
   /* src/fastq_info.c:135-138  "Readnames do not match across files" */
   FQG_E_NAME_MISMATCH = 14,
-  /* Not a reference outcome.  src/fastq.c:249-253 reads lines with gzgets() limits of
-   * MAX_LABEL_LENGTH (headers) and MAX_READ_LENGTH (sequence, quality); a longer line is
-   * silently split there and shifts the framing of everything after it.  The bulk path
-   * refuses such input instead of guessing. */
+  /* Not a reference outcome, and not the programs' last word.  src/fastq.c:249-253 reads lines
+   * with gzgets() limits of MAX_LABEL_LENGTH (headers) and MAX_READ_LENGTH (sequence, quality);
+   * a longer line is split there and shifts the framing of everything after it.  The library
+   * reports the first record with such a line; the caller then hands the input over again cut
+   * the way gzgets cuts it (FQG_VALIDATE_REFRAMED) and gets the reference's findings. */
   FQG_E_LINE_TOO_LONG = 15,
   /* src/fastq.c:249-250  a record whose first line starts with a NUL byte ends the file
    * silently (fastq_read_entry returns 0).  Reported so that the caller can re-run on the

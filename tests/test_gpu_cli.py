@@ -168,24 +168,62 @@ def test_several_devices_many_pieces(kind):
                 assert (rc, out, strip_progress(err)) == (want["exit"], want["stdout"], strip_progress(want["stderr"])), err[-500:]
 
 
-@pytest.mark.parametrize("which", ["header_1500", "header_1500_first", "read_2.6M", "hdr2_1200"])
-def test_overlong_lines_are_refused(which):
-    """The one input class where bin/fastq_info does NOT print what the reference prints: a line beyond
-    the reference's gzgets buffers (src/fastq.c:249-253) is read in pieces there, which puts every later line out of
-    step - the reference then reports whatever the shifted framing trips over (pinned, with the oracle, in
-    tests/test_oracle_vs_ref_fuzz.py::test_lines_beyond_the_gzgets_buffers).  Here the record is named and the program
-    exits with status 2."""
+REF_INFO = os.path.join(REPO, "oracle", "_ref", "fastq_info")
+
+
+def _overlong():
     from tests.test_oracle_vs_ref_fuzz import overlong_images
 
-    img = overlong_images()[which]
+    return overlong_images()
+
+
+@pytest.mark.parametrize("how", ["plain_file", "gz_file", "small_pieces", "several_devices"])
+@pytest.mark.parametrize("which", sorted(_overlong()))
+def test_lines_beyond_the_gzgets_buffers(which, how):
+    """A line beyond the reference's gzgets buffers (src/fastq.c:249-253: 1000 bytes for the header lines, 2 500 000 for
+    sequence and quality) is read in pieces there, which puts every later line out of step - deterministic behaviour,
+    and bin/fastq_info reproduces it: the input is cut the way gzgets cuts it (host/fq_reframe.h) - while it is read
+    when it is inflated anyway, and in a second run of the program when the GPU finds such a line in a plain file
+    (host/fq_respawn.h: nothing is printed twice) - and the GPU sees the pieces as lines.  Exit status, stdout and
+    stderr of the oracle (pinned on the reference binary for these very images, tests/test_oracle_vs_ref_fuzz.py) and,
+    byte for byte with the progress ticker, of the reference binary itself."""
+    import gzip
+
+    img = _overlong()[which]
+    env = {"small_pieces": {"FQGPU_CHUNK_MB": "1"}, "several_devices": {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"}}.get(how)
+    name = "f.fastq.gz" if how == "gz_file" else "f.fastq"
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, name), "wb") as f:
+            f.write(gzip.compress(img, 1) if how == "gz_file" else img)
+        for args in (["-r", name], [name], [name, "pe"], ["-r", "-s", name, name], [name, name]):
+            rc, out, err = run_cli(args, tmp, env)
+            want = oracle_run(args, {name: img})
+            ctx = (args, err[-500:], want["stderr"][-500:])
+            assert rc == want["exit"], ctx
+            assert out == want["stdout"], ctx
+            assert strip_progress(err) == strip_progress(want["stderr"]), ctx
+            if os.path.exists(REF_INFO):
+                p = subprocess.run([REF_INFO] + args, cwd=tmp, capture_output=True, timeout=300)
+                assert (rc, out, err) == (p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1")), ctx
+
+
+@pytest.mark.skipif(not os.path.exists(REF_INFO), reason="oracle/_ref not built")
+@pytest.mark.parametrize("args", [["-r", "f.fastq"], ["f.fastq"]], ids=["r", "index"])
+def test_a_long_line_late_in_a_file_prints_nothing_twice(args):
+    """250 000 reads (the progress ticker has written twice), then a header beyond the limit: the run that finds it has
+    printed the version line, the format line and the ticker; the run that takes over prints the rest.  stderr must be
+    the reference's, byte for byte."""
+    rng = np.random.default_rng(8)
+    ok = fuzz.make_fastq(rng, 250_000, 20, 40, "casava")
+    img = ok + b"@" + b"h" * 1500 + b" 1:N:0:A\nACGT\n+\nIIII\n" + fuzz.make_fastq(rng, 10, 20, 40, "casava")
     with tempfile.TemporaryDirectory() as tmp:
         with open(os.path.join(tmp, "f.fastq"), "wb") as f:
             f.write(img)
-        for args in (["-r", "f.fastq"], ["f.fastq"]):
-            rc, out, err = run_cli(args, tmp)
-            want = oracle_run(args, {"f.fastq": img})
-            assert rc == 2 and "has a line longer than the reference's line buffers" in err, err[-300:]
-            assert want["exit"] != 0   # the reference does not accept these files either: it fails further on, out of step
+        p = subprocess.run([REF_INFO] + args, cwd=tmp, capture_output=True, timeout=600)
+        for env in (None, {"FQGPU_CHUNK_MB": "4"}):
+            rc, out, err = run_cli(args, tmp, env)
+            assert (rc, out) == (p.returncode, p.stdout.decode("latin-1"))
+            assert err == p.stderr.decode("latin-1"), (err[-300:], p.stderr[-300:])
 
 
 # ---- FQGPU_DEVICES in the index modes: names across contexts (host/fq_names_multi.h) ----------------------------------

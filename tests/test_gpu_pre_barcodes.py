@@ -243,7 +243,8 @@ def test_several_devices_golden_invocations(case, per_block):
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
 @pytest.mark.parametrize("extra", [["--outfile1", "o.fastq.gz"], ["--sam", "--outfile1", "-"]], ids=["fastq", "sam"])
 @pytest.mark.parametrize("shape", ["same_length", "index_file_shorter", "read_file_shorter", "index_file_cut", "read_file_cut_at_block",
-                                   "mismatch_late", "wrong_header_late", "gz_inputs"])
+                                   "mismatch_late", "wrong_header_late", "gz_inputs", "nul_record_start_read_file",
+                                   "nul_record_start_index_file"])
 def test_several_devices_against_reference_binary(shape, extra):
     """20 000 10x-style pairs in blocks of ~3 000 (1 MiB pieces) and of 1 000 records over three contexts: outputs, messages
     and exit codes of the reference program - also when one file is shorter, ends inside a record, ends exactly at a block
@@ -265,12 +266,20 @@ def test_several_devices_against_reference_binary(shape, extra):
     elif shape == "wrong_header_late":
         l1[4 * 9044] = b"#" + l1[4 * 9044][1:]
         r1 = b"\n".join(l1)
+    elif shape == "nul_record_start_read_file":  # "no entry" for the reference (src/fastq.c:250): the loop ends there, cleanly
+        l2[4 * 13007] = b"\0" + l2[4 * 13007][1:]
+        r2 = b"\n".join(l2)
+    elif shape == "nul_record_start_index_file":
+        l1[4 * 2999] = b"\0" + l1[4 * 2999][1:]
+        r1 = b"\n".join(l1)
     names = ("r1.fastq", "r2.fastq")
     args = list(V2)
     if shape == "gz_inputs":
         names = ("r1.fastq.gz", "r2.fastq.gz")
         args = [a + ".gz" if a.endswith(".fastq") else a for a in args]
     envs = [dict(SEVERAL, FQGPU_CHUNK_MB="1"), dict(SEVERAL, FQGPU_BLOCK_RECORDS="1000")]
+    if shape.startswith("nul_"):
+        envs += [None, {"FQGPU_CHUNK_MB": "1"}]  # the one-device loop, whole and in 1 MiB pieces: the same answer
     res = []
     for binary, env in [(REF, None)] + [(BIN, e) for e in envs]:
         with tempfile.TemporaryDirectory() as d:

@@ -92,8 +92,18 @@ def overlong_images():
     long_hdr = b"@" + b"h" * 1500 + b" 1:N:0:A\nACGT\n+\nIIII\n"
     n = 2_600_000
     long_read = b"@ultra 1:N:0:A\n" + b"ACGT" * (n // 4) + b"\n+\n" + b"I" * n + b"\n"
+    # crafted so that the PIECES are valid records (the reference accepts these files and prints its summary):
+    # two lines that are each read as two fields ...
+    name = b"n" * 998
+    two_lines = b"@" + name + b"ACGTTGCA\n" + b"+" + name + b"IIIIHHHH\n"
+    # ... and a sequence / quality pair one byte beyond the limit whose overhang is the next field
+    m = 2_499_999
+    at_the_limit = b"@big 1:N:0:A\n" + b"A" * m + b"+\n" + b"I" * m + b"@next 1:N:0:A\nACGT\n+\nIIII\n"
     return {"header_1500": ok + long_hdr + ok, "header_1500_first": long_hdr + ok, "read_2.6M": ok + long_read + ok,
-            "hdr2_1200": b"@r 1:N:0:A\nACGT\n+" + b"x" * 1200 + b"\nIIII\n" + ok}
+            "hdr2_1200": b"@r 1:N:0:A\nACGT\n+" + b"x" * 1200 + b"\nIIII\n" + ok,
+            "pieces_are_records": ok + two_lines + ok, "pieces_are_records_first": two_lines + two_lines + ok,
+            "pieces_at_the_read_limit": at_the_limit + ok, "header_1500_last_no_newline": ok + long_hdr[:-1],
+            "header_999_exactly": ok + b"@" + b"h" * 998 + b"\nACGT\n+\nIIII\n" + ok}
 
 
 @pytest.mark.parametrize("which", sorted(overlong_images()))

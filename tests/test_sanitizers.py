@@ -91,6 +91,23 @@ def test_host_input_stager_runs_clean(tmpdir, san):
             h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         return h
     want = ("%d %d" % (len(data), fnv(data))).encode()
+    # bgzip'd input (BGZF: small gzip members that carry their size) is inflated on many threads (fq_input.h, read_bgzf);
+    # FQGPU_NO_PARALLEL_INFLATE sends the same file through zlib's gzread instead - the same bytes either way
+    from tests import bamgen
+    bgz = tmpdir / "x.txt.bgz.gz"
+    bgz.write_bytes(bamgen.bgzf(data[:1 << 20], block=0x4000, level=1)[:-28] + bamgen.bgzf(data[1 << 20:], level=1))  # small and full-size blocks
+    bgz_env = dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1")
+    for piece in ("4096", "100000", "50000000"):
+        for mode in ("0", "1", "2"):
+            for extra in ({}, {"FQGPU_NO_PARALLEL_INFLATE": "1"}):
+                p = subprocess.run([exe, str(bgz), piece, mode], env=dict(bgz_env, **extra), capture_output=True, timeout=300)
+                assert p.returncode == 0 and p.stdout.strip() == want, (piece, mode, extra, p.stdout, p.stderr.decode()[-1500:])
+    broken = bytearray(bgz.read_bytes())
+    broken[len(broken) // 2] ^= 0x55  # a flipped byte in the middle of some block: inflate or CRC-32 must notice
+    bad = tmpdir / "broken.bgz.gz"
+    bad.write_bytes(bytes(broken))
+    p = subprocess.run([exe, str(bad), "100000", "0"], env=bgz_env, capture_output=True, timeout=300)
+    assert p.returncode != 0 and (b"BGZF" in p.stderr), p.stderr.decode()[-800:]
     for path, wanted in ((plain, want), (gz, want), (empty, ("0 %d" % fnv(b"")).encode())):
         for piece in ("4096", "100000", "50000000"):
             for mode in ("0", "1", "2"):

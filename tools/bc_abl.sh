@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS a measurement build of the library: make -C fastq_utils_amd/csrc clean && make -C fastq_utils_amd/csrc MEASURE=1 (the shipped library ignores the ablation variables)
 # k_bc_emit_tile under its ablation switches (FQGPU_BC_ABL: 1 = no line is written, 2 = no flush, 4 = no name check,
 # 8 = no landing of the spans; results are then wrong)
 for abl in ${ABLS:-0 1 2 4 3 15}; do

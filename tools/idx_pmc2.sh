@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS a measurement build of the library: make -C fastq_utils_amd/csrc clean && make -C fastq_utils_amd/csrc MEASURE=1 (the shipped library ignores the ablation variables)
 # instruction-fetch counters of the capture-fed name kernel with and without the decode (FQGPU_NAMES_ABL 1 / 9)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/idx_pmc2
