@@ -60,6 +60,7 @@ def parse():
                     help="skip the validate pass on mixed-length short reads and on ONT-like long reads")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-fed measurement (the same reads from pinned host RAM / from a tmpfs file)")
+    ap.add_argument("--bgzf-helper", nargs=2, metavar=("SRC", "DST"), help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -123,7 +124,7 @@ def cpu_baseline(image_prefix_bytes, n_reads):
             "sample": sample + "; oracle/fq_oracle.c restatement", "seconds": dt, "ok": r["exit"] == 0}
 
 
-def barcodes_extra(ctx, fq, torch, dev, n_pairs):
+def barcodes_extra(ctx, fq, torch, dev, n_pairs, programs=True):
     """fastq_pre_barcodes' main loop (fqg_barcodes_transform) on BASELINE.json configs[2]: 10x v2 layout,
     index1 = 16 bp cell barcode + 10 bp UMI, read1 = 150 bp cDNA, flags as sh/fastq2bam:125-130 builds
     them plus --min_qual 10, SAM output.  Both files are synthetic and resident in HBM; checked through
@@ -252,6 +253,11 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs):
         out["whitelist_stage"] = {"error": repr(e)[:300]}
     for f in frames.values():
         f.release()
+    if programs:
+        try:
+            out["programs"] = barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, q, kernels_ms)
+        except Exception as e:
+            out["programs"] = {"error": repr(e)[:300]}
     ref = os.path.join(REPO, "oracle", "_ref", "fastq_pre_barcodes")
     if os.path.exists(ref):
         ms = min(n_pairs, 1_000_000)
@@ -270,6 +276,105 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs):
                                          "reference fastq_pre_barcodes (single-threaded)",
                                "seconds": secs, "ok": p.returncode == 0}
     return out
+
+
+V2_FLAGS = ["--read1", "r1.fastq", "--index1", "i1.fastq", "--umi_read", "index1", "--umi_offset", "16", "--umi_size", "10",
+            "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16", "--phred_encoding", "33", "--min_qual", "10"]
+
+
+def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, kernels_ms):
+    """The drop-in PROGRAM on the same pairs: bin/fastq_pre_barcodes on two files in tmpfs, process start
+    to exit, with both outputs the survey names - (i) --sam --outfile1 - (SAM text to stdout, here /dev/null) and
+    (ii) --outfile1 out.fastq.gz (the re-tagged FASTQ through the parallel gzip of host/fq_parallel.h).  As many of
+    the pairs as /dev/shm holds beside the output of (ii).  Checked: the counts the program prints against the recount
+    from the quality bytes; and, on a 2 M-pair prefix, the sha256 of what (ii) inflates to against the sha256 of the
+    library's FASTQ-mode output for the same pairs."""
+    import gzip
+    import hashlib
+    import shutil
+
+    A = fq.abi
+    exe = os.path.join(REPO, "bin", "fastq_pre_barcodes")
+    shm = "/dev/shm"
+    if not (os.path.exists(exe) and os.path.isdir(shm)):
+        return {"skipped": "no bin/fastq_pre_barcodes or no /dev/shm"}
+    free = shutil.disk_usage(shm).free
+    avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    per_pair_in, per_pair_gz = R1 + R2, 260  # (the gzip'd FASTQ of (ii): about 0.6 of its 400 bytes per pair)
+    m = int(min(n_pairs, (min(free, avail) - (24 << 30)) // (per_pair_in + per_pair_gz)))
+    if m < 1_000_000:
+        return {"skipped": f"/dev/shm has {free >> 30} GiB free, the host {avail >> 30} GiB available"}
+    d = tempfile.mkdtemp(prefix="fqg_bench_bc_", dir=shm)
+    res = {"pairs": m, "baseline_pairs": 200_000_000, "input_GB": m * per_pair_in / 1e9,
+           "kernels_only_ms_for_all_pairs_of_the_extra": kernels_ms}
+    try:
+        t0 = time.perf_counter()
+        for name, img, R in (("i1.fastq", img1, R1), ("r1.fastq", img2, R2)):
+            with open(os.path.join(d, name), "wb") as f:
+                rows = (256 << 20) // R
+                for a in range(0, m, rows):
+                    f.write(img[a * R:min(m, a + rows) * R].cpu().numpy().data)
+        res["write_tmpfs_files_s"] = time.perf_counter() - t0
+        want_disc = int((qual_rows[:m] < 33 + 10).any(dim=1).sum().item())
+
+        def counts(err):
+            got = {}
+            for ln in err.decode("latin-1").splitlines():
+                for key in ("Reads processed: ", "Reads discarded: "):
+                    if key in ln:
+                        got[key] = int(ln.split(key)[1].split()[0])
+            return got
+
+        def timed(args, stdout, env=None):
+            t = time.perf_counter()
+            p = subprocess.run(["fastq_pre_barcodes"] + V2_FLAGS + args, executable=exe, cwd=d, stdout=stdout,
+                               stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+            return time.perf_counter() - t, p
+
+        legs = {}
+        for label, args, sink in (("sam_to_stdout", ["--sam", "--outfile1", "-"], subprocess.DEVNULL),
+                                  ("fastq_gz_file", ["--outfile1", "out.fastq.gz"], None)):
+            runs = []
+            for _ in range(2):
+                secs, p = timed(args, sink)
+                c = counts(p.stderr)
+                ok = p.returncode == 0 and c.get("Reads processed: ") == m and c.get("Reads discarded: ") == want_disc
+                runs.append(secs)
+                if not ok:
+                    break
+            best = min(runs)
+            legs[label] = {"seconds": runs, "Mpairs_per_s": m / best / 1e6, "input_GBps": m * per_pair_in / best / 1e9, "ok": ok,
+                           "includes": "process start, HIP initialisation, pinned slots, reading both files, H2D, kernels, D2H, "
+                                       + ("parallel gzip (level as the reference's gzopen \"w\"), file written to tmpfs" if sink is None else "SAM text written to /dev/null")}
+            if sink is None and os.path.exists(os.path.join(d, "out.fastq.gz")):
+                legs[label]["output_gz_GB"] = os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9
+                os.unlink(os.path.join(d, "out.fastq.gz"))
+        res["legs"] = legs
+        # the bytes of (ii) on a prefix: program -> gunzip -> sha256 against the library's own FASTQ-mode output
+        k = min(m, 2_000_000)
+        for name, img, R in (("i1.fastq", img1, R1), ("r1.fastq", img2, R2)):
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img[: k * R].cpu().numpy().data)
+        secs, p = timed(["--outfile1", "out.fastq.gz"], None)
+        with gzip.open(os.path.join(d, "out.fastq.gz"), "rb") as f:
+            prog_sha = hashlib.sha256(f.read()).hexdigest()
+        st1 = A.probe_first_record(bytes(img1[: 4 * R1].cpu().numpy()), True)
+        st2 = A.probe_first_record(bytes(img2[: 4 * R2].cpu().numpy()), True)
+        frames = {}
+        for key, img, st, R in ((A.READ1, img2, st2, R2), (A.INDEX1, img1, st1, R1)):
+            r = ctx.validate(img.data_ptr(), None, st, final=True, flags=A.VALIDATE_FRAME_ONLY, nbytes=k * R)
+            assert r["n_records"] == k, r
+            frames[key] = ctx.retain_frame()
+        r = ctx.barcodes_transform(frames, {A.READ1: st2, A.INDEX1: st1}, k, umi=(A.INDEX1, 16, 10), cell=(A.INDEX1, 0, 16),
+                                   phred=33, min_qual=10, sam=False)
+        lib_sha = hashlib.sha256(ctx.barcodes_output(1, r["out_bytes"][1])).hexdigest()
+        for f in frames.values():
+            f.release()
+        res["prefix_check"] = {"pairs": k, "program_output_sha256": prog_sha, "library_output_sha256": lib_sha,
+                               "identical": p.returncode == 0 and prog_sha == lib_sha}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
 
 
 def filters_extra(ctx, fq, torch, dev, image, n, R, st, read_len):
@@ -408,6 +513,29 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
                 variants[label] = {"seconds": dt, "Mreads_per_s": n / dt / 1e6, "ok": p.returncode == 0,
                                    "says": [ln[ln.find("fqgpu timing"):] for ln in err.splitlines() if "fqgpu timing" in ln]}
             out["negative_controls"] = negative_controls(exe, path, arr, n, R)
+            # the inputs people have are compressed: a bgzip'd copy of the same file (BGZF blocks, inflated on all cores
+            # by host/fq_input.h) through the same program
+            try:
+                bgz = path + ".gz"
+                t0 = time.perf_counter()
+                # (in a process of its own: a pool of workers must not be forked from a process that holds the GPU)
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--bgzf-helper", path, bgz], check=True)
+                bgz_bytes = os.path.getsize(bgz)
+                made = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                p = subprocess.run([exe, "-r", bgz], capture_output=True, env=dict(os.environ, FQGPU_TIMING="1"))
+                dt = time.perf_counter() - t0
+                out["cli_fastq_info_r_bgzf_file"] = {
+                    "seconds": dt, "Mreads_per_s": n / dt / 1e6, "inflated_GBps": nbytes / dt / 1e9, "compressed_GB": bgz_bytes / 1e9,
+                    "ok": p.returncode == 0 and ("Number of reads: %d" % n).encode() in p.stderr,
+                    "times_the_plain_file": dt / med, "made_in_s": made,
+                    "what": "the same reads as a bgzip'd file (64 KiB BGZF blocks, zlib level 1) in tmpfs; blocks inflated on up "
+                            "to 32 threads while the GPU validates the previous piece; a single-member .gz stays on one zlib thread"}
+            except Exception as e:
+                out["cli_fastq_info_r_bgzf_file"] = {"error": repr(e)[:300]}
+            finally:
+                if os.path.exists(path + ".gz"):
+                    os.unlink(path + ".gz")
             out["cli_fastq_info_r_tmpfs_file"] = {
                 "seconds_median_of_3": med, "seconds": runs, "Mreads_per_s": n / med / 1e6, "GBps": nbytes / med / 1e9,
                 "stager": f"3 pinned slots of 128 MiB, a pool of {threads} pread threads (FQGPU_CHUNK_MB / FQGPU_HOST_THREADS)",
@@ -419,6 +547,40 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
     else:
         out["cli_fastq_info_r_tmpfs_file"] = {"skipped": "no bin/fastq_info or not enough room in /dev/shm"}
     return out
+
+
+def _bgzf_slice(args):
+    import struct
+    import zlib
+
+    path, a, b = args
+    out = []
+    with open(path, "rb") as f:
+        f.seek(a)
+        data = f.read(b - a)
+    for i in range(0, len(data), 0xFF00):
+        chunk = data[i:i + 0xFF00]
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+def bgzf_compress_file(src, dst):
+    """src as a BGZF file (what `bgzip` writes: SAM/BAM specification 4.1), compressed by a pool of processes"""
+    from concurrent.futures import ProcessPoolExecutor
+
+    size = os.path.getsize(src)
+    step = 0xFF00 * 1024  # 64 MiB of input per task
+    tasks = [(src, a, min(size, a + step)) for a in range(0, size, step)]
+    total = 0
+    with ProcessPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex, open(dst, "wb") as f:
+        for blob in ex.map(_bgzf_slice, tasks, chunksize=1):
+            f.write(blob)
+            total += len(blob)
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return total + 28
 
 
 def shapes_extra(ctx, fq, torch, dev, target_bytes=8 << 30):
@@ -857,6 +1019,9 @@ def launch_ranks(n_gpus):
 
 def main():
     a = parse()
+    if a.bgzf_helper:
+        bgzf_compress_file(*a.bgzf_helper)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
@@ -1168,7 +1333,7 @@ def main():
             torch.cuda.empty_cache()
         if world == 1 and not a.no_barcodes_extra:
             try:
-                out["pre_barcodes_extra"] = barcodes_extra(ctx, fq, torch, dev, a.barcode_pairs)
+                out["pre_barcodes_extra"] = barcodes_extra(ctx, fq, torch, dev, a.barcode_pairs, programs=not a.no_e2e)
             except Exception as e:
                 out["pre_barcodes_extra"] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()

@@ -42,23 +42,13 @@ __device__ __forceinline__ uint32_t pack_marks16(uint32_t m0, uint32_t m1, uint3
   return (lo >> 7) | (hi << 1);
 }
 
-// newline marks of a word whose bytes are all < 0x80; okacc keeps bit 7 of a byte only while
-// every byte seen there was a '\n' or >= 0x20
-__device__ __forceinline__ uint32_t nl_marks7(uint32_t w, uint32_t& okacc) {
-  const uint32_t x = w ^ 0x0A0A0A0Au;
-  const uint32_t t = kH - x;            // bit 7 of a byte: x == 0
-  const uint32_t y = x + 0x60606060u;   // bit 7 of a byte: x >= 0x20, i.e. the byte itself is >= 0x20
-  okacc &= (t | y);
-  return t & kH;
-}
-
-// The same marks, with the control-character test as ONE three-input boolean instruction per word: `bad` collects bit 7
-// of every byte that is < 0x20 and no '\n'.  (x = byte ^ 0x0A keeps a byte on its side of 0x20; t = 0x80 - x has bit 7
+// Newline marks of a word whose bytes are all < 0x80, with the control-character test as ONE three-input boolean
+// instruction per word: `bad` collects bit 7 of every byte that is < 0x20 and no '\n'.  (x = byte ^ 0x0A keeps a byte on its side of 0x20; t = 0x80 - x has bit 7
 // where x == 0; t + 0x1F = 0x9F - x has bit 7 where x < 0x20.  No byte carries into its neighbour: t is 0x01..0x80.)
 // What an instruction costs on gfx950 decides the form (tools/kbench/valubench.hip, profiles/r04*_valubench.txt): a
 // two-operand VALU instruction on registers or a literal - and v_bitop3_b32 - issues in 2 cycles per wavefront, a
 // three-operand one (v_or3, v_and_or, v_perm, v_dot4, v_xad, v_lshl_or ..) or one that reads an SGPR in 4.
-__device__ __forceinline__ uint32_t nl_marks7b(uint32_t w, uint32_t& bad) {
+__device__ __forceinline__ uint32_t nl_marks7(uint32_t w, uint32_t& bad) {
   const uint32_t x = w ^ 0x0A0A0A0Au;
   const uint32_t t = kH - x;
   const uint32_t c = t + 0x1F1F1F1Fu;
@@ -194,16 +184,13 @@ struct Piece32 {
 // Staging of the newlines of one chunk.  Every lane writes (offset | "second next byte is a newline")
 // of its newlines to the wave's LDS table at their rank; lane i then takes entry i, adds the class
 // of the byte after that newline and stores the 16-bit entry (contiguous 2-byte stores).  The byte
-// after a newline comes from an LDS copy of the chunk (interior chunks; written with conflict-free
-// 16-byte stores: the low halves of all lanes of a slice first, then the high halves) - a gather
-// from global memory would miss the L2 often enough to cost 10 % more HBM reads.
-__device__ __forceinline__ uint32_t lds_chunk_addr(uint32_t o) {  // byte o of the chunk -> its place in the copy
-  return (o & 0x800u) | ((o & 0x10u) << 6) | ((o >> 1) & 0x3F0u) | (o & 0xFu);
-}
-// The name-capturing instantiation keeps the copy in image order instead (header lines are read from it 8 bytes at a
-// time at any alignment), kCopyFront bytes of slack in front of it and kCopyBack behind: a header's 64-byte window
-// starts 3 bytes before its '@' and may reach past the chunk.  (Its 16-byte stores then meet two-way bank conflicts,
-// which the store's own issue time covers.)
+// after a newline comes from an LDS copy of the chunk, in image order (a gather from global memory
+// would miss the L2 often enough to cost 10 % more HBM reads; the copy's 16-byte stores at a 32-byte
+// lane stride meet two-way bank conflicts, which the store's own issue time covers - a conflict-free
+// layout of round 3 paid for itself with six address instructions per look-up).
+// The name-capturing instantiation reads header lines from the copy 8 bytes at a time at any alignment: kCopyFront
+// bytes of slack in front of it and kCopyBack behind - a header's 64-byte window starts 3 bytes before its '@' and may
+// reach past the chunk.
 constexpr uint32_t kCopyFront = 16, kCopyBack = 64;
 constexpr uint32_t kCopyRow = kCopyFront + kChunkBytes + kCopyBack;
 
@@ -211,7 +198,7 @@ __device__ __forceinline__ uint32_t stage_entry(uint32_t ent, uint32_t c1) {
   return ent | ((c1 == '@' ? kClsAt : (c1 == '+' ? kClsPlus : 0u)) << 12);
 }
 
-template <uint32_t ABL, bool LINEAR>
+template <uint32_t ABL>
 __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
                                             const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
                                             const uint32_t (&ex)[kHalves], uint32_t tot,
@@ -236,66 +223,10 @@ __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uin
     const uint32_t o = (ent & 0xFFFu) + 1;  // the byte after the '\n'
     uint32_t c1 = 0;
     if (!(ABL & 4u)) {
-      if (interior) c1 = o < (uint32_t)kChunkBytes ? (uint32_t)copy[LINEAR ? o : lds_chunk_addr(o)] : (tail & 0xFFu);
+      if (interior) c1 = o < (uint32_t)kChunkBytes ? (uint32_t)copy[o] : (tail & 0xFFu);
       else c1 = cb + o < n ? (uint32_t)img[cb + o] : 0u;
     }
     dst[i] = (uint16_t)stage_entry(ent, c1);
-  }
-}
-
-// Staging without the slot table (V2): a lane writes the entries of its OWN newlines - it knows their ranks (ex + the
-// count below them in its mask) - straight to the chunk's place in `stage`; neighbouring ranks are neighbouring lanes,
-// so the 2-byte stores of an instruction fall into one or two lines.  The first two newlines of a lane's 32 bytes are
-// handled without a branch (their look-ups in the LDS copy are in flight together, for both slices); a third and later
-// ones - three line ends within 32 bytes: empty lines - take a loop that ordinary files never enter.  The first form
-// (stage_chunk) went through a per-wave table in LDS: two data-dependent loops, a barrier and two dependent LDS round
-// trips per chunk, 1.1 ms of the pass on 100 M reads although it is 60 of its 540 instructions.
-__device__ __forceinline__ uint32_t stage_one(uint32_t at, uint32_t j, uint32_t nl2, uint32_t c1) {
-  return stage_entry((at + j) | (((nl2 >> j) & 1u) << 14), c1);
-}
-template <uint32_t ABL>
-__device__ __forceinline__ void stage_chunk_direct(const uint8_t* __restrict__ img, uint64_t n, uint64_t cb, uint32_t chunk,
-                                                   const uint32_t (&nl)[kHalves], const uint32_t (&nl2)[kHalves],
-                                                   const uint32_t (&ex)[kHalves], const uint8_t* __restrict__ copy,
-                                                   uint32_t tail, uint16_t* __restrict__ stage, bool interior) {
-  const int lane = lane_id();
-  uint16_t* dst = stage + (uint64_t)chunk * kStageCap;
-  auto next_byte = [&](uint32_t o) -> uint32_t {  // the byte at chunk offset o (the one behind a newline)
-    if (ABL & 4u) return 0u;
-    if (interior) return o < (uint32_t)kChunkBytes ? (uint32_t)copy[o] : (tail & 0xFFu);
-    return cb + o < n ? (uint32_t)img[cb + o] : 0u;
-  };
-  uint32_t j0[kHalves], j1[kHalves], c0[kHalves], c1[kHalves], rest[kHalves];
-#pragma unroll
-  for (int k = 0; k < kHalves; ++k) {
-    const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
-    const uint32_t m0 = nl[k], m1 = m0 & (m0 - 1u);
-    j0[k] = m0 ? (uint32_t)__builtin_ctz(m0) : 0u;
-    j1[k] = m1 ? (uint32_t)__builtin_ctz(m1) : 0u;
-    rest[k] = m1 & (m1 - 1u);
-    // (a lane without a newline looks at its own first bytes: any address of the copy will do)
-    c0[k] = next_byte(at + j0[k] + 1u);
-    c1[k] = next_byte(at + j1[k] + 1u);
-  }
-#pragma unroll
-  for (int k = 0; k < kHalves; ++k) {
-    const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
-    const uint32_t m0 = nl[k], m1 = m0 & (m0 - 1u), r = ex[k];
-    if (m0 && r < (uint32_t)kStageCap) dst[r] = (uint16_t)stage_one(at, j0[k], nl2[k], c0[k]);
-    if (m1 && r + 1u < (uint32_t)kStageCap) dst[r + 1u] = (uint16_t)stage_one(at, j1[k], nl2[k], c1[k]);
-  }
-  if (__ballot((rest[0] | rest[1]) != 0)) {  // rare: a third newline within 32 bytes
-#pragma unroll
-    for (int k = 0; k < kHalves; ++k) {
-      const uint32_t at = (uint32_t)k * kHalfBytes + (uint32_t)lane * kLaneBytes;
-      uint32_t m = rest[k], r = ex[k] + 2u;
-      while (m) {
-        const uint32_t j = (uint32_t)__builtin_ctz(m);
-        m &= m - 1u;
-        if (r < (uint32_t)kStageCap) dst[r] = (uint16_t)stage_one(at, j, nl2[k], next_byte(at + j + 1u));
-        ++r;
-      }
-    }
   }
 }
 
@@ -308,12 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
                                                          CallState* __restrict__ cs, NameCapture nc = NameCapture{}) {
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
   static_assert(!NAMES || !(ABL & 7u), "the name capture needs the speculation, the staged entries and the copy");
-  // (tools/kbench: the forms of round 4 against those of round 3 - 32: marks and range test, 64: staging without the slot
-  // table, 128: the LDS copy in image order for the slot-table staging too)
-  constexpr bool V2 = (ABL & 32u) != 0;
-  constexpr bool DIRECT = (ABL & 64u) != 0 && !NAMES;
-  constexpr bool LINEAR = NAMES || DIRECT || (ABL & 128u) != 0;  // the LDS copy in image order
-  __shared__ uint16_t s_slots[DIRECT ? 1 : kBlock / kWave][DIRECT ? 1 : kStageCap];
+  __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
   __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][NAMES ? kCopyRow : (uint32_t)kChunkBytes];
   // (the wave index is uniform: telling the compiler keeps chunk-level values in scalar registers)
   const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -341,36 +267,22 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     if (!(ABL & 6u)) {
 #pragma unroll
       for (int k = 0; k < kHalves; ++k) {
-        if (LINEAR) {
-          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes]) = v[k].a;
-          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes + 16]) = v[k].b;
-        } else {
-          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * 16]) = v[k].a;
-          *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + kHalfBytes / 2 + lane * 16]) = v[k].b;
-        }
+        *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes]) = v[k].a;
+        *reinterpret_cast<uint4*>(&copy[k * kHalfBytes + lane * kLaneBytes + 16]) = v[k].b;
       }
     }
-    uint32_t okacc = kH, hiacc = 0, badacc = 0;
+    uint32_t hiacc = 0, badacc = 0;
 #pragma unroll
     for (int k = 0; k < kHalves; ++k) {
-      if (V2) {
-        hiacc = or3(or3(or3(or3(hiacc, v[k].a.x, v[k].a.y), v[k].a.z, v[k].a.w), v[k].b.x, v[k].b.y), v[k].b.z, v[k].b.w);
-        const uint32_t lo = pack_marks16(nl_marks7b(v[k].a.x, badacc), nl_marks7b(v[k].a.y, badacc),
-                                         nl_marks7b(v[k].a.z, badacc), nl_marks7b(v[k].a.w, badacc));
-        const uint32_t hi = pack_marks16(nl_marks7b(v[k].b.x, badacc), nl_marks7b(v[k].b.y, badacc),
-                                         nl_marks7b(v[k].b.z, badacc), nl_marks7b(v[k].b.w, badacc));
-        nl[k] = lo | (hi << 16);
-        continue;
-      }
-      hiacc |= v[k].a.x | v[k].a.y | v[k].a.z | v[k].a.w | v[k].b.x | v[k].b.y | v[k].b.z | v[k].b.w;
-      const uint32_t lo = pack_marks16(nl_marks7(v[k].a.x, okacc), nl_marks7(v[k].a.y, okacc),
-                                       nl_marks7(v[k].a.z, okacc), nl_marks7(v[k].a.w, okacc));
-      const uint32_t hi = pack_marks16(nl_marks7(v[k].b.x, okacc), nl_marks7(v[k].b.y, okacc),
-                                       nl_marks7(v[k].b.z, okacc), nl_marks7(v[k].b.w, okacc));
+      hiacc = or3(or3(or3(or3(hiacc, v[k].a.x, v[k].a.y), v[k].a.z, v[k].a.w), v[k].b.x, v[k].b.y), v[k].b.z, v[k].b.w);
+      const uint32_t lo = pack_marks16(nl_marks7(v[k].a.x, badacc), nl_marks7(v[k].a.y, badacc),
+                                       nl_marks7(v[k].a.z, badacc), nl_marks7(v[k].a.w, badacc));
+      const uint32_t hi = pack_marks16(nl_marks7(v[k].b.x, badacc), nl_marks7(v[k].b.y, badacc),
+                                       nl_marks7(v[k].b.z, badacc), nl_marks7(v[k].b.w, badacc));
       nl[k] = lo | (hi << 16);
     }
     const bool high = __ballot((hiacc & kH) != 0) != 0;
-    const bool ctrl = __ballot(V2 ? (badacc & kH) != 0 : (okacc & kH) != kH) != 0;
+    const bool ctrl = __ballot((badacc & kH) != 0) != 0;
     if (high) flags |= kFlagHigh;  // (the masks above are meaningless then; the host drops this pass)
     if (ctrl && !high) {
       // rare: a control byte other than '\n'.  Only NUL and CR change what a line is (C strings,
@@ -466,8 +378,9 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         hi = 0u;
       }
       const uint32_t lob_s = lo * 0x01010101u, hihb_s = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
-      const uint32_t lob = V2 ? in_vgpr(lob_s) : lob_s, hihb = V2 ? in_vgpr(hihb_s) : hihb_s;
-      const uint32_t khv = V2 ? in_vgpr(kH) : kH;  // (a three-operand instruction cannot hold a literal: the compiler would read an SGPR)
+      // (in vector registers: a subtraction that reads an SGPR issues in 4 cycles instead of 2, and a three-operand
+      // instruction cannot hold a literal - the compiler would keep all three in SGPRs)
+      const uint32_t lob = in_vgpr(lob_s), hihb = in_vgpr(hihb_s), khv = in_vgpr(kH);
       QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
       bool any_viol = false;
 #pragma unroll
@@ -548,8 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
   }
 
   if (!(ABL & 2u)) {
-    if constexpr (DIRECT) stage_chunk_direct<ABL>(img, n, cb, chunk, nl, nl2, ex, copy, tail, o.stage, interior);
-    else stage_chunk<ABL, LINEAR>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], copy, tail, o.stage, interior);
+    stage_chunk<ABL>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], copy, tail, o.stage, interior);
   }
   if constexpr (NAMES) {
     // ---- header lines that begin in this chunk -> 64-byte records (NameCapture) ----

@@ -87,13 +87,32 @@ FP_BYTES = 16  # fqg_fp: u64 fingerprint, u64 global record index
 ROUND_PAIRS = 1 << 24  # pairs per (sender, owner) and round: 256 MiB messages
 
 
+def _slice_checksums(buf, counts):
+    """[len(counts), 2] int64: for every slice of `buf` (counts[i] pairs of FP_BYTES bytes, back to back) the sum of
+    its 64-bit words and the sum of their bit-mixed images, both modulo 2^64.  Independent of the order of the pairs
+    inside a slice - which the protocol does not depend on either."""
+    import torch
+
+    words = buf.view(torch.int64)
+    out = torch.zeros((len(counts), 2), dtype=torch.int64, device=buf.device)
+    p = 0
+    for i, c in enumerate(counts):
+        w = words[p:p + 2 * c]
+        p += 2 * c
+        if c:
+            out[i, 0] = w.sum()
+            out[i, 1] = (w ^ (w >> 29) ^ (w << 17)).sum()
+    return out
+
+
 def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
     """The all-to-all of fingerprint buckets.  `send`: uint8 tensor holding this rank's buckets back to
     back (bucket o = send_counts[o] pairs of FP_BYTES bytes, for owner o); returns (received uint8
     tensor with the pairs grouped by sender, counts received from every rank).  Works on device
     tensors with nccl (= RCCL) and on CPU tensors with gloo.  Buckets larger than `round_pairs` go in
     several rounds of at most 256 MiB per peer (a single 1.6 GB all_to_all_single was observed to
-    deliver wrong data with RCCL 2.26 / torch 2.10)."""
+    deliver wrong data with RCCL 2.26 / torch 2.10).  Every round carries a checksum per slice, verified on the
+    receiving side: wrong bytes raise instead of becoming wrong findings."""
     import torch
     import torch.distributed as dist
 
@@ -124,6 +143,16 @@ def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
             dst = torch.empty(sum(r_n) * FP_BYTES, dtype=torch.uint8, device=send.device)
         dist.all_to_all_single(dst, src, output_split_sizes=[c * FP_BYTES for c in r_n],
                                input_split_sizes=[c * FP_BYTES for c in s_n], group=group)
+        # what arrived is what was sent: a checksum per (sender, owner) slice of the round travels beside it and is
+        # held against the received bytes before anybody works on them (the wrong bytes of the 1.6 GB message above
+        # would have been findings, or missed findings, of the protocol)
+        sums_out = _slice_checksums(src, s_n)
+        sums_in = torch.empty_like(sums_out)
+        dist.all_to_all_single(sums_in, sums_out, group=group)
+        if not torch.equal(sums_in, _slice_checksums(dst, r_n)):
+            bad = (sums_in != _slice_checksums(dst, r_n)).any(dim=1).nonzero().flatten().tolist()
+            raise RuntimeError(f"fingerprint exchange: round {k}: the bytes received from rank(s) {bad} are not the bytes "
+                               f"they sent (checksum mismatch) - the collective delivered wrong data")
         if rounds > 1:
             p = 0
             for r in range(world):

@@ -968,6 +968,21 @@ int main(int argc, char** argv) {
   fprintf(stderr, "Read length: %lu %lu %u\n", min_rl - 1, max_rl - 1, (unsigned)(med - 1));
   fprintf(stderr, "OK\n");
   if (getenv("FQGPU_TIMING")) fprintf(stderr, "fqgpu timing: summary printed %.3f s after the program started\n", since_start());
+  if (const char* jm = getenv("FQGPU_JSON_METRICS")) {
+    // SURVEY 5 "metrics": the machine-readable twin of the summary above, as an EXTRA that leaves the command line and
+    // both output streams as the reference has them - one JSON object written to the file the variable names
+    if (FILE* jf = fopen(jm, "w")) {
+      const double secs = since_start();
+      const unsigned long long reads = (unsigned long long)S.num_reads1;  // (what "Number of reads" says)
+      const unsigned long long bytes = fqhost::bytes_handed_out().load();
+      fprintf(jf, "{\"program\": \"fastq_info\", \"reads\": %llu, \"input_bytes\": %llu, \"seconds\": %.6f, "
+                  "\"Mreads_per_s\": %.3f, \"GB_per_s\": %.3f, \"devices\": %zu, \"min_quality\": %lu, \"max_quality\": %lu, "
+                  "\"min_read_length\": %lu, \"max_read_length\": %lu, \"median_read_length\": %u}\n",
+              reads, bytes, secs, secs > 0 ? (double)reads / secs / 1e6 : 0.0, secs > 0 ? (double)bytes / secs / 1e9 : 0.0,
+              std::max<size_t>(devices.size(), 1), min_qual, max_qual, min_rl - 1, max_rl - 1, (unsigned)(med - 1));
+      fclose(jf);
+    }
+  }
   // everything is said and nothing is open for writing: leave without the HIP runtime's tear-down (0.1 s)
   fflush(stdout);
   fflush(stderr);

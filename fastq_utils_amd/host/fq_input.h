@@ -58,6 +58,13 @@ inline bool& keep_slots_until_exit() {
   return v;
 }
 
+// input bytes handed to the GPU so far (every piece an Input gives out, carried tails not counted twice): what the
+// machine-readable metrics of a program are made of (FQGPU_JSON_METRICS)
+inline std::atomic<unsigned long long>& bytes_handed_out() {
+  static std::atomic<unsigned long long> v{0};
+  return v;
+}
+
 class SlotPool {
  public:
   static SlotPool& get() {
@@ -293,6 +300,7 @@ class Input {
       data_ = s.buf + s.head - carry;
     }
     len_ = carry + s.len;
+    bytes_handed_out() += s.len;
     eof_ = s.last;
     if (prev >= 0) {  // the previous slot may be refilled
       std::lock_guard<std::mutex> lk(mu_);
@@ -668,6 +676,7 @@ class Input {
     whole_ = buf;
     data_ = buf;
     len_ = len;
+    bytes_handed_out() += len;
     eof_ = true;
     finished_ = true;
     return true;

@@ -86,6 +86,28 @@ def _fp_worker(rank, world, port, q):
     # the same exchange in rounds of 4 pairs per peer must deliver the same bytes
     recv2, recv_counts2 = fdist.exchange_fingerprints(send, counts, round_pairs=4)
     assert recv_counts2 == recv_counts and recv2.view(torch.int64).view(-1, 2).tolist() == got
+    # a collective that delivers wrong bytes (what one 1.6 GB all_to_all_single did on RCCL 2.26) must be an error on the
+    # rank that received them, not a wrong finding: flip one byte of what rank 1 receives in the payload exchange
+    real = dist.all_to_all_single
+    calls = {"n": 0}
+
+    def flipping(out, inp, *a, **kw):
+        r = real(out, inp, *a, **kw)
+        calls["n"] += 1
+        if rank == 1 and out.dtype == torch.uint8 and out.numel() and not calls.get("done"):  # the payload (counts and checksums are int64)
+            out[out.numel() // 2] ^= 0x40
+            calls["done"] = True
+        return r
+
+    dist.all_to_all_single = flipping
+    caught = None
+    try:
+        fdist.exchange_fingerprints(send, counts)
+    except RuntimeError as e:
+        caught = str(e)
+    finally:
+        dist.all_to_all_single = real
+    assert (caught is not None and "checksum" in caught) == (rank == 1), (rank, caught)
     q.put((rank, recv_counts, got))
     dist.destroy_process_group()
 

@@ -87,14 +87,6 @@ int main(int argc, char** argv) {
     P1(16u, "  pass1 - no quality test");
     P1(24u, "  pass1 - types only");
     P1(0u, "k_stream_pass1");
-    P1(32u, "pass1 marks+range v2, staging r3");
-    P1(32u + 128u, "  ... copy in image order");
-    P1(32u + 64u, "  ... staging without table");
-    P1(64u, "pass1 r3 + staging without table");
-    P1(128u, "pass1 r3 + copy in image order");
-    P1(32u + 2u, "  v2 - no staging");
-    P1(32u + 8u, "  v2 - no base check");
-    P1(32u + 16u, "  v2 - no quality test");
     hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, 0, counts, n_tiles, local, spans);
     hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, 0, spans, n_spans, img, n, cs);
     report("k_stream_pass2", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_pass2, dim3((n_tiles + 31) / 32), dim3(kBlock), 0, 0, img, n, n_tiles, counts, cinfo, stage, local, spans, line_end, 4 * reads + 32, 4 * reads, sm, redo, cs); }));
