@@ -1478,12 +1478,13 @@ int fqg_names_compare(fqg_ctx* c, const fqg_frame* a, const fqg_file_state* sa, 
 // Tile geometry for one call: T iterations whose records and output text fit `budget` bytes of LDS
 // per wavefront, from the mean record sizes (a tile that does not fit anyway takes the direct path).
 // FQGPU_BC_LDS overrides the budget (bytes, 4096..65536).
-static BcTile bc_tile_for(const BcParams& P) {
-  static const unsigned budget = [] {
+static BcTile bc_tile_for(const BcParams& P, unsigned default_budget = 20480u) {
+  static const unsigned env_budget = [] {
     const char* e = getenv("FQGPU_BC_LDS");
     const long v = e ? atol(e) : 0;
-    return (unsigned)(v >= 4096 && v <= 65536 ? v : 20480);
+    return (unsigned)(v >= 4096 && v <= 65536 ? v : 0);
   }();
+  const unsigned budget = env_budget ? env_budget : default_budget;
   double in = 0, out_sam = 0, out_fq = 0;
   int files = 0;
   for (int x = 1; x < kBcFiles; ++x) {
@@ -1850,8 +1851,10 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   memset(&z, 0, sizeof(z));
   *c->h_bcall = z;
   HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
-  BcTile tc = bc_tile_for(F);
-  tc.plan_m = 1;  // the decisions here are a few LDS reads per record: wavefronts in flight matter more than lanes per tile
+  // (the tiles are the EMIT kernel's alone now - the plan works record by record - and that kernel likes 24 KiB per
+  // wavefront better than the 20 KiB it shared with a staging plan: tools/tiles_lds_sweep.sh)
+  BcTile tc = bc_tile_for(F, 24576u);
+  tc.plan_m = 1;
   const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
   if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
   auto resident = [&](const void* kernel, unsigned lds) {
@@ -1863,11 +1866,11 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   unsigned long long* h_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_bcall) + sizeof(BcCall));
   {
     ProfScope ps(c, "k_rf_plan");
-    const unsigned plan_lds = tc.in_cap * tc.plan_m;
-    const uint64_t plan_tiles = (n_tiles + tc.plan_m - 1) / tc.plan_m;
-    const unsigned grid = (unsigned)std::min<uint64_t>(plan_tiles, resident((const void*)k_rf_plan_tile, plan_lds));
-    hipLaunchKernelGGL(k_rf_plan_tile, dim3(grid), dim3(kWave), plan_lds, c->stream, F, P, tc, n_rec,
-                       (uint8_t*)c->bc_status.p, (uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 32));
+    hipLaunchKernelGGL(k_rf_plan_records, dim3(grid), dim3(kBlock), 0, c->stream, F, P, n_rec, (uint8_t*)c->bc_status.p,
+                       (uint32_t*)c->bc_len[1].p);
+    hipLaunchKernelGGL(k_rf_tile_flags, dim3((unsigned)((n_tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, F, tc, n_rec,
+                       (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
   }
   {
     ProfScope ps(c, "k_rf_scan");

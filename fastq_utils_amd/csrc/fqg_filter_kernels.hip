@@ -42,7 +42,26 @@ __device__ __forceinline__ uint32_t rf_count_n(const BcLine& seq) {
       cnt += (uint32_t)__builtin_popcountll(m);
     }
   } else {
-    for (uint32_t i = 0; i < n; ++i) cnt += (seq.p[i] | 0x20) == 'n';
+    // the line where it lies in the image: 16-byte loads on the image's own alignment, the two ends masked (the image
+    // is 16-byte aligned and readable up to the next multiple of 16 behind its last byte, as for the span copies)
+    const uintptr_t a0 = (uintptr_t)seq.p & ~(uintptr_t)15;
+    const uint32_t pre = (uint32_t)((uintptr_t)seq.p - a0), total = pre + n;
+    for (uint32_t at = 0; at < total; at += 16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a0 + at);
+      uint64_t m0 = bytes_eq(((uint64_t)v.x | ((uint64_t)v.y << 32)) | 0x2020202020202020ull, (uint8_t)'n');
+      uint64_t m1 = bytes_eq(((uint64_t)v.z | ((uint64_t)v.w << 32)) | 0x2020202020202020ull, (uint8_t)'n');
+      const uint32_t lo = at == 0 ? pre : 0u, hi = total - at < 16u ? total - at : 16u;  // bytes [lo, hi) of the piece count
+      if (lo | (hi ^ 16u)) {
+        auto keep = [](uint32_t from, uint32_t to) {  // bytes [from, to) of an 8-byte word, 0 <= from, to <= 8
+          const uint64_t below_to = to >= 8 ? ~0ull : (1ull << (8 * to)) - 1ull;
+          const uint64_t below_from = from >= 8 ? ~0ull : (1ull << (8 * from)) - 1ull;
+          return below_to & ~below_from;
+        };
+        m0 &= keep(lo < 8 ? lo : 8, hi < 8 ? hi : 8);
+        m1 &= keep(lo > 8 ? lo - 8 : 0, hi > 8 ? hi - 8 : 0);
+      }
+      cnt += (uint32_t)__builtin_popcountll(m0) + (uint32_t)__builtin_popcountll(m1);
+    }
   }
   return cnt;
 }
@@ -122,88 +141,46 @@ __device__ __forceinline__ void rf_emit(const BcLine (&ln)[4], const RfCut& c, W
   if (c.q_nl) w.ch('\n');
 }
 
-// One wavefront per PLAN tile = plan_m tiles of the emit kernel (see k_bc_plan_tile), one lane per record.
-// F holds the single input as file 1.
-__global__ __launch_bounds__(kWave) void k_rf_plan_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
-                                                        uint8_t* __restrict__ status, uint32_t* __restrict__ len1,
-                                                        uint8_t* __restrict__ tile_big, BcCall* __restrict__ call) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
-  const int lane = (int)threadIdx.x;
-  const uint32_t Tp = tc.T * tc.plan_m, plan_cap = tc.in_cap * tc.plan_m;
-  const uint64_t n_tiles = (n_rec + Tp - 1) / Tp;
-  auto tile_size = [&](uint64_t tile) {
-    const uint64_t left = n_rec - tile * Tp;
-    return (uint32_t)(left < (uint64_t)Tp ? left : (uint64_t)Tp);
-  };
-  auto geo_of = [&](uint64_t tile, TileGeo& tg) {
-    const uint32_t Tn = tile_size(tile);
-    bc_geo_load(F.f[1], tile * Tp + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1), tg.f[1]);
-  };
-  // three tiles under way per wavefront, every request without a branch (see k_bc_emit_tile)
-  const uint64_t stride = gridDim.x;
-  auto clamp_tile = [&](uint64_t t) { return t < n_tiles ? t : n_tiles - 1; };
-  TileGeo cur, nxt, nx2;
-  bc_u32x4 pf[kSpanPf];
-  if (blockIdx.x < n_tiles) {
-    geo_of(blockIdx.x, cur);
-    geo_of(clamp_tile(blockIdx.x + stride), nxt);
-    SpanPlan sp;
-    bc_span_plan<false, 0x02>(F, cur, (int)tile_size(blockIdx.x) - 1, plan_cap, sp);
-    bc_span_fetch(sp, lane, pf);
+// The plan: ONE THREAD PER RECORD, straight from the image.  What it decides needs the four line lengths (the line
+// index: 40 bytes per record, neighbouring lanes neighbouring words) and, of the record's bytes, only the sequence line -
+// all of it for fastq_filter_n (counted in 16-byte pieces), its two ends for fastq_trim_poly_at (the scans stop at the
+// first character that is no A / T / N: one or two bytes per record on ordinary reads).  The first form of this kernel
+// staged whole tiles in LDS the way the emit kernel does and read every record twice (39 GB for the 35 GB image of
+// the bench, 8.2 ms of 22.5); a record's header and quality bytes are nothing the decision looks at.
+__global__ __launch_bounds__(kBlock) void k_rf_plan_records(BcParams F, RfParams P, uint64_t n_rec, uint8_t* __restrict__ status,
+                                                            uint32_t* __restrict__ len1) {
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_rec; k += (uint64_t)gridDim.x * kBlock) {
+    BcLine G[4];
+    bc_lines(F.f[1], k, G);
+    const RfCut c = rf_decide<false>(P, G);
+    status[k] = c.flags;
+    len1[k] = (c.flags & kRfDiscard) ? 0u : rf_out_len(G, c);
   }
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += stride, cur = nxt, nxt = nx2) {
-    const uint64_t k0 = tile * Tp;
-    const uint32_t Tn = tile_size(tile);
-    const bool valid = (uint32_t)lane < Tn;
-    const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
-    BcLine L[kBcFiles][4];
-    bool fit;
-    {
-      SpanPlan sp;
-      bc_span_plan<false, 0x02>(F, cur, (int)Tn - 1, plan_cap, sp);
-      fit = sp.fit;
-      if (fit) bc_span_land(sp, lane, pf, s_lds);
-      bc_span_lines<false, 0x02>(F, cur, sp, s_lds, L);
-    }
-    {
-      const uint64_t tn = clamp_tile(tile + stride);
-      SpanPlan sp;
-      bc_span_plan<false, 0x02>(F, nxt, (int)tile_size(tn) - 1, plan_cap, sp);
-      bc_span_fetch(sp, lane, pf);
-    }
-    geo_of(clamp_tile(tile + 2 * stride), nx2);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    RfCut c;
-    uint32_t n = 0;
-    if (fit) {
-      c = rf_decide<true>(P, L[1]);
-      n = rf_out_len(L[1], c);
-    } else {
-      BcLine G[4];
-      bc_lines(F.f[1], k, G);
-      c = rf_decide<false>(P, G);
-      n = rf_out_len(G, c);
-    }
-    if (c.flags & kRfDiscard) n = 0;
-    if (valid) {
-      status[k] = c.flags;
-      len1[k] = n;
-    } else {
-      n = 0;
-    }
-    for (uint32_t j = 0; j * tc.T < Tn; ++j) {  // the emit tiles inside this plan tile
-      const uint32_t first = j * tc.T, last = (first + tc.T < Tn ? first + tc.T : Tn) - 1;
-      const uint32_t sum = wave_sum32((uint32_t)lane >= first && (uint32_t)lane <= last ? n : 0u);
-      const bool fits_in = bc_emit_tile_fits<0x02>(F, cur, (int)first, (int)last, tc.in_cap);
-      if (lane == 0) {
-        const bool big = !fits_in || sum + 32 > tc.out_cap;
-        tile_big[tile * tc.plan_m + j] = big ? 1 : 0;
-        if (big) atomicAdd(&call->big, 1ull);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+}
+
+// ... and what it decides per EMIT tile - do the tile's input span and its output fit the emit kernel's LDS areas
+// (bc_emit_tile_fits for the one input file): one thread per tile
+__global__ __launch_bounds__(kBlock) void k_rf_tile_flags(BcParams F, BcTile tc, uint64_t n_rec, const uint32_t* __restrict__ len1,
+                                                          uint8_t* __restrict__ tile_big, BcCall* __restrict__ call) {
+  const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
+  const BcFile& f = F.f[1];
+  bool big = false;
+  const uint64_t tile = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tile < n_tiles) {
+    const uint64_t k0 = tile * tc.T, k1 = (k0 + tc.T < n_rec ? k0 + tc.T : n_rec) - 1;
+    uint64_t sum = 0;
+    for (uint64_t k = k0; k <= k1; ++k) sum += len1[k];
+    const uint64_t r0 = f.first + k0 * f.step + f.add, r1 = f.first + k1 * f.step + f.add;
+    const uint64_t s0 = r0 == 0 ? 0 : f.fv.line_end[4 * r0 - 1] + 1, e3l = f.fv.line_end[4 * r1 + 3];
+    const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - s0;
+    const uint32_t skew = (uint32_t)((uintptr_t)(f.fv.img + s0) & 15u);
+    bool fit = n <= (uint64_t)tc.in_cap;
+    if (fit) fit = (uint64_t)((skew + (uint32_t)n + 15u) >> 4) * 16u + 32u <= (uint64_t)tc.in_cap;
+    big = !fit || sum + 32 > tc.out_cap;
+    tile_big[tile] = big ? 1 : 0;
   }
+  const unsigned long long m = __ballot(big);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(&call->big, (unsigned long long)__builtin_popcountll(m));
 }
 
 // discarded / trimmed records: one atomic per workgroup

@@ -910,7 +910,8 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
           if (have[q][k] && L0 + k - 1 < A.line_cap) A.line_end[L0 + k - 1] = e[q][k];
       }
       // checks (complete records only)
-      bool sus = false, complete = have[q][4] && L0 + 3 < A.limit;
+      bool sus = false, complete = have[q][4] && L0 + 3 < A.limit, counted = false;
+      uint64_t rl = 0;
       if (complete) {
         // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
         if (r == 0) sus |= A.img[0] != '@' || (A.n > 1 && A.img[1] == '\n');
@@ -921,13 +922,32 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
         sus |= l1 < 1 || l1 != l3 || A.space != FQG_SPACE_SEQ;
         sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
                l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + has_nl > FQG_MAX_READ_LENGTH - 1;
-        if (A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1) {
-          const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line always ends in '\n' here
+        counted = A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1;
+        if (counted) {
+          rl = l1 + 1;  // strlen(seq): the sequence line always ends in '\n' here
           ++n_ok;
           min_rl = rl < min_rl ? rl : min_rl;
           max_rl = rl > max_rl ? rl : max_rl;
-          if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
-          else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
+        }
+      }
+      // the length histogram: reads of ONE length are the usual file, and 64 lanes adding 1 to one LDS word are 64
+      // serialised atomics (they were most of this kernel's LDS cycles: SQ_LDS_BANK_CONFLICT 3.5x SQ_ACTIVE_INST_LDS in
+      // profiles/r03b_pass1_sq_counters.json) - the lanes that share the first counted lane's length add once, together
+      {
+        const unsigned long long cm = __ballot(counted);
+        if (cm) {
+          const int first = __builtin_ctzll(cm);
+          const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((uint32_t)rl, first);
+          const bool with_first = counted && rl == (uint64_t)rl0;
+          const unsigned long long same = __ballot(with_first);
+          if (lane == first) {
+            if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], (uint32_t)__builtin_popcountll(same));
+            else atomicAdd(&A.hist[rl], (unsigned long long)A.weight * (unsigned long long)__builtin_popcountll(same));
+          }
+          if (counted && !with_first) {
+            if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
+            else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
+          }
         }
       }
       // the wavefront owns records g*64 .. g*64+63 = two whole words of the bitmap

@@ -226,6 +226,44 @@ def test_a_long_line_late_in_a_file_prints_nothing_twice(args):
             assert err == p.stderr.decode("latin-1"), (err[-300:], p.stderr[-300:])
 
 
+def test_bgzipped_input_and_json_metrics():
+    """A bgzip'd FASTQ file (BGZF blocks, inflated on many threads by host/fq_input.h) gives what the same bytes give as a
+    plain file and as an ordinary .gz - in every mode - and FQGPU_JSON_METRICS writes the machine-readable twin of the
+    summary without touching stdout / stderr."""
+    import gzip
+    import json
+
+    from tests import bamgen
+
+    rng = np.random.default_rng(21)
+    img = fuzz.make_fastq(rng, 60_000, 30, 120, "casava")
+    bad = fuzz.mutate(rng, img, "flip_seq")
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, data in (("a", img), ("b", bad)):
+            with open(os.path.join(tmp, name + ".fastq"), "wb") as f:
+                f.write(data)
+            with open(os.path.join(tmp, name + ".bgz.fastq.gz"), "wb") as f:
+                f.write(bamgen.bgzf(data, level=1))
+            with open(os.path.join(tmp, name + ".z.fastq.gz"), "wb") as f:
+                f.write(gzip.compress(data, 1))
+        for stem in ("a", "b"):
+            for mode in (["-r"], [], ["pe"]):
+                want = None
+                for ext in (".fastq", ".bgz.fastq.gz", ".z.fastq.gz"):
+                    args = [a for a in mode if a != "pe"] + [stem + ext] + (["pe"] if "pe" in mode else [])
+                    rc, out, err = run_cli(args, tmp, {"FQGPU_CHUNK_MB": "1"})
+                    got = (rc, out, strip_progress(err).replace(stem + ext, "F"))
+                    want = want or got
+                    assert got == want, (args, err[-300:])
+        jm = os.path.join(tmp, "m.json")
+        rc, out, err = run_cli(["-r", "a.bgz.fastq.gz"], tmp, {"FQGPU_JSON_METRICS": jm})
+        rc0, out0, err0 = run_cli(["-r", "a.bgz.fastq.gz"], tmp)
+        assert (rc, out, err) == (rc0, out0, err0) and rc == 0
+        m = json.load(open(jm))
+        assert m["program"] == "fastq_info" and m["reads"] == 60_000 and m["input_bytes"] == len(img)
+        assert m["seconds"] > 0 and m["Mreads_per_s"] > 0 and m["min_read_length"] == 30 and m["max_read_length"] == 120
+
+
 # ---- FQGPU_DEVICES in the index modes: names across contexts (host/fq_names_multi.h) ----------------------------------
 def test_several_devices_golden_index_and_pairing_invocations():
     """every golden invocation that tests names (no -r, not interleaved "pe"): records spread over three contexts, names
