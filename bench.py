@@ -346,6 +346,15 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
             legs[label] = {"seconds": runs, "Mpairs_per_s": m / best / 1e6, "input_GBps": m * per_pair_in / best / 1e9, "ok": ok,
                            "includes": "process start, HIP initialisation, pinned slots, reading both files, H2D, kernels, D2H, "
                                        + ("parallel gzip (level as the reference's gzopen \"w\"), file written to tmpfs" if sink is None else "SAM text written to /dev/null")}
+            if sink is not None and ok:
+                # H2D of one block and D2H of another can share the link (it is full duplex) when two contexts work on
+                # the one GPU: the record-block path of FQGPU_DEVICES (host/fq_blocks.h) with the same device twice
+                for devs in ("0,0", "0,0,0"):
+                    secs, p = timed(args, sink, {"FQGPU_DEVICES": devs})
+                    c = counts(p.stderr)
+                    legs[label]["contexts_" + devs.replace(",", "_")] = {
+                        "seconds": secs, "Mpairs_per_s": m / secs / 1e6,
+                        "ok": p.returncode == 0 and c.get("Reads processed: ") == m and c.get("Reads discarded: ") == want_disc}
             if sink is None and os.path.exists(os.path.join(d, "out.fastq.gz")):
                 legs[label]["output_gz_GB"] = os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9
                 os.unlink(os.path.join(d, "out.fastq.gz"))

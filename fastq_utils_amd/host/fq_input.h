@@ -505,19 +505,29 @@ class Input {
         if (bz_buf_.size() - bz_at_ >= (1u << 17)) return len;  // (cannot be: a window of 128 KiB holds a block)
         continue;
       }
-      if (!inflate_pool_) inflate_pool_.reset(new ReaderPool(std::max(1u, std::min(32u, std::thread::hardware_concurrency()))));
-      const unsigned T = (unsigned)std::min<size_t>(inflate_pool_->size(), std::max<size_t>(1, blocks.size() / 8));
+      // (inflating is all this input costs - zlib gives a few hundred MB/s per core, the GPU takes tens of GB/s: every
+      // core the host has, FQGPU_HOST_THREADS caps it)
+      if (!inflate_pool_) {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char* e = getenv("FQGPU_HOST_THREADS")) hw = (unsigned)std::max(1L, strtol(e, nullptr, 10));
+        inflate_pool_.reset(new ReaderPool(std::max(1u, std::min(256u, hw ? hw : 1u))));
+      }
+      const unsigned T = (unsigned)std::min<size_t>(inflate_pool_->size(), std::max<size_t>(1, blocks.size() / 4));
       std::atomic<bool> bad{false};
       const unsigned char* src = bz_buf_.data();
       inflate_pool_->run(T, [&](unsigned t) {
-        for (size_t i = blocks.size() * t / T; i < blocks.size() * (t + 1) / T; ++i) {
+        z_stream zs;  // one inflate state per thread and batch, reset per block (setting one up allocates its window)
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) {
+          bad = true;
+          return;
+        }
+        for (size_t i = blocks.size() * t / T; i < blocks.size() * (t + 1) / T && !bad; ++i) {
           const Block& b = blocks[i];
           if (b.isize == 0) continue;  // (the end-of-file marker, or an empty block)
-          z_stream zs;
-          memset(&zs, 0, sizeof(zs));
-          if (inflateInit2(&zs, -15) != Z_OK) {
+          if (inflateReset(&zs) != Z_OK) {
             bad = true;
-            return;
+            break;
           }
           zs.next_in = const_cast<Bytef*>(src + b.at + 12 + b.xlen);
           zs.avail_in = (uInt)(b.size - 12 - b.xlen - 8);
@@ -525,14 +535,12 @@ class Input {
           zs.avail_out = (uInt)b.isize;
           const int rc = inflate(&zs, Z_FINISH);
           const bool good = rc == Z_STREAM_END && zs.total_out == b.isize;
-          inflateEnd(&zs);
           const unsigned char* c = src + b.at + b.size - 8;
           const uint32_t want_crc = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
-          if (!good || (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(dst + b.out_at), (uInt)b.isize) != want_crc) {
+          if (!good || (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(dst + b.out_at), (uInt)b.isize) != want_crc)
             bad = true;
-            return;
-          }
         }
+        inflateEnd(&zs);
       });
       if (bad) {
         fail("corrupt BGZF block (inflate or CRC-32 failed)");
