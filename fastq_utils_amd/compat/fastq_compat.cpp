@@ -37,6 +37,7 @@
 
 #include "../../include/fastq_gpu_compat.h"
 #include "../../include/fqg.h"
+#include "../host/fq_reframe.h"
 
 namespace {
 
@@ -82,12 +83,26 @@ struct Verdict {  // one bulk validation of a file under one file state
 struct FileCtx {
   FASTQ_FILE* fd = nullptr;
   bool loaded = false;
+  // the file's bytes - cut at the reference's gzgets limits when a line is beyond them (host/fq_reframe.h: a piece
+  // that gzgets returns without its newline is followed by "\0\n"); `cuts` = where those two bytes lie in `image`.
+  // Positions the caller sees (FASTQ_ENTRY.offset, INDEX_ENTRY.entry_start, the offsets it seeks to) are the FILE's.
   std::vector<char> image;
+  std::vector<size_t> cuts;
+  uint32_t vflags = 0;  // FQG_VALIDATE_REFRAMED once the image is cut
   std::vector<fqg_record> rec;
   uint64_t n_records = 0, next = 0;
   int tail_lines = 0;   // lines of an incomplete last record
   std::vector<Verdict> verdicts;
 };
+
+uint64_t to_file_offset(const FileCtx* f, uint64_t at) {  // image position (a record start) -> position in the file
+  return at - 2 * (uint64_t)(std::lower_bound(f->cuts.begin(), f->cuts.end(), (size_t)at) - f->cuts.begin());
+}
+uint64_t to_image_offset(const FileCtx* f, uint64_t file_at) {  // ... and back: behind every cut made at or before it
+  uint64_t k = 0;
+  while (k < f->cuts.size() && f->cuts[k] - 2 * k <= file_at) ++k;  // (cuts are few: files with such lines are rare)
+  return file_at + 2 * k;
+}
 
 std::unordered_map<FASTQ_FILE*, FileCtx*> g_files;
 struct Origin {
@@ -145,6 +160,16 @@ void load(FileCtx* f) {
   int got;
   while ((got = gzread(fd->fd, buf, sizeof(buf))) > 0) f->image.insert(f->image.end(), buf, buf + got);
   gzclose(fd->fd);
+  {  // the reference's gzgets calls (src/fastq.c:249-253), as cuts
+    fqhost::Reframer rf;
+    std::string cut_image;
+    bool clean = true;
+    rf.run(f->image.data(), f->image.size(), true, cut_image, &clean, &f->cuts);
+    if (!clean) {
+      f->image.assign(cut_image.begin(), cut_image.end());
+      f->vflags = FQG_VALIDATE_REFRAMED;
+    } else f->cuts.clear();
+  }
   fqg_file_state st;
   memset(&st, 0, sizeof(st));
   st.is_pe = fd->is_pe;
@@ -152,7 +177,7 @@ void load(FileCtx* f) {
   st.space = FQG_SPACE_UNDEF;
   fqg_validate_result r;
   LIB(fqg_validate(gpu(), nullptr, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st,
-                   FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS, &r));
+                   FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | f->vflags, &r));
   f->n_records = r.n_records;
   f->tail_lines = r.tail_lines;
   f->rec.resize(r.n_records ? r.n_records : 1);
@@ -168,7 +193,7 @@ const Verdict& verdict_for(FileCtx* f, const fqg_file_state& st) {
   v.st = st;
   fqg_acc* acc = nullptr;
   LIB(fqg_acc_create(gpu(), &acc));
-  LIB(fqg_validate(gpu(), acc, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st, 0, &v.r));
+  LIB(fqg_validate(gpu(), acc, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st, f->vflags, &v.r));
   LIB(fqg_acc_read(acc, &v.stats));
   fqg_acc_destroy(acc);
   f->verdicts.push_back(v);
@@ -264,7 +289,7 @@ void fastq_new_entry_stats(FASTQ_FILE* fd, FASTQ_ENTRY* entry) {  // src/fastq.c
 int fastq_read_entry(FASTQ_FILE* fd, FASTQ_ENTRY* e) {  // src/fastq.c:245-261
   FileCtx* f = ctx_of(fd);
   load(f);
-  e->offset = f->next < f->n_records ? (long long)f->rec[f->next].offset : (long long)f->image.size();
+  e->offset = (long long)to_file_offset(f, f->next < f->n_records ? f->rec[f->next].offset : (uint64_t)f->image.size());
   if (gzeof(fd->fd)) return 0;
   if (gzgetc(fd->fd) < 0) {
     e->hdr1[0] = '\0';
@@ -275,26 +300,25 @@ int fastq_read_entry(FASTQ_FILE* fd, FASTQ_ENTRY* e) {  // src/fastq.c:245-261
     exit(1);
   }
   const fqg_record& d = f->rec[f->next];
-  if (d.hdr1_len > FQC_MAX_LABEL_LENGTH - 1 || d.hdr2_len > FQC_MAX_LABEL_LENGTH - 1 ||
-      d.seq_len > FQC_MAX_READ_LENGTH - 1 || d.qual_len > FQC_MAX_READ_LENGTH - 1) {
-    PRINT_ERROR(
-        "Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes); the "
-        "reference splits such lines silently, this library refuses them",
-        fd->filename, (unsigned long)(f->next + 1), FQC_MAX_LABEL_LENGTH - 1, FQC_MAX_READ_LENGTH - 1);
-    exit(kExitSys);
-  }
+  // a line of the image into one of the caller's buffers: a piece that ends in the two bytes of a cut is the piece
+  // alone - what gzgets left in the buffer (limit - 1 bytes and the NUL)
   const char* p = f->image.data() + d.offset;
-  memcpy(e->hdr1, p, d.hdr1_len);
-  e->hdr1[d.hdr1_len] = '\0';
-  p += d.hdr1_len;
-  memcpy(e->seq, p, d.seq_len);
-  e->seq[d.seq_len] = '\0';
-  p += d.seq_len;
-  memcpy(e->hdr2, p, d.hdr2_len);
-  e->hdr2[d.hdr2_len] = '\0';
-  p += d.hdr2_len;
-  memcpy(e->qual, p, d.qual_len);
-  e->qual[d.qual_len] = '\0';
+  auto line_to = [&](char* dst, size_t cap, uint32_t len) {
+    size_t n = len;
+    if (f->vflags && n >= 2 && p[n - 2] == '\0' && p[n - 1] == '\n') n -= 2;
+    if (n > cap - 1) {  // (cannot be: the image was cut at the limits)
+      PRINT_ERROR("Error in file %s: record %lu has a line longer than the reference's line buffers", fd->filename,
+                  (unsigned long)(f->next + 1));
+      exit(kExitSys);
+    }
+    memcpy(dst, p, n);
+    dst[n] = '\0';
+    p += len;
+  };
+  line_to(e->hdr1, sizeof(e->hdr1), d.hdr1_len);
+  line_to(e->seq, sizeof(e->seq), d.seq_len);
+  line_to(e->hdr2, sizeof(e->hdr2), d.hdr2_len);
+  line_to(e->qual, sizeof(e->qual), d.qual_len);
   fd->cline += 4;
   e->read_len = d.read_len;
   g_origin[e] = Origin{f, f->next};
@@ -467,7 +491,7 @@ void fastq_index_readnames(FASTQ_FILE* fd1, hashtable index, long long start_off
   fqg_acc* acc = nullptr;
   LIB(fqg_acc_create(c, &acc));
   fqg_validate_result r;
-  LIB(fqg_validate(c, acc, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st, FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES, &r));
+  LIB(fqg_validate(c, acc, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st, FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES | f->vflags, &r));
   fqg_index* ix = nullptr;
   LIB(fqg_index_create(c, r.n_records, &ix));
   fqg_index_result ir;
@@ -566,7 +590,7 @@ INDEX_ENTRY* fastq_index_lookup_header(hashtable sn_index, char* hdr) {
       ic->alive_valid = true;
     }
     if (k >= f->n_records || !ic->alive[k]) return nullptr;
-    found.entry_start = (off_t)f->rec[k].offset;
+    found.entry_start = (off_t)to_file_offset(f, f->rec[k].offset);
     return &found;
   }
   auto asked = ic->asked.find(f);
@@ -580,7 +604,7 @@ INDEX_ENTRY* fastq_index_lookup_header(hashtable sn_index, char* hdr) {
     st.space = f->fd->space;
     fqg_validate_result r;
     LIB(fqg_validate(gpu(), nullptr, f->image.data(), f->image.size(), FQG_MEM_HOST, 1, &st,
-                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | FQG_VALIDATE_NAMES, &r));
+                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | FQG_VALIDATE_NAMES | f->vflags, &r));
     std::vector<uint64_t> m(r.n_records ? r.n_records : 1, FQG_NO_MATCH);
     fqg_index_result ir;
     if (r.n_records) LIB(fqg_index_probe_delete(gpu(), ic->ix, &st, m.data(), &ir));
@@ -588,7 +612,7 @@ INDEX_ENTRY* fastq_index_lookup_header(hashtable sn_index, char* hdr) {
     ic->alive_valid = false;
   }
   if (k >= asked->second.size() || asked->second[k] >= FQG_MATCH_WRONG_HEADER) return nullptr;
-  found.entry_start = (off_t)ic->owner->rec[asked->second[k]].offset;
+  found.entry_start = (off_t)to_file_offset(ic->owner, ic->owner->rec[asked->second[k]].offset);
   return &found;
 }
 
@@ -598,11 +622,12 @@ void fastq_index_delete(char* rname, hashtable index) {
 }
 
 // ---- positions (src/fastq.c:77-80, 124-157, 191-199) -----------------------------------------------------------
-static uint64_t cursor_offset(const FileCtx* f) {
-  return f->next < f->n_records ? f->rec[f->next].offset : (uint64_t)f->image.size();
+static uint64_t cursor_offset(const FileCtx* f) {  // (the FILE's offset of the record the cursor is at)
+  return to_file_offset(f, f->next < f->n_records ? f->rec[f->next].offset : (uint64_t)f->image.size());
 }
 // the record that starts at `offset`, n_records for the end of the file, ~0 for anything else
-static uint64_t record_at(const FileCtx* f, uint64_t offset) {
+static uint64_t record_at(const FileCtx* f, uint64_t file_offset) {
+  const uint64_t offset = to_image_offset(f, file_offset);
   if (offset >= f->image.size()) return offset == f->image.size() ? f->n_records : ~0ull;
   uint64_t lo = 0, hi = f->n_records;
   while (lo < hi) {

@@ -81,6 +81,7 @@ struct fqg_ctx {
   std::string err;
   int cu_count = 256;
   int lines_per_cu = 0;  // workgroups of k_stream_lines a CU holds (asked once)
+  int lines_fast_per_cu = 0;  // ... of k_stream_lines_fast
   uint64_t stream_min = 1ull << 20;  // images at least this large take the single-pass framing path (FQGPU_STREAM_MIN)
 
   DevBuf image;       // staging for host images
@@ -95,6 +96,7 @@ struct fqg_ctx {
   DevBuf cinfo;       // streaming path: u32 info word per chunk
   DevBuf queue;       // streaming path: u64 suspect byte positions
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
+  DevBuf lines_slow;  // streaming path: u32 steps that k_stream_lines_fast leaves to the general kernel
   DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
   DevBuf name_hcount; // ... and the headers every chunk saw
   DevBuf name_redo, name_redo_chunks;  // what the capture-fed name kernel leaves to the line-index one
@@ -301,6 +303,7 @@ void fqg_close(fqg_ctx* c) {
   release(c->cinfo);
   release(c->queue);
   release(c->redo);
+  release(c->lines_slow);
   release(c->name_recs);
   release(c->name_hcount);
   release(c->name_redo);
@@ -748,7 +751,25 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
         c->lines_per_cu = nb;
       }
       const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)c->cu_count * c->lines_per_cu));
-      hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A);
+      static const bool general_only = getenv("FQGPU_LINES_GENERAL") != nullptr;  // (A/B: every step through the general kernel)
+      if (general_only) {
+        hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint32_t*)nullptr,
+                           (const unsigned int*)nullptr);
+      } else {
+        // the steps of ordinary records in the kernel without a search, what it lists in the general one behind it
+        const uint64_t n_steps = (groups + kLinesPer - 1) / kLinesPer;
+        if ((rc = ensure(c, c->lines_slow, (size_t)n_steps * 4 + 4))) return rc;
+        if (!c->lines_fast_per_cu) {
+          int nb = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines_fast), kBlock, 0) != hipSuccess || nb < 1)
+            nb = 4;
+          c->lines_fast_per_cu = nb;
+        }
+        const unsigned grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
+        hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, c->stream, A, (uint32_t*)c->lines_slow.p, c->d_cs);
+        hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint32_t*)c->lines_slow.p,
+                           (const unsigned int*)&c->d_cs->slow_steps);
+      }
     }
     out->records_done = true;
   }
@@ -1867,8 +1888,14 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   {
     ProfScope ps(c, "k_rf_plan");
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 32));
-    hipLaunchKernelGGL(k_rf_plan_records, dim3(grid), dim3(kBlock), 0, c->stream, F, P, n_rec, (uint8_t*)c->bc_status.p,
-                       (uint32_t*)c->bc_len[1].p);
+    if (P.mode == FQG_FILTER_N) {
+      const unsigned grid_n = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + 31) / 32, (uint64_t)c->cu_count * 32));
+      hipLaunchKernelGGL(k_rf_plan_n, dim3(grid_n), dim3(kBlock), 0, c->stream, F, P, n_rec, (uint8_t*)c->bc_status.p,
+                         (uint32_t*)c->bc_len[1].p);
+    } else {
+      hipLaunchKernelGGL(k_rf_plan_records, dim3(grid), dim3(kBlock), 0, c->stream, F, P, n_rec, (uint8_t*)c->bc_status.p,
+                         (uint32_t*)c->bc_len[1].p);
+    }
     hipLaunchKernelGGL(k_rf_tile_flags, dim3((unsigned)((n_tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, F, tc, n_rec,
                        (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
   }

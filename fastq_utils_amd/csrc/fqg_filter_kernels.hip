@@ -158,6 +158,61 @@ __global__ __launch_bounds__(kBlock) void k_rf_plan_records(BcParams F, RfParams
   }
 }
 
+// fastq_filter_n looks at every character of the sequence line: EIGHT LANES PER RECORD read it where it lies, 32 bytes
+// a lane and round on the image's own 16-byte alignment - an instruction of the wavefront covers eight neighbouring
+// records' sequence lines, a handful of cache lines, where one lane per record asked for 64 lines at once (10.2 ms for
+// the 100 M reads of the bench, more than the tile-staging plan it replaced).  The counts meet in the group's first lane.
+__global__ __launch_bounds__(kBlock) void k_rf_plan_n(BcParams F, RfParams P, uint64_t n_rec, uint8_t* __restrict__ status,
+                                                      uint32_t* __restrict__ len1) {
+  const int lane = (int)(threadIdx.x & 63), sub = lane & 7;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  for (uint64_t k0 = wave * 8; k0 < n_rec; k0 += n_waves * 8) {
+    const uint64_t k = k0 + (uint64_t)(lane >> 3);
+    const bool valid = k < n_rec;
+    BcLine G[4];
+    bc_lines(F.f[1], valid ? k : n_rec - 1, G);
+    const uint32_t n = G[1].len;
+    const uintptr_t a0 = (uintptr_t)G[1].p & ~(uintptr_t)15;
+    const uint32_t pre = (uint32_t)((uintptr_t)G[1].p - a0), total = pre + n;
+    uint32_t cnt = 0;
+    for (uint32_t at = (uint32_t)sub * 32u; __ballot(at < total) != 0; at += 256u) {
+      if (at >= total) continue;
+#pragma unroll
+      for (uint32_t h = 0; h < 32u; h += 16u) {
+        const uint32_t b = at + h;
+        if (b >= total) break;
+        const uint4 v = *reinterpret_cast<const uint4*>(a0 + b);
+        uint64_t m0 = bytes_eq(((uint64_t)v.x | ((uint64_t)v.y << 32)) | 0x2020202020202020ull, (uint8_t)'n');
+        uint64_t m1 = bytes_eq(((uint64_t)v.z | ((uint64_t)v.w << 32)) | 0x2020202020202020ull, (uint8_t)'n');
+        const uint32_t lo = b == 0 ? pre : 0u, hi = total - b < 16u ? total - b : 16u;  // bytes [lo, hi) of the piece count
+        if (lo | (hi ^ 16u)) {
+          auto keep = [](uint32_t from, uint32_t to) {
+            const uint64_t below_to = to >= 8 ? ~0ull : (1ull << (8 * to)) - 1ull;
+            const uint64_t below_from = from >= 8 ? ~0ull : (1ull << (8 * from)) - 1ull;
+            return below_to & ~below_from;
+          };
+          m0 &= keep(lo < 8 ? lo : 8, hi < 8 ? hi : 8);
+          m1 &= keep(lo > 8 ? lo - 8 : 0, hi > 8 ? hi - 8 : 0);
+        }
+        cnt += (uint32_t)__builtin_popcountll(m0) + (uint32_t)__builtin_popcountll(m1);
+      }
+    }
+    cnt += (uint32_t)__shfl_xor((int)cnt, 1, 64);
+    cnt += (uint32_t)__shfl_xor((int)cnt, 2, 64);
+    cnt += (uint32_t)__shfl_xor((int)cnt, 4, 64);
+    if (valid && sub == 0) {
+      // rf_decide for FQG_FILTER_N: nothing is cut, the record is dropped when it holds more N/n than max_n % of
+      // read_len allow (src/fastq_filter_n.c:78-86; read_len = strlen(seq), the '\n' included)
+      const uint32_t L = G[1].len + G[1].nl, Lq = G[3].len + G[3].nl;
+      const uint32_t max_num_n = (uint32_t)((unsigned long)L * P.max_n / 100ul);
+      const bool drop = cnt > max_num_n;
+      status[k] = drop ? kRfDiscard : 0;
+      len1[k] = drop ? 0u : G[0].len + G[0].nl + L + G[2].len + G[2].nl + Lq;
+    }
+  }
+}
+
 // ... and what it decides per EMIT tile - do the tile's input span and its output fit the emit kernel's LDS areas
 // (bc_emit_tile_fits for the one input file): one thread per tile
 __global__ __launch_bounds__(kBlock) void k_rf_tile_flags(BcParams F, BcTile tc, uint64_t n_rec, const uint32_t* __restrict__ len1,

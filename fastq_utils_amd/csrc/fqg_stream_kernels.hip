@@ -746,7 +746,8 @@ struct LinesArgs {
 
 constexpr int kLinesHist = 4096;
 constexpr int kLinesPer = 2;  // records per lane and step: their staged-entry loads are in flight together (4: 1.29 -> 1.41 ms; 6 wavefronts per SIMD instead of 5: no change)
-__global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
+__global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint32_t* __restrict__ step_list = nullptr,
+                                                         const unsigned int* __restrict__ n_listed = nullptr) {
   __shared__ uint32_t s_hist[kLinesHist];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
   __shared__ uint64_t s_wr0[kBlock / kWave][kWave];   // per wavefront: first rank of the window's chunks
@@ -758,6 +759,9 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
   // a step = kLinesPer * 64 consecutive records (kLinesPer * 256 lines) per wavefront
   const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);
   const uint64_t n_steps = (n_groups + kLinesPer - 1) / kLinesPer;
+  // with a list (what k_stream_lines_fast left over): entry `it` of the list is the step; without: every step
+  const uint64_t n_its = step_list ? (uint64_t)*n_listed : n_steps;
+  auto step_of = [&](uint64_t it) -> uint64_t { return step_list ? (uint64_t)step_list[it < n_its ? it : n_its - 1] : it; };
   const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
@@ -782,8 +786,9 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
     nx_cnt = A.cr.counts[cl];
     nx_win = cw;
   };
-  if (wave0 < n_steps) window_request(wave0);
-  for (uint64_t step = wave0; step < n_steps; step += n_waves) {
+  if (wave0 < n_its) window_request(step_of(wave0));
+  for (uint64_t it = wave0; it < n_its; it += n_waves) {
+    const uint64_t step = step_of(it);
     // e[0] = end of the line before mine, e[1..4] = ends of my four lines; ent[] = their staged entries
     uint64_t e[kLinesPer][5];
     uint32_t ent[kLinesPer][5];
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
     }
     // ---- phase 1b: every request of the step, nothing else: the next step's window, then the kLinesPer * 5 staged
     // entries of the lane (a lane without an entry asks for entry 0) ----
-    window_request(step + n_waves);
+    window_request(it + n_waves < n_its ? step_of(it + n_waves) : step);
     uint16_t raw[kLinesPer][5];
 #pragma unroll
     for (int q = 0; q < kLinesPer; ++q)
@@ -960,6 +965,202 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A) {
         } else atomicOr(A.flags, kFlagSuspectOverflow);
       }
     }
+  }
+  if (!A.acc) return;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    n_ok += __shfl_down(n_ok, d, 64);
+    const unsigned long long a = __shfl_down(min_rl, d, 64), b = __shfl_down(max_rl, d, 64);
+    min_rl = a < min_rl ? a : min_rl;
+    max_rl = b > max_rl ? b : max_rl;
+  }
+  if (lane == 0) {
+    s_red[0][threadIdx.x >> 6] = n_ok;
+    s_red[1][threadIdx.x >> 6] = min_rl;
+    s_red[2][threadIdx.x >> 6] = max_rl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      n_ok += s_red[0][w];
+      min_rl = s_red[1][w] < min_rl ? s_red[1][w] : min_rl;
+      max_rl = s_red[2][w] > max_rl ? s_red[2][w] : max_rl;
+    }
+    if (n_ok) {
+      atomicAdd(&A.acc->num_rds, n_ok * A.weight);
+      if (min_rl < A.acc->min_rl) atomicMin(&A.acc->min_rl, min_rl);
+      if (max_rl > A.acc->max_rl) atomicMax(&A.acc->max_rl, max_rl);
+    }
+  }
+  for (int i = threadIdx.x; i < kLinesHist; i += kBlock) {
+    const uint32_t cc = s_hist[i];
+    if (cc) atomicAdd(&A.hist[i], (unsigned long long)cc * A.weight);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same pass for the steps of an ordinary file - every record of the step complete, the newlines of its 513 ranks in
+// at most kFastSlots pieces of 64 staged entries - without a search per lane: the WAVEFRONT fetches the staged entries
+// of the chunks its ranks live in, piece by piece with all lanes (coalesced 2-byte loads, all pieces in flight
+// together), and drops them into an LDS array BY RANK; a lane then finds the five entries of a record as five
+// neighbouring words.  k_stream_lines above works out, per lane and record, which chunk a rank lives in (a binary
+// search of the window, then a walk from chunk to chunk: 585 vector and 350 scalar instructions per 128 records,
+// most of them 64-bit index arithmetic); here that is one comparison per window chunk.  Steps that do not qualify (the
+// first and the last records of an image, reads of kilobases whose ranks spread over more chunks than the window
+// holds, chunks that are mostly newlines) are listed for the general kernel, which runs behind this one on the list.
+// ------------------------------------------------------------------------------------------
+constexpr int kFastSlots = 16;
+constexpr int kFastRanks = 4 * kWave * kLinesPer + 1;  // 513: the ranks of 128 records and the one in front of them
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) |
+         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
+}
+
+__global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint32_t* __restrict__ slow_list, CallState* __restrict__ cs) {
+  __shared__ uint32_t s_hist[kLinesHist];
+  __shared__ unsigned long long s_red[3][kBlock / kWave];
+  __shared__ __attribute__((aligned(16))) uint32_t s_ent[kBlock / kWave][(kFastRanks + 7) & ~3];
+  for (int i = threadIdx.x; i < kLinesHist; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+  const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);
+  const uint64_t n_steps = (n_groups + kLinesPer - 1) / kLinesPer;
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
+  unsigned long long n_ok = 0, min_rl = ~0ull, max_rl = 0;
+  // the window of the NEXT step is requested a step ahead and looked at when that step begins (see k_stream_lines)
+  unsigned long long nx_se = 0;
+  uint32_t nx_loc = 0, nx_cnt = 0, nx_win = 0;
+  bool nx_in = false;
+  auto window_request = [&](uint64_t step) {
+    const uint64_t g = (step < n_steps ? step : n_steps - 1) * kLinesPer;
+    const uint64_t Rw = g ? 4 * g * kWave - 1 : 0;
+    const double est = (double)Rw * chunks_per_line;
+    uint32_t cw = est > 2.0 ? (uint32_t)(est - 2.0) : 0u;
+    if (cw + kWave > A.cr.n_chunks) cw = A.cr.n_chunks > (uint32_t)kWave ? A.cr.n_chunks - kWave : 0u;
+    const uint32_t cm = cw + (uint32_t)lane;
+    nx_in = cm < A.cr.n_chunks;
+    const uint32_t cl = nx_in ? cm : A.cr.n_chunks - 1;
+    nx_se = A.cr.span_excl[cl / kScanSpan];
+    nx_loc = A.cr.local[cl];
+    nx_cnt = A.cr.counts[cl];
+    nx_win = cw;
+  };
+  if (wave0 < n_steps) window_request(wave0);
+  for (uint64_t step = wave0; step < n_steps; step += n_waves) {
+    // lane j holds window chunk j: its first rank and its number of newlines
+    const uint64_t w0 = nx_in ? nx_se + nx_loc : ~0ull;
+    const uint32_t wc = nx_in ? nx_cnt : 0u;
+    const uint32_t win0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_win);  // (the same in every lane: scalar arithmetic below)
+    const uint64_t rb = step * (uint64_t)(kWave * kLinesPer);   // the step's first record
+    const uint64_t Rlo = 4 * rb - 1, Rhi = 4 * rb + 4 * kWave * kLinesPer;  // its ranks: [Rlo, Rhi)
+    bool fast = rb > 0 && Rhi <= A.n_newlines && Rhi <= A.limit && Rhi <= A.line_cap &&
+                (rb / kWave + kLinesPer) * kWave <= A.suspect_cap;
+    // the chunks the ranks live in: from the last chunk whose first rank is <= Rlo to the last whose first rank is < Rhi
+    // (first ranks do not decrease along the window; lanes beyond the image hold ~0)
+    const unsigned long long b_lo = __ballot(w0 <= Rlo), b_hi = __ballot(w0 < Rhi);
+    // (every value below is the same in all lanes; saying so - readfirstlane - keeps it in scalar registers and the
+    // branches scalar: the compiler cannot see it through the comparisons that made it)
+    const int jfirst = __builtin_amdgcn_readfirstlane(__builtin_popcountll(b_lo) - 1);
+    const int jlast = __builtin_amdgcn_readfirstlane(__builtin_popcountll(b_hi) - 1);
+    const uint32_t n_cov = (uint32_t)(jlast - jfirst + 1);
+    if (fast && b_lo != 0) {
+      // every covering chunk in ONE piece of 64 entries (reads of 100 bases and more), and the window holds the step's
+      // last rank too
+      const unsigned long long many = __ballot(lane >= jfirst && lane <= jlast && wc > (uint32_t)kWave);
+      const uint64_t last_r0 = readlane64(w0, jlast);
+      const uint32_t last_cnt = (uint32_t)__builtin_amdgcn_readlane((int)wc, jlast);
+      fast = many == 0 && n_cov <= (uint32_t)kFastSlots && last_r0 + last_cnt >= Rhi;
+    } else fast = false;
+    if (!__builtin_amdgcn_readfirstlane((int)fast)) {
+      if (lane == 0) slow_list[atomicAdd(&cs->slow_steps, 1u)] = (uint32_t)step;
+      window_request(step + n_waves);
+      continue;
+    }
+    // ---- every request of the step: the next step's window, then the staged entries chunk by chunk ----
+    window_request(step + n_waves);
+    // where chunk j's first entry goes in s_ent (32-bit, may be "negative": the chunk begins in front of the step's ranks)
+    const uint32_t rel0 = (uint32_t)(w0 - Rlo);
+    constexpr uint32_t kDump = (uint32_t)kFastRanks;  // a word of s_ent nobody reads: where entries outside the step go
+    const uint16_t* const base0 = A.stage + (uint64_t)(win0 + (uint32_t)jfirst) * kStageCap;  // (uniform: scalar arithmetic)
+    uint16_t raw[kFastSlots];
+#pragma unroll
+    for (int sl = 0; sl < kFastSlots; ++sl) {
+      // (a chunk that is not needed asks for the first one again: no branch around a request)
+      const uint32_t cj = (uint32_t)sl < n_cov ? (uint32_t)sl : 0u;
+      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)wc, jfirst + (int)cj);
+      raw[sl] = base0[cj * (uint32_t)kStageCap + ((uint32_t)lane < cnt ? (uint32_t)lane : 0u)];
+    }
+#pragma unroll
+    for (int sl = 0; sl < kFastSlots; ++sl) {
+      const uint32_t cj = (uint32_t)sl < n_cov ? (uint32_t)sl : 0u;
+      const uint32_t cnt = (uint32_t)sl < n_cov ? (uint32_t)__builtin_amdgcn_readlane((int)wc, jfirst + (int)cj) : 0u;
+      const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)rel0, jfirst + (int)cj) + (uint32_t)lane;  // >= 2^31 in front of the step
+      // no branch: an entry that is not wanted lands in the dump word
+      s_ent[wv][((uint32_t)lane < cnt && idx < (uint32_t)kFastRanks) ? idx : kDump] = ((uint32_t)(jfirst + (int)cj) << 16) | (uint32_t)raw[sl];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- the line index, the checks, the statistics: every record of the step is complete ----
+#pragma unroll
+    for (int q = 0; q < kLinesPer; ++q) {
+      const uint64_t g = step * kLinesPer + q;
+      const uint64_t r = g * kWave + (uint64_t)lane;
+      const uint64_t L0 = 4 * r;
+      const uint32_t at = 4u * ((uint32_t)q * kWave + (uint32_t)lane);   // entry of rank 4r - 1
+      const uint4 e03 = *reinterpret_cast<const uint4*>(&s_ent[wv][at]);  // (16-byte aligned: at is a multiple of 4)
+      const uint32_t en[5] = {e03.x, e03.y, e03.z, e03.w, s_ent[wv][at + 4]};
+      uint64_t e[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) e[k] = (uint64_t)(win0 + (en[k] >> 16)) * kChunkBytes + (en[k] & 0xFFFu);
+      if (!(A.ablate & 1)) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 lo2, hi2;
+        lo2.x = e[1]; lo2.y = e[2]; hi2.x = e[3]; hi2.y = e[4];
+        __builtin_nontemporal_store(lo2, reinterpret_cast<u64x2*>(A.line_end + L0));
+        __builtin_nontemporal_store(hi2, reinterpret_cast<u64x2*>(A.line_end + L0 + 2));
+      }
+      // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
+      bool sus = !(((en[0] >> 12) & 3u) == kClsAt && !((en[0] >> 14) & 1u));
+      sus |= !(((en[2] >> 12) & 3u) == kClsPlus && ((en[2] >> 14) & 1u));
+      const uint64_t l0 = e[1] - e[0] - 1, l1 = e[2] - e[1] - 1, l2 = e[3] - e[2] - 1, l3 = e[4] - e[3] - 1;
+      sus |= l1 < 1 || l1 != l3 || A.space != FQG_SPACE_SEQ;
+      sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
+             l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + 1 > FQG_MAX_READ_LENGTH - 1;
+      const bool counted = A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1;
+      const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line ends in '\n'
+      if (counted) {
+        ++n_ok;
+        min_rl = rl < min_rl ? rl : min_rl;
+        max_rl = rl > max_rl ? rl : max_rl;
+      }
+      {  // the length histogram: the lanes that share the first counted lane's length add once, together (see k_stream_lines)
+        const unsigned long long cm = __ballot(counted);
+        if (cm) {
+          const int first = __builtin_ctzll(cm);
+          const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rl, first);
+          const bool with_first = counted && rl == (uint64_t)rl0;
+          const unsigned long long same = __ballot(with_first);
+          if (lane == first) {
+            if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], (uint32_t)__builtin_popcountll(same));
+            else atomicAdd(&A.hist[rl], (unsigned long long)A.weight * (unsigned long long)__builtin_popcountll(same));
+          }
+          if (counted && !with_first) {
+            if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
+            else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
+          }
+        }
+      }
+      const unsigned long long sm = __ballot(sus);
+      if (lane == 0 && sm) {
+        const uint64_t w = g * 2;
+        if ((uint32_t)sm) A.suspect_bits[w] = (uint32_t)sm;
+        if ((uint32_t)(sm >> 32)) A.suspect_bits[w + 1] = (uint32_t)(sm >> 32);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (s_ent is rewritten by the next step)
   }
   if (!A.acc) return;
 #pragma unroll

@@ -10,6 +10,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -641,13 +643,86 @@ int main(int argc, char** argv) {
   }
   unsigned long processed = 0, discarded = 0;
   bool first_batch = true;
-  std::vector<char> hostbuf;
+  // What a batch prints goes to a writer thread (in order: one thread, one queue): gzip'ing and writing batch k - the
+  // reference's whole cost in FASTQ mode - runs beside reading, framing and transforming batch k + 1.  Two batches may
+  // wait; drain() before anything else may be said or the program leaves.
+  struct OutJob {
+    int which;
+    std::vector<char> text;
+  };
+  struct AsyncOut {
+    GzipMembers* gz;
+    std::deque<OutJob> q;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool quit = false, failed = false, busy = false;
+    std::thread th;
+    double t_write = 0;
+    void start() {
+      th = std::thread([this] {
+        for (;;) {
+          OutJob j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return quit || !q.empty(); });
+            if (q.empty()) return;
+            j = std::move(q.front());
+            q.pop_front();
+            busy = true;
+          }
+          const auto t0 = std::chrono::steady_clock::now();
+          bool ok = true;
+          if (j.which == 0) ok = fwrite(j.text.data(), 1, j.text.size(), stdout) == j.text.size();
+          else ok = gz[j.which].write(j.text.data(), j.text.size());
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (!ok) failed = true;
+            busy = false;
+          }
+          cv.notify_all();
+        }
+      });
+    }
+    void push(int which, std::vector<char>&& text) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return q.size() < 2; });
+      q.push_back(OutJob{which, std::move(text)});
+      lk.unlock();
+      cv.notify_all();
+    }
+    bool drain() {  // everything handed over is written; false: a write failed
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return q.empty() && !busy; });
+      return !failed;
+    }
+    void stop() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        quit = true;
+      }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+    }
+  } outq;
+  outq.gz = outgz;
+  outq.start();
+  auto drain_or_die = [&] {
+    if (!outq.drain()) {
+      FQ_PRINT_ERROR("%s.\n", "write error");
+      fqhost::leave(kExitSys);
+    }
+  };
+  const bool timing = getenv("FQGPU_TIMING") != nullptr;
+  double t_refill = 0, t_transform = 0, t_fetch = 0, t_hand = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto step_of = [&](int x) { return (has_interleaved && (x == P.interleaved[0] || x == P.interleaved[1])) ? 2L : 1L; };
   for (int x = READ1; x <= INDEX3; ++x)
     if (file[x]) src[x].use = (has_interleaved && x == P.interleaved[1]) ? 1 : 0;
 
   for (;;) {
     // every input needs a frame that holds the record its next iteration uses
+    const double t_a = now();
     bool out_of_data = false;
     for (int x = READ1; x <= INDEX3 && !out_of_data; ++x)
       if (file[x]) {
@@ -687,8 +762,13 @@ int main(int argc, char** argv) {
         first[x] = (uint64_t)src[x].use - ((has_interleaved && x == P.interleaved[1]) ? 1 : 0);
       }
     fqg_barcode_result r;
+    const double t_b = now();
     LIB(fqg_barcodes_transform(g_ctx, frames, states, first, &Pb, n, processed, &r));
+    const double t_c = now();
+    t_refill += t_b - t_a;
+    t_transform += t_c - t_b;
     if (first_batch && num_input_files > 1) {
+      drain_or_die();
       // format lines of the first fastq_get_readname call per file, in file order (src/fastq.c:459-485)
       for (int x = READ1; x <= INDEX3; ++x)
         if (file[x]) {
@@ -699,18 +779,16 @@ int main(int argc, char** argv) {
     }
     first_batch = false;
     for (uint64_t w = 0; w < r.n_short; ++w) fputs("Warning: Read too short - barcode not found\n", stderr);
-    // hand the text to stdout / gzip
+    // hand the text to the writer (stdout / gzip)
     for (int which = 0; which < 3; ++which)
       if (r.out_bytes[which]) {
-        if (hostbuf.size() < r.out_bytes[which]) hostbuf.resize(r.out_bytes[which]);
-        LIB(fqg_barcodes_output(g_ctx, which, hostbuf.data(), r.out_bytes[which]));
-        if (which == 0) fwrite(hostbuf.data(), 1, r.out_bytes[0], stdout);
-        else {
-          if (!outgz[which].write(hostbuf.data(), r.out_bytes[which])) {
-            FQ_PRINT_ERROR("%s.\n", "write error");
-            fqhost::leave(kExitSys);
-          }
-        }
+        const double t_d = now();
+        std::vector<char> text(r.out_bytes[which]);
+        LIB(fqg_barcodes_output(g_ctx, which, text.data(), r.out_bytes[which]));
+        const double t_e = now();
+        outq.push(which, std::move(text));
+        t_fetch += t_e - t_d;
+        t_hand += now() - t_e;
       }
     const unsigned long before = processed;
     processed += r.n_done;
@@ -720,6 +798,7 @@ int main(int argc, char** argv) {
       fflush(stderr);
     }
     if (r.code != FQG_OK) {
+      drain_or_die();
       if (r.code == FQG_E_WRONG_HEADER) {
         // src/fastq.c:448-451, with the file's own line counter
         Source& s = src[r.file];
@@ -750,6 +829,11 @@ int main(int argc, char** argv) {
         if (ended_on_discard && x == P.interleaved[0]) src[x].use -= 1;  // no re-synchronising read after a discard
       }
   }
+  drain_or_die();
+  outq.stop();
+  if (timing)
+    fprintf(stderr, "\nfqgpu timing: reading + framing %.3f s, transform %.3f s, output D2H %.3f s, waiting for the writer %.3f s; "
+                    "the writer (gzip / stdout) worked %.3f s beside them\n", t_refill, t_transform, t_fetch, t_hand, outq.t_write);
   // an incomplete record where the next read would have happened is a truncated file
   // (src/fastq.c:254-257); a clean end of any input just ends the loop - and so does the loop's own condition
   // (fastq_files_eof, src/fastq_pre_barcodes.c:288-297, :594), before any input is read again: an input whose last line

@@ -256,6 +256,7 @@ class Input {
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     if (bgzf_fd_ >= 0) close(bgzf_fd_);
+    free(bz_raw_);
     for (Slot& s : slots_) slot_release(ctx_, s.buf);
     slot_release(ctx_, whole_);
     slot_release(ctx_, big_);
@@ -448,21 +449,46 @@ class Input {
       cv_.notify_all();
     };
     for (;;) {
-      // refill the compressed window [bz_at_, bz_buf_.size())
+      // refill the compressed window [bz_at_, bz_buf_.size()): what is left of it to the front, then up to 128 MiB of
+      // the file behind it, read by the pool (one thread reads a tmpfs file at a few GB/s - less than the pool inflates)
       if (bz_buf_.size() - bz_at_ < (1u << 17) && bgzf_off_ < bgzf_size_) {
-        bz_buf_.erase(bz_buf_.begin(), bz_buf_.begin() + (long)bz_at_);
-        bz_at_ = 0;
-        const size_t old = bz_buf_.size(), add = (size_t)std::min<uint64_t>(32u << 20, bgzf_size_ - bgzf_off_);
-        bz_buf_.resize(old + add);
-        size_t done = 0;
-        while (done < add) {
-          const ssize_t got = pread(bgzf_fd_, bz_buf_.data() + old + done, add - done, (off_t)(bgzf_off_ + done));
-          if (got <= 0) {
-            fail("read error");
+        if (!inflate_pool_) {
+          unsigned hw = std::thread::hardware_concurrency();
+          if (const char* e = getenv("FQGPU_HOST_THREADS")) hw = (unsigned)std::max(1L, strtol(e, nullptr, 10));
+          inflate_pool_.reset(new ReaderPool(std::max(1u, std::min(256u, hw ? hw : 1u))));
+        }
+        const size_t old = bz_buf_.size() - bz_at_, add = (size_t)std::min<uint64_t>(128u << 20, bgzf_size_ - bgzf_off_);
+        if (bz_raw_cap_ < old + add) {  // (plain memory, never zero-filled: a vector's resize would write it first)
+          unsigned char* nb = static_cast<unsigned char*>(malloc(old + (128u << 20)));
+          if (!nb) {
+            fail("out of memory");
             return len;
           }
-          done += (size_t)got;
+          if (old) memcpy(nb, bz_buf_.data() + bz_at_, old);
+          free(bz_raw_);
+          bz_raw_ = nb;
+          bz_raw_cap_ = old + (128u << 20);
+        } else if (old) memmove(bz_raw_, bz_buf_.data() + bz_at_, old);
+        const unsigned T = (unsigned)std::min<size_t>(inflate_pool_->size(), std::max<size_t>(1, add >> 22));
+        std::atomic<bool> bad_read{false};
+        inflate_pool_->run(T, [&](unsigned t) {
+          const size_t a = (add * t / T) & ~(size_t)4095, b = t + 1 == T ? add : (add * (t + 1) / T) & ~(size_t)4095;
+          size_t done = a;
+          while (done < b) {
+            const ssize_t got = pread(bgzf_fd_, bz_raw_ + old + done, b - done, (off_t)(bgzf_off_ + done));
+            if (got <= 0) {
+              bad_read = true;
+              return;
+            }
+            done += (size_t)got;
+          }
+        });
+        if (bad_read) {
+          fail("read error");
+          return len;
         }
+        bz_buf_ = Span{bz_raw_, old + add};
+        bz_at_ = 0;
         bgzf_off_ += add;
       }
       if (bz_at_ == bz_buf_.size()) {
@@ -507,11 +533,6 @@ class Input {
       }
       // (inflating is all this input costs - zlib gives a few hundred MB/s per core, the GPU takes tens of GB/s: every
       // core the host has, FQGPU_HOST_THREADS caps it)
-      if (!inflate_pool_) {
-        unsigned hw = std::thread::hardware_concurrency();
-        if (const char* e = getenv("FQGPU_HOST_THREADS")) hw = (unsigned)std::max(1L, strtol(e, nullptr, 10));
-        inflate_pool_.reset(new ReaderPool(std::max(1u, std::min(256u, hw ? hw : 1u))));
-      }
       const unsigned T = (unsigned)std::min<size_t>(inflate_pool_->size(), std::max<size_t>(1, blocks.size() / 4));
       std::atomic<bool> bad{false};
       const unsigned char* src = bz_buf_.data();
@@ -697,8 +718,15 @@ class Input {
   uint64_t plain_size_ = 0, plain_off_ = 0;
   int bgzf_fd_ = -1;  // bgzip'd input: blocks inflated on many threads (read_bgzf)
   uint64_t bgzf_size_ = 0, bgzf_off_ = 0;
-  std::vector<unsigned char> bz_buf_;
-  size_t bz_at_ = 0;
+  struct Span {  // the compressed window (bytes of bz_raw_)
+    const unsigned char* p = nullptr;
+    size_t n = 0;
+    const unsigned char* data() const { return p; }
+    size_t size() const { return n; }
+    unsigned char operator[](size_t i) const { return p[i]; }
+  } bz_buf_;
+  unsigned char* bz_raw_ = nullptr;
+  size_t bz_raw_cap_ = 0, bz_at_ = 0;
   std::unique_ptr<ReaderPool> inflate_pool_;
   size_t cap_;
   Slot slots_[kSlots];

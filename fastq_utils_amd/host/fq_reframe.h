@@ -19,6 +19,7 @@
 #include <cstddef>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/fqg_codes.h"
 
@@ -33,8 +34,9 @@ struct Reframer {
   // Returns how many raw bytes were taken: all of them when `at_end` (nothing follows), otherwise everything but a
   // trailing piece that is neither ended by a newline nor as long as its call's limit (it is offered again, with more
   // bytes behind it).  *clean = no cut fell into the taken bytes: they are their own re-framed form and `out` is left
-  // alone; otherwise `out` holds the re-framed form of the taken bytes.
-  size_t run(const char* raw, size_t n, bool at_end, std::string& out, bool* clean) {
+  // alone; otherwise `out` holds the re-framed form of the taken bytes.  `cuts` (optional) collects where in `out`
+  // the two bytes of every cut lie.
+  size_t run(const char* raw, size_t n, bool at_end, std::string& out, bool* clean, std::vector<size_t>* cuts = nullptr) {
     size_t pos = 0, flushed = 0;
     bool cut = false;
     unsigned ph = phase;
@@ -52,6 +54,7 @@ struct Reframer {
           out.clear();
         }
         out.append(raw + flushed, pos + lim - flushed);
+        if (cuts) cuts->push_back(out.size());
         out.append("\0\n", 2);
         pos += lim;
         flushed = pos;
