@@ -306,6 +306,7 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
         return {"skipped": f"/dev/shm has {free >> 30} GiB free, the host {avail >> 30} GiB available"}
     d = tempfile.mkdtemp(prefix="fqg_bench_bc_", dir=shm)
     res = {"pairs": m, "baseline_pairs": 200_000_000, "input_GB": m * per_pair_in / 1e9,
+           "host_cores_usable": len(os.sched_getaffinity(0)), "host_cores": os.cpu_count(),
            "kernels_only_ms_for_all_pairs_of_the_extra": kernels_ms}
     try:
         t0 = time.perf_counter()
@@ -463,7 +464,8 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
     host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
     host.copy_(image[:nbytes])
     torch.cuda.synchronize()
-    out = {"reads": n, "bytes": nbytes, "pin_and_copy_to_host_s": time.perf_counter() - t0}
+    out = {"reads": n, "bytes": nbytes, "pin_and_copy_to_host_s": time.perf_counter() - t0,
+           "host_cores_usable": len(os.sched_getaffinity(0)), "host_cores": os.cpu_count()}
     piece = (1 << 30) // R * R
     best = None
     for _ in range(2):

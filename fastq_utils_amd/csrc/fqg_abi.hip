@@ -96,7 +96,7 @@ struct fqg_ctx {
   DevBuf cinfo;       // streaming path: u32 info word per chunk
   DevBuf queue;       // streaming path: u64 suspect byte positions
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
-  DevBuf lines_slow;  // streaming path: u32 steps that k_stream_lines_fast leaves to the general kernel
+  DevBuf lines_slow;  // streaming path: one byte per step that k_stream_lines_fast leaves to the general kernel
   DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
   DevBuf name_hcount; // ... and the headers every chunk saw
   DevBuf name_redo, name_redo_chunks;  // what the capture-fed name kernel leaves to the line-index one
@@ -746,19 +746,22 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
       // share after the others have finished)
       if (!c->lines_per_cu) {  // (per context: a context is one device, and contexts run on threads of their own)
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines), kBlock, 0) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines<false>), kBlock, 0) != hipSuccess || nb < 1)
           nb = 4;
         c->lines_per_cu = nb;
       }
       const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)c->cu_count * c->lines_per_cu));
       static const bool general_only = getenv("FQGPU_LINES_GENERAL") != nullptr;  // (A/B: every step through the general kernel)
-      if (general_only) {
-        hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint32_t*)nullptr,
-                           (const unsigned int*)nullptr);
+      // (more than 64 newlines in an average chunk - reads below 100 bases - or fewer than 32 - reads of kilobases: hardly a
+      // step would qualify for the kernel without a search)
+      const double nl_per_chunk = (double)out->n_newlines / (double)std::max<uint32_t>(n_chunks, 1);
+      if (general_only || nl_per_chunk > 60.0 || nl_per_chunk < 32.0) {
+        hipLaunchKernelGGL(k_stream_lines<false>, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)nullptr);
       } else {
-        // the steps of ordinary records in the kernel without a search, what it lists in the general one behind it
+        // the steps of ordinary records in the kernel without a search, what it marks in the general one behind it
         const uint64_t n_steps = (groups + kLinesPer - 1) / kLinesPer;
-        if ((rc = ensure(c, c->lines_slow, (size_t)n_steps * 4 + 4))) return rc;
+        if ((rc = ensure(c, c->lines_slow, (size_t)n_steps + 4))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->lines_slow.p, 0, (size_t)n_steps, c->stream));
         if (!c->lines_fast_per_cu) {
           int nb = 0;
           if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines_fast), kBlock, 0) != hipSuccess || nb < 1)
@@ -766,9 +769,8 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
           c->lines_fast_per_cu = nb;
         }
         const unsigned grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
-        hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, c->stream, A, (uint32_t*)c->lines_slow.p, c->d_cs);
-        hipLaunchKernelGGL(k_stream_lines, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint32_t*)c->lines_slow.p,
-                           (const unsigned int*)&c->d_cs->slow_steps);
+        hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, c->stream, A, (uint8_t*)c->lines_slow.p);
+        hipLaunchKernelGGL(k_stream_lines<true>, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)c->lines_slow.p);
       }
     }
     out->records_done = true;

@@ -83,7 +83,6 @@ struct CallState {
   unsigned int redo_count;            // streaming pass: chunks whose checks must be repeated
   unsigned int boot_qmin, boot_qmax;  // streaming pass: quality range of the image's first records
   unsigned int boot_lines;            // streaming pass: newlines in the boot window (mean record size -> NameCapture::K)
-  unsigned int slow_steps;            // streaming pass: steps of k_stream_lines_fast that the general kernel must do
 };
 
 // Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).

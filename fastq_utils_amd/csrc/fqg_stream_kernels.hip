@@ -746,8 +746,8 @@ struct LinesArgs {
 
 constexpr int kLinesHist = 4096;
 constexpr int kLinesPer = 2;  // records per lane and step: their staged-entry loads are in flight together (4: 1.29 -> 1.41 ms; 6 wavefronts per SIMD instead of 5: no change)
-__global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint32_t* __restrict__ step_list = nullptr,
-                                                         const unsigned int* __restrict__ n_listed = nullptr) {
+template <bool TODO>
+__global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint8_t* __restrict__ todo) {
   __shared__ uint32_t s_hist[kLinesHist];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
   __shared__ uint64_t s_wr0[kBlock / kWave][kWave];   // per wavefront: first rank of the window's chunks
@@ -759,9 +759,8 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
   // a step = kLinesPer * 64 consecutive records (kLinesPer * 256 lines) per wavefront
   const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);
   const uint64_t n_steps = (n_groups + kLinesPer - 1) / kLinesPer;
-  // with a list (what k_stream_lines_fast left over): entry `it` of the list is the step; without: every step
-  const uint64_t n_its = step_list ? (uint64_t)*n_listed : n_steps;
-  auto step_of = [&](uint64_t it) -> uint64_t { return step_list ? (uint64_t)step_list[it < n_its ? it : n_its - 1] : it; };
+  // `todo` (what k_stream_lines_fast left over: one byte per step): only the steps it marks, each with a window
+  // request of its own - they are few, or this kernel would have been launched alone
   const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
@@ -786,9 +785,12 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
     nx_cnt = A.cr.counts[cl];
     nx_win = cw;
   };
-  if (wave0 < n_its) window_request(step_of(wave0));
-  for (uint64_t it = wave0; it < n_its; it += n_waves) {
-    const uint64_t step = step_of(it);
+  if (!TODO && wave0 < n_steps) window_request(wave0);
+  for (uint64_t step = wave0; step < n_steps; step += n_waves) {
+    if constexpr (TODO) {
+      if (!todo[step]) continue;
+      window_request(step);
+    }
     // e[0] = end of the line before mine, e[1..4] = ends of my four lines; ent[] = their staged entries
     uint64_t e[kLinesPer][5];
     uint32_t ent[kLinesPer][5];
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
     }
     // ---- phase 1b: every request of the step, nothing else: the next step's window, then the kLinesPer * 5 staged
     // entries of the lane (a lane without an entry asks for entry 0) ----
-    window_request(it + n_waves < n_its ? step_of(it + n_waves) : step);
+    if constexpr (!TODO) window_request(step + n_waves);
     uint16_t raw[kLinesPer][5];
 #pragma unroll
     for (int q = 0; q < kLinesPer; ++q)
@@ -1007,7 +1009,8 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
 // search of the window, then a walk from chunk to chunk: 585 vector and 350 scalar instructions per 128 records,
 // most of them 64-bit index arithmetic); here that is one comparison per window chunk.  Steps that do not qualify (the
 // first and the last records of an image, reads of kilobases whose ranks spread over more chunks than the window
-// holds, chunks that are mostly newlines) are listed for the general kernel, which runs behind this one on the list.
+// holds, chunks with more than 64 newlines) are marked for the general kernel, which runs behind this one on the marks;
+// an image whose chunks hold more than 64 newlines on average (reads below 100 bases) goes to the general kernel alone.
 // ------------------------------------------------------------------------------------------
 constexpr int kFastSlots = 16;
 constexpr int kFastRanks = 4 * kWave * kLinesPer + 1;  // 513: the ranks of 128 records and the one in front of them
@@ -1017,7 +1020,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
          ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
 }
 
-__global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint32_t* __restrict__ slow_list, CallState* __restrict__ cs) {
+__global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8_t* __restrict__ todo) {
   __shared__ uint32_t s_hist[kLinesHist];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
   __shared__ __attribute__((aligned(16))) uint32_t s_ent[kBlock / kWave][(kFastRanks + 7) & ~3];
@@ -1075,7 +1078,8 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint3
       fast = many == 0 && n_cov <= (uint32_t)kFastSlots && last_r0 + last_cnt >= Rhi;
     } else fast = false;
     if (!__builtin_amdgcn_readfirstlane((int)fast)) {
-      if (lane == 0) slow_list[atomicAdd(&cs->slow_steps, 1u)] = (uint32_t)step;
+      if (lane == 0) todo[step] = 1;  // (its one owner writes it: no atomic - a counter all steps append to was 3.5 ms
+                                      // of a 4.2 ms pass on reads of 30 - 150 bases, where no step qualifies)
       window_request(step + n_waves);
       continue;
     }

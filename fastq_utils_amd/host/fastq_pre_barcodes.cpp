@@ -646,13 +646,17 @@ int main(int argc, char** argv) {
   // What a batch prints goes to a writer thread (in order: one thread, one queue): gzip'ing and writing batch k - the
   // reference's whole cost in FASTQ mode - runs beside reading, framing and transforming batch k + 1.  Two batches may
   // wait; drain() before anything else may be said or the program leaves.
+  // (the text travels in pinned buffers that go round: the copy from the GPU into fresh pageable memory - page faults, a
+  // bounce buffer - took four times as long as everything else the program does)
   struct OutJob {
-    int which;
-    std::vector<char> text;
+    int which = 0;
+    char* text = nullptr;
+    size_t size = 0, cap = 0;
   };
   struct AsyncOut {
     GzipMembers* gz;
     std::deque<OutJob> q;
+    std::vector<OutJob> spare;  // buffers that have been written out
     std::mutex mu;
     std::condition_variable cv;
     bool quit = false, failed = false, busy = false;
@@ -672,22 +676,47 @@ int main(int argc, char** argv) {
           }
           const auto t0 = std::chrono::steady_clock::now();
           bool ok = true;
-          if (j.which == 0) ok = fwrite(j.text.data(), 1, j.text.size(), stdout) == j.text.size();
-          else ok = gz[j.which].write(j.text.data(), j.text.size());
+          if (j.which == 0) ok = fwrite(j.text, 1, j.size, stdout) == j.size;
+          else ok = gz[j.which].write(j.text, j.size);
           {
             std::lock_guard<std::mutex> lk(mu);
             t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (!ok) failed = true;
             busy = false;
+            spare.push_back(j);
           }
           cv.notify_all();
         }
       });
     }
-    void push(int which, std::vector<char>&& text) {
+    // a pinned buffer of at least `bytes` for the next batch's text (a spare one when it is large enough)
+    OutJob buffer(fqg_ctx* ctx, size_t bytes) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < spare.size(); ++i)
+          if (spare[i].cap >= bytes) {
+            OutJob j = spare[i];
+            spare.erase(spare.begin() + (long)i);
+            return j;
+          }
+        if (!spare.empty()) {  // too small: replace it
+          fqhost::slot_release(ctx, spare.back().text);
+          spare.pop_back();
+        }
+      }
+      OutJob j;
+      j.cap = bytes + bytes / 8 + (1u << 20);
+      j.text = fqhost::slot_alloc(ctx, j.cap);
+      if (!j.text) {
+        FQ_PRINT_ERROR("unable to allocate %zu bytes of pinned memory", j.cap);
+        fqhost::leave(kExitSys);
+      }
+      return j;
+    }
+    void push(const OutJob& j) {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return q.size() < 2; });
-      q.push_back(OutJob{which, std::move(text)});
+      q.push_back(j);
       lk.unlock();
       cv.notify_all();
     }
@@ -783,10 +812,12 @@ int main(int argc, char** argv) {
     for (int which = 0; which < 3; ++which)
       if (r.out_bytes[which]) {
         const double t_d = now();
-        std::vector<char> text(r.out_bytes[which]);
-        LIB(fqg_barcodes_output(g_ctx, which, text.data(), r.out_bytes[which]));
+        OutJob job = outq.buffer(g_ctx, r.out_bytes[which]);
+        job.which = which;
+        job.size = r.out_bytes[which];
+        LIB(fqg_barcodes_output(g_ctx, which, job.text, job.size));
         const double t_e = now();
-        outq.push(which, std::move(text));
+        outq.push(job);
         t_fetch += t_e - t_d;
         t_hand += now() - t_e;
       }

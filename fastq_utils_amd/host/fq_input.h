@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "../../include/fqg.h"
+#include "fq_parallel.h"
 #include "fq_reframe.h"
 #include "fq_respawn.h"
 
@@ -453,9 +454,7 @@ class Input {
       // the file behind it, read by the pool (one thread reads a tmpfs file at a few GB/s - less than the pool inflates)
       if (bz_buf_.size() - bz_at_ < (1u << 17) && bgzf_off_ < bgzf_size_) {
         if (!inflate_pool_) {
-          unsigned hw = std::thread::hardware_concurrency();
-          if (const char* e = getenv("FQGPU_HOST_THREADS")) hw = (unsigned)std::max(1L, strtol(e, nullptr, 10));
-          inflate_pool_.reset(new ReaderPool(std::max(1u, std::min(256u, hw ? hw : 1u))));
+          inflate_pool_.reset(new ReaderPool(host_threads()));  // (fq_parallel.h: the cores this process may use)
         }
         const size_t old = bz_buf_.size() - bz_at_, add = (size_t)std::min<uint64_t>(128u << 20, bgzf_size_ - bgzf_off_);
         if (bz_raw_cap_ < old + add) {  // (plain memory, never zero-filled: a vector's resize would write it first)

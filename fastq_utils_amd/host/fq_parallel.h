@@ -10,6 +10,7 @@
 // FQGPU_HOST_THREADS sets the number of threads (default: the hardware's, at most 256 - deflate at the reference's
 // level runs at tens of MB/s per core, so 87 GB of re-tagged FASTQ are minutes on 32 cores).
 #pragma once
+#include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -24,12 +25,23 @@
 
 namespace fqhost {
 
+// the cores this process may run on (a container's share of the machine: more threads than that only take turns)
+inline unsigned usable_cores() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int n = CPU_COUNT(&set);
+    if (n > 0) return (unsigned)n;
+  }
+  const unsigned hw = std::thread::hardware_concurrency();
+  return hw ? hw : 1u;
+}
+
 inline unsigned host_threads() {
   const char* e = getenv("FQGPU_HOST_THREADS");
   long v = e ? atol(e) : 0;
-  if (v < 1) v = (long)std::thread::hardware_concurrency();
-  if (v < 1) v = 1;
-  return (unsigned)std::min<long>(v, 256);
+  if (v < 1) v = (long)usable_cores();
+  return (unsigned)std::min<long>(std::max<long>(v, 1), 256);
 }
 
 // fn(i) for i in [0, n) on up to host_threads() threads (dynamic: an atomic counter hands out items)

@@ -74,3 +74,47 @@ def test_reference_filterpair_program_on_the_gpu_library():
     with ThreadPoolExecutor(4) as ex:
         bad = [b for b in ex.map(one, golden) if b]
     assert not bad, f"{len(bad)} of {len(golden)} differ; first: {bad[:3]}"
+
+
+REF_INFO = os.path.join(REPO, "oracle", "_ref", "fastq_info")
+REF_FP = os.path.join(REPO, "oracle", "_ref", "fastq_filterpair")
+
+
+@pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(REF_INFO)), reason="oracle/_ref not built")
+def test_lines_beyond_the_gzgets_buffers_through_the_per_record_api():
+    """The reference's own fastq_info.c on libfastq_gpu.so, on files with lines beyond its gzgets buffers
+    (src/fastq.c:249-253): the library cuts the file's bytes the way those calls do (host/fq_reframe.h) before the GPU
+    frames them, hands the caller's FASTQ_ENTRY the pieces, and speaks of positions in the FILE.  Exit status, stdout and
+    stderr of the reference's own objects - and, for fastq_filterpair (offsets, seeks, copies), the same output files."""
+    import gzip
+    import tempfile
+
+    from tests.test_oracle_vs_ref_fuzz import overlong_images
+
+    imgs = overlong_images()
+    with tempfile.TemporaryDirectory() as tmp:
+        for which, img in sorted(imgs.items()):
+            with open(os.path.join(tmp, "f.fastq"), "wb") as f:
+                f.write(img)
+            for args in (["-r", "f.fastq"], ["f.fastq"], ["f.fastq", "pe"], ["f.fastq", "f.fastq"]):
+                want = subprocess.run([REF_INFO] + args, cwd=tmp, capture_output=True, timeout=300)
+                got = subprocess.run([BIN] + args, cwd=tmp, capture_output=True, timeout=300)
+                assert (got.returncode, got.stdout, strip_progress(got.stderr.decode("latin-1"))) == (
+                    want.returncode, want.stdout, strip_progress(want.stderr.decode("latin-1"))), (which, args, got.stderr[-400:])
+        exe = os.path.join(REPO, "oracle", "_ref", "fastq_filterpair_on_libfastq_gpu")
+        if os.path.exists(exe) and os.path.exists(REF_FP):
+            # the accepted image (its pieces are valid records) paired with itself: every record is copied through the offsets
+            with open(os.path.join(tmp, "a.fastq"), "wb") as f:
+                f.write(imgs["pieces_at_the_read_limit"])
+            outs = {}
+            for tag, binary in (("ref", REF_FP), ("lib", exe)):
+                d = os.path.join(tmp, tag)
+                os.mkdir(d)
+                p = subprocess.run(["fastq_filterpair", "../a.fastq", "../a.fastq", "p1.fastq.gz", "p2.fastq.gz", "up.fastq.gz"],
+                                   executable=binary, cwd=d, capture_output=True, timeout=600)
+                files = {}
+                for k in ("p1", "p2", "up"):
+                    path = os.path.join(d, k + ".fastq.gz")
+                    files[k] = gzip.decompress(open(path, "rb").read()) if os.path.exists(path) and os.path.getsize(path) else b""
+                outs[tag] = (p.returncode, p.stdout, strip_progress(p.stderr.decode("latin-1")), files)
+            assert outs["lib"] == outs["ref"], (outs["lib"][:3], outs["ref"][:3])
