@@ -351,6 +351,16 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
             if sink is None and os.path.exists(os.path.join(d, "out.fastq.gz")):
                 legs[label]["output_gz_GB"] = os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9
                 os.unlink(os.path.join(d, "out.fastq.gz"))
+                # the deflate level is the host's whole cost here: the same run at level 1 (FQGPU_GZIP_LEVEL; what a reader
+                # inflates is the same)
+                secs, p = timed(args, sink, {"FQGPU_GZIP_LEVEL": "1", "FQGPU_TIMING": "1"})
+                c = counts(p.stderr)
+                legs[label]["at_gzip_level_1"] = {
+                    "seconds": secs, "Mpairs_per_s": m / secs / 1e6,
+                    "ok": p.returncode == 0 and c.get("Reads processed: ") == m and c.get("Reads discarded: ") == want_disc,
+                    "output_gz_GB": os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9 if os.path.exists(os.path.join(d, "out.fastq.gz")) else None}
+                if os.path.exists(os.path.join(d, "out.fastq.gz")):
+                    os.unlink(os.path.join(d, "out.fastq.gz"))
         res["legs"] = legs
         # the bytes of (ii) on a prefix: program -> gunzip -> sha256 against the library's own FASTQ-mode output
         k = min(m, 2_000_000)

@@ -76,6 +76,12 @@ __device__ __forceinline__ uint32_t not_acgtn7(uint32_t w) {
 __device__ __forceinline__ uint32_t in_range7(uint32_t w, uint32_t lob, uint32_t hihb, uint32_t kh = kH) {
   return ((w | kH) - lob) & (hihb - w) & kh;
 }
+// The same with the lower bound as an ADDEND: lo_add = (0x80 - lo) * 0x01010101 (lo <= 127).  A byte b < 0x80 plus
+// 0x80 - lo stays below 0x100 - no byte carries into its neighbour - and has bit 7 exactly when b >= lo: one
+// instruction where `(w | 0x80..) - lo..` takes two.
+__device__ __forceinline__ uint32_t in_range7a(uint32_t w, uint32_t lo_add, uint32_t hihb, uint32_t kh) {
+  return (w + lo_add) & (hihb - w) & kh;
+}
 
 // ------------------------------------------------------------------------------------------
 // quality range of the complete records inside the first `span` bytes (span: multiple of 256,
@@ -377,10 +383,10 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         lo = 127u;
         hi = 0u;
       }
-      const uint32_t lob_s = lo * 0x01010101u, hihb_s = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
+      const uint32_t hihb_s = ((hi & 0x7Fu) | 0x80u) * 0x01010101u;
       // (in vector registers: a subtraction that reads an SGPR issues in 4 cycles instead of 2, and a three-operand
       // instruction cannot hold a literal - the compiler would keep all three in SGPRs)
-      const uint32_t lob = in_vgpr(lob_s), hihb = in_vgpr(hihb_s), khv = in_vgpr(kH);
+      const uint32_t lo_add = in_vgpr((0x80u - lo) * 0x01010101u), hihb = in_vgpr(hihb_s), khv = in_vgpr(kH);
       QRange q{0x00FF00FFu, 0x00FF00FFu, 0u, 0u};
       bool any_viol = false;
 #pragma unroll
@@ -393,10 +399,10 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
         const uint32_t bad = (ABL & 8u) ? 0u : inv & M1 & ~nl[k];
         if (bad) queue_suspect(o, cs, wb + (uint64_t)k * kHalfBytes + (uint32_t)__builtin_ctz(bad));
         const uint32_t okq =
-            pack_marks16(in_range7(a.x, lob, hihb, khv), in_range7(a.y, lob, hihb, khv), in_range7(a.z, lob, hihb, khv),
-                         in_range7(a.w, lob, hihb, khv)) |
-            (pack_marks16(in_range7(b.x, lob, hihb, khv), in_range7(b.y, lob, hihb, khv), in_range7(b.z, lob, hihb, khv),
-                          in_range7(b.w, lob, hihb, khv)) << 16);
+            pack_marks16(in_range7a(a.x, lo_add, hihb, khv), in_range7a(a.y, lo_add, hihb, khv), in_range7a(a.z, lo_add, hihb, khv),
+                         in_range7a(a.w, lo_add, hihb, khv)) |
+            (pack_marks16(in_range7a(b.x, lo_add, hihb, khv), in_range7a(b.y, lo_add, hihb, khv), in_range7a(b.z, lo_add, hihb, khv),
+                          in_range7a(b.w, lo_add, hihb, khv)) << 16);
         const uint32_t qm = (ABL & 16u) ? 0u : M3 & ~nl[k];
         if (__ballot((qm & ~okq) != 0)) {  // rare: exact range of this slice's quality bytes
           any_viol = true;

@@ -27,14 +27,32 @@ namespace fqhost {
 
 // the cores this process may run on (a container's share of the machine: more threads than that only take turns)
 inline unsigned usable_cores() {
+  unsigned n = 0;
   cpu_set_t set;
   CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-    const int n = CPU_COUNT(&set);
-    if (n > 0) return (unsigned)n;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+  if (!n) n = std::thread::hardware_concurrency();
+  if (!n) n = 1;
+  // a container's CPU quota (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us): 256 runnable
+  // threads on a quota of a few cores are throttled together
+  double quota = 0, period = 0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+    fclose(f);
+  } else {
+    FILE* a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+    FILE* b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+    if (a && b && fscanf(a, "%lf", &quota) == 1 && fscanf(b, "%lf", &period) == 1) {
+    } else quota = 0;
+    if (a) fclose(a);
+    if (b) fclose(b);
   }
-  const unsigned hw = std::thread::hardware_concurrency();
-  return hw ? hw : 1u;
+  if (quota > 0 && period > 0) {
+    const unsigned q = (unsigned)(quota / period + 0.5);
+    if (q >= 1 && q < n) n = q;
+  }
+  return n;
 }
 
 inline unsigned host_threads() {
@@ -67,6 +85,12 @@ class GzipMembers {
   // path "-": stdout (as the reference's gzdopen(fileno(stdout), "wb")).  false: cannot open.
   bool open(const char* path, int level) {
     level_ = level;
+    // FQGPU_GZIP_LEVEL=1..9: another deflate level than the reference's (what a reader inflates is the same; level 1 is
+    // about three times as fast as the reference's 4 and a fifth larger)
+    if (const char* e = getenv("FQGPU_GZIP_LEVEL")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 9) level_ = v;
+    }
     if (path[0] == '-' && path[1] == 0) f_ = stdout;
     else {
       f_ = fopen(path, "wb");
