@@ -5,8 +5,9 @@
 // Reading runs AHEAD of the GPU: a producer thread fills a ring of pinned slots while the caller has
 // the previous piece copied to the device and validated (what the reference does serially with four
 // gzgets per record, src/fastq.c:245-261).  A plain (not gzipped) regular file is read with pread() by
-// several threads at once - 50 Mreads/s of 150 bp reads are 17.5 GB/s, more than one core copies; gzip
-// input and stdin are inflated by one thread (zlib), still ahead of the GPU.
+// several threads at once - 50 Mreads/s of 150 bp reads are 17.5 GB/s, more than one core copies.  A gzip
+// file is inflated on every core the process may use: a bgzip'd one block by block (read_bgzf), any other one by
+// chunks whose first blocks are searched for (fq_pgzip.h); stdin and small files by one zlib thread - all ahead of the GPU.
 //
 // Layout of a slot: [ headroom | raw bytes ].  The producer writes raw file bytes behind the headroom
 // without knowing where the previous piece's last complete record ended; the consumer learns that from
@@ -34,6 +35,7 @@
 
 #include "../../include/fqg.h"
 #include "fq_parallel.h"
+#include "fq_pgzip.h"
 #include "fq_reframe.h"
 #include "fq_respawn.h"
 
@@ -227,14 +229,23 @@ class Input {
           // inflated on all cores (read_bgzf below) instead of by one zlib thread
           bgzf_fd_ = fd;
           bgzf_size_ = (uint64_t)sb.st_size;
+        } else if ((uint64_t)sb.st_size >= (1u << 20) && host_threads() > 1 && !getenv("FQGPU_NO_PARALLEL_INFLATE")) {
+          // any other gzip file of some size: chunks of it are inflated side by side (fq_pgzip.h); what that reader
+          // does not want to decide it leaves to one zlib stream, so every file gzopen reads is read
+          const unsigned T = std::min(host_threads(), 64u);
+          size_t chunk = std::max<size_t>(256u << 10, std::min<size_t>(2u << 20, (64u << 20) / T));
+          chunk = std::min<size_t>(chunk, std::max<size_t>((size_t)sb.st_size / T, 128u << 10));
+          if (const char* e = getenv("FQGPU_PGZIP_CHUNK")) chunk = (size_t)std::max(4096L, atol(e));
+          pgz_fd_ = fd;
+          pgz_.reset(new ParallelGunzip(fd, (uint64_t)sb.st_size, path, T, chunk));
         }
       }
-      if (plain_fd_ < 0 && bgzf_fd_ < 0) {
+      if (plain_fd_ < 0 && bgzf_fd_ < 0 && pgz_fd_ < 0) {
         if (fd >= 0) close(fd);
         gz_ = gzopen(path, "r");
       }
     }
-    if (!gz_ && plain_fd_ < 0 && bgzf_fd_ < 0) {
+    if (!gz_ && plain_fd_ < 0 && bgzf_fd_ < 0 && pgz_fd_ < 0) {
       FQ_PRINT_ERROR("Unable to open %s", path);
       leave(kExitParams);
     }
@@ -245,7 +256,7 @@ class Input {
     // as it goes (a memchr per line beside the inflate).  A plain file is read by many threads and handed over as it
     // is; the GPU reports a line beyond the limits (FQG_E_LINE_TOO_LONG) and the program starts over with
     // FQGPU_REFRAME set (fq_respawn.h), which brings it here.
-    reframe_ = ((gz_ != nullptr || bgzf_fd_ >= 0) && reframe_supported()) || reframing();
+    reframe_ = ((gz_ != nullptr || bgzf_fd_ >= 0 || pgz_fd_ >= 0) && reframe_supported()) || reframing();
   }
   ~Input() {
     {
@@ -257,6 +268,16 @@ class Input {
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     if (bgzf_fd_ >= 0) close(bgzf_fd_);
+    if (pgz_ && (getenv("FQGPU_PGZIP_DEBUG") || getenv("FQGPU_TIMING"))) {
+      const ParallelGunzip::Stats& st = pgz_->stats();
+      fprintf(stderr, "fqgpu timing: %s inflated by chunks: %llu rounds, %llu chunks joined, %llu without a block start, %llu wrong guesses, "
+              "%llu members%s%s; reading %.3f s, finding + inflating %.3f s, joining %.3f s, markers -> bytes + CRC-32 %.3f s\n",
+              path_.c_str(), (unsigned long long)st.batches, (unsigned long long)st.chunks_joined, (unsigned long long)st.chunks_not_found,
+              (unsigned long long)st.chunks_discarded, (unsigned long long)st.members, st.fell_back ? "; one zlib stream from: " : "",
+              st.fell_back ? st.why.c_str() : "", st.s_load, st.s_decode, st.s_join + st.s_windows, st.s_narrow);
+    }
+    pgz_.reset();
+    if (pgz_fd_ >= 0) close(pgz_fd_);
     free(bz_raw_);
     for (Slot& s : slots_) slot_release(ctx_, s.buf);
     slot_release(ctx_, whole_);
@@ -415,7 +436,18 @@ class Input {
   size_t read_some(char* dst, size_t want, bool* at_end) {
     if (plain_fd_ >= 0) return read_plain(dst, want, at_end);
     if (bgzf_fd_ >= 0) return read_bgzf(dst, want, at_end);
+    if (pgz_) return read_pgz(dst, want, at_end);
     return read_gz(dst, want, at_end);
+  }
+  size_t read_pgz(char* dst, size_t want, bool* at_end) {
+    const size_t len = pgz_->read(dst, want, at_end);
+    if (pgz_->failed()) {  // (zlib's text, as gzerror gives it)
+      std::lock_guard<std::mutex> lk(mu_);
+      fail_msg_ = pgz_->error();
+      failed_ = true;
+      cv_.notify_all();
+    }
+    return len;
   }
 
   // ---- BGZF input (bgzip'd FASTQ; SAM/BAM specification 4.1) ------------------------------------------------------
@@ -674,6 +706,7 @@ class Input {
       }
       if (plain_fd_ >= 0) len += read_plain(buf + len, cap - len, &at_end);
       else if (bgzf_fd_ >= 0) len += read_bgzf(buf + len, cap - len, &at_end);
+      else if (pgz_) len += read_pgz(buf + len, cap - len, &at_end);
       else {
         const int got = gzread(gz_, buf + len, (unsigned)std::min<size_t>(cap - len, 1u << 30));
         if (got < 0) {
@@ -717,6 +750,8 @@ class Input {
   uint64_t plain_size_ = 0, plain_off_ = 0;
   int bgzf_fd_ = -1;  // bgzip'd input: blocks inflated on many threads (read_bgzf)
   uint64_t bgzf_size_ = 0, bgzf_off_ = 0;
+  int pgz_fd_ = -1;  // any other gzip file: chunks inflated on many threads (fq_pgzip.h)
+  std::unique_ptr<ParallelGunzip> pgz_;
   struct Span {  // the compressed window (bytes of bz_raw_)
     const unsigned char* p = nullptr;
     size_t n = 0;

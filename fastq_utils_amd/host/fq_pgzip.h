@@ -1,0 +1,1045 @@
+// fq_pgzip.h - a gzip file inflated on many cores (the boundary work of SURVEY 8f-2; reference: fastq_open's
+// gzopen + one gzgets per line on one thread, src/fastq.c:631-663, :245-261).
+//
+// A gzip member is ONE deflate stream: a block may point up to 32 KiB back into whatever came before it, and nothing
+// in the file says where blocks start.  The inflated bytes of the files people have (gzip, pigz, bcl2fastq output:
+// one member each) therefore come from one zlib thread at 0.3 GB/s however many cores the host has, and the GPU
+// waits.  This reader cuts the compressed bytes into chunks of a few MiB and lets every thread
+//   1. FIND the first deflate block that starts in its chunk: every bit position is tried as the header of a
+//      dynamic-Huffman block (code-length code complete, literal/length and distance codes complete, the block
+//      and its successors decode);
+//   2. INFLATE from there without knowing the 32 KiB in front of it: the output is 16-bit symbols, a byte or
+//      "byte i of the unknown window" - copies out of the window copy the markers along;
+//   3. stop at the first block boundary at or behind the next chunk's first bit.
+// Then, in file order: a chunk is JOINED to its predecessor only if the predecessor's decoding ended at exactly the
+// bit where the chunk started - so a wrong guess in step 1 can cost time (the predecessor decodes on through that
+// chunk) but never a byte; the last 32 KiB of each chunk, resolved with its predecessor's, are the next chunk's
+// window; and all chunks replace their markers and narrow to bytes in parallel, each summing the CRC-32 of its
+// part (crc32_combine glues the parts: every member's CRC-32 and length are checked as zlib checks them).
+// (The scheme is that of pugz - Kerbiriou & Chikhi, 2019 - restated; no code of theirs was at hand.)
+//
+// Whatever this decoder does not want to decide - a corrupt or truncated stream, a block larger than the window of
+// compressed bytes, an over-subscribed code, chunks whose first blocks are not found - goes to zlib: the reader falls
+// back to ONE raw zlib stream primed with the bit position and the 32 KiB in front of it (inflatePrime /
+// inflateSetDictionary) and stays there, so errors are zlib's errors with zlib's texts, and any gzip file zlib
+// reads is read the way zlib reads it (a file that ends inside a member: its bytes up to there, then the end of the
+// data, as gzread does it).  Multi-member files, members that end inside a chunk and bytes behind the last member (zlib's
+// gzread ignores them) are handled in the parallel path.
+#pragma once
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fq_parallel.h"
+
+namespace fqhost {
+namespace pgz {
+
+constexpr uint32_t kWin = 32768;
+constexpr size_t kSlack = 64;  // readable (zero) bytes behind the valid compressed bytes
+
+// ---- entries of the decoding tables ------------------------------------------------------------------------------
+// bits 0-4 code bits to drop | 5-7 type | 8-12 extra bits (sub-table: its index bits) | 16-31 literal / base / sub-table start
+enum : uint32_t { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kBadSym = 4 };
+constexpr uint32_t entry(uint32_t type, uint32_t val, uint32_t extra = 0) { return (val << 16) | (extra << 8) | (type << 5); }
+constexpr uint32_t e_type(uint32_t e) { return (e >> 5) & 7u; }
+constexpr uint32_t e_bits(uint32_t e) { return e & 31u; }
+constexpr uint32_t e_extra(uint32_t e) { return (e >> 8) & 31u; }
+constexpr uint32_t e_val(uint32_t e) { return e >> 16; }
+
+constexpr unsigned kLitBits = 11, kDistBits = 8, kMaxBits = 15;
+constexpr unsigned kLitTable = (1u << kLitBits) + 288u * (1u << (kMaxBits - kLitBits));
+constexpr unsigned kDistTable = (1u << kDistBits) + 32u * (1u << (kMaxBits - kDistBits));
+
+enum CodeKind { kComplete = 0, kEmpty, kSingle, kIncomplete, kOver };
+
+inline uint32_t reverse_bits(uint32_t c, unsigned n) {
+  uint32_t r = 0;
+  for (unsigned i = 0; i < n; ++i) {
+    r = (r << 1) | (c & 1u);
+    c >>= 1;
+  }
+  return r;
+}
+
+// canonical Huffman code of lens[0, n) (RFC 1951 3.2.2) as a two-level table
+inline CodeKind build_table(const uint8_t* lens, unsigned n, const uint32_t* sym_entry, unsigned pbits, unsigned maxbits,
+                            uint32_t* tab, unsigned cap) {
+  unsigned count[16] = {0};
+  for (unsigned s = 0; s < n; ++s) ++count[lens[s]];
+  count[0] = 0;
+  unsigned total = 0;
+  for (unsigned b = 1; b <= maxbits; ++b) total += count[b];
+  for (unsigned i = 0; i < (1u << pbits); ++i) tab[i] = entry(kBadSym, 0);
+  if (!total) return kEmpty;
+  long left = 1;
+  for (unsigned b = 1; b <= maxbits; ++b) {
+    left <<= 1;
+    left -= (long)count[b];
+    if (left < 0) return kOver;
+  }
+  CodeKind kind = kComplete;
+  if (left > 0) {
+    if (total == 1 && count[1] == 1) kind = kSingle;
+    else return kIncomplete;
+  }
+  unsigned next[16];
+  unsigned code = 0;
+  for (unsigned b = 1; b <= maxbits; ++b) {
+    code = (code + count[b - 1]) << 1;
+    next[b] = code;
+  }
+  unsigned sub_next = 1u << pbits;
+  const unsigned sub_bits = maxbits - pbits, sub_size = 1u << sub_bits;
+  for (unsigned s = 0; s < n; ++s) {
+    const unsigned L = lens[s];
+    if (!L) continue;
+    const uint32_t r = reverse_bits(next[L]++, L), e = sym_entry[s];
+    if (L <= pbits) {
+      for (uint32_t i = r; i < (1u << pbits); i += 1u << L) tab[i] = e | L;
+    } else {
+      const uint32_t prefix = r & ((1u << pbits) - 1u);
+      if (e_type(tab[prefix]) != kSub) {
+        if (sub_next + sub_size > cap) return kOver;  // (cannot be: cap allows a sub-table per symbol)
+        for (unsigned i = 0; i < sub_size; ++i) tab[sub_next + i] = entry(kBadSym, 0);
+        tab[prefix] = entry(kSub, sub_next, sub_bits) | pbits;
+        sub_next += sub_size;
+      }
+      const uint32_t start = e_val(tab[prefix]), hi = r >> pbits, Ls = L - pbits;
+      for (uint32_t i = hi; i < sub_size; i += 1u << Ls) tab[start + i] = e | Ls;
+    }
+  }
+  return kind;
+}
+
+struct SymEntries {
+  uint32_t lit[288], dist[32], cl[19];
+  SymEntries() {
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (unsigned s = 0; s < 256; ++s) lit[s] = entry(kLit, s);
+    lit[256] = entry(kEob, 0);
+    for (unsigned s = 257; s < 286; ++s) lit[s] = entry(kLen, lbase[s - 257], lext[s - 257]);
+    lit[286] = lit[287] = entry(kBadSym, 0);
+    for (unsigned s = 0; s < 30; ++s) dist[s] = entry(kLen, dbase[s], dext[s]);
+    dist[30] = dist[31] = entry(kBadSym, 0);
+    for (unsigned s = 0; s < 19; ++s) cl[s] = entry(kLit, s);
+  }
+};
+inline const SymEntries& sym_entries() {
+  static const SymEntries s;
+  return s;
+}
+
+// ---- bits --------------------------------------------------------------------------------------------------------
+struct BitIn {
+  const uint8_t* base = nullptr;
+  const uint8_t* p = nullptr;
+  uint64_t bb = 0;
+  unsigned bc = 0;
+  void refill() {  // 56..63 bits afterwards (the bytes behind the valid input are readable zeros)
+    uint64_t w;
+    memcpy(&w, p, 8);
+    bb |= w << bc;
+    p += (63 - bc) >> 3;
+    bc |= 56;
+  }
+  void seek(const uint8_t* b, uint64_t bit) {
+    base = b;
+    p = b + (bit >> 3);
+    bb = 0;
+    bc = 0;
+    refill();
+    const unsigned r = (unsigned)(bit & 7);
+    bb >>= r;
+    bc -= r;
+  }
+  uint32_t peek(unsigned n) const { return (uint32_t)(bb & ((1ull << n) - 1ull)); }
+  void drop(unsigned n) {
+    bb >>= n;
+    bc -= n;
+  }
+  uint32_t take(unsigned n) {
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  uint64_t bitpos() const { return (uint64_t)(p - base) * 8u - bc; }
+};
+
+// ---- 16-bit output -------------------------------------------------------------------------------------------------
+// d[0, kWin): the 32 KiB in front of the chunk, as symbols (markers 0x8000 | i where they are unknown); d[kWin, pos): output
+struct Out16 {
+  uint16_t* d = nullptr;
+  size_t cap = 0, pos = kWin;
+  Out16() = default;
+  Out16(const Out16&) = delete;
+  Out16& operator=(const Out16&) = delete;
+  ~Out16() { free(d); }
+  bool reserve(size_t want) {  // room for `want` symbols (+ the copy loop's overshoot)
+    if (want + 16 <= cap) return true;
+    size_t nc = std::max<size_t>(cap + cap / 2, want + 16);
+    uint16_t* nd = static_cast<uint16_t*>(realloc(d, nc * sizeof(uint16_t)));
+    if (!nd) return false;
+    d = nd;
+    cap = nc;
+    return true;
+  }
+  void window_unknown() {
+    for (uint32_t i = 0; i < kWin; ++i) d[i] = (uint16_t)(0x8000u | i);
+  }
+  void window_known(const uint8_t* w, size_t n) {  // the last n <= kWin bytes in front; what lies before them must not be asked for
+    for (uint32_t i = 0; i < kWin - n; ++i) d[i] = 0;
+    for (size_t i = 0; i < n; ++i) d[kWin - n + i] = w[i];
+  }
+};
+
+struct MemberEnd {
+  size_t out_pos;  // (index into Out16::d) the member's last byte is out_pos - 1
+  uint32_t crc, isize;
+};
+
+// gzip member header at p (RFC 1952 2.3): its length; 0 = more bytes needed; -1 = no gzip magic (or fewer than two
+// bytes: what zlib's gzread takes for trailing garbage); -2 = magic, but a method or flags that zlib refuses
+inline long gzip_header_len(const uint8_t* p, size_t n) {
+  if (n < 2 || p[0] != 0x1f || p[1] != 0x8b) return -1;
+  if (n < 10) return 0;
+  if (p[2] != 8 || (p[3] & 0xe0)) return -2;
+  const unsigned flg = p[3];
+  size_t q = 10;
+  if (flg & 4) {
+    if (q + 2 > n) return 0;
+    q += 2 + (p[q] | ((size_t)p[q + 1] << 8));
+    if (q > n) return 0;
+  }
+  for (unsigned f = 8; f <= 16; f <<= 1)  // FNAME, FCOMMENT: zero-terminated
+    if (flg & f) {
+      while (q < n && p[q]) ++q;
+      if (q >= n) return 0;
+      ++q;
+    }
+  if (flg & 2) q += 2;  // FHCRC (zlib checks it; a wrong one is an error there - here the member's CRC-32 still guards the data)
+  if (q > n) return 0;
+  return (long)q;
+}
+
+enum Status { kAtBoundary, kFinished, kNeedInput, kBad, kTooBig };
+
+// what one decoder has reached: always a point between two blocks (or behind a member's trailer and the next header)
+struct ChunkState {
+  uint64_t bit = 0;   // in the window of compressed bytes
+  Out16 out;          // out.pos: output up to `bit`
+  long long member_floor = -1;  // where in out.d the current member began; -1: in front of the chunk
+  size_t min_src = kWin;        // lowest index of d[0, kWin) a copy ever read (kWin: none)
+  size_t min_src_member0 = kWin;  // ... while the chunk's first member lasted (later members must not reach back at all)
+  std::vector<MemberEnd> ends;
+  bool finished = false;  // behind the last member: end of file, or bytes that are no gzip header
+  uint64_t blocks = 0;
+  uint64_t start_bit = 0;
+  bool found = false;
+  Status status = kAtBoundary;
+  void reset() {  // (the symbol buffer stays)
+    bit = start_bit = blocks = 0;
+    out.pos = kWin;
+    member_floor = -1;
+    min_src = min_src_member0 = kWin;
+    ends.clear();
+    finished = found = false;
+    status = kAtBoundary;
+  }
+};
+
+class Inflate16 {
+ public:
+  Inflate16() : lit_(kLitTable), dist_(kDistTable), fixed_lit_(kLitTable), fixed_dist_(kDistTable) {
+    uint8_t l[288];
+    for (unsigned s = 0; s < 144; ++s) l[s] = 8;
+    for (unsigned s = 144; s < 256; ++s) l[s] = 9;
+    for (unsigned s = 256; s < 280; ++s) l[s] = 7;
+    for (unsigned s = 280; s < 288; ++s) l[s] = 8;
+    build_table(l, 288, sym_entries().lit, kLitBits, kMaxBits, fixed_lit_.data(), kLitTable);
+    for (unsigned s = 0; s < 32; ++s) l[s] = 5;
+    build_table(l, 32, sym_entries().dist, kDistBits, kMaxBits, fixed_dist_.data(), kDistTable);
+  }
+
+  // Header of a dynamic block behind its three type bits (RFC 1951 3.2.7) -> lit_ / dist_.  false: not a header this
+  // decoder takes (zlib may still: an incomplete literal/length code with a single symbol).
+  bool dynamic_header(BitIn& in) {
+    in.refill();
+    const unsigned hlit = in.take(5) + 257, hdist = in.take(5) + 1, hclen = in.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    in.refill();  // (>= 56 bits: 14 are gone, 42 left = 14 lengths; the rest behind another refill)
+    for (unsigned i = 0; i < hclen; ++i) {
+      if (i == 14) in.refill();
+      cl[order[i]] = (uint8_t)in.take(3);
+    }
+    uint32_t clt[128];
+    if (build_table(cl, 19, sym_entries().cl, 7, 7, clt, 128) != kComplete) return false;
+    uint8_t lens[320];
+    unsigned i = 0;
+    const unsigned total = hlit + hdist;
+    while (i < total) {
+      in.refill();
+      const uint32_t e = clt[in.peek(7)];
+      if (e_type(e) != kLit) return false;
+      in.drop(e_bits(e));
+      const unsigned s = e_val(e);
+      if (s < 16) lens[i++] = (uint8_t)s;
+      else {
+        unsigned rep, v = 0;
+        if (s == 16) {
+          if (!i) return false;
+          v = lens[i - 1];
+          rep = 3 + in.take(2);
+        } else if (s == 17) rep = 3 + in.take(3);
+        else rep = 11 + in.take(7);
+        if (i + rep > total) return false;
+        while (rep--) lens[i++] = (uint8_t)v;
+      }
+    }
+    if (!lens[256]) return false;
+    if (build_table(lens, hlit, sym_entries().lit, kLitBits, kMaxBits, lit_.data(), kLitTable) != kComplete) return false;
+    const CodeKind dk = build_table(lens + hlit, hdist, sym_entries().dist, kDistBits, kMaxBits, dist_.data(), kDistTable);
+    return dk == kComplete || dk == kEmpty || dk == kSingle;
+  }
+
+  // Decodes on from cs (a point between blocks) until the first such point at or behind stop_bit, the end of the last
+  // member, or trouble; cs always ends at the last point reached.  base[0, nvalid) are the compressed bytes at hand
+  // (kSlack readable bytes behind them), eof = the file ends with them; out_limit bounds cs.out.pos.
+  Status run(ChunkState& cs, const uint8_t* base, size_t nvalid, bool eof, uint64_t stop_bit, size_t out_limit) {
+    BitIn in;
+    in.seek(base, cs.bit);
+    const uint64_t nbits = (uint64_t)nvalid * 8u;
+    size_t pos = cs.out.pos;
+    long long floor_ = cs.member_floor;
+    size_t min_src = cs.min_src;
+    for (;;) {
+      if (cs.bit >= stop_bit) return cs.status = kAtBoundary;
+      if (in.bitpos() + 3 > nbits) return cs.status = kNeedInput;
+      in.refill();
+      const unsigned bfinal = in.take(1), btype = in.take(2);
+      Status st;
+      if (btype == 0) st = stored(in, cs.out, pos, nvalid, out_limit);
+      else if (btype == 3) st = kBad;
+      else {
+        const uint32_t *lt = fixed_lit_.data(), *dt = fixed_dist_.data();
+        if (btype == 2) {
+          if (!dynamic_header(in)) return cs.status = (in.bitpos() > nbits ? kNeedInput : kBad);
+          lt = lit_.data();
+          dt = dist_.data();
+        }
+        st = codes(in, lt, dt, cs.out, pos, floor_, min_src, base + nvalid + 8, out_limit);
+      }
+      if (st != kAtBoundary) return cs.status = st;
+      if (in.bitpos() > nbits) return cs.status = kNeedInput;
+      if (!bfinal) {
+        cs.bit = in.bitpos();
+        cs.out.pos = pos;
+        cs.min_src = min_src;
+        ++cs.blocks;
+        continue;
+      }
+      // the member's trailer, and what follows it
+      const size_t at = (size_t)((in.bitpos() + 7) >> 3);
+      if (at + 8 > nvalid) return cs.status = kNeedInput;
+      auto le32 = [&](size_t o) { return (uint32_t)base[o] | ((uint32_t)base[o + 1] << 8) | ((uint32_t)base[o + 2] << 16) | ((uint32_t)base[o + 3] << 24); };
+      const MemberEnd me{pos, le32(at), le32(at + 4)};
+      const size_t next = at + 8;
+      long hl = -1;
+      if (!(next == nvalid && eof)) {
+        hl = gzip_header_len(base + next, nvalid - next);
+        if (hl == 0) return cs.status = (eof ? kBad : kNeedInput);  // (a header the file ends in: zlib's "unexpected end of file")
+        if (hl == -2) return cs.status = kBad;
+        if (hl > 0 && next + (size_t)hl >= nvalid && !eof) return cs.status = kNeedInput;
+      }
+      cs.ends.push_back(me);
+      cs.out.pos = pos;
+      if (cs.member_floor < 0 && cs.ends.size() == 1) cs.min_src_member0 = min_src;
+      cs.min_src = min_src;
+      ++cs.blocks;
+      if (hl < 0) {
+        cs.bit = (uint64_t)next * 8u;
+        cs.finished = true;
+        return cs.status = kFinished;
+      }
+      cs.bit = (uint64_t)(next + (size_t)hl) * 8u;
+      cs.member_floor = floor_ = (long long)pos;
+      in.seek(base, cs.bit);
+    }
+  }
+
+ private:
+  static Status stored(BitIn& in, Out16& out, size_t& pos, size_t nvalid, size_t out_limit) {
+    const size_t at = (size_t)((in.bitpos() + 7) >> 3);
+    if (at + 4 > nvalid) return kNeedInput;
+    const uint8_t* b = in.base + at;
+    const unsigned len = b[0] | ((unsigned)b[1] << 8), nlen = b[2] | ((unsigned)b[3] << 8);
+    if ((len ^ 0xFFFFu) != nlen) return kBad;
+    if (at + 4 + len > nvalid) return kNeedInput;
+    if (pos + len > out_limit) return kTooBig;
+    if (!out.reserve(pos + len)) return kTooBig;
+    for (unsigned i = 0; i < len; ++i) out.d[pos + i] = b[4 + i];
+    pos += len;
+    in.seek(in.base, (uint64_t)(at + 4 + len) * 8u);
+    return kAtBoundary;
+  }
+
+  static Status codes(BitIn& in, const uint32_t* lt, const uint32_t* dt, Out16& out, size_t& pos_io, long long floor_,
+                      size_t& min_src_io, const uint8_t* in_limit, size_t out_limit) {
+    size_t pos = pos_io, min_src = min_src_io;
+    uint16_t* d = out.d;
+    size_t room = out.cap;  // symbols that may be written without asking
+    auto lookup = [&](const uint32_t* t, unsigned pbits) {
+      uint32_t e = t[in.bb & ((1u << pbits) - 1u)];
+      if (__builtin_expect(e_type(e) == kSub, 0)) {
+        in.drop(e_bits(e));
+        e = t[e_val(e) + (in.bb & ((1u << e_extra(e)) - 1u))];
+      }
+      in.drop(e_bits(e));
+      return e;
+    };
+    for (;;) {
+      if (__builtin_expect(pos + 300 > room, 0)) {
+        if (pos + 300 > out_limit) return kTooBig;
+        if (!out.reserve(pos + (1u << 20))) return kTooBig;
+        d = out.d;
+        room = out.cap - 16;
+      }
+      if (__builtin_expect(in.p > in_limit, 0)) return kNeedInput;
+      in.refill();
+      uint32_t e = lookup(lt, kLitBits);
+      if (e_type(e) == kLit) {
+        d[pos++] = (uint16_t)e_val(e);
+        e = lookup(lt, kLitBits);
+        if (e_type(e) == kLit) {
+          d[pos++] = (uint16_t)e_val(e);
+          continue;
+        }
+      }
+      if (e_type(e) == kEob) break;
+      if (e_type(e) != kLen) return kBad;
+      const unsigned length = e_val(e) + in.take(e_extra(e));
+      in.refill();
+      const uint32_t de = lookup(dt, kDistBits);
+      if (e_type(de) != kLen) return kBad;
+      const size_t dist = e_val(de) + in.take(e_extra(de));
+      const size_t src = pos - dist;  // (pos >= kWin >= dist)
+      if (src < kWin) {
+        if (floor_ >= 0) return kBad;  // in front of this chunk AND of the member that began inside it
+        if (src < min_src) min_src = src;
+      } else if ((long long)src < floor_) return kBad;  // in front of the member's first byte: zlib's "invalid distance too far back"
+      uint16_t* o = d + pos;
+      const uint16_t* s = d + src;
+      if (dist >= 4) {
+        size_t i = 0;
+        do {
+          memcpy(o + i, s + i, 8);
+          i += 4;
+        } while (i < length);
+      } else {
+        for (size_t i = 0; i < length; ++i) o[i] = s[i];
+      }
+      pos += length;
+    }
+    pos_io = pos;
+    min_src_io = min_src;
+    return kAtBoundary;
+  }
+
+  std::vector<uint32_t> lit_, dist_, fixed_lit_, fixed_dist_;
+};
+
+// first bit in [from, to) at which a non-final dynamic block's header parses (codes complete); `to` if none
+inline uint64_t find_block(const uint8_t* base, size_t nvalid, uint64_t from, uint64_t to, Inflate16& dec) {
+  const uint64_t nbits = (uint64_t)nvalid * 8u;
+  for (uint64_t bit = from; bit < to && bit + 80 < nbits; ++bit) {
+    uint64_t w;
+    memcpy(&w, base + (bit >> 3), 8);
+    w >>= bit & 7;
+    if ((w & 7u) != 4u) continue;  // BFINAL 0, BTYPE 10 (dynamic)
+    if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;  // HLIT, HDIST
+    // the code-length code must be complete: sum of 2^(7 - len) over its non-zero lengths == 2^7
+    const unsigned hclen = (unsigned)((w >> 13) & 15u) + 4;
+    uint64_t v = w >> 17;  // 40 bits = 13 lengths at hand
+    unsigned sum = 0, have = 13;
+    for (unsigned i = 0; i < hclen; ++i) {
+      if (!have) {
+        memcpy(&v, base + ((bit + 17 + 3 * i) >> 3), 8);
+        v >>= (bit + 17 + 3 * i) & 7;
+        have = 19;
+      }
+      const unsigned l = (unsigned)(v & 7u);
+      v >>= 3;
+      --have;
+      if (l) sum += 128u >> l;
+    }
+    if (sum != 128u) continue;
+    BitIn in;
+    in.seek(base, bit + 3);
+    if (dec.dynamic_header(in) && in.bitpos() <= nbits) return bit;
+  }
+  return to;
+}
+
+}  // namespace pgz
+
+// The reader.  read() is gzread(): up to `want` inflated bytes, *at_end once nothing follows; on an error error()
+// holds zlib's text (as gzerror's: "<path>: <message>") and read() returns what it had.
+class ParallelGunzip {
+ public:
+  ParallelGunzip(int fd, uint64_t file_size, std::string path, unsigned threads, size_t chunk_bytes)
+      : fd_(fd), size_(file_size), path_(std::move(path)), threads_(std::max(1u, threads)), chunk_(std::max<size_t>(chunk_bytes, 4096)) {}
+  ~ParallelGunzip() {
+    if (zs_live_) inflateEnd(&zs_);
+    free(cbuf_);
+  }
+  ParallelGunzip(const ParallelGunzip&) = delete;
+  ParallelGunzip& operator=(const ParallelGunzip&) = delete;
+
+  bool failed() const { return failed_; }
+  const std::string& error() const { return error_; }
+  struct Stats {
+    uint64_t batches = 0, chunks_joined = 0, chunks_not_found = 0, chunks_discarded = 0, serial_bits = 0, members = 0;
+    bool fell_back = false, truncated = false;
+    std::string why;
+    double s_load = 0, s_decode = 0, s_join = 0, s_windows = 0, s_narrow = 0, s_serial = 0;  // seconds per phase
+  };
+  const Stats& stats() const { return stats_; }
+
+  size_t read(char* dst, size_t want, bool* at_end) {
+    size_t len = 0;
+    while (len < want && !failed_) {
+      if (ready_at_ < ready_.size()) {
+        const size_t n = std::min(want - len, ready_.size() - ready_at_);
+        memcpy(dst + len, ready_.data() + ready_at_, n);
+        ready_at_ += n;
+        len += n;
+        continue;
+      }
+      if (done_) break;
+      if (serial_) len += serial_read(dst + len, want - len);
+      else len += batch(dst + len, want - len);
+    }
+    if (done_ && ready_at_ >= ready_.size()) *at_end = true;
+    return len;
+  }
+
+ private:
+  void fail(const char* msg) {
+    failed_ = true;
+    error_ = path_ + ": " + msg;
+  }
+  // The file ends inside a member.  zlib's gzread hands out what could be inflated and then reports the end of the data:
+  // Z_BUF_ERROR ("unexpected end of file") is the one error it does not return -1 for (gzread.c: gz_read), and what the
+  // reference's gzgets loop sees is an ordinary end of file.  The same here.
+  void truncated() {
+    done_ = true;
+    stats_.truncated = true;
+  }
+  void fall_back(const char* why) {
+    serial_ = true;
+    stats_.fell_back = true;
+    if (stats_.why.empty()) stats_.why = why;
+  }
+
+  // compressed bytes [coff_, coff_ + n) of the file into cbuf_ (+ zeroed slack)
+  bool load(size_t n) {
+    if (cbuf_cap_ < n + pgz::kSlack) {
+      free(cbuf_);
+      cbuf_cap_ = n + pgz::kSlack;
+      cbuf_ = static_cast<uint8_t*>(malloc(cbuf_cap_));
+      if (!cbuf_) {
+        cbuf_cap_ = 0;
+        fail("out of memory");
+        return false;
+      }
+    }
+    size_t done = 0;
+    while (done < n) {
+      const ssize_t got = pread(fd_, cbuf_ + done, n - done, (off_t)(coff_ + done));
+      if (got <= 0) {
+        fail("read error");
+        return false;
+      }
+      done += (size_t)got;
+    }
+    memset(cbuf_ + n, 0, pgz::kSlack);
+    cn_ = n;
+    return true;
+  }
+
+  // One round of the parallel path: output goes to dst (room bytes) first, the rest to ready_.  Returns bytes put into dst.
+  size_t batch(char* dst, size_t room) {
+    using namespace pgz;
+    ++stats_.batches;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_start = now();
+    const size_t n = (size_t)std::min<uint64_t>((uint64_t)chunk_ * threads_ + (bit0_ >> 3) + 1, size_ - coff_);
+    if (!load(n)) return 0;
+    const bool eof = coff_ + n == size_;
+    if (!in_member_) {  // a member's header is expected at byte 0
+      const long hl = gzip_header_len(cbuf_, cn_);
+      if (hl == -1) {
+        if (first_member_) fall_back("no gzip header");  // (not reached: the caller looked at the magic)
+        else done_ = true;  // bytes behind the last member: gzread ignores them
+        return 0;
+      }
+      if (hl <= 0 || (size_t)hl >= cn_) {
+        fall_back("gzip header");
+        return 0;
+      }
+      bit0_ = (uint64_t)hl * 8u;
+      in_member_ = true;
+      first_member_ = false;
+      win_n_ = 0;
+      member_crc_ = crc32(0L, Z_NULL, 0);
+      member_len_ = 0;
+    }
+    const uint64_t nbits = (uint64_t)cn_ * 8u;
+    // chunk k looks for its first block from byte first + k * chunk_ on (chunk 0 starts where the last round ended)
+    const size_t first = (size_t)(bit0_ >> 3);
+    unsigned K = (unsigned)std::min<size_t>(threads_, (cn_ - first + chunk_ - 1) / chunk_);
+    if (K < 1) K = 1;
+    // (the chunks' symbol buffers are kept from round to round: fresh ones are tens of megabytes of page faults each)
+    while (pool_.size() < K) pool_.emplace_back(new ChunkState());
+    std::vector<ChunkState*> cs(K);
+    for (unsigned k = 0; k < K; ++k) {
+      cs[k] = pool_[k].get();
+      cs[k]->reset();
+    }
+    const size_t out_limit = kWin + chunk_ * 200 + (1u << 20);  // symbols per chunk; beyond: fall back (memory)
+    auto start_of = [&](unsigned k) { return (uint64_t)(first + (size_t)k * chunk_) * 8u; };
+    std::atomic<bool> oom{false};
+    const auto t_loaded = now();
+    stats_.s_load += secs(t_start, t_loaded);
+    parallel_items(K, [&](size_t k) {
+      ChunkState& c = *cs[k];
+      Inflate16 dec;
+      const uint64_t stop = k + 1 < K ? start_of((unsigned)k + 1) : ~0ull;
+      if (!c.out.reserve(kWin + chunk_ * 6)) {
+        oom = true;
+        return;
+      }
+      if (k == 0) {
+        c.out.window_known(win_, win_n_);
+        c.bit = c.start_bit = bit0_;
+        c.found = true;
+        dec.run(c, cbuf_, cn_, eof, stop, out_limit);
+        return;
+      }
+      c.out.window_unknown();
+      uint64_t from = start_of((unsigned)k);
+      while (from < stop) {
+        const uint64_t at = find_block(cbuf_, cn_, from, std::min(stop, nbits), dec);
+        if (at >= std::min(stop, nbits)) break;
+        c.reset();
+        c.bit = c.start_bit = at;
+        const Status st = dec.run(c, cbuf_, cn_, eof, stop, out_limit);
+        // (a guess that dies within a few blocks was no block start; real damage is found by whoever decodes up to here)
+        if (st == kBad && c.blocks < 4) {
+          from = at + 1;
+          continue;
+        }
+        if ((st == kNeedInput || st == kTooBig) && c.blocks == 0) break;
+        c.found = true;
+        break;
+      }
+    });
+    if (oom) {
+      fail("out of memory");
+      return 0;
+    }
+    // ---- join, in file order ----
+    const auto t_decoded = now();
+    stats_.s_decode += secs(t_loaded, t_decoded);
+    std::vector<unsigned> joined{0};
+    Inflate16 dec;
+    unsigned cur = 0;
+    uint64_t serial_bits = 0;
+    const char* stop_why = nullptr;
+    for (unsigned j = 1; j < K && !stop_why;) {
+      ChunkState& c = *cs[cur];
+      if (c.status != kAtBoundary) break;  // the end of the last member, the end of the bytes at hand, or trouble: the round ends here
+      ChunkState& nx = *cs[j];
+      if (!nx.found) {
+        ++stats_.chunks_not_found;
+        ++j;
+        if (j == K) extend(dec, c, eof, ~0ull, out_limit, serial_bits);
+        continue;
+      }
+      if (c.bit == nx.start_bit) {
+        joined.push_back(j);
+        cur = j;
+        ++j;
+        continue;
+      }
+      if (c.bit > nx.start_bit) {  // the guess was wrong: its work is lost, the predecessor decodes on
+        ++stats_.chunks_discarded;
+        ++j;
+        if (j == K) extend(dec, c, eof, ~0ull, out_limit, serial_bits);
+        continue;
+      }
+      extend(dec, c, eof, nx.start_bit, out_limit, serial_bits);
+      if (serial_bits > (uint64_t)chunk_ * 8u * 3u) stop_why = "block starts not found";
+    }
+    stats_.serial_bits += serial_bits;
+    const auto t_joined = now();
+    stats_.s_join += secs(t_decoded, t_joined);
+    // ---- windows, in file order; what the chunks may have asked of them ----
+    // valid = bytes of the current member in front of the chunk (what a copy may reach back into), capped at kWin
+    std::vector<std::vector<uint8_t>> wins(joined.size());
+    size_t use = joined.size();
+    {
+      std::vector<uint8_t> w(win_, win_ + win_n_);
+      uint64_t valid = std::min<uint64_t>(member_len_, kWin);
+      if (win_n_ < valid) valid = win_n_;
+      std::vector<uint64_t> valid_at(joined.size() + 1, 0);
+      for (size_t q = 0; q < joined.size(); ++q) {
+        ChunkState& c = *cs[joined[q]];
+        wins[q] = w;
+        valid_at[q] = valid;
+        // the chunk's first member continues the one in front of it: its copies must stay inside `valid`
+        const size_t reach = c.ends.empty() && c.member_floor < 0 ? c.min_src : c.min_src_member0;
+        if ((uint64_t)(kWin - reach) > valid) {
+          use = q;  // zlib's "invalid distance too far back" - let zlib say it
+          stop_why = "distance too far back";
+          break;
+        }
+        // the next window: the last kWin bytes of (w, this chunk's output)
+        const size_t produced = c.out.pos - kWin;
+        std::vector<uint8_t> nw;
+        const size_t keep = produced >= kWin ? 0 : std::min<size_t>(w.size(), kWin - produced);
+        nw.reserve(keep + std::min<size_t>(produced, kWin));
+        nw.insert(nw.end(), w.end() - (long)keep, w.end());
+        const size_t from = produced > kWin ? c.out.pos - kWin : kWin;
+        for (size_t i = from; i < c.out.pos; ++i) nw.push_back(resolve(c.out.d[i], w));
+        valid = c.member_floor >= 0 ? std::min<uint64_t>(c.out.pos - (size_t)c.member_floor, kWin) : std::min<uint64_t>(valid + produced, kWin);
+        w.swap(nw);
+        if (c.status != kAtBoundary && q + 1 < joined.size()) {  // (cannot be: the join stops at such a chunk)
+          use = q + 1;
+          break;
+        }
+      }
+      valid_at[joined.size()] = valid;
+      if (use == joined.size()) next_win_.swap(w);
+      else next_win_ = wins[use];  // the window in front of the first chunk that is not used
+      // (what lies in front of the current member's first byte is no window of it: zlib must not be handed it either)
+      const size_t keep = (size_t)std::min<uint64_t>(valid_at[use], next_win_.size());
+      next_win_.erase(next_win_.begin(), next_win_.end() - (long)keep);
+    }
+    // ---- markers -> bytes, CRC-32 per stretch between member ends: in parallel ----
+    const auto t_windows = now();
+    stats_.s_windows += secs(t_joined, t_windows);
+    struct Part {
+      std::vector<uint32_t> crc;  // one per stretch (ends.size() + 1)
+      std::vector<size_t> len;
+      size_t off = 0;  // of the chunk's bytes in this round's output
+    };
+    std::vector<Part> parts(use);
+    size_t total = 0;
+    for (size_t q = 0; q < use; ++q) {
+      parts[q].off = total;
+      total += cs[joined[q]]->out.pos - kWin;
+    }
+    const size_t direct = std::min(room, total);
+    ready_.resize(total - direct);
+    ready_at_ = 0;
+    parallel_items(use, [&](size_t q) {
+      const ChunkState& c = *cs[joined[q]];
+      Part& p = parts[q];
+      uint8_t lut_win[kWin];
+      memset(lut_win, 0, sizeof(lut_win));
+      const std::vector<uint8_t>& w = wins[q];
+      memcpy(lut_win + kWin - w.size(), w.data(), w.size());
+      size_t a = kWin;
+      for (size_t s = 0; s <= c.ends.size(); ++s) {
+        const size_t b = s < c.ends.size() ? c.ends[s].out_pos : c.out.pos;
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        // [a, b) of the chunk = bytes [o, o + b - a) of the round: to dst below `direct`, to ready_ above
+        size_t o = p.off + (a - kWin), i = a;
+        while (i < b) {
+          char* out;
+          size_t m;
+          if (o < direct) {
+            out = dst + o;
+            m = std::min(b - i, direct - o);
+          } else {
+            out = ready_.data() + (o - direct);
+            m = b - i;
+          }
+          narrow(c.out.d + i, m, lut_win, reinterpret_cast<uint8_t*>(out));
+          size_t left = m;
+          const Bytef* cp = reinterpret_cast<const Bytef*>(out);
+          while (left) {
+            const uInt step = (uInt)std::min<size_t>(left, 1u << 30);
+            crc = (uint32_t)crc32(crc, cp, step);
+            cp += step;
+            left -= step;
+          }
+          i += m;
+          o += m;
+        }
+        p.crc.push_back(crc);
+        p.len.push_back(b - a);
+        a = b;
+      }
+    });
+    stats_.s_narrow += secs(t_windows, now());
+    // ---- members' checks, in file order ----
+    for (size_t q = 0; q < use && !failed_; ++q) {
+      const ChunkState& c = *cs[joined[q]];
+      for (size_t s = 0; s < parts[q].crc.size(); ++s) {
+        member_crc_ = crc32_combine(member_crc_, parts[q].crc[s], (z_off_t)parts[q].len[s]);
+        member_len_ += parts[q].len[s];
+        if (s < c.ends.size()) {
+          ++stats_.members;
+          if ((uint32_t)member_crc_ != c.ends[s].crc) fail("incorrect data check");
+          else if ((uint32_t)member_len_ != c.ends[s].isize) fail("incorrect length check");
+          member_crc_ = crc32(0L, Z_NULL, 0);
+          member_len_ = 0;
+        }
+      }
+    }
+    if (failed_) {
+      ready_.clear();
+      return 0;
+    }
+    stats_.chunks_joined += use;
+    // ---- where the next round starts ----
+    if (use == 0) {  // nothing usable (the very first chunk was refused): zlib from here
+      fall_back(stop_why ? stop_why : "no progress");
+      coff_ += bit0_ >> 3;
+      bit0_ &= 7u;
+      return 0;
+    }
+    const ChunkState& last = *cs[joined[use - 1]];
+    memcpy(win_, next_win_.data(), next_win_.size());
+    win_n_ = next_win_.size();
+    in_member_ = !last.finished;
+    if (last.finished) {
+      done_ = true;
+    } else {
+      const uint64_t adv = last.bit >> 3;
+      if (use < joined.size() || stop_why) fall_back(stop_why ? stop_why : "join");
+      else if (last.status == kBad) fall_back("a block zlib must judge");
+      else if (last.status == kTooBig) fall_back("a chunk inflates too far");
+      else if (last.status == kNeedInput) {
+        if (eof) fall_back("the file ends inside a block");  // zlib's "unexpected end of file"
+        else if (adv == (bit0_ >> 3) && use == 1 && last.out.pos == kWin) fall_back("a block larger than the window");
+      }
+      coff_ += adv;
+      bit0_ = last.bit & 7u;
+    }
+    return direct;
+  }
+
+  // the predecessor decodes on, on this thread, to the first boundary at or behind stop_bit
+  void extend(pgz::Inflate16& dec, pgz::ChunkState& c, bool eof, uint64_t stop_bit, size_t out_limit, uint64_t& serial_bits) {
+    const uint64_t before = c.bit;
+    dec.run(c, cbuf_, cn_, eof, stop_bit, out_limit + (c.out.pos - pgz::kWin));
+    serial_bits += c.bit - before;
+  }
+
+  static uint8_t resolve(uint16_t v, const std::vector<uint8_t>& w) {
+    if (v < 256) return (uint8_t)v;
+    const size_t i = v & 0x7FFFu;  // index into the kWin bytes in front of the chunk; w holds the last w.size() of them
+    const size_t missing = pgz::kWin - w.size();
+    return i >= missing ? w[i - missing] : 0;
+  }
+  static void narrow(const uint16_t* s, size_t n, const uint8_t* win, uint8_t* out) {
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+      uint16_t any = 0;
+      for (int k = 0; k < 16; ++k) any |= s[i + k];
+      if (any < 256) {
+        for (int k = 0; k < 16; ++k) out[i + k] = (uint8_t)s[i + k];
+      } else {
+        for (int k = 0; k < 16; ++k) {
+          const uint16_t v = s[i + k];
+          out[i + k] = v < 256 ? (uint8_t)v : win[v & 0x7FFFu];
+        }
+      }
+    }
+    for (; i < n; ++i) {
+      const uint16_t v = s[i];
+      out[i] = v < 256 ? (uint8_t)v : win[v & 0x7FFFu];
+    }
+  }
+
+  // ---- one zlib stream from (coff_, bit0_) on, primed with win_ ----
+  size_t serial_read(char* dst, size_t want) {
+    using namespace pgz;
+    if (!zs_live_) {
+      memset(&zs_, 0, sizeof(zs_));
+      if (inflateInit2(&zs_, -15) != Z_OK) {
+        fail("out of memory");
+        return 0;
+      }
+      zs_live_ = true;
+      sbuf_.resize(1u << 20);
+      s_at_ = s_n_ = 0;
+      if (in_member_) {
+        unsigned char first = 0;
+        const unsigned off = (unsigned)(bit0_ & 7u);
+        if (off) {
+          if (pread(fd_, &first, 1, (off_t)coff_) != 1) {
+            truncated();
+            return 0;
+          }
+          ++coff_;
+          inflatePrime(&zs_, 8 - (int)off, first >> off);
+        }
+        if (win_n_) inflateSetDictionary(&zs_, win_, (uInt)win_n_);
+      }
+    }
+    size_t len = 0;
+    while (len < want && !done_ && !failed_) {
+      if (s_at_ == s_n_) {
+        const size_t n = (size_t)std::min<uint64_t>(sbuf_.size(), size_ - coff_);
+        if (n) {
+          const ssize_t got = pread(fd_, sbuf_.data(), n, (off_t)coff_);
+          if (got <= 0) {
+            fail("read error");
+            break;
+          }
+          coff_ += (uint64_t)got;
+          s_at_ = 0;
+          s_n_ = (size_t)got;
+        }
+      }
+      if (!in_member_) {
+        // the trailer's eight bytes and the next header come through a small look-ahead of their own
+        std::vector<uint8_t> hdr(sbuf_.begin() + (long)s_at_, sbuf_.begin() + (long)s_n_);
+        while (hdr.size() < (1u << 16) && coff_ < size_) {  // (a header beyond 64 KiB: zlib would take it, this gives up)
+          const size_t n = (size_t)std::min<uint64_t>(1u << 16, size_ - coff_);
+          const size_t old = hdr.size();
+          hdr.resize(old + n);
+          if (pread(fd_, hdr.data() + old, n, (off_t)coff_) != (ssize_t)n) {
+            fail("read error");
+            return len;
+          }
+          coff_ += n;
+        }
+        if (hdr.empty()) {
+          done_ = true;
+          break;
+        }
+        const long hl = gzip_header_len(hdr.data(), hdr.size());
+        if (hl == -1) {
+          if (first_member_) fail("not in gzip format");
+          done_ = true;  // trailing garbage
+          break;
+        }
+        if (hl == -2) {
+          fail(hdr[2] != 8 ? "unknown compression method" : "unknown header flags set");
+          break;
+        }
+        if (hl == 0) {
+          truncated();
+          break;
+        }
+        sbuf_.assign(hdr.begin() + hl, hdr.end());
+        if (sbuf_.size() < (1u << 20)) sbuf_.resize(1u << 20);
+        s_at_ = 0;
+        s_n_ = hdr.size() - (size_t)hl;
+        inflateReset(&zs_);
+        in_member_ = true;
+        first_member_ = false;
+        member_crc_ = crc32(0L, Z_NULL, 0);
+        member_len_ = 0;
+        continue;
+      }
+      if (s_at_ == s_n_ && coff_ >= size_) {
+        truncated();
+        break;
+      }
+      zs_.next_in = sbuf_.data() + s_at_;
+      zs_.avail_in = (uInt)(s_n_ - s_at_);
+      zs_.next_out = reinterpret_cast<Bytef*>(dst + len);
+      zs_.avail_out = (uInt)std::min<size_t>(want - len, 1u << 30);
+      const uInt out_before = zs_.avail_out;
+      const int rc = inflate(&zs_, Z_NO_FLUSH);
+      s_at_ = s_n_ - zs_.avail_in;
+      const size_t got = out_before - zs_.avail_out;
+      member_crc_ = crc32(member_crc_, reinterpret_cast<const Bytef*>(dst + len), (uInt)got);
+      member_len_ += got;
+      len += got;
+      if (rc == Z_STREAM_END) {
+        uint8_t t[8];
+        size_t have = 0;
+        while (have < 8) {
+          if (s_at_ < s_n_) t[have++] = sbuf_[s_at_++];
+          else if (coff_ < size_) {
+            const size_t n = (size_t)std::min<uint64_t>(sbuf_.size(), size_ - coff_);
+            const ssize_t g = pread(fd_, sbuf_.data(), n, (off_t)coff_);
+            if (g <= 0) {
+              fail("read error");
+              return len;
+            }
+            coff_ += (uint64_t)g;
+            s_at_ = 0;
+            s_n_ = (size_t)g;
+          } else {
+            truncated();
+            return len;
+          }
+        }
+        const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t isz = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        ++stats_.members;
+        if ((uint32_t)member_crc_ != crc) fail("incorrect data check");
+        else if ((uint32_t)member_len_ != isz) fail("incorrect length check");
+        in_member_ = false;
+      } else if (rc == Z_NEED_DICT || rc == Z_DATA_ERROR || rc == Z_MEM_ERROR || rc == Z_STREAM_ERROR) {
+        fail(zs_.msg ? zs_.msg : "compressed data error");
+      } else if (rc == Z_BUF_ERROR && got == 0 && zs_.avail_in == 0 && coff_ >= size_) {
+        truncated();
+      }
+    }
+    return len;
+  }
+
+  int fd_;
+  uint64_t size_;
+  std::string path_;
+  unsigned threads_;
+  size_t chunk_;
+  // where the next byte comes from: file offset of the window's first byte, bit in it, inside a member or in front of a header
+  uint64_t coff_ = 0, bit0_ = 0;
+  bool in_member_ = false, first_member_ = true, done_ = false, serial_ = false, failed_ = false;
+  uint8_t win_[pgz::kWin];  // the last win_n_ inflated bytes
+  size_t win_n_ = 0;
+  std::vector<uint8_t> next_win_;
+  uLong member_crc_ = 0;
+  uint64_t member_len_ = 0;
+  uint8_t* cbuf_ = nullptr;
+  size_t cbuf_cap_ = 0, cn_ = 0;
+  std::vector<char> ready_;
+  size_t ready_at_ = 0;
+  std::vector<std::unique_ptr<pgz::ChunkState>> pool_;
+  std::string error_;
+  Stats stats_;
+  // serial path
+  z_stream zs_;
+  bool zs_live_ = false;
+  std::vector<uint8_t> sbuf_;
+  size_t s_at_ = 0, s_n_ = 0;
+};
+
+}  // namespace fqhost

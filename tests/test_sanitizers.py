@@ -108,6 +108,20 @@ def test_host_input_stager_runs_clean(tmpdir, san):
     bad.write_bytes(bytes(broken))
     p = subprocess.run([exe, str(bad), "100000", "0"], env=bgz_env, capture_output=True, timeout=300)
     assert p.returncode != 0 and (b"BGZF" in p.stderr), p.stderr.decode()[-800:]
+    # any other gzip file beyond 1 MiB is inflated by chunks whose first blocks are searched for (fq_pgzip.h); small chunks
+    # here, so that this file is dozens of them, and a file of several members with bytes behind the last one
+    big = tmpdir / "big.txt.gz"
+    big.write_bytes(gzip.compress(data, 6) + gzip.compress(data[:300000], 1) + b"trailing bytes")
+    want_big = ("%d %d" % (len(data) + 300000, fnv(data + data[:300000]))).encode()
+    assert big.stat().st_size > (1 << 20)
+    for piece in ("100000", "50000000"):
+        for mode in ("0", "2"):
+            for extra in ({"FQGPU_PGZIP_CHUNK": "30000"}, {}, {"FQGPU_NO_PARALLEL_INFLATE": "1"}):
+                p = subprocess.run([exe, str(big), piece, mode], env=dict(bgz_env, FQGPU_PGZIP_DEBUG="1", **extra), capture_output=True, timeout=300)
+                assert p.returncode == 0 and p.stdout.strip() == want_big, (piece, mode, extra, p.stdout, p.stderr.decode()[-1500:])
+                assert (b"inflated by chunks" in p.stderr) == ("FQGPU_NO_PARALLEL_INFLATE" not in extra), p.stderr.decode()[-800:]
+                if "FQGPU_PGZIP_CHUNK" in extra:
+                    assert b"one zlib stream" not in p.stderr and b" 2 members" in p.stderr, p.stderr.decode()[-800:]
     for path, wanted in ((plain, want), (gz, want), (empty, ("0 %d" % fnv(b"")).encode())):
         for piece in ("4096", "100000", "50000000"):
             for mode in ("0", "1", "2"):
