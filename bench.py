@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-fed measurement (the same reads from pinned host RAM / from a tmpfs file)")
     ap.add_argument("--bgzf-helper", nargs=2, metavar=("SRC", "DST"), help=argparse.SUPPRESS)
+    ap.add_argument("--gz-helper", nargs=3, metavar=("SRC", "DST", "NBYTES"), help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -561,6 +562,34 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
             finally:
                 if os.path.exists(path + ".gz"):
                     os.unlink(path + ".gz")
+            # ... and what most people have is ONE gzip member (gzip, pigz, bcl2fastq): the first 10 M reads as such a file
+            # (written the way pigz writes: independent deflate runs between flush points), read by the chunked many-core
+            # reader (host/fq_pgzip.h) and, for comparison, by one zlib thread as the reference reads it
+            try:
+                gz = path + ".1member.gz"
+                n_gz = min(n, 10_000_000)
+                t0 = time.perf_counter()
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--gz-helper", path, gz, str(n_gz * R)], check=True)
+                made = time.perf_counter() - t0
+                leg = {"reads": n_gz, "inflated_GB": n_gz * R / 1e9, "compressed_GB": os.path.getsize(gz) / 1e9, "made_in_s": made,
+                       "what": "the first reads of the same file as a single-member .gz (deflate level 1, flush points every 32 MiB "
+                               "as pigz makes them) in tmpfs, through bin/fastq_info -r: chunks of the compressed bytes inflated side "
+                               "by side (block starts searched for, 32 KiB windows resolved afterwards), then by one zlib thread"}
+                for label, env in (("by_chunks", {}), ("one_zlib_thread", {"FQGPU_NO_PARALLEL_INFLATE": "1"})):
+                    t0 = time.perf_counter()
+                    p = subprocess.run([exe, "-r", gz], capture_output=True, env=dict(os.environ, FQGPU_TIMING="1", **env))
+                    dt = time.perf_counter() - t0
+                    leg[label] = {"seconds": dt, "Mreads_per_s": n_gz / dt / 1e6, "inflated_GBps": n_gz * R / dt / 1e9,
+                                  "ok": p.returncode == 0 and ("Number of reads: %d" % n_gz).encode() in p.stderr,
+                                  "says": [ln[ln.find("fqgpu timing"):] for ln in p.stderr.decode("latin-1").splitlines()
+                                           if "inflated by chunks" in ln or "pieces" in ln]}
+                leg["speedup"] = leg["one_zlib_thread"]["seconds"] / leg["by_chunks"]["seconds"]
+                out["cli_fastq_info_r_gz_file"] = leg
+            except Exception as e:
+                out["cli_fastq_info_r_gz_file"] = {"error": repr(e)[:300]}
+            finally:
+                if os.path.exists(path + ".1member.gz"):
+                    os.unlink(path + ".1member.gz")
             out["cli_fastq_info_r_tmpfs_file"] = {
                 "seconds_median_of_3": med, "seconds": runs, "Mreads_per_s": n / med / 1e6, "GBps": nbytes / med / 1e9,
                 "stager": f"3 pinned slots of 128 MiB, a pool of {threads} pread threads (FQGPU_CHUNK_MB / FQGPU_HOST_THREADS)",
@@ -572,6 +601,62 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
     else:
         out["cli_fastq_info_r_tmpfs_file"] = {"skipped": "no bin/fastq_info or not enough room in /dev/shm"}
     return out
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """CRC-32 of A + B from crc32(A), crc32(B) and len(B): crc1 pushed through len2 zero bytes - the operator for one
+    zero bit, squared as often as len2 has binary digits - then xor crc2 (what zlib's crc32_combine computes)"""
+    def times(mat, vec):
+        acc, i = 0, 0
+        while vec:
+            if vec & 1:
+                acc ^= mat[i]
+            vec >>= 1
+            i += 1
+        return acc
+
+    if len2 <= 0:
+        return crc1
+    op = [0xEDB88320] + [1 << k for k in range(31)]  # one zero bit
+    for _ in range(3):
+        op = [times(op, op[k]) for k in range(32)]  # ... two, four, eight bits: one zero byte
+    while len2:
+        if len2 & 1:
+            crc1 = times(op, crc1)
+        len2 >>= 1
+        if len2:
+            op = [times(op, op[k]) for k in range(32)]
+    return crc1 ^ crc2
+
+
+def _gz_slice(args):
+    import zlib
+
+    path, a, b, last = args
+    with open(path, "rb") as f:
+        f.seek(a)
+        data = f.read(b - a)
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    blob = c.compress(data) + (c.flush() if last else c.flush(zlib.Z_SYNC_FLUSH))
+    return blob, zlib.crc32(data) & 0xFFFFFFFF, len(data)
+
+
+def gz_compress_file(src, dst, nbytes):
+    """the first nbytes of src as ONE gzip member, deflated by a pool of processes the way pigz does it: every slice an
+    independent run of deflate blocks that ends in a flush point, the slices back to back, one trailer"""
+    import struct
+    from concurrent.futures import ProcessPoolExecutor
+
+    step = 32 << 20
+    tasks = [(src, a, min(nbytes, a + step), a + step >= nbytes) for a in range(0, nbytes, step)]
+    crc, total = 0, 0
+    with ProcessPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex, open(dst, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+        for blob, c, ln in ex.map(_gz_slice, tasks, chunksize=1):
+            f.write(blob)
+            crc = _crc32_combine(crc, c, ln) if total else c
+            total += ln
+        f.write(struct.pack("<II", crc, total & 0xFFFFFFFF))
 
 
 def _bgzf_slice(args):
@@ -1044,6 +1129,9 @@ def launch_ranks(n_gpus):
 
 def main():
     a = parse()
+    if a.gz_helper:
+        gz_compress_file(a.gz_helper[0], a.gz_helper[1], int(a.gz_helper[2]))
+        return
     if a.bgzf_helper:
         bgzf_compress_file(*a.bgzf_helper)
         return

@@ -43,8 +43,50 @@
 
 #include "fq_parallel.h"
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
 namespace fqhost {
 namespace pgz {
+
+// CRC-32 (the gzip polynomial, reflected: 0xEDB88320) sixteen bytes per step from sixteen tables - zlib 1.2.11's
+// crc32 goes four bytes per step (1 GB/s per core where this gives 3), and every inflated byte passes through it.
+// Same function as zlib's: crc32(crc, p, n) == crc32_16(crc, p, n) (tests/cxx/pgzip_check.cpp compares them).
+struct Crc32Tables {
+  uint32_t t[16][256];
+  Crc32Tables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int k = 1; k < 16; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFFu];
+  }
+};
+inline uint32_t crc32_16(uint32_t crc, const uint8_t* p, size_t n) {
+  static const Crc32Tables T;
+  crc = ~crc;
+  while (n && (reinterpret_cast<uintptr_t>(p) & 7u)) {
+    crc = (crc >> 8) ^ T.t[0][(crc ^ *p++) & 0xFFu];
+    --n;
+  }
+  while (n >= 16) {
+    uint64_t a, b;
+    memcpy(&a, p, 8);
+    memcpy(&b, p + 8, 8);
+    a ^= crc;
+    crc = T.t[15][a & 0xFFu] ^ T.t[14][(a >> 8) & 0xFFu] ^ T.t[13][(a >> 16) & 0xFFu] ^ T.t[12][(a >> 24) & 0xFFu] ^
+          T.t[11][(a >> 32) & 0xFFu] ^ T.t[10][(a >> 40) & 0xFFu] ^ T.t[9][(a >> 48) & 0xFFu] ^ T.t[8][a >> 56] ^
+          T.t[7][b & 0xFFu] ^ T.t[6][(b >> 8) & 0xFFu] ^ T.t[5][(b >> 16) & 0xFFu] ^ T.t[4][(b >> 24) & 0xFFu] ^
+          T.t[3][(b >> 32) & 0xFFu] ^ T.t[2][(b >> 40) & 0xFFu] ^ T.t[1][(b >> 48) & 0xFFu] ^ T.t[0][b >> 56];
+    p += 16;
+    n -= 16;
+  }
+  while (n--) crc = (crc >> 8) ^ T.t[0][(crc ^ *p++) & 0xFFu];
+  return ~crc;
+}
 
 constexpr uint32_t kWin = 32768;
 constexpr size_t kSlack = 64;  // readable (zero) bytes behind the valid compressed bytes
@@ -503,7 +545,8 @@ inline uint64_t find_block(const uint8_t* base, size_t nvalid, uint64_t from, ui
 class ParallelGunzip {
  public:
   ParallelGunzip(int fd, uint64_t file_size, std::string path, unsigned threads, size_t chunk_bytes)
-      : fd_(fd), size_(file_size), path_(std::move(path)), threads_(std::max(1u, threads)), chunk_(std::max<size_t>(chunk_bytes, 4096)) {}
+      : fd_(fd), size_(file_size), path_(std::move(path)), threads_(std::max(1u, threads)), chunk_(std::max<size_t>(chunk_bytes, 4096)),
+        pool_threads_(threads_) {}
   ~ParallelGunzip() {
     if (zs_live_) inflateEnd(&zs_);
     free(cbuf_);
@@ -524,9 +567,12 @@ class ParallelGunzip {
   size_t read(char* dst, size_t want, bool* at_end) {
     size_t len = 0;
     while (len < want && !failed_) {
-      if (ready_at_ < ready_.size()) {
-        const size_t n = std::min(want - len, ready_.size() - ready_at_);
-        memcpy(dst + len, ready_.data() + ready_at_, n);
+      if (ready_at_ < ready_n_) {
+        const size_t n = std::min(want - len, ready_n_ - ready_at_);
+        const unsigned T = (unsigned)std::min<size_t>(pool_threads_.size(), std::max<size_t>(1, n >> 22));
+        char* to = dst + len;
+        const char* from = ready_.get() + ready_at_;
+        pool_threads_.run(T, [&](unsigned t) { memcpy(to + n * t / T, from + n * t / T, n * (t + 1) / T - n * t / T); });
         ready_at_ += n;
         len += n;
         continue;
@@ -535,7 +581,7 @@ class ParallelGunzip {
       if (serial_) len += serial_read(dst + len, want - len);
       else len += batch(dst + len, want - len);
     }
-    if (done_ && ready_at_ >= ready_.size()) *at_end = true;
+    if (done_ && ready_at_ >= ready_n_) *at_end = true;
     return len;
   }
 
@@ -569,14 +615,23 @@ class ParallelGunzip {
         return false;
       }
     }
-    size_t done = 0;
-    while (done < n) {
-      const ssize_t got = pread(fd_, cbuf_ + done, n - done, (off_t)(coff_ + done));
-      if (got <= 0) {
-        fail("read error");
-        return false;
+    const unsigned T = (unsigned)std::min<size_t>(pool_threads_.size(), std::max<size_t>(1, n >> 20));
+    std::atomic<bool> bad{false};
+    pool_threads_.run(T, [&](unsigned t) {  // (a tmpfs or page-cache file is copied, not waited for: every thread its share)
+      const size_t a = (n * t / T) & ~(size_t)4095, b = t + 1 == T ? n : (n * (t + 1) / T) & ~(size_t)4095;
+      size_t done = a;
+      while (done < b) {
+        const ssize_t got = pread(fd_, cbuf_ + done, b - done, (off_t)(coff_ + done));
+        if (got <= 0) {
+          bad = true;
+          return;
+        }
+        done += (size_t)got;
       }
-      done += (size_t)got;
+    });
+    if (bad) {
+      fail("read error");
+      return false;
     }
     memset(cbuf_ + n, 0, pgz::kSlack);
     cn_ = n;
@@ -628,7 +683,7 @@ class ParallelGunzip {
     std::atomic<bool> oom{false};
     const auto t_loaded = now();
     stats_.s_load += secs(t_start, t_loaded);
-    parallel_items(K, [&](size_t k) {
+    pool_threads_.run(K, [&](unsigned k) {
       ChunkState& c = *cs[k];
       Inflate16 dec;
       const uint64_t stop = k + 1 < K ? start_of((unsigned)k + 1) : ~0ull;
@@ -758,9 +813,13 @@ class ParallelGunzip {
       total += cs[joined[q]]->out.pos - kWin;
     }
     const size_t direct = std::min(room, total);
-    ready_.resize(total - direct);
+    if (total - direct > ready_cap_) {  // (never zero-filled: every byte is written below)
+      ready_cap_ = total - direct + (total - direct) / 4;
+      ready_.reset(new char[ready_cap_]);
+    }
+    ready_n_ = total - direct;
     ready_at_ = 0;
-    parallel_items(use, [&](size_t q) {
+    if (use) pool_threads_.run((unsigned)use, [&](unsigned q) {
       const ChunkState& c = *cs[joined[q]];
       Part& p = parts[q];
       uint8_t lut_win[kWin];
@@ -780,18 +839,11 @@ class ParallelGunzip {
             out = dst + o;
             m = std::min(b - i, direct - o);
           } else {
-            out = ready_.data() + (o - direct);
+            out = ready_.get() + (o - direct);
             m = b - i;
           }
           narrow(c.out.d + i, m, lut_win, reinterpret_cast<uint8_t*>(out));
-          size_t left = m;
-          const Bytef* cp = reinterpret_cast<const Bytef*>(out);
-          while (left) {
-            const uInt step = (uInt)std::min<size_t>(left, 1u << 30);
-            crc = (uint32_t)crc32(crc, cp, step);
-            cp += step;
-            left -= step;
-          }
+          crc = crc32_16(crc, reinterpret_cast<const uint8_t*>(out), m);
           i += m;
           o += m;
         }
@@ -817,7 +869,7 @@ class ParallelGunzip {
       }
     }
     if (failed_) {
-      ready_.clear();
+      ready_n_ = 0;
       return 0;
     }
     stats_.chunks_joined += use;
@@ -864,6 +916,20 @@ class ParallelGunzip {
   }
   static void narrow(const uint16_t* s, size_t n, const uint8_t* win, uint8_t* out) {
     size_t i = 0;
+#if defined(__SSE2__)
+    for (; i + 16 <= n; i += 16) {  // sixteen symbols: bytes as they are when none of them is a marker
+      const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+      const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 8));
+      if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_srli_epi16(_mm_or_si128(a, b), 8), _mm_setzero_si128())) == 0xFFFF) {
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + i), _mm_packus_epi16(a, b));
+      } else {
+        for (int k = 0; k < 16; ++k) {
+          const uint16_t v = s[i + k];
+          out[i + k] = v < 256 ? (uint8_t)v : win[v & 0x7FFFu];
+        }
+      }
+    }
+#endif
     for (; i + 16 <= n; i += 16) {
       uint16_t any = 0;
       for (int k = 0; k < 16; ++k) any |= s[i + k];
@@ -1030,8 +1096,9 @@ class ParallelGunzip {
   uint64_t member_len_ = 0;
   uint8_t* cbuf_ = nullptr;
   size_t cbuf_cap_ = 0, cn_ = 0;
-  std::vector<char> ready_;
-  size_t ready_at_ = 0;
+  std::unique_ptr<char[]> ready_;
+  size_t ready_n_ = 0, ready_cap_ = 0, ready_at_ = 0;
+  ReaderPool pool_threads_;
   std::vector<std::unique_ptr<pgz::ChunkState>> pool_;
   std::string error_;
   Stats stats_;

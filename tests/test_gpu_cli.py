@@ -43,6 +43,50 @@ def test_all_golden_invocations():
     assert not bad, f"{len(bad)} of {len(GOLDEN)} differ; first: {bad[:3]}"
 
 
+CHUNKED = {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "4096", "FQGPU_HOST_THREADS": "3"}
+
+
+def test_all_golden_invocations_with_gzip_input_inflated_by_chunks():
+    """the goldens' inputs are .fastq.gz files: the same invocations with every one of them read by the many-core gzip
+    reader (host/fq_pgzip.h; files this small are one zlib thread's otherwise), in chunks of 4 KiB"""
+    def one(case):
+        rc, out, err = run_cli(case["args"], GOLD, CHUNKED)
+        ok = (rc == case["exit"] and out == case["stdout"]
+              and strip_progress(err) == strip_progress(case["stderr"]))
+        return None if ok else (case["args"], rc, case["exit"], err[-400:], case["stderr"][-400:])
+
+    with ThreadPoolExecutor(8) as ex:
+        bad = [b for b in ex.map(one, GOLDEN) if b]
+    assert not bad, f"{len(bad)} of {len(GOLDEN)} differ; first: {bad[:3]}"
+
+
+def test_gzip_files_of_many_chunks_in_every_mode():
+    """paired files of 30 000 reads as .gz (levels 1 and 9, one of them of three members): dozens of chunks of 64 KiB per
+    file, pieces of 1 MiB on the GPU side; all modes against the oracle, and the timing line must say that the chunks
+    were found and joined"""
+    import gzip
+
+    with tempfile.TemporaryDirectory() as tmp:
+        a = fuzz.make_fastq(np.random.default_rng(1), 30000, 50, 150, "casava", mate=1)
+        b = fuzz.make_fastq(np.random.default_rng(1), 30000, 50, 150, "casava", mate=2)
+        dup = a + b"\n".join(a.split(b"\n")[4 * 123:4 * 123 + 4]) + b"\n"
+        files = {"a.fastq.gz": a, "b.fastq.gz": b, "d.fastq.gz": dup}
+        third = len(b) // 3
+        packed = {"a.fastq.gz": gzip.compress(a, 9), "d.fastq.gz": gzip.compress(dup, 1),
+                  "b.fastq.gz": gzip.compress(b[:third], 6) + gzip.compress(b[third:2 * third], 1) + gzip.compress(b[2 * third:], 6)}
+        for name, blob in packed.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(blob)
+        env = {"FQGPU_CHUNK_MB": "1", "FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "65536", "FQGPU_HOST_THREADS": "4"}
+        for args in (["-r", "a.fastq.gz"], ["a.fastq.gz"], ["a.fastq.gz", "b.fastq.gz"], ["d.fastq.gz"], ["-s", "a.fastq.gz", "b.fastq.gz"]):
+            compare_with_oracle(tmp, args, files, env)
+        rc, out, err = run_cli(["-r", "b.fastq.gz"], tmp, dict(env, FQGPU_TIMING="1"))
+        line = [ln for ln in err.splitlines() if "inflated by chunks" in ln]
+        assert rc == 0 and line and " 3 members" in line[0] and "one zlib stream" not in line[0], err[-800:]
+        joined = int(line[0].split(" chunks joined")[0].split()[-1])
+        assert joined >= 20, line[0]
+
+
 def oracle_run(args, files):
     flags, pos = orc.parse_args(args)
     if len(pos) == 1:
@@ -177,7 +221,7 @@ def _overlong():
     return overlong_images()
 
 
-@pytest.mark.parametrize("how", ["plain_file", "gz_file", "small_pieces", "several_devices"])
+@pytest.mark.parametrize("how", ["plain_file", "gz_file", "gz_file_by_chunks", "small_pieces", "several_devices"])
 @pytest.mark.parametrize("which", sorted(_overlong()))
 def test_lines_beyond_the_gzgets_buffers(which, how):
     """A line beyond the reference's gzgets buffers (src/fastq.c:249-253: 1000 bytes for the header lines, 2 500 000 for
@@ -190,11 +234,12 @@ def test_lines_beyond_the_gzgets_buffers(which, how):
     import gzip
 
     img = _overlong()[which]
-    env = {"small_pieces": {"FQGPU_CHUNK_MB": "1"}, "several_devices": {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"}}.get(how)
-    name = "f.fastq.gz" if how == "gz_file" else "f.fastq"
+    env = {"small_pieces": {"FQGPU_CHUNK_MB": "1"}, "several_devices": {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"},
+           "gz_file_by_chunks": dict(CHUNKED, FQGPU_PGZIP_CHUNK="30000")}.get(how)
+    name = "f.fastq.gz" if how.startswith("gz_file") else "f.fastq"
     with tempfile.TemporaryDirectory() as tmp:
         with open(os.path.join(tmp, name), "wb") as f:
-            f.write(gzip.compress(img, 1) if how == "gz_file" else img)
+            f.write(gzip.compress(img, 1) if how.startswith("gz_file") else img)
         for args in (["-r", name], [name], [name, "pe"], ["-r", "-s", name, name], [name, name]):
             rc, out, err = run_cli(args, tmp, env)
             want = oracle_run(args, {name: img})
