@@ -149,6 +149,28 @@ inline uint64_t pgzip_min_bytes() {
   return 1u << 20;
 }
 
+// The many-core reader for the gzip file open on fd (fq_pgzip.h), or nothing when one zlib thread is to read it: small
+// files, a single usable core, FQGPU_NO_PARALLEL_INFLATE.  (What that reader does not want to decide it leaves to one
+// zlib stream of its own, so every file gzopen reads is read.)
+inline std::unique_ptr<ParallelGunzip> open_pgzip(int fd, uint64_t size, const char* path) {
+  if (size < pgzip_min_bytes() || host_threads() <= 1 || getenv("FQGPU_NO_PARALLEL_INFLATE")) return nullptr;
+  const unsigned T = std::min(host_threads(), 64u);
+  // (tools/pgzip_scan.sh on the 16-core share of an EPYC 9575F: 2.6 / 3.0 / 3.5 GB/s inflated with chunks of 1 / 2 / 4 MiB)
+  size_t chunk = std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (128u << 20) / T));
+  chunk = std::min<size_t>(chunk, std::max<size_t>((size_t)size / T, 128u << 10));
+  if (const char* e = getenv("FQGPU_PGZIP_CHUNK")) chunk = (size_t)std::max(4096L, atol(e));
+  return std::unique_ptr<ParallelGunzip>(new ParallelGunzip(fd, size, path, T, chunk));
+}
+inline void pgzip_report(const ParallelGunzip* pg, const std::string& path) {
+  if (!pg || !(getenv("FQGPU_PGZIP_DEBUG") || getenv("FQGPU_TIMING"))) return;
+  const ParallelGunzip::Stats& st = pg->stats();
+  fprintf(stderr, "fqgpu timing: %s inflated by chunks: %llu rounds, %llu chunks joined, %llu without a block start, %llu wrong guesses, "
+          "%llu members%s%s; reading %.3f s, finding + inflating %.3f s, joining %.3f s, markers -> bytes + CRC-32 %.3f s\n",
+          path.c_str(), (unsigned long long)st.batches, (unsigned long long)st.chunks_joined, (unsigned long long)st.chunks_not_found,
+          (unsigned long long)st.chunks_discarded, (unsigned long long)st.members, st.fell_back ? "; one zlib stream from: " : "",
+          st.fell_back ? st.why.c_str() : "", st.s_load, st.s_decode, st.s_join + st.s_windows, st.s_narrow);
+}
+
 class Input {
  public:
   Input(fqg_ctx* ctx, const char* path, size_t piece_bytes) : ctx_(ctx), path_(path), cap_(piece_bytes) {
@@ -170,16 +192,8 @@ class Input {
           // inflated on all cores (read_bgzf below) instead of by one zlib thread
           bgzf_fd_ = fd;
           bgzf_size_ = (uint64_t)sb.st_size;
-        } else if ((uint64_t)sb.st_size >= pgzip_min_bytes() && host_threads() > 1 && !getenv("FQGPU_NO_PARALLEL_INFLATE")) {
-          // any other gzip file of some size: chunks of it are inflated side by side (fq_pgzip.h); what that reader
-          // does not want to decide it leaves to one zlib stream, so every file gzopen reads is read
-          const unsigned T = std::min(host_threads(), 64u);
-          // (tools/pgzip_scan.sh on the 16-core share of an EPYC 9575F: 2.6 / 3.0 / 3.5 GB/s inflated with chunks of 1 / 2 / 4 MiB)
-          size_t chunk = std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (128u << 20) / T));
-          chunk = std::min<size_t>(chunk, std::max<size_t>((size_t)sb.st_size / T, 128u << 10));
-          if (const char* e = getenv("FQGPU_PGZIP_CHUNK")) chunk = (size_t)std::max(4096L, atol(e));
-          pgz_fd_ = fd;
-          pgz_.reset(new ParallelGunzip(fd, (uint64_t)sb.st_size, path, T, chunk));
+        } else if ((pgz_ = open_pgzip(fd, (uint64_t)sb.st_size, path))) {
+          pgz_fd_ = fd;  // any other gzip file of some size: chunks of it are inflated side by side
         }
       }
       if (plain_fd_ < 0 && bgzf_fd_ < 0 && pgz_fd_ < 0) {
@@ -210,14 +224,7 @@ class Input {
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     if (bgzf_fd_ >= 0) close(bgzf_fd_);
-    if (pgz_ && (getenv("FQGPU_PGZIP_DEBUG") || getenv("FQGPU_TIMING"))) {
-      const ParallelGunzip::Stats& st = pgz_->stats();
-      fprintf(stderr, "fqgpu timing: %s inflated by chunks: %llu rounds, %llu chunks joined, %llu without a block start, %llu wrong guesses, "
-              "%llu members%s%s; reading %.3f s, finding + inflating %.3f s, joining %.3f s, markers -> bytes + CRC-32 %.3f s\n",
-              path_.c_str(), (unsigned long long)st.batches, (unsigned long long)st.chunks_joined, (unsigned long long)st.chunks_not_found,
-              (unsigned long long)st.chunks_discarded, (unsigned long long)st.members, st.fell_back ? "; one zlib stream from: " : "",
-              st.fell_back ? st.why.c_str() : "", st.s_load, st.s_decode, st.s_join + st.s_windows, st.s_narrow);
-    }
+    pgzip_report(pgz_.get(), path_);
     pgz_.reset();
     if (pgz_fd_ >= 0) close(pgz_fd_);
     free(bz_raw_);

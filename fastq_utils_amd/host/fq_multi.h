@@ -39,17 +39,19 @@ class AlignedPieces {
       if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
         unsigned char magic[2] = {0, 0};
         const ssize_t got = pread(fd, magic, 2, 0);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+          if ((pgz_ = open_pgzip(fd, (uint64_t)sb.st_size, path))) pgz_fd_ = fd;  // inflated on many cores (fq_pgzip.h)
+        } else {
           plain_fd_ = fd;
           plain_size_ = std::min<uint64_t>((uint64_t)sb.st_size, limit_);
         }
       }
-      if (plain_fd_ < 0) {
+      if (plain_fd_ < 0 && pgz_fd_ < 0) {
         if (fd >= 0) close(fd);
         gz_ = gzopen(path, "r");
       }
     }
-    if (!gz_ && plain_fd_ < 0) {
+    if (!gz_ && plain_fd_ < 0 && pgz_fd_ < 0) {
       FQ_PRINT_ERROR("Unable to open %s", path);
       fqhost::leave(kExitParams);
     }
@@ -65,6 +67,9 @@ class AlignedPieces {
     if (producer_.joinable()) producer_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
+    pgzip_report(pgz_.get(), path_);
+    pgz_.reset();
+    if (pgz_fd_ >= 0) close(pgz_fd_);
     for (auto& s : slots_) slot_release(ctx_, s.buf);
   }
   // next piece in file order; false when the file is exhausted.  Thread-safe.
@@ -142,7 +147,14 @@ class AlignedPieces {
       return len;
     }
     want = (size_t)std::min<uint64_t>(want, limit_ - gz_total_);
-    while (len < want) {
+    if (pgz_) {
+      len = pgz_->read(dst, want, at_end);
+      if (pgz_->failed()) {
+        fail(pgz_->error().c_str());
+        return len;
+      }
+    }
+    while (!pgz_ && len < want) {
       const int got = gzread(gz_, dst + len, (unsigned)std::min<size_t>(want - len, 1u << 30));
       if (got < 0) {
         int en = 0;
@@ -157,7 +169,7 @@ class AlignedPieces {
     }
     gz_total_ += len;
     if (gz_total_ >= limit_) *at_end = true;
-    if (!*at_end) {
+    if (!*at_end && !pgz_) {
       const int c = gzgetc(gz_);
       if (c < 0) *at_end = true;
       else gzungetc(c, gz_);
@@ -283,6 +295,8 @@ class AlignedPieces {
   fqg_ctx* ctx_;
   std::string path_;
   gzFile gz_ = nullptr;
+  int pgz_fd_ = -1;  // a gzip file inflated on many cores (fq_pgzip.h)
+  std::unique_ptr<ParallelGunzip> pgz_;
   int plain_fd_ = -1;
   uint64_t plain_size_ = 0, plain_off_ = 0;
   size_t cap_;

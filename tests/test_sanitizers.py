@@ -151,10 +151,14 @@ def test_record_aligned_piece_cutter_runs_clean(tmpdir, san):
         size = len(data if name.endswith(".gz") else content)
         for piece in ("512", "4096", "100000", "50000000"):
             for consumers in ("1", "3"):
-                p = subprocess.run([exe, str(tmpdir / name), piece, consumers],
-                                   env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"), capture_output=True, timeout=300)
-                out = p.stdout.decode().split()
-                assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, piece, consumers, p.stdout, p.stderr.decode()[-1500:])
+                # (a .gz once more through the many-core gzip reader, fq_pgzip.h, in chunks of 20 kB: files this small are
+                # one zlib thread's otherwise)
+                for extra in ({}, {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "20000", "FQGPU_PGZIP_DEBUG": "1"}) if name.endswith(".gz") else ({},):
+                    p = subprocess.run([exe, str(tmpdir / name), piece, consumers],
+                                       env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1", **extra), capture_output=True, timeout=300)
+                    out = p.stdout.decode().split()
+                    assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, piece, consumers, p.stdout, p.stderr.decode()[-1500:])
+                    assert (b"inflated by chunks" in p.stderr) == bool(extra), p.stderr.decode()[-500:]
 
 
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
@@ -182,7 +186,9 @@ def test_record_block_cutter_runs_clean(tmpdir, san):
             if per_block in ("1", "7") and size > 100000:
                 continue
             for consumers in ("1", "3"):
-                p = subprocess.run([exe, str(tmpdir / name), per_block, consumers],
-                                   env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1"), capture_output=True, timeout=300)
-                out = p.stdout.decode().split()
-                assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, per_block, consumers, p.stdout, p.stderr.decode()[-1500:])
+                for extra in ({}, {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "20000", "FQGPU_PGZIP_DEBUG": "1"}) if name.endswith(".gz") else ({},):
+                    p = subprocess.run([exe, str(tmpdir / name), per_block, consumers],
+                                       env=dict(ENV, FQGPU_HOST_THREADS="3", TSAN_OPTIONS="halt_on_error=1", **extra), capture_output=True, timeout=300)
+                    out = p.stdout.decode().split()
+                    assert p.returncode == 0 and out[-1] == "ok" and int(out[1]) == size, (name, per_block, consumers, p.stdout, p.stderr.decode()[-1500:])
+                    assert (b"inflated by chunks" in p.stderr) == bool(extra), p.stderr.decode()[-500:]
