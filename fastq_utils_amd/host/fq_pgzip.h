@@ -561,6 +561,7 @@ class ParallelGunzip {
     bool fell_back = false, truncated = false;
     std::string why;
     double s_load = 0, s_decode = 0, s_join = 0, s_windows = 0, s_narrow = 0, s_serial = 0;  // seconds per phase
+    double t_decode_sum = 0, t_decode_max = 0, t_narrow_sum = 0, t_narrow_max = 0;  // thread seconds inside two of them (max: summed per round)
   };
   const Stats& stats() const { return stats_; }
 
@@ -683,7 +684,14 @@ class ParallelGunzip {
     std::atomic<bool> oom{false};
     const auto t_loaded = now();
     stats_.s_load += secs(t_start, t_loaded);
+    std::vector<double> tsec(K, 0.0);
     pool_threads_.run(K, [&](unsigned k) {
+      const auto t_in = now();
+      struct Tick {
+        double& d;
+        std::chrono::steady_clock::time_point t0;
+        ~Tick() { d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+      } tick{tsec[k], t_in};
       ChunkState& c = *cs[k];
       Inflate16 dec;
       const uint64_t stop = k + 1 < K ? start_of((unsigned)k + 1) : ~0ull;
@@ -723,6 +731,14 @@ class ParallelGunzip {
     // ---- join, in file order ----
     const auto t_decoded = now();
     stats_.s_decode += secs(t_loaded, t_decoded);
+    {
+      double mx = 0;
+      for (double v : tsec) {
+        stats_.t_decode_sum += v;
+        mx = std::max(mx, v);
+      }
+      stats_.t_decode_max += mx;
+    }
     std::vector<unsigned> joined{0};
     Inflate16 dec;
     unsigned cur = 0;
@@ -819,7 +835,13 @@ class ParallelGunzip {
     }
     ready_n_ = total - direct;
     ready_at_ = 0;
+    std::vector<double> nsec(use + 1, 0.0);
     if (use) pool_threads_.run((unsigned)use, [&](unsigned q) {
+      struct Tick {
+        double& d;
+        std::chrono::steady_clock::time_point t0;
+        ~Tick() { d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+      } tick{nsec[q], std::chrono::steady_clock::now()};
       const ChunkState& c = *cs[joined[q]];
       Part& p = parts[q];
       uint8_t lut_win[kWin];
@@ -853,6 +875,14 @@ class ParallelGunzip {
       }
     });
     stats_.s_narrow += secs(t_windows, now());
+    {
+      double mx = 0;
+      for (double v : nsec) {
+        stats_.t_narrow_sum += v;
+        mx = std::max(mx, v);
+      }
+      stats_.t_narrow_max += mx;
+    }
     // ---- members' checks, in file order ----
     for (size_t q = 0; q < use && !failed_; ++q) {
       const ChunkState& c = *cs[joined[q]];

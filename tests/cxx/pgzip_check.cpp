@@ -75,9 +75,9 @@ int main(int argc, char** argv) {
   const auto t2 = std::chrono::steady_clock::now();
   const fqhost::ParallelGunzip::Stats& s = pg.stats();
   if (timing_only) {
-    printf("timing bytes=%zu threads=%u chunk=%zu in_read=%.3f GBps=%.2f (load %.2f decode %.2f join %.2f windows %.2f narrow %.2f) joined=%llu fell_back=%d\n",
+    printf("timing bytes=%zu threads=%u chunk=%zu in_read=%.3f GBps=%.2f (load %.2f decode %.2f join %.2f windows %.2f narrow %.2f) joined=%llu fell_back=%d | thread seconds: decode sum %.2f slowest %.2f, narrow sum %.2f slowest %.2f\n",
            total_timing, threads, chunk, in_read, total_timing / in_read / 1e9, s.s_load, s.s_decode, s.s_join, s.s_windows, s.s_narrow,
-           (unsigned long long)s.chunks_joined, s.fell_back ? 1 : 0);
+           (unsigned long long)s.chunks_joined, s.fell_back ? 1 : 0, s.t_decode_sum, s.t_decode_max, s.t_narrow_sum, s.t_narrow_max);
     return 0;
   }
   // (the reader sums CRC-32 with a routine of its own: it must be zlib's function, at every alignment and length)

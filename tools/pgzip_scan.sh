@@ -5,6 +5,7 @@ set -e
 out=${1:-gpurun_out/pgzip_scan}
 mkdir -p $out
 g++ -O2 -std=c++17 -o $out/pgzip_check tests/cxx/pgzip_check.cpp -lz -pthread
+g++ -O2 -std=c++17 -o $out/pgzip_parts tools/kbench/pgzip_parts.cpp -lz -pthread
 python3 - "$out" <<'PY'
 import sys, numpy as np
 out = sys.argv[1]
@@ -31,8 +32,9 @@ ls -la /dev/shm/pgzip_scan.fastq
 python3 bench.py --gz-helper /dev/shm/pgzip_scan.fastq /dev/shm/pgzip_scan.gz $(stat -c %s /dev/shm/pgzip_scan.fastq)
 ls -la /dev/shm/pgzip_scan.gz
 nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null || true
-$out/pgzip_check /dev/shm/pgzip_scan.gz 16 2097152 134217728 2>&1 | tee $out/scan.txt
-for t in 4 8 16 32 64; do for c in 1048576 2097152 4194304; do
+$out/pgzip_parts /dev/shm/pgzip_scan.gz 2>&1 | tee $out/scan.txt
+$out/pgzip_check /dev/shm/pgzip_scan.gz 16 2097152 134217728 2>&1 | tee -a $out/scan.txt
+for t in 1 16 32; do for c in 2097152 4194304; do
   $out/pgzip_check /dev/shm/pgzip_scan.gz $t $c 134217728 timing 2>&1 | tee -a $out/scan.txt
 done; done
 rm -f /dev/shm/pgzip_scan.fastq /dev/shm/pgzip_scan.gz
