@@ -1006,6 +1006,28 @@ class ParallelGunzip {
     }
     size_t len = 0;
     while (len < want && !done_ && !failed_) {
+      if (transparent_) {
+        if (s_at_ < s_n_) {
+          const size_t m = std::min(want - len, s_n_ - s_at_);
+          memcpy(dst + len, sbuf_.data() + s_at_, m);
+          s_at_ += m;
+          len += m;
+          continue;
+        }
+        if (coff_ >= size_) {
+          done_ = true;
+          break;
+        }
+        const size_t n = (size_t)std::min<uint64_t>(want - len, size_ - coff_);
+        const ssize_t got = pread(fd_, dst + len, n, (off_t)coff_);
+        if (got <= 0) {
+          fail("read error");
+          break;
+        }
+        coff_ += (uint64_t)got;
+        len += (size_t)got;
+        continue;
+      }
       if (s_at_ == s_n_) {
         const size_t n = (size_t)std::min<uint64_t>(sbuf_.size(), size_ - coff_);
         if (n) {
@@ -1038,7 +1060,14 @@ class ParallelGunzip {
         }
         const long hl = gzip_header_len(hdr.data(), hdr.size());
         if (hl == -1) {
-          if (first_member_) fail("not in gzip format");
+          if (first_member_) {  // no gzip file at all: gzread hands out the bytes as they are
+            transparent_ = true;
+            sbuf_.assign(hdr.begin(), hdr.end());
+            s_at_ = 0;
+            s_n_ = hdr.size();
+            if (sbuf_.size() < (1u << 20)) sbuf_.resize(1u << 20);
+            continue;
+          }
           done_ = true;  // trailing garbage
           break;
         }
@@ -1118,7 +1147,7 @@ class ParallelGunzip {
   size_t chunk_;
   // where the next byte comes from: file offset of the window's first byte, bit in it, inside a member or in front of a header
   uint64_t coff_ = 0, bit0_ = 0;
-  bool in_member_ = false, first_member_ = true, done_ = false, serial_ = false, failed_ = false;
+  bool in_member_ = false, first_member_ = true, done_ = false, serial_ = false, failed_ = false, transparent_ = false;
   uint8_t win_[pgz::kWin];  // the last win_n_ inflated bytes
   size_t win_n_ = 0;
   std::vector<uint8_t> next_win_;

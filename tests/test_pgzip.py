@@ -213,6 +213,18 @@ def test_other_kinds_of_content(check, tmp_path):
                 assert int(st["bytes"]) == len(data), (name, line)
 
 
+def test_files_that_are_no_gzip_files_come_out_as_they_are(check, tmp_path):
+    # (zlib's gzread is transparent for them; the programs never send such a file here - they look at the magic first)
+    data = text(3000, 14)
+    raw = bytearray(gzip.compress(data, 6))
+    raw[1] ^= 0x10
+    f = tmp_path / "p"
+    for blob in (b"plain text\n" * 100000, b"\x1f", b"", bytes(raw), data):
+        f.write_bytes(blob)
+        rc, line, st = run(check, f, 4, 30000)
+        assert rc == 0 and int(st["bytes"]) == len(blob), line
+
+
 def test_a_reference_in_front_of_the_members_first_byte(check, tmp_path):
     # a second member whose first block copies from "before the member": zlib says "invalid distance too far back"
     data = text(3000, 12)

@@ -90,6 +90,71 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, 0, counts, n_tiles, local, spans);
     hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, 0, spans, n_spans, img, n, cs);
     report("k_stream_pass2", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_pass2, dim3((n_tiles + 31) / 32), dim3(kBlock), 0, 0, img, n, n_tiles, counts, cinfo, stage, local, spans, line_end, 4 * reads + 32, 4 * reads, sm, redo, cs); }));
+    {
+      // Does the second framing pass overlap with pass 1 when the two run on streams of their own?  (pass 1 is bound by
+      // vector-ALU cycles, k_stream_lines_fast by memory latency - but pass 1 fills every wave slot and most of the LDS.)
+      // The arrays the line kernel reads are those of the run above; the pass 1 beside it writes to a second set.
+      uint32_t *counts2, *cinfo2; uint16_t* stage2;
+      CK(hipMalloc(&counts2, n_tiles * 4ull)); CK(hipMalloc(&cinfo2, n_tiles * 4ull)); CK(hipMalloc(&stage2, (size_t)n_tiles * kStageCap * 2));
+      StreamOut so2{counts2, cinfo2, stage2, queue, 1ull << 20};
+      LinesArgs A{};
+      A.img = img; A.n = n; A.cr = ChunkRanks{counts, local, spans, n_tiles}; A.stage = stage; A.line_end = line_end;
+      A.line_cap = 4 * reads + 32; A.n_newlines = 4 * reads; A.n_lines = 4 * reads; A.limit = 4 * reads; A.suspect_bits = suspect;
+      A.suspect_cap = reads; A.flags = &cs->flags; A.space = 0; A.weight = 1; A.acc = acc; A.hist = hist; A.ablate = 0;
+      const uint64_t groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave), n_steps = (groups + kLinesPer - 1) / kLinesPer;
+      uint8_t* todo; CK(hipMalloc(&todo, n_steps + 4)); CK(hipMemset(todo, 0, n_steps + 4));
+      int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines_fast), kBlock, 0));
+      const unsigned grid_f = (unsigned)std::min<uint64_t>((n_steps + 3) / 4, 256ull * nb);
+      report("k_stream_lines_fast", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, 0, A, todo); }));
+      int lo_p = 0, hi_p = 0; CK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+      hipStream_t sa, sb, sb0; CK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, lo_p)); CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, hi_p));
+      CK(hipStreamCreateWithPriority(&sb0, hipStreamNonBlocking, lo_p));
+      hipEvent_t e0, e1, eb; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&eb));
+      auto both = [&](hipStream_t second, int order, const char* label) {
+        double tot = 0;
+        for (int i = 0; i <= reps; ++i) {
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(e0, sa));
+          CK(hipStreamWaitEvent(second, e0, 0));
+          if (order == 0) hipLaunchKernelGGL(k_stream_pass1<0u>, dim3((n_tiles + 3) / 4), dim3(kBlock), 0, sa, img, n, n_tiles, so2, cs);
+          hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, second, A, todo);
+          if (order == 1) hipLaunchKernelGGL(k_stream_pass1<0u>, dim3((n_tiles + 3) / 4), dim3(kBlock), 0, sa, img, n, n_tiles, so2, cs);
+          CK(hipEventRecord(eb, second));
+          CK(hipStreamWaitEvent(sa, eb, 0));
+          CK(hipEventRecord(e1, sa));
+          CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          if (i) tot += ms;
+        }
+        report(label, tot / reps);
+      };
+      printf("stream priorities: least %d, greatest %d\n", lo_p, hi_p);
+      both(sb0, 0, "pass1 || lines_fast, equal prio");
+      both(sb, 0, "pass1 || lines_fast, lines high");
+      both(sb, 1, "lines_fast first, then pass1");
+      // pass 1 in four launches, the line kernel beside the second
+      {
+        double tot = 0;
+        const uint32_t per = ((n_tiles / 4 + 3) / 4) * 4;
+        for (int i = 0; i <= reps; ++i) {
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(e0, sa));
+          for (int sgm = 0; sgm < 4; ++sgm) {
+            const uint32_t c0 = sgm * per, c1 = sgm == 3 ? n_tiles : (sgm + 1) * per;
+            // (a launch over the first c1 chunks whose first c0 / 4 workgroups return at once would skew the timing: the kernel takes no offset)
+            hipLaunchKernelGGL(k_stream_pass1<0u>, dim3((c1 - c0 + 3) / 4), dim3(kBlock), 0, sa, img + (uint64_t)c0 * kChunkBytes, n - (uint64_t)c0 * kChunkBytes, c1 - c0, so2, cs);
+            if (sgm == 0) { CK(hipEventRecord(eb, sa)); CK(hipStreamWaitEvent(sb, eb, 0)); hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, sb, A, todo); }
+          }
+          CK(hipEventRecord(eb, sb));
+          CK(hipStreamWaitEvent(sa, eb, 0));
+          CK(hipEventRecord(e1, sa));
+          CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          if (i) tot += ms;
+        }
+        report("pass1 x4, lines beside 2..4", tot / reps);
+      }
+    }
     CallState h; CK(hipMemcpy(&h, cs, sizeof(h), hipMemcpyDeviceToHost));
     printf("stream: flags=%u queue=%llu redo=%u (of %u x %d launches) boot q=[%u,%u]\n", h.flags, h.queue_count, h.redo_count, n_tiles, reps + 1, h.boot_qmin, h.boot_qmax);
   }
