@@ -363,14 +363,16 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
             if sink is None and os.path.exists(os.path.join(d, "out.fastq.gz")):
                 legs[label]["output_gz_GB"] = os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9
                 os.unlink(os.path.join(d, "out.fastq.gz"))
-                # the deflate level is the host's whole cost here: the same run at level 1 (FQGPU_GZIP_LEVEL; what a reader
-                # inflates is the same)
-                secs, p = timed(args, sink, {"FQGPU_GZIP_LEVEL": "1", "FQGPU_TIMING": "1"})
+                # deflate is the host's whole cost here: the same run with the members from host/fq_fastdeflate.h instead of
+                # zlib's (FQGPU_GZIP_FAST=1: zlib level 1's size class; what a reader inflates is the same - the prefix check
+                # below runs with it too)
+                secs, p = timed(args, sink, {"FQGPU_GZIP_FAST": "1", "FQGPU_TIMING": "1"})
                 c = counts(p.stderr)
-                legs[label]["at_gzip_level_1"] = {
+                legs[label]["with_FQGPU_GZIP_FAST"] = {
                     "seconds": secs, "Mpairs_per_s": m / secs / 1e6,
                     "ok": p.returncode == 0 and c.get("Reads processed: ") == m and c.get("Reads discarded: ") == want_disc,
-                    "output_gz_GB": os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9 if os.path.exists(os.path.join(d, "out.fastq.gz")) else None}
+                    "output_gz_GB": os.path.getsize(os.path.join(d, "out.fastq.gz")) / 1e9 if os.path.exists(os.path.join(d, "out.fastq.gz")) else None,
+                    "says": [ln[ln.find("fqgpu timing"):] for ln in p.stderr.decode("latin-1").splitlines() if "fqgpu timing" in ln][:1]}
                 if os.path.exists(os.path.join(d, "out.fastq.gz")):
                     os.unlink(os.path.join(d, "out.fastq.gz"))
         res["legs"] = legs
@@ -382,6 +384,9 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
         secs, p = timed(["--outfile1", "out.fastq.gz"], None)
         with gzip.open(os.path.join(d, "out.fastq.gz"), "rb") as f:
             prog_sha = hashlib.sha256(f.read()).hexdigest()
+        secs, p_fast = timed(["--outfile1", "out.fastq.gz"], None, {"FQGPU_GZIP_FAST": "1"})
+        with gzip.open(os.path.join(d, "out.fastq.gz"), "rb") as f:
+            fast_sha = hashlib.sha256(f.read()).hexdigest()
         st1 = A.probe_first_record(bytes(img1[: 4 * R1].cpu().numpy()), True)
         st2 = A.probe_first_record(bytes(img2[: 4 * R2].cpu().numpy()), True)
         frames = {}
@@ -395,7 +400,8 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
         for f in frames.values():
             f.release()
         res["prefix_check"] = {"pairs": k, "program_output_sha256": prog_sha, "library_output_sha256": lib_sha,
-                               "identical": p.returncode == 0 and prog_sha == lib_sha}
+                               "with_FQGPU_GZIP_FAST_sha256": fast_sha,
+                               "identical": p.returncode == 0 and p_fast.returncode == 0 and prog_sha == lib_sha == fast_sha}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return res

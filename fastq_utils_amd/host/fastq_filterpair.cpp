@@ -20,41 +20,40 @@ namespace {
 
 constexpr unsigned kHashSize = 100000001u;  // src/fastq_filterpair.c:33
 
-gzFile open_out(const char* path) {  // fastq_new(path, FALSE, "w3") -> fastq_open (src/fastq.c:631-664)
-  gzFile g;
-  if (path[0] == '-' && path[1] == '\0') g = gzdopen(fileno(stdout), "wb");
-  else g = gzopen(path, "w3");
-  if (!g) {
+// The reference writes its three outputs through gzopen(path, "w3") / gzwrite on its one thread (fastq_new(path, FALSE,
+// "w3") -> fastq_open, src/fastq.c:631-664) - 50 MB/s, which is all a run of this program would be.  Here the text
+// of a batch is cut into blocks and every block becomes a gzip member on a core of its own (fq_parallel.h: what a reader
+// inflates is the same bytes); the level is the reference's 3, zlib's default for "-" as gzdopen(stdout, "wb") has it.
+using Out = fqhost::GzipMembers;
+Out* open_out(const char* path) {
+  Out* g = new Out();
+  const bool to_stdout = path[0] == '-' && path[1] == '\0';
+  if (!g->open(path, to_stdout ? Z_DEFAULT_COMPRESSION : 3)) {
     FQ_PRINT_ERROR("Unable to open %s", path);
     fqhost::leave(kExitParams);
   }
-  gzbuffer(g, 128000);
   return g;
 }
 
 // records `list` of `frame`, in that order, appended to the output
-void emit(const fqg_frame* frame, const std::vector<uint64_t>& list, gzFile out, std::vector<char>& host) {
+void emit(const fqg_frame* frame, const std::vector<uint64_t>& list, Out* out, std::vector<char>& host) {
   if (list.empty()) return;
   uint64_t bytes = 0;
   LIB(fqg_records_gather(g_ctx, frame, list.data(), list.size(), &bytes));
   if (host.size() < bytes) host.resize(bytes);
   LIB(fqg_records_gather_output(g_ctx, host.data(), bytes));
-  for (uint64_t o = 0; o < bytes;) {
-    const unsigned n = (unsigned)std::min<uint64_t>(bytes - o, 1u << 30);
-    if (gzwrite(out, host.data() + o, n) != (int)n) {
-      int en = 0;
-      FQ_PRINT_ERROR("%s.\n", gzerror(out, &en));  // GZ_WRITE, src/fastq.c:211-235
-      fqhost::leave(kExitSys);
-    }
-    o += n;
+  if (!out->write(host.data(), bytes)) {
+    FQ_PRINT_ERROR("%s.\n", "write error");  // GZ_WRITE, src/fastq.c:211-235
+    fqhost::leave(kExitSys);
   }
 }
 
-void close_out(gzFile g) {  // fastq_destroy -> fastq_close (src/fastq.c:615-629)
-  if (gzclose(g) != Z_OK) {
+void close_out(Out* g) {  // fastq_destroy -> fastq_close (src/fastq.c:615-629)
+  if (!g->close()) {
     FQ_PRINT_ERROR("unable to close file descriptor");
     fqhost::leave(kExitSys);
   }
+  delete g;
 }
 
 }  // namespace
@@ -90,7 +89,7 @@ int main(int argc, char** argv) {
   index_mem += F1.index_mem;
   fprintf(stderr, "Reads indexed: %llu\n", (unsigned long long)F1.entries);
   fprintf(stderr, "Memory used in indexing: %ld MB\n", (long)(index_mem / 1024 / 1024));
-  gzFile w1 = open_out(argv[3]), w2 = open_out(argv[4]), w3 = open_out(argv[5]);
+  Out *w1 = open_out(argv[3]), *w2 = open_out(argv[4]), *w3 = open_out(argv[5]);
   unsigned long up2 = 0, paired = 0;
   std::vector<char> host;
   const fqg_frame* frame1 = fqg_index_frame(F1.index, 0);  // (null for an empty file)
@@ -110,7 +109,7 @@ int main(int argc, char** argv) {
       fqg_file_state st;
       fqg_index* other;
       uint64_t n;
-      gzFile pair_out;
+      Out* pair_out;
       bool counts;
     } sides[2] = {{path1, frame1, F1.st, F2.index, F1.n_records, w1, true},
                   {path2, frame2, F2.st, F1.index, F2.n_records, w2, false}};

@@ -26,6 +26,8 @@
 #include <utility>
 #include <vector>
 
+#include "fq_fastdeflate.h"
+
 namespace fqhost {
 
 // the cores this process may run on (a container's share of the machine: more threads than that only take turns)
@@ -161,6 +163,9 @@ class GzipMembers {
       const int v = atoi(e);
       if (v >= 1 && v <= 9) level_ = v;
     }
+    // FQGPU_GZIP_FAST=1: the members from fq_fastdeflate.h instead of zlib's - three times as fast as the reference's
+    // level 4 and a tenth larger (zlib level 1's size class)
+    if (const char* e = getenv("FQGPU_GZIP_FAST")) fast_ = atoi(e) != 0;
     if (path[0] == '-' && path[1] == 0) f_ = stdout;
     else {
       f_ = fopen(path, "wb");
@@ -199,6 +204,7 @@ class GzipMembers {
 
  private:
   bool member(const char* p, size_t n, std::vector<uint8_t>& out) const {
+    if (fast_) return fdef::gzip_member_fast(p, n, out);
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, level_, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
@@ -213,7 +219,7 @@ class GzipMembers {
     return rc == Z_STREAM_END;
   }
   FILE* f_ = nullptr;
-  bool own_ = false, wrote_ = false;
+  bool own_ = false, wrote_ = false, fast_ = false;
   int level_ = 4;
 };
 

@@ -482,3 +482,29 @@ def test_loop_condition_ends_the_loop_before_a_truncated_record_is_read(which, o
         assert rc == want["exit"], (err[-300:], want["stderr"][-300:])
         assert out == want["stdout"]
         assert strip_progress(err) == strip_progress(want["stderr"])
+
+
+def test_fast_gzip_output_inflates_to_the_same_text():
+    """FQGPU_GZIP_FAST=1 (host/fq_fastdeflate.h instead of zlib for the output members): another compressed file, the
+    same text in it"""
+    rng = np.random.default_rng(31)
+    from tests import fuzz
+
+    with tempfile.TemporaryDirectory() as tmp:
+        n = 20000
+        r1 = fuzz.make_fastq(np.random.default_rng(7), n, 60, 100, "casava", mate=1)
+        i1 = fuzz.make_fastq(np.random.default_rng(7), n, 26, 26, "casava", mate=2)
+        for name, img in (("r1.fastq", r1), ("i1.fastq", i1)):
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(img)
+        args = ["--read1", "r1.fastq", "--index1", "i1.fastq", "--umi_read", "index1", "--umi_offset", "16", "--umi_size", "10",
+                "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16", "--phred_encoding", "33", "--min_qual", "0"]
+        texts, sizes = {}, {}
+        for tag, env in (("zlib", {}), ("fast", {"FQGPU_GZIP_FAST": "1"})):
+            out = "out_%s.fastq.gz" % tag
+            rc, so, se = run(BIN, args + ["--outfile1", out], tmp, env)
+            assert rc == 0, se[-500:]
+            texts[tag] = gunzip_file(os.path.join(tmp, out))
+            sizes[tag] = os.path.getsize(os.path.join(tmp, out))
+        assert texts["fast"] == texts["zlib"] and len(texts["zlib"]) > 1000000
+        assert sizes["fast"] != sizes["zlib"] and sizes["fast"] < 1.3 * sizes["zlib"]

@@ -70,6 +70,23 @@ def test_host_parallel_compression_runs_clean(tmpdir):
     assert gzip.decompress(dst.read_bytes()) == src.read_bytes()
 
 
+def test_fast_deflate_runs_clean(tmpdir):
+    """fq_fastdeflate.h (FQGPU_GZIP_FAST) under ASan + UBSan: the round trip through zlib on text, noise, runs and an empty input"""
+    exe = str(tmpdir / "fdef_san")
+    subprocess.run(["g++", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1", "-o", exe,
+                    os.path.join(CXX, "fastdeflate_check.cpp"), "-lz"], check=True)
+    rng = np.random.default_rng(8)
+    lines = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(1, 400))).astype(np.uint8)) for _ in range(8000)]
+    cases = {"text": b"@r\n".join(lines), "noise": bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), "zeros": bytes(500000), "empty": b"",
+             "skewed": bytes(np.minimum(255, rng.exponential(40, 300000)).astype(np.uint8))}
+    for name, data in cases.items():
+        f = tmpdir / name
+        f.write_bytes(data)
+        for member in ("1048576", "5000"):
+            p = subprocess.run([exe, str(f), member], env=ENV, capture_output=True, timeout=300)
+            assert p.returncode == 0 and p.stdout.startswith(b"ok"), (name, member, p.stdout, p.stderr.decode()[-1500:])
+
+
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
 def test_host_input_stager_runs_clean(tmpdir, san):
     flags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g", "-O1"]
