@@ -441,6 +441,12 @@ class Inflate16 {
     return kAtBoundary;
   }
 
+  // (two builds of the inner loop, chosen when the program starts: with BMI2 - shifts and masks by a register in one
+  // instruction each - it runs a quarter to a third faster, and every x86-64 of the last ten years has it)
+  // (not in sanitizer builds: the resolver that chooses runs before their run times are up)
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(__SANITIZE_THREAD__) && !defined(__SANITIZE_ADDRESS__)
+  __attribute__((target_clones("default", "bmi2")))
+#endif
   static Status codes(BitIn& in, const uint32_t* lt, const uint32_t* dt, Out16& out, size_t& pos_io, long long floor_,
                       size_t& min_src_io, const uint8_t* in_limit, size_t out_limit) {
     size_t pos = pos_io, min_src = min_src_io;
@@ -847,7 +853,7 @@ class ParallelGunzip {
       uint8_t lut_win[kWin];
       memset(lut_win, 0, sizeof(lut_win));
       const std::vector<uint8_t>& w = wins[q];
-      memcpy(lut_win + kWin - w.size(), w.data(), w.size());
+      if (!w.empty()) memcpy(lut_win + kWin - w.size(), w.data(), w.size());
       size_t a = kWin;
       for (size_t s = 0; s <= c.ends.size(); ++s) {
         const size_t b = s < c.ends.size() ? c.ends[s].out_pos : c.out.pos;
@@ -911,7 +917,7 @@ class ParallelGunzip {
       return 0;
     }
     const ChunkState& last = *cs[joined[use - 1]];
-    memcpy(win_, next_win_.data(), next_win_.size());
+    if (!next_win_.empty()) memcpy(win_, next_win_.data(), next_win_.size());
     win_n_ = next_win_.size();
     in_member_ = !last.finished;
     if (last.finished) {
