@@ -254,6 +254,12 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs, programs=True):
         out["whitelist_stage"] = {"error": repr(e)[:300]}
     for f in frames.values():
         f.release()
+    # a file set without a specialised kernel (three barcode sources, as the reference's pre3 fixture has them): the
+    # generic instantiations k_bc_*_tile<.., 0>
+    try:
+        out["generic_file_set"] = barcodes_generic(ctx, fq, torch, dev, img2, R2, min(n_pairs, 50_000_000))
+    except Exception as e:
+        out["generic_file_set"] = {"error": repr(e)[:300]}
     if programs:
         try:
             out["programs"] = barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, q, kernels_ms)
@@ -281,6 +287,66 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs, programs=True):
 
 V2_FLAGS = ["--read1", "r1.fastq", "--index1", "i1.fastq", "--umi_read", "index1", "--umi_offset", "16", "--umi_size", "10",
             "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16", "--phred_encoding", "33", "--min_qual", "10"]
+
+
+def barcodes_generic(ctx, fq, torch, dev, img_read, R_read, n):
+    """fqg_barcodes_transform with the UMI, the cell and the sample barcode in three files of their own beside the read
+    (index1 / index2 / index3: the layout of the reference's pre3 fixture): no kernel is specialised for this file set"""
+    import time
+
+    from oracle import pre_barcodes_oracle as pbo
+
+    A = fq.abi
+    Ri = A.synth_record_bytes(26)
+    idx = []
+    for k in range(3):
+        t = torch.empty(n * Ri, dtype=torch.uint8, device=dev)
+        ctx.synth_fastq(t.data_ptr(), n, 26, first_index=0, seed=900 + k, mate=1)
+        idx.append(t)
+    ctx.synchronize()
+    keys = (A.READ1, A.INDEX1, A.INDEX2, A.INDEX3)
+    imgs = (img_read, idx[0], idx[1], idx[2])
+    Rs = (R_read, Ri, Ri, Ri)
+    frames, states = {}, {}
+    for key, img, R in zip(keys, imgs, Rs):
+        st = A.probe_first_record(bytes(img[: 4 * R].cpu().numpy()), True)
+        r = ctx.validate(img.data_ptr(), None, st, final=True, flags=A.VALIDATE_FRAME_ONLY, nbytes=n * R)
+        assert r["n_records"] == n, r
+        frames[key] = ctx.retain_frame()
+        states[key] = st
+
+    def run():
+        return ctx.barcodes_transform(frames, states, n, umi=(A.INDEX1, 0, 10), cell=(A.INDEX2, 0, 16), sample=(A.INDEX3, 0, 8),
+                                      phred=33, min_qual=0, sam=True)
+
+    run()
+    ctx.profile(True)
+    ctx.profile_reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    r = run()
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith("k_bc") and v[0] > 0}
+    ctx.profile(False)
+    m = min(2000, n)
+    names = ("r1.fastq", "i1.fastq", "i2.fastq", "i3.fastq")
+    files = {nm: bytes(img[: m * R].cpu().numpy()) for nm, img, R in zip(names, imgs, Rs)}
+    want = pbo.run_pre_barcodes(["--read1", "r1.fastq", "--index1", "i1.fastq", "--index2", "i2.fastq", "--index3", "i3.fastq",
+                                 "--umi_read", "index1", "--umi_offset", "0", "--umi_size", "10", "--cell_read", "index2", "--cell_offset", "0",
+                                 "--cell_size", "16", "--sample_read", "index3", "--sample_offset", "0", "--sample_size", "8",
+                                 "--phred_encoding", "33", "--sam", "--outfile1", "-"], files.get)
+    body = "".join(ln + "\n" for ln in want["stdout"].splitlines() if not ln.startswith("@"))
+    got = ctx.barcodes_output(0, len(body)).decode("latin-1")
+    for f in frames.values():
+        f.release()
+    kms = sum(prof.values())
+    algo = n * (R_read + 3 * Ri) + r["out_bytes"][0]
+    return {"what": "read1 + index1 (UMI) + index2 (cell) + index3 (sample): the generic tile kernels", "pairs": n,
+            "kernels_ms": kms, "kernels_ms_breakdown": prof, "wall_ms_one_call": wall * 1e3, "algorithmic_GB": algo / 1e9,
+            "achieved_GBps_kernels": algo / (kms * 1e-3) / 1e9 if kms else None,
+            "ok": r["code"] == 0 and r["n_done"] == n and r["n_discarded"] == 0,
+            "first_2000_pairs_identical_to_oracle": got == body and want["exit"] == 0}
 
 
 def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, kernels_ms):
