@@ -37,4 +37,9 @@ $out/pgzip_check /dev/shm/pgzip_scan.gz 16 2097152 134217728 2>&1 | tee -a $out/
 for t in 1 16 32; do for c in 2097152 4194304; do
   $out/pgzip_check /dev/shm/pgzip_scan.gz $t $c 134217728 timing 2>&1 | tee -a $out/scan.txt
 done; done
+# the symbol buffer's span between slides (KiB of symbols; FQGPU_PGZIP_SPAN)
+for k in 68 512; do
+  echo "span $k Ki symbols:" | tee -a $out/scan.txt
+  FQGPU_PGZIP_SPAN=$k $out/pgzip_check /dev/shm/pgzip_scan.gz 16 4194304 134217728 timing 2>&1 | tee -a $out/scan.txt
+done
 rm -f /dev/shm/pgzip_scan.fastq /dev/shm/pgzip_scan.gz
