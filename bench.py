@@ -340,6 +340,8 @@ def barcodes_generic(ctx, fq, torch, dev, img_read, R_read, n):
     got = ctx.barcodes_output(0, len(body)).decode("latin-1")
     for f in frames.values():
         f.release()
+    del idx, imgs
+    torch.cuda.empty_cache()  # (the programs timed next are processes of their own and need device memory too)
     kms = sum(prof.values())
     algo = n * (R_read + 3 * Ri) + r["out_bytes"][0]
     return {"what": "read1 + index1 (UMI) + index2 (cell) + index3 (sample): the generic tile kernels", "pairs": n,
@@ -423,6 +425,8 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
                 if not ok:
                     break
             best = min(runs)
+            if not ok:  # (what the program said: a leg that fails must say why)
+                says = says + ["exit status %d" % p.returncode, p.stderr.decode("latin-1")[-600:]]
             legs[label] = {"pairs": m, "seconds": runs, "Mpairs_per_s": m / best / 1e6, "input_GBps": m * per_pair_in / best / 1e9, "ok": ok, "says": says,
                            "includes": "process start, HIP initialisation, pinned slots, reading both files, H2D, kernels, D2H, "
                                        + ("parallel gzip (level as the reference's gzopen \"w\"), file written to tmpfs" if sink is None else "SAM text written to /dev/null")}
