@@ -89,7 +89,9 @@ inline uint32_t crc32_16(uint32_t crc, const uint8_t* p, size_t n) {
 }
 
 constexpr uint32_t kWin = 32768;
-constexpr size_t kSlack = 64;  // readable (zero) bytes behind the valid compressed bytes
+// readable (zero) bytes behind the valid compressed bytes: the header of a dynamic block is read without a look at the
+// end of the input (at most 14 + 57 + 316 * 14 bits = 562 bytes), the symbol loop looks once per symbol
+constexpr size_t kSlack = 1024;
 
 // ---- entries of the decoding tables ------------------------------------------------------------------------------
 // bits 0-4 code bits to drop | 5-7 type | 8-12 extra bits (sub-table: its index bits) | 16-31 literal / base / sub-table start
@@ -824,12 +826,12 @@ class ParallelGunzip {
         dec.run(c, cbuf_, cn_, eof, stop, out_limit);
         return;
       }
-      c.out.window_unknown();
       uint64_t from = start_of((unsigned)k);
       while (from < stop) {
         const uint64_t at = find_block(cbuf_, cn_, from, std::min(stop, nbits), dec);
         if (at >= std::min(stop, nbits)) break;
         c.reset();
+        c.out.window_unknown();  // (again for every guess: a guess that ran for a while has slid its symbols over it)
         c.bit = c.start_bit = at;
         const Status st = dec.run(c, cbuf_, cn_, eof, stop, out_limit);
         // (a guess that dies within a few blocks was no block start; real damage is found by whoever decodes up to here)

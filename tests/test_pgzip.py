@@ -213,6 +213,20 @@ def test_other_kinds_of_content(check, tmp_path):
                 assert int(st["bytes"]) == len(data), (name, line)
 
 
+def test_a_gzip_file_inside_a_gzip_file(check, tmp_path):
+    """the content is itself deflate data: stored in the outer member byte for byte, so the search for block starts finds
+    the INNER file's blocks - guesses that decode for a long while and are wrong for the outer stream.  They must cost
+    time only."""
+    inner = gzip.compress(text(40000, 15), 6)
+    f = tmp_path / "g.gz"
+    for outer in (member(inner, level=0), member(inner, level=1), member(inner + text(3000, 16) + inner, level=6)):
+        f.write_bytes(outer)
+        for chunk in (30000, 200000):
+            rc, line, st = run(check, f, 4, chunk)
+            assert rc == 0, line
+            assert st["zlib_error"] == "-" and st["error"] == "-", line
+
+
 def test_files_that_are_no_gzip_files_come_out_as_they_are(check, tmp_path):
     # (zlib's gzread is transparent for them; the programs never send such a file here - they look at the magic first)
     data = text(3000, 14)
