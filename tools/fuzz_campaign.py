@@ -21,7 +21,9 @@ BIN = os.path.join(REPO, "bin", "fastq_info")
 REF = os.path.join(REPO, "oracle", "_ref", "fastq_info")
 ENVS = [("default", {}), ("pieces", {"FQGPU_CHUNK_MB": "1"}), ("stream", {"FQGPU_STREAM_MIN": "256"}),
         ("devices", {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"}),
-        ("devices_stream", {"FQGPU_DEVICES": "0,0,0", "FQGPU_CHUNK_MB": "1", "FQGPU_STREAM_MIN": "256"})]
+        ("devices_stream", {"FQGPU_DEVICES": "0,0,0", "FQGPU_CHUNK_MB": "1", "FQGPU_STREAM_MIN": "256"}),
+        # (.gz inputs through the many-core gzip reader, host/fq_pgzip.h, in chunks of 8 KiB - files this small are one zlib thread's otherwise)
+        ("gz_chunks", {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "8192", "FQGPU_HOST_THREADS": "3", "FQGPU_CHUNK_MB": "1"})]
 if os.environ.get("CAMPAIGN_COMPAT") == "1":
     # the zero-change route: the reference's own fastq_info.c linked against libfastq_gpu.so (oracle/Makefile)
     BIN = os.path.join(REPO, "oracle", "_ref", "fastq_info_on_libfastq_gpu")
@@ -102,14 +104,15 @@ def one_case(seed):
             for name, img in (("a.fastq", a), ("b.fastq", b), ("i.fastq", inter)):
                 with open(os.path.join(d, name), "wb") as f:
                     f.write(img)
-            with open(os.path.join(d, "a.fastq.gz"), "wb") as f:
-                f.write(gzip.compress(a, 1))
+            for name, img, level in (("a.fastq.gz", a, 1), ("b.fastq.gz", b, 6), ("i.fastq.gz", inter, 9)):
+                with open(os.path.join(d, name), "wb") as f:
+                    f.write(gzip.compress(img, level))
         modes = [["-r", "a.fastq"], ["a.fastq"], ["i.fastq", "pe"], ["a.fastq", "b.fastq"], ["-s", "a.fastq", "b.fastq"],
-                 ["a.fastq.gz", "b.fastq"]]
+                 ["a.fastq.gz", "b.fastq"], ["a.fastq.gz", "b.fastq.gz"], ["i.fastq.gz", "pe"]]
         if not big:
             modes += [["-r", "-s", "a.fastq", "b.fastq"], ["b.fastq", "a.fastq"], ["a.fastq", "pe"], ["-r", "a.fastq.gz"],
                       ["-e", "-q", "a.fastq"], ["-f", "a.fastq"]]
-        envs = ENVS if big else [ENVS[0], ENVS[2], ENVS[4]]
+        envs = ENVS if big else [ENVS[0], ENVS[2], ENVS[4], ENVS[5]]
         if os.environ.get("CAMPAIGN_COMPAT") == "1":
             envs = [ENVS[0], ENVS[2]]
         for args in modes:

@@ -70,10 +70,12 @@ def compare(name, args, files, outs, envs, seed, what):
     if want[0] == "timeout" or (isinstance(want[0], int) and want[0] < 0):
         return bad
     for tag, env in envs:
+        env = dict(env)
+        gz_inputs = env.pop("_gz_inputs", None)  # the product reads the same inputs gzip'd (under the same names: gzip is known by its magic)
         with tempfile.TemporaryDirectory() as d:
             for fn, img in files.items():
                 with open(os.path.join(d, fn), "wb") as f:
-                    f.write(img)
+                    f.write(gzip.compress(img, int(gz_inputs)) if gz_inputs else img)
             got = run(prod, name, args, d, env)
             got_files = [gunzip(os.path.join(d, o)) if o.endswith(".gz") else None for o in outs]
         same = got == want and (want[0] != 0 or got_files == want_files)
@@ -91,6 +93,9 @@ def one_case(seed):
     style = ["casava", "slash", "int", "nosuffix"][int(rng.integers(0, 4))]
     sub = int(rng.integers(0, 1 << 30))
     pieces = [("default", {}), ("pieces", {"FQGPU_CHUNK_MB": "1"})] if big else [("default", {}), ("tiny_tiles", {"FQGPU_BC_LDS": "4096"})]
+    # gzip'd inputs through the many-core gzip reader in chunks of 8 KiB, gzip output from the fast compressor (round 4)
+    pieces.append(("gz_in_chunks_fast_gz_out", {"_gz_inputs": str(int(rng.integers(1, 10))), "FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "8192",
+                                                  "FQGPU_HOST_THREADS": "3", "FQGPU_GZIP_FAST": "1", "FQGPU_CHUNK_MB": "1"}))
     # ---- fastq_filterpair
     a = fuzz.make_fastq(np.random.default_rng(sub), n, 20, 120, style, mate=1)
     b = fuzz.make_fastq(np.random.default_rng(sub), n, 20, 120, style, mate=2)
