@@ -37,6 +37,9 @@
 
 #include "../../include/fastq_gpu_compat.h"
 #include "../../include/fqg.h"
+#include <sys/stat.h>
+
+#include "../host/fq_pgzip.h"
 #include "../host/fq_reframe.h"
 
 namespace {
@@ -156,9 +159,37 @@ void load(FileCtx* f) {
   if (f->loaded) return;
   f->loaded = true;
   FASTQ_FILE* fd = f->fd;
-  char buf[1 << 16];
-  int got;
-  while ((got = gzread(fd->fd, buf, sizeof(buf))) > 0) f->image.insert(f->image.end(), buf, buf + got);
+  // A gzip file of some size is inflated on every core the process may use (host/fq_pgzip.h, as in the drop-in programs;
+  // FQGPU_NO_PARALLEL_INFLATE / FQGPU_PGZIP_MIN / FQGPU_PGZIP_CHUNK as there); anything else through the gzFile that
+  // fastq_new opened.  An inflate error ends the data where it is met - gzgets gives the reference NULL there.
+  bool inflated = false;
+  if (!(fd->filename[0] == '-' && fd->filename[1] == '\0') && !getenv("FQGPU_NO_PARALLEL_INFLATE") && fqhost::host_threads() > 1) {
+    const int h = open(fd->filename, O_RDONLY);
+    struct stat sb;
+    unsigned char magic[2] = {0, 0};
+    const char* e_min = getenv("FQGPU_PGZIP_MIN");
+    const uint64_t min_bytes = e_min ? (uint64_t)std::max(0L, atol(e_min)) : (1u << 20);
+    if (h >= 0 && fstat(h, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= min_bytes && pread(h, magic, 2, 0) == 2 &&
+        magic[0] == 0x1f && magic[1] == 0x8b) {
+      const unsigned T = std::min(fqhost::host_threads(), 64u);
+      size_t chunk = std::max<size_t>(512u << 10, std::min<size_t>(4u << 20, (128u << 20) / T));
+      chunk = std::min<size_t>(chunk, std::max<size_t>((size_t)sb.st_size / T, 128u << 10));
+      if (const char* e = getenv("FQGPU_PGZIP_CHUNK")) chunk = (size_t)std::max(4096L, atol(e));
+      fqhost::ParallelGunzip pg(h, (uint64_t)sb.st_size, fd->filename, T, chunk);
+      std::vector<char> piece(32u << 20);
+      for (bool at_end = false; !at_end && !pg.failed();) {
+        const size_t n = pg.read(piece.data(), piece.size(), &at_end);
+        f->image.insert(f->image.end(), piece.data(), piece.data() + n);
+      }
+      inflated = true;
+    }
+    if (h >= 0) close(h);
+  }
+  if (!inflated) {
+    char buf[1 << 16];
+    int got;
+    while ((got = gzread(fd->fd, buf, sizeof(buf))) > 0) f->image.insert(f->image.end(), buf, buf + got);
+  }
   gzclose(fd->fd);
   {  // the reference's gzgets calls (src/fastq.c:249-253), as cuts
     fqhost::Reframer rf;

@@ -18,18 +18,22 @@ LIB = os.path.join(REPO, "fastq_utils_amd", "libfastq_gpu.so")
 GOLDEN = load_fastq_info_golden()
 
 
-def run(args):
-    p = subprocess.run([BIN] + args, cwd=GOLD, capture_output=True, timeout=300)
+def run(args, env=None):
+    p = subprocess.run([BIN] + args, cwd=GOLD, capture_output=True, timeout=300, env=dict(os.environ, **(env or {})))
     return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1")
 
 
-def test_reference_main_program_on_the_gpu_library():
+@pytest.mark.parametrize("inflate", ["one_zlib_thread", "by_chunks"])
+def test_reference_main_program_on_the_gpu_library(inflate):
+    """(by_chunks: the library reads every .fastq.gz of the goldens through the many-core gzip reader, host/fq_pgzip.h, in
+    chunks of 4 KiB - files this small are one zlib thread's otherwise)"""
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/fastq_info_on_libfastq_gpu was not built (needs the reference checkout at build time)")
     assert os.path.exists(LIB)
+    env = {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "4096", "FQGPU_HOST_THREADS": "3"} if inflate == "by_chunks" else {}
 
     def one(case):
-        rc, out, err = run(case["args"])
+        rc, out, err = run(case["args"], env)
         ok = (rc == case["exit"] and out == case["stdout"]
               and strip_progress(err) == strip_progress(case["stderr"]))
         return None if ok else (case["args"], rc, case["exit"], out[-200:], case["stdout"][-200:], err[-500:],
