@@ -643,7 +643,7 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
             # reader (host/fq_pgzip.h) and, for comparison, by one zlib thread as the reference reads it
             try:
                 gz = path + ".1member.gz"
-                n_gz = min(n, 10_000_000)
+                n_gz = min(n, int(os.environ.get("FQGPU_BENCH_GZ_READS", "10000000")))  # (all 100 M: a member beyond 4 GiB, 45 s to make)
                 t0 = time.perf_counter()
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--gz-helper", path, gz, str(n_gz * R)], check=True)
                 made = time.perf_counter() - t0
