@@ -43,8 +43,12 @@ int main(int argc, char** argv) {
     // abort() must let all of them go (this block would hang without it).
     fqhost::AlignedPieces src(nullptr, argv[1], piece, 3);
     std::mutex fetch;
-    std::atomic<int> held{0};
+    std::atomic<int> held{0}, gone{0};
     auto hoard = [&] {
+      struct Gone {
+        std::atomic<int>& g;
+        ~Gone() { ++g; }
+      } on_return{gone};
       fqhost::Piece p;
       for (;;) {
         std::lock_guard<std::mutex> lk(fetch);
@@ -54,7 +58,9 @@ int main(int argc, char** argv) {
       }
     };
     std::thread a(hoard), b(hoard);
-    for (int spin = 0; spin < 2000 && held.load() < 3; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    // (until three pieces are held - or the file has no more to give: a hoarder that got the last piece has returned,
+    // and waiting out the two seconds for every small file was most of the sanitizer tests' time)
+    for (int spin = 0; spin < 2000 && held.load() < 3 && gone.load() == 0; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     src.abort();
     a.join();
     b.join();
