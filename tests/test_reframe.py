@@ -20,9 +20,8 @@ def gzgets_image(data):
     out, pos, ph = [], 0, 0
     while pos < len(data):
         lim = LIMITS[ph & 1]
-        seg = data[pos:pos + lim]
-        k = seg.find(b"\n")
-        piece = seg if k < 0 else seg[:k + 1]
+        k = data.find(b"\n", pos, pos + lim)  # (no copy of the 2.5 MB a sequence call may look at)
+        piece = data[pos:pos + lim] if k < 0 else data[pos:k + 1]
         pos += len(piece)
         ph += 1
         if piece.endswith(b"\n") or (len(piece) < lim and pos == len(data)):
@@ -69,6 +68,12 @@ def images():
     for i in range(300):
         many.append(rec(i, int(rng.integers(0, 1300)) if i % 7 == 0 else 0, int(rng.integers(1, 300)), 1100 if i % 31 == 5 else 0))
     out["many_cuts"] = b"".join(many)
+    # Megabytes of ordinary records in front of the long lines: pieces of them take the short cut of the stager (a search
+    # for the longest line on many threads, host/fq_input.h: short_lines_only), which must leave the line reader's state
+    # as the walk line by line would - the stray line puts every later line one call out of step
+    plain = b"".join(rec(i) for i in range(60000))
+    out["long_lines_behind_7MB"] = plain + b"stray line\n" + rec(7, 1500) + ok + rec(8, 0, 2_600_000) + ok
+    out["7MB_without_a_long_line"] = plain + b"stray line\n" + ok
     return out
 
 
