@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task description)
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -942,7 +943,52 @@ def filterpair_extra(ctx, fq, torch, dev, n, read_len):
     gathered = sum(big["bytes"])
     # names in (two header lines of ~45 bytes per pair of records), one 8-byte slot written and read, records in and out
     alg = 2 * n * 45 + 2 * n * 8 + 2 * gathered
+    # the program: two tmpfs files of 10 M records, three .fastq.gz outputs (gzip members on every core; the reference
+    # - and this program until round 4 - writes them through one gzwrite thread), against the reference on 500 000
+    program = None
+    exe = os.path.join(REPO, "bin", "fastq_filterpair")
+    ref = os.path.join(REPO, "oracle", "_ref", "fastq_filterpair")
+    shm = "/dev/shm"
+    m = min(n, 10_000_000)
+    if os.path.exists(exe) and os.path.isdir(shm) and shutil.disk_usage(shm).free > 4 * m * R + (8 << 30):
+        d = tempfile.mkdtemp(prefix="fqg_fp_", dir=shm)
+        try:
+            img = [torch.empty(m * R + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+            ctx.synth_fastq(img[0].data_ptr(), m, read_len, m // 10, 4242, 1)
+            ctx.synth_fastq(img[1].data_ptr(), m, read_len, 0, 4242, 2)
+            torch.cuda.synchronize()
+            for k, name in enumerate(("a_1.fastq", "a_2.fastq")):
+                with open(os.path.join(d, name), "wb") as f:
+                    f.write(img[k][: m * R].cpu().numpy().data)
+            args = ["a_1.fastq", "a_2.fastq", "p1.fastq.gz", "p2.fastq.gz", "up.fastq.gz"]
+            t0 = time.perf_counter()
+            p = subprocess.run(["fastq_filterpair"] + args, executable=exe, cwd=d, capture_output=True)
+            secs = time.perf_counter() - t0
+            sizes = [os.path.getsize(os.path.join(d, o)) for o in args[2:] if os.path.exists(os.path.join(d, o))]
+            program = {"records_per_file": m, "seconds": secs, "Mrecords_per_s": 2 * m / secs / 1e6, "ok": p.returncode == 0,
+                       "output_gz_GB": sum(sizes) / 1e9, "says": p.stderr.decode("latin-1")[-200:]}
+            if os.path.exists(ref):
+                k = 500_000
+                small_img = [torch.empty(k * R + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+                ctx.synth_fastq(small_img[0].data_ptr(), k, read_len, k // 10, 4242, 1)  # (the same shape: nine in ten are mates)
+                ctx.synth_fastq(small_img[1].data_ptr(), k, read_len, 0, 4242, 2)
+                torch.cuda.synchronize()
+                for name, i in (("b_1.fastq", 0), ("b_2.fastq", 1)):
+                    with open(os.path.join(d, name), "wb") as f:
+                        f.write(small_img[i][: k * R].cpu().numpy().data)
+                t0 = time.perf_counter()
+                pr = subprocess.run(["fastq_filterpair", "b_1.fastq", "b_2.fastq", "q1.fastq.gz", "q2.fastq.gz", "uq.fastq.gz"], executable=ref,
+                                    cwd=d, capture_output=True)
+                rs = time.perf_counter() - t0
+                program["reference_on_500k_records_per_file"] = {"seconds": rs, "Mrecords_per_s": 2 * k / rs / 1e6, "ok": pr.returncode == 0}
+            del img
+            torch.cuda.empty_cache()
+        except Exception as e:
+            program = {"error": repr(e)[:300]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
     return {"what": "fastq_filterpair: index file 1, probe + take with file 2, ordered gather of paired / unpaired records",
+            "program": program,
             "records_per_file": n, "mates": n - shift, "matched": big["matched"], "left_in_file1": big["alive"],
             "as_expected": big["codes"] == [0, 0, 0, 13] and  # (13: FQG_E_UNPAIRED - file 2 has reads without a mate)
                            big["matched"] == n - shift and big["alive"] == shift
