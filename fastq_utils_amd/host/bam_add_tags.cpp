@@ -106,11 +106,11 @@ int main(int argc, char* argv[]) {
   FILE* out = out2stdout ? stdout : fopen(outbam_file, "wb");
   if (!in) {
     PRINT_ERROR("Failed to open BAM file %s", inbam_file);
-    return 1;
+    leave(1);
   }
   if (!out) {
     PRINT_ERROR("Failed to open BAM file %s", outbam_file);
-    return 1;
+    leave(1);
   }
   // gene <tab> transcript; the first line of a transcript wins (hash.c:161-184 appends, get_gene returns the first match)
   std::unordered_map<std::string, std::string> t2g;
@@ -146,26 +146,26 @@ int main(int argc, char* argv[]) {
   int rc = fqg_open(0, &g_ctx);
   if (rc != 0) {
     PRINT_ERROR("no usable MI355X device (fqg_open: %d); this program has no CPU path", rc);
-    return 2;
+    leave(2);
   }
   std::vector<uint8_t> raw, stream;
   if (!read_all(in, raw) || !fqhost::bgzf_inflate_parallel(raw, stream)) {
     PRINT_ERROR("%s is not a readable BGZF / BAM file", inbam_file);
-    return 2;
+    leave(2);
   }
   raw.clear();
   raw.shrink_to_fit();
   uint64_t n_rec = 0, used = 0;
   if (fqg_bam_index_records(stream.data(), stream.size(), nullptr, 0, &n_rec, &used) != 0) {
     PRINT_ERROR("%s is not a BAM file", inbam_file);
-    return 2;
+    leave(2);
   }
   std::vector<uint64_t> offsets(n_rec ? n_rec : 1);
   fqg_bam_index_records(stream.data(), stream.size(), offsets.data(), n_rec, &n_rec, &used);
   const uint64_t header_end = n_rec ? offsets[0] : used;
   if (header_end > stream.size()) {
     PRINT_ERROR("%s is not a BAM file", inbam_file);
-    return 2;
+    leave(2);
   }
 
   // the references of the header (bam_header_read): names as C strings
@@ -184,7 +184,7 @@ int main(int argc, char* argv[]) {
       // (fqg_bam_index_records vouches for the walk as a whole; each name is checked again where it is used)
       if (p + 8 > stream.size() || p + 8 + (uint64_t)(uint32_t)rd32(p) > stream.size()) {
         PRINT_ERROR("%s: truncated BAM header (reference %d)", inbam_file, i);
-        return 2;
+        leave(2);
       }
       const uint32_t l_name = (uint32_t)rd32(p);
       const char* nm = (const char*)&stream[p + 4];
@@ -192,7 +192,7 @@ int main(int argc, char* argv[]) {
       if (len + 1 != l_name) {
         PRINT_ERROR("%s: reference %d has a name that is not one C string (bam_header_write would not write it back as read)",
                     inbam_file, i);
-        return 2;
+        leave(2);
       }
       tx_off.push_back((uint32_t)names.size());
       tx_len.push_back((uint32_t)len);
@@ -230,30 +230,30 @@ int main(int argc, char* argv[]) {
   rc = fqg_bam_add_tags(g_ctx, stream.data(), used, FQG_MEM_HOST, offsets.data(), n_rec, &prm, &res);
   if (rc != 0) {
     PRINT_ERROR("GPU library failure in fqg_bam_add_tags (%d): %s", rc, fqg_last_error(g_ctx));
-    return 2;
+    leave(2);
   }
   if (res.code == FQG_E_TAGS_NAME) {
     PRINT_ERROR("%s: alignment %llu: a barcode in the read name runs to the end of the record or has %d characters or more; the "
                 "reference reads and writes memory it does not own there, this program refuses the file",
                 inbam_file, (unsigned long long)res.record + 1, 50);
-    return 2;
+    leave(2);
   }
   if (res.code == FQG_E_TAGS_TID) {
     PRINT_ERROR("%s: alignment %llu: reference id beyond the header's references", inbam_file, (unsigned long long)res.record + 1);
-    return 2;
+    leave(2);
   }
   std::vector<uint8_t> recs(res.out_bytes ? res.out_bytes : 1);
   rc = fqg_bam_add_tags_output(g_ctx, recs.data(), res.out_bytes);
   if (rc != 0) {
     PRINT_ERROR("GPU library failure in fqg_bam_add_tags_output (%d): %s", rc, fqg_last_error(g_ctx));
-    return 2;
+    leave(2);
   }
   std::vector<uint8_t> bgzf;
   if (!fqhost::bgzf_deflate_parallel({{stream.data(), (size_t)header_end}, {recs.data(), (size_t)res.out_bytes}}, Z_DEFAULT_COMPRESSION,
                                      bgzf) ||
       fwrite(bgzf.data(), 1, bgzf.size(), out) != bgzf.size() || fflush(out) != 0) {
     PRINT_ERROR("Failed to write %s", outbam_file);
-    return 2;
+    leave(2);
   }
   if (!out2stdout) {
     fclose(out);

@@ -193,7 +193,7 @@ int main(int argc, char* argv[]) {
   if (!in) {
     fprintf(stderr, "open: %s\n", strerror(errno));  // bgzf.c reports through perror("open")
     PRINT_ERROR("Failed to open BAM file %s", bam_file);
-    return 1;
+    leave(1);
   }
   const char* umi_tag = tenx ? "UB" : "RX";
   fprintf(stderr, "@min_num_reads=%u\n", min_num_reads);
@@ -208,12 +208,12 @@ int main(int argc, char* argv[]) {
   int rc = fqg_open(0, &g_ctx);
   if (rc != 0) {
     PRINT_ERROR("no usable MI355X device (fqg_open: %d); this program has no CPU path", rc);
-    return 2;
+    leave(2);
   }
   std::vector<uint8_t> raw, stream;
   if (!read_all(in, raw) || !fqhost::bgzf_inflate_parallel(raw, stream)) {
     PRINT_ERROR("%s is not a readable BGZF / BAM file", bam_file);
-    return 2;
+    leave(2);
   }
   raw.clear();
   raw.shrink_to_fit();
@@ -244,7 +244,7 @@ int main(int argc, char* argv[]) {
   std::vector<uint64_t> offsets;
   if (fqg_bam_index_records(stream.data(), stream.size(), nullptr, 0, &n_rec, &used) != 0) {
     PRINT_ERROR("%s is not a BAM file", bam_file);
-    return 2;
+    leave(2);
   }
   offsets.resize(n_rec ? n_rec : 1);
   fqg_bam_index_records(stream.data(), stream.size(), offsets.data(), n_rec, &n_rec, &used);
@@ -274,8 +274,11 @@ int main(int argc, char* argv[]) {
   LIB(fqg_umi_count(g_ctx, stream.data(), stream.size(), FQG_MEM_HOST, offsets.data(), n_rec, &prm, &res));
   if (res.rl_unresolved) {  // never silently different from the reference
     fprintf(stderr, "\nERROR: bam_umi_count: a UMI set could not be replayed within this build's limits\n");
-    return 2;
+    leave(2);
   }
+  if (getenv("FQGPU_RL_DEBUG"))  // (where `undefined` is not 0 the reference's own counts depend on what its heap held: DESIGN.md 7.1)
+    fprintf(stderr, "[rl] sets replayed %llu, alignments decided differently from a set %llu, reads of tree memory the reference never wrote: undefined %llu\n",
+            (unsigned long long)res.rl_replayed, (unsigned long long)res.rl_changed, (unsigned long long)res.rl_undefined);
 
   const uint64_t alns_seen = res.code ? res.record + 1 : res.n_alignments;
   if (!bam_sorted_by_cell)

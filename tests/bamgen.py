@@ -80,6 +80,8 @@ def tagged_bam(rng, n_cells=12, genes=40, reads_per_cell=(5, 120), umi_len=8, ce
                 if seen_pairs and rng.random() < 0.3:
                     g, fresh = seen_pairs[int(rng.integers(0, len(seen_pairs)))]
                 else:
+                    if len(used) >= 4 ** umi_len:
+                        raise ValueError("fresh_umis: every UMI of %d bases has been used" % umi_len)
                     while fresh is None or fresh in used:
                         fresh = barcode(rng, umi_len)
                     used.add(fresh)

@@ -42,6 +42,8 @@ def one_case(seed):
     kw["multi_gx"] = bool(rng.random() < 0.3)
     kw["noise"] = bool(rng.random() < 0.3)
     kw["fresh_umis"] = bool(rng.random() < 0.2) and not kw["noise"]
+    if kw["fresh_umis"]:
+        kw["umi_len"] = max(kw["umi_len"], 8)  # (a fresh UMI per read needs that many: the generator looked for a 257th four-base UMI for ever)
     unsorted = rng.random() < 0.2
     if unsorted:
         kw["sort_cells"] = False
@@ -86,6 +88,19 @@ def one_case(seed):
         if want is None or want["rc"] < 0:
             return []
         got = run(BIN, args, d, "gpu")
+        if got is not None and got != want and want["rc"] == 0 and got["rc"] == 0:
+            # where the reference's tree reads memory it never wrote, heap bytes decide its counts: the
+            # library says so when asked (FQGPU_RL_DEBUG)
+            e = dict(os.environ, FQGPU_RL_DEBUG="1")
+            p = subprocess.run(["bam_umi_count"] + args + ["--ucounts", "dbg_u", "--rcounts", "dbg_r"], executable=BIN, cwd=d, capture_output=True,
+                               timeout=180, env=e)
+            import re
+            found = [int(x) for x in re.findall(r"\[rl\].* undefined (\d+)", p.stderr.decode("latin-1"))]
+            m = found and max(found) > 0
+            if m:
+                return [("known: undefined tree reads (DESIGN 7.1)", seed, max(found))]
+    if got is not None and want["rc"] != 0 and got["rc"] == want["rc"] and got["stderr"] == want["stderr"]:
+        return []  # (a run that fails: the same status and the same words; what it had written by then is not compared)
     if got != want:
         keys = [k for k in want if got is None or got.get(k) != want[k]]
         return [(seed, args, kw, want["rc"], None if got is None else got["rc"], keys, want["stderr"][-200:],
@@ -160,14 +175,18 @@ def main():
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-    n_bad = 0
+    n_bad = n_known = 0
     with ThreadPoolExecutor(workers) as ex:
         for bad in ex.map(one_case, range(seed0, seed0 + cases)):
             for b in bad:
+                if isinstance(b[0], str) and b[0].startswith("known"):
+                    n_known += 1
+                    continue
                 n_bad += 1
                 if n_bad <= 30:
                     print("DIFF", b, flush=True)
-    print(f"campaign ({one_case.__name__}) seeds {seed0}..{seed0 + cases - 1}: {n_bad} differing runs", flush=True)
+    print(f"campaign ({one_case.__name__}) seeds {seed0}..{seed0 + cases - 1}: {n_bad} differing runs"
+          f" (+ {n_known} in which the reference's tree read memory it never wrote)", flush=True)
 
 
 if __name__ == "__main__":
