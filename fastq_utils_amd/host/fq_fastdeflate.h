@@ -366,6 +366,7 @@ class FastDeflate {
 
 // one gzip member of [p, p + n)
 inline bool gzip_member_fast(const char* p, size_t n, std::vector<uint8_t>& out) {
+  if (n > (1u << 30)) return false;  // (positions are 32-bit: GzipMembers hands over a MiB at a time)
   static thread_local FastDeflate fd;
   static thread_local std::vector<uint8_t> scratch;  // (kept: a fresh vector of this size would be zero-filled every time)
   const size_t need = 10 + FastDeflate::bound(n) + 16;
