@@ -8,9 +8,14 @@ already in HBM when the timed region starts.  With --gpus N every rank validates
 of the same size (weak scaling; no data-path collective - records are independent), and the
 per-rank statistics are merged once at the end.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description), extended with
+The LAST stdout line of rank 0 is the bench line of the driver contract: compact (<= 4 KB), plain ASCII, with
   roofline      HBM roofline of the dominant kernel, measured with hipEvents on the launch stream
   cpu_baseline  the reference's own fastq_info -r (oracle/_ref) timed on this box's host cores
+  host_fed      the configs[1] placement (reads in host RAM, fed over PCIe): C-ABI and program rates
+  extras        a few numbers per untimed extra; extras_ok = every comparison in them held
+The same line (marked "final": false, without host_fed/extras) is printed once before the untimed extras start, so a
+crash in an extra cannot take the measured numbers with it; each extra then goes out as ONE line of its own
+({"extra": name, ...}), and all of them are written to --extras-out as one JSON document.
 """
 import argparse
 import json
@@ -26,6 +31,127 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_READ_EXTRA = 32  # descriptor bytes per record
+
+HEADLINE_MAX_BYTES = 4096  # the driver keeps a bounded tail of stdout: the last line must fit in it with room to spare
+
+
+def _plain(v, sig=6):
+    """JSON-ready copy of v: floats rounded to `sig` significant digits, strings reduced to printable ASCII (a captured
+    stderr once carried a run of backspaces into the line), numpy/torch scalars to Python numbers."""
+    if isinstance(v, dict):
+        return {str(k): _plain(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x, sig) for x in v]
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, bytes):
+        v = v.decode("latin-1")
+    if isinstance(v, str):
+        return "".join(c if 32 <= ord(c) < 127 else " " for c in v)
+    if hasattr(v, "item"):
+        return _plain(v.item(), sig)
+    return _plain(str(v), sig)
+
+
+def _all_checks_hold(block):
+    """every boolean of an extra whose key says it is a comparison (ok / *identical* / as_expected / ...) is true and
+    no "error" key is anywhere in it"""
+    if isinstance(block, dict):
+        for k, x in block.items():
+            if k == "error":
+                return False
+            if isinstance(x, bool) and (k == "ok" or k.endswith("_ok") or "identical" in k or k.startswith("as_expected")
+                                        or k.endswith("as_expected") or k == "properties_hold"):
+                if not x:
+                    return False
+            if not _all_checks_hold(x):
+                return False
+    elif isinstance(block, (list, tuple)):
+        return all(_all_checks_hold(x) for x in block)
+    return True
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def extras_summary(extras):
+    """a few numbers per extra for the bench line (the full blocks are the {"extra": ...} lines and --extras-out)"""
+    e = extras
+    s = {
+        "default_mode_ms_over_r": _get(e, "default_mode_extra", "ms_over_validate_only"),
+        "name_insert_ms": _get(e, "default_mode_extra", "insert_ms"),
+        "file2_match_ms": _get(e, "default_mode_extra", "file2_loop", "match_ms"),
+        "pre_barcodes_200M_kernels_ms": _get(e, "pre_barcodes_extra", "kernels_ms"),
+        "pre_barcodes_GBps": _get(e, "pre_barcodes_extra", "achieved_GBps_kernels"),
+        "pre_barcodes_generic_50M_ms": _get(e, "pre_barcodes_extra", "generic_file_set", "kernels_ms"),
+        "filter_n_ms": _get(e, "filters_extra", "filter_n", "kernels_ms"),
+        "trim_poly_at_ms": _get(e, "filters_extra", "trim_poly_at", "kernels_ms"),
+        "umi_count_kernels_ms": _get(e, "umi_count_extra", "kernels_ms"),
+        "umi_count_call_ms": _get(e, "umi_count_extra", "wall_ms_one_call_incl_allocations"),
+        "umi_matrix_identical_to_reference": _get(e, "umi_count_extra", "matrix_identical_to_reference_program"),
+        "filterpair_kernels_ms": _get(e, "filterpair_extra", "kernels_ms"),
+        "bam_add_tags_kernels_ms": _get(e, "bam_add_tags_extra", "kernels_ms"),
+        "short_reads_GBps": _get(e, "read_shapes_extra", "short_reads_30_150bp", "GBps_wall"),
+        "long_reads_GBps": _get(e, "read_shapes_extra", "long_reads_2_20kb", "GBps_wall"),
+    }
+    return {k: v for k, v in s.items() if v is not None}
+
+
+def headline_line(out, extras=None, final=True):
+    """The bench line: the contract's keys + roofline + cpu_baseline + host_fed + a short extras summary, serialised
+    as ONE line of printable ASCII no longer than HEADLINE_MAX_BYTES.  Anything that would push it over the limit is
+    dropped from the optional end (extras, then host_fed details), never from the contract's keys."""
+    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_source",
+                 "algorithmic_bytes_per_launch", "avg_launch_ms", "launches", "all_kernels_ms_per_step",
+                 "pipeline_achieved", "pipeline_frac", "launches_per_step", "kernels_ms_per_step")
+    keep_cpu = ("value", "unit", "cores", "kind", "sample", "seconds", "ok")
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
+    line["roofline"] = {k: out["roofline"][k] for k in keep_roof if k in out["roofline"]}
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {k: cb[k] for k in keep_cpu if k in cb}
+        ac = cb.get("all_cores")
+        if ac:
+            line["cpu_baseline"]["all_cores"] = {k: ac[k] for k in ("value", "unit", "cores", "kind", "seconds", "ok") if k in ac}
+    if out.get("host_fed") is not None:
+        line["host_fed"] = out["host_fed"]
+    if out.get("dedup_extra") is not None:
+        d = out["dedup_extra"]
+        line["dedup"] = {k: d[k] for k in ("error", "names_total", "finding", "wall_ms_max_over_ranks",
+                                           "Mnames_per_s_whole_job") if k in d}
+        if isinstance(d.get("pairing"), dict):
+            line["dedup"]["pairing_ok"] = d["pairing"].get("ok")
+            line["dedup"]["Mpairs_per_s_whole_job"] = d["pairing"].get("Mpairs_per_s_whole_job")
+    line["final"] = bool(final)
+    if extras is not None:
+        line["extras_ok"] = all(_all_checks_hold(b) for b in extras.values())
+        line["extras_failed"] = [k for k, b in extras.items() if not _all_checks_hold(b)]
+        line["extras"] = extras_summary(extras)
+    line = _plain(line)
+    for drop in (None, "extras", "dedup", "host_fed"):
+        if drop is not None:
+            line.pop(drop, None)
+        text = json.dumps(line, ensure_ascii=True, separators=(", ", ": "))
+        if len(text) <= HEADLINE_MAX_BYTES:
+            break
+    assert len(text) <= HEADLINE_MAX_BYTES and "\n" not in text, len(text)
+    return text
+
+
+def extra_line(name, block):
+    """one untimed extra as a stdout line of its own, printable ASCII"""
+    return json.dumps({"extra": name, **_plain(block)}, ensure_ascii=True)
+
 
 
 def parse():
@@ -61,6 +187,9 @@ def parse():
                     help="skip the validate pass on mixed-length short reads and on ONT-like long reads")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-fed measurement (the same reads from pinned host RAM / from a tmpfs file)")
+    ap.add_argument("--extras-out", default=None, metavar="PATH",
+                    help="also write every untimed extra as one JSON document here (default: gpurun_out/bench_extras.json "
+                         "when gpurun_out/ exists)")
     ap.add_argument("--bgzf-helper", nargs=2, metavar=("SRC", "DST"), help=argparse.SUPPRESS)
     ap.add_argument("--gz-helper", nargs=3, metavar=("SRC", "DST", "NBYTES"), help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -966,7 +1095,7 @@ def filterpair_extra(ctx, fq, torch, dev, n, read_len):
             secs = time.perf_counter() - t0
             sizes = [os.path.getsize(os.path.join(d, o)) for o in args[2:] if os.path.exists(os.path.join(d, o))]
             program = {"records_per_file": m, "seconds": secs, "Mrecords_per_s": 2 * m / secs / 1e6, "ok": p.returncode == 0,
-                       "output_gz_GB": sum(sizes) / 1e9, "says": p.stderr.decode("latin-1")[-200:]}
+                       "output_gz_GB": sum(sizes) / 1e9}
             if os.path.exists(ref):
                 k = 500_000
                 small_img = [torch.empty(k * R + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -1381,9 +1510,18 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms,
                 "all_kernels_ms_per_step": all_ms,
                 "pipeline_achieved": algo_bytes / (all_ms * 1e-3) / 1e9,
+                "pipeline_frac": algo_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "launches": launches,
+                "launches_per_step": sum(v[0] for v in kernels.values()) / a.steps,
                 "kernels_ms_per_step": {k: v[1] / a.steps for k, v in kernels.items()},
             },
         }
+        if world == 1 and not a.no_cpu_baseline:
+            m = min(n, a.cpu_sample_reads)
+            out["cpu_baseline"] = cpu_baseline(bytes(image[: m * R].cpu().numpy()), m)
+        # the measured numbers go out before any untimed extra runs (marked "final": false); the line is printed again,
+        # complete, as the last line of stdout
+        print(headline_line(out, final=False), flush=True)
     # The extra below is the only part of a --gpus N run with collectives in the data path (RCCL all-to-all).
     # If it should hang on some topology, the line above must still come out: a watchdog prints it and ends
     # every rank.
@@ -1392,7 +1530,7 @@ def main():
     def give_up():
         if rank == 0:
             out["dedup_extra"] = {"error": "timed out (watchdog) - the headline numbers above are unaffected"}
-            print(json.dumps(out), flush=True)
+            print(headline_line(out), flush=True)
         os._exit(3)  # the headline line is out, but the run did not complete: not a success
 
     watchdog = None
@@ -1459,8 +1597,20 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
+        extras = {}
+
+        def extra(name, fn):
+            """run one untimed extra; whatever it does, the bench line still goes out; its block is a line of its own"""
+            try:
+                extras[name] = fn()
+            except Exception as e:
+                extras[name] = {"error": repr(e)[:300]}
+            print(extra_line(name, extras[name]), flush=True)
+            return extras[name]
+
         if dedup is not None:
             out["dedup_extra"] = dedup
+            print(extra_line("dedup_extra", dedup), flush=True)
         if world == 1 and not a.no_index_extra:
             # untimed extra: fastq_info's default mode = the same pass + the unique read-name index, and the file-2 loop
             # of a pair (src/fastq_info.c:333-356: the same names once more as the second file - every record finds its
@@ -1468,14 +1618,14 @@ def main():
             # streaming pass (FQG_VALIDATE_NAMES, what the programs do) and through the line index (frames that were
             # not streamed take that path).
             def default_mode(names):
-                extra = fq.abi.VALIDATE_NAMES if names else 0
+                extra_flags = fq.abi.VALIDATE_NAMES if names else 0
 
                 def index_pass(lookups):
                     acc2 = ctx.accumulator()
                     ctx.profile(True)
                     ctx.profile_reset()
                     t1 = time.perf_counter()
-                    r2 = ctx.validate(image.data_ptr(), acc2, st, final=True, flags=fq.abi.VALIDATE_COUNT_TWICE | extra, nbytes=n * R)
+                    r2 = ctx.validate(image.data_ptr(), acc2, st, final=True, flags=fq.abi.VALIDATE_COUNT_TWICE | extra_flags, nbytes=n * R)
                     idx = ctx.name_index(n)
                     if not lookups:
                         idx.expect_lookups(False)
@@ -1507,7 +1657,7 @@ def main():
                     d["pair_first_file"] = {k: d1[k] for k in ("insert_ms", "all_kernels_ms", "ms_over_validate_only")}
                     ctx.profile(True)
                     ctx.profile_reset()
-                    ctx.validate(image.data_ptr(), None, st, final=True, flags=fq.abi.VALIDATE_NO_STATS | extra, nbytes=n * R)
+                    ctx.validate(image.data_ptr(), None, st, final=True, flags=fq.abi.VALIDATE_NO_STATS | extra_flags, nbytes=n * R)
                     mr = idx.match_delete(st)
                     ctx.synchronize()
                     p3 = ctx.profile_read()
@@ -1524,71 +1674,61 @@ def main():
                     d["file2_loop"] = {"error": repr(e)[:200]}
                 return d
 
-            dm = default_mode(True)
-            dm["what"] = ("fastq_info default mode: validate + insert every read name into the GPU index (all unique), then the "
-                          "same names as a second file; header lines captured by the streaming pass")
-            dm["k_index_insert_ms"] = dm["insert_ms"]
-            try:
-                dm["through_the_line_index"] = default_mode(False)
-            except Exception as e:
-                dm["through_the_line_index"] = {"error": repr(e)[:200]}
-            out["default_mode_extra"] = dm
-        if world == 1 and not a.no_cpu_baseline:
-            m = min(n, a.cpu_sample_reads)
-            out["cpu_baseline"] = cpu_baseline(bytes(image[: m * R].cpu().numpy()), m)
+            def default_mode_both():
+                dm = default_mode(True)
+                dm["what"] = ("fastq_info default mode: validate + insert every read name into the GPU index (all unique), then "
+                              "the same names as a second file; header lines captured by the streaming pass")
+                dm["k_index_insert_ms"] = dm["insert_ms"]
+                try:
+                    dm["through_the_line_index"] = default_mode(False)
+                except Exception as e:
+                    dm["through_the_line_index"] = {"error": repr(e)[:200]}
+                return dm
+
+            extra("default_mode_extra", default_mode_both)
         if world == 1 and not a.no_e2e:
-            try:
-                out["e2e"] = e2e_block(ctx, fq, torch, dev, image, n, R, st)
-            except Exception as e:
-                out["e2e"] = {"error": repr(e)[:300]}
+            e2e = extra("e2e", lambda: e2e_block(ctx, fq, torch, dev, image, n, R, st))
             # SURVEY 8(d) "report two rates": `value` above is the kernel-side (HBM-resident) rate; this is the
             # configs[1] placement - the same reads "uncompressed in host RAM" - through the C-ABI and through the program
-            abi_leg = out["e2e"].get("abi_pinned_host_image") or {}
-            cli_leg = out["e2e"].get("cli_fastq_info_r_tmpfs_file") or {}
+            abi_leg = e2e.get("abi_pinned_host_image") or {}
+            cli_leg = e2e.get("cli_fastq_info_r_tmpfs_file") or {}
             out["host_fed"] = {
                 "what": "configs[1] placement: the same reads uncompressed in host RAM, fed over PCIe",
                 "abi_Mreads_per_s": abi_leg.get("Mreads_per_s"), "abi_GBps": abi_leg.get("PCIe_GBps"),
                 "cli_Mreads_per_s": cli_leg.get("Mreads_per_s"), "cli_GBps": cli_leg.get("GBps"),
-                "ceiling": "PCIe 5 x16, 63 GB/s spec = 180 Mreads/s at this record size (MI355X_MICROARCH.md)",
-                "target_Mreads_per_s": 50.0, "details": "e2e",
+                "ceiling": "PCIe 5 x16, 63 GB/s spec = 180 Mreads/s at this record size",
+                "target_Mreads_per_s": 50.0,
             }
         if world == 1 and not a.no_filters_extra:
-            try:
-                out["filters_extra"] = filters_extra(ctx, fq, torch, dev, image, n, R, st, a.read_len)
-            except Exception as e:
-                out["filters_extra"] = {"error": repr(e)[:300]}
+            extra("filters_extra", lambda: filters_extra(ctx, fq, torch, dev, image, n, R, st, a.read_len))
         if world == 1 and not (a.no_umi_extra and a.no_barcodes_extra and a.no_shapes_extra):
             del image
             torch.cuda.empty_cache()
         if world == 1 and not a.no_shapes_extra:
-            try:
-                out["read_shapes_extra"] = shapes_extra(ctx, fq, torch, dev)
-            except Exception as e:
-                out["read_shapes_extra"] = {"error": repr(e)[:300]}
+            extra("read_shapes_extra", lambda: shapes_extra(ctx, fq, torch, dev))
             torch.cuda.empty_cache()
         if world == 1 and not a.no_barcodes_extra:
-            try:
-                out["pre_barcodes_extra"] = barcodes_extra(ctx, fq, torch, dev, a.barcode_pairs, programs=not a.no_e2e)
-            except Exception as e:
-                out["pre_barcodes_extra"] = {"error": repr(e)[:300]}
+            extra("pre_barcodes_extra", lambda: barcodes_extra(ctx, fq, torch, dev, a.barcode_pairs, programs=not a.no_e2e))
             torch.cuda.empty_cache()
         if world == 1 and not a.no_umi_extra:
-            try:
-                out["umi_count_extra"] = umi_extra(ctx, torch, dev, a.umi_triples)
-            except Exception as e:
-                out["umi_count_extra"] = {"error": repr(e)[:300]}
+            extra("umi_count_extra", lambda: umi_extra(ctx, torch, dev, a.umi_triples))
         if world == 1 and not a.no_filterpair_extra:
-            try:
-                out["filterpair_extra"] = filterpair_extra(ctx, fq, torch, dev, a.filterpair_records, a.read_len)
-            except Exception as e:
-                out["filterpair_extra"] = {"error": repr(e)[:300]}
+            extra("filterpair_extra", lambda: filterpair_extra(ctx, fq, torch, dev, a.filterpair_records, a.read_len))
             torch.cuda.empty_cache()
         if world == 1 and not a.no_tags_extra:
+            extra("bam_add_tags_extra", lambda: bam_tags_extra(ctx, torch, dev, a.tags_alignments))
+        extras_path = a.extras_out
+        if extras_path is None and os.path.isdir(os.path.join(REPO, "gpurun_out")):
+            extras_path = os.path.join(REPO, "gpurun_out", "bench_extras.json")
+        if extras_path:
             try:
-                out["bam_add_tags_extra"] = bam_tags_extra(ctx, torch, dev, a.tags_alignments)
-            except Exception as e:
-                out["bam_add_tags_extra"] = {"error": repr(e)[:300]}
-        print(json.dumps(out), flush=True)
+                with open(extras_path, "w") as f:
+                    json.dump(_plain({"headline": json.loads(headline_line(out, extras)), "roofline_full": out["roofline"],
+                                      "cpu_baseline_full": out.get("cpu_baseline"), "dedup_extra": dedup, **extras}, sig=9), f)
+                    f.write("\n")
+            except OSError as e:
+                print(f"bench.py: could not write {extras_path}: {e}", file=sys.stderr)
+        print(headline_line(out, extras), flush=True)  # the bench line: LAST on stdout
     if world > 1:
         # every rank has what it needs; a rank that failed in the extra must not keep the others waiting in a
         # collective tear-down

@@ -1,7 +1,7 @@
 """bench.py's multi-rank control flow (barriers, max-over-ranks time, statistics merge, the cross-rank
 unique-name and pairing extra, the exit without a collective tear-down) on a ONE-GPU box: two ranks on
 GPU 0 over gloo (FQGPU_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on one device).  The numbers mean
-nothing here; the line must come out once, complete, with exit status 0."""
+nothing here; the bench line must be the last line of stdout, complete, with exit status 0."""
 import json
 import os
 import sys
@@ -35,11 +35,15 @@ def test_bench_starts_its_own_ranks():
 def check_line(p, ranks):
     assert p.returncode == 0, p.stderr.decode("latin-1")[-2000:]
     lines = [ln for ln in p.stdout.decode("latin-1").splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    # the measured line once before the extra and once, complete, as the LAST line; the extra as a line of its own
+    assert len(lines) == 3 and all(len(ln) <= 4096 for ln in (lines[0], lines[-1]))
+    first, d = json.loads(lines[0]), json.loads(lines[-1])
+    assert first["final"] is False and d["final"] is True and first["value"] == d["value"]
     assert d["n_gpus"] == ranks and d["scaling"] == "weak" and d["value"] > 0
-    assert d["steps"] == 2 and d["warmup"] == 1
-    x = d["dedup_extra"]
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["roofline"]["frac"] > 0
+    assert d["dedup"]["finding"] is None and d["dedup"]["pairing_ok"] is True
+    x = json.loads(lines[1])
+    assert x["extra"] == "dedup_extra"
     assert "error" not in x, x
     assert x["names_total"] == ranks * 2000000 and x["finding"] is None
     assert x["pairing"]["ok"] and x["pairing"]["matched"] == ranks * 2000000

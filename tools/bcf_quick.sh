@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick look at the tile kernels on the GPU (fastq_pre_barcodes + the record filters): the two bench extras alone
 mkdir -p gpurun_out/bc_quick
-python bench.py --reads ${1:-100000000} --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-shapes-extra --no-filterpair-extra --no-tags-extra > gpurun_out/bc_quick/bench.json 2> gpurun_out/bc_quick/bench.err
+python bench.py --reads ${1:-100000000} --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-shapes-extra --no-filterpair-extra --no-tags-extra --extras-out gpurun_out/bc_quick/bench.json > gpurun_out/bc_quick/bench.out 2> gpurun_out/bc_quick/bench.err
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bc_quick/bench.json"))

@@ -5,7 +5,7 @@ if [ "${1:-}" != "notest" ]; then
 python -m pytest tests/test_gpu_bam_tags.py -x -q > gpurun_out/bt_quick/pytest.txt 2>&1
 grep -n "passed\|failed\|rror" gpurun_out/bt_quick/pytest.txt | head -5
 fi
-python bench.py --reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-filterpair-extra > gpurun_out/bt_quick/bench.json 2> gpurun_out/bt_quick/bench.err
+python bench.py --reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-filterpair-extra --extras-out gpurun_out/bt_quick/bench.json > gpurun_out/bt_quick/bench.out 2> gpurun_out/bt_quick/bench.err
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bt_quick/bench.json"))

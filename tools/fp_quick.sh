@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick look at the fastq_filterpair bench extra (output under gpurun_out/fp_quick)
 mkdir -p gpurun_out/fp_quick
-python bench.py --reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-tags-extra ${FP_ARGS:-} > gpurun_out/fp_quick/bench.json 2> gpurun_out/fp_quick/bench.err
+python bench.py --reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-umi-extra --no-barcodes-extra --no-filters-extra --no-shapes-extra --no-tags-extra ${FP_ARGS:-} --extras-out gpurun_out/fp_quick/bench.json > gpurun_out/fp_quick/bench.out 2> gpurun_out/fp_quick/bench.err
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/fp_quick/bench.json"))

@@ -24,7 +24,7 @@ ONLY_UMI="--reads 4000000 --steps 2 --no-cpu-baseline --no-e2e --no-index-extra 
 for w in $WHAT; do
   case $w in
   bench)
-    python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+    python3 $R/bench.py --extras-out $O/bench.json > $O/bench_stdout.txt 2> $O/bench.err  # bench.json: headline + every extra as one document; the last line of bench_stdout.txt is the judged line
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-e2e > $O/under_rocprof.json 2> $O/under_rocprof.err
     find $O/stats -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats.csv \;
     find $O/stats -name '*kernel_trace.csv' -delete
