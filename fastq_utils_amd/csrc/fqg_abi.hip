@@ -564,6 +564,7 @@ void init_call_state(fqg_ctx* c) {
   memset(&init, 0, sizeof(init));
   init.first_key = ~0ull;
   init.stop_record = ~0ull;
+  init.trunc_record = ~0ull;
   init.qmin_byte = 255;
   init.boot_qmin = 255;
   *c->h_cs = init;
@@ -896,12 +897,12 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   }
 
   // a record that starts with NUL ends the file silently (src/fastq.c:250)
-  bool tail_is_stop = false;
+  bool tail_is_stop = false, nul_truncated = false;
   if (img_flags & kFlagNul) {
     if (n_records) {
       ProfScope ps(c, "k_find_stop");
       hipLaunchKernelGGL(k_find_stop, dim3((unsigned)((n_records + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                         c->stream, fv, c->d_cs);
+                         c->stream, fv, c->d_cs, frame_only ? 1 : 0);
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
     if (leftover && final) {
@@ -921,6 +922,11 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
     if (c->h_cs->stop_record < n_records) {
       n_records = c->h_cs->stop_record;
       out->stopped = 1;
+    }
+    if (c->h_cs->trunc_record < n_records) {  // (frame-only: an earlier record with an empty line - the file is truncated THERE)
+      n_records = c->h_cs->trunc_record;
+      out->stopped = 0;
+      nul_truncated = true;
     }
     fv.n_records = n_records;
   }
@@ -974,7 +980,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   out->n_records = n_records;
   out->n_lines = n_lines_all;
-  out->tail_lines = (final && leftover && !out->stopped && !tail_is_stop) ? (int32_t)leftover : 0;
+  out->tail_lines = nul_truncated ? 1 : (final && leftover && !out->stopped && !tail_is_stop) ? (int32_t)leftover : 0;
   out->consumed = n_records ? c->h_scalar[1] + 1 : 0;
   if (out->consumed > nbytes) out->consumed = nbytes;  // unterminated last line
 
@@ -1003,8 +1009,9 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
       out->aux0 = c->h_cs->aux0;
       out->aux1 = c->h_cs->aux1;
     }
-  } else if (final && leftover && !out->stopped && !tail_is_stop) {
-    // src/fastq.c:254-257: fewer than four lines left
+  } else if (nul_truncated || (final && leftover && !out->stopped && !tail_is_stop)) {
+    // src/fastq.c:254-257: fewer than four lines left (or, in an image that is only framed, a record with a line that
+    // starts with NUL - an empty string to the reference: n_records counts the records in front of it)
     out->code = FQG_E_TRUNCATED;
     out->record = n_records;
   } else if (tail_is_stop && !out->stopped) {
@@ -1562,9 +1569,11 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   for (int x = 1; x < kBcFiles; ++x) {
     if (!bp->present[x]) continue;
     if (!frames[x]) return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: missing frame");
-    if (frames[x]->flags & kFlagNul) return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: input holds NUL bytes");
     BcFile& f = P.f[x];
     f.fv = frames[x]->fv;
+    // NUL bytes (and the "\0\n" behind a piece of a line cut at the gzgets limits): lines are C strings (bc_clip_nul)
+    f.has_nul = (frames[x]->flags & kFlagNul) ? 1 : 0;
+    P.has_nul |= f.has_nul;
     f.first = first_record[x];
     f.present = 1;
     f.fmt = states[x].readname_format;
@@ -1846,7 +1855,6 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   memset(out, 0, sizeof(*out));
   c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
   if (fp->mode != FQG_FILTER_N && fp->mode != FQG_FILTER_POLY_AT) return fail(c, FQG_ERR_ARG, "fqg_records_filter: unknown mode");
-  if (frame->flags & kFlagNul) return fail(c, FQG_ERR_ARG, "fqg_records_filter: input holds NUL bytes");
   if (first_record + n_rec > frame->fv.n_records) return fail(c, FQG_ERR_ARG, "fqg_records_filter: records beyond the frame");
   HIP_TRY(c, hipSetDevice(c->device));
   out->n_records = n_rec;
@@ -1857,6 +1865,7 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   F.f[1].first = first_record;
   F.f[1].step = 1;
   F.f[1].present = 1;
+  F.f[1].has_nul = F.has_nul = (frame->flags & kFlagNul) ? 1 : 0;  // lines are C strings then (bc_clip_nul)
   F.n_inputs = 1;
   F.emit[1] = 1;
   RfParams P;
@@ -1956,6 +1965,7 @@ int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* recor
     if (records[k] >= frame->fv.n_records) return fail(c, FQG_ERR_ARG, "fqg_records_gather: record outside the frame");
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
+  const bool nul = (frame->flags & kFlagNul) != 0;
   const uint64_t nb = (n + kScan64Span - 1) / kScan64Span;
   if ((rc = ensure(c, c->bc_off[1], n * 8))) return rc;     // the list
   if ((rc = ensure(c, c->bc_len[1], n * 4))) return rc;
@@ -1965,8 +1975,12 @@ int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* recor
   HIP_TRY(c, hipMemcpyAsync(c->bc_off[1].p, records, n * 8, hipMemcpyHostToDevice, c->stream));
   {
     ProfScope ps(c, "k_gather_plan");
-    hipLaunchKernelGGL(k_gather_lens, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, frame->fv,
-                       (const unsigned long long*)c->bc_off[1].p, n, (uint32_t*)c->bc_len[1].p);
+    if (nul)
+      hipLaunchKernelGGL(k_gather_lens_nul, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, frame->fv,
+                         (const unsigned long long*)c->bc_off[1].p, n, (uint32_t*)c->bc_len[1].p);
+    else
+      hipLaunchKernelGGL(k_gather_lens, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, frame->fv,
+                         (const unsigned long long*)c->bc_off[1].p, n, (uint32_t*)c->bc_len[1].p);
     hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const uint32_t*)c->bc_len[1].p, n,
                        (unsigned long long*)c->bc_off[2].p, (unsigned long long*)c->bc_sum[1].p);
     hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->bc_sum[1].p, nb, d_tot);
@@ -1978,9 +1992,15 @@ int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* recor
   {
     ProfScope ps(c, "k_gather_copy");
     const unsigned grid = (unsigned)std::min<uint64_t>((n + 4 * kWave - 1) / (4 * kWave), (uint64_t)c->cu_count * 16);
-    hipLaunchKernelGGL(k_gather_copy, dim3(grid), dim3(kBlock), 0, c->stream, frame->fv,
-                       (const unsigned long long*)c->bc_off[1].p, n, (const unsigned long long*)c->bc_off[2].p,
-                       (const unsigned long long*)c->bc_sum[1].p, (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_out[1].p);
+    if (nul)  // what gzputs writes of a line is the C string: four pieces per record
+      hipLaunchKernelGGL(k_gather_copy_nul, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, (uint64_t)c->cu_count * 16)), dim3(kBlock), 0,
+                         c->stream, frame->fv, (const unsigned long long*)c->bc_off[1].p, n,
+                         (const unsigned long long*)c->bc_off[2].p, (const unsigned long long*)c->bc_sum[1].p,
+                         (uint8_t*)c->bc_out[1].p);
+    else
+      hipLaunchKernelGGL(k_gather_copy, dim3(grid), dim3(kBlock), 0, c->stream, frame->fv,
+                         (const unsigned long long*)c->bc_off[1].p, n, (const unsigned long long*)c->bc_off[2].p,
+                         (const unsigned long long*)c->bc_sum[1].p, (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_out[1].p);
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());

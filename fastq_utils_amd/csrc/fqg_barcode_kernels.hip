@@ -40,6 +40,8 @@ struct BcFile {
   uint32_t add;    // 1 for the second interleaved reference
   int32_t present;
   int32_t fmt;     // read-name format of this file
+  int32_t has_nul; // the image holds NUL bytes: lines are C strings (bc_clip_nul)
+  int32_t pad_;
 };
 
 struct BcParams {
@@ -48,6 +50,7 @@ struct BcParams {
   int32_t umi_read, cell_read, sample_read;
   int32_t phred, min_qual;
   int32_t out_sam, tenx;
+  int32_t has_nul;  // some input's image holds NUL bytes: every tile takes the record-by-record kernels (bc_clip_nul)
   int32_t ablate;  // measurement only (FQGPU_BC_ABL, SAM emit): 1 = no line is written, 2 = no flush, 4 = no name check, 8 = no landing of the spans
   int32_t emit[3];
   int64_t umi_off, umi_size, cell_off, cell_size, sample_off, sample_size;
@@ -75,6 +78,31 @@ __device__ __forceinline__ bool bc_has(const BcParams& P, int x) {
   return MASK ? ((MASK >> x) & 1) != 0 : P.f[x].present != 0;
 }
 
+// A line as the reference holds it: gzgets puts it into a buffer and everything after that is a C string function
+// (strlen, gzputs, printf("%s"), strncpy, the scans) - the line ENDS at its first NUL byte, and a line that ends there
+// has no '\n'.  This is also what a line cut at the gzgets limits is (host/fq_reframe.h: the piece is followed by
+// "\0\n").  Only images that hold a NUL byte come here (BcFile::has_nul); the line is in global memory.
+__device__ inline void bc_clip_nul(BcLine& l) {
+  const uint32_t n = l.len;
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    __builtin_memcpy(&w, l.p + i, 8);
+    const uint64_t z = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;  // 0x80 in the lowest zero byte (and maybe above it)
+    if (z) {
+      l.len = i + ((uint32_t)__builtin_ctzll(z) >> 3);
+      l.nl = 0;
+      return;
+    }
+  }
+  for (; i < n; ++i)
+    if (l.p[i] == 0) {
+      l.len = i;
+      l.nl = 0;
+      return;
+    }
+}
+
 __device__ __forceinline__ void bc_lines(const BcFile& f, uint64_t k, BcLine ln[4]) {
   const uint64_t r = f.first + k * f.step + f.add;
   uint64_t prev = r == 0 ? ~0ull : f.fv.line_end[4 * r - 1];
@@ -85,6 +113,10 @@ __device__ __forceinline__ void bc_lines(const BcFile& f, uint64_t k, BcLine ln[
     ln[i].len = (uint32_t)(e - prev - 1);
     ln[i].nl = e < f.fv.nbytes ? 1u : 0u;
     prev = e;
+  }
+  if (f.has_nul) {
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) bc_clip_nul(ln[i]);
   }
 }
 
@@ -681,7 +713,8 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
     BcLine L[kBcFiles][4];
     geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);  // the next tile's index (requested without a branch)
-    const bool fit = bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
+    // (an image with NUL bytes: lines are C strings, found by scanning them where they lie - bc_lines)
+    const bool fit = !P.has_nul && bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     BcTags t;
@@ -716,7 +749,7 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
       const uint32_t sa = wave_sum32(mine ? a : 0u), sb = wave_sum32(mine ? b : 0u), sc = wave_sum32(mine ? c : 0u);
       const bool fits_in = bc_emit_tile_fits<MASK>(P, cur, (int)first, (int)last, tc.in_cap);
       if (lane == 0) {
-        const bool big = !fits_in || sa + 32 > tc.out_cap || sb + 32 > tc.out_cap || sc + 32 > tc.out_cap;
+        const bool big = P.has_nul || !fits_in || sa + 32 > tc.out_cap || sb + 32 > tc.out_cap || sc + 32 > tc.out_cap;
         tile_big[tile * tc.plan_m + j] = big ? 1 : 0;
         if (big) atomicAdd(&call->big, 1ull);
       }

@@ -83,6 +83,8 @@ struct CallState {
   unsigned int redo_count;            // streaming pass: chunks whose checks must be repeated
   unsigned int boot_qmin, boot_qmax;  // streaming pass: quality range of the image's first records
   unsigned int boot_lines;            // streaming pass: newlines in the boot window (mean record size -> NameCapture::K)
+  unsigned int pad_;
+  unsigned long long trunc_record;    // frame-only images: min record whose 2nd, 3rd or 4th line starts with NUL
 };
 
 // Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_rf_tile_flags(BcParams F, BcTile tc,
     const uint32_t skew = (uint32_t)((uintptr_t)(f.fv.img + s0) & 15u);
     bool fit = n <= (uint64_t)tc.in_cap;
     if (fit) fit = (uint64_t)((skew + (uint32_t)n + 15u) >> 4) * 16u + 32u <= (uint64_t)tc.in_cap;
-    big = !fit || sum + 32 > tc.out_cap;
+    big = F.has_nul || !fit || sum + 32 > tc.out_cap;  // (NUL bytes: lines are C strings - the record-by-record kernel, bc_lines)
     tile_big[tile] = big ? 1 : 0;
   }
   const unsigned long long m = __ballot(big);
@@ -450,6 +450,44 @@ __global__ __launch_bounds__(kBlock) void k_gather_copy(FrameView f, const unsig
         else
           for (uint32_t q = o; q < L; ++q) dst[q] = src[q];
       }
+    }
+  }
+}
+
+// ... of an image with NUL bytes: what GZ_WRITE / gzputs write of a line is the C string (bc_clip_nul) - four pieces per
+// record.  Such images are rare and small: one wavefront per record, byte by byte.
+__device__ __forceinline__ void gather_lines_nul(const FrameView& f, uint64_t r, BcLine ln[4]) {
+  BcFile bf;
+  bf.fv = f;
+  bf.first = 0;
+  bf.step = 1;
+  bf.add = 0;
+  bf.has_nul = 1;
+  bc_lines(bf, r, ln);
+}
+__global__ __launch_bounds__(kBlock) void k_gather_lens_nul(FrameView f, const unsigned long long* __restrict__ list,
+                                                            uint64_t n, uint32_t* __restrict__ lens) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  BcLine ln[4];
+  gather_lines_nul(f, list[k], ln);
+  lens[k] = ln[0].len + ln[0].nl + ln[1].len + ln[1].nl + ln[2].len + ln[2].nl + ln[3].len + ln[3].nl;
+}
+__global__ __launch_bounds__(kBlock) void k_gather_copy_nul(FrameView f, const unsigned long long* __restrict__ list, uint64_t n,
+                                                            const unsigned long long* __restrict__ off_local,
+                                                            const unsigned long long* __restrict__ off_span,
+                                                            uint8_t* __restrict__ out) {
+  const int lane = (int)(threadIdx.x & 63);
+  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  for (uint64_t k = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); k < n; k += n_waves) {
+    BcLine ln[4];
+    gather_lines_nul(f, list[k], ln);
+    uint8_t* dst = out + off_local[k] + off_span[k / kScan64Span];
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t m = ln[i].len + ln[i].nl;  // (a line that kept its '\n' holds no NUL: the newline is the byte behind its text)
+      for (uint32_t o = (uint32_t)lane; o < m; o += kWave) dst[o] = ln[i].p[o];
+      dst += m;
     }
   }
 }

@@ -857,11 +857,22 @@ __global__ __launch_bounds__(kBlock) void k_records_fast(FrameView f, int space,
 
 // first record whose first line starts with a NUL byte (src/fastq.c:250): only launched for
 // images that contain NUL bytes at all
-__global__ __launch_bounds__(kBlock) void k_find_stop(FrameView f, CallState* __restrict__ cs) {
+// also_lines (images that are only framed: nobody else looks at the records): a sequence, second header or quality line
+// that starts with NUL is an empty string in the reference's buffer - "file truncated" at that record (src/fastq.c:254)
+__global__ __launch_bounds__(kBlock) void k_find_stop(FrameView f, CallState* __restrict__ cs, int also_lines) {
   const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= f.n_records) return;
   const uint64_t s = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
   if (f.img[s] == 0) atomicMin(&cs->stop_record, (unsigned long long)r);
+  else if (also_lines) {
+    bool cut = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const uint64_t b = f.line_end[4 * r + i] + 1;  // (an unterminated last line is line 4: b < nbytes here)
+      cut |= b < f.nbytes && f.img[b] == 0;
+    }
+    if (cut) atomicMin(&cs->trunc_record, (unsigned long long)r);
+  }
 }
 
 // lines [first, f.n_lines) against the gzgets limits of the reference (src/fastq.c:249-253): the record of the first

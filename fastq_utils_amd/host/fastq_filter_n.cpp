@@ -9,6 +9,7 @@
 using namespace fqhost;
 
 int main(int argc, char** argv) {
+  fqhost::install_counted_output(argv);  // (fq_respawn.h: a run that starts over on input cut at the gzgets limits prints nothing twice)
   int nopt = 0, c;
   opterr = 0;
   fprintf(stderr, "fastq_utils %s\n", "0.25.3");

@@ -43,7 +43,7 @@ void emit(const fqg_frame* frame, const std::vector<uint64_t>& list, Out* out, s
   if (host.size() < bytes) host.resize(bytes);
   LIB(fqg_records_gather_output(g_ctx, host.data(), bytes));
   if (!out->write(host.data(), bytes)) {
-    FQ_PRINT_ERROR("%s.\n", "write error");  // GZ_WRITE, src/fastq.c:211-235
+    FQ_PRINT_ERROR("%s.\n", out->error().c_str());  // GZ_WRITE's gzerror() text, src/fastq.c:211-235
     fqhost::leave(kExitSys);
   }
 }
@@ -59,6 +59,7 @@ void close_out(Out* g) {  // fastq_destroy -> fastq_close (src/fastq.c:615-629)
 }  // namespace
 
 int main(int argc, char** argv) {
+  fqhost::install_counted_output(argv);  // (fq_respawn.h: a run that starts over on input cut at the gzgets limits prints nothing twice)
   fprintf(stderr, "fastq_utils %s\n", "0.25.3");  // fastq_print_version
   if (argc != 6 && argc != 7) {
     fprintf(stderr, "Usage: filterpair fastq1 fastq2 paired1 paired2 unpaired [sorted]\n");
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
     probe_piece(pr2, in2.data(), in2.size(), 1);
     fqg_validate_result r2;
     LIB(fqg_validate(g_ctx, nullptr, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st,
-                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | FQG_VALIDATE_NAMES, &r2));
+                     FQG_VALIDATE_FRAME_ONLY | FQG_VALIDATE_NO_STATS | FQG_VALIDATE_NAMES | in2.vflags(), &r2));
     if (r2.code == FQG_E_LINE_TOO_LONG) fail_too_long(path2, r2.record);
     const uint64_t n2 = r2.n_records;
     std::vector<uint64_t> match(n2 ? n2 : 1), p1, p2, u2;

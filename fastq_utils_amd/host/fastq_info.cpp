@@ -55,7 +55,7 @@ void run_single_noindex(const char* path, Stats& S) {
     const uint64_t& p;
     const uint64_t& b;
     ~Report() {
-      if (on) fprintf(stderr, "\nfqgpu timing: %llu pieces, %.3f GB; waiting for the reader %.3f s, copy + validate %.3f s; %.3f s since the program started\n",
+      if (on) fprintf(fqhost::diag(), "\nfqgpu timing: %llu pieces, %.3f GB; waiting for the reader %.3f s, copy + validate %.3f s; %.3f s since the program started\n",
                       (unsigned long long)p, b / 1e9, w, g, (double)clock() / CLOCKS_PER_SEC >= 0 ? since_start() : 0.0);
     }
   } report{timing, t_wait, t_gpu, n_pieces, n_bytes};
@@ -67,7 +67,7 @@ void run_single_noindex(const char* path, Stats& S) {
     fqg_validate_result r;
     LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st, in.vflags(), &r));
     if (timing) {
-      if (!n_pieces) fprintf(stderr, "fqgpu timing: first piece in hand %.3f s, validated %.3f s after the program started\n",
+      if (!n_pieces) fprintf(fqhost::diag(), "fqgpu timing: first piece in hand %.3f s, validated %.3f s after the program started\n",
                              since_start() - (now() - t1), since_start());
       t_wait += t1 - t0;
       t_gpu += now() - t1;
@@ -879,7 +879,7 @@ int main(int argc, char** argv) {
   const std::vector<int> devices = devices_from_env();  // FQGPU_DEVICES=0,1,..: the -r pass over several GPUs
   fqhost::keep_slots_until_exit() = true;
   int rc = fqg_open(!devices.empty() ? devices[0] : dev ? atoi(dev) : 0, &g_ctx);
-  if (getenv("FQGPU_TIMING")) fprintf(stderr, "fqgpu timing: context open %.3f s after the program started\n", since_start());
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: context open %.3f s after the program started\n", since_start());
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);
     fqhost::leave(kExitSys);
@@ -967,7 +967,7 @@ int main(int argc, char** argv) {
   LIB(fqg_acc_median(S.acc1, S.acc2, &med));
   fprintf(stderr, "Read length: %lu %lu %u\n", min_rl - 1, max_rl - 1, (unsigned)(med - 1));
   fprintf(stderr, "OK\n");
-  if (getenv("FQGPU_TIMING")) fprintf(stderr, "fqgpu timing: summary printed %.3f s after the program started\n", since_start());
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: summary printed %.3f s after the program started\n", since_start());
   if (const char* jm = getenv("FQGPU_JSON_METRICS")) {
     // SURVEY 5 "metrics": the machine-readable twin of the summary above, as an EXTRA that leaves the command line and
     // both output streams as the reference has them - one JSON object written to the file the variable names

@@ -135,9 +135,13 @@ bool probe_bytes(const char* data, size_t size, fqg_file_state* st, std::string*
   return true;
 }
 
-// the reference reads a line beyond its gzgets buffers in pieces (src/fastq.c:249-253) and goes on out of step; this
-// program copies records, it does not reproduce that: refused, loudly
+// The reference reads a line beyond its gzgets buffers in pieces (src/fastq.c:249-253) and goes on out of step, every
+// piece a line of its own.  Everything in front of this piece of input went the reference's way; the program runs itself
+// again, as a child and on one device, on input that is cut where gzgets cuts it (fq_respawn.h, fq_reframe.h: inflated
+// input is cut while it is read and never comes here) - every piece a line, a C string to the kernels as to the
+// reference.  Only a stream that cannot be read twice is refused.
 [[noreturn]] void refuse_long_line(const char* path, uint64_t record) {
+  if (fqhost::reframe_supported() && !fqhost::reframing() && strcmp(path, "-") != 0) fqhost::respawn_reframed();
   FQ_PRINT_ERROR("Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes)", path,
                  (unsigned long)(record + 1), FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
   fflush(stdout);
@@ -170,17 +174,20 @@ bool refill(Source& s) {
   probe(s);
   fqg_validate_result r;
   LIB(fqg_validate(g_ctx, nullptr, s.in->data(), s.in->size(), FQG_MEM_HOST, s.in->final() ? 1 : 0, &s.st,
-                   FQG_VALIDATE_FRAME_ONLY, &r));
+                   FQG_VALIDATE_FRAME_ONLY | s.in->vflags(), &r));
   if (r.code == FQG_E_LINE_TOO_LONG) refuse_long_line(s.in->path().c_str(), s.records_before + r.record);
-  const bool ends_here = r.stopped != 0;  // a header line that starts with a NUL byte: "no entry" (src/fastq.c:250), the input ends
+  bool ends_here = r.stopped != 0;  // a header line that starts with a NUL byte: "no entry" (src/fastq.c:250), the input ends
   if (ends_here)  // the records in front of it, framed alone
-    LIB(fqg_validate(g_ctx, nullptr, s.in->data(), r.consumed, FQG_MEM_HOST, 1, &s.st, FQG_VALIDATE_FRAME_ONLY, &r));
-  s.final_piece = s.in->final() || ends_here;
+    LIB(fqg_validate(g_ctx, nullptr, s.in->data(), r.consumed, FQG_MEM_HOST, 1, &s.st, FQG_VALIDATE_FRAME_ONLY | s.in->vflags(), &r));
+  // a record with a sequence / second header / quality line that starts with NUL: an empty string to the reference - the
+  // file is truncated THERE (src/fastq.c:254; tail_lines > 0), whatever follows
+  const bool cut_short = !ends_here && r.code == FQG_E_TRUNCATED && !s.in->final();
+  s.final_piece = s.in->final() || ends_here || cut_short;
   s.tail_lines = r.tail_lines;
   s.open_end = s.final_piece && !ends_here && r.tail_lines == 0 && r.n_records > 0 && s.in->size() > 0 && s.in->data()[s.in->size() - 1] != '\n';
   s.avail = r.n_records;
   if (r.n_records) LIB(fqg_frame_retain(g_ctx, &s.frame));
-  if (!s.in->final() && !ends_here) {
+  if (!s.in->final() && !ends_here && !cut_short) {
     s.carry_pending = true;
     s.carry_at = r.consumed;
   } else s.exhausted = true;
@@ -240,6 +247,8 @@ struct BlockRun {
     bool final[6] = {false, false, false, false, false, false};
     bool open_end[6] = {false, false, false, false, false, false};  // see Source::open_end
     bool ends = false;                            // an input ends inside this unit although its block is not the last
+    int long_line_file = 0;                       // an input of this unit has a line beyond the gzgets limits ...
+    uint64_t long_line_record = 0;                // ... in this record of the file
     std::vector<char> out[3];
     std::string wrong_header;                     // the text of the header line of a FQG_E_WRONG_HEADER finding
   };
@@ -293,15 +302,19 @@ struct BlockRun {
             lib_fail("fqg_validate", rc);
             break;
           }
-          if (r.code == FQG_E_LINE_TOO_LONG) {
+          if (r.code == FQG_E_LINE_TOO_LONG) {  // (the thread that takes the results starts the program over: refuse_long_line)
+            u.long_line_file = x;
+            u.long_line_record = u.seq * B + r.record;
             u.rc = FQG_ERR_ARG;
-            u.err = std::string("fqg_validate: ") + A.file[x] + " has a line longer than the reference's line buffers (record " +
-                    std::to_string(u.seq * B + r.record + 1) + "); the reference reads such a line in pieces, this program refuses it";
             break;
           }
           // a header line that starts with a NUL byte is "no entry" for the reference (src/fastq.c:250): this input ends
           // HERE, cleanly, whatever follows - the unit is the last one the consumer looks at
           const bool ends_here = r.stopped != 0;
+          // ... and another line of a record that starts with NUL is an empty string: the file is truncated there
+          // (src/fastq.c:254; tail_lines > 0) - the last unit as well
+          const bool cut_short = !ends_here && r.code == FQG_E_TRUNCATED && !b[x].final;
+          if (cut_short) u.ends = true;
           if (ends_here) {
             // frame the records in front of it once more, alone: what follows the NUL is not this file's any more
             u.ends = true;
@@ -311,14 +324,14 @@ struct BlockRun {
               break;
             }
           }
-          if (!b[x].final && !ends_here && (r.n_records != B || r.consumed != b[x].size)) {
+          if (!b[x].final && !ends_here && !cut_short && (r.n_records != B || r.consumed != b[x].size)) {
             u.rc = FQG_ERR_STATE;
             u.err = std::string("a block of ") + A.file[x] + " cut at a record boundary was not consumed whole";
             break;
           }
           u.records[x] = r.n_records;
           u.tail_lines[x] = ends_here ? 0 : r.tail_lines;
-          u.final[x] = b[x].final || ends_here;
+          u.final[x] = b[x].final || ends_here || cut_short;
           u.open_end[x] = b[x].final && !ends_here && r.tail_lines == 0 && r.n_records > 0 && b[x].size > 0 && b[x].data[b[x].size - 1] != '\n';
           u.n = std::min<uint64_t>(u.n, r.n_records);
           if (r.n_records) {
@@ -387,6 +400,7 @@ struct BlockRun {
     }
     if (u.rc) {
       join_all();
+      if (u.long_line_file) refuse_long_line(A.file[u.long_line_file], u.long_line_record);
       FQ_PRINT_ERROR("GPU library failure in %s (%d)", u.err.c_str(), u.rc);
       fqhost::leave(kExitSys);
     }
@@ -407,7 +421,7 @@ struct BlockRun {
       for (int which = 1; which < 3; ++which)
         if (r.out_bytes[which] && !A.outgz[which].write(u.out[which].data(), r.out_bytes[which])) {
           join_all();
-          FQ_PRINT_ERROR("%s.\n", "write error");
+          FQ_PRINT_ERROR("%s.\n", A.outgz[which].error().c_str());  // GZ_WRITE's gzerror() text, src/fastq.c:211-235
           fqhost::leave(kExitSys);
         }
       const unsigned long before = processed;
@@ -469,6 +483,7 @@ struct BlockRun {
 }  // namespace
 
 int main(int argc, char** argv) {
+  fqhost::install_counted_output(argv);  // (fq_respawn.h: a run that starts over on input cut at the gzgets limits prints nothing twice)
   static int verbose = 0, paired = 0, help = 0, out_sam = 0, tenx = 0;
   fqg_barcode_params P;
   memset(&P, 0, sizeof(P));
@@ -738,7 +753,10 @@ int main(int argc, char** argv) {
   outq.start();
   auto drain_or_die = [&] {
     if (!outq.drain()) {
-      FQ_PRINT_ERROR("%s.\n", "write error");
+      const char* why = "write error";
+      for (int which = 1; which < 3; ++which)
+        if (!outgz[which].error().empty()) why = outgz[which].error().c_str();
+      FQ_PRINT_ERROR("%s.\n", why);  // GZ_WRITE's gzerror() text, src/fastq.c:211-235
       fqhost::leave(kExitSys);
     }
   };
@@ -863,7 +881,7 @@ int main(int argc, char** argv) {
   drain_or_die();
   outq.stop();
   if (timing)
-    fprintf(stderr, "\nfqgpu timing: reading + framing %.3f s, transform %.3f s, output D2H %.3f s, waiting for the writer %.3f s; "
+    fprintf(fqhost::diag(), "\nfqgpu timing: reading + framing %.3f s, transform %.3f s, output D2H %.3f s, waiting for the writer %.3f s; "
                     "the writer (gzip / stdout) worked %.3f s beside them\n", t_refill, t_transform, t_fetch, t_hand, outq.t_write);
   // an incomplete record where the next read would have happened is a truncated file
   // (src/fastq.c:254-257); a clean end of any input just ends the loop - and so does the loop's own condition

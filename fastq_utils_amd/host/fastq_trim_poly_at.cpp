@@ -30,6 +30,7 @@ static void print_usage() {  // src/fastq_trim_poly_at.c:121-133
 }
 
 int main(int argc, char** argv) {
+  fqhost::install_counted_output(argv);  // (fq_respawn.h: a run that starts over on input cut at the gzgets limits prints nothing twice)
   const char* file = nullptr;
   const char* outfile = nullptr;
   long min_poly_at_len = 10, min_len = 10;
@@ -104,7 +105,7 @@ int main(int argc, char** argv) {
       ctx, file, fp,
       [&](const char* text, size_t n) {
         if (!out.write(text, n)) {
-          FQ_PRINT_ERROR("%s.\n", "write error");
+          FQ_PRINT_ERROR("%s.\n", out.error().c_str());  // GZ_WRITE's gzerror() text, src/fastq.c:211-235
           fqhost::leave(kExitSys);
         }
       },

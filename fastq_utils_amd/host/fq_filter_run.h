@@ -40,9 +40,15 @@ inline FilterTotals run_filter(fqg_ctx* ctx, const char* path, const fqg_filter_
   int tail_lines = 0;
   while (in.next()) {
     fqg_validate_result r;
-    lib(fqg_validate(ctx, nullptr, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &st, FQG_VALIDATE_FRAME_ONLY, &r),
+    lib(fqg_validate(ctx, nullptr, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &st,
+                     FQG_VALIDATE_FRAME_ONLY | in.vflags(), &r),
         "fqg_validate");
-    if (r.code == FQG_E_LINE_TOO_LONG) {  // (the reference would read it in pieces, src/fastq.c:249-253: DESIGN.md 7.1)
+    if (r.code == FQG_E_LINE_TOO_LONG) {
+      // The reference reads such a line in pieces (src/fastq.c:249-253) and copies the pieces.  Everything in front of
+      // this piece of input went the reference's way; the program runs itself again, as a child, on input that is cut
+      // where gzgets cuts it (fq_respawn.h, fq_reframe.h: inflated input and stdin are cut while they are read and never
+      // come here), where every piece is a line - a C string to the kernels, as it is to the reference.
+      if (reframe_supported() && !reframing() && strcmp(path, "-") != 0) respawn_reframed();
       FQ_PRINT_ERROR("Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes)", path,
                      t.processed + (unsigned long)r.record + 1, FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
       fflush(stdout);
@@ -66,6 +72,9 @@ inline FilterTotals run_filter(fqg_ctx* ctx, const char* path, const fqg_filter_
       t.discarded += fr.n_discarded;
       progress(before, t.processed);
     }
+    // a record whose first line starts with a NUL byte: "no entry", the loop ends (src/fastq.c:250); one with another
+    // line that starts with NUL: an empty string - the file is truncated there (tail_lines says so)
+    if (r.stopped || r.code == FQG_E_TRUNCATED) break;
     if (!in.final()) in.carry_from(r.consumed);
   }
   if (tail_lines > 0) {

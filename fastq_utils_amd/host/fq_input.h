@@ -164,7 +164,7 @@ inline std::unique_ptr<ParallelGunzip> open_pgzip(int fd, uint64_t size, const c
 inline void pgzip_report(const ParallelGunzip* pg, const std::string& path) {
   if (!pg || !(getenv("FQGPU_PGZIP_DEBUG") || getenv("FQGPU_TIMING"))) return;
   const ParallelGunzip::Stats& st = pg->stats();
-  fprintf(stderr, "fqgpu timing: %s inflated by chunks: %llu rounds, %llu chunks joined, %llu without a block start, %llu wrong guesses, "
+  fprintf(fqhost::diag(), "fqgpu timing: %s inflated by chunks: %llu rounds, %llu chunks joined, %llu without a block start, %llu wrong guesses, "
           "%llu members%s%s; reading %.3f s, finding + inflating %.3f s, joining %.3f s, markers -> bytes + CRC-32 %.3f s\n",
           path.c_str(), (unsigned long long)st.batches, (unsigned long long)st.chunks_joined, (unsigned long long)st.chunks_not_found,
           (unsigned long long)st.chunks_discarded, (unsigned long long)st.members, st.fell_back ? "; one zlib stream from: " : "",

@@ -18,10 +18,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -166,43 +168,80 @@ class GzipMembers {
     // FQGPU_GZIP_FAST=1: the members from fq_fastdeflate.h instead of zlib's - three times as fast as the reference's
     // level 4 and a tenth larger (zlib level 1's size class)
     if (const char* e = getenv("FQGPU_GZIP_FAST")) fast_ = atoi(e) != 0;
-    if (path[0] == '-' && path[1] == 0) f_ = stdout;
-    else {
+    if (path[0] == '-' && path[1] == 0) {
+      f_ = stdout;
+      name_ = "<fd:1>";  // (what zlib's gzdopen calls it in its messages)
+    } else {
       f_ = fopen(path, "wb");
       own_ = true;
+      name_ = path;
     }
     return f_ != nullptr;
   }
+  // what gzerror() would say about the write that failed (zlib's gz_error: "<path>: <text>", the text being
+  // strerror(errno) for a failed write(2) and "out of memory" for a failed deflate)
+  const std::string& error() const { return err_; }
+  // Every member holds exactly 1 MiB of text (the last one the rest), whatever the sizes of the calls: the bytes
+  // written are a function of the text alone.  A run that starts over on re-framed input (fq_respawn.h) skips as many
+  // bytes of its stdout as the first run wrote - they must be the same bytes, though the two runs cut their input into
+  // different pieces.  Text short of a member waits in pend_ (the first run never writes it).
   bool write(const char* text, size_t n) {
-    if (!n) return true;
     const size_t block = 1u << 20;  // (a member per MiB: a piece of 128 MiB is work for every core)
-    const size_t nb = (n + block - 1) / block;
-    std::vector<std::vector<uint8_t>> out(nb);
-    std::atomic<bool> ok{true};
-    parallel_items(nb, [&](size_t i) {
-      const size_t from = i * block, len = std::min(block, n - from);
-      if (!member(text + from, len, out[i])) ok = false;
-    });
-    if (!ok) return false;
-    for (auto& m : out)
-      if (fwrite(m.data(), 1, m.size(), f_) != m.size()) return false;
-    wrote_ = true;
+    if (!pend_.empty()) {
+      const size_t take = std::min(block - pend_.size(), n);
+      pend_.append(text, take);
+      text += take;
+      n -= take;
+      if (pend_.size() < block) return true;
+      std::vector<uint8_t> m;
+      if (!member(pend_.data(), pend_.size(), m)) {
+        err_ = name_ + ": out of memory";
+        return false;
+      }
+      pend_.clear();
+      if (!put(m)) return false;
+    }
+    const size_t nb = n / block;
+    if (nb) {
+      std::vector<std::vector<uint8_t>> out(nb);
+      std::atomic<bool> ok{true};
+      parallel_items(nb, [&](size_t i) {
+        if (!member(text + i * block, block, out[i])) ok = false;
+      });
+      if (!ok) {
+        err_ = name_ + ": out of memory";
+        return false;
+      }
+      for (auto& m : out)
+        if (!put(m)) return false;
+    }
+    pend_.assign(text + nb * block, n - nb * block);
     return true;
   }
   bool close() {
     bool ok = true;
     if (!f_) return true;
-    if (!wrote_) {  // an empty gzip stream is still a gzip stream
+    if (!pend_.empty() || !wrote_) {  // the rest - and an empty gzip stream is still a gzip stream
       std::vector<uint8_t> m;
-      ok = member("", 0, m) && fwrite(m.data(), 1, m.size(), f_) == m.size();
+      ok = member(pend_.data(), pend_.size(), m) && put(m);
+      pend_.clear();
     }
     if (own_) ok = fclose(f_) == 0 && ok;
     else ok = fflush(f_) == 0 && ok;
+    if (!ok && err_.empty()) err_ = name_ + ": " + strerror(errno);
     f_ = nullptr;
     return ok;
   }
 
  private:
+  bool put(const std::vector<uint8_t>& m) {
+    if (fwrite(m.data(), 1, m.size(), f_) != m.size()) {
+      err_ = name_ + ": " + strerror(errno);
+      return false;
+    }
+    wrote_ = true;
+    return true;
+  }
   bool member(const char* p, size_t n, std::vector<uint8_t>& out) const {
     if (fast_) return fdef::gzip_member_fast(p, n, out);
     z_stream zs;
@@ -219,6 +258,7 @@ class GzipMembers {
     return rc == Z_STREAM_END;
   }
   FILE* f_ = nullptr;
+  std::string name_, err_, pend_;
   bool own_ = false, wrote_ = false, fast_ = false;
   int level_ = 4;
 };

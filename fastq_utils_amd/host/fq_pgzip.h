@@ -339,9 +339,12 @@ struct MemberEnd {
   uint32_t crc, isize;
 };
 
-// gzip member header at p (RFC 1952 2.3): its length; 0 = more bytes needed; -1 = no gzip magic (or fewer than two
-// bytes: what zlib's gzread takes for trailing garbage); -2 = magic, but a method or flags that zlib refuses
-inline long gzip_header_len(const uint8_t* p, size_t n) {
+// gzip member header at p (RFC 1952 2.3): its length; 0 = more bytes needed; -1 = no gzip magic (or, AT THE END OF
+// THE FILE, fewer than two bytes: what zlib's gzread takes for trailing garbage); -2 = magic, but a method or flags
+// that zlib refuses.  eof = the n bytes are all the file has: only then do 0 or 1 bytes decide anything - in the
+// middle of a file they are where a window ended, and the next member may start right there.
+inline long gzip_header_len(const uint8_t* p, size_t n, bool eof) {
+  if (n < 2 && !eof && (n == 0 || p[0] == 0x1f)) return 0;
   if (n < 2 || p[0] != 0x1f || p[1] != 0x8b) return -1;
   if (n < 10) return 0;
   if (p[2] != 8 || (p[3] & 0xe0)) return -2;
@@ -499,7 +502,7 @@ class Inflate16 {
       const size_t next = at + 8;
       long hl = -1;
       if (!(next == nvalid && eof)) {
-        hl = gzip_header_len(base + next, nvalid - next);
+        hl = gzip_header_len(base + next, nvalid - next, eof);
         if (hl == 0) return leave(eof ? kBad : kNeedInput);  // (a header the file ends in: zlib's "unexpected end of file")
         if (hl == -2) return leave(kBad);
         if (hl > 0 && next + (size_t)hl >= nvalid && !eof) return leave(kNeedInput);
@@ -768,7 +771,7 @@ class ParallelGunzip {
     if (!load(n)) return 0;
     const bool eof = coff_ + n == size_;
     if (!in_member_) {  // a member's header is expected at byte 0
-      const long hl = gzip_header_len(cbuf_, cn_);
+      const long hl = gzip_header_len(cbuf_, cn_, eof);
       if (hl == -1) {
         if (first_member_) fall_back("no gzip header");  // (not reached: the caller looked at the magic)
         else done_ = true;  // bytes behind the last member: gzread ignores them
@@ -1149,7 +1152,7 @@ class ParallelGunzip {
           done_ = true;
           break;
         }
-        const long hl = gzip_header_len(hdr.data(), hdr.size());
+        const long hl = gzip_header_len(hdr.data(), hdr.size(), coff_ == size_);
         if (hl == -1) {
           if (first_member_) {  // no gzip file at all: gzread hands out the bytes as they are
             transparent_ = true;

@@ -50,6 +50,18 @@ inline bool& reframe_supported() {
   return v;
 }
 
+// Where diagnostics go (FQGPU_TIMING, FQGPU_PGZIP_DEBUG): fd 2 itself, NOT the counted stream.  Their text carries
+// times and differs from run to run, so it must neither be counted in the parent (the child's text of the same lines
+// has another length: the skip would cut the child's real output in the wrong place) nor be dropped in the child.
+inline FILE* diag() {
+  static FILE* f = [] {
+    FILE* g = fdopen(dup(2), "w");
+    if (g) setvbuf(g, nullptr, _IONBF, 0);
+    return g;
+  }();
+  return f ? f : stderr;
+}
+
 inline ssize_t counted_write(void* cookie, const char* buf, size_t n) {
   CountedStream* c = static_cast<CountedStream*>(cookie);
   c->written += n;

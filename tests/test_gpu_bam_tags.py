@@ -16,30 +16,41 @@ import pytest
 
 from oracle import bam_tags_oracle as bto
 from tests import bamgen
-from tests.util import GOLD, REPO
+from tests.util import GOLD, REPO, SideBySide
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(REPO, "bin", "bam_add_tags")
 GOLDEN = json.load(open(os.path.join(GOLD, "bam_tags.json")))
 
 
-@pytest.mark.parametrize("case", GOLDEN, ids=lambda c: " ".join(c["args"])[-70:] or "no arguments")
-def test_golden_invocations(case):
+def golden_run(i):
+    case = GOLDEN[i]
     with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
         rel = os.path.relpath(tmp, GOLD)
         args = [rel + "/o.bam" if a == "OUT" else a for a in case["args"]]
         p = subprocess.run(["bam_add_tags"] + args, executable=BIN, cwd=GOLD, capture_output=True, timeout=300)
-        assert p.returncode == case["exit"], p.stderr[-500:]
-        assert p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/") == case["stderr"]
         path = os.path.join(tmp, "o.bam")
-        if not case["stdout_is_bam"]:
-            assert os.path.exists(path) == case["out_created"]
-            assert p.stdout.decode("latin-1") == case.get("stdout", "")
-        if "out_sha256" in case:
-            blob = p.stdout if case["stdout_is_bam"] else open(path, "rb").read()
-            data = gzip.decompress(blob)
-            assert len(data) == case["out_bytes"]
-            assert hashlib.sha256(data).hexdigest() == case["out_sha256"]
+        written = open(path, "rb").read() if os.path.exists(path) else None
+    return p.returncode, p.stdout, p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"), written
+
+
+# (the programs of all cases start side by side the first time one is asked for: tests/util.py)
+GOLDEN_RUNS = SideBySide(golden_run, range(len(GOLDEN)))
+
+
+@pytest.mark.parametrize("i", range(len(GOLDEN)), ids=[" ".join(c["args"])[-70:] or "no arguments" for c in GOLDEN])
+def test_golden_invocations(i):
+    case = GOLDEN[i]
+    rc, out, err, written = GOLDEN_RUNS.get(i)
+    assert rc == case["exit"], err[-500:]
+    assert err == case["stderr"]
+    if not case["stdout_is_bam"]:
+        assert (written is not None) == case["out_created"]
+        assert out.decode("latin-1") == case.get("stdout", "")
+    if "out_sha256" in case:
+        data = gzip.decompress(out if case["stdout_is_bam"] else written)
+        assert len(data) == case["out_bytes"]
+        assert hashlib.sha256(data).hexdigest() == case["out_sha256"]
 
 
 @pytest.fixture(scope="module")

@@ -23,23 +23,29 @@ def run(args, env=None):
     return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1")
 
 
-@pytest.mark.parametrize("inflate", ["one_zlib_thread", "by_chunks"])
-def test_reference_main_program_on_the_gpu_library(inflate):
-    """(by_chunks: the library reads every .fastq.gz of the goldens through the many-core gzip reader, host/fq_pgzip.h, in
-    chunks of 4 KiB - files this small are one zlib thread's otherwise)"""
+POOL = 12  # programs started side by side (see tests/test_gpu_cli.py)
+
+
+def test_reference_main_program_on_the_gpu_library():
+    """Every golden invocation, once.  In every second case (a checksum of the arguments decides, the OTHER half than in
+    tests/test_gpu_cli.py) the library reads the .fastq.gz files of the goldens through the many-core gzip reader,
+    host/fq_pgzip.h, in chunks of 4 KiB - files this small are one zlib thread's otherwise."""
+    import zlib
+
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/fastq_info_on_libfastq_gpu was not built (needs the reference checkout at build time)")
     assert os.path.exists(LIB)
-    env = {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "4096", "FQGPU_HOST_THREADS": "3"} if inflate == "by_chunks" else {}
+    by_chunks = {"FQGPU_PGZIP_MIN": "0", "FQGPU_PGZIP_CHUNK": "4096", "FQGPU_HOST_THREADS": "3"}
 
     def one(case):
-        rc, out, err = run(case["args"], env)
+        chunked = not (zlib.crc32(" ".join(case["args"]).encode()) & 1)
+        rc, out, err = run(case["args"], by_chunks if chunked else {})
         ok = (rc == case["exit"] and out == case["stdout"]
               and strip_progress(err) == strip_progress(case["stderr"]))
-        return None if ok else (case["args"], rc, case["exit"], out[-200:], case["stdout"][-200:], err[-500:],
+        return None if ok else (case["args"], chunked, rc, case["exit"], out[-200:], case["stdout"][-200:], err[-500:],
                                 case["stderr"][-500:])
 
-    with ThreadPoolExecutor(8) as ex:
+    with ThreadPoolExecutor(POOL) as ex:
         bad = [b for b in ex.map(one, GOLDEN) if b]
     assert not bad, f"{len(bad)} of {len(GOLDEN)} differ; first: {bad[:4]}"
 
@@ -75,7 +81,7 @@ def test_reference_filterpair_program_on_the_gpu_library():
                     return case["args"], "file", k
         return None
 
-    with ThreadPoolExecutor(4) as ex:
+    with ThreadPoolExecutor(POOL) as ex:
         bad = [b for b in ex.map(one, golden) if b]
     assert not bad, f"{len(bad)} of {len(golden)} differ; first: {bad[:3]}"
 
@@ -97,14 +103,23 @@ def test_lines_beyond_the_gzgets_buffers_through_the_per_record_api():
 
     imgs = overlong_images()
     with tempfile.TemporaryDirectory() as tmp:
+        jobs = []
         for which, img in sorted(imgs.items()):
-            with open(os.path.join(tmp, "f.fastq"), "wb") as f:
+            os.mkdir(os.path.join(tmp, which))
+            with open(os.path.join(tmp, which, "f.fastq"), "wb") as f:
                 f.write(img)
-            for args in (["-r", "f.fastq"], ["f.fastq"], ["f.fastq", "pe"], ["f.fastq", "f.fastq"]):
-                want = subprocess.run([REF_INFO] + args, cwd=tmp, capture_output=True, timeout=300)
-                got = subprocess.run([BIN] + args, cwd=tmp, capture_output=True, timeout=300)
-                assert (got.returncode, got.stdout, strip_progress(got.stderr.decode("latin-1"))) == (
-                    want.returncode, want.stdout, strip_progress(want.stderr.decode("latin-1"))), (which, args, got.stderr[-400:])
+            jobs += [(which, args) for args in (["-r", "f.fastq"], ["f.fastq"], ["f.fastq", "pe"], ["f.fastq", "f.fastq"])]
+
+        def one(job):
+            which, args = job
+            d = os.path.join(tmp, which)
+            want = subprocess.run([REF_INFO] + args, cwd=d, capture_output=True, timeout=300)
+            got = subprocess.run([BIN] + args, cwd=d, capture_output=True, timeout=300)
+            assert (got.returncode, got.stdout, strip_progress(got.stderr.decode("latin-1"))) == (
+                want.returncode, want.stdout, strip_progress(want.stderr.decode("latin-1"))), (which, args, got.stderr[-400:])
+
+        with ThreadPoolExecutor(POOL) as ex:
+            list(ex.map(one, jobs))
         exe = os.path.join(REPO, "oracle", "_ref", "fastq_filterpair_on_libfastq_gpu")
         if os.path.exists(exe) and os.path.exists(REF_FP):
             # the accepted image (its pieces are valid records) paired with itself: every record is copied through the offsets

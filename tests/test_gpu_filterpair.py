@@ -12,7 +12,7 @@ import tempfile
 
 import pytest
 
-from tests.util import GOLD, REPO
+from tests.util import GOLD, REPO, SideBySide
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(REPO, "bin", "fastq_filterpair")
@@ -37,9 +37,14 @@ def run_case(case, env=None):
         return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"), files
 
 
-@pytest.mark.parametrize("case", GOLDEN, ids=lambda c: " ".join(c["args"])[:90] or "no-args")
-def test_cli_matches_reference_binary(case):
-    rc, out, err, files = run_case(case)
+# (the programs of all cases start side by side the first time one is asked for: tests/util.py)
+GOLDEN_RUNS = SideBySide(lambda i: run_case(GOLDEN[i]), range(len(GOLDEN)))
+
+
+@pytest.mark.parametrize("i", range(len(GOLDEN)), ids=[" ".join(c["args"])[:90] or "no-args" for c in GOLDEN])
+def test_cli_matches_reference_binary(i):
+    case = GOLDEN[i]
+    rc, out, err, files = GOLDEN_RUNS.get(i)
     assert rc == case["exit"], err[-400:]
     assert out == case["stdout"]
     assert err == case["stderr"]

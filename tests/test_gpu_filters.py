@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import filter_oracle as fo
-from tests.util import GOLD, REPO, strip_progress
+from tests.util import GOLD, REPO, strip_progress, SideBySide
 
 pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(GOLD, "filters.json")))
@@ -49,26 +49,42 @@ FN_CASES = pick(GOLDEN["filter_n"], 9)
 TP_CASES = pick(GOLDEN["trim_poly_at"], 13)
 
 
-@pytest.mark.parametrize("case", FN_CASES, ids=ids(FN_CASES))
-def test_filter_n_golden(case):
-    rc, out, err = run(BIN_N, "fastq_filter_n", case["args"], GOLD)
+# (the programs of all cases start side by side the first time one is asked for: tests/util.py)
+FN_RUNS = SideBySide(lambda i: run(BIN_N, "fastq_filter_n", FN_CASES[i]["args"], GOLD), range(len(FN_CASES)))
+
+
+@pytest.mark.parametrize("i", range(len(FN_CASES)), ids=ids(FN_CASES))
+def test_filter_n_golden(i):
+    case = FN_CASES[i]
+    rc, out, err = FN_RUNS.get(i)
     assert rc == case["exit"], err
     same_text(case["stdout"], out)
     assert strip_progress(err) == strip_progress(case["stderr"])
 
 
-@pytest.mark.parametrize("case", TP_CASES, ids=ids(TP_CASES))
-def test_trim_poly_at_golden(case):
+def tp_run(i):
+    case = TP_CASES[i]
     with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
         rel = os.path.relpath(tmp, GOLD)
         args = [rel + "/o.fastq.gz" if a == "OUT" else a for a in case["args"]]
         rc, out, err = run(BIN_T, "fastq_trim_poly_at", args, GOLD)
-        assert rc == case["exit"], err
-        assert out.decode("latin-1") == case["stdout"]
-        assert strip_progress(err.replace(rel + "/", "SCRATCH/")) == strip_progress(case["stderr"])
-        if case["out"] is not None:
-            raw = open(os.path.join(tmp, "o.fastq.gz"), "rb").read()
-            same_text(case["out"], gzip.decompress(raw) if raw else b"")
+        path = os.path.join(tmp, "o.fastq.gz")
+        raw = open(path, "rb").read() if os.path.exists(path) else None
+    return rc, out, err.replace(rel + "/", "SCRATCH/"), raw
+
+
+TP_RUNS = SideBySide(tp_run, range(len(TP_CASES)))
+
+
+@pytest.mark.parametrize("i", range(len(TP_CASES)), ids=ids(TP_CASES))
+def test_trim_poly_at_golden(i):
+    case = TP_CASES[i]
+    rc, out, err, raw = TP_RUNS.get(i)
+    assert rc == case["exit"], err
+    assert out.decode("latin-1") == case["stdout"]
+    assert strip_progress(err) == strip_progress(case["stderr"])
+    if case["out"] is not None:
+        same_text(case["out"], gzip.decompress(raw) if raw else b"")
 
 
 def make_reads(rng, n, long_every=0):

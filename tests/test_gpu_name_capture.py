@@ -18,7 +18,7 @@ import pytest
 import fastq_utils_amd as fq
 from oracle import loader as orc
 from tests import fuzz
-from tests.test_gpu_cli import GOLDEN, compare_with_oracle, run_cli
+from tests.test_gpu_cli import GOLDEN, POOL, compare_all, compare_with_oracle, put, run_cli
 from tests.util import GOLD, REPO, strip_progress
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +50,7 @@ def test_golden_index_and_pairing_invocations_with_the_capture():
         ok = (rc == case["exit"] and out == case["stdout"] and strip_progress(err) == strip_progress(case["stderr"]))
         return None if ok else (case["args"], rc, case["exit"], err[-400:], case["stderr"][-400:])
 
-    with ThreadPoolExecutor(8) as ex:
+    with ThreadPoolExecutor(POOL) as ex:
         bad = [b for b in ex.map(one, cases) if b]
     assert not bad, f"{len(bad)} of {len(cases)} differ; first: {bad[:3]}"
 
@@ -58,18 +58,20 @@ def test_golden_index_and_pairing_invocations_with_the_capture():
 @pytest.mark.parametrize("kind", fuzz.MUTATIONS)
 def test_mutated_files(kind):
     rng = np.random.default_rng(abs(hash("cap" + kind)) % 100000)
+    jobs = []
     with tempfile.TemporaryDirectory() as tmp:
         for trial in range(4):
             style = ["casava", "slash", "int", "nosuffix"][trial % 4]
             img = fuzz.make_fastq(rng, int(rng.integers(40, 600)), 1, 120, style, hdr2_names=bool(trial & 1), rna=(trial == 2))
             img = fuzz.mutate(rng, img, kind)
-            write(tmp, {"f.fastq": img})
-            for args in (["f.fastq"], ["f.fastq", "pe"]):
-                compare_with_oracle(tmp, args, {"f.fastq": img}, STREAM)
+            d = put(tmp, "t%d" % trial, {"f.fastq": img})
+            jobs += [(d, args, {"f.fastq": img}, STREAM) for args in (["f.fastq"], ["f.fastq", "pe"])]
+        compare_all(jobs)
 
 
 def test_duplicates_and_pairs():
     rng = np.random.default_rng(55)
+    jobs = []
     with tempfile.TemporaryDirectory() as tmp:
         for trial in range(10):
             style = ["casava", "slash"][trial % 2]
@@ -88,10 +90,10 @@ def test_duplicates_and_pairs():
             if trial % 5 == 4:  # a name twice in file 2
                 lb = lb[:-1] + lb[4 * k:4 * k + 4] + [b""]
             files = {"a.fastq": b"\n".join(la), "b.fastq": b"\n".join(lb)}
-            write(tmp, files)
-            for args in (["a.fastq"], ["a.fastq", "b.fastq"], ["b.fastq", "a.fastq"]):
-                compare_with_oracle(tmp, args, files, STREAM)
-                compare_with_oracle(tmp, args, files, PIECES)
+            d = put(tmp, "t%d" % trial, files)
+            jobs += [(d, args, files, env) for args in (["a.fastq"], ["a.fastq", "b.fastq"], ["b.fastq", "a.fastq"])
+                     for env in (STREAM, PIECES)]
+        compare_all(jobs)
 
 
 def names_of_every_kind(rng, n, mate=1):
@@ -131,10 +133,9 @@ def test_every_seam_of_the_capture(seed):
              "s.fastq": b"".join(r2[i] for i in perm), "m.fastq": b"".join(r2[:k] + r2[k + 1:])}
     with tempfile.TemporaryDirectory() as tmp:
         write(tmp, files)
-        for env in (STREAM, PIECES):
-            for args in (["a.fastq"], ["d.fastq"], ["a.fastq", "b.fastq"], ["a.fastq", "s.fastq"], ["a.fastq", "m.fastq"],
-                         ["m.fastq", "a.fastq"]):
-                compare_with_oracle(tmp, args, files, env)
+        compare_all([(tmp, args, files, env) for env in (STREAM, PIECES)
+                     for args in (["a.fastq"], ["d.fastq"], ["a.fastq", "b.fastq"], ["a.fastq", "s.fastq"], ["a.fastq", "m.fastq"],
+                                  ["m.fastq", "a.fastq"])])
 
 
 @pytest.mark.parametrize("style", ["slash", "nosuffix", "int"])
@@ -156,8 +157,7 @@ def test_names_that_are_the_whole_line(style):
     files = {"a.fastq": a, "b.fastq": b}
     with tempfile.TemporaryDirectory() as tmp:
         write(tmp, files)
-        for args in (["a.fastq"], ["a.fastq", "b.fastq"]):
-            compare_with_oracle(tmp, args, files, PIECES)
+        compare_all([(tmp, args, files, PIECES) for args in (["a.fastq"], ["a.fastq", "b.fastq"])])
 
 
 def test_a_file2_name_asked_twice_across_two_pieces():

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import pre_barcodes_oracle as pbo
-from tests.util import GOLD, REPO, read_image, strip_progress
+from tests.util import GOLD, REPO, SideBySide, read_image, strip_progress
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(REPO, "bin", "fastq_pre_barcodes")
@@ -34,20 +34,37 @@ def gunzip_file(path):
     return gzip.decompress(raw).decode("latin-1") if raw else ""
 
 
-@pytest.mark.parametrize("case", GOLDEN, ids=[str(i) + ":" + " ".join(c["args"])[:60] for i, c in enumerate(GOLDEN)])
-def test_golden_invocations(case):
+def golden_run(job):
+    """one golden invocation (index into GOLDEN, environment): what the program printed and wrote"""
+    i, env = job
+    case = GOLDEN[i]
     with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
         rel = os.path.relpath(tmp, GOLD)
         args = [a.replace("OUT1", rel + "/o1.fastq.gz").replace("OUT2", rel + "/o2.fastq.gz") for a in case["args"]]
-        rc, out, err = run(BIN, args, GOLD)
+        rc, out, err = run(BIN, args, GOLD, dict(env) if env else None)
         out, err = out.replace(rel + "/", "SCRATCH/"), err.replace(rel + "/", "SCRATCH/")
-        assert rc == case["exit"], err
-        assert out == case["stdout"]
-        assert strip_progress(err) == strip_progress(case["stderr"])
-        if case["exit"] == 0:
-            for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
-                if tag in case["files"]:
-                    assert gunzip_file(os.path.join(tmp, fn)) == case["files"][tag]
+        files = {tag: gunzip_file(os.path.join(tmp, fn)) for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz"))}
+    return rc, out, err, files
+
+
+def golden_check(case, got, files_also_on_failure=False):
+    rc, out, err, files = got
+    assert rc == case["exit"], err
+    assert out == case["stdout"]
+    assert strip_progress(err) == strip_progress(case["stderr"])
+    if case["exit"] == 0 or files_also_on_failure:
+        for tag in ("OUT1", "OUT2"):
+            if tag in case["files"]:
+                assert files[tag] == case["files"][tag]
+
+
+GOLDEN_IDS = [str(i) + ":" + " ".join(c["args"])[:60] for i, c in enumerate(GOLDEN)]
+PLAIN_RUNS = SideBySide(golden_run, [(i, None) for i in range(len(GOLDEN))])
+
+
+@pytest.mark.parametrize("i", range(len(GOLDEN)), ids=GOLDEN_IDS)
+def test_golden_invocations(i):
+    golden_check(GOLDEN[i], PLAIN_RUNS.get((i, None)))
 
 
 def make_10x(rng, n, umi_q_low=0.05, short=0.01):
@@ -175,21 +192,14 @@ def test_file_sets_and_tile_sizes_against_reference_binary(name, lds):
         assert (res[0][1] or res[0][3])  # something was written
 
 
+TILE_CASES = [i for i, c in enumerate(GOLDEN) if c["exit"] == 0][::3]
+TILE_RUNS = SideBySide(golden_run, [(i, (("FQGPU_BC_LDS", lds),)) for lds in ("4096", "12288") for i in TILE_CASES])
+
+
 @pytest.mark.parametrize("lds", ["4096", "12288"])
-@pytest.mark.parametrize("case", [c for c in GOLDEN if c["exit"] == 0][::3],
-                         ids=lambda c: " ".join(c["args"])[:50] if isinstance(c, dict) else str(c))
-def test_golden_invocations_other_tile_sizes(case, lds):
-    with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
-        rel = os.path.relpath(tmp, GOLD)
-        args = [a.replace("OUT1", rel + "/o1.fastq.gz").replace("OUT2", rel + "/o2.fastq.gz") for a in case["args"]]
-        rc, out, err = run(BIN, args, GOLD, {"FQGPU_BC_LDS": lds})
-        out, err = out.replace(rel + "/", "SCRATCH/"), err.replace(rel + "/", "SCRATCH/")
-        assert rc == case["exit"], err
-        assert out == case["stdout"]
-        assert strip_progress(err) == strip_progress(case["stderr"])
-        for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
-            if tag in case["files"]:
-                assert gunzip_file(os.path.join(tmp, fn)) == case["files"][tag]
+@pytest.mark.parametrize("i", TILE_CASES, ids=[" ".join(GOLDEN[i]["args"])[:50] for i in TILE_CASES])
+def test_golden_invocations_other_tile_sizes(i, lds):
+    golden_check(GOLDEN[i], TILE_RUNS.get((i, (("FQGPU_BC_LDS", lds),))), files_also_on_failure=True)
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
@@ -220,24 +230,17 @@ def test_odd_inputs_against_reference_binary(variant, extra):
 SEVERAL = {"FQGPU_DEVICES": "0,0,0"}
 
 
+def several_env(per_block):
+    return tuple(sorted(dict(SEVERAL, **({"FQGPU_BLOCK_RECORDS": per_block} if per_block else {})).items()))
+
+
+SEVERAL_RUNS = SideBySide(golden_run, [(i, several_env(pb)) for pb in ("3", "50", None) for i in range(len(GOLDEN))])
+
+
 @pytest.mark.parametrize("per_block", ["3", "50", None], ids=["blocks_of_3", "blocks_of_50", "one_block"])
-@pytest.mark.parametrize("case", GOLDEN, ids=[str(i) + ":" + " ".join(c["args"])[:60] for i, c in enumerate(GOLDEN)])
-def test_several_devices_golden_invocations(case, per_block):
-    env = dict(SEVERAL)
-    if per_block:
-        env["FQGPU_BLOCK_RECORDS"] = per_block
-    with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
-        rel = os.path.relpath(tmp, GOLD)
-        args = [a.replace("OUT1", rel + "/o1.fastq.gz").replace("OUT2", rel + "/o2.fastq.gz") for a in case["args"]]
-        rc, out, err = run(BIN, args, GOLD, env)
-        out, err = out.replace(rel + "/", "SCRATCH/"), err.replace(rel + "/", "SCRATCH/")
-        assert rc == case["exit"], err
-        assert out == case["stdout"]
-        assert strip_progress(err) == strip_progress(case["stderr"])
-        if case["exit"] == 0:
-            for tag, fn in (("OUT1", "o1.fastq.gz"), ("OUT2", "o2.fastq.gz")):
-                if tag in case["files"]:
-                    assert gunzip_file(os.path.join(tmp, fn)) == case["files"][tag]
+@pytest.mark.parametrize("i", range(len(GOLDEN)), ids=GOLDEN_IDS)
+def test_several_devices_golden_invocations(i, per_block):
+    golden_check(GOLDEN[i], SEVERAL_RUNS.get((i, several_env(per_block))))
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")

@@ -13,7 +13,7 @@ import pytest
 from oracle import umi_oracle as uo
 from tests import bamgen
 from tests.test_oracle_umi import GOLDEN, comparable, golden_files, want_exit
-from tests.util import GOLD, REPO, free_port
+from tests.util import GOLD, REPO, SideBySide, free_port
 
 pytestmark = pytest.mark.gpu
 fq = pytest.importorskip("fastq_utils_amd")
@@ -26,26 +26,39 @@ def run_cli(args, cwd):
     return p.returncode, p.stderr.decode("latin-1")
 
 
-@pytest.mark.parametrize("case", [c for c in GOLDEN if comparable(c)], ids=lambda c: " ".join(c["args"])[:80])
-def test_cli_matches_reference_binary(case):
+CLI_CASES = [c for c in GOLDEN if comparable(c)]
+
+
+def cli_case_run(i):
+    case = CLI_CASES[i]
     with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
         rel = os.path.relpath(tmp, GOLD)
         real = [a.replace("OUTU", rel + "/u.mtx").replace("OUTR", rel + "/r.mtx") for a in case["args"]]
         rc, err = run_cli(real, GOLD)
-        err = err.replace(rel + "/", "SCRATCH/")
-        assert (rc if rc >= 0 else 128 - rc) == want_exit(case), err[-400:]
-        if case["exit"] == -6:
-            assert "Assertion `len1+1 < FEAT_ID_MAX_LEN' failed" in err
-            return
-        assert err == case["stderr"]
-        if case["exit"] == 0:
-            got = {}
-            for base in ("u.mtx", "r.mtx"):
-                for ext in ("", "_rows", "_cols"):
-                    path = os.path.join(tmp, base + ext)
-                    if os.path.exists(path):
-                        got["SCRATCH/" + base + ext] = open(path, "rb").read().decode("latin-1")
-            assert got == golden_files(case)
+        got = {}
+        for base in ("u.mtx", "r.mtx"):
+            for ext in ("", "_rows", "_cols"):
+                path = os.path.join(tmp, base + ext)
+                if os.path.exists(path):
+                    got["SCRATCH/" + base + ext] = open(path, "rb").read().decode("latin-1")
+    return rc, err.replace(rel + "/", "SCRATCH/"), got
+
+
+# (the programs of all cases start side by side the first time one is asked for: tests/util.py)
+CLI_RUNS = SideBySide(cli_case_run, range(len(CLI_CASES)))
+
+
+@pytest.mark.parametrize("i", range(len(CLI_CASES)), ids=[" ".join(c["args"])[:80] for c in CLI_CASES])
+def test_cli_matches_reference_binary(i):
+    case = CLI_CASES[i]
+    rc, err, got = CLI_RUNS.get(i)
+    assert (rc if rc >= 0 else 128 - rc) == want_exit(case), err[-400:]
+    if case["exit"] == -6:
+        assert "Assertion `len1+1 < FEAT_ID_MAX_LEN' failed" in err
+        return
+    assert err == case["stderr"]
+    if case["exit"] == 0:
+        assert got == golden_files(case)
 
 
 @pytest.fixture(scope="module")

@@ -254,3 +254,46 @@ def test_a_reference_in_front_of_the_members_first_byte(check, tmp_path):
             rc, line, st = run(check, f, 4, chunk)
             assert rc == 0, line
             assert "too far back" in st.get("zlib_error", "") or "too far back" in line, line
+
+
+def stored_member(payload):
+    """a member of ONE stored block: its compressed length is len(payload) + 10 (header) + 5 (block) + 8 (trailer)"""
+    assert len(payload) < 65536
+    body = b"\x01" + struct.pack("<HH", len(payload), len(payload) ^ 0xFFFF) + payload
+    return (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + body +
+            struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+@pytest.mark.parametrize("threads", [1, 3, 4])
+@pytest.mark.parametrize("lead", [0, 3], ids=["first_round", "later_round"])
+def test_a_member_that_ends_where_the_loaded_window_ends(check, tmp_path, threads, lead):
+    """The trailer of a member at (or one byte before, or behind) the end of the bytes a round has loaded, with more
+    members behind it: 0 or 1 bytes in the middle of a file decide nothing about what follows (round 4 took them for
+    bytes behind the last member and ended the file there, silently)."""
+    chunk = 4096
+    r = random.Random(11 + threads)
+    rest = [r.randbytes(r.choice([1, 700, 3000])) for _ in range(3)]
+    before = [r.randbytes(chunk * threads + 17) for _ in range(lead)]  # whole windows of members in front of it
+    f = tmp_path / "w.gz"
+    window = chunk * threads
+    for total in range(window - 14, window + 40):  # the compressed length of the member in question
+        payload = r.randbytes(total - 23)
+        parts = before + [payload] + rest
+        f.write_bytes(b"".join(stored_member(p) if len(p) < 65536 else member(p, level=0) for p in parts))
+        rc, line, st = run(check, f, threads, chunk)
+        assert rc == 0, (total, line)
+        assert int(st["bytes"]) == sum(len(p) for p in parts), (total, line)
+        assert int(st["members"]) == len(parts) and st["error"] == "-", (total, line)
+
+
+def test_a_header_cut_by_the_window_end(check, tmp_path):
+    """... and a next member whose header (with a name and an extra field) straddles the end of the loaded window"""
+    chunk, threads = 4096, 2
+    r = random.Random(5)
+    header = b"\x1f\x8b\x08\x0c\x00\x00\x00\x00\x00\x03" + struct.pack("<H", 6) + b"abcdef" + b"a name.fastq\x00"
+    f = tmp_path / "h.gz"
+    for total in range(chunk * threads - 40, chunk * threads + 12):
+        a, b = r.randbytes(total - 23), r.randbytes(900)
+        f.write_bytes(stored_member(a) + member(b, header=header, level=6) + stored_member(b"tail"))
+        rc, line, st = run(check, f, threads, chunk)
+        assert rc == 0 and int(st["bytes"]) == len(a) + len(b) + 4 and int(st["members"]) == 3, (total, line)

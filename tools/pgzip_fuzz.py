@@ -5,7 +5,9 @@ Random content (FASTQ of short and long reads, noise, repeats, text, mixtures), 
 (level, strategy, window, memory level, flush points), 1 - 30 members, then a cut, a flipped bit or bytes behind the
 last member in half of the cases; random thread counts and chunk sizes.  Prints DIFF lines and keeps the files.
 Round 4: seeds 1-3 and 11-13, 150 cases each: no difference (the five of seeds 1-3 were files whose magic the flip had
-destroyed - gzread copies such a file through; the reader now does too)."""
+destroyed - gzread copies such a file through; the reader now does too).
+Round 5: a quarter of the cases carry members in front whose trailer ends within a few bytes of the end of a round's
+loaded window (the case the round-4 reader ended the file in, silently); seeds 21-26, 150 cases each."""
 import os, random, struct, subprocess, sys, zlib
 sys.path.insert(0, '/root/repo')
 from tests.test_pgzip import fastq_text
@@ -49,6 +51,17 @@ for it in range(n):
         if r.random() < 0.2:
             hdr = b"\x1f\x8b\x08\x08\x00\x00\x00\x00\x00\x03" + b"name%d\x00" % it
         raw += hdr + body + struct.pack("<II", zlib.crc32(p) & 0xFFFFFFFF, len(p) & 0xFFFFFFFF)
+    threads = r.choice([1, 2, 3, 4, 8]); chunk = r.choice([4096, 9000, 30000, 100000, 1 << 20])
+    if r.random() < 0.25 and chunk * threads <= 400000:
+        # a member in FRONT whose trailer ends within a few bytes of where a round's loaded window ends (stored blocks
+        # of noise: the compressed length is known), or k windows of such members in front of that one
+        lead = b''
+        for k in range(r.choice([1, 1, 2, 3])):
+            total = chunk * threads + r.randint(-14, 40)
+            pay = r.randbytes(max(0, total - 18 - 5 * ((total - 18) // 65535 + 1)))
+            co = zlib.compressobj(0, zlib.DEFLATED, -15)
+            lead += b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + co.compress(pay) + co.flush() + struct.pack("<II", zlib.crc32(pay) & 0xFFFFFFFF, len(pay))
+        raw = lead + raw
     what = r.choice(['ok', 'ok', 'ok', 'cut', 'flip', 'tail'])
     if what == 'cut' and len(raw) > 20: raw = raw[:r.randrange(1, len(raw))]
     elif what == 'flip' and len(raw) > 20:
@@ -56,7 +69,6 @@ for it in range(n):
     elif what == 'tail': raw += r.choice([b'\x00' * 5, b'\x1f', b'\x1f\x8b', b'xyz' * 50, b'\x1f\x8b\x08\x00'])
     path = os.path.join(OUT, 'fuzz_%d.gz' % seed0)
     open(path, 'wb').write(raw)
-    threads = r.choice([1, 2, 3, 4, 8]); chunk = r.choice([4096, 9000, 30000, 100000, 1 << 20])
     p = subprocess.run([CHECK, path, str(threads), str(chunk)], capture_output=True, text=True, timeout=600)
     if p.returncode != 0:
         bad += 1
