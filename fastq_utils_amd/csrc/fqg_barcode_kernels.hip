@@ -400,7 +400,11 @@ __device__ __forceinline__ void bc_tags_of_kept(const BcParams& P, const BcLine 
 __device__ __forceinline__ uint32_t bc_fastq_len(bool sliced, long off, long size, const BcLine (&ln)[4], const BcTags& t) {
   const bool tagged = (t.n[0] | t.n[1] | t.n[2]) != 0;
   uint32_t n = ln[0].len + ln[0].nl + (tagged ? 31u + t.n[0] + t.n[1] + t.n[2] : 0u);
-  n += (tagged || sliced) ? 2u : ln[2].len + ln[2].nl;
+  if (tagged && n >= (uint32_t)FQG_MAX_LABEL_LENGTH) {  // the tagged header runs over hdr1[] into hdr2[]: bc_emit_fastq
+    n = n == (uint32_t)FQG_MAX_LABEL_LENGTH ? n : (uint32_t)FQG_MAX_LABEL_LENGTH + 2u;
+    n += n == (uint32_t)FQG_MAX_LABEL_LENGTH ? 0u : 2u;
+  } else
+    n += (tagged || sliced) ? 2u : ln[2].len + ln[2].nl;
   if (sliced) {
     const Cut cs = bc_cut(ln[1].len + ln[1].nl, off, size);
     const Cut cq = bc_cut(ln[3].len + ln[3].nl, off, size);
@@ -1071,7 +1075,15 @@ __device__ __forceinline__ void bc_put_cut(W& w, const uint8_t* s, const Cut& c)
 template <class W>
 __device__ __forceinline__ void bc_emit_fastq(bool sliced, long off, long size, const BcLine (&ln)[4], const BcTags& t, W& w) {
   const bool tagged = (t.n[0] | t.n[1] | t.n[2]) != 0;
-  if (tagged) {  // add_tags2readname, src/fastq_pre_barcodes.c:192-216
+  // add_tags2readname (src/fastq_pre_barcodes.c:192-216) moves the header up by the tags' length inside hdr1[1000] -
+  // and, when the tagged header has 1000 characters or more (a header line near the gzgets limit, or a piece of a longer
+  // one), on into hdr2[], the next member of the struct (src/fastq.h:98-101), whose bytes [1] and [2] are then set to
+  // '\n' and 0: what is printed as hdr1 runs through hdr2[0] and ends with that '\n', what is printed as hdr2 is the
+  // header's character number 1000 and the '\n' (exactly 1000 characters: the string's 0 lands in hdr2[0] - hdr2 is empty)
+  const uint32_t tags_n = 31u + t.n[0] + t.n[1] + t.n[2];
+  const uint32_t hn = ln[0].len + ln[0].nl + (tagged ? tags_n : 0u);
+  const bool spills = tagged && hn >= (uint32_t)FQG_MAX_LABEL_LENGTH;
+  if (tagged) {
     w.ch((char)ln[0].p[0]);
     BC_LIT(w, "STAGS_CELL=");
     w.bytes(t.s[1], t.n[1]);
@@ -1080,13 +1092,22 @@ __device__ __forceinline__ void bc_emit_fastq(bool sliced, long off, long size, 
     BC_LIT(w, "_SAMPLE=");
     w.bytes(t.s[2], t.n[2]);
     BC_LIT(w, "_ETAGS_");
-    w.bytes(ln[0].p + 1, ln[0].len + ln[0].nl - 1);
+    const uint32_t rest = ln[0].len + ln[0].nl - 1;
+    if (spills && hn > (uint32_t)FQG_MAX_LABEL_LENGTH) {
+      w.bytes(ln[0].p + 1, (uint32_t)FQG_MAX_LABEL_LENGTH - tags_n);  // ... up to character number 1000 of the tagged header
+      w.ch('\n');
+    } else w.bytes(ln[0].p + 1, rest);
   } else {
     w.bytes(ln[0].p, ln[0].len + ln[0].nl);
   }
   if (sliced) bc_put_cut(w, ln[1].p, bc_cut(ln[1].len + ln[1].nl, off, size));
   else w.bytes(ln[1].p, ln[1].len + ln[1].nl);
-  if (tagged || sliced) {
+  if (spills) {
+    if (hn > (uint32_t)FQG_MAX_LABEL_LENGTH) {
+      w.ch((char)ln[0].p[(uint32_t)FQG_MAX_LABEL_LENGTH - tags_n]);
+      w.ch('\n');
+    }
+  } else if (tagged || sliced) {
     w.ch((char)ln[2].p[0]);
     w.ch('\n');
   } else {

@@ -130,6 +130,7 @@ inline void slot_release(fqg_ctx* ctx, char* p) { SlotPool::get().give(ctx, p); 
 [[noreturn]] inline void leave(int code) {
   fflush(stdout);
   fflush(stderr);
+  if (getenv("FQGPU_PLAIN_EXIT")) exit(code);  // (tools/exit_stress.py: does the process survive exit()'s hooks?)
   _exit(code);
 }
 
@@ -170,6 +171,52 @@ inline void pgzip_report(const ParallelGunzip* pg, const std::string& path) {
           (unsigned long long)st.chunks_discarded, (unsigned long long)st.members, st.fell_back ? "; one zlib stream from: " : "",
           st.fell_back ? st.why.c_str() : "", st.s_load, st.s_decode, st.s_join + st.s_windows, st.s_narrow);
 }
+
+// Readers that run ahead of the GPU, and exit().  A program that links the per-record library (libfastq_gpu.so under the
+// reference's own main()) leaves through exit() whenever it likes - on its first finding, say, while a producer thread is
+// pinning or filling the next slot, i.e. is INSIDE a HIP call.  exit() runs the HIP runtime's own teardown from one of
+// its hooks; a thread of ours inside the runtime at that moment is a crash after everything has been said (a wrong exit
+// status).  So the hooks stop the readers first: every Input with a live producer is registered here, and the handler
+// - registered with atexit() when the first of them starts, i.e. AFTER the runtime was initialised by fqg_open, and
+// therefore run BEFORE the runtime's handlers (exit() runs them last-registered first) - tells them to stop and joins
+// them.  The drop-in programs themselves leave through _exit() (leave(), above) and never get here.
+class ExitQuiesce {
+ public:
+  typedef void (*StopFn)(void*);
+  static ExitQuiesce& get() {
+    static ExitQuiesce* p = new ExitQuiesce;  // (never destroyed: it is used from an exit handler)
+    return *p;
+  }
+  void add(void* who, StopFn stop) {
+    std::lock_guard<std::mutex> lk(mu_);
+    live_.emplace_back(who, stop);
+    if (!hooked_) {
+      hooked_ = true;
+      atexit([] { ExitQuiesce::get().stop_all(); });
+    }
+  }
+  void remove(void* who) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (size_t i = 0; i < live_.size(); ++i)
+      if (live_[i].first == who) {
+        live_.erase(live_.begin() + (long)i);
+        return;
+      }
+  }
+  void stop_all() {
+    std::vector<std::pair<void*, StopFn>> all;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      all.swap(live_);
+    }
+    for (auto& e : all) e.second(e.first);
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<std::pair<void*, StopFn>> live_;
+  bool hooked_ = false;
+};
 
 class Input {
  public:
@@ -214,13 +261,18 @@ class Input {
     // FQGPU_REFRAME set (fq_respawn.h), which brings it here.
     reframe_ = ((gz_ != nullptr || bgzf_fd_ >= 0 || pgz_fd_ >= 0) && reframe_supported()) || reframing();
   }
-  ~Input() {
+  // the producer is told to stop and joined (the destructor; exit(): ExitQuiesce)
+  void stop_reading() {
     {
       std::lock_guard<std::mutex> lk(mu_);
       quit_ = true;
     }
     cv_.notify_all();
-    if (producer_.joinable()) producer_.join();
+    if (producer_.joinable() && producer_.get_id() != std::this_thread::get_id()) producer_.join();
+  }
+  ~Input() {
+    ExitQuiesce::get().remove(this);
+    stop_reading();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     if (bgzf_fd_ >= 0) close(bgzf_fd_);
@@ -240,7 +292,10 @@ class Input {
   bool next(bool whole_file = false) {
     if (finished_) return false;
     if (whole_file) return next_whole();
-    if (!producer_.joinable()) producer_ = std::thread([this] { produce(); });
+    if (!producer_.joinable()) {
+      ExitQuiesce::get().add(this, [](void* in) { static_cast<Input*>(in)->stop_reading(); });
+      producer_ = std::thread([this] { produce(); });
+    }
     const int prev = cur_;
     // carried bytes of the piece the caller is done with
     const char* carry_src = nullptr;

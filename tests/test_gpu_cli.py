@@ -347,11 +347,20 @@ def test_bgzipped_input_and_json_metrics():
 
 
 # ---- FQGPU_DEVICES in the index modes: names across contexts (host/fq_names_multi.h) ----------------------------------
+def goes_to_several_devices(case):
+    """The golden invocations that test names are run once more on two other paths: every second one (a checksum of its
+    arguments decides) over several devices, here; the others through the streaming pass with header capture,
+    tests/test_gpu_name_capture.py.  (A program start is what the suite's time is made of: tools/golden_concurrency.py.)"""
+    import zlib
+
+    return (zlib.crc32(("paths " + " ".join(case["args"])).encode()) >> 3) & 1 == 1
+
+
 def test_several_devices_golden_index_and_pairing_invocations():
-    """every golden invocation that tests names (no -r, not interleaved "pe"): records spread over three contexts, names
+    """golden invocations that test names (no -r, not interleaved "pe"): records spread over three contexts, names
     tested across them by the fingerprint exchange - same exit status, stdout and stderr as the reference binary"""
-    cases = [c for c in GOLDEN if "-r" not in c["args"] and "pe" not in c["args"]]
-    assert len(cases) > 150
+    cases = [c for c in GOLDEN if "-r" not in c["args"] and "pe" not in c["args"] and goes_to_several_devices(c)]
+    assert len(cases) > 75
 
     def one(case):
         rc, out, err = run_cli(case["args"], GOLD, MULTI)

@@ -18,7 +18,7 @@ import pytest
 import fastq_utils_amd as fq
 from oracle import loader as orc
 from tests import fuzz
-from tests.test_gpu_cli import GOLDEN, POOL, compare_all, compare_with_oracle, put, run_cli
+from tests.test_gpu_cli import GOLDEN, POOL, compare_all, compare_with_oracle, goes_to_several_devices, put, run_cli
 from tests.util import GOLD, REPO, strip_progress
 
 pytestmark = pytest.mark.gpu
@@ -41,9 +41,10 @@ def write(tmp, files):
 
 
 def test_golden_index_and_pairing_invocations_with_the_capture():
-    """every golden invocation that builds an index (no -r), streamed"""
-    cases = [c for c in GOLDEN if "-r" not in c["args"]]
-    assert len(cases) > 200
+    """golden invocations that build an index (no -r), streamed: the interleaved ones, and of the others those that
+    tests/test_gpu_cli.py does not run over several devices (goes_to_several_devices)"""
+    cases = [c for c in GOLDEN if "-r" not in c["args"] and ("pe" in c["args"] or not goes_to_several_devices(c))]
+    assert len(cases) > 100
 
     def one(case):
         rc, out, err = run_cli(case["args"], GOLD, STREAM)

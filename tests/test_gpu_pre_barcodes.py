@@ -86,6 +86,16 @@ def make_10x(rng, n, umi_q_low=0.05, short=0.01):
     return b"".join(r1), b"".join(r2)
 
 
+_TEN_X = {}
+
+
+def ten_x_pairs_20000():
+    """the 20 000 pairs of test_several_devices_against_reference_binary (made once: a second of Python per call)"""
+    if not _TEN_X:
+        _TEN_X["p"] = make_10x(np.random.default_rng(41), 20000)
+    return _TEN_X["p"]
+
+
 V2 = ["--read1", "r2.fastq", "--index1", "r1.fastq", "--umi_read", "index1", "--umi_offset", "16", "--umi_size", "10",
       "--cell_read", "index1", "--cell_offset", "0", "--cell_size", "16", "--phred_encoding", "33", "--min_qual", "10"]
 
@@ -252,8 +262,7 @@ def test_several_devices_against_reference_binary(shape, extra):
     """20 000 10x-style pairs in blocks of ~3 000 (1 MiB pieces) and of 1 000 records over three contexts: outputs, messages
     and exit codes of the reference program - also when one file is shorter, ends inside a record, ends exactly at a block
     boundary with a record cut, or the first finding lies many blocks into the files"""
-    rng = np.random.default_rng(41)
-    r1, r2 = make_10x(rng, 20000)
+    r1, r2 = ten_x_pairs_20000()
     l1, l2 = r1.split(b"\n"), r2.split(b"\n")
     if shape == "index_file_shorter":
         r1 = b"\n".join(l1[:4 * 15555]) + b"\n"
@@ -283,14 +292,19 @@ def test_several_devices_against_reference_binary(shape, extra):
     envs = [dict(SEVERAL, FQGPU_CHUNK_MB="1"), dict(SEVERAL, FQGPU_BLOCK_RECORDS="1000")]
     if shape.startswith("nul_"):
         envs += [None, {"FQGPU_CHUNK_MB": "1"}]  # the one-device loop, whole and in 1 MiB pieces: the same answer
-    res = []
-    for binary, env in [(REF, None)] + [(BIN, e) for e in envs]:
+    def one(job):
+        binary, env = job
         with tempfile.TemporaryDirectory() as d:
             for fn, img in zip(names, (r1, r2)):
                 with open(os.path.join(d, fn), "wb") as f:
                     f.write(gzip.compress(img, 1) if fn.endswith(".gz") else img)
             rc, out, err = run(binary, args + extra, d, env)
-            res.append((rc, out, strip_progress(err), gunzip_file(os.path.join(d, "o.fastq.gz")) if rc == 0 else None))
+            return rc, out, strip_progress(err), gunzip_file(os.path.join(d, "o.fastq.gz")) if rc == 0 else None
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(6) as ex:  # the reference and the program's runs side by side
+        res = list(ex.map(one, [(REF, None)] + [(BIN, e) for e in envs]))
     for got in res[1:]:
         assert got[0] == res[0][0], got[2][-400:]
         assert got[2] == res[0][2]
