@@ -34,7 +34,7 @@ EXPORTS = [
     "fqg_index_destroy", "fqg_index_insert_unique", "fqg_index_match_delete", "fqg_index_probe_delete",
     "fqg_index_alive", "fqg_index_n_frames", "fqg_index_frame", "fqg_index_names_captured", "fqg_index_expect_lookups", "fqg_records_gather",
     "fqg_records_gather_output", "fqg_names_compare",
-    "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_records_filter", "fqg_records_filter_output",
+    "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_barcodes_output_begin", "fqg_barcodes_output_wait", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_whitelist_create", "fqg_whitelist_destroy", "fqg_barcodes_whitelist",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
     "fqg_umi_count", "fqg_umi_features", "fqg_umi_record_features", "fqg_umi_replayed_features", "fqg_umi_umis",
@@ -238,6 +238,8 @@ def load():
     L.fqg_barcodes_transform.argtypes = [vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64),
                                          C.POINTER(BarcodeParams), u64, u64, C.POINTER(BarcodeResult)]
     L.fqg_barcodes_output.argtypes = [vp, C.c_int, vp, u64]
+    L.fqg_barcodes_output_begin.argtypes = [vp, C.c_int, vp, u64]
+    L.fqg_barcodes_output_wait.argtypes = [vp]
     L.fqg_records_filter.argtypes = [vp, vp, u64, u64, C.POINTER(FilterParams), C.POINTER(FilterResult)]
     L.fqg_records_filter_output.argtypes = [vp, vp, u64]
     L.fqg_fp_owner.argtypes = [u64, C.c_uint32]
@@ -608,9 +610,15 @@ class Context:
             d["valid"] = flags[:n]
         return d
 
-    def barcodes_output(self, which, nbytes):
+    def barcodes_output(self, which, nbytes, beside_next_call=False):
+        """output `which` of the last transform.  beside_next_call: through fqg_barcodes_output_begin / _wait (the copy
+        runs on a stream of its own; the caller may launch other work on the context before it waits)"""
         buf = C.create_string_buffer(max(1, nbytes))
-        self._check(load().fqg_barcodes_output(self.h, which, buf, nbytes))
+        if beside_next_call:
+            self._check(load().fqg_barcodes_output_begin(self.h, which, buf, nbytes))
+            self._check(load().fqg_barcodes_output_wait(self.h))
+        else:
+            self._check(load().fqg_barcodes_output(self.h, which, buf, nbytes))
         return buf.raw[:nbytes]
 
     def names_fingerprints(self, frame, state, record_base, n_owners, out_device_ptr):

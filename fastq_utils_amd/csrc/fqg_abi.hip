@@ -77,6 +77,9 @@ inline int measure_int(const char* name) {
 struct fqg_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t out_stream = nullptr;   // fqg_barcodes_output_begin: device-to-host copies beside the next piece's upload
+  hipEvent_t out_ready = nullptr;     // ... recorded on `stream` where the output was produced
+  bool out_pending = false;
   hipStream_t stream = nullptr;
   std::string err;
   int cu_count = 256;
@@ -332,6 +335,11 @@ void fqg_close(fqg_ctx* c) {
   if (c->d_cs) (void)hipFree(c->d_cs);
   if (c->h_cs) (void)hipHostFree(c->h_cs);
   if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+  if (c->out_stream) {
+    (void)hipStreamSynchronize(c->out_stream);
+    (void)hipStreamDestroy(c->out_stream);
+  }
+  if (c->out_ready) (void)hipEventDestroy(c->out_ready);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1560,6 +1568,10 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
                            const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_iter,
                            uint64_t first_read_number, fqg_barcode_result* out) {
   if (!c || !frames || !states || !first_record || !bp || !out) return FQG_ERR_ARG;
+  if (c->out_pending) {  // (a copy of the previous output is still on its way: this call writes the same buffers)
+    const int rcw = fqg_barcodes_output_wait(c);
+    if (rcw) return rcw;
+  }
   memset(out, 0, sizeof(*out));
   c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1852,6 +1864,10 @@ int fqg_barcodes_whitelist(fqg_ctx* c, const fqg_frame* frame, uint64_t first, u
 int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record, uint64_t n_rec,
                        const fqg_filter_params* fp, fqg_filter_result* out) {
   if (!c || !frame || !fp || !out) return FQG_ERR_ARG;
+  if (c->out_pending) {  // (a copy of the previous output is still on its way: this call writes the same buffers)
+    const int rcw = fqg_barcodes_output_wait(c);
+    if (rcw) return rcw;
+  }
   memset(out, 0, sizeof(*out));
   c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
   if (fp->mode != FQG_FILTER_N && fp->mode != FQG_FILTER_POLY_AT) return fail(c, FQG_ERR_ARG, "fqg_records_filter: unknown mode");
@@ -1954,10 +1970,39 @@ int fqg_barcodes_output(fqg_ctx* c, int which, void* host_dst, uint64_t nbytes) 
   return 0;
 }
 
+int fqg_barcodes_output_wait(fqg_ctx* c) {
+  if (!c) return FQG_ERR_ARG;
+  if (!c->out_pending) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->out_stream));
+  c->out_pending = false;
+  return 0;
+}
+
+int fqg_barcodes_output_begin(fqg_ctx* c, int which, void* host_dst, uint64_t nbytes) {
+  if (!c || which < 0 || which > 2 || (!host_dst && nbytes)) return FQG_ERR_ARG;
+  if (nbytes > c->bc_out_bytes[which]) return fail(c, FQG_ERR_ARG, "fqg_barcodes_output_begin: more than was produced");
+  if (!nbytes) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->out_stream) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->out_ready, hipEventDisableTiming));
+  }
+  HIP_TRY(c, hipEventRecord(c->out_ready, c->stream));  // (what produced the text has been launched on `stream`)
+  HIP_TRY(c, hipStreamWaitEvent(c->out_stream, c->out_ready, 0));
+  HIP_TRY(c, hipMemcpyAsync(host_dst, c->bc_out[which].p, nbytes, hipMemcpyDeviceToHost, c->out_stream));
+  c->out_pending = true;
+  return 0;
+}
+
 int fqg_records_filter_output(fqg_ctx* c, void* host_dst, uint64_t nbytes) { return fqg_barcodes_output(c, 1, host_dst, nbytes); }
 
 int fqg_records_gather(fqg_ctx* c, const fqg_frame* frame, const uint64_t* records, uint64_t n, uint64_t* out_bytes) {
   if (!c || !frame || !out_bytes || (!records && n)) return FQG_ERR_ARG;
+  if (c->out_pending) {  // (a copy of the previous output is still on its way: this call writes the same buffers)
+    const int rcw = fqg_barcodes_output_wait(c);
+    if (rcw) return rcw;
+  }
   *out_bytes = 0;
   c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
   if (!n) return 0;

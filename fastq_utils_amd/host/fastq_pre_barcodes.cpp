@@ -13,6 +13,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -140,8 +141,12 @@ bool probe_bytes(const char* data, size_t size, fqg_file_state* st, std::string*
 // again, as a child and on one device, on input that is cut where gzgets cuts it (fq_respawn.h, fq_reframe.h: inflated
 // input is cut while it is read and never comes here) - every piece a line, a C string to the kernels as to the
 // reference.  Only a stream that cannot be read twice is refused.
+std::function<void()> g_before_respawn;  // (the one-device loop: text still on its way to stdout is written first)
 [[noreturn]] void refuse_long_line(const char* path, uint64_t record) {
-  if (fqhost::reframe_supported() && !fqhost::reframing() && strcmp(path, "-") != 0) fqhost::respawn_reframed();
+  if (fqhost::reframe_supported() && !fqhost::reframing() && strcmp(path, "-") != 0) {
+    if (g_before_respawn) g_before_respawn();
+    fqhost::respawn_reframed();
+  }
   FQ_PRINT_ERROR("Error in file %s: record %lu has a line longer than the reference's line buffers (%d / %d bytes)", path,
                  (unsigned long)(record + 1), FQG_MAX_LABEL_LENGTH - 1, FQG_MAX_READ_LENGTH - 1);
   fflush(stdout);
@@ -767,6 +772,21 @@ int main(int argc, char** argv) {
   for (int x = READ1; x <= INDEX3; ++x)
     if (file[x]) src[x].use = (has_interleaved && x == P.interleaved[1]) ? 1 : 0;
 
+  std::vector<OutJob> in_flight;  // output of the last transform, on its way to the host
+  auto land_output = [&] {
+    if (in_flight.empty()) return;
+    const double t_d = now();
+    LIB(fqg_barcodes_output_wait(g_ctx));
+    const double t_e = now();
+    for (const OutJob& job : in_flight) outq.push(job);
+    in_flight.clear();
+    t_fetch += t_e - t_d;
+    t_hand += now() - t_e;
+  };
+  g_before_respawn = [&] {
+    land_output();
+    drain_or_die();
+  };
   for (;;) {
     // every input needs a frame that holds the record its next iteration uses
     const double t_a = now();
@@ -809,13 +829,14 @@ int main(int argc, char** argv) {
         first[x] = (uint64_t)src[x].use - ((has_interleaved && x == P.interleaved[1]) ? 1 : 0);
       }
     fqg_barcode_result r;
+    land_output();  // (the transform writes the device buffers the previous batch's text is copied from)
     const double t_b = now();
     LIB(fqg_barcodes_transform(g_ctx, frames, states, first, &Pb, n, processed, &r));
     const double t_c = now();
     t_refill += t_b - t_a;
     t_transform += t_c - t_b;
     if (first_batch && num_input_files > 1) {
-      drain_or_die();
+      drain_or_die();  // (nothing is in flight yet: the first batch)
       // format lines of the first fastq_get_readname call per file, in file order (src/fastq.c:459-485)
       for (int x = READ1; x <= INDEX3; ++x)
         if (file[x]) {
@@ -826,18 +847,18 @@ int main(int argc, char** argv) {
     }
     first_batch = false;
     for (uint64_t w = 0; w < r.n_short; ++w) fputs("Warning: Read too short - barcode not found\n", stderr);
-    // hand the text to the writer (stdout / gzip)
+    // The text comes back on a stream of its own, beside the upload and framing of the NEXT pieces of input (the link
+    // carries both directions at once: tools/kbench/duplex.hip); it is handed to the writer (stdout / gzip) when the
+    // next batch is about to be transformed - land_output(), at the top of the loop - or the loop ends.
     for (int which = 0; which < 3; ++which)
       if (r.out_bytes[which]) {
         const double t_d = now();
         OutJob job = outq.buffer(g_ctx, r.out_bytes[which]);
         job.which = which;
         job.size = r.out_bytes[which];
-        LIB(fqg_barcodes_output(g_ctx, which, job.text, job.size));
-        const double t_e = now();
-        outq.push(job);
-        t_fetch += t_e - t_d;
-        t_hand += now() - t_e;
+        LIB(fqg_barcodes_output_begin(g_ctx, which, job.text, job.size));
+        in_flight.push_back(job);
+        t_fetch += now() - t_d;
       }
     const unsigned long before = processed;
     processed += r.n_done;
@@ -847,6 +868,7 @@ int main(int argc, char** argv) {
       fflush(stderr);
     }
     if (r.code != FQG_OK) {
+      land_output();
       drain_or_die();
       if (r.code == FQG_E_WRONG_HEADER) {
         // src/fastq.c:448-451, with the file's own line counter
@@ -878,6 +900,7 @@ int main(int argc, char** argv) {
         if (ended_on_discard && x == P.interleaved[0]) src[x].use -= 1;  // no re-synchronising read after a discard
       }
   }
+  land_output();
   drain_or_die();
   outq.stop();
   if (timing)

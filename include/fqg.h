@@ -331,6 +331,13 @@ int fqg_barcodes_transform(fqg_ctx *ctx, const fqg_frame *const frames[6], const
                            uint64_t n_iterations, uint64_t first_read_number, fqg_barcode_result *out);
 /* copy output `which` (0 SAM, 1, 2) of the last transform to host memory */
 int fqg_barcodes_output(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
+/* ... the same copy on a stream of its own: it returns at once and runs beside whatever the context does next in the
+ * OTHER direction of the link (fqg_validate of the next piece of input: host to device).  host_dst must be pinned
+ * (fqg_host_alloc) for the copy to be asynchronous.  fqg_barcodes_output_wait returns when every such copy has
+ * landed; the next fqg_barcodes_transform / fqg_records_filter / fqg_records_gather of the context, which write
+ * the same device buffers, wait for them by themselves. */
+int fqg_barcodes_output_begin(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
+int fqg_barcodes_output_wait(fqg_ctx *ctx);
 
 /* ---- whitelist membership of a barcode (BASELINE configs[2]: "known_cells whitelist") ------------------
  * The cell barcode that fastq_pre_barcodes cuts out of a read is what bam_umi_count later packs with char2uint_64
