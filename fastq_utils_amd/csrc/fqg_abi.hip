@@ -7,7 +7,6 @@
 
 #include <algorithm>
 #include <memory>
-#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -372,44 +371,6 @@ void fqg_host_free(fqg_ctx* c, void* p) {
   (void)c;
   if (p) (void)hipHostFree(p);
 }
-extern "C++" {
-namespace {
-// Ranges made reachable by fqg_host_register (process-wide: the registrations are portable).  A copy that starts in
-// one registration and ends in the next is two copies to the runtime - it looks the source up as ONE registration and
-// refuses what reaches beyond it - so the image upload is cut where the registrations meet (upload_image).
-struct HostRanges {
-  std::mutex mu;
-  std::vector<std::pair<uintptr_t, uintptr_t>> r;  // [begin, end), unordered (a handful: windows of a mapped file)
-  static HostRanges& get() {
-    static HostRanges* p = new HostRanges;  // (never destroyed: used from reader threads until the process leaves)
-    return *p;
-  }
-};
-hipError_t upload_image(void* dst, const void* src, size_t n, hipStream_t st) {
-  uintptr_t at = (uintptr_t)src;
-  const uintptr_t end = at + n;
-  char* d = static_cast<char*>(dst);
-  while (at < end) {
-    uintptr_t stop = end;
-    {
-      HostRanges& H = HostRanges::get();
-      std::lock_guard<std::mutex> lk(H.mu);
-      for (auto& e : H.r)
-        if (at >= e.first && at < e.second) {
-          stop = std::min(end, e.second);
-          break;
-        }
-    }
-    const hipError_t e = hipMemcpyAsync(d, (const void*)at, stop - at, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return e;
-    d += stop - at;
-    at = stop;
-  }
-  return hipSuccess;
-}
-}  // namespace
-}  // extern "C++"
-
 int fqg_host_register(fqg_ctx* c, const void* p, size_t bytes) {
   if (!c || !p || !bytes) return FQG_ERR_ARG;
   if (hipSetDevice(c->device) != hipSuccess) return FQG_ERR_NO_DEVICE;  // (callable from the programs' reader threads)
@@ -418,22 +379,10 @@ int fqg_host_register(fqg_ctx* c, const void* p, size_t bytes) {
     (void)hipGetLastError();  // (the caller falls back to staging slots: not an error of the context)
     return FQG_ERR_HIP;
   }
-  HostRanges& H = HostRanges::get();
-  std::lock_guard<std::mutex> lk(H.mu);
-  H.r.emplace_back((uintptr_t)p, (uintptr_t)p + bytes);
   return 0;
 }
 int fqg_host_unregister(fqg_ctx* c, const void* p) {
   if (!c || !p) return FQG_ERR_ARG;
-  {
-    HostRanges& H = HostRanges::get();
-    std::lock_guard<std::mutex> lk(H.mu);
-    for (size_t i = 0; i < H.r.size(); ++i)
-      if (H.r[i].first == (uintptr_t)p) {
-        H.r.erase(H.r.begin() + (long)i);
-        break;
-      }
-  }
   return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? 0 : FQG_ERR_HIP;
 }
 
@@ -903,7 +852,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   if (mem == FQG_MEM_HOST) {
     if ((rc = ensure(c, c->image, nbytes + 64))) return rc;
     ProfScope ps(c, "h2d_image");
-    HIP_TRY(c, upload_image(c->image.p, image, nbytes, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->image.p, image, nbytes, hipMemcpyHostToDevice, c->stream));
     d_img = (const uint8_t*)c->image.p;
   } else {
     if (((uintptr_t)image & 15u) != 0) return fail(c, FQG_ERR_ARG, "device image must be 16-byte aligned");

@@ -683,7 +683,7 @@ class Input {
     if (const char* e = getenv("FQGPU_MMAP_WINDOW_KB")) map_win_ = std::max<uint64_t>(4096, (strtoull(e, nullptr, 10) << 10) & ~4095ull);
     // the first window now: a failure here (a limit on locked memory, a file system that cannot be mapped for DMA)
     // means the slots, and nobody has seen a piece yet
-    if (!map_register_next(&map_hi_)) {
+    if (!map_register_next()) {
       munmap(map_, (size_t)plain_size_);
       map_ = nullptr;
       return;
@@ -697,13 +697,12 @@ class Input {
     munmap(map_, (size_t)plain_size_);
     map_ = nullptr;
   }
-  // page tables of the window that starts at `from`, filled by the reader threads (a registration of pages nobody has
-  // touched fills them on ONE thread: 17 - 22 GB/s however many register side by side; MADV_POPULATE_READ on four
-  // threads: 120 GB/s, and the registration behind it 49 GB/s - tools/kbench/regbench.hip)
-  void map_populate(uint64_t from) {
-    const uint64_t len = std::min<uint64_t>(map_win_, plain_size_ - from), padded = (len + 4095) & ~4095ull;
-    const unsigned T = (unsigned)std::min<uint64_t>(std::min(host_read_threads(), 4u), std::max<uint64_t>(1, len >> 22));
-    if (T > 1 && !pool_) pool_.reset(new ReaderPool(4));
+  // [map_hi_, map_hi_ + window) becomes reachable for the copy engine; false: it cannot be
+  bool map_register_next() {
+    const uint64_t from = map_hi_, len = std::min<uint64_t>(map_win_, plain_size_ - from);
+    const uint64_t padded = (len + 4095) & ~4095ull;  // (the mapping covers the file's last page whole)
+    const unsigned T = (unsigned)std::min<uint64_t>(host_read_threads(), std::max<uint64_t>(1, len >> 22));
+    if (T > 1 && !pool_) pool_.reset(new ReaderPool(host_read_threads()));
     auto part = [&](unsigned t) {
       const uint64_t a = (len * t / T) & ~4095ull, b = t + 1 == T ? padded : (len * (t + 1) / T) & ~4095ull;
       if (b > a && madvise(map_ + from + a, (size_t)(b - a), 22 /* MADV_POPULATE_READ, Linux 5.14 */) != 0) {
@@ -713,26 +712,8 @@ class Input {
     };
     if (T <= 1) part(0);
     else pool_->run(T, part);
-  }
-  // [map_hi_, map_hi_ + window) becomes reachable for the copy engine - while the NEXT window's page tables are filled;
-  // false: it cannot be
-  bool map_register_next(uint64_t* new_hi) {
-    const uint64_t from = map_hi_, len = std::min<uint64_t>(map_win_, plain_size_ - from);  // (only this thread moves map_hi_)
-    const uint64_t padded = (len + 4095) & ~4095ull;  // (the mapping covers the file's last page whole)
-    if (map_pop_ <= from) {
-      map_populate(from);
-      map_pop_ = from + len;
-    }
-    std::thread ahead;
-    const uint64_t nxt = from + map_win_;
-    if (nxt < plain_size_ && map_pop_ <= nxt) ahead = std::thread([this, nxt] { map_populate(nxt); });
-    const bool ok = fqg_host_register(ctx_, map_ + from, (size_t)padded) == 0;
-    if (ahead.joinable()) {
-      ahead.join();
-      map_pop_ = std::min<uint64_t>(plain_size_, nxt + map_win_);
-    }
-    if (!ok) return false;
-    *new_hi = from + len;
+    if (fqg_host_register(ctx_, map_ + from, (size_t)padded) != 0) return false;
+    map_hi_ = from + len;
     return true;
   }
   void map_registrar() {
@@ -755,10 +736,8 @@ class Input {
         more = map_hi_ < plain_size_ && map_hi_ < map_want_;
       }
       if (more) {
-        uint64_t hi = 0;
-        const bool ok = map_register_next(&hi);
+        const bool ok = map_register_next();  // (map_hi_ moves under the lock below: readers wait on it)
         std::lock_guard<std::mutex> lk(mu_);
-        if (ok) map_hi_ = hi;  // (under the lock: readers wait on it)
         if (!ok) {
           fail_msg_ = "unable to register the mapped file for the copy engine";
           failed_ = true;
@@ -996,7 +975,7 @@ class Input {
   // a mapped plain file (map_open): the mapping, where the next piece starts, the registered range [map_lo_, map_hi_),
   // how far the registrar is asked to go and what it may give back (all under mu_)
   char* map_ = nullptr;
-  uint64_t map_pos_ = 0, map_lo_ = 0, map_hi_ = 0, map_pop_ = 0, map_want_ = 0, map_release_ = 0, map_win_ = kMapWindow;
+  uint64_t map_pos_ = 0, map_lo_ = 0, map_hi_ = 0, map_want_ = 0, map_release_ = 0, map_win_ = kMapWindow;
   // the reference's gzgets limits (fq_reframe.h); the state belongs to whichever thread reads (producer or next_whole)
   bool reframe_ = false;
   Reframer rf_;
