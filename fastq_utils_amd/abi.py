@@ -25,7 +25,7 @@ CODE_NAMES = {
 # every symbol include/fqg.h declares (checked by tests/test_abi_symbols.py against the header)
 EXPORTS = [
     "fqg_open", "fqg_close", "fqg_last_error", "fqg_abi_version", "fqg_set_stream",
-    "fqg_synchronize", "fqg_host_alloc", "fqg_host_free", "fqg_host_register", "fqg_host_unregister", "fqg_probe_readname_format",
+    "fqg_synchronize", "fqg_host_alloc", "fqg_host_free", "fqg_probe_readname_format",
     "fqg_probe_space", "fqg_probe_first_record", "fqg_acc_create", "fqg_acc_destroy",
     "fqg_acc_reset", "fqg_acc_read", "fqg_acc_hist_nonzero", "fqg_acc_median", "fqg_acc_export",
     "fqg_acc_merge", "fqg_validate", "fqg_frame_records", "fqg_profile_enable",
@@ -192,8 +192,6 @@ def load():
     L.fqg_host_alloc.argtypes = [vp, sz]
     L.fqg_host_alloc.restype = vp
     L.fqg_host_free.argtypes = [vp, vp]
-    L.fqg_host_register.argtypes = [vp, vp, sz]
-    L.fqg_host_unregister.argtypes = [vp, vp]
     L.fqg_host_free.restype = None
     L.fqg_probe_readname_format.argtypes = [C.c_char_p]
     L.fqg_probe_space.argtypes = [C.c_char_p]

@@ -371,20 +371,6 @@ void fqg_host_free(fqg_ctx* c, void* p) {
   (void)c;
   if (p) (void)hipHostFree(p);
 }
-int fqg_host_register(fqg_ctx* c, const void* p, size_t bytes) {
-  if (!c || !p || !bytes) return FQG_ERR_ARG;
-  if (hipSetDevice(c->device) != hipSuccess) return FQG_ERR_NO_DEVICE;  // (callable from the programs' reader threads)
-  const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterReadOnly | hipHostRegisterPortable);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();  // (the caller falls back to staging slots: not an error of the context)
-    return FQG_ERR_HIP;
-  }
-  return 0;
-}
-int fqg_host_unregister(fqg_ctx* c, const void* p) {
-  if (!c || !p) return FQG_ERR_ARG;
-  return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? 0 : FQG_ERR_HIP;
-}
 
 // ---- accumulator --------------------------------------------------------------------------
 int fqg_acc_reset(fqg_acc* a) {

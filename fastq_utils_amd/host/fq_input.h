@@ -33,8 +33,6 @@
 #include <thread>
 #include <vector>
 
-#include <sys/mman.h>
-
 #include "../../include/fqg.h"
 #include "fq_parallel.h"
 #include "fq_pgzip.h"
@@ -262,7 +260,6 @@ class Input {
     // is; the GPU reports a line beyond the limits (FQG_E_LINE_TOO_LONG) and the program starts over with
     // FQGPU_REFRAME set (fq_respawn.h), which brings it here.
     reframe_ = ((gz_ != nullptr || bgzf_fd_ >= 0 || pgz_fd_ >= 0) && reframe_supported()) || reframing();
-    map_open();
   }
   // the producer is told to stop and joined (the destructor; exit(): ExitQuiesce)
   void stop_reading() {
@@ -276,7 +273,6 @@ class Input {
   ~Input() {
     ExitQuiesce::get().remove(this);
     stop_reading();
-    map_close();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     if (bgzf_fd_ >= 0) close(bgzf_fd_);
@@ -295,7 +291,6 @@ class Input {
   // the final piece has been handed out.  An empty file yields one empty, final piece.
   bool next(bool whole_file = false) {
     if (finished_) return false;
-    if (map_) return whole_file ? map_next_whole() : map_next();
     if (whole_file) return next_whole();
     if (!producer_.joinable()) {
       ExitQuiesce::get().add(this, [](void* in) { static_cast<Input*>(in)->stop_reading(); });
@@ -661,147 +656,6 @@ class Input {
     }
   }
 
-  // ---- a plain file handed to the copy engine where it lies in the page cache --------------------------------------
-  // pread into pinned slots is a copy of the whole file through host memory before the copy that matters (12 threads:
-  // 17 GB/s on the round-5 box, beside a link that takes 57 - tools/kbench/regbench.hip); the file's pages can be read
-  // by the copy engine directly once they are registered (hipHostRegister on the mapping: 57 GB/s, no staging).  The
-  // registrar thread stays a few windows ahead of the pieces: page tables filled by many threads
-  // (MADV_POPULATE_READ), then one registration per window; windows behind the piece in hand are given back.  A piece
-  // is [the unconsumed tail of the last one | cap_ fresh bytes] of the MAPPING - nothing is carried by copying.
-  // Not for input that is cut at the gzgets limits (that is a copy by nature) and not where mapping or registering
-  // fails: then the slots take over before the first piece (FQGPU_NO_MMAP=1: never; FQGPU_MMAP_MIN: smallest file).
-  static constexpr uint64_t kMapWindow = 128ull << 20;
-  void map_open() {
-    if (plain_fd_ < 0 || reframe_ || getenv("FQGPU_NO_MMAP")) return;
-    uint64_t least = 32ull << 20;
-    if (const char* e = getenv("FQGPU_MMAP_MIN")) least = strtoull(e, nullptr, 10);
-    if (plain_size_ < std::max<uint64_t>(least, 1)) return;
-    void* m = mmap(nullptr, (size_t)plain_size_, PROT_READ, MAP_SHARED, plain_fd_, 0);
-    if (m == MAP_FAILED) return;
-    map_ = static_cast<char*>(m);
-    map_win_ = kMapWindow;
-    if (const char* e = getenv("FQGPU_MMAP_WINDOW_KB")) map_win_ = std::max<uint64_t>(4096, (strtoull(e, nullptr, 10) << 10) & ~4095ull);
-    // the first window now: a failure here (a limit on locked memory, a file system that cannot be mapped for DMA)
-    // means the slots, and nobody has seen a piece yet
-    if (!map_register_next()) {
-      munmap(map_, (size_t)plain_size_);
-      map_ = nullptr;
-      return;
-    }
-    ExitQuiesce::get().add(this, [](void* in) { static_cast<Input*>(in)->stop_reading(); });
-    producer_ = std::thread([this] { map_registrar(); });
-  }
-  void map_close() {
-    if (!map_) return;
-    for (uint64_t w = map_lo_; w < map_hi_; w += map_win_) fqg_host_unregister(ctx_, map_ + w);
-    munmap(map_, (size_t)plain_size_);
-    map_ = nullptr;
-  }
-  // [map_hi_, map_hi_ + window) becomes reachable for the copy engine; false: it cannot be
-  bool map_register_next() {
-    const uint64_t from = map_hi_, len = std::min<uint64_t>(map_win_, plain_size_ - from);
-    const uint64_t padded = (len + 4095) & ~4095ull;  // (the mapping covers the file's last page whole)
-    const unsigned T = (unsigned)std::min<uint64_t>(host_read_threads(), std::max<uint64_t>(1, len >> 22));
-    if (T > 1 && !pool_) pool_.reset(new ReaderPool(host_read_threads()));
-    auto part = [&](unsigned t) {
-      const uint64_t a = (len * t / T) & ~4095ull, b = t + 1 == T ? padded : (len * (t + 1) / T) & ~4095ull;
-      if (b > a && madvise(map_ + from + a, (size_t)(b - a), 22 /* MADV_POPULATE_READ, Linux 5.14 */) != 0) {
-        volatile char sink = 0;  // (an older kernel: touch the pages)
-        for (uint64_t o = a; o < b && o < len; o += 4096) sink = sink + map_[from + o];
-      }
-    };
-    if (T <= 1) part(0);
-    else pool_->run(T, part);
-    if (fqg_host_register(ctx_, map_ + from, (size_t)padded) != 0) return false;
-    map_hi_ = from + len;
-    return true;
-  }
-  void map_registrar() {
-    for (;;) {
-      uint64_t give_back = 0;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return quit_ || map_release_ > map_lo_ || (map_hi_ < plain_size_ && map_hi_ < map_want_); });
-        if (quit_) return;
-        if (map_release_ > map_lo_) give_back = map_release_;
-      }
-      while (give_back && map_lo_ + map_win_ <= give_back && map_lo_ + map_win_ <= map_hi_) {
-        fqg_host_unregister(ctx_, map_ + map_lo_);
-        std::lock_guard<std::mutex> lk(mu_);
-        map_lo_ += map_win_;
-      }
-      bool more;
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        more = map_hi_ < plain_size_ && map_hi_ < map_want_;
-      }
-      if (more) {
-        const bool ok = map_register_next();  // (map_hi_ moves under the lock below: readers wait on it)
-        std::lock_guard<std::mutex> lk(mu_);
-        if (!ok) {
-          fail_msg_ = "unable to register the mapped file for the copy engine";
-          failed_ = true;
-        }
-        cv_.notify_all();
-        if (!ok) return;
-      }
-    }
-  }
-  // bytes [at, at + n) of the mapping must be registered; keeps the registrar `ahead` windows in front of them
-  bool map_need(uint64_t at, uint64_t n, unsigned ahead, bool fatal = true) {
-    std::unique_lock<std::mutex> lk(mu_);
-    map_want_ = std::max(map_want_, std::min<uint64_t>(plain_size_, at + n + ahead * map_win_));
-    map_release_ = at / map_win_ * map_win_;  // (windows start at multiples of the window size)
-    cv_.notify_all();
-    cv_.wait(lk, [&] { return map_hi_ >= at + n || failed_; });
-    if (failed_ && fatal) {
-      FQ_PRINT_ERROR("%s.\n", fail_msg_.c_str());
-      leave(kExitSys);
-    }
-    return !failed_;
-  }
-  bool map_next() {
-    if (cur_ >= 0) map_pos_ += have_carry_ ? carry_at_ : len_;  // the tail the caller did not consume stays in front
-    const uint64_t carry = cur_ >= 0 && have_carry_ ? len_ - carry_at_ : 0;
-    have_carry_ = false;
-    cur_ = 0;
-    const uint64_t n = std::min<uint64_t>(carry + cap_, plain_size_ - map_pos_);
-    map_need(map_pos_, n, 3);
-    data_ = map_ + map_pos_;
-    len_ = (size_t)n;
-    bytes_handed_out() += n - carry;
-    eof_ = map_pos_ + n == plain_size_;
-    if (eof_) finished_ = true;
-    return true;
-  }
-  bool map_next_whole() {  // the whole rest of the file as one piece
-    if (cur_ >= 0) map_pos_ += have_carry_ ? carry_at_ : len_;
-    const uint64_t carry = cur_ >= 0 && have_carry_ ? len_ - carry_at_ : 0;
-    have_carry_ = false;
-    cur_ = 0;
-    const uint64_t n = plain_size_ - map_pos_;
-    // (the whole file locked in memory at once may be more than the system allows: before anything has been handed
-    // out the staging slots can still take over)
-    const bool first = map_pos_ == 0 && carry == 0;
-    if (!map_need(map_pos_, n, 0, !first)) {
-      stop_reading();
-      map_close();
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        quit_ = failed_ = false;
-      }
-      cur_ = -1;
-      return next_whole();
-    }
-    whole_mode_ = true;
-    data_ = map_ + map_pos_;
-    len_ = (size_t)n;
-    bytes_handed_out() += n - carry;
-    eof_ = true;
-    finished_ = true;
-    return true;
-  }
-
   void produce() {
     // pinning a slot takes as long as filling it: the slots behind the first are allocated by a helper while the first
     // is being read (the file may well end inside the first)
@@ -972,10 +826,6 @@ class Input {
   size_t len_ = 0, carry_at_ = 0, whole_carry_ = 0;
   bool have_carry_ = false, whole_mode_ = false;
   bool eof_ = false, finished_ = false;
-  // a mapped plain file (map_open): the mapping, where the next piece starts, the registered range [map_lo_, map_hi_),
-  // how far the registrar is asked to go and what it may give back (all under mu_)
-  char* map_ = nullptr;
-  uint64_t map_pos_ = 0, map_lo_ = 0, map_hi_ = 0, map_want_ = 0, map_release_ = 0, map_win_ = kMapWindow;
   // the reference's gzgets limits (fq_reframe.h); the state belongs to whichever thread reads (producer or next_whole)
   bool reframe_ = false;
   Reframer rf_;

@@ -55,11 +55,6 @@ int fqg_synchronize(fqg_ctx *ctx);
 /* pinned host memory for staging file contents */
 void *fqg_host_alloc(fqg_ctx *ctx, size_t bytes);
 void fqg_host_free(fqg_ctx *ctx, void *p);
-/* Memory the caller already has - a file mapped from the page cache, say - made reachable for the copy engine where it
- * lies (hipHostRegister, read-only, portable): fqg_validate(FQG_MEM_HOST) on bytes inside a registered range copies
- * them at the rate of pinned memory without a staging copy.  p and bytes: multiples of the page size. */
-int fqg_host_register(fqg_ctx *ctx, const void *p, size_t bytes);
-int fqg_host_unregister(fqg_ctx *ctx, const void *p);
 
 /* ---- per-file state decided from the first record --------------------------------------
  * Mirrors the FASTQ_FILE fields that steer validation (src/fastq.h:125-130): the read-name

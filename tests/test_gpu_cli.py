@@ -165,9 +165,8 @@ def test_duplicates_and_pairs():
             a, b = b"\n".join(la), b"\n".join(lb)
             files = {"a.fastq": a, "b.fastq": b}
             d = put(tmp, "t%d" % trial, files)
-            env = {"FQGPU_MMAP_MIN": "1", "FQGPU_MMAP_WINDOW_KB": "4"} if trial & 1 else None  # (every second pair from the mapped files)
-            jobs += [(d, args, files, env) for args in (["a.fastq"], ["a.fastq", "b.fastq"], ["b.fastq", "a.fastq"],
-                                                        ["-r", "-s", "a.fastq", "b.fastq"], ["-s", "a.fastq", "b.fastq"])]
+            jobs += [(d, args, files, None) for args in (["a.fastq"], ["a.fastq", "b.fastq"], ["b.fastq", "a.fastq"],
+                                                         ["-r", "-s", "a.fastq", "b.fastq"], ["-s", "a.fastq", "b.fastq"])]
         compare_all(jobs)
 
 
@@ -182,12 +181,8 @@ def test_small_pieces_exercise_the_carry():
         for name, img in files.items():
             with open(os.path.join(tmp, name), "wb") as f:
                 f.write(img)
-        # ... from staging slots, and straight from the mapped file (host/fq_input.h: map_open) in windows of 64 KiB: a
-        # piece then spans sixteen registrations and the tail of a piece is the head of the next without a copy
-        mapped = {"FQGPU_CHUNK_MB": "1", "FQGPU_MMAP_MIN": "1", "FQGPU_MMAP_WINDOW_KB": "64"}
-        compare_all([(tmp, args, files, env) for env in ({"FQGPU_CHUNK_MB": "1"}, mapped, dict(mapped, FQGPU_STREAM_MIN="256"))
-                     for args in (["-r", "a.fastq"], ["a.fastq"], ["a.fastq", "b.fastq"], ["d.fastq"], ["-s", "a.fastq", "b.fastq"],
-                                  ["-r", "-s", "a.fastq", "b.fastq"], ["a.fastq", "pe"])])
+        env = {"FQGPU_CHUNK_MB": "1"}
+        compare_all([(tmp, args, files, env) for args in (["-r", "a.fastq"], ["a.fastq"], ["a.fastq", "b.fastq"], ["d.fastq"])])
 
 
 # ---- FQGPU_DEVICES: the -r pass over several contexts (host/fq_multi.h) ---------------------------------------------
@@ -242,8 +237,7 @@ def _overlong():
 
 
 LONG_HOW = {"plain_file": None, "gz_file": None, "gz_file_by_chunks": dict(CHUNKED, FQGPU_PGZIP_CHUNK="30000"),
-            "small_pieces": {"FQGPU_CHUNK_MB": "1"}, "several_devices": {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"},
-            "mapped_file": {"FQGPU_MMAP_MIN": "1", "FQGPU_MMAP_WINDOW_KB": "64", "FQGPU_CHUNK_MB": "1"}}
+            "small_pieces": {"FQGPU_CHUNK_MB": "1"}, "several_devices": {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1"}}
 LONG_ARGS = (["-r", "F"], ["F"], ["F", "pe"], ["-r", "-s", "F", "F"], ["F", "F"])
 LONG_ROOT = tempfile.TemporaryDirectory()
 

@@ -56,8 +56,7 @@ PROGRAMS = {
                                                 "--cell_size", "3", "--read1_offset", "0", "--read1_size", "-1", "--read1", "IN",
                                                 "--outfile1", "-", "--sam"]),
 }
-MAPPED = {"FQGPU_MMAP_MIN": "1", "FQGPU_MMAP_WINDOW_KB": "64", "FQGPU_CHUNK_MB": "1"}  # host/fq_input.h: map_open
-HOW = {"plain_file": None, "gz_file": None, "small_pieces": {"FQGPU_CHUNK_MB": "1"}, "mapped_file": MAPPED,
+HOW = {"plain_file": None, "gz_file": None, "small_pieces": {"FQGPU_CHUNK_MB": "1"},
        "several_devices": {"FQGPU_DEVICES": "0,0", "FQGPU_CHUNK_MB": "1", "FQGPU_BLOCK_RECORDS": "3"}}
 
 
@@ -85,8 +84,7 @@ def one_run(root, exe_dir, prog, which, how):
 ROOT = tempfile.TemporaryDirectory()
 KEYS = [(prog, which, how) for prog in PROGRAMS for which in sorted(IMAGES) for how in HOW
         if not (how == "several_devices" and not prog.startswith("pre_barcodes"))   # (FQGPU_DEVICES: fastq_pre_barcodes only)
-        and not (how == "small_pieces" and which.startswith("nul_"))                # (the NUL images are a few hundred bytes)
-        and not (how == "mapped_file" and which.startswith("nul_") and which not in ("nul_in_seq", "nul_starts_qual"))]
+        and not (how == "small_pieces" and which.startswith("nul_"))]               # (the NUL images are a few hundred bytes)
 # (the programs of all cases start side by side the first time one is asked for: tests/util.py)
 OURS = SideBySide(lambda k: one_run(ROOT.name, BIN, *k), KEYS)
 
