@@ -67,8 +67,42 @@ int main(int argc, char** argv) {
            total / t_read / 1e9, total / t_copy / 1e9, total / (t_read + t_copy) / 1e9);
     CK(hipHostFree(pin));
   }
-  for (unsigned flags : {(unsigned)hipHostRegisterReadOnly, (unsigned)hipHostRegisterDefault}) {
-    for (int T : {1, 2, 4, 8}) {
+  for (unsigned flags : {(unsigned)hipHostRegisterReadOnly, (unsigned)hipHostRegisterDefault, 100u + (unsigned)hipHostRegisterReadOnly}) {
+    const bool populate = flags >= 100u;  // MADV_POPULATE_READ by the threads first, then ONE registration per piece
+    if (populate) flags -= 100u;
+    for (int T : {1, 2, 4, 8, 16}) {
+      // a fresh mapping for every configuration: what a program pays is the COLD cost (page tables to fill)
+      munmap(map, total);
+      map = (char*)mmap(nullptr, total, PROT_READ, MAP_SHARED, fd, 0);
+      if (map == MAP_FAILED) return 3;
+      if (populate) {
+        double t_pop = 0, t_reg = 0, t_copy = 0;
+        for (size_t k = 0; k < n_pieces; ++k) {
+          const double a = now();
+          std::vector<std::thread> th;
+          for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+              const size_t part = (piece / (size_t)T) & ~(size_t)4095, from = (size_t)t * part, len = t == T - 1 ? piece - from : part;
+              if (madvise(map + k * piece + from, len, 22 /* MADV_POPULATE_READ */) != 0) {
+                volatile char sink = 0;
+                for (size_t o = 0; o < len; o += 4096) sink += map[k * piece + from + o];
+              }
+            });
+          for (auto& x : th) x.join();
+          const double b = now();
+          CK(hipHostRegister(map + k * piece, piece, flags));
+          const double c = now();
+          CK(hipMemcpyAsync(dev, map + k * piece, piece, hipMemcpyHostToDevice, st));
+          CK(hipStreamSynchronize(st));
+          t_pop += b - a;
+          t_reg += c - b;
+          t_copy += now() - c;
+          (void)hipHostUnregister(map + k * piece);
+        }
+        printf("populate with %d threads %.2f GB/s, then register %.2f GB/s, copy %.2f GB/s\n", T, total / t_pop / 1e9,
+               total / t_reg / 1e9, total / t_copy / 1e9);
+        continue;
+      }
       double t_reg = 0, t_copy = 0, t_unreg = 0;
       bool ok = true;
       for (size_t k0 = 0; k0 < n_pieces && ok; k0 += (size_t)T) {
