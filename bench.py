@@ -1353,6 +1353,14 @@ def committed_traffic(kernel, n_reads, read_len, record_bytes):
     return None, None
 
 
+def under_a_profiler():
+    """rocprofv3 preloads its tool library and writes its output when the process leaves through exit()"""
+    if os.environ.get("FQGPU_BENCH_PLAIN_EXIT"):
+        return True
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ)
+
+
 def launch_ranks(n_gpus):
     """`python3 bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as CHILDREN (this process
     has not touched the GPU - nothing that initialises HIP is imported before this point - and never execs), relay
@@ -1740,6 +1748,8 @@ def main():
     # drop-in program that left through exit() ended with a segmentation fault once in a few hundred runs)
     sys.stdout.flush()
     sys.stderr.flush()
+    if under_a_profiler():
+        return  # (rocprofv3 writes its files from an exit hook: leave the ordinary way)
     os._exit(0)
 
 
