@@ -1916,17 +1916,16 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint64_t span = ends[1] - (ends[0] + 1) + 1;
     if ((rc = ensure(c, c->bc_out[1], span + 2 * n_rec + 64))) return rc;
-    const uint64_t n_groups = (n_tiles + kRfGroup - 1) / kRfGroup;
-    if ((rc = ensure(c, c->bc_off[1], n_groups * 8 + 16))) return rc;  // look-back state per group of tiles, then the ticket
+    if ((rc = ensure(c, c->bc_off[1], n_tiles * 8 + 16))) return rc;  // look-back state per tile, then the ticket
     unsigned long long* state = (unsigned long long*)c->bc_off[1].p;
-    HIP_TRY(c, hipMemsetAsync(state, 0, n_groups * 8 + 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(state, 0, n_tiles * 8 + 16, c->stream));
     memset(h_tot, 0, 64);
     HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall) + 64, hipMemcpyHostToDevice, c->stream));
     {
       ProfScope ps(c, "k_rf_fused");
-      const RfFused fz{state, state + n_groups, d_tot + 1, (uint8_t*)c->bc_out[1].p, c->d_bcall};
+      const RfFused fz{state, state + n_tiles, d_tot + 1, (uint8_t*)c->bc_out[1].p, c->d_bcall};
       const unsigned lds = tc.in_cap + tc.out_cap;
-      const unsigned grid = (unsigned)std::min<uint64_t>(n_groups, resident((const void*)k_rf_fused_tile, lds));
+      const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_rf_fused_tile, lds));
       hipLaunchKernelGGL(k_rf_fused_tile, dim3(grid), dim3(kWave), lds, c->stream, F, P, tc, n_rec, fz);
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall) + 64, hipMemcpyDeviceToHost, c->stream));
