@@ -1891,13 +1891,20 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   P.min_len = (uint64_t)fp->min_len;
   int rc;
   const uint64_t nb = (n_rec + kScan64Span - 1) / kScan64Span;
+  if ((rc = ensure(c, c->bc_status, n_rec))) return rc;
+  if ((rc = ensure(c, c->bc_len[1], n_rec * 4))) return rc;
+  if ((rc = ensure(c, c->bc_off[1], n_rec * 8))) return rc;
+  if ((rc = ensure(c, c->bc_sum[1], nb * 8))) return rc;
   BcCall z;
   memset(&z, 0, sizeof(z));
   *c->h_bcall = z;
-  // (24 KiB per wavefront for the staged records: tools/tiles_lds_sweep.sh)
+  HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
+  // (the tiles are the EMIT kernel's alone now - the plan works record by record - and that kernel likes 24 KiB per
+  // wavefront better than the 20 KiB it shared with a staging plan: tools/tiles_lds_sweep.sh)
   BcTile tc = bc_tile_for(F, 24576u);
   tc.plan_m = 1;
   const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
+  if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
   auto resident = [&](const void* kernel, unsigned lds) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -1905,45 +1912,6 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
   };
   unsigned long long* d_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_bcall) + sizeof(BcCall));
   unsigned long long* h_tot = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_bcall) + sizeof(BcCall));
-  static const bool two_pass = getenv("FQGPU_RF_TWO_PASS") != nullptr;  // (measurement: plan, scan, emit - rounds 2 to 4)
-  if (!two_pass) {
-    // ONE pass (k_rf_fused_tile): no record keeps more text than it has - a trimmed line may gain the '\n' that an
-    // unterminated last line lacks - so the records' bytes + 2 per record hold whatever is written
-    const uint64_t r0 = first_record, r1 = first_record + n_rec - 1;
-    uint64_t ends[2] = {~0ull, 0};
-    if (r0 > 0) HIP_TRY(c, hipMemcpyAsync(&ends[0], frame->fv.line_end + 4 * r0 - 1, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&ends[1], frame->fv.line_end + 4 * r1 + 3, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint64_t span = ends[1] - (ends[0] + 1) + 1;
-    if ((rc = ensure(c, c->bc_out[1], span + 2 * n_rec + 64))) return rc;
-    if ((rc = ensure(c, c->bc_off[1], n_tiles * 8 + 16))) return rc;  // look-back state per tile, then the ticket
-    unsigned long long* state = (unsigned long long*)c->bc_off[1].p;
-    HIP_TRY(c, hipMemsetAsync(state, 0, n_tiles * 8 + 16, c->stream));
-    memset(h_tot, 0, 64);
-    HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall) + 64, hipMemcpyHostToDevice, c->stream));
-    {
-      ProfScope ps(c, "k_rf_fused");
-      const RfFused fz{state, state + n_tiles, d_tot + 1, (uint8_t*)c->bc_out[1].p, c->d_bcall};
-      const unsigned lds = tc.in_cap + tc.out_cap;
-      const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, resident((const void*)k_rf_fused_tile, lds));
-      hipLaunchKernelGGL(k_rf_fused_tile, dim3(grid), dim3(kWave), lds, c->stream, F, P, tc, n_rec, fz);
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall) + 64, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    out->n_discarded = c->h_bcall->discarded;
-    out->n_trimmed = c->h_bcall->short_warnings;
-    out->n_kept = n_rec - out->n_discarded;
-    out->out_bytes = h_tot[1];
-    c->bc_out_bytes[1] = h_tot[1];
-    return 0;
-  }
-  if ((rc = ensure(c, c->bc_status, n_rec))) return rc;
-  if ((rc = ensure(c, c->bc_len[1], n_rec * 4))) return rc;
-  if ((rc = ensure(c, c->bc_off[1], n_rec * 8))) return rc;
-  if ((rc = ensure(c, c->bc_sum[1], nb * 8))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_bcall, c->h_bcall, sizeof(BcCall), hipMemcpyHostToDevice, c->stream));
-  if ((rc = ensure(c, c->bc_tile_big, n_tiles))) return rc;
   {
     ProfScope ps(c, "k_rf_plan");
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 32));

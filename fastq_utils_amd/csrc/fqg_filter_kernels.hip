@@ -342,170 +342,6 @@ __global__ __launch_bounds__(kWave, 2) void k_rf_emit_tile(BcParams F, RfParams 
   }
 }
 
-// ---- ONE pass: decide, place and write (round 5) ---------------------------------------------------------------
-// The three steps above read the image twice - the plan to learn every record's output length, the emit to write it -
-// and keep 17 bytes per record of plan in memory between them (110 GB of traffic for the 67.5 GB a filter has to move
-// at 100 M reads).  Where a record's text goes is a prefix sum over the lengths of everything before it: here the
-// wavefront that has staged a tile in LDS decides its records, sums their lengths, publishes the tile's total and
-// looks back along the tiles before it for theirs (a decoupled look-back: a tile's word is first its own total, then
-// the total of everything up to and including it; a looker adds totals until it meets one of the second kind) - and
-// writes.  Tiles are handed out by a counter, not by block index: a tile somebody waits for is always in the hands of
-// a wavefront that is running (a grid larger than what the GPU holds at the moment - other processes use it too -
-// cannot wait for a workgroup that has not started).  A tile too large for LDS (long reads) and an image with NUL
-// bytes (lines are C strings: bc_clip_nul) are decided and written record by record from the image, inside the same
-// pass.  State: one 64-bit word per tile, zeroed by the host; *ticket = 0.
-constexpr unsigned long long kLookAgg = 1ull << 62, kLookIncl = 2ull << 62, kLookMask = 3ull << 62;
-struct RfFused {
-  unsigned long long* tile_state;  // [n_tiles]
-  unsigned long long* ticket;      // next tile to hand out
-  unsigned long long* total;       // bytes written in all (the last tile stores it)
-  uint8_t* out;
-  BcCall* call;                    // discarded, short_warnings (= trimmed), big
-};
-__device__ __forceinline__ unsigned long long rf_look_back(const unsigned long long* __restrict__ state, uint64_t tile, int lane) {
-  unsigned long long base = 0;
-  for (int64_t j = (int64_t)tile - 1; j >= 0;) {
-    const int64_t idx = j - lane;
-    unsigned long long v = kLookIncl;  // (in front of tile 0: an inclusive total of nothing)
-    if (idx >= 0) v = __hip_atomic_load(state + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long incl = __ballot((v & kLookMask) == kLookIncl), none = __ballot((v & kLookMask) == 0ull);
-    const int first_incl = incl ? __builtin_ctzll(incl) : 64;
-    const unsigned long long upto = first_incl == 64 ? ~0ull : ((2ull << first_incl) - 1ull);  // lanes 0 .. first_incl
-    if (none & upto) {  // a tile between here and the first inclusive total has not said anything yet
-      __builtin_amdgcn_s_sleep(1);
-      continue;
-    }
-    unsigned long long mine = (upto >> lane) & 1ull ? (v & ~kLookMask) : 0ull;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    base += mine;
-    if (first_incl != 64) break;
-    j -= kWave;
-  }
-  return base;
-}
-
-__global__ __launch_bounds__(kWave, 2) void k_rf_fused_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec, RfFused fz) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
-  uint8_t* s_in = s_lds;
-  uint8_t* s_out = s_lds + tc.in_cap;
-  const int lane = (int)threadIdx.x;
-  const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
-  auto tile_size = [&](uint64_t tile) {
-    const uint64_t left = n_rec - tile * tc.T;
-    return (uint32_t)(left < (uint64_t)tc.T ? left : (uint64_t)tc.T);
-  };
-  auto take = [&]() -> uint64_t {  // the next tile (the same in every lane); n_tiles and beyond: none left
-    unsigned long long t = 0;
-    if (lane == 0) t = atomicAdd(fz.ticket, 1ull);
-    return rfl64(t);
-  };
-  auto clamp_tile = [&](uint64_t t) { return t < n_tiles ? t : n_tiles - 1; };
-  auto geo_of = [&](uint64_t tile, TileGeo& tg) {
-    const uint32_t Tn = tile_size(tile);
-    const uint64_t k = tile * tc.T + ((uint32_t)lane < Tn ? (uint32_t)lane : Tn - 1);
-    bc_geo_load(F.f[1], k, tg.f[1]);
-  };
-  // three tiles under way per wavefront, as in k_rf_emit_tile: the index of the tile after next and the spans of the
-  // next one are requested while the current one is worked on
-  uint64_t t_cur = take(), t_nxt = take(), t_nx2 = 0;
-  if (t_cur >= n_tiles) return;
-  TileGeo cur, nxt, nx2;
-  bc_u32x4 pf[kSpanPf];
-  geo_of(t_cur, cur);
-  geo_of(clamp_tile(t_nxt), nxt);
-  {
-    SpanPlan sp;
-    bc_span_plan<false, 0x02>(F, cur, (int)tile_size(t_cur) - 1, tc.in_cap, sp);
-    bc_span_fetch(sp, lane, pf);
-  }
-  unsigned long long n_disc = 0, n_trim = 0, n_big = 0;
-  for (;; t_cur = t_nxt, t_nxt = t_nx2, cur = nxt, nxt = nx2) {
-    if (t_cur >= n_tiles) break;
-    const uint64_t tile = t_cur;
-    const uint32_t Tn = tile_size(tile);
-    const bool valid = (uint32_t)lane < Tn;
-    const uint64_t k = tile * tc.T + (valid ? (uint32_t)lane : Tn - 1);
-    BcLine L[kBcFiles][4];
-    bool fit;
-    {
-      SpanPlan sp;
-      bc_span_plan<false, 0x02>(F, cur, (int)Tn - 1, tc.in_cap, sp);
-      fit = sp.fit && !F.has_nul;
-      if (fit) bc_span_land(sp, lane, pf, s_in);
-      bc_span_lines<false, 0x02>(F, cur, sp, s_in, L);
-    }
-    t_nx2 = take();
-    {
-      const uint64_t tn = clamp_tile(t_nxt);
-      SpanPlan sp;
-      bc_span_plan<false, 0x02>(F, nxt, (int)tile_size(tn) - 1, tc.in_cap, sp);
-      bc_span_fetch(sp, lane, pf);
-    }
-    geo_of(clamp_tile(t_nx2), nx2);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    RfCut c;
-    uint32_t my_len;
-    if (fit) {
-      c = rf_decide<true>(P, L[1]);
-      my_len = rf_out_len(L[1], c);
-    } else {  // from the image (a lane per record): long reads, lines that are C strings
-      BcLine G[4];
-      bc_lines(F.f[1], k, G);
-      c = rf_decide<false>(P, G);
-      my_len = rf_out_len(G, c);
-    }
-    const bool keep = valid && !(c.flags & kRfDiscard);
-    if (!keep) my_len = 0;
-    n_disc += (unsigned long long)__popcll(__ballot(valid && (c.flags & kRfDiscard)));
-    n_trim += (unsigned long long)__popcll(__ballot(valid && (c.flags & kRfTrimmed)));
-    // where the lane's record starts inside the tile's text, and the tile's total
-    uint32_t incl = my_len;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
-    const uint32_t start = incl - my_len;
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-    if (lane == 0) __hip_atomic_store(fz.tile_state + tile, kLookAgg | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long tile_at = rf_look_back(fz.tile_state, tile, lane);
-    if (lane == 0) {
-      __hip_atomic_store(fz.tile_state + tile, kLookIncl | (tile_at + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (tile + 1 == n_tiles) *fz.total = tile_at + total;
-    }
-    uint8_t* dst = fz.out + tile_at;
-    if (fit && total + 32u <= tc.out_cap) {
-      const uint32_t skew = (uint32_t)((uintptr_t)dst & 15u);
-      if (keep) {
-        LaneWriter w{s_out + skew + start};
-        rf_emit(L[1], c, w);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      emit_flush(s_out, skew, total, dst, lane);
-      __builtin_amdgcn_wave_barrier();
-    } else {  // record by record, all lanes on one record, straight from image to image
-      ++n_big;
-      for (uint32_t j = 0; j < Tn; ++j) {
-        const bool kj = __builtin_amdgcn_readlane((int)(keep ? 1 : 0), (int)j) != 0;
-        if (!kj) continue;
-        BcLine G[4];
-        bc_lines(F.f[1], tile * tc.T + j, G);
-        const RfCut cj = rf_decide<false>(P, G);
-        Writer w{dst + (uint32_t)__builtin_amdgcn_readlane((int)start, (int)j), lane};
-        rf_emit(G, cj, w);
-      }
-    }
-  }
-  if (lane == 0) {
-    if (n_disc) atomicAdd(&fz.call->discarded, n_disc);
-    if (n_trim) atomicAdd(&fz.call->short_warnings, n_trim);  // (the field holds the trimmed count here)
-    if (n_big) atomicAdd(&fz.call->big, n_big);
-  }
-}
-
 // records of the tiles that do not fit LDS: one wavefront per record, straight from image to image
 __global__ __launch_bounds__(kBlock) void k_rf_emit_direct(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
                                                            const uint8_t* __restrict__ status,
