@@ -82,7 +82,7 @@ __device__ __forceinline__ bool bc_has(const BcParams& P, int x) {
 // (strlen, gzputs, printf("%s"), strncpy, the scans) - the line ENDS at its first NUL byte, and a line that ends there
 // has no '\n'.  This is also what a line cut at the gzgets limits is (host/fq_reframe.h: the piece is followed by
 // "\0\n").  Only images that hold a NUL byte come here (BcFile::has_nul); the line is in global memory.
-__device__ inline void bc_clip_nul(BcLine& l) {
+__device__ __forceinline__ void bc_clip_nul(BcLine& l) {
   const uint32_t n = l.len;
   uint32_t i = 0;
   for (; i + 8 <= n; i += 8) {
@@ -114,9 +114,11 @@ __device__ __forceinline__ void bc_lines(const BcFile& f, uint64_t k, BcLine ln[
     ln[i].nl = e < f.fv.nbytes ? 1u : 0u;
     prev = e;
   }
-  if (f.has_nul) {
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) bc_clip_nul(ln[i]);
+  if (f.has_nul) {  // (four calls, not a loop over ln[i]: an index that is no constant puts the lines in scratch memory)
+    bc_clip_nul(ln[0]);
+    bc_clip_nul(ln[1]);
+    bc_clip_nul(ln[2]);
+    bc_clip_nul(ln[3]);
   }
 }
 
