@@ -39,8 +39,8 @@ EXPORTS = [
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
     "fqg_umi_count", "fqg_umi_features", "fqg_umi_record_features", "fqg_umi_replayed_features", "fqg_umi_umis",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
-    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_names_fingerprints_acct", "fqg_device_alloc", "fqg_device_free",
-    "fqg_device_copy", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert",
+    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_names_fingerprints_acct", "fqg_names_fingerprints_named", "fqg_device_alloc", "fqg_device_free",
+    "fqg_device_copy", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert", "fqg_fpset_insert_named",
     "fqg_fpset_candidates", "fqg_fpset_pair_runs", "fqg_frame_name",
 ]
 
@@ -255,6 +255,8 @@ def load():
     L.fqg_fpset_destroy.argtypes = [vp]
     L.fqg_fpset_destroy.restype = None
     L.fqg_fpset_insert.argtypes = [vp, vp, vp, u64]
+    L.fqg_fpset_insert_named.argtypes = [vp, vp, vp, vp, u64]
+    L.fqg_names_fingerprints_named.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, vp, C.POINTER(u64), C.POINTER(u64)]
     L.fqg_fpset_candidates.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
     L.fqg_fpset_pair_runs.argtypes = [vp, vp, C.POINTER(PairSummary), C.POINTER(u64), u64]
     L.fqg_frame_name.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_char_p, u64]
@@ -392,6 +394,9 @@ class PairSummary(C.Structure):
                 ("first_unpaired", C.c_uint64), ("n_complex", C.c_uint64)]
 
 
+NAME_REC_BYTES = 64  # FQG_NAME_REC_BYTES
+
+
 class FingerprintSet:
     """Owner-side collection of read-name fingerprints (fqg_fpset)."""
 
@@ -401,8 +406,14 @@ class FingerprintSet:
         ctx._check(load().fqg_fpset_create(ctx.h, expected, C.byref(h)))
         self.h = h
 
-    def insert(self, device_ptr, n):
-        self.ctx._check(load().fqg_fpset_insert(self.ctx.h, self.h, C.c_void_p(int(device_ptr)), n))
+    def insert(self, device_ptr, n, names_device_ptr=None):
+        """n pairs from device memory; with names_device_ptr also their NAME_REC_BYTES-byte name records (then a
+        holder and its asker only pair when the names are the same bytes: fqg_fpset_insert_named)"""
+        if names_device_ptr is None:
+            self.ctx._check(load().fqg_fpset_insert(self.ctx.h, self.h, C.c_void_p(int(device_ptr)), n))
+        else:
+            self.ctx._check(load().fqg_fpset_insert_named(self.ctx.h, self.h, C.c_void_p(int(device_ptr)),
+                                                          C.c_void_p(int(names_device_ptr)), n))
 
     def candidates(self, cap=1 << 16):
         pairs = (C.c_uint64 * (2 * cap))()
@@ -621,12 +632,18 @@ class Context:
             self._check(load().fqg_barcodes_output(self.h, which, buf, nbytes))
         return buf.raw[:nbytes]
 
-    def names_fingerprints(self, frame, state, record_base, n_owners, out_device_ptr):
+    def names_fingerprints(self, frame, state, record_base, n_owners, out_device_ptr, names_device_ptr=None):
         """(fingerprint, global index) pairs of a retained frame (None: the current one) into device
-        memory, bucketed by owner; returns the bucket sizes."""
+        memory, bucketed by owner; returns the bucket sizes.  names_device_ptr: also the NAME_REC_BYTES-byte name record
+        of every pair, at the same place of that second array."""
         counts = (C.c_uint64 * n_owners)()
-        self._check(load().fqg_names_fingerprints(self.h, frame.h if frame is not None else None, C.byref(state),
-                                                  record_base, n_owners, C.c_void_p(int(out_device_ptr)), counts))
+        if names_device_ptr is None:
+            self._check(load().fqg_names_fingerprints(self.h, frame.h if frame is not None else None, C.byref(state),
+                                                      record_base, n_owners, C.c_void_p(int(out_device_ptr)), counts))
+        else:
+            self._check(load().fqg_names_fingerprints_named(self.h, frame.h if frame is not None else None, C.byref(state),
+                                                            record_base, n_owners, C.c_void_p(int(out_device_ptr)),
+                                                            C.c_void_p(int(names_device_ptr)), counts, None))
         return [int(x) for x in counts]
 
     def fingerprint_set(self, expected):

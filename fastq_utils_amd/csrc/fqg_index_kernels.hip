@@ -761,11 +761,18 @@ __device__ __forceinline__ uint32_t fp_owner(unsigned long long fp, uint32_t n_o
 
 // pass 0: count per owner; pass 1: write into the owner's bucket (cursor[] starts at the bucket offsets)
 constexpr int kFpPerThread = 8;  // records per thread: a workgroup reserves its bucket space once per 2048 records
-template <int PASS>
+// NAMED (pass 1 of a pairing): the name itself travels beside every pair - a 64-byte record [56 name bytes, zero padded |
+// name length] at the pair's place in a second array - so that the owner can hold a holder's name against its
+// asker's BYTES (k_fp_pair_runs).  A name of more than 56 bytes says so by its length: such runs go to the resolution
+// by record index, which fetches whole names.
+constexpr uint32_t kFpNameWords = 8;  // 64-bit words per name record
+template <int PASS, bool NAMED = false>
 __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int fmt, int is_pe, int may_have_nul,
                                                               uint64_t record_base, uint32_t n_owners,
                                                               unsigned long long* __restrict__ cursor,
-                                                              FpRec* __restrict__ out) {
+                                                              FpRec* __restrict__ out,
+                                                              unsigned long long* __restrict__ names_out = nullptr,
+                                                              int weak_bits = 0) {
   __shared__ unsigned int s_cnt[kMaxOwners];
   __shared__ unsigned long long s_base[kMaxOwners];
   if (threadIdx.x < kMaxOwners) s_cnt[threadIdx.x] = 0;
@@ -790,6 +797,10 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
       if (at_sign) {  // (a wrong header is the local pass's finding, src/fastq.c:448)
         if (PASS == 0) name_bytes += acct;
         unsigned long long h = h64;
+        if (weak_bits) {  // (tests, FQGPU_FP_WEAK_BITS: fingerprints of a few bits, no check bits - collisions galore)
+          h &= (1ull << weak_bits) - 1ull;
+          h2 = 0;
+        }
         if (h >= kSlotEmpty - 1) h = kSlotEmpty - 2;
         me[j].fp = h;
         me[j].idx = (record_base + r) | ((h2 << kFpCheckShift) & kFpCheckMask);
@@ -813,6 +824,24 @@ __global__ __launch_bounds__(kBlock) void k_names_fingerprint(FrameView f, int f
 #pragma unroll
   for (int j = 0; j < kFpPerThread; ++j)
     if (have[j]) out[s_base[owner[j]] + slot[j]] = me[j];
+  if (NAMED) {  // (the names once more: eight of them would not stay in registers beside the pairs)
+#pragma unroll 1
+    for (int j = 0; j < kFpPerThread; ++j) {
+      if (!have[j]) continue;
+      const uint64_t r = ((uint64_t)blockIdx.x * kFpPerThread + j) * kBlock + threadIdx.x;
+      const uint64_t b = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+      const uint64_t e = f.line_end[4 * r];
+      uint32_t acct;
+      uint64_t h64;
+      bool at_sign;
+      unsigned long long nm[kNameInline / 8];
+      const uint32_t n = name_and_hash(f.img, f.nbytes, b, e, fmt, is_pe, may_have_nul, &acct, &h64, &at_sign, nullptr, nm);
+      unsigned long long* dst = names_out + (s_base[owner[j]] + slot[j]) * kFpNameWords;
+#pragma unroll
+      for (uint32_t k = 0; k < kNameInline / 8; ++k) dst[k] = nm[k];
+      dst[kFpNameWords - 1] = n;
+    }
+  }
 }
 
 // Owner side: the received pairs are radix-sorted by fingerprint (rocPRIM, stable); equal
@@ -853,29 +882,57 @@ constexpr unsigned long long kFpFile2 = 1ull << 63;
 struct FpPairSummary {
   unsigned long long matched, leftover, unpaired, first_unpaired, n_complex;
 };
+// With names (names != nullptr): val[] holds ARRIVAL POSITIONS, idx_of[] and names[] are in arrival order, and a run of
+// one holder and one asker is a pair only when the two names are the same BYTES (the strcmp behind the key match of
+// src/fastq.c:577-587); names too long for their record leave the run to the resolution by record index.
 __global__ __launch_bounds__(kBlock) void k_fp_pair_runs(const unsigned long long* __restrict__ fp,
-                                                         const unsigned long long* __restrict__ idx, uint64_t n,
+                                                         const unsigned long long* __restrict__ val, uint64_t n,
                                                          unsigned long long* __restrict__ entries, unsigned long long cap,
-                                                         FpPairSummary* __restrict__ sum) {
+                                                         FpPairSummary* __restrict__ sum,
+                                                         const unsigned long long* __restrict__ idx_of = nullptr,
+                                                         const unsigned long long* __restrict__ names = nullptr) {
   __shared__ unsigned long long s_acc[kBlock / kWave][4];
   unsigned long long matched = 0, leftover = 0, unpaired = 0, first = ~0ull;
+  auto index_at = [&](uint64_t e) { return names ? idx_of[val[e]] : val[e]; };
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const unsigned long long f = fp[i];
     if (i > 0 && fp[i - 1] == f) continue;  // not the start of a run
     unsigned long long h = 0, a = 0, min_a = ~0ull, chk_h = 0, chk_a = 0;
-    uint64_t e = i;
+    uint64_t e = i, at_h = 0, at_a = 0;
     for (; e < n && fp[e] == f; ++e) {
-      const unsigned long long v = idx[e];
+      const unsigned long long v = index_at(e);
       if (v & kFpFile2) {
         ++a;
+        at_a = e;
         chk_a = v & kFpCheckMask;
         min_a = (v & kFpIndexMask) < min_a ? (v & kFpIndexMask) : min_a;
       } else {
         ++h;
+        at_h = e;
         chk_h = v & kFpCheckMask;
       }
     }
-    if (h == 1 && a == 1 && chk_h == chk_a) ++matched;
+    bool pair = h == 1 && a == 1 && chk_h == chk_a;
+    bool by_index = false;  // the names decide, and these records cannot: whole names, fetched by record index
+    if (pair && names) {
+      const unsigned long long* nh = names + val[at_h] * kFpNameWords;
+      const unsigned long long* na = names + val[at_a] * kFpNameWords;
+      bool same = true;
+#pragma unroll
+      for (uint32_t k = 0; k < kFpNameWords; ++k) same = same && nh[k] == na[k];
+      if (nh[kFpNameWords - 1] > kNameInline || na[kFpNameWords - 1] > kNameInline) by_index = true;
+      else if (!same) by_index = true;  // (a collision of 87 hash bits: two different names - one left over, one unpaired)
+      pair = same && !by_index;
+    }
+    if (pair) ++matched;
+    else if (by_index) {
+      const unsigned long long at = atomicAdd(&sum->n_complex, (unsigned long long)(e - i));
+      for (uint64_t k = i; k < e; ++k)
+        if (at + (k - i) < cap) {
+          entries[2 * (at + (k - i))] = i;  // the run
+          entries[2 * (at + (k - i)) + 1] = index_at(k) & ~kFpCheckMask;
+        }
+    }
     else if (a == 0) leftover += h;
     else if (h == 0) {
       unpaired += a;
@@ -885,7 +942,7 @@ __global__ __launch_bounds__(kBlock) void k_fp_pair_runs(const unsigned long lon
       for (uint64_t k = i; k < e; ++k)
         if (at + (k - i) < cap) {
           entries[2 * (at + (k - i))] = i;  // the run
-          entries[2 * (at + (k - i)) + 1] = idx[k] & ~kFpCheckMask;
+          entries[2 * (at + (k - i)) + 1] = index_at(k) & ~kFpCheckMask;
         }
     }
   }
@@ -917,6 +974,11 @@ __global__ __launch_bounds__(kBlock) void k_fp_pair_runs(const unsigned long lon
     if (u) atomicAdd(&sum->unpaired, u);
     if (fst != ~0ull) atomicMin(&sum->first_unpaired, fst);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fp_iota(unsigned long long* __restrict__ v, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) v[i] = i;
 }
 
 // split (fp, idx) records into key / value arrays for the sort

@@ -87,25 +87,28 @@ FP_BYTES = 16  # fqg_fp: u64 fingerprint, u64 global record index
 ROUND_PAIRS = 1 << 24  # pairs per (sender, owner) and round: 256 MiB messages
 
 
-def _slice_checksums(buf, counts):
-    """[len(counts), 2] int64: for every slice of `buf` (counts[i] pairs of FP_BYTES bytes, back to back) the sum of
-    its 64-bit words and the sum of their bit-mixed images, both modulo 2^64.  Independent of the order of the pairs
-    inside a slice - which the protocol does not depend on either."""
+NAME_BYTES = 64  # FQG_NAME_REC_BYTES: a name record that travels beside its pair (pairing: the names decide)
+
+
+def _slice_checksums(buf, counts, record_bytes=FP_BYTES):
+    """[len(counts), 2] int64: for every slice of `buf` (counts[i] records of record_bytes bytes, back to back) the sum
+    of its 64-bit words and the sum of their bit-mixed images, both modulo 2^64.  Independent of the order of the
+    records inside a slice - which the protocol does not depend on either."""
     import torch
 
     words = buf.view(torch.int64)
     out = torch.zeros((len(counts), 2), dtype=torch.int64, device=buf.device)
-    p = 0
+    p, wpr = 0, record_bytes // 8
     for i, c in enumerate(counts):
-        w = words[p:p + 2 * c]
-        p += 2 * c
+        w = words[p:p + wpr * c]
+        p += wpr * c
         if c:
             out[i, 0] = w.sum()
             out[i, 1] = (w ^ (w >> 29) ^ (w << 17)).sum()
     return out
 
 
-def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
+def exchange_fingerprints(send, send_counts, group=None, round_pairs=None, record_bytes=FP_BYTES):
     """The all-to-all of fingerprint buckets.  `send`: uint8 tensor holding this rank's buckets back to
     back (bucket o = send_counts[o] pairs of FP_BYTES bytes, for owner o); returns (received uint8
     tensor with the pairs grouped by sender, counts received from every rank).  Works on device
@@ -116,7 +119,7 @@ def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
     import torch
     import torch.distributed as dist
 
-    rp = round_pairs or ROUND_PAIRS
+    rp = round_pairs or max(1, ROUND_PAIRS * FP_BYTES // record_bytes)  # (rounds of at most 256 MiB per peer)
     world = dist.get_world_size(group)
     assert len(send_counts) == world
     cnt_in = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
@@ -126,7 +129,7 @@ def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
     biggest = torch.tensor([max(send_counts + [0])], dtype=torch.int64, device=send.device)
     dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
     rounds = max(1, -(-int(biggest.item()) // rp))
-    recv = torch.empty(max(1, sum(recv_counts)) * FP_BYTES, dtype=torch.uint8, device=send.device)
+    recv = torch.empty(max(1, sum(recv_counts)) * record_bytes, dtype=torch.uint8, device=send.device)
     send_start = [sum(send_counts[:o]) for o in range(world)]
     recv_start = [sum(recv_counts[:r]) for r in range(world)]
     for k in range(rounds):
@@ -135,31 +138,31 @@ def exchange_fingerprints(send, send_counts, group=None, round_pairs=None):
         r_lo = [min(c, k * rp) for c in recv_counts]
         r_n = [min(c, (k + 1) * rp) - lo for c, lo in zip(recv_counts, r_lo)]
         if rounds == 1:
-            src, dst = send[: sum(send_counts) * FP_BYTES], recv[: sum(recv_counts) * FP_BYTES]
+            src, dst = send[: sum(send_counts) * record_bytes], recv[: sum(recv_counts) * record_bytes]
         else:
-            parts = [send[(send_start[o] + s_lo[o]) * FP_BYTES:(send_start[o] + s_lo[o] + s_n[o]) * FP_BYTES]
+            parts = [send[(send_start[o] + s_lo[o]) * record_bytes:(send_start[o] + s_lo[o] + s_n[o]) * record_bytes]
                      for o in range(world)]
             src = torch.cat(parts) if sum(s_n) else send[:0]
-            dst = torch.empty(sum(r_n) * FP_BYTES, dtype=torch.uint8, device=send.device)
-        dist.all_to_all_single(dst, src, output_split_sizes=[c * FP_BYTES for c in r_n],
-                               input_split_sizes=[c * FP_BYTES for c in s_n], group=group)
+            dst = torch.empty(sum(r_n) * record_bytes, dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(dst, src, output_split_sizes=[c * record_bytes for c in r_n],
+                               input_split_sizes=[c * record_bytes for c in s_n], group=group)
         # what arrived is what was sent: a checksum per (sender, owner) slice of the round travels beside it and is
         # held against the received bytes before anybody works on them (the wrong bytes of the 1.6 GB message above
         # would have been findings, or missed findings, of the protocol)
-        sums_out = _slice_checksums(src, s_n)
+        sums_out = _slice_checksums(src, s_n, record_bytes)
         sums_in = torch.empty_like(sums_out)
         dist.all_to_all_single(sums_in, sums_out, group=group)
-        if not torch.equal(sums_in, _slice_checksums(dst, r_n)):
-            bad = (sums_in != _slice_checksums(dst, r_n)).any(dim=1).nonzero().flatten().tolist()
+        if not torch.equal(sums_in, _slice_checksums(dst, r_n, record_bytes)):
+            bad = (sums_in != _slice_checksums(dst, r_n, record_bytes)).any(dim=1).nonzero().flatten().tolist()
             raise RuntimeError(f"fingerprint exchange: round {k}: the bytes received from rank(s) {bad} are not the bytes "
                                f"they sent (checksum mismatch) - the collective delivered wrong data")
         if rounds > 1:
             p = 0
             for r in range(world):
-                recv[(recv_start[r] + r_lo[r]) * FP_BYTES:(recv_start[r] + r_lo[r] + r_n[r]) * FP_BYTES] = \
-                    dst[p * FP_BYTES:(p + r_n[r]) * FP_BYTES]
+                recv[(recv_start[r] + r_lo[r]) * record_bytes:(recv_start[r] + r_lo[r] + r_n[r]) * record_bytes] = \
+                    dst[p * record_bytes:(p + r_n[r]) * record_bytes]
                 p += r_n[r]
-    recv = recv[: sum(recv_counts) * FP_BYTES]
+    recv = recv[: sum(recv_counts) * record_bytes]
     if recv.is_cuda:
         torch.cuda.synchronize(recv.device)  # the library launches on its own stream: the data must have landed
     return recv, recv_counts
@@ -298,23 +301,29 @@ def merge_pairing(parts):
     return (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts), min(firsts) if firsts else None)
 
 
-def _export_fingerprints(ctx, frames, state, base, world, dev, torch):
-    """fingerprints of the frames [(frame, n)] bucketed by owner -> (uint8 tensor, counts per owner)"""
+def _export_fingerprints(ctx, frames, state, base, world, dev, torch, named=False):
+    """fingerprints of the frames [(frame, n)] bucketed by owner -> (per owner: list of uint8 tensors, counts per
+    owner[, per owner: the name records of the same pairs in the same order])"""
     n_local = sum(n for _, n in frames)
     send = torch.empty(max(1, n_local) * FP_BYTES, dtype=torch.uint8, device=dev)
+    names = torch.empty(max(1, n_local) * NAME_BYTES, dtype=torch.uint8, device=dev) if named else None
     per_frame, off = [], 0
     for fr, n in frames:
-        counts = ctx.names_fingerprints(fr, state, base, world, send.data_ptr() + off * FP_BYTES)
+        counts = ctx.names_fingerprints(fr, state, base, world, send.data_ptr() + off * FP_BYTES,
+                                        names.data_ptr() + off * NAME_BYTES if named else None)
         per_frame.append((off, counts))
         off += sum(counts)
         base += n
-    parts = [[] for _ in range(world)]
+    parts, nparts = [[] for _ in range(world)], [[] for _ in range(world)]
     for o0, counts in per_frame:
         p = o0
         for o, c in enumerate(counts):
             parts[o].append(send[p * FP_BYTES:(p + c) * FP_BYTES])
+            if named:
+                nparts[o].append(names[p * NAME_BYTES:(p + c) * NAME_BYTES])
             p += c
-    return parts, [sum(c[o] for _, c in per_frame) for o in range(world)]
+    totals = [sum(c[o] for _, c in per_frame) for o in range(world)]
+    return (parts, totals, nparts) if named else (parts, totals)
 
 
 def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=None, device=None):
@@ -331,16 +340,21 @@ def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=No
 
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    p1, c1 = _export_fingerprints(ctx, frames1, state1, base1, world, dev, torch)
-    p2, c2 = _export_fingerprints(ctx, frames2, state2, base2 | FP_FILE2, world, dev, torch)
+    p1, c1, n1 = _export_fingerprints(ctx, frames1, state1, base1, world, dev, torch, named=True)
+    p2, c2, n2 = _export_fingerprints(ctx, frames2, state2, base2 | FP_FILE2, world, dev, torch, named=True)
     pieces = [t for o in range(world) for t in (p1[o] + p2[o])]
     send = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=dev)
+    npieces = [t for o in range(world) for t in (n1[o] + n2[o])]
+    send_names = torch.cat(npieces) if npieces else torch.empty(0, dtype=torch.uint8, device=dev)
     send_counts = [a + b for a, b in zip(c1, c2)]
     recv, recv_counts = exchange_fingerprints(send, send_counts, group)
+    recv_names, name_counts = exchange_fingerprints(send_names, send_counts, group, record_bytes=NAME_BYTES)
+    assert name_counts == recv_counts
+    del send, send_names, pieces, npieces, p1, p2, n1, n2
     n_recv = sum(recv_counts)
     fps = ctx.fingerprint_set(max(1024, n_recv))
     try:
-        fps.insert(recv.data_ptr(), n_recv)
+        fps.insert(recv.data_ptr(), n_recv, recv_names.data_ptr())
         summary, entries = fps.pair_runs()
     finally:
         fps.close()

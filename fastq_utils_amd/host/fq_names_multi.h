@@ -9,7 +9,10 @@
 //   3. every owner sorts what it received and classifies runs of equal fingerprints on its device
 //      (fqg_fpset_candidates / fqg_fpset_pair_runs);
 //   4. what a fingerprint cannot decide is decided on the name BYTES, fetched from the context that holds the record
-//      (fqg_frame_name) - a hash collision can neither fake nor hide a finding.
+//      (fqg_frame_name) - a hash collision can neither fake nor hide a finding.  In the pairing the names themselves
+//      travel beside the pairs (64-byte records, fqg_names_fingerprints_named / fqg_fpset_insert_named): one holder and
+//      one asker are a pair only when their names are the same bytes, as the strcmp behind the key match says
+//      (src/fastq.c:577-587).
 // One thread per context for steps 1 and 3 (a context is not thread-safe, different contexts are independent).
 #pragma once
 #include <algorithm>
@@ -125,7 +128,7 @@ class NamesExchange {
     *out = PairingOutcome();
     std::vector<const NamesOfFile*> files{&f1, &f2};
     Exchanged x;
-    if (!exchange(files, x)) return false;
+    if (!exchange(files, x, true)) return false;
     struct Part {
       fqg_pair_summary s{};
       std::vector<uint64_t> entries;  // (run, index) pairs
@@ -137,7 +140,7 @@ class NamesExchange {
       parts[o].s.first_unpaired = ~0ull;
       if (!ow.n) return;
       fqg_fpset* set = nullptr;
-      if (fqg_fpset_create(ow.ctx, ow.n, &set) != 0 || fqg_fpset_insert(ow.ctx, set, ow.recv, ow.n) != 0) {
+      if (fqg_fpset_create(ow.ctx, ow.n, &set) != 0 || fqg_fpset_insert_named(ow.ctx, set, ow.recv, ow.recv_names, ow.n) != 0) {
         parts[o].err = fqg_last_error(ow.ctx);
         if (set) fqg_fpset_destroy(set);
         return;
@@ -215,6 +218,7 @@ class NamesExchange {
   struct Owner {
     fqg_ctx* ctx = nullptr;
     void* recv = nullptr;
+    void* recv_names = nullptr;  // (pairing) the name record of every received pair, in the same order
     uint64_t n = 0;
   };
   struct Exchanged {
@@ -233,8 +237,10 @@ class NamesExchange {
     for (auto& t : th) t.join();
   }
   static void release(Exchanged& x) {
-    for (auto& o : x.owners)
+    for (auto& o : x.owners) {
       if (o.recv) fqg_device_free(o.ctx, o.recv);
+      if (o.recv_names) fqg_device_free(o.ctx, o.recv_names);
+    }
     x.owners.clear();
   }
 
@@ -254,7 +260,7 @@ class NamesExchange {
 
   // steps 1 and 2: fingerprints of all files on all contexts, every bucket copied to its owner.  The owners are the
   // contexts of files[0] (every file has a shard on every context, possibly without pieces).
-  bool exchange(const std::vector<const NamesOfFile*>& files, Exchanged& x) {
+  bool exchange(const std::vector<const NamesOfFile*>& files, Exchanged& x, bool named = false) {
     const size_t D = files[0]->shards.size();
     if (D == 0 || D > FQG_MAX_OWNERS) return fail("between 1 and 64 contexts");
     for (auto* f : files)
@@ -262,9 +268,11 @@ class NamesExchange {
     struct Bucket {
       const void* src;
       uint64_t n;
+      const void* nsrc;  // (named) the bucket's name records
     };
     struct Local {
       void* buf = nullptr;
+      void* nbuf = nullptr;
       std::vector<std::vector<Bucket>> to;  // per owner
       uint64_t name_bytes = 0;
       std::string err;
@@ -279,7 +287,8 @@ class NamesExchange {
         for (auto& p : f->shards[d].pieces) total += p.n_records;
       if (!total) return;
       L.buf = fqg_device_alloc(ctx, total * sizeof(fqg_fp));
-      if (!L.buf) {
+      if (named) L.nbuf = fqg_device_alloc(ctx, total * FQG_NAME_REC_BYTES);
+      if (!L.buf || (named && !L.nbuf)) {
         L.err = "device allocation failed";
         return;
       }
@@ -291,14 +300,17 @@ class NamesExchange {
             return;
           }
           uint64_t counts[FQG_MAX_OWNERS], nb = 0;
-          if (fqg_names_fingerprints_acct(ctx, p.frame, &f->st, p.first_record | f->flag, (uint32_t)D,
-                                          (char*)L.buf + off * sizeof(fqg_fp), counts, &nb) != 0) {
+          if (fqg_names_fingerprints_named(ctx, p.frame, &f->st, p.first_record | f->flag, (uint32_t)D,
+                                           (char*)L.buf + off * sizeof(fqg_fp),
+                                           named ? (char*)L.nbuf + off * FQG_NAME_REC_BYTES : nullptr, counts, &nb) != 0) {
             L.err = fqg_last_error(ctx);
             return;
           }
           if (!f->flag) L.name_bytes += nb;
           for (size_t o = 0; o < D; ++o) {
-            if (counts[o]) L.to[o].push_back(Bucket{(char*)L.buf + off * sizeof(fqg_fp), counts[o]});
+            if (counts[o])
+              L.to[o].push_back(Bucket{(char*)L.buf + off * sizeof(fqg_fp), counts[o],
+                                       named ? (char*)L.nbuf + off * FQG_NAME_REC_BYTES : nullptr});
             off += counts[o];
           }
         }
@@ -320,14 +332,17 @@ class NamesExchange {
         for (auto& b : loc[d].to[o]) ow.n += b.n;
       if (!ow.n) continue;
       ow.recv = fqg_device_alloc(ow.ctx, ow.n * sizeof(fqg_fp));
-      if (!ow.recv) {
+      if (named) ow.recv_names = fqg_device_alloc(ow.ctx, ow.n * FQG_NAME_REC_BYTES);
+      if (!ow.recv || (named && !ow.recv_names)) {
         ok = fail("device allocation failed");
         break;
       }
       uint64_t at = 0;
       for (size_t d = 0; d < D && ok; ++d)
         for (auto& b : loc[d].to[o]) {
-          if (fqg_device_copy(ow.ctx, (char*)ow.recv + at * sizeof(fqg_fp), files[0]->shards[d].ctx, b.src, b.n * sizeof(fqg_fp)) != 0) {
+          if (fqg_device_copy(ow.ctx, (char*)ow.recv + at * sizeof(fqg_fp), files[0]->shards[d].ctx, b.src, b.n * sizeof(fqg_fp)) != 0 ||
+              (named && fqg_device_copy(ow.ctx, (char*)ow.recv_names + at * FQG_NAME_REC_BYTES, files[0]->shards[d].ctx, b.nsrc,
+                                        b.n * FQG_NAME_REC_BYTES) != 0)) {
             ok = fail(fqg_last_error(ow.ctx));
             break;
           }
@@ -337,6 +352,7 @@ class NamesExchange {
     for (size_t d = 0; d < D; ++d) {
       x.name_bytes += loc[d].name_bytes;
       if (loc[d].buf) fqg_device_free(files[0]->shards[d].ctx, loc[d].buf);
+      if (loc[d].nbuf) fqg_device_free(files[0]->shards[d].ctx, loc[d].nbuf);
     }
     if (!ok) release(x);
     return ok;

@@ -276,6 +276,17 @@ int fqg_fpset_create(fqg_ctx *ctx, uint64_t expected, fqg_fpset **out);
 void fqg_fpset_destroy(fqg_fpset *set);
 /* fps: DEVICE memory, n fqg_fp */
 int fqg_fpset_insert(fqg_ctx *ctx, fqg_fpset *set, const void *fps_device, uint64_t n);
+/* Pairing with the names themselves (src/fastq.c:577-587: the key match is followed by strcmp).
+ * fqg_names_fingerprints_named writes, beside every pair, a record of FQG_NAME_REC_BYTES at the same place of a second
+ * device array: the name's first 56 bytes, zero padded, and its length; the two arrays travel together, and a set whose
+ * entries were all inserted with fqg_fpset_insert_named counts a holder and its asker as a pair only when the two names
+ * are the same bytes (names beyond 56 bytes, and names that differ under equal fingerprints, are left to the caller's
+ * resolution by record index like every run the fingerprints cannot decide). */
+#define FQG_NAME_REC_BYTES 64
+int fqg_names_fingerprints_named(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t record_base,
+                                 uint32_t n_owners, void *out_device, void *names_device, uint64_t *counts,
+                                 uint64_t *name_bytes);
+int fqg_fpset_insert_named(fqg_ctx *ctx, fqg_fpset *set, const void *fps_device, const void *names_device, uint64_t n);
 /* After every insert: pairs[2k], pairs[2k+1] (host) = (earliest holder, another holder) for every
  * fingerprint value held by more than one of the inserted records; *n_found may exceed cap. */
 int fqg_fpset_candidates(fqg_ctx *ctx, fqg_fpset *set, uint64_t *pairs, uint64_t cap, uint64_t *n_found);

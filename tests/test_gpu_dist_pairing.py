@@ -33,10 +33,12 @@ def mates(img):
     return img.replace(b" 1:N:0:", b" 2:N:0:")
 
 
-def virtual_pairing(ctx, img1, img2, n_shards):
+def virtual_pairing(ctx, img1, img2, n_shards, named=True):
+    """named: the names travel beside the pairs (64-byte records) and the owners hold a holder's name against its
+    asker's bytes - what dist.global_pairing and host/fq_names_multi.h do; False: fingerprints alone"""
     st1, st2 = fq.abi.probe_first_record(img1, True), fq.abi.probe_first_record(img2, True)
     held = []  # (flag, first, cnt, frame, state)
-    bufs, counts = [], []
+    bufs, nbufs, counts = [], [], []
     for img, st, flag, shards in ((img1, st1, 0, n_shards), (img2, st2, fdist.FP_FILE2, max(1, n_shards - 1) if n_shards > 2 else n_shards)):
         for first, cnt, piece in shard_image(img, shards):
             fr = None
@@ -46,8 +48,11 @@ def virtual_pairing(ctx, img1, img2, n_shards):
                 fr = ctx.retain_frame()
             held.append((flag, first, cnt, fr, st))
             buf = torch.empty(max(1, cnt) * fdist.FP_BYTES, dtype=torch.uint8, device="cuda")
-            counts.append(ctx.names_fingerprints(fr, st, first | flag, n_shards, buf.data_ptr()) if cnt else [0] * n_shards)
+            nbuf = torch.empty(max(1, cnt) * fdist.NAME_BYTES, dtype=torch.uint8, device="cuda")
+            counts.append(ctx.names_fingerprints(fr, st, first | flag, n_shards, buf.data_ptr(), nbuf.data_ptr() if named else None)
+                          if cnt else [0] * n_shards)
             bufs.append(buf)
+            nbufs.append(nbuf)
 
     def name_of(g):
         raw, flag = g & ~fdist.FP_FILE2, g & fdist.FP_FILE2
@@ -58,15 +63,16 @@ def virtual_pairing(ctx, img1, img2, n_shards):
 
     parts = []
     for owner in range(n_shards):
-        chunks = []
+        chunks, nchunks = [], []
         for r in range(len(bufs)):
-            start = sum(counts[r][:owner]) * fdist.FP_BYTES
-            chunks.append(bufs[r][start:start + counts[r][owner] * fdist.FP_BYTES])
-        recv = torch.cat(chunks)
+            start = sum(counts[r][:owner])
+            chunks.append(bufs[r][start * fdist.FP_BYTES:(start + counts[r][owner]) * fdist.FP_BYTES])
+            nchunks.append(nbufs[r][start * fdist.NAME_BYTES:(start + counts[r][owner]) * fdist.NAME_BYTES])
+        recv, nrecv = torch.cat(chunks), torch.cat(nchunks)
         n_recv = recv.numel() // fdist.FP_BYTES
         torch.cuda.synchronize()
         s = ctx.fingerprint_set(max(1024, n_recv))
-        s.insert(recv.data_ptr(), n_recv)
+        s.insert(recv.data_ptr(), n_recv, nrecv.data_ptr() if named else None)
         summary, entries = s.pair_runs()
         assert summary["n_complex"] == len(entries)
         s.close()
@@ -155,3 +161,47 @@ def test_protocol_through_a_one_rank_rccl_group(ctx):
                 fr.release()
     finally:
         dist.destroy_process_group()
+
+
+def orphans_on_both_sides(seed, n=3000, long_names=False):
+    """two files of which every seventh read of file 1 and every eleventh of file 2 has no mate, file 2 in another order
+    (long_names: names of 60 - 90 bytes - beyond the 56 a name record holds)"""
+    rng = np.random.default_rng(seed)
+    img1 = fuzz.make_fastq(rng, n, 20, 60, "casava")
+    if long_names:
+        lines = img1.split(b"\n")
+        for k in range(0, len(lines) - 1, 4):  # (header lines only)
+            name, rest = lines[k].split(b" ", 1)
+            lines[k] = name + b":" + b"x" * (40 + len(name) % 30) + b" " + rest
+        img1 = b"\n".join(lines)
+    recs1, recs2 = records_of(img1), records_of(mates(img1))
+    perm = rng.permutation(n)
+    f1 = b"".join(r for i, r in enumerate(recs1) if i % 7)
+    f2 = b"".join(recs2[i] for i in perm if i % 11)
+    return f1, f2
+
+
+@pytest.mark.parametrize("named", [True, False], ids=["names_travel", "fingerprints_alone"])
+@pytest.mark.parametrize("n_shards", [1, 3])
+def test_names_beside_the_pairs_change_nothing_where_fingerprints_are_right(ctx, n_shards, named):
+    for long_names in (False, True):
+        f1, f2 = orphans_on_both_sides(5 + n_shards, long_names=long_names)
+        want = oracle_pairing(f1, f2)
+        got = virtual_pairing(ctx, f1, f2, n_shards, named=named)
+        assert got[3] == want[0] is not None, (got, want)
+
+
+def test_names_decide_where_fingerprints_collide():
+    """FQGPU_FP_WEAK_BITS=10 (a process of its own: the library reads it once): fingerprints of ten bits and no check
+    bits - with hundreds of reads without a mate on both sides, runs of one holder and one asker with DIFFERENT names
+    are the rule.  With the names beside the pairs the outcome is the serial loop's; without them it is not (which
+    is what says that the names decided)."""
+    import subprocess
+    import sys
+
+    from tests.util import REPO
+
+    p = subprocess.run([sys.executable, "-m", "tests.weak_fp_pairing"], cwd=REPO, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, FQGPU_FP_WEAK_BITS="10"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "names_travel: as the serial loop" in p.stdout and "fingerprints_alone: NOT as the serial loop" in p.stdout, p.stdout
