@@ -177,3 +177,54 @@ def test_the_files_umi_numbers_from_the_shards_lists():
     assert dict(zip(keys.tolist(), ids.tolist())) == {50: 1, 7: 2, 900: 3, 3: 4, 11: 5, 2: 6, 1000: 7}
     k0, i0 = fdist.umi_global_table([])
     assert len(k0) == 0 and len(i0) == 0
+
+
+def _exchange_name_records(rank, world, port, q):
+    """the same exchange with 64-byte records (the names that travel beside the pairs in a pairing), in rounds"""
+    import torch
+    import torch.distributed as dist
+
+    from fastq_utils_amd import dist as fdist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        counts = [5 + 3 * rank + o for o in range(world)]
+        send = torch.randint(0, 256, (sum(counts) * fdist.NAME_BYTES,), dtype=torch.uint8, generator=g)
+        whole, c1 = fdist.exchange_fingerprints(send, counts, record_bytes=fdist.NAME_BYTES)
+        rounds, c2 = fdist.exchange_fingerprints(send, counts, round_pairs=2, record_bytes=fdist.NAME_BYTES)
+        assert c1 == c2 == [5 + 3 * r + rank for r in range(world)]
+        assert torch.equal(whole, rounds) and whole.numel() == sum(c1) * fdist.NAME_BYTES
+        # what rank r sent to me is the slice of ITS buffer for owner `rank`
+        p = 0
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            cr = [5 + 3 * r + o for o in range(world)]
+            theirs = torch.randint(0, 256, (sum(cr) * fdist.NAME_BYTES,), dtype=torch.uint8, generator=gr)
+            start = sum(cr[:rank]) * fdist.NAME_BYTES
+            want = theirs[start:start + cr[rank] * fdist.NAME_BYTES]
+            assert torch.equal(whole[p:p + want.numel()], want), (rank, r)
+            p += want.numel()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_of_name_records_two_ranks():
+    import torch.multiprocessing as mp
+
+    from tests.util import free_port
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    ps = [ctx.Process(target=_exchange_name_records, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert got == [(0, "ok"), (1, "ok")], got
