@@ -57,6 +57,21 @@ def damaged(rng, img, p_none, kinds=None):
     return img, what
 
 
+def in_pieces(rng, img, p):
+    """Round 5: with probability p one more kind of damage - a NUL byte somewhere, or a header line beyond the gzgets
+    limit (1000 - 3000 bytes: the reference reads it in pieces and every later line is out of step).  The programs
+    reproduce both since round 5: a line is a C string."""
+    if rng.random() >= p or not img:
+        return img, []
+    if rng.random() < 0.5:
+        return fuzz.mutate(rng, img, "ins_nul"), ["ins_nul"]
+    lines = img.split(b"\n")
+    k = 4 * int(rng.integers(0, max(1, len(lines) // 4)))
+    if k < len(lines) and lines[k]:
+        lines[k] = lines[k][:1] + b"L" * int(rng.integers(1000, 3000)) + lines[k][1:]
+    return b"\n".join(lines), ["long_hdr"]
+
+
 def compare(name, args, files, outs, envs, seed, what):
     """run reference and product in fresh directories; outs: output files to compare when the exit status is 0"""
     ref, prod = binaries(name)
@@ -107,6 +122,9 @@ def one_case(seed):
     b2 = b"".join(b"\n".join(lb[4 * i:4 * i + 4]) + b"\n" for i in order if keep_b[i])
     a2, w1 = damaged(rng, a2, 0.7)
     b2, w2 = damaged(rng, b2, 0.7)
+    a2, x1 = in_pieces(rng, a2, 0.15)
+    b2, x2 = in_pieces(rng, b2, 0.15)
+    w1, w2 = w1 + x1, w2 + x2
     args = ["a.fastq", "b.fastq", "p1.fastq.gz", "p2.fastq.gz", "up.fastq.gz"]
     if rng.random() < 0.25:
         args.append("sorted")
@@ -128,7 +146,8 @@ def one_case(seed):
         recs.append(b"@r%d x\n" % i + bytes(s) + b"\n+\n" + q + b"\n")
     img, w = damaged(rng, b"".join(recs), 0.6)
     nflag = [[], ["-n", str(int(rng.integers(0, 60)))]][int(rng.integers(0, 2))]
-    bad += compare("fastq_filter_n", nflag + ["in.fastq"], {"in.fastq": img}, [], pieces, seed, w)
+    img_n, xn = in_pieces(rng, img, 0.25)
+    bad += compare("fastq_filter_n", nflag + ["in.fastq"], {"in.fastq": img_n}, [], pieces, seed, w + xn)
     if not any(k in w for k in ("del_byte", "truncate", "drop_line", "dup_line", "ins_cr", "empty_hdr")):
         # (lines out of step make the reference print bytes of earlier records: DESIGN 7.1)
         tflags = ["--min_poly_at_len", str(int(rng.integers(1, 30))), "--min_len", str(int(rng.integers(0, 80)))]
@@ -149,6 +168,8 @@ def one_case(seed):
     #  bytes of earlier records that are still in its buffer - DESIGN 7.1; seed 20226 of an earlier version found it)
     i1, w1 = damaged(rng, b"".join(r1), 0.75, ["flip_seq", "bad_at", "empty_hdr", "strip_last_nl", "empty_seq"])
     i2, w2 = damaged(rng, b"".join(r2), 0.75)
+    i2, x2 = in_pieces(rng, i2, 0.2)
+    w2 = w2 + x2
     if rng.random() < 0.2:
         k = int(rng.integers(0, n + 1))
         i2 = b"".join(r2[:k])
