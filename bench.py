@@ -97,6 +97,7 @@ def extras_summary(extras):
         "trim_poly_at_ms": _get(e, "filters_extra", "trim_poly_at", "kernels_ms"),
         "umi_count_kernels_ms": _get(e, "umi_count_extra", "kernels_ms"),
         "umi_count_call_ms": _get(e, "umi_count_extra", "wall_ms_one_call_incl_allocations"),
+        "umi_count_call_ms_index_in_hbm": _get(e, "umi_count_extra", "wall_ms_one_call_index_in_hbm"),
         "umi_matrix_identical_to_reference": _get(e, "umi_count_extra", "matrix_identical_to_reference_program"),
         "filterpair_kernels_ms": _get(e, "filterpair_extra", "kernels_ms"),
         "bam_add_tags_kernels_ms": _get(e, "bam_add_tags_extra", "kernels_ms"),
@@ -1255,9 +1256,26 @@ def umi_extra(ctx, torch, dev, n_triples):
     prof = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if k.startswith(("k_umi", "k_rl"))}
     ctx.profile(False)
     got = run(True)
+    # the same call with the record index resident in HBM beside the records (FQG_MEM_DEVICE_INDEXED): no 52 MB upload
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+
+    def run_indexed(want_entries):
+        return ctx.umi_count(stream.data_ptr(), nbytes=len(hdr) + rec.size, want_entries=want_entries,
+                             offsets_device=(d_offs.data_ptr(), n))
+
+    run_indexed(False)
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    run_indexed(False)
+    ctx.synchronize()
+    wall_indexed = time.perf_counter() - t1
+    got_indexed = run_indexed(True)
     kernels_ms = sum(prof.values())
     out = {
         "what": "bam_umi_count alignment loop + output decisions (fqg_umi_count), BASELINE.json configs[3]",
+        "wall_ms_one_call_index_in_hbm": wall_indexed * 1e3,
+        "index_in_hbm_identical": got_indexed["code"] == got["code"] and got_indexed.get("entries") == got.get("entries"),
         "alignments": n, "distinct_triples": int(len(np.unique((cell.astype(np.int64) * 20000 + gene) * 4 ** 10 + umi.astype(np.int64)))),
         "cells": got["n_cells"], "genes": got["n_features"],
         "matrix_lines": len(got["entries"][0]) if got["code"] == 0 else None,

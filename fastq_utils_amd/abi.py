@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfqgpu.so")
 
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_DEVICE_INDEXED = 0, 1, 2
 VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE, VALIDATE_FRAME_ONLY = 0, 1, 2, 4, 8
 VALIDATE_TWO_PASS = 16
 VALIDATE_NAMES = 32
@@ -705,7 +705,7 @@ class Context:
     def umi_count(self, stream, offsets=None, sorted_by_cell=True, uniq_mapped_only=False, feat_tag=b"GX",
                   cell_tag=b"CR", umi_tag=b"RX", max_cells=None, max_features=100000, min_reads=0, min_umis=0,
                   known_umis=None, known_cells=None, nbytes=None, want_entries=True, defer_output=False,
-                  strict_set=False, umi_table=None, db_start=None, db_skip=0):
+                  strict_set=False, umi_table=None, db_start=None, db_skip=0, offsets_device=None):
         """bam_umi_count's alignment loop on an inflated BAM stream: bytes (host) or an int device pointer
         (then `nbytes` and `offsets` are required).  Returns the result fields plus, when the call
         succeeded, feature names / packed cells in id order and the (row, col, value) lines."""
@@ -714,7 +714,10 @@ class Context:
         if host:
             buf = (C.c_char * len(stream)).from_buffer_copy(stream)
             nbytes = len(stream)
-        if offsets is None:
+        if offsets_device is not None:  # (device pointer, number of records): the index lies in HBM beside the records
+            assert not host
+            offs, n_rec = C.cast(C.c_void_p(int(offsets_device[0])), C.POINTER(C.c_uint64)), int(offsets_device[1])
+        elif offsets is None:
             n, used = C.c_uint64(), C.c_uint64()
             self._check(L.fqg_bam_index_records(buf, nbytes, None, 0, C.byref(n), C.byref(used)))
             offs = (C.c_uint64 * max(1, n.value))()
@@ -750,7 +753,8 @@ class Context:
             p.n_umi_table = len(tk)
         r = UmiResult()
         self._check(L.fqg_umi_count(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
-                                    MEM_HOST if host else MEM_DEVICE, offs, n_rec, C.byref(p), C.byref(r)))
+                                    MEM_HOST if host else (MEM_DEVICE_INDEXED if offsets_device is not None else MEM_DEVICE), offs,
+                                    n_rec, C.byref(p), C.byref(r)))
         out = self._umi_result(r)
         if r.code == 0 and want_entries:
             names = C.create_string_buffer(max(1, r.n_features * 25))
@@ -803,7 +807,10 @@ class Context:
         if host:
             buf = (C.c_char * max(1, len(stream))).from_buffer_copy(stream)
             nbytes = len(stream)
-        if offsets is None:
+        if offsets_device is not None:  # (device pointer, number of records): the index lies in HBM beside the records
+            assert not host
+            offs, n_rec = C.cast(C.c_void_p(int(offsets_device[0])), C.POINTER(C.c_uint64)), int(offsets_device[1])
+        elif offsets is None:
             n, used = C.c_uint64(), C.c_uint64()
             self._check(L.fqg_bam_index_records(buf, nbytes, None, 0, C.byref(n), C.byref(used)))
             offs = (C.c_uint64 * max(1, n.value))()
@@ -829,7 +836,8 @@ class Context:
         p.names, p.names_bytes = keep[4], len(blob)
         r = BamTagsResult()
         self._check(L.fqg_bam_add_tags(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
-                                       MEM_HOST if host else MEM_DEVICE, offs, n_rec, C.byref(p), C.byref(r)))
+                                       MEM_HOST if host else (MEM_DEVICE_INDEXED if offsets_device is not None else MEM_DEVICE), offs,
+                                    n_rec, C.byref(p), C.byref(r)))
         out = {k: getattr(r, k) for k, _ in BamTagsResult._fields_ if k != "reserved"}
         if r.code == 0 and want_output:
             dst = C.create_string_buffer(max(1, r.out_bytes))

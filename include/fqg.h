@@ -40,6 +40,7 @@ extern "C" {
 
 #define FQG_MEM_HOST 0
 #define FQG_MEM_DEVICE 1
+#define FQG_MEM_DEVICE_INDEXED 2 /* fqg_umi_count: the record stream AND the array of record offsets are device memory */
 
 typedef struct fqg_ctx fqg_ctx;
 typedef struct fqg_acc fqg_acc;
@@ -466,6 +467,9 @@ void fqg_unpack_barcode(uint64_t v, char *out);
  * too small `cap` (*n then holds the number needed). */
 int fqg_bam_index_records(const void *stream, uint64_t nbytes, uint64_t *offsets, uint64_t cap, uint64_t *n,
                           uint64_t *used);
+/* mem: where `stream` lies.  offsets is host memory - 8 bytes per alignment to upload, 1 ms of a 6 ms call on
+ * BASELINE configs[3] - unless mem is FQG_MEM_DEVICE_INDEXED (a caller that keeps the inflated records in HBM keeps
+ * their index there too). */
 int fqg_umi_count(fqg_ctx *ctx, const void *stream, uint64_t nbytes, int mem, const uint64_t *offsets,
                   uint64_t n_records, const fqg_umi_params *params, fqg_umi_result *out);
 /* After fqg_umi_count(defer_output = 1): apply the output rules with feature ids mapped through

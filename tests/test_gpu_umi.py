@@ -420,3 +420,28 @@ def test_sharded_protocol_through_a_one_rank_group(ctx):
             whole["n_entries"], whole["total"], whole["tot_reads"], whole["tot_umi"])
     finally:
         dist.destroy_process_group()
+
+
+def test_record_index_resident_on_the_device(ctx):
+    """FQG_MEM_DEVICE_INDEXED: records and their offsets in device memory give what host offsets give"""
+    import numpy as np
+
+    torch = pytest.importorskip("torch")
+    from tests import bamgen
+
+    rng = np.random.default_rng(12)
+    rec, _, _, _ = bamgen.config4(rng, n_cells=40, n_genes=300, n_triples=20000)
+    hdr = bamgen.header()
+    n = rec.shape[0]
+    blob = hdr + rec.tobytes()
+    dev = torch.device("cuda", 0)
+    stream = torch.frombuffer(bytearray(blob + b"\0" * 64), dtype=torch.uint8).to(dev)
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(bamgen.REC_BYTES) + np.uint64(len(hdr))
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    a = ctx.umi_count(blob)
+    b = ctx.umi_count(stream.data_ptr(), offsets=list(int(x) for x in offs), nbytes=len(blob))
+    c = ctx.umi_count(stream.data_ptr(), nbytes=len(blob), offsets_device=(d_offs.data_ptr(), n))
+    assert a["code"] == b["code"] == c["code"] == 0
+    for k in ("entries", "features", "cells", "n_counted", "n_new", "rl_replayed"):
+        assert a[k] == b[k] == c[k], k
