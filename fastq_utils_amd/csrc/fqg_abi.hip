@@ -80,6 +80,7 @@ struct fqg_ctx {
   hipStream_t out_stream = nullptr;   // fqg_barcodes_output_begin: device-to-host copies beside the next piece's upload
   hipEvent_t out_ready = nullptr;     // ... recorded on `stream` where the output was produced
   bool out_pending = false;
+  uint64_t umi_replay_lds = 0, umi_cells_lds = 0;  // dynamic LDS sizes k_rl_replay / k_umi_cells have been allowed (fqg_umi_abi.inc)
   hipStream_t stream = nullptr;
   std::string err;
   int cu_count = 256;

@@ -62,8 +62,11 @@ __global__ __launch_bounds__(kBlock) void k_umi_cell_first(uint64_t n_slots, Key
   if (f == kNoIdx) return;
   cell_first[pc.at(f) + 1u] = f;
 }
-__global__ __launch_bounds__(kBlock) void k_umi_cell_sizes(uint32_t n_cells, uint32_t n, uint32_t* __restrict__ cell_first,
-                                                           UmiCall* __restrict__ call) {
+// (n_cells is read from the device - tot[1], the scan's total - so that the kernel can be launched before the host has
+// seen it: the grid covers n + 1 threads, the number of cells a call of n alignments can have at most)
+__global__ __launch_bounds__(kBlock) void k_umi_cell_sizes(const unsigned long long* __restrict__ tot, uint32_t n,
+                                                           uint32_t* __restrict__ cell_first, UmiCall* __restrict__ call) {
+  const uint32_t n_cells = (uint32_t)tot[1];
   const uint32_t c = blockIdx.x * kBlock + threadIdx.x + 1u;
   if (c == n_cells + 1u) cell_first[c] = n;
   if (c > n_cells) return;
