@@ -14,15 +14,35 @@ import gzip
 VERSION = b"fastq_utils 0.25.3\n"
 
 
+MAX_LABEL_LENGTH = 1000      # src/fastq.h:36
+MAX_READ_LENGTH = 2500000    # src/fastq.h:32
+
+
+def _gzgets(data, pos, limit):
+    """gzgets(fd, buf, limit): at most limit - 1 bytes, through the first '\n' -> (piece, new pos); b"" at the end of
+    the file (GZ_READ then stores a NUL in buf[0], src/fastq.c:202-206)"""
+    end = data.find(b"\n", pos, pos + limit - 1)
+    stop = end + 1 if end >= 0 else min(len(data), pos + limit - 1)
+    return data[pos:stop], stop
+
+
 def _lines4(data):
-    """-> (records as 4-tuples of bytes lines with '\\n', tail_lines)"""
-    lines = data.split(b"\n")
-    last = lines.pop()  # text after the final '\n' ('' when the file ends with one)
-    lines = [ln + b"\n" for ln in lines]
-    if last:
-        lines.append(last)
-    n = len(lines) // 4
-    return [tuple(lines[4 * i:4 * i + 4]) for i in range(n)], len(lines) - 4 * n
+    """fastq_read_entry until it returns 0 or exits (src/fastq.c:245-261) -> (records as 4-tuples of the pieces the
+    four reads return, tail): tail != 0 = the reference ends with "file truncated" after these records.  A line longer
+    than its read's buffer comes back in pieces, the next piece to the NEXT read; a record whose first read yields a
+    string that starts with NUL (or nothing) ends the file quietly, one whose other reads do is the truncation."""
+    records, pos = [], 0
+    while pos < len(data):
+        h1, pos = _gzgets(data, pos, MAX_LABEL_LENGTH)
+        if h1[:1] == b"\0":
+            break
+        seq, pos = _gzgets(data, pos, MAX_READ_LENGTH)
+        h2, pos = _gzgets(data, pos, MAX_LABEL_LENGTH)
+        qual, pos = _gzgets(data, pos, MAX_READ_LENGTH)
+        if any(x[:1] in (b"", b"\0") for x in (seq, h2, qual)):
+            return records, 1
+        records.append((h1, seq, h2, qual))
+    return records, 0
 
 
 def _cstr(b):
