@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -257,6 +258,41 @@ extern "C" {
 
 int fqg_abi_version(void) { return FQG_ABI_VERSION; }
 
+// The runtime prepares its path for copies of more than a few KiB when the first one is submitted (13 ms,
+// tools/kbench/firstcopy.hip), and threads that submit their first ones at the same moment - the contexts of
+// FQGPU_DEVICES, a thread each, every one with the first piece of a file - can die inside that preparation or leave a
+// copy that never completes: 27 of 2 600 runs of one fuzz-campaign case ended with SIGSEGV below hipMemcpyAsync and
+// one hung in hipStreamSynchronize, none of 3 900 with such a copy made beforehand by ONE thread
+// (tools/repro_campaign_case.py, profiles/r05t_first_copy_race.txt).  So when a process opens a SECOND context - the
+// only way two threads can be copying at once: a context is one thread's at a time - the opening thread makes that
+// first copy on every device that has a context, before it hands anything to other threads.  (A process with one
+// context does not pay for it: most never copy that much.)  FQGPU_NO_FIRST_COPY=1 leaves it out, for that tool.
+static void first_large_copy(int device) {
+  static std::mutex mu;
+  static std::vector<int> opened, copied;
+  static const bool off = getenv("FQGPU_NO_FIRST_COPY") != nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  opened.push_back(device);
+  if (off || opened.size() < 2) return;
+  constexpr size_t kBytes = 256u << 10;
+  for (int dev : opened) {
+    if (std::find(copied.begin(), copied.end(), dev) != copied.end()) continue;
+    copied.push_back(dev);
+    void *h = nullptr, *d = nullptr;
+    hipStream_t st = nullptr;
+    if (hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+        hipHostMalloc(&h, kBytes, hipHostMallocPortable) == hipSuccess && hipMalloc(&d, kBytes) == hipSuccess) {
+      (void)hipMemcpyAsync(d, h, kBytes, hipMemcpyHostToDevice, st);
+      (void)hipMemcpyAsync(h, d, kBytes, hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+    }
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  (void)hipSetDevice(device);
+}
+
 int fqg_open(int device_ordinal, fqg_ctx** out) {
   if (!out) return FQG_ERR_ARG;
   *out = nullptr;
@@ -284,6 +320,7 @@ int fqg_open(int device_ordinal, fqg_ctx** out) {
     fqg_close(c);
     return FQG_ERR_NOMEM;
   }
+  first_large_copy(device_ordinal);
   *out = c;
   return 0;
 }

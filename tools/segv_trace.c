@@ -19,6 +19,17 @@ static void on_signal(int sig, siginfo_t* si, void* ctx) {
   _exit(128 + sig);
 }
 
+/* SIGUSR1 (tools/repro_campaign_case.py sends it to every thread of a run that does not end): where this thread is */
+static void on_ask(int sig) {
+  (void)sig;
+  char line[96];
+  int n = snprintf(line, sizeof(line), "\n[segv_trace] thread %d of pid %d is here:\n", (int)gettid(), (int)getpid());
+  if (n > 0) (void)!write(2, line, (size_t)n);
+  void* frames[64];
+  const int depth = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, depth, 2);
+}
+
 __attribute__((constructor)) static void install(void) {
   struct sigaction sa;
   memset(&sa, 0, sizeof(sa));
@@ -27,4 +38,9 @@ __attribute__((constructor)) static void install(void) {
   sigaction(SIGSEGV, &sa, 0);
   sigaction(SIGBUS, &sa, 0);
   sigaction(SIGABRT, &sa, 0);
+  struct sigaction ask;
+  memset(&ask, 0, sizeof(ask));
+  ask.sa_handler = on_ask;
+  ask.sa_flags = SA_RESTART;
+  sigaction(SIGUSR1, &ask, 0);
 }
