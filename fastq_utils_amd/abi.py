@@ -13,6 +13,7 @@ MEM_HOST, MEM_DEVICE, MEM_DEVICE_INDEXED = 0, 1, 2
 VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE, VALIDATE_FRAME_ONLY = 0, 1, 2, 4, 8
 VALIDATE_TWO_PASS = 16
 VALIDATE_NAMES = 32
+VALIDATE_INDEX = 128  # the frame will be used: the whole line index in this call, not on demand
 NAME_DEFAULT, NAME_CASAVA18, NAME_INTEGER, NAME_UNDEF = 0, 1, 2, -1
 SPACE_SEQ, SPACE_COLOUR, SPACE_UNDEF = 0, 1, -1
 

@@ -102,6 +102,14 @@ struct fqg_ctx {
   DevBuf queue;       // streaming path: u64 suspect byte positions
   DevBuf redo;        // streaming path: u32 chunks whose checks are repeated with the true rank
   DevBuf lines_slow;  // streaming path: one byte per step that k_stream_lines_fast leaves to the general kernel
+  // The line index on demand (LinesArgs::no_index): the streaming path's line kernels have checked the records but
+  // stored only the index's tail; `args` are the arguments of the run that stores it all (index_now).
+  struct LazyIndex {
+    bool pending = false;
+    bool fast = false;  // k_stream_lines_fast + the steps it marked, or the general kernel alone
+    unsigned grid = 0, grid_f = 0;
+    LinesArgs args;
+  } lazy;
   DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
   DevBuf name_hcount; // ... and the headers every chunk saw
   DevBuf name_redo, name_redo_chunks;  // what the capture-fed name kernel leaves to the line-index one
@@ -680,7 +688,7 @@ struct RecordDuties {  // what k_stream_lines needs from the caller of frame_str
 };
 
 int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_chunks, bool final, SuspectMap sm,
-                 const RecordDuties& rd, bool want_names, Framed* out) {
+                 const RecordDuties& rd, bool want_names, bool want_index, Framed* out) {
   int rc;
   c->names_img = nullptr;
   const uint32_t n_spans = (n_chunks + kScanSpan - 1) / kScanSpan;
@@ -786,6 +794,14 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     A.hist = rd.hist;
     static const int lines_abl = measure_int("FQGPU_LINES_ABL");
     A.ablate = lines_abl;
+    // the index on demand: when the caller has not said it wants it, and nothing queued by pass 1 needs it (the
+    // queue kernel finds its records through the index).  FQGPU_EAGER_INDEX=1: always in this call (A/B)
+    static const bool eager_index = getenv("FQGPU_EAGER_INDEX") != nullptr;
+    const bool lazy = !want_index && !eager_index && c->h_cs->queue_count == 0;
+    A.no_index = lazy ? 1u : 0u;
+    A.index_only = 0u;
+    A.keep_from = limit >= 8 ? limit - 8 : 0;
+    c->lazy.pending = false;
     {
       ProfScope ps(c, "k_stream_lines");
       const uint64_t groups = (n_lines_all + 4 * kWave - 1) / (4 * kWave);
@@ -802,6 +818,8 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
       // (more than 64 newlines in an average chunk - reads below 100 bases - or fewer than 32 - reads of kilobases: hardly a
       // step would qualify for the kernel without a search)
       const double nl_per_chunk = (double)out->n_newlines / (double)std::max<uint32_t>(n_chunks, 1);
+      c->lazy.grid = grid;
+      c->lazy.fast = false;
       if (general_only || nl_per_chunk > 60.0 || nl_per_chunk < 32.0) {
         hipLaunchKernelGGL(k_stream_lines<false>, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)nullptr);
       } else {
@@ -818,11 +836,21 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
         const unsigned grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
         hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, c->stream, A, (uint8_t*)c->lines_slow.p);
         hipLaunchKernelGGL(k_stream_lines<true>, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)c->lines_slow.p);
+        c->lazy.grid_f = grid_f;
+        c->lazy.fast = true;
       }
+    }
+    if (lazy) {
+      c->lazy.pending = true;
+      c->lazy.args = A;
+      c->lazy.args.no_index = 0u;
+      c->lazy.args.index_only = 1u;
+      c->lazy.args.acc = nullptr;
+      c->lazy.args.hist = nullptr;
     }
     out->records_done = true;
   }
-  {
+  if (!c->lazy.pending) {  // (on demand only when pass 1 queued nothing: see above)
     ProfScope ps(c, "k_stream_queue");
     hipLaunchKernelGGL(k_stream_queue, dim3(64), dim3(kBlock), 0, c->stream, (const unsigned long long*)c->queue.p,
                        (unsigned long long)kStreamQueueCap, (const uint64_t*)c->line_end.p, n_lines_all, limit / 4, sm,
@@ -854,6 +882,24 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
   return 0;
 }
 
+// The line index of the current frame, if the call that framed it left it for later (LinesArgs::no_index): the line
+// kernels once more, stores only, on the context's stream - whatever is launched behind them there finds it written.
+int index_now(fqg_ctx* c) {
+  if (!c->lazy.pending) return 0;
+  c->lazy.pending = false;
+  HIP_TRY(c, hipSetDevice(c->device));
+  ProfScope ps(c, "k_stream_lines_index");
+  const LinesArgs& A = c->lazy.args;
+  if (c->lazy.fast) {
+    hipLaunchKernelGGL(k_stream_lines_fast, dim3(c->lazy.grid_f), dim3(kBlock), 0, c->stream, A, (uint8_t*)c->lines_slow.p);
+    hipLaunchKernelGGL(k_stream_lines<true>, dim3(c->lazy.grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)c->lines_slow.p);
+  } else {
+    hipLaunchKernelGGL(k_stream_lines<false>, dim3(c->lazy.grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)nullptr);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, int mem, int final,
@@ -866,6 +912,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   memset(out, 0, sizeof(*out));
   c->frame_valid = false;
   c->frame_borrowed = false;
+  c->lazy.pending = false;
   c->names_img = nullptr;
   HIP_TRY(c, hipSetDevice(c->device));
   if (nbytes == 0) return 0;
@@ -906,7 +953,8 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   bool streamed = false;
   if (want_checks && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS)) {
     RecordDuties rd{st->space, weight, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr};
-    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, (flags & FQG_VALIDATE_NAMES) != 0, &fr);
+    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, (flags & FQG_VALIDATE_NAMES) != 0,
+                      (flags & (FQG_VALIDATE_NAMES | FQG_VALIDATE_INDEX)) != 0, &fr);
     if (rc < 0) return rc;
     streamed = rc == 0;
     if (!streamed) HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(sm.cap / 32 + 2) * 4, c->stream));
@@ -1002,7 +1050,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
                            (unsigned long long*)c->list.p, list_cap, &c->d_cs->list_count,
                            acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr, c->d_cs);
       }
-      {
+      if (!c->lazy.pending) {  // (on demand: once the number of listed records is known, below)
         ProfScope ps(c, "k_validate_exact");
         hipLaunchKernelGGL(k_validate_exact, dim3(c->cu_count * 2), dim3(kBlock), 0, c->stream, fv, st->is_pe,
                            st->readname_format, st->space, weight, (AccState*)nullptr,
@@ -1024,6 +1072,18 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
                               hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->lazy.pending && fast && n_records && c->h_cs->list_count > 0 && c->h_cs->list_count <= list_cap &&
+      !(c->h_cs->flags & (kFlagSuspectOverflow | kFlagQueueOverflow))) {
+    // records the line kernels could not vouch for: the exact validator reads them through the index
+    if ((rc = index_now(c))) return rc;
+    ProfScope ps(c, "k_validate_exact");
+    hipLaunchKernelGGL(k_validate_exact, dim3(c->cu_count * 2), dim3(kBlock), 0, c->stream, fv, st->is_pe,
+                       st->readname_format, st->space, weight, (AccState*)nullptr,
+                       (unsigned long long*)nullptr, c->d_cs, kNoRecord,
+                       (const unsigned long long*)c->list.p, (const unsigned long long*)&c->d_cs->list_count);
+    HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   out->n_records = n_records;
   out->n_lines = n_lines_all;
   out->tail_lines = nul_truncated ? 1 : (final && leftover && !out->stopped && !tail_is_stop) ? (int32_t)leftover : 0;
@@ -1034,6 +1094,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
       (c->h_cs->list_count > list_cap || (c->h_cs->flags & (kFlagSuspectOverflow | kFlagQueueOverflow)))) {
     // more suspects than the queue / bitmap holds (e.g. every record carries its name on line 3):
     // let the exact validator look at every record; the statistics of the tiled pass stand
+    if ((rc = index_now(c))) return rc;
     ProfScope ps(c, "k_validate_exact");
     hipLaunchKernelGGL(k_validate_exact, dim3(grid_for_waves(c, n_records)), dim3(kBlock), 0, c->stream, fv,
                        st->is_pe, st->readname_format, st->space, weight, (AccState*)nullptr,
@@ -1046,6 +1107,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
     out->record = c->h_cs->first_key >> 8;
     out->code = (int32_t)(c->h_cs->first_key & 0xFF);
     if (out->code != FQG_E_LINE_TOO_LONG) {  // (that one has no arguments, and its record may be the incomplete last one)
+      if ((rc = index_now(c))) return rc;
       hipLaunchKernelGGL(k_validate_exact, dim3(1), dim3(kBlock), 0, c->stream, fv, st->is_pe,
                          st->readname_format, st->space, 1u, (AccState*)nullptr, (unsigned long long*)nullptr,
                          c->d_cs, out->record, (const unsigned long long*)nullptr,
@@ -1074,6 +1136,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
 int fqg_frame_records(fqg_ctx* c, uint64_t first, uint64_t count, fqg_record* out, int mem) {
   if (!c || (!out && count)) return FQG_ERR_ARG;
   if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  if (const int irc = index_now(c)) return irc;
   if (first + count > c->frame.n_records) return fail(c, FQG_ERR_ARG, "record range outside the frame");
   if (!count) return 0;
   int rc;
@@ -1107,6 +1170,7 @@ int fqg_frame_make_current(fqg_ctx* c, const fqg_frame* f) {
   if (!c || !f || f->ctx != c) return FQG_ERR_ARG;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->frame = f->fv;
+  c->lazy.pending = false;  // (a retained frame has its index: fqg_frame_retain)
   c->frame_flags = f->flags;
   c->frame_valid = true;
   c->frame_img_owned = false;
@@ -1117,6 +1181,7 @@ int fqg_frame_make_current(fqg_ctx* c, const fqg_frame* f) {
 int fqg_frame_retain(fqg_ctx* c, fqg_frame** out) {
   if (!c || !out) return FQG_ERR_ARG;
   if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  if (const int irc = index_now(c)) return irc;
   if (c->frame_borrowed) return fail(c, FQG_ERR_STATE, "the current frame is a retained one: it cannot be retained again");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   fqg_frame* f = new fqg_frame();
@@ -1353,6 +1418,7 @@ void fqg_index_destroy(fqg_index* ix) {
 int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, fqg_index_result* out) {
   if (!c || !ix || !st || !out || ix->ctx != c) return FQG_ERR_ARG;
   if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  if (const int irc = index_now(c)) return irc;
   memset(out, 0, sizeof(*out));
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
@@ -1433,6 +1499,7 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
 static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st, uint64_t* match, fqg_index_result* out) {
   if (!c || !ix || !st || !out || ix->ctx != c) return FQG_ERR_ARG;
   if (!c->frame_valid) return fail(c, FQG_ERR_STATE, "no frame: call fqg_validate first");
+  if (const int irc = index_now(c)) return irc;
   memset(out, 0, sizeof(*out));
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;

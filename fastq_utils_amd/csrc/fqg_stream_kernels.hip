@@ -748,6 +748,12 @@ struct LinesArgs {
   AccState* acc;              // null: no statistics
   unsigned long long* hist;
   int ablate;                 // measurement only (FQGPU_LINES_ABL): 1 = no line-index stores
+  // The line index on demand: a call that only validates never reads most of it back (32 B per record written for
+  // nothing: 3.6 GB per 100 M records).  no_index: only the records that hold a line >= keep_from are stored (the last
+  // complete record - its end is what the call consumed - and the lines of an incomplete one); index_only: the stores
+  // and nothing else - the second run, when something does ask for the index (index_now in fqg_abi.hip).
+  uint32_t no_index, index_only;
+  uint64_t keep_from;
 };
 
 constexpr int kLinesHist = 4096;
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
         }
       }
       // four ends per lane, 32 contiguous bytes
-      if (A.ablate & 1) {
+      if ((A.ablate & 1) || (A.no_index && L0 + 4 <= A.keep_from)) {
       } else if (have[q][4] && L0 + 3 < A.line_cap) {
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
         u64x2 lo2, hi2;
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
           if (have[q][k] && L0 + k - 1 < A.line_cap) A.line_end[L0 + k - 1] = e[q][k];
       }
       // checks (complete records only)
-      bool sus = false, complete = have[q][4] && L0 + 3 < A.limit, counted = false;
+      bool sus = false, complete = have[q][4] && L0 + 3 < A.limit && !A.index_only, counted = false;
       uint64_t rl = 0;
       if (complete) {
         // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
@@ -1125,13 +1131,14 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8
       uint64_t e[5];
 #pragma unroll
       for (int k = 0; k < 5; ++k) e[k] = (uint64_t)(win0 + (en[k] >> 16)) * kChunkBytes + (en[k] & 0xFFFu);
-      if (!(A.ablate & 1)) {
+      if (!(A.ablate & 1) && !(A.no_index && L0 + 4 <= A.keep_from)) {
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
         u64x2 lo2, hi2;
         lo2.x = e[1]; lo2.y = e[2]; hi2.x = e[3]; hi2.y = e[4];
         __builtin_nontemporal_store(lo2, reinterpret_cast<u64x2*>(A.line_end + L0));
         __builtin_nontemporal_store(hi2, reinterpret_cast<u64x2*>(A.line_end + L0 + 2));
       }
+      if (A.index_only) continue;
       // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
       bool sus = !(((en[0] >> 12) & 3u) == kClsAt && !((en[0] >> 14) & 1u));
       sus |= !(((en[2] >> 12) & 3u) == kClsPlus && ((en[2] >> 14) & 1u));

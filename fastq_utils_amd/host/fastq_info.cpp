@@ -423,7 +423,7 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
     }
     if (fqg_acc_create(M.D[i].ctx, &M.D[i].acc) != 0) die_lib("fqg_acc_create", -1);
   }
-  MultiPass pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE, nullptr);
+  MultiPass pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_INDEX, nullptr);
   if (pass.stopped) {
     // a NUL byte at a record start ends the file there (src/fastq.c:250): what later pieces added to the accumulators
     // and to the shards does not belong to it - once more, with the file ending where the reference stops reading
@@ -434,7 +434,7 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
     }
     for (auto& d : M.D)
       if (fqg_acc_reset(d.acc) != 0) die_lib("fqg_acc_reset", -1);
-    pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE, nullptr, pass.stop_offset, !pass.probe_printed);
+    pass = multi_pass(path, M.D, is_pe, FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_INDEX, nullptr, pass.stop_offset, !pass.probe_printed);
     if (pass.stopped) {
       FQ_PRINT_ERROR("Error in file %s: the file changed while it was read", path);
       fqhost::leave(kExitSys);
@@ -497,7 +497,7 @@ void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, 
     before[i].resize(used);
     if (fqg_acc_export(M.D[i].acc, before[i].data(), before[i].size(), &used) != 0) die_lib("fqg_acc_export", -1);
   }
-  MultiPass pass = multi_pass(path2, M.D, 1, 0, &F.st);
+  MultiPass pass = multi_pass(path2, M.D, 1, FQG_VALIDATE_INDEX, &F.st);
   if (pass.stopped) {
     release_shards(pass.shards);
     if (strcmp(path2, "-") == 0) {
@@ -508,7 +508,7 @@ void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, 
       if (fqg_acc_reset(M.D[i].acc) != 0) die_lib("fqg_acc_reset", -1);
       if (fqg_acc_merge(M.D[i].acc, before[i].data(), before[i].size()) != 0) die_lib("fqg_acc_merge", -1);
     }
-    pass = multi_pass(path2, M.D, 1, 0, &F.st, pass.stop_offset, !pass.probe_printed);
+    pass = multi_pass(path2, M.D, 1, FQG_VALIDATE_INDEX, &F.st, pass.stop_offset, !pass.probe_printed);
     if (pass.stopped) {
       FQ_PRINT_ERROR("Error in file %s: the file changed while it was read", path2);
       fqhost::leave(kExitSys);
@@ -627,7 +627,7 @@ void run_interleaved(const char* path, Stats& S) {
   Probe pr;
   probe_piece(pr, in.data(), in.size(), 1);
   fqg_validate_result r;
-  LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, 1, &pr.st, in.vflags(), &r));
+  LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, 1, &pr.st, FQG_VALIDATE_INDEX | in.vflags(), &r));
   const uint64_t n = r.n_records;
   fqg_index_result cr{};
   if (n >= 2) {
@@ -723,10 +723,10 @@ void run_paired_sorted(const char* p1, const char* p2, Stats& S) {
   probe_piece(pr1, in1.data(), in1.size(), 1);
   probe_piece(pr2, in2.data(), in2.size(), 1);
   fqg_validate_result r1, r2;
-  LIB(fqg_validate(g_ctx, S.acc1, in1.data(), in1.size(), FQG_MEM_HOST, 1, &pr1.st, in1.vflags(), &r1));
+  LIB(fqg_validate(g_ctx, S.acc1, in1.data(), in1.size(), FQG_MEM_HOST, 1, &pr1.st, FQG_VALIDATE_INDEX | in1.vflags(), &r1));
   fqg_frame *f1 = nullptr, *f2 = nullptr;
   if (r1.n_records) LIB(fqg_frame_retain(g_ctx, &f1));
-  LIB(fqg_validate(g_ctx, S.acc2, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st, in2.vflags(), &r2));
+  LIB(fqg_validate(g_ctx, S.acc2, in2.data(), in2.size(), FQG_MEM_HOST, 1, &pr2.st, FQG_VALIDATE_INDEX | in2.vflags(), &r2));
   if (r2.n_records) LIB(fqg_frame_retain(g_ctx, &f2));
   fqg_index_result cr{};
   if (f1 && f2) LIB(fqg_names_compare(g_ctx, f1, &pr1.st, f2, &pr2.st, &cr));

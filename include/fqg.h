@@ -150,6 +150,11 @@ typedef struct {
                                        would return without its newline is followed by "\0\n" - the NUL the reference's
                                        buffer holds behind it, and a newline that only frames.  No line is held against the
                                        limits then (FQG_E_LINE_TOO_LONG is never reported). */
+#define FQG_VALIDATE_INDEX 128u     /* the frame this call leaves will be used (fqg_frame_retain, fqg_frame_records, the name
+                                       calls): write the whole line index now.  Without it the single-pass framing checks
+                                       the records but stores only the end of the index (32 bytes per record that a call
+                                       which only validates never reads back), and the first call that needs the frame
+                                       writes the rest - same results, the line kernels run a second time. */
 #define FQG_VALIDATE_COUNT_TWICE 4u /* every record counts twice in acc: the index loop runs
                                        fastq_new_entry_stats in both fastq_read_next_entry and
                                        fastq_validate_entry (src/fastq.c:415,432) */

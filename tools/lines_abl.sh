@@ -4,5 +4,5 @@
 for abl in 0 1; do
   FQGPU_LINES_ABL=$abl python bench.py --steps 3 --no-cpu-baseline --no-e2e --no-index-extra --no-dedup-extra --no-barcodes-extra --no-filters-extra --no-umi-extra --no-shapes-extra --no-tags-extra --no-filterpair-extra 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['roofline']['kernels_ms_per_step']; print('abl $abl', 'lines', round(k['k_stream_lines'],3), 'pass1', round(k['k_stream_pass1'],3), 'all', round(d['roofline']['all_kernels_ms_per_step'],3))"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels_ms_per_step']; print('abl $abl', 'lines', round(k['k_stream_lines'],3), 'pass1', round(k['k_stream_pass1'],3), 'all', round(d['roofline']['all_kernels_ms_per_step'],3))"
 done
