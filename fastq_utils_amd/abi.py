@@ -808,10 +808,7 @@ class Context:
         if host:
             buf = (C.c_char * max(1, len(stream))).from_buffer_copy(stream)
             nbytes = len(stream)
-        if offsets_device is not None:  # (device pointer, number of records): the index lies in HBM beside the records
-            assert not host
-            offs, n_rec = C.cast(C.c_void_p(int(offsets_device[0])), C.POINTER(C.c_uint64)), int(offsets_device[1])
-        elif offsets is None:
+        if offsets is None:
             n, used = C.c_uint64(), C.c_uint64()
             self._check(L.fqg_bam_index_records(buf, nbytes, None, 0, C.byref(n), C.byref(used)))
             offs = (C.c_uint64 * max(1, n.value))()
@@ -837,8 +834,8 @@ class Context:
         p.names, p.names_bytes = keep[4], len(blob)
         r = BamTagsResult()
         self._check(L.fqg_bam_add_tags(self.h, buf if host else C.c_void_p(int(stream)), nbytes,
-                                       MEM_HOST if host else (MEM_DEVICE_INDEXED if offsets_device is not None else MEM_DEVICE), offs,
-                                    n_rec, C.byref(p), C.byref(r)))
+                                       MEM_HOST if host else MEM_DEVICE, offs,
+                                       n_rec, C.byref(p), C.byref(r)))
         out = {k: getattr(r, k) for k, _ in BamTagsResult._fields_ if k != "reserved"}
         if r.code == 0 and want_output:
             dst = C.create_string_buffer(max(1, r.out_bytes))

@@ -798,11 +798,23 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint
     nx_win = cw;
   };
   if (!TODO && wave0 < n_steps) window_request(wave0);
-  for (uint64_t step = wave0; step < n_steps; step += n_waves) {
+  // TODO: the marks of 64 consecutive steps at a time, a lane each (a wavefront that asked for them one by one waited
+  // for 150 loads in a row to find its two or three steps: 66 of the 886 us of the line kernels)
+  uint64_t blk = wave0 * (uint64_t)kWave, blk_cur = 0;
+  unsigned long long marks = 0;
+  for (uint64_t step = wave0;; step += n_waves) {
     if constexpr (TODO) {
-      if (!todo[step]) continue;
+      while (!marks && blk < n_steps) {
+        const uint64_t s = blk + (uint64_t)lane;
+        marks = __ballot(s < n_steps && todo[s] != 0);
+        blk_cur = blk;
+        blk += n_waves * (uint64_t)kWave;
+      }
+      if (!marks) break;
+      step = blk_cur + (uint64_t)__builtin_ctzll(marks);
+      marks &= marks - 1;
       window_request(step);
-    }
+    } else if (step >= n_steps) break;
     // e[0] = end of the line before mine, e[1..4] = ends of my four lines; ent[] = their staged entries
     uint64_t e[kLinesPer][5];
     uint32_t ent[kLinesPer][5];
@@ -1044,7 +1056,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8
   const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
-  unsigned long long n_ok = 0, min_rl = ~0ull, max_rl = 0;
+  uint32_t n_ok32 = 0, min_rl32 = ~0u, max_rl32 = 0;  // (a wavefront's share of the records and a step's lengths fit)
   // the window of the NEXT step is requested a step ahead and looked at when that step begins (see k_stream_lines)
   unsigned long long nx_se = 0;
   uint32_t nx_loc = 0, nx_cnt = 0, nx_win = 0;
@@ -1128,13 +1140,16 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8
       const uint32_t at = 4u * ((uint32_t)q * kWave + (uint32_t)lane);   // entry of rank 4r - 1
       const uint4 e03 = *reinterpret_cast<const uint4*>(&s_ent[wv][at]);  // (16-byte aligned: at is a multiple of 4)
       const uint32_t en[5] = {e03.x, e03.y, e03.z, e03.w, s_ent[wv][at + 4]};
-      uint64_t e[5];
+      // positions relative to the window's first chunk, 32 bits (a step's ranks live in at most 16 chunks): the lengths
+      // and the checks need no more; the 64-bit ends only where the index is stored
+      uint32_t rel[5];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) e[k] = (uint64_t)(win0 + (en[k] >> 16)) * kChunkBytes + (en[k] & 0xFFFu);
+      for (int k = 0; k < 5; ++k) rel[k] = ((en[k] >> 16) << 12) | (en[k] & 0xFFFu);
       if (!(A.ablate & 1) && !(A.no_index && L0 + 4 <= A.keep_from)) {
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const uint64_t wbase = (uint64_t)win0 * kChunkBytes;
         u64x2 lo2, hi2;
-        lo2.x = e[1]; lo2.y = e[2]; hi2.x = e[3]; hi2.y = e[4];
+        lo2.x = wbase + rel[1]; lo2.y = wbase + rel[2]; hi2.x = wbase + rel[3]; hi2.y = wbase + rel[4];
         __builtin_nontemporal_store(lo2, reinterpret_cast<u64x2*>(A.line_end + L0));
         __builtin_nontemporal_store(hi2, reinterpret_cast<u64x2*>(A.line_end + L0 + 2));
       }
@@ -1142,30 +1157,30 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8
       // header line: '@' and not empty; third line: exactly "+\n"  (what the entry BEFORE a line says about it)
       bool sus = !(((en[0] >> 12) & 3u) == kClsAt && !((en[0] >> 14) & 1u));
       sus |= !(((en[2] >> 12) & 3u) == kClsPlus && ((en[2] >> 14) & 1u));
-      const uint64_t l0 = e[1] - e[0] - 1, l1 = e[2] - e[1] - 1, l2 = e[3] - e[2] - 1, l3 = e[4] - e[3] - 1;
+      const uint32_t l0 = rel[1] - rel[0] - 1, l1 = rel[2] - rel[1] - 1, l2 = rel[3] - rel[2] - 1, l3 = rel[4] - rel[3] - 1;
       sus |= l1 < 1 || l1 != l3 || A.space != FQG_SPACE_SEQ;
       sus |= l0 + 1 > FQG_MAX_LABEL_LENGTH - 1 || l2 + 1 > FQG_MAX_LABEL_LENGTH - 1 ||
              l1 + 1 > FQG_MAX_READ_LENGTH - 1 || l3 + 1 > FQG_MAX_READ_LENGTH - 1;
       const bool counted = A.acc && l1 + 1 <= FQG_MAX_READ_LENGTH - 1;
-      const uint64_t rl = l1 + 1;  // strlen(seq): the sequence line ends in '\n'
+      const uint32_t rl = l1 + 1;  // strlen(seq): the sequence line ends in '\n'
       if (counted) {
-        ++n_ok;
-        min_rl = rl < min_rl ? rl : min_rl;
-        max_rl = rl > max_rl ? rl : max_rl;
+        ++n_ok32;
+        min_rl32 = rl < min_rl32 ? rl : min_rl32;
+        max_rl32 = rl > max_rl32 ? rl : max_rl32;
       }
       {  // the length histogram: the lanes that share the first counted lane's length add once, together (see k_stream_lines)
         const unsigned long long cm = __ballot(counted);
         if (cm) {
           const int first = __builtin_ctzll(cm);
-          const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rl, first);
-          const bool with_first = counted && rl == (uint64_t)rl0;
+          const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((int)rl, first);
+          const bool with_first = counted && rl == rl0;
           const unsigned long long same = __ballot(with_first);
           if (lane == first) {
-            if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], (uint32_t)__builtin_popcountll(same));
+            if (rl < (uint32_t)kLinesHist) atomicAdd(&s_hist[rl], (uint32_t)__builtin_popcountll(same));
             else atomicAdd(&A.hist[rl], (unsigned long long)A.weight * (unsigned long long)__builtin_popcountll(same));
           }
           if (counted && !with_first) {
-            if (rl < (uint64_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
+            if (rl < (uint32_t)kLinesHist) atomicAdd(&s_hist[rl], 1u);
             else atomicAdd(&A.hist[rl], (unsigned long long)A.weight);
           }
         }
@@ -1180,6 +1195,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8
     __builtin_amdgcn_wave_barrier();  // (s_ent is rewritten by the next step)
   }
   if (!A.acc) return;
+  unsigned long long n_ok = n_ok32, min_rl = min_rl32 == ~0u ? ~0ull : (unsigned long long)min_rl32, max_rl = max_rl32;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     n_ok += __shfl_down(n_ok, d, 64);
