@@ -756,7 +756,7 @@ struct LinesArgs {
   uint64_t keep_from;
 };
 
-constexpr int kLinesHist = 4096;
+constexpr int kLinesHist = 3072;
 constexpr int kLinesPer = 2;  // records per lane and step: their staged-entry loads are in flight together (4: 1.29 -> 1.41 ms; 6 wavefronts per SIMD instead of 5: no change)
 template <bool TODO>
 __global__ __launch_bounds__(kBlock) void k_stream_lines(LinesArgs A, const uint8_t* __restrict__ todo) {
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
          ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
 }
 
-__global__ __launch_bounds__(kBlock) void k_stream_lines_fast(LinesArgs A, uint8_t* __restrict__ todo) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stream_lines_fast(LinesArgs A, uint8_t* __restrict__ todo) {
   __shared__ uint32_t s_hist[kLinesHist];
   __shared__ unsigned long long s_red[3][kBlock / kWave];
   __shared__ __attribute__((aligned(16))) uint32_t s_ent[kBlock / kWave][(kFastRanks + 7) & ~3];
