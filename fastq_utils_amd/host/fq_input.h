@@ -120,6 +120,17 @@ class SlotPool {
   std::vector<std::pair<char*, size_t>> free_;
   std::map<char*, size_t> size_;
 };
+// The piece size for a regular file of `file_bytes` bytes on disk: a slot for a small file need not have the size of a
+// piece - pinning memory takes as long as filling it (128 MiB: 22 ms of every start, 512 MiB: 90 ms, per input file).
+// A compressed file is given what 24 times its size inflates to, at least 1 MiB; one that inflates to more comes in
+// several pieces, like any large file.  FQGPU_CHUNK_MB set: that size, exactly (the tests cut files where they want).
+inline size_t piece_for_file(size_t piece, uint64_t file_bytes, bool compressed) {
+  if (getenv("FQGPU_CHUNK_MB")) return piece;
+  const uint64_t may = compressed ? file_bytes * 24 : file_bytes;
+  const uint64_t mib = 1u << 20;
+  const uint64_t want = std::max<uint64_t>(mib, (may + mib) & ~(mib - 1));
+  return (size_t)std::min<uint64_t>(piece, want);
+}
 inline char* slot_alloc(fqg_ctx* ctx, size_t bytes) { return SlotPool::get().take(ctx, bytes); }
 inline void slot_release(fqg_ctx* ctx, char* p) { SlotPool::get().give(ctx, p); }
 
@@ -234,7 +245,8 @@ class Input {
         if (!(got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
           plain_fd_ = fd;
           plain_size_ = (uint64_t)sb.st_size;
-        } else if (got == 18 && bgzf_block_size(magic, 18) > 0 && !getenv("FQGPU_NO_PARALLEL_INFLATE")) {
+        } else if (cap_ = piece_for_file(cap_, (uint64_t)sb.st_size, true);
+                   got == 18 && bgzf_block_size(magic, 18) > 0 && !getenv("FQGPU_NO_PARALLEL_INFLATE")) {
           // bgzip'd FASTQ: a sequence of small gzip members that say how long they are (SAM/BAM specification 4.1) -
           // inflated on all cores (read_bgzf below) instead of by one zlib thread
           bgzf_fd_ = fd;

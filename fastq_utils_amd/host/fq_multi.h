@@ -40,10 +40,12 @@ class AlignedPieces {
         unsigned char magic[2] = {0, 0};
         const ssize_t got = pread(fd, magic, 2, 0);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+          cap_ = piece_for_file(cap_, (uint64_t)sb.st_size, true);  // (small files: small slots - pinning is start-up time)
           if ((pgz_ = open_pgzip(fd, (uint64_t)sb.st_size, path))) pgz_fd_ = fd;  // inflated on many cores (fq_pgzip.h)
         } else {
           plain_fd_ = fd;
           plain_size_ = std::min<uint64_t>((uint64_t)sb.st_size, limit_);
+          cap_ = piece_for_file(cap_, plain_size_, false);
         }
       }
       if (plain_fd_ < 0 && pgz_fd_ < 0) {
