@@ -12,7 +12,7 @@ import pytest
 
 from oracle import loader as orc
 from tests import fuzz
-from tests.util import GOLD, REPO, SideBySide, load_fastq_info_golden, strip_progress
+from tests.util import GOLD, REPO, SideBySide, load_fastq_info_golden, strip_progress, thinned
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(REPO, "bin", "fastq_info")
@@ -194,6 +194,7 @@ MULTI = {"FQGPU_DEVICES": "0,0,0"}
 def test_several_devices_golden_dash_r_invocations():
     cases = [c for c in GOLDEN if "-r" in c["args"] and len([a for a in c["args"] if not a.startswith("-")]) == 1]
     assert len(cases) > 20
+    cases = thinned(cases)
 
     def one(case):
         rc, out, err = run_cli(case["args"], GOLD, MULTI)
@@ -263,7 +264,9 @@ def _long_line_run(key):
 
 
 # (the programs of all cases start side by side the first time one is asked for: tests/util.py)
-LONG_RUNS = SideBySide(_long_line_run, [(w, h, a) for w in sorted(_overlong()) for h in LONG_HOW for a in range(len(LONG_ARGS))])
+LONG_RUNS = SideBySide(_long_line_run, [(w, h, a) for w in sorted(_overlong()) for h in LONG_HOW for a in range(len(LONG_ARGS))],
+                       select=lambda ks: [k for k in ks if k[1] == list(LONG_HOW)[0]] +
+                       [k for k in ks if k[1] != list(LONG_HOW)[0] and (k[0], k[1]) in set(thinned({(w, h) for w, h, _ in ks if h != list(LONG_HOW)[0]}, key="-".join))])
 
 
 @pytest.mark.parametrize("how", list(LONG_HOW))
@@ -361,6 +364,7 @@ def test_several_devices_golden_index_and_pairing_invocations():
     tested across them by the fingerprint exchange - same exit status, stdout and stderr as the reference binary"""
     cases = [c for c in GOLDEN if "-r" not in c["args"] and "pe" not in c["args"] and goes_to_several_devices(c)]
     assert len(cases) > 75
+    cases = thinned(cases)
 
     def one(case):
         rc, out, err = run_cli(case["args"], GOLD, MULTI)

@@ -19,7 +19,7 @@ import fastq_utils_amd as fq
 from oracle import loader as orc
 from tests import fuzz
 from tests.test_gpu_cli import GOLDEN, POOL, compare_all, compare_with_oracle, goes_to_several_devices, put, run_cli
-from tests.util import GOLD, REPO, strip_progress
+from tests.util import GOLD, REPO, strip_progress, thinned
 
 pytestmark = pytest.mark.gpu
 STREAM = {"FQGPU_STREAM_MIN": "256"}
@@ -45,6 +45,7 @@ def test_golden_index_and_pairing_invocations_with_the_capture():
     tests/test_gpu_cli.py does not run over several devices (goes_to_several_devices)"""
     cases = [c for c in GOLDEN if "-r" not in c["args"] and ("pe" in c["args"] or not goes_to_several_devices(c))]
     assert len(cases) > 100
+    cases = thinned(cases)
 
     def one(case):
         rc, out, err = run_cli(case["args"], GOLD, STREAM)
