@@ -136,3 +136,25 @@ def test_a_second_call_forgets_the_first_calls_index(ctx):
     got = ctx.frame_records(6990, 10)
     ctx.validate(b, None, st, flags=A.VALIDATE_NO_STATS | A.VALIDATE_TWO_PASS)
     assert got == ctx.frame_records(6990, 10)
+
+
+def test_fingerprints_of_the_current_frame_after_an_on_demand_call(ctx):
+    """fqg_names_fingerprints on the CURRENT frame (no retained one): the export reads the names through the line index"""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(18)
+    img = clean(rng, n=9000, lo=150, hi=150)
+    st = A.probe_first_record(img, False)
+    got = []
+    for flags in (0, A.VALIDATE_INDEX):
+        r = ctx.validate(img, None, st, flags=flags | A.VALIDATE_NO_STATS)
+        buf = torch.zeros(r["n_records"] * 16, dtype=torch.uint8, device="cuda")
+        counts = ctx.names_fingerprints(None, st, 0, 3, buf.data_ptr())
+        ctx.synchronize()
+        pairs = buf.cpu().numpy().view(np.uint64).reshape(-1, 2)
+        start, buckets = 0, []
+        for c in counts:  # (the order inside a bucket is not fixed: sorted)
+            b = pairs[start:start + c]
+            buckets.append(b[np.lexsort((b[:, 1], b[:, 0]))].tobytes())
+            start += c
+        got.append((counts, buckets))
+    assert got[0] == got[1] and sum(got[0][0]) == 9000
