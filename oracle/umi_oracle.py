@@ -501,6 +501,11 @@ def run_bam_umi_count(argv, reader, writable=lambda path: True):
                 if prev_cell_id != cell_id:
                     if cell_id <= prev_cell_id:
                         err.append("Error: The BAM file does not seem to be sorted by CR\n")
+                        # exit(1) flushes what cell2MM has written: the complete cells, behind the header of MM_header
+                        # (:708-722) that only the end of main comes back to (:1093-1113)
+                        files[ucounts] = HDR + "%-10d %-10d %-15d\n" % (0, 0, 0) + "".join(out_u)
+                        if rcounts is not None:
+                            files[rcounts] = HDR + "%-10d %-10d %-15d\n" % (0, 0, 0) + "".join(out_r)
                         raise Exit(1)
                     if prev_cell_id != 0:
                         ncells += 1

@@ -53,6 +53,20 @@ def barcode(rng, n) -> bytes:
     return bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)])
 
 
+def cells_in_runs(rng, order, per_cell=(3, 40), genes=30):
+    """a BAM whose alignments come in runs of one cell each, in the given order of cell numbers"""
+    cells = {c: barcode(np.random.default_rng(1000 + c), 12) for c in set(order)}
+    out = [header()]
+    k = 0
+    for c in order:
+        for _ in range(int(rng.integers(*per_cell))):
+            aux = (aux_z(b"GX", b"GENE%05d" % int(rng.integers(0, genes))) + aux_z(b"RX", barcode(rng, 8)) +
+                   aux_z(b"CR", cells[c]) + aux_int(b"NH", 1))
+            out.append(record(b"r%d" % k, aux))
+            k += 1
+    return b"".join(out)
+
+
 def tagged_bam(rng, n_cells=12, genes=40, reads_per_cell=(5, 120), umi_len=8, cell_len=12, nh=False, multi_gx=False,
                noise=False, sort_cells=True, gene_prefix=b"GENE", fresh_umis=False):
     """A CR-grouped BAM with GX / RX / CR (/ NH) tags.  Returns (bam bytes, inflated record stream).

@@ -226,20 +226,6 @@ def test_reference_binary_differential(fresh):
                 assert outs["ref" + base + ext] == outs["gpu" + base + ext], base + ext
 
 
-def _cells_in_runs(rng, order, per_cell=(3, 40), genes=30):
-    """a BAM whose alignments come in runs of one cell each, in the given order of cell numbers"""
-    cells = {c: bamgen.barcode(np.random.default_rng(1000 + c), 12) for c in set(order)}
-    out = [bamgen.header()]
-    k = 0
-    for c in order:
-        for _ in range(int(rng.integers(*per_cell))):
-            aux = (bamgen.aux_z(b"GX", b"GENE%05d" % int(rng.integers(0, genes))) + bamgen.aux_z(b"RX", bamgen.barcode(rng, 8)) +
-                   bamgen.aux_z(b"CR", cells[c]) + bamgen.aux_int(b"NH", 1))
-            out.append(bamgen.record(b"r%d" % k, aux))
-            k += 1
-    return b"".join(out)
-
-
 @pytest.mark.parametrize("order", [[1, 2, 3, 1], [1, 2, 1, 3], [1, 1, 2, 3, 4, 2, 5], [1, 2, 3, 4, 5, 6, 7, 8, 3], [1, 2, 2, 1]],
                          ids=lambda o: "".join(map(str, o)))
 @pytest.mark.parametrize("extra", [[], ["--min_reads", "2"]], ids=["plain", "min_reads"])
@@ -251,7 +237,7 @@ def test_a_bam_that_is_not_grouped_by_cell_leaves_the_files_the_reference_leaves
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref/bam_umi_count not built")
     rng = np.random.default_rng(sum(order) * 7 + len(order))
-    bam = bamgen.bgzf(_cells_in_runs(rng, order), level=1)
+    bam = bamgen.bgzf(bamgen.cells_in_runs(rng, order), level=1)
     with tempfile.TemporaryDirectory() as tmp:
         with open(os.path.join(tmp, "in.bam"), "wb") as f:
             f.write(bam)

@@ -93,3 +93,32 @@ def test_reference_rl_tree_defect():
         got = uo.run_bam_umi_count(real_args(c["args"]), reader)
         assert got["exit"] == c["exit"] == 0
         assert got["files"] == golden_files(c)
+
+
+UNSORTED = [[1, 2, 3, 1], [1, 2, 1, 3], [1, 1, 2, 3, 4, 2, 5], [1, 2, 3, 4, 5, 6, 7, 8, 3], [1, 2, 2, 1]]
+
+
+@pytest.mark.parametrize("order", UNSORTED, ids=lambda o: "".join(map(str, o)))
+@pytest.mark.parametrize("extra", [[], ["--min_reads", "2"], ["--min_umis", "2"]], ids=["plain", "min_reads", "min_umis"])
+def test_a_bam_that_is_not_grouped_by_cell_against_the_reference_binary(order, extra, tmp_path):
+    """src/bam_umi_count.c:1000-1015: the reference stops at the alignment that is out of order with the complete cells
+    in its files (all but the one in front of that alignment), behind the header it never comes back to"""
+    import subprocess
+
+    import numpy as np
+
+    from tests import bamgen
+    from tests.util import REPO
+    ref = os.path.join(REPO, "oracle", "_ref", "bam_umi_count")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/bam_umi_count not built")
+    bam = bamgen.bgzf(bamgen.cells_in_runs(np.random.default_rng(sum(order) * 7 + len(order)), order), level=1)
+    (tmp_path / "in.bam").write_bytes(bam)
+    args = ["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"] + extra
+    p = subprocess.run(["bam_umi_count"] + args, executable=ref, cwd=tmp_path, capture_output=True, timeout=300)
+    got = uo.run_bam_umi_count(args, lambda path: bam if path == "in.bam" else None)
+    assert p.returncode == 1 and got["exit"] == 1
+    assert got["stderr"] == p.stderr.decode("latin-1")
+    for name in ("u", "r"):
+        assert got["files"].get(name) == (tmp_path / name).read_text(), name
+    assert sorted(got["files"]) == ["r", "u"] and sorted(x.name for x in tmp_path.iterdir()) == ["in.bam", "r", "u"]
