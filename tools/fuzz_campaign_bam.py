@@ -99,8 +99,10 @@ def one_case(seed):
             m = found and max(found) > 0
             if m:
                 return [("known: undefined tree reads (DESIGN 7.1)", seed, max(found))]
-    if got is not None and want["rc"] != 0 and got["rc"] == want["rc"] and got["stderr"] == want["stderr"]:
-        return []  # (a run that fails: the same status and the same words; what it had written by then is not compared)
+    if got is not None and want["rc"] != 0 and got["rc"] == want["rc"] and got["stderr"] == want["stderr"] and \
+            "does not seem to be sorted by CR" not in want["stderr"]:
+        return []  # (a run that fails: the same status and the same words; what it had written by then is not compared -
+        #            but for a BAM that is not grouped by cell, where the reference's exit(1) leaves the complete cells)
     if got != want:
         keys = [k for k in want if got is None or got.get(k) != want[k]]
         return [(seed, args, kw, want["rc"], None if got is None else got["rc"], keys, want["stderr"][-200:],
