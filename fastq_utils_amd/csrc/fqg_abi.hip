@@ -277,11 +277,12 @@ int fqg_abi_version(void) { return FQG_ABI_VERSION; }
 // context does not pay for it: most never copy that much.)  FQGPU_NO_FIRST_COPY=1 leaves it out, for that tool.
 static void first_large_copy(int device) {
   static std::mutex mu;
-  static std::vector<int> opened, copied;
+  static std::vector<int> opened, copied;  // devices, each once
+  static unsigned n_opens = 0;
   static const bool off = getenv("FQGPU_NO_FIRST_COPY") != nullptr;
   std::lock_guard<std::mutex> lk(mu);
-  opened.push_back(device);
-  if (off || opened.size() < 2) return;
+  if (std::find(opened.begin(), opened.end(), device) == opened.end()) opened.push_back(device);
+  if (off || ++n_opens < 2) return;
   constexpr size_t kBytes = 256u << 10;
   for (int dev : opened) {
     if (std::find(copied.begin(), copied.end(), dev) != copied.end()) continue;
