@@ -1371,6 +1371,16 @@ def committed_traffic(kernel, n_reads, read_len, record_bytes):
     return None, None
 
 
+def flush_c_stdio():
+    """A library's printf into a pipe sits in libc's buffer until the process leaves through exit(): flushed now, it
+    cannot land behind the bench line (which must be the last line of stdout)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def under_a_profiler():
     """rocprofv3 preloads its tool library and writes its output when the process leaves through exit()"""
     if os.environ.get("FQGPU_BENCH_PLAIN_EXIT"):
@@ -1754,6 +1764,7 @@ def main():
                     f.write("\n")
             except OSError as e:
                 print(f"bench.py: could not write {extras_path}: {e}", file=sys.stderr)
+        flush_c_stdio()  # (what a library printed through C stdio - RCCL's start-up banner - goes out BEFORE the line)
         print(headline_line(out, extras), flush=True)  # the bench line: LAST on stdout
     if world > 1:
         # every rank has what it needs; a rank that failed in the extra must not keep the others waiting in a
