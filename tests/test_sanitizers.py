@@ -139,6 +139,17 @@ def test_host_input_stager_runs_clean(tmpdir, san):
                 assert (b"inflated by chunks" in p.stderr) == ("FQGPU_NO_PARALLEL_INFLATE" not in extra), p.stderr.decode()[-800:]
                 if "FQGPU_PGZIP_CHUNK" in extra:
                     assert b"one zlib stream" not in p.stderr and b" 2 members" in p.stderr, p.stderr.decode()[-800:]
+    # a file that inflates to far more than 24 times its size: its slots are sized by the file (piece_for_file), so it
+    # comes in several pieces where a piece of 50 MB was asked for - and whole when asked for whole
+    rep_data = b"ACGTACGTAC\n" * 400000
+    rep = tmpdir / "rep.txt.gz"
+    rep.write_bytes(gzip.compress(rep_data, 6))
+    assert rep.stat().st_size * 24 < len(rep_data) // 2
+    want_rep = ("%d %d" % (len(rep_data), fnv(rep_data))).encode()
+    for mode in ("0", "1", "2"):
+        for extra in ({}, {"FQGPU_NO_PARALLEL_INFLATE": "1"}):
+            p = subprocess.run([exe, str(rep), "50000000", mode], env=dict(bgz_env, **extra), capture_output=True, timeout=300)
+            assert p.returncode == 0 and p.stdout.strip() == want_rep, (mode, extra, p.stdout, p.stderr.decode()[-1500:])
     for path, wanted in ((plain, want), (gz, want), (empty, ("0 %d" % fnv(b"")).encode())):
         for piece in ("4096", "100000", "50000000"):
             for mode in ("0", "1", "2"):
