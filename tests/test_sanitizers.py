@@ -174,12 +174,19 @@ def test_record_aligned_piece_cutter_runs_clean(tmpdir, san):
     data = b"".join(recs)
     files = {"full.fq": data, "full.fq.gz": gzip.compress(data, 1), "cut.fq": data[:-57], "nonl.fq": data[:-1],
              "empty.fq": b"", "one.fq": recs[0], "blank.fq": b"\n" * 1001}
+    # (a file that inflates to far more than 24 times its size: the slots are sized by the file - piece_for_file -, so
+    # it comes in several pieces whatever piece was asked for)
+    rep = b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n" * 120000
+    files["rep.fq.gz"] = gzip.compress(rep, 6)
+    assert len(files["rep.fq.gz"]) * 24 < len(rep) // 2
+    inflated = {"full.fq.gz": len(data), "rep.fq.gz": len(rep)}
     for name, content in files.items():
         (tmpdir / name).write_bytes(content)
-        size = len(data if name.endswith(".gz") else content)
+        size = inflated.get(name, len(content))
         # (pieces of 512 bytes only for the small files: a thousand hand-overs per run under the sanitizers' run times are
         # what made these two tests half of the CPU suite's time)
-        for piece in (("512", "4096", "100000", "50000000") if len(content) < 100000 else ("4096", "100000", "50000000")):
+        for piece in (("100000", "50000000") if name == "rep.fq.gz" else
+                      ("512", "4096", "100000", "50000000") if len(content) < 100000 else ("4096", "100000", "50000000")):
             for consumers in ("1", "3"):
                 # (a .gz once more through the many-core gzip reader, fq_pgzip.h, in chunks of 20 kB: files this small are
                 # one zlib thread's otherwise)
