@@ -14,6 +14,7 @@ VALIDATE_DEFAULT, VALIDATE_FORCE_EXACT, VALIDATE_NO_STATS, VALIDATE_COUNT_TWICE,
 VALIDATE_TWO_PASS = 16
 VALIDATE_NAMES = 32
 VALIDATE_INDEX = 128  # the frame will be used: the whole line index in this call, not on demand
+VALIDATE_NAME_DIGESTS = 256  # names for a uniqueness-only index: 16-byte digests instead of 64-byte records
 NAME_DEFAULT, NAME_CASAVA18, NAME_INTEGER, NAME_UNDEF = 0, 1, 2, -1
 SPACE_SEQ, SPACE_COLOUR, SPACE_UNDEF = 0, 1, -1
 
@@ -37,6 +38,8 @@ EXPORTS = [
     "fqg_records_gather_output", "fqg_names_compare",
     "fqg_barcodes_transform", "fqg_barcodes_output", "fqg_barcodes_output_begin", "fqg_barcodes_output_wait", "fqg_records_filter", "fqg_records_filter_output",
     "fqg_whitelist_create", "fqg_whitelist_destroy", "fqg_barcodes_whitelist",
+    "fqg_census_create", "fqg_census_destroy", "fqg_barcodes_census", "fqg_census_finish", "fqg_census_cells",
+    "fqg_census_pairs", "fqg_census_device_pairs",
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
     "fqg_umi_count", "fqg_umi_features", "fqg_umi_record_features", "fqg_umi_replayed_features", "fqg_umi_umis",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
@@ -239,6 +242,16 @@ def load():
     L.fqg_barcodes_transform.argtypes = [vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64),
                                          C.POINTER(BarcodeParams), u64, u64, C.POINTER(BarcodeResult)]
     L.fqg_barcodes_output.argtypes = [vp, C.c_int, vp, u64]
+    L.fqg_census_create.argtypes = [vp, C.POINTER(vp)]
+    L.fqg_census_destroy.argtypes = [vp]
+    L.fqg_census_destroy.restype = None
+    L.fqg_barcodes_census.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(FileState), C.POINTER(u64), C.POINTER(BarcodeParams), u64,
+                                      C.POINTER(u64)]
+    L.fqg_census_finish.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.fqg_census_cells.argtypes = [vp, vp, vp, u64]
+    L.fqg_census_pairs.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64), u64]
+    L.fqg_census_device_pairs.argtypes = [vp, C.c_int]
+    L.fqg_census_device_pairs.restype = vp
     L.fqg_barcodes_output_begin.argtypes = [vp, C.c_int, vp, u64]
     L.fqg_barcodes_output_wait.argtypes = [vp]
     L.fqg_records_filter.argtypes = [vp, vp, u64, u64, C.POINTER(FilterParams), C.POINTER(FilterResult)]
@@ -366,6 +379,44 @@ class Whitelist:
         if self.h:
             load().fqg_whitelist_destroy(self.h)
             self.h = None
+
+
+class Census:
+    """FASTQ -> (cell, UMI) without the BAM round trip (fqg_barcodes_census, include/fqg.h)"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._check(load().fqg_census_create(ctx.h, C.byref(self.h)))
+
+    def finish(self):
+        """sorts the pairs by (cell, UMI) and counts; (pairs, cells)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.ctx._check(load().fqg_census_finish(self.ctx.h, self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def cells(self, n_cells):
+        """numpy array (n_cells, 3): packed cell, reads, distinct UMIs - ascending packed cell"""
+        import numpy as np
+        out = np.zeros((max(1, n_cells), 3), dtype=np.uint64)
+        self.ctx._check(load().fqg_census_cells(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p), n_cells))
+        return out[:n_cells]
+
+    def pairs(self, n_pairs):
+        import numpy as np
+        ce = np.zeros(max(1, n_pairs), dtype=np.uint64)
+        um = np.zeros(max(1, n_pairs), dtype=np.uint64)
+        self.ctx._check(load().fqg_census_pairs(self.ctx.h, self.h, ce.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                um.ctypes.data_as(C.POINTER(C.c_uint64)), n_pairs))
+        return ce[:n_pairs], um[:n_pairs]
+
+    def device_pairs(self, which):
+        return load().fqg_census_device_pairs(self.h, which)
+
+    def close(self):
+        if self.h:
+            load().fqg_census_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class Frame:
@@ -567,6 +618,27 @@ class Context:
         """fastq_pre_barcodes' main loop on retained frames.  frames / states: {READ1..INDEX3: Frame / FileState};
         umi / cell / sample: (file reference, offset, size) or None.  Output stays on the device
         (barcodes_output copies it)."""
+        p, fr, stt, first = self._barcode_args(frames, states, umi, cell, sample, phred, min_qual, sam, tenx)
+        r = BarcodeResult()
+        self._check(load().fqg_barcodes_transform(self.h, fr, stt, first, C.byref(p), n_iterations, first_read_number,
+                                                  C.byref(r)))
+        out = {k: getattr(r, k) for k, _ in BarcodeResult._fields_ if k != "out_bytes"}
+        out["out_bytes"] = list(r.out_bytes)
+        return out
+
+    def barcodes_census(self, census, frames, states, n_done, umi=None, cell=None, sample=None, phred=33, min_qual=0,
+                        sam=True, tenx=False):
+        """behind the barcodes_transform of the same batch, with its arguments and its n_done: the (cell, UMI) pairs of the
+        reads it kept go to the census (device memory).  Returns how many were added."""
+        p, fr, stt, first = self._barcode_args(frames, states, umi, cell, sample, phred, min_qual, sam, tenx)
+        added = C.c_uint64(0)
+        self._check(load().fqg_barcodes_census(self.h, census.h, fr, stt, first, C.byref(p), n_done, C.byref(added)))
+        return int(added.value)
+
+    def census(self):
+        return Census(self)
+
+    def _barcode_args(self, frames, states, umi, cell, sample, phred, min_qual, sam, tenx):
         p = BarcodeParams()
         fr = (C.c_void_p * 6)()
         stt = (FileState * 6)()
@@ -587,12 +659,7 @@ class Context:
         if not sam:
             p.emit[1] = 1
             p.emit[2] = 1 if READ2 in frames else 0
-        r = BarcodeResult()
-        self._check(load().fqg_barcodes_transform(self.h, fr, stt, first, C.byref(p), n_iterations, first_read_number,
-                                                  C.byref(r)))
-        out = {k: getattr(r, k) for k, _ in BarcodeResult._fields_ if k != "out_bytes"}
-        out["out_bytes"] = list(r.out_bytes)
-        return out
+        return p, fr, stt, first
 
     def records_filter(self, frame, n_records, mode, max_n_percent=0, min_poly_at_len=10, min_len=10, first_record=0):
         """fastq_filter_n (mode FILTER_N) / fastq_trim_poly_at (FILTER_POLY_AT) on a retained frame; the kept

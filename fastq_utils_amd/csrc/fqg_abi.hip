@@ -6,6 +6,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <memory>
 #include <mutex>
 #include <cstdio>
@@ -18,7 +19,9 @@
 #include "fqg_kernels.hip"
 #include "fqg_stream_kernels.hip"
 #include "fqg_index_kernels.hip"
+#include "fqg_names_build_kernels.hip"
 #include "fqg_barcode_kernels.hip"
+#include "fqg_census_kernels.hip"
 #include "fqg_filter_kernels.hip"
 #include "fqg_umi_kernels.hip"
 #include "fqg_umi_rl_kernels.hip"
@@ -110,6 +113,8 @@ struct fqg_ctx {
     unsigned grid = 0, grid_f = 0;
     LinesArgs args;
   } lazy;
+  uint64_t bc_status_valid = 0;  // iterations of the last fqg_barcodes_transform whose status bytes stand (fqg_barcodes_census)
+  DevBuf build_keys[2], build_cursor, build_spill;  // the name table built in LDS (fqg_names_build_kernels.hip)
   DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
   DevBuf name_hcount; // ... and the headers every chunk saw
   DevBuf name_redo, name_redo_chunks;  // what the capture-fed name kernel leaves to the line-index one
@@ -354,6 +359,10 @@ void fqg_close(fqg_ctx* c) {
   release(c->queue);
   release(c->redo);
   release(c->lines_slow);
+  release(c->build_keys[0]);
+  release(c->build_keys[1]);
+  release(c->build_cursor);
+  release(c->build_spill);
   release(c->name_recs);
   release(c->name_hcount);
   release(c->name_redo);
@@ -686,10 +695,11 @@ struct RecordDuties {  // what k_stream_lines needs from the caller of frame_str
   uint32_t weight;
   AccState* acc;
   unsigned long long* hist;
+  int fmt, is_pe;  // name digests are made under the caller's file state
 };
 
 int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_chunks, bool final, SuspectMap sm,
-                 const RecordDuties& rd, bool want_names, bool want_index, Framed* out) {
+                 const RecordDuties& rd, int want_names /* 0, 1 = records, 2 = digests */, bool want_index, Framed* out) {
   int rc;
   c->names_img = nullptr;
   const uint32_t n_spans = (n_chunks + kScanSpan - 1) / kScanSpan;
@@ -724,19 +734,24 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     uint32_t shift = 3;
     while (shift < 7 && (double)(1u << shift) < 1.25 * per_chunk + 1.0) ++shift;
     nc.K = 1u << shift;
-    if ((rc = ensure(c, c->name_recs, ((size_t)n_chunks << shift) * kNameRecWords * 8))) return rc;
+    nc.fmt = rd.fmt;
+    nc.is_pe = rd.is_pe;
+    if ((rc = ensure(c, c->name_recs, ((size_t)n_chunks << shift) * (want_names == 2 ? kDigestWords : kNameRecWords) * 8))) return rc;
     if ((rc = ensure(c, c->name_hcount, (size_t)n_chunks * 2))) return rc;
     nc.recs = (unsigned long long*)c->name_recs.p;
     nc.hcount = (uint16_t*)c->name_hcount.p;
     c->names.k_shift = shift;
   }
   {
-    ProfScope ps(c, want_names ? "k_stream_pass1(names)" : "k_stream_pass1");
-    if (want_names)
-      hipLaunchKernelGGL((k_stream_pass1<0u, true>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
+    ProfScope ps(c, want_names == 2 ? "k_stream_pass1(digests)" : want_names ? "k_stream_pass1(names)" : "k_stream_pass1");
+    if (want_names == 2)
+      hipLaunchKernelGGL((k_stream_pass1<0u, 2>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
+                         n_chunks, so, c->d_cs, nc);
+    else if (want_names)
+      hipLaunchKernelGGL((k_stream_pass1<0u, 1>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
                          n_chunks, so, c->d_cs, nc);
     else
-      hipLaunchKernelGGL((k_stream_pass1<0u, false>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
+      hipLaunchKernelGGL((k_stream_pass1<0u, 0>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
                          n_chunks, so, c->d_cs, nc);
   }
   {
@@ -877,6 +892,9 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     c->names.cr.span_excl = (const unsigned long long*)c->span_sums.p;
     c->names.cr.n_chunks = n_chunks;
     c->names.K = nc.K;
+    c->names.digests = want_names == 2 ? 1u : 0u;
+    c->names.fmt = rd.fmt;
+    c->names.is_pe = rd.is_pe;
     c->names_img = d_img;
     c->names_nbytes = nbytes;
   }
@@ -934,7 +952,7 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   const bool frame_only = (flags & FQG_VALIDATE_FRAME_ONLY) != 0;
   if (frame_only) acc = nullptr;
   // (frame only + names: the single-pass framing runs for its capture records; what its checks find is not looked at)
-  const bool names_only = frame_only && (flags & FQG_VALIDATE_NAMES) && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS);
+  const bool names_only = frame_only && (flags & (FQG_VALIDATE_NAMES | FQG_VALIDATE_NAME_DIGESTS)) && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS);
   const bool want_checks = !(flags & FQG_VALIDATE_FORCE_EXACT) && (!frame_only || names_only);
   const uint32_t weight = (flags & FQG_VALIDATE_COUNT_TWICE) ? 2u : 1u;
 
@@ -953,9 +971,12 @@ int fqg_validate(fqg_ctx* c, fqg_acc* acc, const void* image, uint64_t nbytes, i
   Framed fr;
   bool streamed = false;
   if (want_checks && nbytes >= c->stream_min && !(flags & FQG_VALIDATE_TWO_PASS)) {
-    RecordDuties rd{st->space, weight, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr};
-    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, (flags & FQG_VALIDATE_NAMES) != 0,
-                      (flags & (FQG_VALIDATE_NAMES | FQG_VALIDATE_INDEX)) != 0, &fr);
+    RecordDuties rd{st->space, weight, acc ? acc->d_state : nullptr, acc ? acc->d_hist : nullptr, st->readname_format, st->is_pe};
+    // (digests need a format to canonicalise under: a file state that has none yet gets records)
+    const int names_mode = (flags & FQG_VALIDATE_NAME_DIGESTS) && st->readname_format != FQG_NAME_UNDEF ? 2
+                           : (flags & (FQG_VALIDATE_NAMES | FQG_VALIDATE_NAME_DIGESTS)) ? 1 : 0;
+    rc = frame_stream(c, d_img, nbytes, n_chunks, final != 0, sm, rd, names_mode,
+                      (flags & (FQG_VALIDATE_NAMES | FQG_VALIDATE_NAME_DIGESTS | FQG_VALIDATE_INDEX)) != 0, &fr);
     if (rc < 0) return rc;
     streamed = rc == 0;
     if (!streamed) HIP_TRY(c, hipMemsetAsync(c->suspect.p, 0, (size_t)(sm.cap / 32 + 2) * 4, c->stream));
@@ -1310,9 +1331,13 @@ unsigned index_grid(fqg_ctx* c, uint64_t n) {
 }
 
 // the capture records of the last fqg_validate belong to this frame (FQG_VALIDATE_NAMES, streamed)
-bool names_usable(const fqg_ctx* c, const FrameView& fv) {
+// (digests hold no name bytes and are made under one file state: they serve the insert into an index that keeps no name
+// records, for that very state - everybody else reads the names through the line index)
+bool names_usable(const fqg_ctx* c, const FrameView& fv, const fqg_file_state* st, bool bytes_needed) {
   static const bool off = getenv("FQGPU_NO_NAME_CAPTURE") != nullptr;  // (A/B: always go through the line index)
-  return !off && c->names_img && c->names_img == fv.img && c->names_nbytes == fv.nbytes;
+  if (off || !c->names_img || c->names_img != fv.img || c->names_nbytes != fv.nbytes) return false;
+  if (c->names.digests) return !bytes_needed && st->readname_format == c->names.fmt && st->is_pe == c->names.is_pe;
+  return true;
 }
 // the lists k_names_pass fills for k_names_rest
 int env_int(const char* name, int dflt);
@@ -1321,7 +1346,7 @@ int names_prepare(fqg_ctx* c, const FrameView& fv) {
   (void)fv;
   const uint64_t n_slots = (uint64_t)c->names.cr.n_chunks << c->names.k_shift;
   if ((rc = ensure(c, c->name_redo, ((n_slots + 63) / 64 + 1) * 8))) return rc;
-  if ((rc = ensure(c, c->name_redo_chunks, (size_t)std::max<uint32_t>(c->names.cr.n_chunks, 1)))) return rc;
+  if ((rc = ensure(c, c->name_redo_chunks, (((size_t)std::max<uint32_t>(c->names.cr.n_chunks, 1) + 15) & ~(size_t)15) + 16))) return rc;
   c->names.redo_bits = (unsigned long long*)c->name_redo.p;
   c->names.chunk_redo = (uint8_t*)c->name_redo_chunks.p;
   static const int abl = measure_int("FQGPU_NAMES_ABL");
@@ -1349,11 +1374,92 @@ void launch_names_pass(fqg_ctx* c, bool match, const FrameView& fv, const IndexV
   if (match) {
     if (nt) FQG_NAMES_PASS(true, true);
     else FQG_NAMES_PASS(true, false);
+  } else if (c->names.digests) {
+    hipLaunchKernelGGL((k_names_pass<false, true, true>), dim3(names_grid(c)), dim3(kBlock), dyn_lds, c->stream, fv, c->names, iv,
+                       st->readname_format, st->is_pe, base, found, c->d_icall);
   } else {
     if (nt) FQG_NAMES_PASS(false, true);
     else FQG_NAMES_PASS(false, false);
   }
 #undef FQG_NAMES_PASS
+}
+
+// The table built part by part in LDS from the name digests of the current frame (fqg_names_build_kernels.hip) instead of
+// one CAS per name.  Returns 0 when it ran (the call's scalars hold its counts and findings), 1 when it does not apply
+// or a bucket overflowed (nothing has touched the table: the caller takes k_names_pass), < 0 on errors.
+constexpr unsigned long long kBuildSpillCap = 1ull << 20;
+int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_state* st, uint64_t record_base) {
+  const int mode = env_int("FQGPU_NAMES_BUILD", -1);  // 0: never, 1: whenever the table allows it (tests), -1: by size
+  if (mode == 0 || !c->names.digests) return 1;
+  uint32_t k = 0;
+  while ((1ull << k) < ix->capacity) ++k;
+  if (k < kPartLogMin + 1) return 1;
+  uint32_t part_log = std::min(std::max(k > 16 ? k - 16 : 0u, kPartLogMin), kPartLogMax);
+  {
+    const int forced = env_int("FQGPU_BUILD_PART_LOG", 0);  // (A/B)
+    if (forced == 12 || forced == 13) part_log = std::max<uint32_t>(forced, k > 16 ? k - 16 : 0u);
+    if (part_log > kPartLogMax || k < part_log + 1) return 1;
+  }
+  const uint32_t part_bits = k - part_log;
+  const uint32_t bits0 = std::min<uint32_t>(part_bits, 8), bits1 = part_bits - bits0;
+  if (bits1 > 8) return 1;
+  // worth it when the frame brings a sizeable share of the table: the build writes (and, for an index that is not
+  // empty, first reads) every part - 8 bytes per SLOT -, the CAS pass costs by the name
+  const bool empty = ix->n_records_total == 0;
+  if (mode < 0 && fv.n_records < ix->capacity / (empty ? 16 : 8)) return 1;
+  const uint64_t n = fv.n_records;
+  auto room = [](double mean) { return (unsigned long long)(mean + 8.0 * std::sqrt(mean + 1.0) + 64.0); };
+  const unsigned long long cap0 = room((double)n / (double)(1u << bits0));
+  const unsigned long long cap1 = bits1 ? room((double)n / (double)(1u << part_bits)) : 0;
+  int rc;
+  if ((rc = ensure(c, c->build_keys[0], (size_t)(cap0 << bits0) * sizeof(BuildKey)))) return rc;
+  if (bits1 && (rc = ensure(c, c->build_keys[1], (size_t)(cap1 << part_bits) * sizeof(BuildKey)))) return rc;
+  const size_t n_cursors = (size_t)(1u << bits0) + (bits1 ? (size_t)(1u << part_bits) : 0);
+  if ((rc = ensure(c, c->build_cursor, n_cursors * 4))) return rc;
+  if ((rc = ensure(c, c->build_spill, (size_t)kBuildSpillCap * sizeof(BuildKey)))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->build_cursor.p, 0, n_cursors * 4, c->stream));
+  unsigned int* cur0 = (unsigned int*)c->build_cursor.p;
+  unsigned int* cur1 = cur0 + (1u << bits0);
+  const uint64_t mask = ix->capacity - 1;
+  BuildLevel L0{(BuildKey*)c->build_keys[0].p, cur0, cap0, k - bits0, bits0};
+  const uint64_t n_slots = (uint64_t)c->names.cr.n_chunks << c->names.k_shift;
+  {
+    ProfScope ps(c, "k_names_build_scatter0");
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_slots + kBuildTile - 1) / kBuildTile, (uint64_t)c->cu_count * 8));
+    hipLaunchKernelGGL(k_build_scatter<0>, dim3(grid), dim3(kBlock), 0, c->stream, fv, c->names, record_base, mask, L0,
+                       (const BuildKey*)nullptr, (const unsigned int*)nullptr, 0ull, c->d_icall);
+  }
+  const BuildKey* part_keys = L0.out;
+  const unsigned int* part_count = cur0;
+  unsigned long long part_cap = cap0;
+  if (bits1) {
+    BuildLevel L1{(BuildKey*)c->build_keys[1].p, cur1, cap1, part_log, bits1};
+    ProfScope ps(c, "k_names_build_scatter1");
+    const unsigned tiles = (unsigned)((cap0 + kBuildTile - 1) / kBuildTile);
+    hipLaunchKernelGGL(k_build_scatter<1>, dim3(tiles, 1u << bits0), dim3(kBlock), 0, c->stream, fv, c->names, record_base, mask, L1,
+                       (const BuildKey*)L0.out, (const unsigned int*)cur0, cap0, c->d_icall);
+    part_keys = L1.out;
+    part_count = cur1;
+    part_cap = cap1;
+  }
+  {
+    ProfScope ps(c, "k_names_build_parts");
+    if (part_log == 12)
+      hipLaunchKernelGGL(k_build_parts<12>, dim3(1u << part_bits), dim3(kBlock), 0, c->stream, fv, index_view(ix), record_base, part_keys,
+                         part_count, part_cap, empty ? 0 : 1, (BuildKey*)c->build_spill.p, kBuildSpillCap, c->d_icall);
+    else
+      hipLaunchKernelGGL(k_build_parts<13>, dim3(1u << part_bits), dim3(kBlock), 0, c->stream, fv, index_view(ix), record_base, part_keys,
+                         part_count, part_cap, empty ? 0 : 1, (BuildKey*)c->build_spill.p, kBuildSpillCap, c->d_icall);
+  }
+  {
+    ProfScope ps(c, "k_names_build_spill");
+    hipLaunchKernelGGL(k_build_spill, dim3(64), dim3(kBlock), 0, c->stream, fv, index_view(ix), record_base,
+                       (const BuildKey*)c->build_spill.p, kBuildSpillCap, c->d_icall);
+  }
+  if ((rc = index_fetch_call(c))) return rc;
+  if (c->h_icall->build_overflow) return 1;
+  (void)st;
+  return 0;
 }
 
 // rebuild the table at a larger capacity from the retained segments
@@ -1459,10 +1565,13 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
   if ((rc = index_reserve_records(ix, ix->n_records_total + sg.n_records))) return drop(rc);
   if ((rc = index_upload_segs(ix))) return drop(rc);
   if ((rc = index_reset_call(c))) return drop(rc);
-  const bool captured = names_usable(c, fr->fv);
+  const bool captured = names_usable(c, fr->fv, st, ix->keep_names);
   if (sg.n_records && captured) {
     if ((rc = names_prepare(c, fr->fv))) return drop(rc);
-    {
+    const int built = names_build(c, ix, fr->fv, st, sg.record_base);
+    if (built < 0) return drop(built);
+    if (built == 1) {
+      if ((rc = index_reset_call(c))) return drop(rc);
       ProfScope ps(c, "k_names_insert");
       launch_names_pass(c, false, fr->fv, index_view(ix), st, sg.record_base, nullptr);
     }
@@ -1516,7 +1625,7 @@ static int index_match_impl(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
     d_match = (unsigned long long*)ix->match.p;
   }
   if (fv.n_records) {
-    if (names_usable(c, fv)) {
+    if (names_usable(c, fv, st, true)) {
       if ((rc = names_prepare(c, fv))) return rc;
       {
         ProfScope ps(c, "k_names_match");
@@ -1670,20 +1779,12 @@ static BcTile bc_tile_for(const BcParams& P, unsigned default_budget = 20480u) {
   return tc;
 }
 
-int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const fqg_file_state states[6],
-                           const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_iter,
-                           uint64_t first_read_number, fqg_barcode_result* out) {
-  if (!c || !frames || !states || !first_record || !bp || !out) return FQG_ERR_ARG;
-  if (c->out_pending) {  // (a copy of the previous output is still on its way: this call writes the same buffers)
-    const int rcw = fqg_barcodes_output_wait(c);
-    if (rcw) return rcw;
-  }
-  memset(out, 0, sizeof(*out));
-  c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
-  HIP_TRY(c, hipSetDevice(c->device));
-  BcParams P;
+// the kernels' view of one batch (shared by the transform and the census of what it kept)
+static int bc_make_params(fqg_ctx* c, const fqg_frame* const frames[6], const fqg_file_state states[6],
+                          const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_iter,
+                          uint64_t first_read_number, BcParams& P, bool& inter) {
   memset(&P, 0, sizeof(P));
-  const bool inter = bp->interleaved[0] != 0 || bp->interleaved[1] != 0;
+  inter = bp->interleaved[0] != 0 || bp->interleaved[1] != 0;
   for (int x = 1; x < kBcFiles; ++x) {
     if (!bp->present[x]) continue;
     if (!frames[x]) return fail(c, FQG_ERR_ARG, "fqg_barcodes_transform: missing frame");
@@ -1736,9 +1837,27 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
     P.read_size[x] = bp->read_size[x];
   }
   P.first_read_number = first_read_number;
+  return 0;
+}
+
+int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const fqg_file_state states[6],
+                           const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_iter,
+                           uint64_t first_read_number, fqg_barcode_result* out) {
+  if (!c || !frames || !states || !first_record || !bp || !out) return FQG_ERR_ARG;
+  if (c->out_pending) {  // (a copy of the previous output is still on its way: this call writes the same buffers)
+    const int rcw = fqg_barcodes_output_wait(c);
+    if (rcw) return rcw;
+  }
+  memset(out, 0, sizeof(*out));
+  c->bc_out_bytes[0] = c->bc_out_bytes[1] = c->bc_out_bytes[2] = 0;
+  c->bc_status_valid = 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  BcParams P;
+  bool inter;
+  int rc;
+  if ((rc = bc_make_params(c, frames, states, first_record, bp, n_iter, first_read_number, P, inter))) return rc;
   if (!n_iter) return 0;
 
-  int rc;
   if ((rc = ensure(c, c->bc_status, n_iter))) return rc;
   const uint64_t nb = (n_iter + kScan64Span - 1) / kScan64Span;
   for (int i = 0; i < 3; ++i) {
@@ -1888,7 +2007,161 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
       out->n_short = c->h_bcall->short_warnings;
     }
   }
+  c->bc_status_valid = out->n_done;  // (fqg_barcodes_census: the status bytes of the iterations this batch yielded)
   return 0;
+}
+
+// ---- census of what the transform kept (fqg_census_kernels.hip) -------------------------------------
+struct fqg_census {
+  fqg_ctx* ctx = nullptr;
+  DevBuf cells, umis;     // the pairs, in arrival order until fqg_census_finish sorts them
+  DevBuf cells2, umis2, tmp, flag, local, sums, lines;
+  unsigned long long* d_count = nullptr;
+  uint64_t n_pairs = 0, n_cells = 0;
+  bool finished = false;
+};
+
+int fqg_census_create(fqg_ctx* c, fqg_census** out) {
+  if (!c || !out) return FQG_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::unique_ptr<fqg_census> z(new fqg_census());
+  z->ctx = c;
+  if (hipMalloc((void**)&z->d_count, 8) != hipSuccess) return fail(c, FQG_ERR_NOMEM, "fqg_census_create");
+  HIP_TRY(c, hipMemsetAsync(z->d_count, 0, 8, c->stream));
+  *out = z.release();
+  return 0;
+}
+
+void fqg_census_destroy(fqg_census* z) {
+  if (!z) return;
+  (void)hipStreamSynchronize(z->ctx->stream);
+  for (DevBuf* b : {&z->cells, &z->umis, &z->cells2, &z->umis2, &z->tmp, &z->flag, &z->local, &z->sums, &z->lines}) release(*b);
+  if (z->d_count) (void)hipFree(z->d_count);
+  delete z;
+}
+
+// room for `need` pairs in a pair of arrays that keep their contents
+static int census_reserve(fqg_ctx* c, fqg_census* z, uint64_t need) {
+  if (need * 8 <= z->cells.cap) return 0;
+  const uint64_t cap = std::max<uint64_t>(need + need / 2, 1u << 16);
+  DevBuf a, b;
+  if (hipMalloc(&a.p, cap * 8) != hipSuccess) return fail(c, FQG_ERR_NOMEM, "fqg_barcodes_census");
+  if (hipMalloc(&b.p, cap * 8) != hipSuccess) {
+    (void)hipFree(a.p);
+    return fail(c, FQG_ERR_NOMEM, "fqg_barcodes_census");
+  }
+  a.cap = b.cap = cap * 8;
+  if (z->n_pairs) {
+    (void)hipMemcpyAsync(a.p, z->cells.p, z->n_pairs * 8, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(b.p, z->umis.p, z->n_pairs * 8, hipMemcpyDeviceToDevice, c->stream);
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  release(z->cells);
+  release(z->umis);
+  z->cells = a;
+  z->umis = b;
+  return 0;
+}
+
+int fqg_barcodes_census(fqg_ctx* c, fqg_census* z, const fqg_frame* const frames[6], const fqg_file_state states[6],
+                        const uint64_t first_record[6], const fqg_barcode_params* bp, uint64_t n_done, uint64_t* n_added) {
+  if (!c || !z || z->ctx != c || !frames || !states || !first_record || !bp) return FQG_ERR_ARG;
+  if (z->finished) return fail(c, FQG_ERR_STATE, "fqg_barcodes_census: the census is finished");
+  if (n_done > c->bc_status_valid)
+    return fail(c, FQG_ERR_STATE, "fqg_barcodes_census: call it behind the fqg_barcodes_transform of the same batch, with that call's n_done");
+  if (n_added) *n_added = 0;
+  if (!n_done) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  BcParams P;
+  bool inter;
+  int rc;
+  if ((rc = bc_make_params(c, frames, states, first_record, bp, n_done, 0, P, inter))) return rc;
+  if ((rc = census_reserve(c, z, z->n_pairs + n_done))) return rc;
+  HIP_TRY(c, hipMemsetAsync(z->d_count, 0, 8, c->stream));
+  {
+    ProfScope ps(c, "k_bc_census");
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 16));
+    hipLaunchKernelGGL(k_bc_census, dim3(grid), dim3(kBlock), 0, c->stream, P, n_done, (const uint8_t*)c->bc_status.p,
+                       (unsigned long long*)z->cells.p, (unsigned long long*)z->umis.p, (unsigned long long)z->n_pairs,
+                       (unsigned long long)(z->cells.cap / 8), z->d_count);
+  }
+  unsigned long long added = 0;
+  HIP_TRY(c, hipMemcpyAsync(&added, z->d_count, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  z->n_pairs += added;
+  if (n_added) *n_added = added;
+  return 0;
+}
+
+int fqg_census_finish(fqg_ctx* c, fqg_census* z, uint64_t* n_pairs, uint64_t* n_cells) {
+  if (!c || !z || z->ctx != c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t n = z->n_pairs;
+  if (!z->finished && n) {
+    int rc;
+    if ((rc = ensure(c, z->cells2, n * 8)) || (rc = ensure(c, z->umis2, n * 8))) return rc;
+    if (n >= (1ull << 31)) return fail(c, FQG_ERR_ARG, "fqg_census_finish: more than 2^31 pairs");
+    // by UMI, then (stable) by cell: sorted by (cell, UMI)
+    unsigned long long *ce = (unsigned long long*)z->cells.p, *um = (unsigned long long*)z->umis.p;
+    unsigned long long *ce2 = (unsigned long long*)z->cells2.p, *um2 = (unsigned long long*)z->umis2.p;
+    size_t tmp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, um, um2, ce, ce2, n, 0, 64, c->stream) != hipSuccess)
+      return fail(c, FQG_ERR_HIP, "fqg_census_finish: sort");
+    if ((rc = ensure(c, z->tmp, tmp_bytes + 16))) return rc;
+    ProfScope ps(c, "k_census_finish");
+    if (rocprim::radix_sort_pairs(z->tmp.p, tmp_bytes, um, um2, ce, ce2, n, 0, 64, c->stream) != hipSuccess ||
+        rocprim::radix_sort_pairs(z->tmp.p, tmp_bytes, ce2, ce, um2, um, n, 0, 64, c->stream) != hipSuccess)
+      return fail(c, FQG_ERR_HIP, "fqg_census_finish: sort");
+    const uint64_t nb = (n + kScan64Span - 1) / kScan64Span;
+    if ((rc = ensure(c, z->flag, n * 4)) || (rc = ensure(c, z->local, n * 8)) || (rc = ensure(c, z->sums, nb * 8 + 8))) return rc;
+    unsigned long long* d_total = (unsigned long long*)z->sums.p + nb;
+    HIP_TRY(c, hipMemsetAsync(d_total, 0, 8, c->stream));
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_census_flags, dim3(grid), dim3(kBlock), 0, c->stream, (const unsigned long long*)ce, n, (uint32_t*)z->flag.p);
+    hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const uint32_t*)z->flag.p, n,
+                       (unsigned long long*)z->local.p, (unsigned long long*)z->sums.p);
+    hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)z->sums.p, nb, d_total);
+    unsigned long long cells = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cells, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    z->n_cells = cells;
+    if ((rc = ensure(c, z->lines, cells * sizeof(CensusCell)))) return rc;
+    HIP_TRY(c, hipMemsetAsync(z->lines.p, 0, cells * sizeof(CensusCell), c->stream));
+    hipLaunchKernelGGL(k_census_count, dim3(grid), dim3(kBlock), 0, c->stream, (const unsigned long long*)ce,
+                       (const unsigned long long*)um, n, (const uint32_t*)z->flag.p, (const unsigned long long*)z->local.p,
+                       (const unsigned long long*)z->sums.p, (CensusCell*)z->lines.p);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+  }
+  z->finished = true;
+  if (n_pairs) *n_pairs = z->n_pairs;
+  if (n_cells) *n_cells = z->n_cells;
+  return 0;
+}
+
+int fqg_census_cells(fqg_ctx* c, fqg_census* z, fqg_census_cell* out, uint64_t cap) {
+  if (!c || !z || z->ctx != c || (!out && cap)) return FQG_ERR_ARG;
+  if (!z->finished) return fail(c, FQG_ERR_STATE, "fqg_census_cells: fqg_census_finish first");
+  static_assert(sizeof(fqg_census_cell) == sizeof(CensusCell), "the C-ABI line is the device line");
+  const uint64_t n = std::min<uint64_t>(cap, z->n_cells);
+  if (n) HIP_TRY(c, hipMemcpy(out, z->lines.p, n * sizeof(CensusCell), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fqg_census_pairs(fqg_ctx* c, fqg_census* z, uint64_t* cells, uint64_t* umis, uint64_t cap) {
+  if (!c || !z || z->ctx != c || ((!cells || !umis) && cap)) return FQG_ERR_ARG;
+  const uint64_t n = std::min<uint64_t>(cap, z->n_pairs);
+  if (n) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(cells, z->cells.p, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(umis, z->umis.p, n * 8, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+const void* fqg_census_device_pairs(const fqg_census* z, int which) {
+  return z ? (which ? z->umis.p : z->cells.p) : nullptr;
 }
 
 // ---- whitelist membership ---------------------------------------------------------------------

@@ -64,10 +64,42 @@ constexpr uint32_t kNameRecText = 60;       // header bytes behind the '@' in a 
 constexpr uint32_t kNameInline = 56;        // name bytes the index keeps per record (NameRec)
 constexpr uint32_t kNoCapture = 0xFFFFu;
 struct NameCapture {
-  unsigned long long* recs;  // n_chunks * K records
+  unsigned long long* recs;  // n_chunks * K records (or digests)
   uint16_t* hcount;          // per chunk
   uint32_t K;                // record slots per chunk
+  int fmt, is_pe;            // digests: the read-name format / is_pe the names are canonicalised under (fqg_file_state)
 };
+// ---- name DIGESTS instead of records (FQG_VALIDATE_NAME_DIGESTS) ------------------------------------
+// For an index that only tests names for uniqueness (fastq_info on ONE file: nobody will look a name up, so nobody needs
+// its bytes unless two tags agree) the streaming pass canonicalises and hashes every header line itself while the chunk
+// is in LDS - four lanes per header, 16 name bytes each - and stores 16 bytes per header instead of 64:
+//     word 0   the hash of the canonical name (name_fin below: the value every other path computes for it)
+//     word 1   bits 0..9 n, the canonical name's length; 10..19 the `len` the reference accounts for it
+//              (src/fastq.c:609); 20..28 v (as in a record); bit 29 the line starts with '@'; bit 30 the digest is
+//              good - clear: the line's end was not seen, the name is longer than kDigestText bytes, a Casava header has
+//              no blank ... the name kernels then read that header through the line index, as they do for records
+// Same places as records: [chunk * K + ordinal], hcount[chunk], trusted under the same conditions.
+constexpr uint32_t kDigestWords = 2;
+constexpr uint32_t kDigestText = 64;        // name bytes the four lanes of a header look at
+constexpr uint32_t kDigestAt = 1u << 29, kDigestOk = 1u << 30;
+
+// The hash of a name (round 6): H = fin(seed(n) + sum over the name's 8-byte words w_k of w_k * M_k), zero bytes behind
+// the name.  A SUM, so that the words can be taken in any order and by different lanes - the streaming pass hashes a
+// header with four lanes of 16 bytes each while the chunk is in LDS (name digests, fqg_stream_kernels.hip) - and a word
+// of zeros adds nothing, so that nobody has to know where the last word is.  The multipliers are odd: two names that
+// differ in one word never share a sum.  (Rounds 1 - 5 chained a multiply per word: eight dependent 64-bit multiplies
+// on one lane.)  Equality is decided on the name BYTES wherever this value is used; it chooses a slot and a tag.
+__host__ __device__ constexpr uint64_t name_mul(uint32_t k) {
+  return (0x9E3779B97F4A7C15ull + (uint64_t)k * 0xD1B54A32D192ED03ull) | 1ull;
+}
+// (what a 64-bit multiply costs decides the rest: v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of the rate, a 64 x 64
+// product is three of them - the seed and the final mix are made of 32 x 32 -> 64 products, one and two)
+__device__ __forceinline__ uint64_t name_seed(uint32_t n) { return 0x2545F4914F6CDD1Dull ^ ((uint64_t)n * 0x9E3779B1u); }
+__device__ __forceinline__ uint64_t name_fin(uint64_t h) {
+  const uint32_t hi = (uint32_t)(h >> 32), t = (uint32_t)h ^ hi;  // (the low bits of a sum of products are its weak ones)
+  const uint64_t p = (uint64_t)t * 0xD6E8FEB9u, q = (uint64_t)hi * 0x85EBCA6Bu;
+  return p ^ ((q << 32) | (q >> 32));
+}
 
 // Scalars of one fqg_validate() call.  Lives in device memory; the host copies it back once.
 struct CallState {

@@ -71,7 +71,8 @@ struct IndexCall {
   unsigned long long seen;          // records the call looked at (a check on the enumeration by chunk: must be the frame's)
   unsigned long long captured;      // ... of them straight from a capture record
   unsigned int table_full;
-  unsigned int pad;
+  unsigned int build_overflow;      // table built in LDS (fqg_names_build_kernels.hip): a key bucket was too small
+  unsigned long long spilled;       // ... keys that ran past the end of their part
 };
 
 __device__ __forceinline__ uint64_t mix_hash(uint64_t h, uint64_t w) {
@@ -80,7 +81,6 @@ __device__ __forceinline__ uint64_t mix_hash(uint64_t h, uint64_t w) {
   h ^= h >> 29;
   return h;
 }
-
 // Canonical read name of the header line [line, line+len) (+'\n' when has_nl), after
 // fastq_get_readname (reference src/fastq.c:488-512).  Returns its length; the name starts at
 // line+1.  *acct is the `len` value the reference hands to new_indexentry (index_mem accounting).
@@ -124,23 +124,20 @@ __device__ __forceinline__ uint64_t fin_hash2(uint64_t h) {
   return h;
 }
 __device__ __forceinline__ uint64_t hash_name(const uint8_t* __restrict__ p, uint32_t n, uint64_t* second = nullptr) {
-  uint64_t h = 0x2545F4914F6CDD1Dull ^ n, g = 0x9E3779B97F4A7C15ull + n;
+  uint64_t h = name_seed(n), g = 0x9E3779B97F4A7C15ull + n;
   uint32_t i = 0;
   for (; i + 8 <= n; i += 8) {
     uint64_t w;
     __builtin_memcpy(&w, p + i, 8);
-    h = mix_hash(h, w);
+    h += w * name_mul(i >> 3);
     g = mix_hash2(g, w);
   }
   uint64_t w = 0;
   for (uint32_t k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
-  h = mix_hash(h, w);
+  h += w * name_mul(i >> 3);
   g = mix_hash2(g, w);
-  h ^= h >> 32;
-  h *= 0xD6E8FEB86659FD93ull;
-  h ^= h >> 32;
   if (second) *second = fin_hash2(g);
-  return h;
+  return name_fin(h);
 }
 
 __device__ __forceinline__ bool same_bytes(const uint8_t* a, const uint8_t* b, uint32_t n) {
@@ -232,7 +229,7 @@ __device__ __forceinline__ uint32_t canon_name_regs(const HdrRegs& H, uint32_t c
 }
 // hash_name(line + 1, n) on registers: the same value, word for word
 __device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n, uint64_t* second = nullptr) {
-  uint64_t h = 0x2545F4914F6CDD1Dull ^ n, g = 0x9E3779B97F4A7C15ull + n;
+  uint64_t h = name_seed(n), g = 0x9E3779B97F4A7C15ull + n;
 #pragma unroll
   for (int k = 0; k < kHdrWords; ++k) {
     const uint64_t nw = (H.w[k] >> 8) | (H.w[k + 1] << 56);  // bytes 8k .. 8k+7 of the name
@@ -241,15 +238,12 @@ __device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n,
     const uint32_t rem = n - 8u * k;         // 0..7 when `last`
     const uint64_t w = full ? nw : (nw & ((1ull << (8 * (rem & 7))) - 1ull));
     if (full || last) {
-      h = mix_hash(h, w);
+      h += w * name_mul((uint32_t)k);
       g = mix_hash2(g, w);
     }
   }
-  h ^= h >> 32;
-  h *= 0xD6E8FEB86659FD93ull;
-  h ^= h >> 32;
   if (second) *second = fin_hash2(g);
-  return h;
+  return name_fin(h);
 }
 // name (length, hash) of the header line at img + b; the fast path when the line allows it
 // (nm, optional: the first kNameInline bytes of the name as zero-padded words)
@@ -342,20 +336,17 @@ __device__ __forceinline__ bool name_from_record(const unsigned long long (&w)[k
     n = l >= 1 ? (uint32_t)(l - 1) : L;
   }
   // hash_name(line + 1, n), word for word
-  uint64_t h = 0x2545F4914F6CDD1Dull ^ n;
+  uint64_t h = name_seed(n);
 #pragma unroll
   for (uint32_t i = 0; i < kNameRecWords; ++i) {
     const bool full = 8u * i + 8u <= n;
     const bool last = !full && 8u * i <= n;
     const uint32_t rem = n - 8u * i;
     const uint64_t x = full ? t[i] : (t[i] & ((1ull << (8 * (rem & 7))) - 1ull));
-    if (full || last) h = mix_hash(h, x);
+    if (full || last) h += x * name_mul(i);
     if (i < kNameInline / 8) k.nm[i] = (full || last) ? x : 0ull;
   }
-  h ^= h >> 32;
-  h *= 0xD6E8FEB86659FD93ull;
-  h ^= h >> 32;
-  k.h = h;
+  k.h = name_fin(h);
   k.n = n;
   k.acct = acct;
   return true;
@@ -549,6 +540,8 @@ struct NamesView {
   const uint32_t* cinfo;
   ChunkRanks cr;
   uint32_t K, k_shift;  // K = 1 << k_shift record slots per chunk
+  uint32_t digests;     // the slots hold 16-byte digests made under (fmt, is_pe), not 64-byte records (fqg_device.h)
+  int fmt, is_pe;
   // what k_names_pass leaves to k_names_rest - written with plain stores, one owner per word (a list with ONE counter
   // was the whole cost of this pass: a million appends to one address take 12 ms):
   unsigned long long* redo_bits;  // per 64 record slots: the slots whose record cannot give the name
@@ -556,7 +549,7 @@ struct NamesView {
   int ablate;  // measurement only (FQGPU_NAMES_ABL): 1 = no table access, 8 = no decoding
 };
 
-template <bool MATCH, bool NT = true>
+template <bool MATCH, bool NT = true, bool DIGEST = false>
 __global__ __launch_bounds__(kBlock) void k_names_pass(FrameView f, NamesView nv, IndexView ix, int fmt, int is_pe,
                                                        uint64_t base /* record_base or asker_base */,
                                                        unsigned long long* __restrict__ found,
@@ -579,7 +572,22 @@ __global__ __launch_bounds__(kBlock) void k_names_pass(FrameView f, NamesView nv
       const bool trusted = hc != kNoCapture && hc <= nv.K && !(info & (kInfoUnknown | kInfoOneLine)) && (info & 3u) == ((uint32_t)rank0 & 3u);
       if (j == 0) nv.chunk_redo[c] = trusted ? 0 : 1;
       live = trusted && j < hc;
-      if (live) {
+      if (live && DIGEST) {
+        // the streaming pass has done the work: hash, lengths, '@' (an index without name records asks for no bytes)
+        const u64x2_t* src = reinterpret_cast<const u64x2_t*>(nv.recs + s * kDigestWords);
+        const u64x2_t x = NT ? __builtin_nontemporal_load(src) : src[0];
+        const uint32_t meta = (uint32_t)x.y;
+        k.h = x.x;
+        k.n = meta & 1023u;
+        k.acct = (meta >> 10) & 1023u;
+        at_sign = (meta & kDigestAt) != 0;
+        r = (rank0 + ((meta >> 20) & 511u)) >> 2;
+        if (r >= f.n_records) live = false;
+        else if (!(meta & kDigestOk)) {
+          redo = true;
+          live = false;
+        }
+      } else if (live) {
         unsigned long long w[kNameRecWords];
         const u64x2_t* src = reinterpret_cast<const u64x2_t*>(nv.recs + s * kNameRecWords);
 #pragma unroll
@@ -642,18 +650,27 @@ __global__ __launch_bounds__(kBlock) void k_names_rest(FrameView f, NamesView nv
       const uint64_t s = (wd << 6) + (uint64_t)__builtin_ctzll(m);
       m &= m - 1;
       const uint32_t c = (uint32_t)(s >> nv.k_shift);
-      const uint32_t v = ((uint32_t)nv.recs[s * kNameRecWords] >> 10) & 511u;
+      const uint32_t v = nv.digests ? ((uint32_t)nv.recs[s * kDigestWords + 1] >> 20) & 511u
+                                    : ((uint32_t)nv.recs[s * kNameRecWords] >> 10) & 511u;
       one((nv.cr.rank0(c) + v) >> 2);
     }
   }
-  // a flagged chunk: 16 lanes share its candidates
-  for (uint64_t c = tid >> 4; c < nv.cr.n_chunks; c += stride >> 4) {
-    if (!nv.chunk_redo[c]) continue;
-    const uint64_t rank0 = nv.cr.rank0((uint32_t)c);
-    const uint64_t r_lo = (rank0 + 3) >> 2, r_hi = (rank0 + nv.cr.counts[c]) >> 2;
-    for (uint64_t r = r_lo + (tid & 15u); r <= r_hi && r < f.n_records; r += 16) {
-      const uint64_t start = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
-      if (start / kChunkBytes == c) one(r);
+  // a flagged chunk: 16 lanes share its candidates.  The flags are looked at 16 bytes at a time (a group of 16 lanes
+  // walks 16 chunks per load: a byte per load was 0.2 ms of dependent round trips for the handful of chunks an ordinary
+  // file flags); the flag array is padded to a multiple of 16 by names_prepare
+  const uint64_t n_groups = ((uint64_t)nv.cr.n_chunks + 15) >> 4;
+  for (uint64_t g = tid >> 4; g < n_groups; g += stride >> 4) {
+    const u64x2_t fl = *reinterpret_cast<const u64x2_t*>(nv.chunk_redo + 16 * g);
+    if (!(fl.x | fl.y)) continue;
+    for (uint32_t q = 0; q < 16; ++q) {
+      const uint64_t c = 16 * g + q;
+      if (c >= nv.cr.n_chunks || !((q < 8 ? fl.x >> (8 * q) : fl.y >> (8 * (q - 8))) & 0xFFu)) continue;
+      const uint64_t rank0 = nv.cr.rank0((uint32_t)c);
+      const uint64_t r_lo = (rank0 + 3) >> 2, r_hi = (rank0 + nv.cr.counts[c]) >> 2;
+      for (uint64_t r = r_lo + (tid & 15u); r <= r_hi && r < f.n_records; r += 16) {
+        const uint64_t start = r == 0 ? 0 : f.line_end[4 * r - 1] + 1;
+        if (start / kChunkBytes == c) one(r);
+      }
     }
   }
   tally_flush(t, call);

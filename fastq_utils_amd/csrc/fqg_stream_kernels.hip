@@ -239,12 +239,13 @@ __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uin
 // ABL: ablation mask for tools/kbench (product code instantiates 0): 1 = no byte-class checks,
 // 2 = no staging, 4 = no fetch of the byte after a newline, 8 = no base check, 16 = no quality test
 // NAMES: also capture the header lines that begin in the chunk (NameCapture, fqg_device.h)
-template <uint32_t ABL, bool NAMES = false>
+// NAMES: 0 = no capture, 1 = 64-byte records, 2 = 16-byte digests (fqg_device.h)
+template <uint32_t ABL, int NAMES = 0>
 __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restrict__ img, uint64_t n,
                                                          uint32_t n_chunks, StreamOut o,
                                                          CallState* __restrict__ cs, NameCapture nc = NameCapture{}) {
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
-  static_assert(!NAMES || !(ABL & 7u), "the name capture needs the speculation, the staged entries and the copy");
+  static_assert(NAMES == 0 || !(ABL & 7u), "the name capture needs the speculation, the staged entries and the copy");
   __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
   __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][NAMES ? kCopyRow : (uint32_t)kChunkBytes];
   // (the wave index is uniform: telling the compiler keeps chunk-level values in scalar registers)
@@ -469,7 +470,119 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
   if (!(ABL & 2u)) {
     stage_chunk<ABL>(img, n, cb, chunk, nl, nl2, ex, tot, s_slots[wv], copy, tail, o.stage, interior);
   }
-  if constexpr (NAMES) {
+  if constexpr (NAMES == 2) {
+    // ---- header lines that begin in this chunk -> 16-byte digests: canonical name + hash, four lanes per header ----
+    // The line that starts at v (v = 0: the chunk's first byte, else behind the chunk's v-th newline) has type t0 + v:
+    // headers are every fourth line start from v0 on, so quad q of the wavefront takes the header at v0 + 4 q without a
+    // compaction.  Lane `sub` of a quad looks at name bytes [16 sub, 16 sub + 16) - the bytes behind the '@'.
+    uint32_t hc = kNoCapture;
+    if (found && total <= (uint32_t)kStageCap) {
+      hc = 0;
+      const uint16_t* slots = s_slots[wv];
+      const bool first_is_start = prev == '\n';
+      uint32_t v0 = (0u - t0) & 3u;
+      if (v0 == 0u && !first_is_start) v0 = 4u;
+      const uint32_t sub = (uint32_t)lane & 3u, q = (uint32_t)lane >> 2;
+      const bool casava = nc.fmt == FQG_NAME_CASAVA18;
+      const uint32_t pe_cut = (nc.fmt == FQG_NAME_DEFAULT && nc.is_pe) ? 1u : 0u;
+      for (uint32_t base = 0; v0 + 4u * base <= tot; base += kWave / 4) {
+        const uint32_t j = base + q, vv = v0 + 4u * j;
+        bool is_hdr = vv <= tot;
+        uint32_t at = 0;
+        if (is_hdr && vv > 0) {
+          at = (slots[vv - 1] & 0xFFFu) + 1u;
+          is_hdr = at < (uint32_t)kChunkBytes;
+        }
+        hc += (uint32_t)__builtin_popcountll(__ballot(is_hdr && sub == 0u));
+        if (is_hdr && j < nc.K) {
+          const bool end_known = vv < tot;
+          uint32_t lnm = end_known ? (uint32_t)(slots[vv] & 0xFFFu) - at - 1u : ~0u;  // name bytes in front of the '\n'
+          const bool at_sign = copy[at] == '@';
+          bool ok = true;
+          uint4 x;
+          if (end_known) {
+            __builtin_memcpy(&x, copy + at + 1u + 16u * sub, 16);
+          } else if (cb + at + 1u + kDigestText <= n) {
+            // the line runs into the next chunk (one header in eight at 150 bp): its bytes from the image - the
+            // wavefront next door is loading them anyway - and its length from the '\n' among them, if there is one
+            __builtin_memcpy(&x, img + cb + at + 1u + 16u * sub, 16);
+            const uint32_t m = pack_marks16(eq_bytes(x.x, 0x0A0A0A0Au), eq_bytes(x.y, 0x0A0A0A0Au), eq_bytes(x.z, 0x0A0A0A0Au),
+                                            eq_bytes(x.w, 0x0A0A0A0Au));
+            uint32_t mine = m ? 16u * sub + (uint32_t)__builtin_ctz(m) : ~0u;
+            uint32_t o = dpp0<0xB1, 0xf, 0xf>(mine);  // quad_perm [1,0,3,2]
+            mine = o < mine ? o : mine;
+            o = dpp0<0x4E, 0xf, 0xf>(mine);           // quad_perm [2,3,0,1]
+            lnm = o < mine ? o : mine;
+          } else {
+            x = make_uint4(0, 0, 0, 0);
+            ok = false;
+          }
+          uint32_t nlen = 0, acct = 0;
+          if (casava) {
+            // the name ends at the first blank of the line (src/fastq.c:496-503); "/1" in front of it is dropped
+            const uint32_t m = pack_marks16(eq_bytes(x.x, 0x20202020u), eq_bytes(x.y, 0x20202020u), eq_bytes(x.z, 0x20202020u),
+                                            eq_bytes(x.w, 0x20202020u));
+            uint32_t mine = m ? 16u * sub + (uint32_t)__builtin_ctz(m) : ~0u;
+            uint32_t o = dpp0<0xB1, 0xf, 0xf>(mine);
+            mine = o < mine ? o : mine;
+            o = dpp0<0x4E, 0xf, 0xf>(mine);
+            const uint32_t sp = o < mine ? o : mine;
+            if (sp >= lnm || sp >= kDigestText) ok = false;  // no blank in the line (or none in what the quad sees of it)
+            // the byte two places in front of the blank: with the lane that holds it
+            const uint32_t two = sp - 2u;
+            uint32_t slash = 0;
+            if (ok && sp >= 2u && (two >> 4) == sub) {
+              const uint32_t wsel = (two >> 2) & 3u;
+              const uint32_t wd = wsel == 0u ? x.x : wsel == 1u ? x.y : wsel == 2u ? x.z : x.w;
+              slash = ((wd >> (8u * (two & 3u))) & 0xFFu) == '/' ? 1u : 0u;
+            }
+            slash |= dpp0<0xB1, 0xf, 0xf>(slash);
+            slash |= dpp0<0x4E, 0xf, 0xf>(slash);
+            nlen = acct = ok ? sp - 2u * slash : 0u;
+          } else {
+            // strlen(&hdr[1]) counts the '\n' (src/fastq.c:505-511); a line whose end nobody saw, or one so short that
+            // the name would hold the '\n', is left to the byte-wise path
+            const uint32_t L = lnm + 1u;
+            if (lnm == ~0u || L < 1u + pe_cut) ok = false;
+            const uint32_t l = L - pe_cut;
+            acct = l;
+            nlen = l - 1u;
+            if (nlen > kDigestText) ok = false;
+          }
+          if (nlen > 1023u || acct > 1023u) ok = false;
+          if (!ok) nlen = acct = 0;
+          // the hash: this lane's two words, bytes behind the name zeroed, summed over the quad
+          const uint32_t lo = 16u * sub;
+          const uint32_t k0 = nlen > lo ? nlen - lo : 0u;             // name bytes in this lane's first word and beyond
+          const uint32_t k1 = nlen > lo + 8u ? nlen - lo - 8u : 0u;   // ... in its second word and beyond
+          uint64_t w0 = ((uint64_t)x.y << 32) | x.x, w1 = ((uint64_t)x.w << 32) | x.z;
+          w0 = k0 >= 8u ? w0 : (w0 & ((1ull << (8u * k0)) - 1ull));
+          w1 = k1 >= 8u ? w1 : (w1 & ((1ull << (8u * k1)) - 1ull));
+          // (the multipliers by selection: sub is one of four, and computing name_mul() costs two more 64-bit products)
+          const uint64_t m0 = sub == 0u ? name_mul(0) : sub == 1u ? name_mul(2) : sub == 2u ? name_mul(4) : name_mul(6);
+          const uint64_t m1 = sub == 0u ? name_mul(1) : sub == 1u ? name_mul(3) : sub == 2u ? name_mul(5) : name_mul(7);
+          uint64_t part = w0 * m0 + w1 * m1;
+          uint32_t plo = (uint32_t)part, phi = (uint32_t)(part >> 32);
+          uint64_t oth = ((uint64_t)dpp0<0xB1, 0xf, 0xf>(phi) << 32) | dpp0<0xB1, 0xf, 0xf>(plo);
+          part += oth;
+          plo = (uint32_t)part;
+          phi = (uint32_t)(part >> 32);
+          oth = ((uint64_t)dpp0<0x4E, 0xf, 0xf>(phi) << 32) | dpp0<0x4E, 0xf, 0xf>(plo);
+          part += oth;
+          if (sub == 0u) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 dg;
+            dg.x = name_fin(name_seed(nlen) + part);
+            dg.y = (unsigned long long)(nlen | (acct << 10) | (vv << 20) | (at_sign ? kDigestAt : 0u) | (ok ? kDigestOk : 0u));
+            *reinterpret_cast<u64x2*>(nc.recs + ((uint64_t)chunk * nc.K + j) * kDigestWords) = dg;
+          }
+        }
+      }
+      if (hc >= kNoCapture) hc = kNoCapture - 1u;
+    }
+    if (lane == 0) nc.hcount[chunk] = (uint16_t)hc;
+  }
+  if constexpr (NAMES == 1) {
     // ---- header lines that begin in this chunk -> 64-byte records (NameCapture) ----
     // Line starts: the chunk's first byte when the byte in front of it is a '\n' (v = 0), and the byte behind the
     // chunk's v-th newline unless that newline is the chunk's last byte; the line that starts at v has type t0 + v.

@@ -256,7 +256,7 @@ void run_index_input(Input& in, const char* path, int is_pe, Stats& S, IndexedFi
     probe_piece(pr, in.data(), in.size(), is_pe);
     fqg_validate_result r;
     LIB(fqg_validate(g_ctx, S.acc1, in.data(), in.size(), FQG_MEM_HOST, in.final() ? 1 : 0, &pr.st,
-                     FQG_VALIDATE_COUNT_TWICE | FQG_VALIDATE_NAMES | in.vflags(), &r));
+                     FQG_VALIDATE_COUNT_TWICE | (F.lookups ? FQG_VALIDATE_NAMES : FQG_VALIDATE_NAME_DIGESTS) | in.vflags(), &r));
     if (!F.index) {
       // sized from the first piece: a plain file holds about (its bytes / this piece's mean record) names - the table
       // then never has to be rebuilt at twice the size

@@ -145,6 +145,12 @@ typedef struct {
                                        single-pass framing also copies every header line into a 64-byte record while the
                                        bytes are on the chip, and the index calls work from those records instead of going
                                        back to the image.  Results are the same with or without it. */
+#define FQG_VALIDATE_NAME_DIGESTS 256u /* FQG_VALIDATE_NAMES for an index that will only be tested for uniqueness
+                                       (fqg_index_expect_lookups(index, 0): fastq_info on ONE file, src/fastq_info.c:289-300):
+                                       the single-pass framing canonicalises and hashes every header line itself (under the
+                                       `state` of this call) and keeps 16 bytes per header instead of 64.  An insert into any
+                                       other index, and a look-up, do not use digests: they read the names through the
+                                       line index.  Results are the same with or without it. */
 #define FQG_VALIDATE_REFRAMED 64u    /* the host has already cut the image at the reference's gzgets() limits
                                        (src/fastq.c:249-253; fastq_utils_amd/host/fq_input.h, Reframer): a piece that gzgets
                                        would return without its newline is followed by "\0\n" - the NUL the reference's
@@ -355,6 +361,33 @@ int fqg_barcodes_output(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes
  * the same device buffers, wait for them by themselves. */
 int fqg_barcodes_output_begin(fqg_ctx *ctx, int which, void *host_dst, uint64_t nbytes);
 int fqg_barcodes_output_wait(fqg_ctx *ctx);
+
+/* ---- FASTQ -> (cell, UMI) without the BAM round trip ---------------------------------------
+ * In the reference's pipeline (sh/fastq2bam:116-273) the barcodes of a kept read travel inside its name
+ * (add_tags2readname, src/fastq_pre_barcodes.c:192-216) through the aligner into a BAM file, where bam_add_tags parses
+ * them out again (get_barcodes, src/bam_add_tags.c:43-99) as CR / RX tags, which bam_umi_count packs with char2uint_64
+ * (src/bam_umi_count.c:364-382).  None of that depends on the alignment.  fqg_barcodes_census - called behind the
+ * fqg_barcodes_transform of the same batch, with the same frames / states / first_record / params and that call's
+ * n_done - appends, in device memory, one (cell, UMI) pair of packed values per read the transform kept and that
+ * bam_umi_count would count: a read without a UMI has none (src/bam_umi_count.c:960), a read without a cell barcode
+ * has the cell 0 (char2uint_64 of a missing tag), a value that holds a '_' ends get_barcodes (no tags: no pair).
+ * fqg_census_finish sorts the pairs by (cell, UMI) and makes one line per cell, in ascending order of the packed cell:
+ * its reads and its distinct UMIs - bam_umi_count's per-cell totals before a gene tag exists. */
+typedef struct fqg_census fqg_census;
+typedef struct {
+  uint64_t cell, reads, umis;
+} fqg_census_cell;
+int fqg_census_create(fqg_ctx *ctx, fqg_census **out);
+void fqg_census_destroy(fqg_census *census);
+int fqg_barcodes_census(fqg_ctx *ctx, fqg_census *census, const fqg_frame *const frames[6], const fqg_file_state states[6],
+                        const uint64_t first_record[6], const fqg_barcode_params *params, uint64_t n_done,
+                        uint64_t *n_added);
+int fqg_census_finish(fqg_ctx *ctx, fqg_census *census, uint64_t *n_pairs, uint64_t *n_cells);
+/* the lines / the pairs (sorted once the census is finished) copied to host memory; at most cap of them */
+int fqg_census_cells(fqg_ctx *ctx, fqg_census *census, fqg_census_cell *out, uint64_t cap);
+int fqg_census_pairs(fqg_ctx *ctx, fqg_census *census, uint64_t *cells, uint64_t *umis, uint64_t cap);
+/* the pairs where they live: device pointers to the packed cells (which = 0) / UMIs (1), n_pairs of each */
+const void *fqg_census_device_pairs(const fqg_census *census, int which);
 
 /* ---- whitelist membership of a barcode (BASELINE configs[2]: "known_cells whitelist") ------------------
  * The cell barcode that fastq_pre_barcodes cuts out of a read is what bam_umi_count later packs with char2uint_64

@@ -218,3 +218,72 @@ def test_the_capture_is_what_runs():
                     acc.close()
     finally:
         os.environ.pop("FQGPU_STREAM_MIN", None)
+
+
+@pytest.mark.parametrize("build", ["cas", "lds", "lds2"])
+@pytest.mark.parametrize("style", ["casava", "slash", "int", "nosuffix"])
+def test_digests_give_what_records_and_the_line_index_give(style, build):
+    """FQG_VALIDATE_NAME_DIGESTS (the streaming pass canonicalises and hashes the headers itself, 16 bytes per header):
+    an index that keeps no name records takes its names from them; finding, entries and accounted bytes are those of the
+    capture records and of the line index - on regular names, on names of every kind, with a duplicate, with a wrong
+    header - and an index that will be asked ignores the digests.  build: the digests through k_names_pass (one CAS per
+    name), or the table built part by part in LDS (fqg_names_build_kernels.hip) with one level of buckets / two"""
+    os.environ["FQGPU_STREAM_MIN"] = "256"
+    os.environ["FQGPU_NAMES_BUILD"] = "0" if build == "cas" else "1"
+    try:
+        rng = np.random.default_rng(21)
+        n = 12000
+        expect = 2 * n if build != "lds2" else 1 << 21  # (2^22 slots and more: parts behind two levels of buckets)
+        if style == "casava":
+            recs = [r for r in names_of_every_kind(np.random.default_rng(4), n, 1)]
+        else:
+            img0 = fuzz.make_fastq(rng, n, 30, 150, style)
+            l0 = img0.split(b"\n")
+            recs = [b"\n".join(l0[4 * i:4 * i + 4]) + b"\n" for i in range(n)]
+        clean = b"".join(recs)
+        k = int(rng.integers(0, n - 10))
+        dup = b"".join(recs[:n - 5] + [recs[k]] + recs[n - 5:])
+        three = b"".join(recs[:n // 2] + [recs[k // 2]] + recs[n // 2:] + [recs[k // 2]])
+        wrong = b"".join(recs[:k] + [b"X" + recs[k][1:]] + recs[k + 1:])
+        with fq.Context(0) as ctx:
+            for image in (clean, dup, three, wrong):
+                st = fq.abi.probe_first_record(image, False)
+                got = []
+                for flags, lookups in ((fq.abi.VALIDATE_NAME_DIGESTS, False), (fq.abi.VALIDATE_NAMES, False), (0, False),
+                                       (fq.abi.VALIDATE_NAME_DIGESTS, True)):
+                    r = ctx.validate(image, None, st, flags=fq.abi.VALIDATE_NO_STATS | flags)
+                    idx = ctx.name_index(expect)
+                    if not lookups:
+                        idx.expect_lookups(False)
+                    ir = idx.insert_unique(st)
+                    cap = idx.names_captured()
+                    if r["path"] == 3 and flags == fq.abi.VALIDATE_NAME_DIGESTS and not lookups:
+                        assert cap > 0.5 * n, (cap, n)  # the digests are what ran
+                    if flags == 0 or lookups:
+                        assert cap == 0, cap  # (digests hold no bytes: an index that keeps names reads the lines)
+                    got.append((ir["code"], ir["record"], ir["n_entries"], ir["index_mem"]))
+                    idx.close()
+                assert got[0] == got[1] == got[2] == got[3], (style, got)
+            # two frames into one index: the second one's parts are merged with what the table holds; a name of the
+            # first frame again in the second is the second frame's finding
+            half = b"".join(recs[:n // 2])
+            rest_clean = b"".join(recs[n // 2:])
+            rest_dup = b"".join(recs[n // 2:n - 7] + [recs[k // 2]] + recs[n - 7:])
+            st = fq.abi.probe_first_record(half, False)
+            for second in (rest_clean, rest_dup):
+                got = []
+                for flags in (fq.abi.VALIDATE_NAME_DIGESTS, 0):
+                    idx = ctx.name_index(expect)
+                    idx.expect_lookups(False)
+                    out = []
+                    for image in (half, second):
+                        ctx.validate(image, None, st, final=True, flags=fq.abi.VALIDATE_NO_STATS | flags)
+                        ir = idx.insert_unique(st)
+                        out.append((ir["code"], ir["record"], ir["n_entries"], ir["index_mem"]))
+                    got.append(out)
+                    idx.close()
+                assert got[0] == got[1], (style, got)
+                assert (got[0][1][0] != 0) == (second is rest_dup), got
+    finally:
+        os.environ.pop("FQGPU_STREAM_MIN", None)
+        os.environ.pop("FQGPU_NAMES_BUILD", None)
