@@ -93,6 +93,7 @@ def extras_summary(extras):
         "pre_barcodes_200M_kernels_ms": _get(e, "pre_barcodes_extra", "kernels_ms"),
         "pre_barcodes_GBps": _get(e, "pre_barcodes_extra", "achieved_GBps_kernels"),
         "pre_barcodes_generic_50M_ms": _get(e, "pre_barcodes_extra", "generic_file_set", "kernels_ms"),
+        "census_200M_ms": _get(e, "pre_barcodes_extra", "census_stage", "census_kernel_ms"),
         "filter_n_ms": _get(e, "filters_extra", "filter_n", "kernels_ms"),
         "trim_poly_at_ms": _get(e, "filters_extra", "trim_poly_at", "kernels_ms"),
         "umi_count_kernels_ms": _get(e, "umi_count_extra", "kernels_ms"),
@@ -112,6 +113,7 @@ def headline_line(out, extras=None, final=True):
     as ONE line of printable ASCII no longer than HEADLINE_MAX_BYTES.  Anything that would push it over the limit is
     dropped from the optional end (extras, then host_fed details), never from the contract's keys."""
     keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "traffic_source",
+                 "frac_on_measured_bytes", "step_frac_wall", "algorithmic_bytes_per_step", "dominant_ms_per_step",
                  "algorithmic_bytes_per_launch", "avg_launch_ms", "launches", "all_kernels_ms_per_step",
                  "pipeline_achieved", "pipeline_frac", "launches_per_step", "kernels_ms_per_step")
     keep_cpu = ("value", "unit", "cores", "kind", "sample", "seconds", "ok")
@@ -383,6 +385,53 @@ def barcodes_extra(ctx, fq, torch, dev, n_pairs, programs=True):
         wl.close()
     except Exception as e:
         out["whitelist_stage"] = {"error": repr(e)[:300]}
+    # FASTQ -> (cell, UMI) without the BAM round trip (fqg_barcodes_census): the packed (cell, UMI) pair of
+    # every read the transform above kept - what bam_add_tags + bam_umi_count make of the tags in its name - sorted, and one
+    # line per cell (reads, distinct UMIs).  Checked at full size by its invariants, on the first 2 000 pairs against the
+    # composition of the three oracles (names of the oracle's SAM lines -> get_barcodes -> char2uint_64).
+    try:
+        kw = dict(umi=(A.INDEX1, 16, 10), cell=(A.INDEX1, 0, 16), phred=33, min_qual=10, sam=True)
+        torch.cuda.empty_cache()
+        z = ctx.census()
+        ctx.profile(True)
+        ctx.profile_reset()
+        ctx.synchronize()
+        tc0 = time.perf_counter()
+        added = ctx.barcodes_census(z, frames, states, r["n_done"], **kw)
+        n_cp, n_cc = z.finish()
+        ctx.synchronize()
+        cwall = time.perf_counter() - tc0
+        cms = {k: v[1] / max(1, v[0]) for k, v in ctx.profile_read().items() if ("census" in k) and v[0] > 0}
+        ctx.profile(False)
+        lines = z.cells(n_cc)
+        inv = (added == kept and n_cp == kept and int(lines[:, 1].sum()) == kept and bool((lines[:, 2] <= lines[:, 1]).all())
+               and bool((lines[1:, 0] > lines[:-1, 0]).all()))
+        z.close()
+        # the first m pairs again, as a batch of their own, against the oracles' composition
+        from oracle import bam_tags_oracle as bto
+        from oracle import umi_oracle as uo
+        r_small = ctx.barcodes_transform(frames, states, m, **kw)
+        z2 = ctx.census()
+        ctx.barcodes_census(z2, frames, states, r_small["n_done"], **kw)
+        p2, c2 = z2.finish()
+        ce, um = z2.pairs(p2)
+        z2.close()
+        want_pairs = []
+        for ln in body.splitlines():
+            qn = ln.split("\t")[0].encode("latin-1") + b"\0"
+            okb, cellb, umib, _ = bto.get_barcodes(qn, 0, len(qn))
+            if okb and umib:
+                want_pairs.append((uo.char2uint_64(cellb), uo.char2uint_64(umib)))
+        out["census_stage"] = {
+            "what": "fqg_barcodes_census + fqg_census_finish: (cell, UMI) of every kept read, sorted, one line per cell (SURVEY 8f-3)",
+            "pairs": int(n_cp), "cells": int(n_cc), "kernel_ms": cms, "wall_ms": cwall * 1e3,
+            "census_kernel_ms": cms.get("k_bc_census"), "Mpairs_per_s_census_kernel": (n_pairs / (cms["k_bc_census"] * 1e-3) / 1e6) if cms.get("k_bc_census") else None,
+            "properties_hold": bool(inv),
+            "first_2000_pairs_identical_to_oracles": sorted(zip(ce.tolist(), um.tolist())) == sorted(want_pairs) and len(want_pairs) > 0,
+        }
+        run()  # (the status bytes and the SAM text of the whole batch again, for what follows)
+    except Exception as e:
+        out["census_stage"] = {"error": repr(e)[:300]}
     for f in frames.values():
         f.release()
     # a file set without a specialised kernel (three barcode sources, as the reference's pre3 fixture has them): the
@@ -1516,9 +1565,21 @@ def main():
         kernels = {k: v for k, v in prof.items() if k.startswith("k_") and v[0] > 0}
         dom = max(kernels, key=lambda k: kernels[k][1])
         launches, total_ms = kernels[dom]
+        algo_bytes = n * (R + ALGO_BYTES_PER_READ_EXTRA)  # per step: one batch
+        dom_label = dom
+        if dom in ("k_stream_pass1", "k_stream_pass1_lines") and "k_stream_pass1_lines" in kernels:
+            # the streaming pass in parts (round 6): pass 1 of a step is one k_stream_pass1 launch + the k_stream_pass1_lines
+            # launches, which carry the line workers of the part before beside their chunks.  Priced together: every
+            # launch processes its share of the step's bytes, so bytes per launch / average launch duration is the
+            # step's bytes over the sum of the launches' durations.
+            a1, b1 = kernels.get("k_stream_pass1", (0, 0.0)), kernels["k_stream_pass1_lines"]
+            launches, total_ms = a1[0] + b1[0], a1[1] + b1[1]
+            dom = "k_stream_pass1"
+            dom_label = (f"k_stream_pass1 in {launches // max(1, a.steps)} launches per step: 1 x k_stream_pass1 + "
+                         f"{b1[0] // max(1, a.steps)} x k_stream_pass1_lines (pass 1 of a part beside the line workers of the part before)")
         avg_ms = total_ms / launches
-        algo_bytes = n * (R + ALGO_BYTES_PER_READ_EXTRA)  # per launch: one batch
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        bytes_per_launch = algo_bytes * a.steps / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         all_ms = sum(v[1] for v in kernels.values()) / a.steps
         traffic, traffic_src = committed_traffic(dom, n, a.read_len, R)
         out = {
@@ -1540,13 +1601,19 @@ def main():
                 "reads_per_gpu": n, "read_len": a.read_len, "record_bytes": R, "path": res["path"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": dom_label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms,
+                # the same kernel priced on the bytes the counters saw instead of SURVEY 8d's algorithmic figure (which
+                # counts a 32-byte descriptor per record that a call which only validates no longer writes)
+                "frac_on_measured_bytes": (traffic / (total_ms / a.steps * 1e-3) / HBM_PEAK_GBS) if traffic else None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_step": algo_bytes, "dominant_ms_per_step": total_ms / a.steps,
                 "all_kernels_ms_per_step": all_ms,
                 "pipeline_achieved": algo_bytes / (all_ms * 1e-3) / 1e9,
                 "pipeline_frac": algo_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # ... and by the wall clock of the timed steps (host gaps included): what the driver's clock sees
+                "step_frac_wall": algo_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
                 "launches": launches,
                 "launches_per_step": sum(v[0] for v in kernels.values()) / a.steps,
                 "kernels_ms_per_step": {k: v[1] / a.steps for k, v in kernels.items()},

@@ -64,6 +64,11 @@ inline bool measured_wrong(int ablate) {
   return false;
 #endif
 }
+// a tuning knob that changes HOW a result is computed, never the result (A/B runs)
+inline int env_int_early(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 inline int measure_int(const char* name) {
 #ifdef FQG_MEASURE
   const char* e = getenv(name);
@@ -113,6 +118,10 @@ struct fqg_ctx {
     unsigned grid = 0, grid_f = 0;
     LinesArgs args;
   } lazy;
+  // the streaming pass in parts (k_stream_pass1_lines): the line workers' statistics until the image has passed
+  AccState* pipe_acc = nullptr;
+  unsigned long long* pipe_hist = nullptr;
+  bool pipe_dirty = false;  // a parted pass left without its merge (an error in between): cleared by the next one
   uint64_t bc_status_valid = 0;  // iterations of the last fqg_barcodes_transform whose status bytes stand (fqg_barcodes_census)
   DevBuf build_keys[2], build_cursor, build_spill;  // the name table built in LDS (fqg_names_build_kernels.hip)
   DevBuf name_recs;   // streaming path with FQG_VALIDATE_NAMES: 64-byte header records, K per chunk (NameCapture)
@@ -359,6 +368,8 @@ void fqg_close(fqg_ctx* c) {
   release(c->queue);
   release(c->redo);
   release(c->lines_slow);
+  if (c->pipe_acc) (void)hipFree(c->pipe_acc);
+  if (c->pipe_hist) (void)hipFree(c->pipe_hist);
   release(c->build_keys[0]);
   release(c->build_keys[1]);
   release(c->build_cursor);
@@ -721,7 +732,7 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
   {
     ProfScope ps(c, "k_stream_boot");
     const uint32_t span = (uint32_t)std::min<uint64_t>(kStreamBootBytes, nbytes & ~255ull);
-    hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBlock), 0, c->stream, d_img, span, c->d_cs);
+    hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBootBlock), 0, c->stream, d_img, span, c->d_cs);
   }
   NameCapture nc{};
   if (want_names) {
@@ -742,28 +753,98 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     nc.hcount = (uint16_t*)c->name_hcount.p;
     c->names.k_shift = shift;
   }
-  {
-    ProfScope ps(c, want_names == 2 ? "k_stream_pass1(digests)" : want_names ? "k_stream_pass1(names)" : "k_stream_pass1");
-    if (want_names == 2)
-      hipLaunchKernelGGL((k_stream_pass1<0u, 2>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
-                         n_chunks, so, c->d_cs, nc);
-    else if (want_names)
-      hipLaunchKernelGGL((k_stream_pass1<0u, 1>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
-                         n_chunks, so, c->d_cs, nc);
-    else
-      hipLaunchKernelGGL((k_stream_pass1<0u, 0>), dim3((n_chunks + 3) / 4), dim3(kBlock), 0, c->stream, d_img, nbytes,
-                         n_chunks, so, c->d_cs, nc);
+  // Large images that only want to be validated take the pass in PARTS: pass 1 of part p shares its launch with the line
+  // workers of part p - 1 (k_stream_pass1_lines), whose statistics wait in accumulators of the context until the whole
+  // image has passed without a flag that sends it to the two-pass path.  FQGPU_STREAM_PARTS=1: one launch, as before.
+  // (read per call: tests and A/B runs switch them inside one process)
+  const int parts_env = env_int_early("FQGPU_STREAM_PARTS", 3);
+  const int workers_env = env_int_early("FQGPU_STREAM_LINE_WORKERS", 1);  // line-worker workgroups per CU
+  const uint32_t parts_min_spans = (uint32_t)std::max(env_int_early("FQGPU_STREAM_PARTS_MIN_SPANS", 24), 1);  // (16 MiB each)
+  static const bool old_pass2_early = getenv("FQGPU_STREAM_PASS2_OLD") != nullptr;
+  uint32_t n_parts = (!want_names && !want_index && !old_pass2_early && rd.acc && n_spans >= parts_min_spans)
+                         ? (uint32_t)std::min(std::max(parts_env, 1), 4) : 1u;
+  n_parts = std::min(n_parts, n_spans);
+  LinesArgs PA{};  // what the line workers inside the pass-1 launches go by (the rest comes from the call state)
+  uint64_t todo_steps_cap = 0;
+  if (n_parts > 1) {
+    if (!c->pipe_hist) {
+      if (!c->pipe_acc) HIP_TRY(c, hipMalloc((void**)&c->pipe_acc, sizeof(AccState)));
+      HIP_TRY(c, hipMalloc((void**)&c->pipe_hist, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH));
+      HIP_TRY(c, hipMemsetAsync(c->pipe_hist, 0, sizeof(unsigned long long) * FQG_MAX_READ_LENGTH, c->stream));
+      hipLaunchKernelGGL(k_acc_scratch_reset, dim3(1), dim3(1), 0, c->stream, c->pipe_acc);
+      c->pipe_dirty = false;
+    }
+    if (c->pipe_dirty) {
+      hipLaunchKernelGGL(k_acc_merge, dim3(64), dim3(kBlock), 0, c->stream, c->pipe_acc, c->pipe_hist, (AccState*)nullptr,
+                         (unsigned long long*)nullptr, 1);
+      hipLaunchKernelGGL(k_acc_scratch_reset, dim3(1), dim3(1), 0, c->stream, c->pipe_acc);
+    }
+    c->pipe_dirty = true;
+    // one mark per step for the general line kernel: every line has a byte, 512 lines a step
+    todo_steps_cap = nbytes / (uint64_t)(4 * kWave * kLinesPer) + 8;
+    if ((rc = ensure(c, c->lines_slow, (size_t)todo_steps_cap + 4))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->lines_slow.p, 0, (size_t)todo_steps_cap, c->stream));
+    PA.img = d_img;
+    PA.n = nbytes;
+    PA.cr.counts = (const uint32_t*)c->tile_counts.p;
+    PA.cr.local = (const uint32_t*)c->tile_local.p;
+    PA.cr.span_excl = (const unsigned long long*)c->span_sums.p;
+    PA.stage = (const uint16_t*)c->stage.p;
+    PA.line_end = nullptr;
+    PA.line_cap = ~0ull;
+    PA.suspect_bits = sm.bits;
+    PA.suspect_cap = sm.cap;
+    PA.flags = sm.flags;
+    PA.space = rd.space;
+    PA.weight = rd.weight;
+    PA.acc = c->pipe_acc;
+    PA.hist = c->pipe_hist;
+    PA.ablate = 0;
+    PA.no_index = 1u;
+    PA.index_only = 0u;
+    PA.keep_from = ~0ull;
   }
-  {
-    ProfScope ps(c, "k_scan");
-    hipLaunchKernelGGL(k_scan_a, dim3(n_spans), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
-                       n_chunks, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p);
-    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
-                       n_spans, d_img, nbytes, c->d_cs);
+  for (uint32_t part = 0; part < n_parts; ++part) {
+    const uint32_t span_lo = (uint32_t)((uint64_t)n_spans * part / n_parts), span_hi = (uint32_t)((uint64_t)n_spans * (part + 1) / n_parts);
+    const uint32_t chunk_lo = span_lo * kScanSpan, chunk_hi = std::min<uint32_t>(n_chunks, span_hi * kScanSpan);
+    {
+      ProfScope ps(c, want_names == 2 ? "k_stream_pass1(digests)" : want_names ? "k_stream_pass1(names)" : part ? "k_stream_pass1_lines" : "k_stream_pass1");
+      const unsigned blocks = (chunk_hi - chunk_lo + 3) / 4;
+      if (want_names == 2)
+        hipLaunchKernelGGL((k_stream_pass1<0u, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks, so, c->d_cs, nc);
+      else if (want_names)
+        hipLaunchKernelGGL((k_stream_pass1<0u, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks, so, c->d_cs, nc);
+      else if (part == 0)
+        hipLaunchKernelGGL((k_stream_pass1<0u, 0>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, chunk_hi, so, c->d_cs, nc);
+      else {
+        const unsigned workers = (unsigned)c->cu_count * (unsigned)std::min(std::max(workers_env, 1), 4);
+        hipLaunchKernelGGL(k_stream_pass1_lines, dim3(workers + blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, chunk_lo, chunk_hi, so,
+                           c->d_cs, PA, (uint8_t*)c->lines_slow.p, workers, part - 1);
+      }
+    }
+    {
+      ProfScope ps(c, "k_scan");
+      hipLaunchKernelGGL(k_scan_a, dim3(span_hi - span_lo), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
+                         n_chunks, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p, span_lo);
+      hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
+                         span_hi, d_img, nbytes, c->d_cs, span_lo, part);
+    }
   }
+  // (leaving the parted pass without its statistics: the scratch is cleared, nothing reaches the caller's accumulator)
+  auto drop_parted = [&]() {
+    if (n_parts > 1) {
+      hipLaunchKernelGGL(k_acc_merge, dim3(64), dim3(kBlock), 0, c->stream, c->pipe_acc, c->pipe_hist, (AccState*)nullptr,
+                         (unsigned long long*)nullptr, 1);
+      hipLaunchKernelGGL(k_acc_scratch_reset, dim3(1), dim3(1), 0, c->stream, c->pipe_acc);
+      c->pipe_dirty = false;
+    }
+  };
   HIP_TRY(c, hipMemcpyAsync(c->h_cs, c->d_cs, sizeof(CallState), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->h_cs->flags & (kFlagNul | kFlagCr | kFlagHigh | kFlagStageOverflow)) return 1;
+  if (c->h_cs->flags & (kFlagNul | kFlagCr | kFlagHigh | kFlagStageOverflow)) {
+    drop_parted();
+    return 1;
+  }
   out->n_newlines = c->h_cs->n_newlines;
   out->last_nl = c->h_cs->last_byte_is_nl != 0;
   out->img_flags = 0;
@@ -818,6 +899,13 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     A.index_only = 0u;
     A.keep_from = limit >= 8 ? limit - 8 : 0;
     c->lazy.pending = false;
+    // the steps the line workers inside the pass-1 launches have done (the parted pass): the launches below begin behind
+    // them, and every line kernel of such a call adds to the context's accumulators, merged at the end
+    const uint64_t done_steps = n_parts > 1 ? c->h_cs->lines_done_steps : 0;
+    if (n_parts > 1) {
+      A.acc = c->pipe_acc;
+      A.hist = c->pipe_hist;
+    }
     {
       ProfScope ps(c, "k_stream_lines");
       const uint64_t groups = (n_lines_all + 4 * kWave - 1) / (4 * kWave);
@@ -836,25 +924,50 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
       const double nl_per_chunk = (double)out->n_newlines / (double)std::max<uint32_t>(n_chunks, 1);
       c->lazy.grid = grid;
       c->lazy.fast = false;
-      if (general_only || nl_per_chunk > 60.0 || nl_per_chunk < 32.0) {
+      if (done_steps == 0 && (general_only || nl_per_chunk > 60.0 || nl_per_chunk < 32.0)) {
         hipLaunchKernelGGL(k_stream_lines<false>, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)nullptr);
       } else {
         // the steps of ordinary records in the kernel without a search, what it marks in the general one behind it
         const uint64_t n_steps = (groups + kLinesPer - 1) / kLinesPer;
-        if ((rc = ensure(c, c->lines_slow, (size_t)n_steps + 4))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->lines_slow.p, 0, (size_t)n_steps, c->stream));
+        if (n_parts > 1 && n_steps + 4 > todo_steps_cap) return fail(c, FQG_ERR_STATE, "streaming pass: more steps than lines");
+        if (n_parts == 1) {
+          if ((rc = ensure(c, c->lines_slow, (size_t)n_steps + 4))) return rc;
+          HIP_TRY(c, hipMemsetAsync(c->lines_slow.p, 0, (size_t)n_steps, c->stream));
+        }
         if (!c->lines_fast_per_cu) {
           int nb = 0;
           if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_stream_lines_fast), kBlock, 0) != hipSuccess || nb < 1)
             nb = 4;
           c->lines_fast_per_cu = nb;
         }
-        const unsigned grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
-        hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, c->stream, A, (uint8_t*)c->lines_slow.p);
+        const unsigned grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps - std::min(done_steps, n_steps) + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
+        if (done_steps && !lazy) {
+          // the index is wanted after all (pass 1 queued byte positions): the stores of the steps that are done
+          LinesArgs I = A;
+          I.index_only = 1u;
+          I.acc = nullptr;
+          I.hist = nullptr;
+          I.step_lo = 0;
+          I.step_hi = done_steps;
+          const unsigned grid_i = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((done_steps + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
+          hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_i), dim3(kBlock), 0, c->stream, I, (uint8_t*)c->lines_slow.p);
+        }
+        LinesArgs F = A;
+        F.step_lo = done_steps;
+        F.step_hi = 0;
+        hipLaunchKernelGGL(k_stream_lines_fast, dim3(grid_f), dim3(kBlock), 0, c->stream, F, (uint8_t*)c->lines_slow.p);
         hipLaunchKernelGGL(k_stream_lines<true>, dim3(grid), dim3(kBlock), 0, c->stream, A, (const uint8_t*)c->lines_slow.p);
-        c->lazy.grid_f = grid_f;
+        c->lazy.grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
         c->lazy.fast = true;
       }
+    }
+    if (n_parts > 1) {
+      ProfScope ps(c, "k_acc_merge");
+      hipLaunchKernelGGL(k_acc_merge, dim3(64), dim3(kBlock), 0, c->stream, c->pipe_acc, c->pipe_hist, rd.acc, rd.hist, 0);
+      hipLaunchKernelGGL(k_acc_scratch_reset, dim3(1), dim3(1), 0, c->stream, c->pipe_acc);
+      c->pipe_dirty = false;
+      A.acc = rd.acc;
+      A.hist = rd.hist;
     }
     if (lazy) {
       c->lazy.pending = true;
@@ -1426,7 +1539,7 @@ int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_s
   {
     ProfScope ps(c, "k_names_build_scatter0");
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_slots + kBuildTile - 1) / kBuildTile, (uint64_t)c->cu_count * 8));
-    hipLaunchKernelGGL(k_build_scatter<0>, dim3(grid), dim3(kBlock), 0, c->stream, fv, c->names, record_base, mask, L0,
+    hipLaunchKernelGGL(k_build_scatter<0>, dim3(grid), dim3(kBuildThreads), 0, c->stream, fv, c->names, record_base, mask, L0,
                        (const BuildKey*)nullptr, (const unsigned int*)nullptr, 0ull, c->d_icall);
   }
   const BuildKey* part_keys = L0.out;
@@ -1436,7 +1549,7 @@ int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_s
     BuildLevel L1{(BuildKey*)c->build_keys[1].p, cur1, cap1, part_log, bits1};
     ProfScope ps(c, "k_names_build_scatter1");
     const unsigned tiles = (unsigned)((cap0 + kBuildTile - 1) / kBuildTile);
-    hipLaunchKernelGGL(k_build_scatter<1>, dim3(tiles, 1u << bits0), dim3(kBlock), 0, c->stream, fv, c->names, record_base, mask, L1,
+    hipLaunchKernelGGL(k_build_scatter<1>, dim3(tiles, 1u << bits0), dim3(kBuildThreads), 0, c->stream, fv, c->names, record_base, mask, L1,
                        (const BuildKey*)L0.out, (const unsigned int*)cur0, cap0, c->d_icall);
     part_keys = L1.out;
     part_count = cur1;

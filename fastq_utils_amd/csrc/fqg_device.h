@@ -83,18 +83,25 @@ constexpr uint32_t kDigestWords = 2;
 constexpr uint32_t kDigestText = 64;        // name bytes the four lanes of a header look at
 constexpr uint32_t kDigestAt = 1u << 29, kDigestOk = 1u << 30;
 
-// The hash of a name (round 6): H = fin(seed(n) + sum over the name's 8-byte words w_k of w_k * M_k), zero bytes behind
-// the name.  A SUM, so that the words can be taken in any order and by different lanes - the streaming pass hashes a
-// header with four lanes of 16 bytes each while the chunk is in LDS (name digests, fqg_stream_kernels.hip) - and a word
-// of zeros adds nothing, so that nobody has to know where the last word is.  The multipliers are odd: two names that
-// differ in one word never share a sum.  (Rounds 1 - 5 chained a multiply per word: eight dependent 64-bit multiplies
-// on one lane.)  Equality is decided on the name BYTES wherever this value is used; it chooses a slot and a tag.
+// The hash of a name (round 6): H = fin(seed(n) + sum over the name's 8-byte words (lo_k, hi_k) of
+// (lo_k + A_k) * (hi_k + B_k)), zero bytes behind the name, the words that hold at least one name byte (8 k < n) - the NH
+// construction: ONE 32 x 32 -> 64 multiply-add per eight bytes.  A SUM, so that the words can be taken in any order and
+// by different lanes: the streaming pass hashes a header with four lanes of 16 bytes each while the chunk is in LDS
+// (name digests, fqg_stream_kernels.hip).  What a multiply costs decides the form: v_mul_lo_u32 / v_mad_u64_u32 issue
+// at a quarter of the rate and a 64 x 64 product is three of them (rounds 1 - 5 chained one per word, eight dependent
+// on one lane; the first form of this round - w_k * M_k with 64-bit M_k - was nine quarter-rate operations per lane of
+// pass 1, 0.6 ms of its 10).  Equality is decided on the name BYTES wherever this value is used: it only chooses a
+// slot and a tag.
 __host__ __device__ constexpr uint64_t name_mul(uint32_t k) {
   return (0x9E3779B97F4A7C15ull + (uint64_t)k * 0xD1B54A32D192ED03ull) | 1ull;
 }
-// (what a 64-bit multiply costs decides the rest: v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of the rate, a 64 x 64
-// product is three of them - the seed and the final mix are made of 32 x 32 -> 64 products, one and two)
-__device__ __forceinline__ uint64_t name_seed(uint32_t n) { return 0x2545F4914F6CDD1Dull ^ ((uint64_t)n * 0x9E3779B1u); }
+__host__ __device__ constexpr uint32_t name_key_a(uint32_t k) { return (uint32_t)name_mul(k); }
+__host__ __device__ constexpr uint32_t name_key_b(uint32_t k) { return (uint32_t)(name_mul(k) >> 32); }
+// word k of a name (its bytes 8 k .. 8 k + 7, zero behind the name) into the sum
+__device__ __forceinline__ uint64_t name_word(uint64_t sum, uint64_t w, uint32_t k) {
+  return sum + (uint64_t)((uint32_t)w + name_key_a(k)) * (uint64_t)((uint32_t)(w >> 32) + name_key_b(k));
+}
+__device__ __forceinline__ uint64_t name_seed(uint32_t n) { return 0x2545F4914F6CDD1Dull + (uint64_t)n; }
 __device__ __forceinline__ uint64_t name_fin(uint64_t h) {
   const uint32_t hi = (uint32_t)(h >> 32), t = (uint32_t)h ^ hi;  // (the low bits of a sum of products are its weak ones)
   const uint64_t p = (uint64_t)t * 0xD6E8FEB9u, q = (uint64_t)hi * 0x85EBCA6Bu;
@@ -117,6 +124,10 @@ struct CallState {
   unsigned int boot_lines;            // streaming pass: newlines in the boot window (mean record size -> NameCapture::K)
   unsigned int pad_;
   unsigned long long trunc_record;    // frame-only images: min record whose 2nd, 3rd or 4th line starts with NUL
+  // the streaming pass in parts (k_stream_pass1_lines): newlines up to and including part p; the steps the line workers
+  // inside the pass-1 launches have done
+  unsigned long long part_newlines[4];
+  unsigned long long lines_done_steps;
 };
 
 // Device counterpart of FASTQ_FILE's counters (src/fastq.h:116-122).

@@ -129,12 +129,12 @@ __device__ __forceinline__ uint64_t hash_name(const uint8_t* __restrict__ p, uin
   for (; i + 8 <= n; i += 8) {
     uint64_t w;
     __builtin_memcpy(&w, p + i, 8);
-    h += w * name_mul(i >> 3);
+    h = name_word(h, w, i >> 3);
     g = mix_hash2(g, w);
   }
   uint64_t w = 0;
   for (uint32_t k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
-  h += w * name_mul(i >> 3);
+  if (i < n) h = name_word(h, w, i >> 3);  // (only a word that holds a name byte)
   g = mix_hash2(g, w);
   if (second) *second = fin_hash2(g);
   return name_fin(h);
@@ -238,7 +238,7 @@ __device__ __forceinline__ uint64_t hash_name_regs(const HdrRegs& H, uint32_t n,
     const uint32_t rem = n - 8u * k;         // 0..7 when `last`
     const uint64_t w = full ? nw : (nw & ((1ull << (8 * (rem & 7))) - 1ull));
     if (full || last) {
-      h += w * name_mul((uint32_t)k);
+      if (8u * k < n) h = name_word(h, w, (uint32_t)k);  // (only a word that holds a name byte)
       g = mix_hash2(g, w);
     }
   }
@@ -343,7 +343,7 @@ __device__ __forceinline__ bool name_from_record(const unsigned long long (&w)[k
     const bool last = !full && 8u * i <= n;
     const uint32_t rem = n - 8u * i;
     const uint64_t x = full ? t[i] : (t[i] & ((1ull << (8 * (rem & 7))) - 1ull));
-    if (full || last) h += x * name_mul(i);
+    if (8u * i < n) h = name_word(h, x, i);
     if (i < kNameInline / 8) k.nm[i] = (full || last) ? x : 0ull;
   }
   k.h = name_fin(h);

@@ -122,12 +122,13 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_wave
 }
 
 // phase A: each workgroup scans kScanSpan tile counts (16 per thread)
+// (first_block: the launch covers spans first_block .. first_block + gridDim.x - 1 - the streaming pass in parts)
 __global__ __launch_bounds__(kBlock) void k_scan_a(const uint32_t* __restrict__ counts,
                                                    uint32_t n_tiles,
                                                    uint32_t* __restrict__ local_excl,
-                                                   unsigned long long* __restrict__ block_sums) {
+                                                   unsigned long long* __restrict__ block_sums, uint32_t first_block = 0) {
   __shared__ uint32_t s_wave[kBlock / kWave];
-  const uint32_t first = blockIdx.x * kScanSpan + threadIdx.x * 16;
+  const uint32_t first = (blockIdx.x + first_block) * kScanSpan + threadIdx.x * 16;
   uint32_t v[16];
   uint32_t sum = 0;
 #pragma unroll
@@ -142,18 +143,20 @@ __global__ __launch_bounds__(kBlock) void k_scan_a(const uint32_t* __restrict__ 
     if (first + k < n_tiles) local_excl[first + k] = run;
     run += v[k];
   }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  if (threadIdx.x == 0) block_sums[blockIdx.x + first_block] = total;
 }
 
 // phase B: one workgroup turns the span sums into exclusive prefixes in place
+// (first_block, part: spans [first_block, n_blocks) continue from what part - 1 left in the call state, and leave the
+// newline count up to here as part_newlines[part])
 __global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restrict__ block_sums,
                                                    uint32_t n_blocks, const uint8_t* __restrict__ img,
-                                                   uint64_t n, CallState* __restrict__ cs) {
+                                                   uint64_t n, CallState* __restrict__ cs, uint32_t first_block = 0, uint32_t part = 0) {
   __shared__ unsigned long long s_part[kBlock];
   __shared__ unsigned long long s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
+  if (threadIdx.x == 0) s_carry = part ? cs->part_newlines[part - 1] : 0ull;
   __syncthreads();
-  for (uint32_t base = 0; base < n_blocks; base += kBlock) {
+  for (uint32_t base = first_block; base < n_blocks; base += kBlock) {
     const uint32_t i = base + threadIdx.x;
     const unsigned long long v = (i < n_blocks) ? block_sums[i] : 0ull;
     s_part[threadIdx.x] = v;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restric
   }
   if (threadIdx.x == 0) {
     cs->n_newlines = s_carry;
+    cs->part_newlines[part < 4u ? part : 3u] = s_carry;
     cs->last_byte_is_nl = (n > 0 && img[n - 1] == '\n') ? 1u : 0u;
   }
 }

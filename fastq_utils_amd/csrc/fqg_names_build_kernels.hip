@@ -34,6 +34,10 @@ namespace fqg {
 constexpr uint32_t kPartLogMin = 12, kPartLogMax = 13;
 constexpr uint32_t kBuildTile = 4096;                   // keys a workgroup bins at once (64 KiB of staging)
 constexpr uint32_t kBuildMaxBuckets = 256;              // per level
+// the scatter kernels run 512 threads per workgroup: the 64 KiB staging area allows two workgroups per CU, and eight
+// keys per thread instead of sixteen halve the registers (16 per thread in 256 threads: 257 registers, ONE workgroup of
+// four wavefronts per CU - 2.0 ms for level 0)
+constexpr int kBuildThreads = 512;
 
 struct BuildKey {
   unsigned long long h, g;  // hash of the canonical name, global record index
@@ -46,15 +50,58 @@ struct BuildLevel {
   uint32_t shift, bits;     // output bucket of a key: ((h & mask) >> shift) & ((1 << bits) - 1), under its input bucket
 };
 
+// exclusive prefix over one value per bucket (threads 0 .. 255 bring one, the others 0); every thread of the workgroup calls
+__device__ __forceinline__ uint32_t build_scan_excl(uint32_t v, uint32_t* s_wave /*[kBuildThreads / kWave]*/, uint32_t* total) {
+  const uint32_t incl = wave_scan_incl(v);
+  if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kBuildThreads / kWave; ++w) {
+    const uint32_t t = s_wave[w];
+    if (w < (int)(threadIdx.x >> 6)) before += t;
+    all += t;
+  }
+  __syncthreads();
+  *total = all;
+  return before + incl - v;
+}
+// tally_flush for a workgroup of kBuildThreads
+__device__ __forceinline__ void build_tally_flush(IndexTally& t, IndexCall* __restrict__ call) {
+  if (t.first_dup != kNoRecord) atomicMin(&call->first_dup, t.first_dup);
+  if (t.first_wrong != kNoRecord) atomicMin(&call->first_wrong, t.first_wrong);
+  if (t.first_missing != kNoRecord) atomicMin(&call->first_missing, t.first_missing);
+  unsigned long long v[5] = {t.inserted, t.matched, t.name_bytes, t.seen, t.captured};
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] += __shfl_down(v[i], d, 64);
+  __shared__ unsigned long long s_sum[kBuildThreads / kWave][5];
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s_sum[threadIdx.x >> 6][i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long a = 0;
+    for (int w = 0; w < kBuildThreads / kWave; ++w) a += s_sum[w][threadIdx.x];
+    unsigned long long* dst = threadIdx.x == 0   ? &call->inserted
+                              : threadIdx.x == 1 ? &call->matched
+                              : threadIdx.x == 2 ? &call->name_bytes
+                              : threadIdx.x == 3 ? &call->seen
+                                                 : &call->captured;
+    if (a) atomicAdd(dst, a);
+  }
+}
+
 // One tile: every thread brings up to kBuildTile / kBlock keys (live[i]: it has one), the workgroup writes them grouped
 // by bucket.  `prefix` = the input bucket (level 1; 0 at level 0): output bucket = prefix << bits | own bits.
 template <int PER>
 __device__ __forceinline__ void build_scatter_tile(const BuildKey (&key)[PER], const bool (&live)[PER], uint64_t mask,
                                                    const BuildLevel& L, uint32_t prefix, IndexCall* __restrict__ call,
-                                                   BuildKey* s_stage, uint16_t* s_bkt, uint32_t* s_cnt, uint32_t* s_ofs,
+                                                   BuildKey* s_stage, uint8_t* s_bkt, uint32_t* s_cnt, uint32_t* s_ofs,
                                                    uint32_t* s_gbase, uint32_t* s_wave) {
   const uint32_t nb = 1u << L.bits;
-  for (uint32_t i = threadIdx.x; i < kBuildMaxBuckets; i += kBlock) s_cnt[i] = 0;
+  for (uint32_t i = threadIdx.x; i < kBuildMaxBuckets; i += kBuildThreads) s_cnt[i] = 0;
   __syncthreads();
   uint16_t bk[PER], rk[PER];
 #pragma unroll
@@ -69,7 +116,7 @@ __device__ __forceinline__ void build_scatter_tile(const BuildKey (&key)[PER], c
   // one reservation per bucket and tile; the buckets' places in the staging area
   const uint32_t mine = threadIdx.x < nb ? s_cnt[threadIdx.x] : 0u;
   uint32_t total;
-  const uint32_t ofs = block_scan_excl(mine, s_wave, &total);
+  const uint32_t ofs = build_scan_excl(mine, s_wave, &total);
   if (threadIdx.x < nb) {
     s_ofs[threadIdx.x] = ofs;
     uint32_t gb = 0;
@@ -85,11 +132,11 @@ __device__ __forceinline__ void build_scatter_tile(const BuildKey (&key)[PER], c
     if (live[i]) {
       const uint32_t e = s_ofs[bk[i]] + rk[i];
       s_stage[e] = key[i];
-      s_bkt[e] = bk[i];
+      s_bkt[e] = (uint8_t)bk[i];
     }
   __syncthreads();
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
+  for (uint32_t e = threadIdx.x; e < total; e += kBuildThreads) {
     const uint32_t b = s_bkt[e];
     const unsigned long long at = (unsigned long long)s_gbase[b] + (e - s_ofs[b]);
     if (at < L.cap) {
@@ -102,17 +149,17 @@ __device__ __forceinline__ void build_scatter_tile(const BuildKey (&key)[PER], c
   __syncthreads();
 }
 
-constexpr int kBuildPer = kBuildTile / kBlock;  // 16
+constexpr int kBuildPer = kBuildTile / kBuildThreads;  // 8
 
 // LEVEL 0: from the digests of the streaming pass (the logic of k_names_pass<insert, DIGEST>); LEVEL 1: from the buckets
 // level 0 wrote (in: n_in buckets of `in_cap`, in_count[] keys each; blockIdx.y = input bucket)
 template <int LEVEL>
-__global__ __launch_bounds__(kBlock) void k_build_scatter(FrameView f, NamesView nv, uint64_t base, uint64_t mask, BuildLevel L,
+__global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_build_scatter(FrameView f, NamesView nv, uint64_t base, uint64_t mask, BuildLevel L,
                                                           const BuildKey* __restrict__ in, const unsigned int* __restrict__ in_count,
                                                           unsigned long long in_cap, IndexCall* __restrict__ call) {
   __shared__ BuildKey s_stage[kBuildTile];
-  __shared__ uint16_t s_bkt[kBuildTile];
-  __shared__ uint32_t s_cnt[kBuildMaxBuckets], s_ofs[kBuildMaxBuckets], s_gbase[kBuildMaxBuckets], s_wave[kBlock / kWave];
+  __shared__ uint8_t s_bkt[kBuildTile];  // (at most kBuildMaxBuckets = 256 buckets per level)
+  __shared__ uint32_t s_cnt[kBuildMaxBuckets], s_ofs[kBuildMaxBuckets], s_gbase[kBuildMaxBuckets], s_wave[kBuildThreads / kWave];
   IndexTally t;
   if (LEVEL == 0) {
     // what a slot's digest is worth depends on its CHUNK (was the speculated line type the true one, how many headers
@@ -129,10 +176,10 @@ __global__ __launch_bounds__(kBlock) void k_build_scatter(FrameView f, NamesView
       u64x2_t dg[kBuildPer];
 #pragma unroll
       for (int i = 0; i < kBuildPer; ++i) {
-        const uint64_t s = tile * kBuildTile + (uint64_t)i * kBlock + threadIdx.x;
+        const uint64_t s = tile * kBuildTile + (uint64_t)i * kBuildThreads + threadIdx.x;
         dg[i] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(nv.recs + (s < n_slots ? s : n_slots - 1) * kDigestWords));
       }
-      for (uint32_t ci = threadIdx.x; ci < chunks_per_tile; ci += kBlock) {
+      for (uint32_t ci = threadIdx.x; ci < chunks_per_tile; ci += kBuildThreads) {
         const uint64_t c64 = tile * chunks_per_tile + ci;
         uint32_t hcv = kNoCapture;
         uint64_t r0 = 0;
@@ -152,8 +199,8 @@ __global__ __launch_bounds__(kBlock) void k_build_scatter(FrameView f, NamesView
       bool live[kBuildPer];
 #pragma unroll
       for (int i = 0; i < kBuildPer; ++i) {
-        const uint32_t in_tile = (uint32_t)i * kBlock + threadIdx.x;
-        const uint64_t s0 = tile * kBuildTile + (uint64_t)i * kBlock + (threadIdx.x & ~63u);
+        const uint32_t in_tile = (uint32_t)i * kBuildThreads + threadIdx.x;
+        const uint64_t s0 = tile * kBuildTile + (uint64_t)i * kBuildThreads + (threadIdx.x & ~63u);
         const uint64_t s = s0 + lane;
         const uint32_t ci = in_tile >> nv.k_shift, j = in_tile & (nv.K - 1u);
         const uint32_t hc = s_hc[ci];
@@ -188,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_build_scatter(FrameView f, NamesView
       }
       build_scatter_tile<kBuildPer>(key, live, mask, L, 0u, call, s_stage, s_bkt, s_cnt, s_ofs, s_gbase, s_wave);
     }
-    tally_flush(t, call);
+    build_tally_flush(t, call);
   } else {
     const uint32_t b = blockIdx.y;
     const unsigned long long n = in_count[b] < in_cap ? in_count[b] : in_cap;
@@ -198,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_build_scatter(FrameView f, NamesView
       bool live[kBuildPer];
 #pragma unroll
       for (int i = 0; i < kBuildPer; ++i) {
-        const unsigned long long e = t0 + (unsigned long long)i * kBlock + threadIdx.x;
+        const unsigned long long e = t0 + (unsigned long long)i * kBuildThreads + threadIdx.x;
         live[i] = e < n;
         key[i].h = key[i].g = 0;
         if (live[i]) {
@@ -210,6 +257,18 @@ __global__ __launch_bounds__(kBlock) void k_build_scatter(FrameView f, NamesView
       build_scatter_tile<kBuildPer>(key, live, mask, L, b, call, s_stage, s_bkt, s_cnt, s_ofs, s_gbase, s_wave);
     }
   }
+}
+
+// rare: two keys of one tag - is the name of this frame's record r the stored record's?  (not inlined: the header in
+// registers, the byte-wise fallbacks ... would sit in the register budget of a loop that never needs them - 169
+// registers instead of 81 for the 8192-slot kernel.)  *acct = what the reference accounts for the name.
+__device__ __attribute__((noinline)) bool build_same_name(const FrameView& f, const IndexView& ix, uint64_t r, unsigned long long other,
+                                                           uint32_t* acct) {
+  NameKey k;
+  bool at_sign;
+  name_from_image(f, r, ix.fmt, ix.is_pe, ix.may_have_nul, k, &at_sign);
+  *acct = k.acct;
+  return stored_name_is(ix, other, NameAt{f, r}(), k.n);
 }
 
 // One workgroup per part of the table.  keys: n_parts buckets of `cap`; count[p] keys in part p.
@@ -249,16 +308,13 @@ __global__ __launch_bounds__(kBlock) void k_build_parts(FrameView f, IndexView i
       if ((cur >> 40) == (me >> 40)) {
         // rare: the tags agree - the bytes decide, through the line index (this frame's record, the other one wherever
         // it lives)
-        const uint64_t r = g - record_base;
-        NameKey k;
-        bool at_sign;
-        name_from_image(f, r, ix.fmt, ix.is_pe, ix.may_have_nul, k, &at_sign);
-        if (stored_name_is(ix, cur & kIdxMask, NameAt{f, r}(), k.n)) {
+        uint32_t acct;
+        if (build_same_name(f, ix, g - record_base, cur & kIdxMask, &acct)) {
           const unsigned long long prev = atomicMin(&s_slots[at], me);
           const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
           atomicMin(&call->first_dup, late);
-          atomicAdd(&call->inserted, ~0ull);                                // (k_build_scatter counted it,
-          atomicAdd(&call->name_bytes, 0ull - (unsigned long long)k.acct);  //  and its bytes)
+          atomicAdd(&call->inserted, ~0ull);                              // (k_build_scatter counted it,
+          atomicAdd(&call->name_bytes, 0ull - (unsigned long long)acct);  //  and its bytes)
           done = true;
           break;
         }
@@ -292,16 +348,13 @@ __global__ __launch_bounds__(kBlock) void k_build_spill(FrameView f, IndexView i
       const unsigned long long cur = atomicCAS(&ix.slots[at], kSlotEmpty, me);
       if (cur == kSlotEmpty) done = true;
       else if ((cur >> 40) == (me >> 40)) {
-        const uint64_t r = g - record_base;
-        NameKey k;
-        bool at_sign;
-        name_from_image(f, r, ix.fmt, ix.is_pe, ix.may_have_nul, k, &at_sign);
-        if (stored_name_is(ix, cur & kIdxMask, NameAt{f, r}(), k.n)) {
+        uint32_t acct;
+        if (build_same_name(f, ix, g - record_base, cur & kIdxMask, &acct)) {
           const unsigned long long prev = atomicMin(&ix.slots[at], me);
           const unsigned long long late = (prev & kIdxMask) > g ? (prev & kIdxMask) : g;
           atomicMin(&call->first_dup, late);
           atomicAdd(&call->inserted, ~0ull);
-          atomicAdd(&call->name_bytes, 0ull - (unsigned long long)k.acct);
+          atomicAdd(&call->name_bytes, 0ull - (unsigned long long)acct);
           done = true;
         }
       }

@@ -41,10 +41,12 @@
 
 #if defined(__HIPCC__)
 #define FQG_HD __host__ __device__ __forceinline__
+#define FQG_HD_COLD __host__ __device__ __attribute__((noinline))
 // (everything is inlined on the device: a version that kept the large pieces - load_run, extend, subtree_nodes,
 // open_node - as functions put the simulator's state in scratch memory and ran 1.3 - 1.9 times slower)
 #else
 #define FQG_HD inline
+#define FQG_HD_COLD inline
 #endif
 
 namespace fqg {
@@ -169,6 +171,7 @@ struct Stats {
 // memoised: an entry (slot, depth, size) stays valid until something is written inside [slot, slot + size), and
 // moves along when an insert shifts the nodes behind its place.
 constexpr uint32_t kMemo = 64;
+constexpr uint32_t kMemoWords = 3 * kMemo;
 constexpr uint32_t kMemoMin = 1024;  // subtrees smaller than this are walked again (keeping the memo valid costs more)
 
 template <class W>
@@ -180,8 +183,19 @@ struct WorkT {
   typename W::p32 base;     // [mcap + 1]
   typename W::p32 scratch;  // [lanes + 1] for the scan
   uint32_t cap, mcap;
-  typename W::p32 memo;     // [3 * kMemo] sizes of saturated subtrees: slot | depth | size (0: free entry)
+  typename W::p32 memo;     // [kMemoWords] sizes of saturated subtrees: slot | depth | size (0: free entry)
 };
+
+template <class W>
+struct History;
+// History::get's slow path - one more run of the past, and another, until slot k is covered - as ONE function the device
+// code CALLS (round 6).  Inlined, every read of a node (rd: some fifty places) carried its own copy of extend() and
+// load_run() - the sort, the trie, the wait for an earlier replay: ten copies in the instruction stream of a kernel that
+// one wavefront per CU executes, several times the instruction cache (46 000 instructions; 50 cycles per instruction by the
+// counters).  The state travels BY VALUE (the worker's pointers, pos, S): nothing of the simulator has its address
+// taken, so it stays in registers - what the attempts of round 3 (functions taking `this`) lost.
+template <class W>
+FQG_HD_COLD unsigned long long history_fill(const ChainView* cv, WorkT<W> wk, Stats* st, uint32_t pos, uint32_t S, uint32_t k);
 
 template <class W>
 struct History {
@@ -307,7 +321,9 @@ struct History {
   FQG_HD uint16_t get(uint32_t k) {
     if (S <= k && more()) {
       const unsigned long long t0 = W::clock();
-      while (S <= k && more()) extend();
+      const unsigned long long r = history_fill<W>(cv, *wk, st, pos, S, k);
+      pos = (uint32_t)(r >> 32);
+      S = (uint32_t)r;
       st->clk_lookback += W::clock() - t0;
     }
     if (k < S) return wk->stale[k];
@@ -317,6 +333,19 @@ struct History {
 };
 
 template <class W>
+FQG_HD_COLD unsigned long long history_fill(const ChainView* cv, WorkT<W> wk, Stats* st, uint32_t pos, uint32_t S, uint32_t k) {
+  History<W> h;
+  h.cv = cv;
+  h.wk = &wk;
+  h.st = st;
+  h.pos = pos;
+  h.S = S;
+  h.count = true;
+  while (h.S <= k && h.more()) h.extend();
+  return ((unsigned long long)h.pos << 32) | h.S;
+}
+
+template <class W>
 struct Sim {
   WorkT<W>* wk;
   History<W>* hist;
@@ -324,6 +353,7 @@ struct Sim {
   uint32_t size, unknown_live, pending, memo_next, memo_live;  // memo_live: valid entries (the same in every lane)
 
   FQG_HD uint32_t memo_get(uint32_t idx, uint32_t d) {
+    if (!memo_live) return 0;  // (the usual case: sets below kMemoMin nodes never put anything)
     for (uint32_t e0 = 0; e0 < kMemo; e0 += (uint32_t)W::lanes) {
       const uint32_t e = e0 + W::lane();
       const bool hit = e < kMemo && wk->memo[2 * kMemo + e] && wk->memo[e] == idx && wk->memo[kMemo + e] == d;
@@ -428,15 +458,21 @@ struct Sim {
   // tree_size (src/range_list.c:566-593) of the node at idx taken as a node of depth d
   FQG_HD uint32_t subtree_nodes(uint32_t idx, uint32_t d) {
     if (d >= 8) return 1;
-    const uint32_t c0 = count(idx);
+    const uint16_t root = rd(idx);
+    const uint32_t c0 = root >> 8;
     if (c0 != 255u) return c0;
     {
       const uint32_t m = memo_get(idx, d);
       if (m) return m;
     }
+    // Every node of the walk is READ ONCE (round 6): its value stays in s_nv while its four quadrants are looked at -
+    // nothing writes to the node array during the walk, and a read is an LDS round trip plus a readfirstlane, which is
+    // what this walk is made of (a node was read five times: four quadrants and its count, 13 us per insert on the
+    // longest chain of BASELINE configs[3]).
     uint32_t s_idx[9], s_c[9], s_q[9];
+    uint16_t s_nv[9];
     int sp = 0;
-    s_idx[0] = idx; s_c[0] = 1; s_q[0] = 1;
+    s_idx[0] = idx; s_c[0] = 1; s_q[0] = 1; s_nv[0] = root;
     for (;;) {
       if (s_q[sp] > 4) {
         const uint32_t r = s_c[sp];
@@ -447,16 +483,20 @@ struct Sim {
         ++s_q[sp];
         continue;
       }
-      if (quad(s_idx[sp], s_q[sp]) == kQPart) {
+      if (quad_of(s_nv[sp], s_q[sp]) == kQPart) {
         const uint32_t child = s_idx[sp] + s_c[sp], cd = d + (uint32_t)sp + 1u;
         uint32_t cc = 1;
-        if (cd < 8 && (cc = count(child)) == 255u && sp < 8) {
-          const uint32_t m = memo_get(child, cd);
-          if (m) cc = m;
-          else {
-            ++sp;
-            s_idx[sp] = child; s_c[sp] = 1; s_q[sp] = 1;
-            continue;
+        if (cd < 8) {
+          const uint16_t cv = rd(child);
+          cc = cv >> 8;
+          if (cc == 255u && sp < 8) {
+            const uint32_t m = memo_get(child, cd);
+            if (m) cc = m;
+            else {
+              ++sp;
+              s_idx[sp] = child; s_c[sp] = 1; s_q[sp] = 1; s_nv[sp] = cv;
+              continue;
+            }
           }
         }
         s_c[sp] += cc;
@@ -614,6 +654,8 @@ struct Sim {
   FQG_HD bool member_or_insert(uint32_t umi_id) {
     const uint32_t v = umi_id - 1u;
     uint32_t path[8], before[8];
+    uint16_t pnv[8];  // what the path's nodes hold (round 6: the refresh below does not read them again - a read is an
+                      // LDS round trip, and the only writes to them in between are open_node's, mirrored here)
     uint32_t idx = 0, d = 0;
     bool opened = false;
     for (; d < 8; ++d) {
@@ -621,9 +663,11 @@ struct Sim {
       before[d] = size;
       const uint32_t q = ((v >> (18u - 2u * d)) & 3u) + 1u;
       const uint16_t nv = rd(idx);
+      pnv[d] = nv;
       const uint32_t s = quad_of(nv, q);
       if (s == kQOut) {
         idx = open_node(idx, nv, q, d);
+        pnv[d] = (uint16_t)((nv & ~(3u << (2u * (q - 1u)))) | (kQPart << (2u * (q - 1u))));  // set_quadrant(father, q, PART)
         opened = true;
       } else if (s == kQAll) return true;  // (never on a freshly opened path)
       else idx += child_offset(idx, nv, q, d);
@@ -634,7 +678,7 @@ struct Sim {
     for (int k = 7; k >= 0; --k) {
       const uint32_t node = path[k];
       const uint32_t added = size - before[k];
-      const uint16_t nv = rd(node);
+      const uint16_t nv = path[k] < wk->cap ? pnv[k] : (uint16_t)rd(node);  // (beyond the array: rd flags the overflow)
       const uint32_t c0 = nv >> 8;
       uint32_t c = c0 == 255u ? subtree_nodes(node, (uint32_t)k + 1u) : added + c0;  // (:485: the child's width)
       if (c > 254u) c = 255u;

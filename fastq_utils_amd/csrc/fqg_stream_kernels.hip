@@ -88,15 +88,18 @@ __device__ __forceinline__ uint32_t in_range7a(uint32_t w, uint32_t lo_add, uint
 // span <= image size).  One workgroup.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBootMax = 64u << 10;  // span <= kBootMax (host: kStreamBootBytes)
-__global__ __launch_bounds__(kBlock) void k_stream_boot(const uint8_t* __restrict__ img, uint32_t span,
-                                                        CallState* __restrict__ cs) {
-  __shared__ uint32_t s_cnt[kBlock / kWave];
+constexpr int kBootBlock = 1024;          // 16 wavefronts, 4 KiB of the window each: the walks below are serial per
+                                          // wavefront, and the whole call waits for this one workgroup (0.040 -> 0.02 ms)
+__global__ __launch_bounds__(kBootBlock) void k_stream_boot(const uint8_t* __restrict__ img, uint32_t span,
+                                                            CallState* __restrict__ cs) {
+  constexpr int kBootWaves = kBootBlock / kWave;
+  __shared__ uint32_t s_cnt[kBootWaves];
   __shared__ __attribute__((aligned(16))) uint8_t s_img[kBootMax];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
-  const uint32_t part = span / (kBlock / kWave);
+  const uint32_t part = span / kBootWaves;  // (span is a multiple of 256: part is a multiple of 16)
   // the prefix goes to LDS first (all loads in flight at once): the two byte-wise walks below would
   // otherwise pay a memory round trip per 64 bytes each
-  for (uint32_t o = threadIdx.x * 16u; o < span; o += kBlock * 16u)
+  for (uint32_t o = threadIdx.x * 16u; o < span; o += kBootBlock * 16u)
     *reinterpret_cast<uint4*>(s_img + o) = *reinterpret_cast<const uint4*>(img + o);
   __syncthreads();
   const uint8_t* p = s_img + (uint64_t)wv * part;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_boot(const uint8_t* __restric
   if (lane == 0) s_cnt[wv] = cnt;
   __syncthreads();
   uint32_t before = 0, total = 0;
-  for (int w = 0; w < kBlock / kWave; ++w) {
+  for (int w = 0; w < kBootWaves; ++w) {
     if (w < wv) before += s_cnt[w];
     total += s_cnt[w];
   }
@@ -114,10 +117,10 @@ __global__ __launch_bounds__(kBlock) void k_stream_boot(const uint8_t* __restric
   if (threadIdx.x == 0) cs->boot_lines = total;
   uint32_t line = before, qmin = 255, qmax = 0;
   for (uint32_t o = 0; o < part; o += kWave) {
-    const uint32_t c = p[o + lane];
-    const uint64_t bal = __ballot(c == '\n');
+    const uint32_t c = o + lane < part ? (uint32_t)p[o + lane] : 0u;
+    const uint64_t bal = __ballot(o + lane < part && c == '\n');
     const uint32_t mine = line + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-    if ((mine & 3u) == 3u && mine < limit && c != '\n') {
+    if ((mine & 3u) == 3u && mine < limit && c != '\n' && o + lane < part) {
       qmin = c < qmin ? c : qmin;
       qmax = c > qmax ? c : qmax;
     }
@@ -240,18 +243,26 @@ __device__ __forceinline__ void stage_chunk(const uint8_t* __restrict__ img, uin
 // 2 = no staging, 4 = no fetch of the byte after a newline, 8 = no base check, 16 = no quality test
 // NAMES: also capture the header lines that begin in the chunk (NameCapture, fqg_device.h)
 // NAMES: 0 = no capture, 1 = 64-byte records, 2 = 16-byte digests (fqg_device.h)
-template <uint32_t ABL, int NAMES = 0>
-__global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restrict__ img, uint64_t n,
-                                                         uint32_t n_chunks, StreamOut o,
-                                                         CallState* __restrict__ cs, NameCapture nc = NameCapture{}) {
+// LDS of a pass-1 workgroup: the staging slots and the copies of its four chunks (static in k_stream_pass1, a piece of the
+// dynamic LDS in the kernel that also runs the line workers, k_stream_pass1_lines)
+template <int NAMES>
+struct Pass1Lds {
+  uint16_t slots[kBlock / kWave][kStageCap];
+  __attribute__((aligned(16))) uint8_t copy[kBlock / kWave][NAMES ? kCopyRow : (uint32_t)kChunkBytes];
+};
+// block: which workgroup of the pass this is (chunks 4 block .. 4 block + 3), n_chunks: the pass ends in front of it
+template <uint32_t ABL, int NAMES>
+__device__ __forceinline__ void stream_pass1_body(const uint8_t* __restrict__ img, uint64_t n, uint32_t n_chunks, const StreamOut& o,
+                                                  CallState* __restrict__ cs, const NameCapture& nc, uint32_t block,
+                                                  Pass1Lds<NAMES>& lds) {
   static_assert(kHalves == 2 && kHalves * kHalfBytes == kChunkBytes, "one packed scan covers the two slices");
   static_assert(NAMES == 0 || !(ABL & 7u), "the name capture needs the speculation, the staged entries and the copy");
-  __shared__ uint16_t s_slots[kBlock / kWave][kStageCap];
-  __shared__ __attribute__((aligned(16))) uint8_t s_copy[kBlock / kWave][NAMES ? kCopyRow : (uint32_t)kChunkBytes];
+  auto& s_slots = lds.slots;
+  auto& s_copy = lds.copy;
   // (the wave index is uniform: telling the compiler keeps chunk-level values in scalar registers)
   const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* const copy = s_copy[wv] + (NAMES ? kCopyFront : 0u);
-  const uint32_t chunk = blockIdx.x * (kBlock / kWave) + wv;
+  const uint32_t chunk = block * (kBlock / kWave) + wv;
   if (chunk >= n_chunks) return;
   const uint64_t cb = (uint64_t)chunk * kChunkBytes;
   const uint64_t wb = cb + (uint64_t)lane * kLaneBytes;
@@ -558,10 +569,14 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
           uint64_t w0 = ((uint64_t)x.y << 32) | x.x, w1 = ((uint64_t)x.w << 32) | x.z;
           w0 = k0 >= 8u ? w0 : (w0 & ((1ull << (8u * k0)) - 1ull));
           w1 = k1 >= 8u ? w1 : (w1 & ((1ull << (8u * k1)) - 1ull));
-          // (the multipliers by selection: sub is one of four, and computing name_mul() costs two more 64-bit products)
-          const uint64_t m0 = sub == 0u ? name_mul(0) : sub == 1u ? name_mul(2) : sub == 2u ? name_mul(4) : name_mul(6);
-          const uint64_t m1 = sub == 0u ? name_mul(1) : sub == 1u ? name_mul(3) : sub == 2u ? name_mul(5) : name_mul(7);
-          uint64_t part = w0 * m0 + w1 * m1;
+          // (the keys by selection: sub is one of four; a word counts when it holds a name byte - name_word)
+          const uint32_t a0 = sub == 0u ? name_key_a(0) : sub == 1u ? name_key_a(2) : sub == 2u ? name_key_a(4) : name_key_a(6);
+          const uint32_t b0 = sub == 0u ? name_key_b(0) : sub == 1u ? name_key_b(2) : sub == 2u ? name_key_b(4) : name_key_b(6);
+          const uint32_t a1 = sub == 0u ? name_key_a(1) : sub == 1u ? name_key_a(3) : sub == 2u ? name_key_a(5) : name_key_a(7);
+          const uint32_t b1 = sub == 0u ? name_key_b(1) : sub == 1u ? name_key_b(3) : sub == 2u ? name_key_b(5) : name_key_b(7);
+          uint64_t part = 0;
+          if (k0) part = (uint64_t)((uint32_t)w0 + a0) * (uint64_t)((uint32_t)(w0 >> 32) + b0);
+          if (k1) part += (uint64_t)((uint32_t)w1 + a1) * (uint64_t)((uint32_t)(w1 >> 32) + b1);
           uint32_t plo = (uint32_t)part, phi = (uint32_t)(part >> 32);
           uint64_t oth = ((uint64_t)dpp0<0xB1, 0xf, 0xf>(phi) << 32) | dpp0<0xB1, 0xf, 0xf>(plo);
           part += oth;
@@ -654,6 +669,14 @@ __global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restri
     o.cinfo[chunk] = info;
     if (flags) atomicOr(&cs->flags, flags);
   }
+}
+
+template <uint32_t ABL, int NAMES = 0>
+__global__ __launch_bounds__(kBlock) void k_stream_pass1(const uint8_t* __restrict__ img, uint64_t n,
+                                                         uint32_t n_chunks, StreamOut o,
+                                                         CallState* __restrict__ cs, NameCapture nc = NameCapture{}) {
+  __shared__ Pass1Lds<NAMES> lds;
+  stream_pass1_body<ABL, NAMES>(img, n, n_chunks, o, cs, nc, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -867,6 +890,7 @@ struct LinesArgs {
   // and nothing else - the second run, when something does ask for the index (index_now in fqg_abi.hip).
   uint32_t no_index, index_only;
   uint64_t keep_from;
+  uint64_t step_lo = 0, step_hi = 0;  // k_stream_lines_fast: the steps of this launch ([0, every step) by default)
 };
 
 constexpr int kLinesHist = 3072;
@@ -1157,17 +1181,26 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
          ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
 }
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stream_lines_fast(LinesArgs A, uint8_t* __restrict__ todo) {
-  __shared__ uint32_t s_hist[kLinesHist];
-  __shared__ unsigned long long s_red[3][kBlock / kWave];
-  __shared__ __attribute__((aligned(16))) uint32_t s_ent[kBlock / kWave][(kFastRanks + 7) & ~3];
+struct LinesFastLds {
+  uint32_t hist[kLinesHist];
+  unsigned long long red[3][kBlock / kWave];
+  __attribute__((aligned(16))) uint32_t ent[kBlock / kWave][(kFastRanks + 7) & ~3];
+};
+// worker / n_workers: which workgroup of the persistent grid this is; the steps it shares are [A.step_lo, A.step_hi)
+// (step_hi = 0: up to the last step of the image)
+__device__ __forceinline__ void stream_lines_fast_body(const LinesArgs& A, uint8_t* __restrict__ todo, uint32_t worker,
+                                                       uint32_t n_workers, LinesFastLds& lds) {
+  auto& s_hist = lds.hist;
+  auto& s_red = lds.red;
+  auto& s_ent = lds.ent;
   for (int i = threadIdx.x; i < kLinesHist; i += kBlock) s_hist[i] = 0;
   __syncthreads();
   const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
   const uint64_t n_groups = (A.n_lines + 4 * kWave - 1) / (4 * kWave);
-  const uint64_t n_steps = (n_groups + kLinesPer - 1) / kLinesPer;
-  const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-  const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const uint64_t n_steps_all = (n_groups + kLinesPer - 1) / kLinesPer;
+  const uint64_t n_steps = A.step_hi && A.step_hi < n_steps_all ? A.step_hi : n_steps_all;
+  const uint64_t wave0 = A.step_lo + (uint64_t)worker * (kBlock / kWave) + (threadIdx.x >> 6);
+  const uint64_t n_waves = (uint64_t)n_workers * (kBlock / kWave);
   const double chunks_per_line = A.n_newlines ? (double)A.cr.n_chunks / (double)A.n_newlines : 0.0;
   uint32_t n_ok32 = 0, min_rl32 = ~0u, max_rl32 = 0;  // (a wavefront's share of the records and a step's lengths fit)
   // the window of the NEXT step is requested a step ahead and looked at when that step begins (see k_stream_lines)
@@ -1338,6 +1371,83 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) 
     const uint32_t cc = s_hist[i];
     if (cc) atomicAdd(&A.hist[i], (unsigned long long)cc * A.weight);
   }
+}
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stream_lines_fast(LinesArgs A, uint8_t* __restrict__ todo) {
+  __shared__ LinesFastLds lds;
+  stream_lines_fast_body(A, todo, blockIdx.x, gridDim.x, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass 1 of one part of the image and the line workers of the part BEFORE it in ONE kernel (round 6).  Pass 1 is bound by
+// vector-ALU cycles, the line kernel by the latency of its dependent loads: side by side they hide each other (two
+// streams with priorities: 7.97 -> 7.58 ms, profiles/r04c_kbench_overlap.txt).  As one launch the overlap needs no second
+// stream, no host in between, no priorities: the first `line_workers` workgroups are the persistent line workers - they
+// start first and keep one slot per CU -, the others are pass-1 workgroups of chunks [chunk_first, n_chunks).  The line
+// workers take what they need from DEVICE memory: the newline count behind the parts scanned so far (CallState::
+// part_newlines, k_scan_b) gives their steps - every step whose ranks are all staged - and the flags that send an image
+// to the two-pass path (NUL, CR, high bytes, a chunk with too many newlines) make them do nothing.  Their statistics go
+// to accumulators the caller merges once the whole image has passed (k_acc_merge): a later part can still raise a flag.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stream_pass1_lines(
+    const uint8_t* __restrict__ img, uint64_t n, uint32_t chunk_first, uint32_t n_chunks, StreamOut o, CallState* __restrict__ cs,
+    LinesArgs A, uint8_t* __restrict__ todo, uint32_t line_workers, uint32_t part /* whose lines: >= 0 */) {
+  union Lds {
+    Pass1Lds<0> p1;
+    LinesFastLds lf;
+  };
+  __shared__ Lds lds;
+  if (blockIdx.x >= line_workers) {
+    stream_pass1_body<0u, 0>(img, n, n_chunks, o, cs, NameCapture{}, chunk_first / (kBlock / kWave) + (blockIdx.x - line_workers), lds.p1);
+    return;
+  }
+  // ---- a line worker: the steps of part `part`, from what the scans have left in the call state ----
+  if (__hip_atomic_load(&cs->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (kFlagNul | kFlagCr | kFlagHigh | kFlagStageOverflow)) return;
+  const unsigned long long R = cs->part_newlines[part], R0 = part ? cs->part_newlines[part - 1] : 0ull;
+  const double per_chunk = (double)R / (double)(chunk_first ? chunk_first : 1u);
+  if (per_chunk > 60.0 || per_chunk < 32.0) return;  // (the host decides the same way for the whole image: frame_stream)
+  A.n_newlines = R;
+  A.n_lines = R;
+  A.limit = R & ~3ull;
+  A.cr.n_chunks = chunk_first;
+  A.step_lo = R0 / (uint64_t)(4 * kWave * kLinesPer);
+  A.step_hi = R / (uint64_t)(4 * kWave * kLinesPer);  // full steps only: every rank of theirs has a staged entry
+  if (blockIdx.x == 0 && threadIdx.x == 0) cs->lines_done_steps = A.step_hi;
+  if (A.step_hi <= A.step_lo) return;
+  stream_lines_fast_body(A, todo, blockIdx.x, line_workers, lds.lf);
+}
+
+// the statistics of the line workers -> the caller's accumulator (discard: only the clearing), and the scratch cleared
+__global__ __launch_bounds__(kBlock) void k_acc_merge(AccState* __restrict__ src, unsigned long long* __restrict__ src_hist,
+                                                      AccState* __restrict__ dst, unsigned long long* __restrict__ dst_hist,
+                                                      int discard) {
+  __shared__ unsigned long long s_lo, s_hi;
+  if (threadIdx.x == 0) {
+    s_lo = src->min_rl;
+    s_hi = src->max_rl;
+  }
+  __syncthreads();
+  const unsigned long long lo = s_lo, hi = s_hi;
+  if (lo <= hi)
+    for (unsigned long long i = lo + (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i <= hi; i += (unsigned long long)gridDim.x * kBlock) {
+      const unsigned long long v = src_hist[i];
+      if (v) {
+        if (!discard && dst_hist) atomicAdd(&dst_hist[i], v);
+        src_hist[i] = 0;
+      }
+    }
+  if (!discard && dst && blockIdx.x == 0 && threadIdx.x == 0 && src->num_rds) {
+    atomicAdd(&dst->num_rds, src->num_rds);
+    atomicMin(&dst->min_rl, src->min_rl);
+    atomicMax(&dst->max_rl, src->max_rl);
+  }
+}
+__global__ void k_acc_scratch_reset(AccState* __restrict__ a) {
+  a->num_rds = 0;
+  a->min_rl = FQG_MAX_READ_LENGTH;
+  a->max_rl = 0;
+  a->min_qbyte = 255;
+  a->max_qbyte = 0;
 }
 
 // After every marking kernel: the suspect bitmap -> the list the exact validator walks; the image's quality range

@@ -191,7 +191,7 @@ __device__ __forceinline__ void rl_replay_body(const RlReplayArgs& A, P8 g, type
   wk.known = (typename W::p32)carve((uint64_t)A.cap / 8 + 4);
   wk.mem = (typename W::p32)carve((uint64_t)A.mcap * 4);
   wk.base = (typename W::p32)carve((uint64_t)(A.mcap + 1) * 4);
-  wk.memo = (typename W::p32)carve((uint64_t)3 * rl::kMemo * 4);
+  wk.memo = (typename W::p32)carve((uint64_t)rl::kMemoWords * 4);
   wk.scratch = scan;
   rl::Stats st{};
   for (;;) {  // tickets in replay order
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kWave) void k_rl_replay(RlReplayArgs A) {
 static inline uint64_t rl_work_bytes(uint32_t cap, uint32_t mcap) {
   auto r = [](uint64_t b) { return (b + 15) & ~15ull; };
   return 2 * r((uint64_t)cap * 2) + r((uint64_t)cap / 8 + 4) + r((uint64_t)mcap * 4) + r((uint64_t)(mcap + 1) * 4) +
-         r((uint64_t)3 * rl::kMemo * 4);
+         r((uint64_t)rl::kMemoWords * 4);
 }
 
 __global__ __launch_bounds__(kBlock) void k_rl_flag_lens(uint32_t n_flagged, const uint32_t* __restrict__ flagged,

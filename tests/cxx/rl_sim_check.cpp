@@ -115,7 +115,7 @@ extern "C" int rl_sim_check(uint32_t n, const uint32_t* chain, const uint32_t* e
   std::vector<uint16_t> arena(arena_n + 1);
   std::vector<uint16_t> node(cap), stale(cap);
   std::vector<uint32_t> known(cap / 32 + 1), mem(mcap + 1), base(mcap + 2), scratch(4);
-  std::vector<uint32_t> memo(3 * kMemo);
+  std::vector<uint32_t> memo(kMemoWords);
   WorkT<CpuWave> wk{node.data(), known.data(), stale.data(), mem.data(), base.data(), scratch.data(), cap, mcap, memo.data()};
   Stats st{};
   for (uint32_t p = 0; p < n_runs; ++p) {  // flagged runs in (chain, cell) order: the order the GPU hands them out

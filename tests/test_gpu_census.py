@@ -162,7 +162,8 @@ def test_10x_synthetic_against_the_three_oracles(layout):
         assert got_pairs == [] and got_cells == []
     else:
         assert len(got_cells) >= (1 if layout == "umi_only" else 40)
-        assert any(reads > umis for _, reads, umis in got_cells)   # a UMI seen twice in a cell counts once
+        if layout != "other_file":   # (a cell from 12 random bases of the cDNA read is nearly every read's own)
+            assert any(reads > umis for _, reads, umis in got_cells)   # a UMI seen twice in a cell counts once
 
 
 def test_census_must_follow_its_transform():

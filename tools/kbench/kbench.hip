@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
     uint32_t *cinfo, *redo; uint16_t* stage; unsigned long long* queue;
     CK(hipMalloc(&cinfo, n_tiles * 4ull)); CK(hipMalloc(&redo, n_tiles * 4ull)); CK(hipMalloc(&stage, (size_t)n_tiles * kStageCap * 2)); CK(hipMalloc(&queue, 8ull << 20));
     StreamOut so{counts, cinfo, stage, queue, 1ull << 20};
-    report("k_stream_boot", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBlock), 0, 0, img, 65536u, cs); }));
+    report("k_stream_boot", time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_boot, dim3(1), dim3(kBootBlock), 0, 0, img, 65536u, cs); }));
 #define P1(ABL, label) report(label, time_ms(reps, [&] { hipLaunchKernelGGL(k_stream_pass1<ABL>, dim3((n_tiles + 3) / 4), dim3(kBlock), 0, 0, img, n, n_tiles, so, cs); }))
     P1(1u, "  pass1 - no checks");
     P1(2u, "  pass1 - no staging");
