@@ -170,6 +170,9 @@ def parse():
     ap.add_argument("--two-pass", action="store_true", help="census + framing passes instead of the single-pass path")
     ap.add_argument("--no-index-extra", action="store_true",
                     help="skip the untimed extra: fastq_info default mode (validate + unique read-name index)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE.json configs[4] as written: 125 M pairs per GPU (1 B over eight), the pairing leg of the "
+                         "cross-rank extra between two DISTINCT mate files (it always is; this only sets the size)")
     ap.add_argument("--no-dedup-extra", action="store_true",
                     help="skip the extra: unique read names across ALL ranks (fingerprint all-to-all over RCCL)")
     ap.add_argument("--dedup-extra", action="store_true",
@@ -195,7 +198,10 @@ def parse():
                          "when gpurun_out/ exists)")
     ap.add_argument("--bgzf-helper", nargs=2, metavar=("SRC", "DST"), help=argparse.SUPPRESS)
     ap.add_argument("--gz-helper", nargs=3, metavar=("SRC", "DST", "NBYTES"), help=argparse.SUPPRESS)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config4:
+        a.reads = 125_000_000
+    return a
 
 
 def cpu_baseline(image_prefix_bytes, n_reads):
@@ -1665,15 +1671,26 @@ def main():
             barrier()
             dt_dedup = time.perf_counter() - t1
             pd = ctx.profile_read()
-            # ... and the file-2 loop of a pair over all ranks: the same names once more as "file 2" (every name
-            # finds its mate on whatever rank holds it)
+            # ... and the file-2 loop of a pair over all ranks (BASELINE configs[4]): a DISTINCT mate file - the "2:N:0"
+            # records - of which this rank holds the shard whose mates the NEXT rank holds (every name finds its mate on
+            # another rank: the exchange carries real traffic)
+            other = (rank + 1) % world
+            image2 = torch.empty(n * R + 64, dtype=torch.uint8, device=dev)
+            ctx.synth_fastq(image2.data_ptr(), n, a.read_len, first_index=other * n, seed=12345, mate=2)
+            ctx.synchronize()
+            st2 = fq.abi.probe_first_record(bytes(image2[: 4 * R].cpu().numpy()), True)
+            rv2 = ctx.validate(image2.data_ptr(), None, st2, final=True, flags=fq.abi.VALIDATE_NO_STATS, nbytes=n * R)
+            frame2 = ctx.retain_frame()
+            barrier()
             t2 = time.perf_counter()
-            pairing = fdist.global_pairing(ctx, [(frame, rv["n_records"])], st, rank * n, [(frame, rv["n_records"])], st,
-                                           rank * n, device=dev)
+            pairing = fdist.global_pairing(ctx, [(frame, rv["n_records"])], st, rank * n, [(frame2, rv2["n_records"])], st2,
+                                           other * n, device=dev)
             barrier()
             dt_pair = time.perf_counter() - t2
             ctx.profile(False)
             frame.release()
+            frame2.release()
+            del image2
             tt = torch.tensor([dt_dedup, dt_pair], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1686,7 +1703,9 @@ def main():
                 "Mnames_per_s_whole_job": n * world / float(tt.item()) / 1e6,
                 "bytes_exchanged_per_rank": n * 16,
                 "kernels_ms_rank0": {k: v[1] for k, v in pd.items() if k.startswith("k_") and v[0] > 0},
-                "pairing": {"what": "file-2 loop over all ranks (both files' names exchanged, runs classified on the owners)",
+                "pairing": {"what": "file-2 loop over all ranks, two distinct mate files, a rank's file-2 shard holding the mates of the "
+                                    "next rank's file-1 shard (both files' names exchanged, runs classified on the owners; configs[4])",
+                            "pairs_total": n * world, "config4_size": bool(a.config4),
                             "matched": pairing["matched"], "leftover": pairing["leftover"], "unpaired": pairing["unpaired"],
                             "ok": pairing["matched"] == n * world and pairing["first_unpaired"] is None,
                             "wall_ms_max_over_ranks": dt_pair * 1e3,
@@ -1741,7 +1760,8 @@ def main():
                     ctx.profile(False)
                     acc2.close()
                     assert r2["code"] == 0 and ir["code"] == 0 and ir["n_entries"] == n, (r2, ir)
-                    kern = {k: v[1] / max(1, v[0]) for k, v in p2.items() if k.startswith("k_") and v[0] > 0}
+                    # (totals of this one pass: a scope with several launches - the streaming pass in parts - counts whole)
+                    kern = {k: v[1] for k, v in p2.items() if k.startswith("k_") and v[0] > 0}
                     ki = kern.get("k_names_insert", kern.get("k_index_insert", 0.0)) + sum(v for k, v in kern.items() if k.startswith("k_names_build"))
                     total = sum(kern.values())
                     return idx, {
@@ -1767,7 +1787,7 @@ def main():
                     ctx.synchronize()
                     p3 = ctx.profile_read()
                     ctx.profile(False)
-                    k3 = {k: v[1] / max(1, v[0]) for k, v in p3.items() if k.startswith("k_") and v[0] > 0}
+                    k3 = {k: v[1] for k, v in p3.items() if k.startswith("k_") and v[0] > 0}
                     km = k3.get("k_names_match", k3.get("k_index_match_delete", 0.0))
                     d["file2_loop"] = {
                         "match_ms": km, "kernels_ms": k3, "all_kernels_ms": sum(k3.values()), "code": mr["code"],

@@ -757,13 +757,22 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
   // workers of part p - 1 (k_stream_pass1_lines), whose statistics wait in accumulators of the context until the whole
   // image has passed without a flag that sends it to the two-pass path.  FQGPU_STREAM_PARTS=1: one launch, as before.
   // (read per call: tests and A/B runs switch them inside one process)
-  const int parts_env = env_int_early("FQGPU_STREAM_PARTS", 3);
+  const int parts_env = env_int_early("FQGPU_STREAM_PARTS", 4);
   const int workers_env = env_int_early("FQGPU_STREAM_LINE_WORKERS", 1);  // line-worker workgroups per CU
   const uint32_t parts_min_spans = (uint32_t)std::max(env_int_early("FQGPU_STREAM_PARTS_MIN_SPANS", 24), 1);  // (16 MiB each)
   static const bool old_pass2_early = getenv("FQGPU_STREAM_PASS2_OLD") != nullptr;
-  uint32_t n_parts = (!want_names && !want_index && !old_pass2_early && rd.acc && n_spans >= parts_min_spans)
+  // (with the index wanted - the name modes - the line workers store it as they go, into room sized from the boot window)
+  uint32_t n_parts = ((want_names || !want_index) && !old_pass2_early && rd.acc && n_spans >= parts_min_spans)
                          ? (uint32_t)std::min(std::max(parts_env, 1), 4) : 1u;
   n_parts = std::min(n_parts, n_spans);
+  uint64_t early_line_cap = 0;
+  if (n_parts > 1 && want_index) {
+    // lines of the image from the lines of the boot window (the name modes have waited for it above), a quarter more
+    const uint32_t span = (uint32_t)std::min<uint64_t>(kStreamBootBytes, nbytes & ~255ull);
+    const double per_byte = (double)(c->h_cs->boot_lines + 4) / (double)std::max<uint32_t>(span, 1);
+    early_line_cap = (uint64_t)(per_byte * 1.25 * (double)nbytes) + 4096;
+    if ((rc = ensure(c, c->line_end, (size_t)early_line_cap * 8))) return rc;
+  }
   LinesArgs PA{};  // what the line workers inside the pass-1 launches go by (the rest comes from the call state)
   uint64_t todo_steps_cap = 0;
   if (n_parts > 1) {
@@ -790,8 +799,8 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     PA.cr.local = (const uint32_t*)c->tile_local.p;
     PA.cr.span_excl = (const unsigned long long*)c->span_sums.p;
     PA.stage = (const uint16_t*)c->stage.p;
-    PA.line_end = nullptr;
-    PA.line_cap = ~0ull;
+    PA.line_end = want_index ? (uint64_t*)c->line_end.p : nullptr;
+    PA.line_cap = want_index ? early_line_cap : ~0ull;
     PA.suspect_bits = sm.bits;
     PA.suspect_cap = sm.cap;
     PA.flags = sm.flags;
@@ -800,7 +809,7 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     PA.acc = c->pipe_acc;
     PA.hist = c->pipe_hist;
     PA.ablate = 0;
-    PA.no_index = 1u;
+    PA.no_index = want_index ? 0u : 1u;
     PA.index_only = 0u;
     PA.keep_from = ~0ull;
   }
@@ -808,22 +817,29 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     const uint32_t span_lo = (uint32_t)((uint64_t)n_spans * part / n_parts), span_hi = (uint32_t)((uint64_t)n_spans * (part + 1) / n_parts);
     const uint32_t chunk_lo = span_lo * kScanSpan, chunk_hi = std::min<uint32_t>(n_chunks, span_hi * kScanSpan);
     {
-      ProfScope ps(c, want_names == 2 ? "k_stream_pass1(digests)" : want_names ? "k_stream_pass1(names)" : part ? "k_stream_pass1_lines" : "k_stream_pass1");
+      ProfScope ps(c, want_names == 2 ? (part ? "k_stream_pass1_lines(digests)" : "k_stream_pass1(digests)")
+                      : want_names    ? (part ? "k_stream_pass1_lines(names)" : "k_stream_pass1(names)")
+                      : part          ? "k_stream_pass1_lines" : "k_stream_pass1");
       const unsigned blocks = (chunk_hi - chunk_lo + 3) / 4;
-      if (want_names == 2)
-        hipLaunchKernelGGL((k_stream_pass1<0u, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks, so, c->d_cs, nc);
-      else if (want_names)
-        hipLaunchKernelGGL((k_stream_pass1<0u, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks, so, c->d_cs, nc);
-      else if (part == 0)
-        hipLaunchKernelGGL((k_stream_pass1<0u, 0>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, chunk_hi, so, c->d_cs, nc);
-      else {
-        const unsigned workers = (unsigned)c->cu_count * (unsigned)std::min(std::max(workers_env, 1), 4);
-        hipLaunchKernelGGL(k_stream_pass1_lines, dim3(workers + blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, chunk_lo, chunk_hi, so,
-                           c->d_cs, PA, (uint8_t*)c->lines_slow.p, workers, part - 1);
-      }
+      const unsigned workers = (unsigned)c->cu_count * (unsigned)std::min(std::max(workers_env, 1), 4);
+#define FQG_PASS1_PART(N)                                                                                                    \
+  do {                                                                                                                       \
+    if (part == 0)                                                                                                           \
+      hipLaunchKernelGGL((k_stream_pass1<0u, N>), dim3(blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, chunk_hi, so,      \
+                         c->d_cs, nc);                                                                                       \
+    else                                                                                                                     \
+      hipLaunchKernelGGL(k_stream_pass1_lines<N>, dim3(workers + blocks), dim3(kBlock), 0, c->stream, d_img, nbytes, chunk_lo, \
+                         chunk_hi, so, c->d_cs, PA, (uint8_t*)c->lines_slow.p, workers, part - 1, nc);                        \
+  } while (0)
+      if (want_names == 2) FQG_PASS1_PART(2);
+      else if (want_names) FQG_PASS1_PART(1);
+      else FQG_PASS1_PART(0);
+#undef FQG_PASS1_PART
     }
     {
       ProfScope ps(c, "k_scan");
+      // (two launches: ONE, with the workgroup that finishes last doing phase B, was tried - the release fence every
+      // workgroup needs in front of its count writes the L2 back: 0.21 ms a step instead of 0.11)
       hipLaunchKernelGGL(k_scan_a, dim3(span_hi - span_lo), dim3(kBlock), 0, c->stream, (const uint32_t*)c->tile_counts.p,
                          n_chunks, (uint32_t*)c->tile_local.p, (unsigned long long*)c->span_sums.p, span_lo);
       hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->span_sums.p,
@@ -852,6 +868,9 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
   const uint64_t usable = (final || out->last_nl) ? n_lines_all : out->n_newlines;
   const uint64_t line_cap = n_lines_all + 17;
   const uint64_t limit = 4 * (usable / 4);
+  // (the parted pass of a name mode: its line workers have stored index entries already - into room sized from the
+  // boot window.  Too small after all: a new allocation, and their stores once more, below)
+  const bool index_lost = early_line_cap && (size_t)line_cap * 8 > c->line_end.cap;
   if ((rc = ensure(c, c->line_end, (size_t)line_cap * 8))) return rc;
   static const bool old_pass2 = getenv("FQGPU_STREAM_PASS2_OLD") != nullptr;  // (A/B: the chunk-owned second pass)
   if (old_pass2) {
@@ -941,8 +960,9 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
           c->lines_fast_per_cu = nb;
         }
         const unsigned grid_f = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_steps - std::min(done_steps, n_steps) + 3) / 4, (uint64_t)c->cu_count * c->lines_fast_per_cu));
-        if (done_steps && !lazy) {
-          // the index is wanted after all (pass 1 queued byte positions): the stores of the steps that are done
+        if (done_steps && !lazy && (!early_line_cap || index_lost)) {
+          // the index is wanted after all (pass 1 queued byte positions), or its room was too small: the stores of the
+          // steps that are done
           LinesArgs I = A;
           I.index_only = 1u;
           I.acc = nullptr;
@@ -989,7 +1009,10 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     // chunks whose speculated line type was wrong or missing: the two-pass kernel repeats the checks
     // with the true rank (no line-index stores)
     ProfScope ps(c, "k_stream_redo");
-    const unsigned grid = (unsigned)std::min<uint64_t>((n_chunks + 3) / 4, (uint64_t)c->cu_count * 8);
+    // (ordinary reads send a handful of chunks here - the ones whose speculation failed -, reads of kilobases a quarter of
+    // all: a grid that fills the GPU costs 0.06 ms to start and end for the former)
+    const double nlpc = (double)out->n_newlines / (double)std::max<uint32_t>(n_chunks, 1);
+    const unsigned grid = (unsigned)std::min<uint64_t>((n_chunks + 3) / 4, (uint64_t)c->cu_count * (nlpc >= 32.0 ? 1 : 8));
     hipLaunchKernelGGL(k_frame_fast_t<8u>, dim3(grid), dim3(kBlock), 0, c->stream, d_img, nbytes, n_chunks,
                        (const uint32_t*)c->tile_local.p, (const unsigned long long*)c->span_sums.p,
                        (uint64_t*)c->line_end.p, line_cap, limit, sm, c->d_cs, (const uint32_t*)c->redo.p,

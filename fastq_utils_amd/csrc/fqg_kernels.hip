@@ -149,12 +149,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_a(const uint32_t* __restrict__ 
 // phase B: one workgroup turns the span sums into exclusive prefixes in place
 // (first_block, part: spans [first_block, n_blocks) continue from what part - 1 left in the call state, and leave the
 // newline count up to here as part_newlines[part])
-__global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restrict__ block_sums,
-                                                   uint32_t n_blocks, const uint8_t* __restrict__ img,
-                                                   uint64_t n, CallState* __restrict__ cs, uint32_t first_block = 0, uint32_t part = 0) {
-  __shared__ unsigned long long s_part[kBlock];
-  __shared__ unsigned long long s_carry;
-  if (threadIdx.x == 0) s_carry = part ? cs->part_newlines[part - 1] : 0ull;
+__device__ __forceinline__ void scan_b_body(unsigned long long* __restrict__ block_sums, uint32_t n_blocks, const uint8_t* __restrict__ img,
+                                            uint64_t n, CallState* __restrict__ cs, uint32_t first_block, uint32_t part,
+                                            unsigned long long* s_part, unsigned long long* s_carry) {
+  if (threadIdx.x == 0) *s_carry = part ? cs->part_newlines[part - 1] : 0ull;
   __syncthreads();
   for (uint32_t base = first_block; base < n_blocks; base += kBlock) {
     const uint32_t i = base + threadIdx.x;
@@ -168,17 +166,26 @@ __global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restric
       s_part[threadIdx.x] += o;
       __syncthreads();
     }
-    const unsigned long long carry = s_carry;
+    const unsigned long long carry = *s_carry;
     if (i < n_blocks) block_sums[i] = carry + s_part[threadIdx.x] - v;
     __syncthreads();
-    if (threadIdx.x == kBlock - 1) s_carry = carry + s_part[kBlock - 1];
+    if (threadIdx.x == kBlock - 1) *s_carry = carry + s_part[kBlock - 1];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    cs->n_newlines = s_carry;
-    cs->part_newlines[part < 4u ? part : 3u] = s_carry;
+    cs->n_newlines = *s_carry;
+    cs->part_newlines[part < 4u ? part : 3u] = *s_carry;
     cs->last_byte_is_nl = (n > 0 && img[n - 1] == '\n') ? 1u : 0u;
   }
+}
+// (first_block, part: spans [first_block, n_blocks) continue from what part - 1 left in the call state, and leave the
+// newline count up to here as part_newlines[part])
+__global__ __launch_bounds__(kBlock) void k_scan_b(unsigned long long* __restrict__ block_sums,
+                                                   uint32_t n_blocks, const uint8_t* __restrict__ img,
+                                                   uint64_t n, CallState* __restrict__ cs, uint32_t first_block = 0, uint32_t part = 0) {
+  __shared__ unsigned long long s_part[kBlock];
+  __shared__ unsigned long long s_carry;
+  scan_b_body(block_sums, n_blocks, img, n, cs, first_block, part, s_part, &s_carry);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1389,16 +1389,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) 
 // to the two-pass path (NUL, CR, high bytes, a chunk with too many newlines) make them do nothing.  Their statistics go
 // to accumulators the caller merges once the whole image has passed (k_acc_merge): a later part can still raise a flag.
 // ------------------------------------------------------------------------------------------
+template <int NAMES>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stream_pass1_lines(
     const uint8_t* __restrict__ img, uint64_t n, uint32_t chunk_first, uint32_t n_chunks, StreamOut o, CallState* __restrict__ cs,
-    LinesArgs A, uint8_t* __restrict__ todo, uint32_t line_workers, uint32_t part /* whose lines: >= 0 */) {
+    LinesArgs A, uint8_t* __restrict__ todo, uint32_t line_workers, uint32_t part /* whose lines: >= 0 */, NameCapture nc) {
   union Lds {
-    Pass1Lds<0> p1;
+    Pass1Lds<NAMES> p1;
     LinesFastLds lf;
   };
   __shared__ Lds lds;
   if (blockIdx.x >= line_workers) {
-    stream_pass1_body<0u, 0>(img, n, n_chunks, o, cs, NameCapture{}, chunk_first / (kBlock / kWave) + (blockIdx.x - line_workers), lds.p1);
+    stream_pass1_body<0u, NAMES>(img, n, n_chunks, o, cs, nc, chunk_first / (kBlock / kWave) + (blockIdx.x - line_workers), lds.p1);
     return;
   }
   // ---- a line worker: the steps of part `part`, from what the scans have left in the call state ----

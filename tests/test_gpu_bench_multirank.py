@@ -13,13 +13,16 @@ from tests.util import REPO, free_port, run_group
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_two_ranks_on_one_device(ranks):
+    """(8: the shape of the driver's eight-GPU run - every rank's file-2 shard holds the mates of the next rank's file-1
+    shard, BASELINE configs[4] - at a million reads a rank)"""
     env = dict(os.environ, FQGPU_BENCH_ONE_DEVICE="1")
+    reads = 1000000 if ranks == 8 else 2000000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
-           "--reads", "2000000"]
-    check_line(run_group(cmd, 600, cwd=REPO, env=env), ranks)
+           "--reads", str(reads)]
+    check_line(run_group(cmd, 900, cwd=REPO, env=env), ranks, reads)
 
 
 def test_bench_starts_its_own_ranks():
@@ -32,7 +35,7 @@ def test_bench_starts_its_own_ranks():
     check_line(run_group(cmd, 600, cwd=REPO, env=env), 2)
 
 
-def check_line(p, ranks):
+def check_line(p, ranks, reads=2000000):
     assert p.returncode == 0, p.stderr.decode("latin-1")[-2000:]
     lines = [ln for ln in p.stdout.decode("latin-1").splitlines() if ln.startswith("{")]
     # the measured line once before the extra and once, complete, as the LAST line; the extra as a line of its own
@@ -45,5 +48,5 @@ def check_line(p, ranks):
     x = json.loads(lines[1])
     assert x["extra"] == "dedup_extra"
     assert "error" not in x, x
-    assert x["names_total"] == ranks * 2000000 and x["finding"] is None
-    assert x["pairing"]["ok"] and x["pairing"]["matched"] == ranks * 2000000
+    assert x["names_total"] == ranks * reads and x["finding"] is None
+    assert x["pairing"]["ok"] and x["pairing"]["matched"] == ranks * reads and x["pairing"]["pairs_total"] == ranks * reads

@@ -145,3 +145,48 @@ def test_incomplete_tail_and_piecewise_input():
             acc.close()
             r = ctx.validate(cut, None, st, final=True, flags=A.VALIDATE_NO_STATS)
             assert r["code"] != 0 and r["record"] == 209_999  # the truncated last record
+
+
+@pytest.mark.parametrize("mode", ["digests", "records"])
+def test_name_modes_in_parts(mode):
+    """FQG_VALIDATE_NAMES / _NAME_DIGESTS want the line index: the line workers of the parted pass store it as they go
+    (room sized from the boot window).  The index calls behind such a frame give what they give behind a one-launch
+    pass and through the line index alone: entries, accounted bytes, a duplicate, a wrong header; a second file finds
+    every name of the first."""
+    n = 200_000
+    recs = image(21, n, 150, 150)
+    clean = b"".join(recs)
+    k = n // 3
+    dup = b"".join(recs[:n - 9] + [recs[k]] + recs[n - 9:])
+    wrong = b"".join(recs[:k] + [b"X" + recs[k][1:]] + recs[k + 1:])
+    flags = A.VALIDATE_NAME_DIGESTS if mode == "digests" else A.VALIDATE_NAMES
+    with fq.Context(0) as ctx:
+        for img in (clean, dup, wrong):
+            st = A.probe_first_record(img, False)
+            got = []
+            for parts, fl in ((4, flags), (1, flags), (1, 0)):
+                os.environ["FQGPU_STREAM_PARTS"] = str(parts)
+                acc = ctx.accumulator()
+                r = ctx.validate(img, acc, st, flags=A.VALIDATE_COUNT_TWICE | fl)
+                idx = ctx.name_index(n + 16)
+                if mode == "digests":
+                    idx.expect_lookups(False)
+                ir = idx.insert_unique(st)
+                cap = idx.names_captured()
+                assert (cap > 0.9 * n) == (fl != 0), (cap, parts, fl)
+                s = acc.read()
+                mr = None
+                if mode == "records" and img is clean:
+                    ctx.validate(img, None, st, flags=A.VALIDATE_NO_STATS | fl)
+                    m = idx.match_delete(st)
+                    mr = (m["code"], m["n_entries"])
+                got.append((r["code"], r["record"], r["n_records"], s["num_rds"], ir["code"], ir["record"], ir["n_entries"], ir["index_mem"], mr))
+                idx.close()
+                acc.close()
+            assert got[0] == got[1] == got[2], got
+            if img is clean:
+                assert got[0][4] == 0 and got[0][6] == n and got[0][3] == 2 * n
+                if mode == "records":
+                    assert got[0][8] == (0, 0)
+            else:
+                assert got[0][4] != 0 or got[0][0] != 0
