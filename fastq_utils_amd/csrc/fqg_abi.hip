@@ -89,7 +89,6 @@ struct fqg_ctx {
   hipStream_t out_stream = nullptr;   // fqg_barcodes_output_begin: device-to-host copies beside the next piece's upload
   hipEvent_t out_ready = nullptr;     // ... recorded on `stream` where the output was produced
   bool out_pending = false;
-  uint64_t umi_replay_lds = 0, umi_cells_lds = 0;  // dynamic LDS sizes k_rl_replay / k_umi_cells have been allowed (fqg_umi_abi.inc)
   hipStream_t stream = nullptr;
   std::string err;
   int cu_count = 256;
@@ -266,6 +265,27 @@ struct ProfScope {
 };
 
 void umi_drop_state(fqg_ctx* c);  // fqg_umi_abi.inc
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the FUNCTION ON A DEVICE, not to a context: two contexts of one
+// device (FQGPU_DEVICES=0,0,0) share it.  The largest size asked for so far is kept per (device, kernel) for the whole
+// process and only ever raised - a context that needs less never lowers what another one is about to launch with - and
+// the attribute is set when (and only when) the mark moves, not per call.
+int raise_dynamic_lds(fqg_ctx* c, const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<std::pair<int, const void*>, size_t>> marks;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t* mark = nullptr;
+  for (auto& m : marks)
+    if (m.first.first == c->device && m.first.second == kernel) mark = &m.second;
+  if (!mark) {
+    marks.push_back({{c->device, kernel}, 0});
+    mark = &marks.back().second;
+  }
+  if (bytes <= *mark) return 0;
+  HIP_TRY(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  *mark = bytes;
+  return 0;
+}
 
 int grid_for_waves(fqg_ctx* c, uint64_t n_records) {
   // persistent wave-per-record kernels: enough workgroups to fill every CU 8 deep

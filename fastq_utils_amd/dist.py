@@ -347,10 +347,13 @@ def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=No
     npieces = [t for o in range(world) for t in (n1[o] + n2[o])]
     send_names = torch.cat(npieces) if npieces else torch.empty(0, dtype=torch.uint8, device=dev)
     send_counts = [a + b for a, b in zip(c1, c2)]
+    # (memory: 16 bytes a pair + 64 a name, sent and received - 160 bytes a record at the peak if everything lived at once;
+    # every buffer goes as soon as its exchange is over: 80 + 64 at the peak.  The owner's set copies the names once more)
     recv, recv_counts = exchange_fingerprints(send, send_counts, group)
+    del send, pieces, p1, p2
     recv_names, name_counts = exchange_fingerprints(send_names, send_counts, group, record_bytes=NAME_BYTES)
     assert name_counts == recv_counts
-    del send, send_names, pieces, npieces, p1, p2, n1, n2
+    del send_names, npieces, n1, n2
     n_recv = sum(recv_counts)
     fps = ctx.fingerprint_set(max(1024, n_recv))
     try:

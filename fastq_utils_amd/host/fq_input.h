@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -203,7 +204,8 @@ class ExitQuiesce {
     live_.emplace_back(who, stop);
     if (!hooked_) {
       hooked_ = true;
-      atexit([] { ExitQuiesce::get().stop_all(); });
+      // (on_exit, glibc: the handler learns the status exit() was called with - it needs it when it gives up waiting)
+      on_exit([](int status, void*) { ExitQuiesce::get().stop_all(status); }, nullptr);
     }
   }
   void remove(void* who) {
@@ -214,14 +216,42 @@ class ExitQuiesce {
         return;
       }
   }
-  void stop_all() {
+  // Stops and joins every live reader - for at most kPatience: a reader blocked in read() / gzread() on a pipe that
+  // has stalled (stdin, a slow upstream) only sees its stop flag when the read returns, and a program that leaves on its
+  // first finding must not hang in exit() behind it.  When the patience runs out the process ends at once with the
+  // status it was leaving with (_exit: no further handlers - the runtime's teardown is exactly what must not run beside
+  // a thread that is still inside a HIP call).
+  void stop_all(int status) {
     std::vector<std::pair<void*, StopFn>> all;
     {
       std::lock_guard<std::mutex> lk(mu_);
       all.swap(live_);
     }
-    for (auto& e : all) e.second(e.first);
+    if (all.empty()) return;
+    struct Wait {
+      std::mutex mu;
+      std::condition_variable cv;
+      bool done = false;
+    };
+    auto w = std::make_shared<Wait>();
+    std::thread t([all, w] {
+      for (auto& e : all) e.second(e.first);
+      {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->done = true;
+      }
+      w->cv.notify_all();
+    });
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      if (!w->cv.wait_for(lk, std::chrono::seconds(kPatienceSeconds), [&] { return w->done; })) {
+        fflush(nullptr);
+        _exit(status);
+      }
+    }
+    t.join();
   }
+  static constexpr int kPatienceSeconds = 3;
 
  private:
   std::mutex mu_;

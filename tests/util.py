@@ -101,7 +101,8 @@ class SideBySide:
 # suite 2.5 times slower).  The sweeps that run EVERY golden invocation again under another configuration measure the
 # box first - 24 starts, side by side - and on a slow one take every second or third invocation of their list (chosen
 # by a hash of the arguments, so the same ones every time; the sweep of the default configuration always runs them
-# all).  FQGPU_TEST_THIN=1 runs everything whatever the box, =2 / =3 force the thinning (how the path itself is tested).
+# all).  Since round 6 the thinning is OPT-IN (FQGPU_TEST_THIN=auto measures the box, =2 / =3 force it): by default every
+# sweep runs every invocation, whatever the box.
 _THIN = None
 
 
@@ -128,19 +129,21 @@ def start_rate():
 
 
 def sweep_thinning():
-    """1: every invocation; 2, 3: every second / third one (a slow box, or FQGPU_TEST_THIN)"""
+    """1: every invocation (the default since round 6: a box that runs less than the builder's is no longer decided
+    silently); FQGPU_TEST_THIN=2 / 3: every second / third one; =auto: measure the box's program starts and thin below 10
+    a second, as rounds 4 - 5 did by themselves"""
     global _THIN
     if _THIN is None:
-        forced = os.environ.get("FQGPU_TEST_THIN")
-        if forced:
-            _THIN = max(1, int(forced))
-        else:
+        forced = os.environ.get("FQGPU_TEST_THIN", "")
+        if forced == "auto":
             rate = start_rate()
             _THIN = 1 if rate >= 10.0 or rate == 0.0 else 2 if rate >= 5.0 else 3
             if _THIN > 1:
                 import warnings
                 warnings.warn(f"this box starts {rate:.1f} programs a second: the repeated golden sweeps take every "
-                              f"{'second' if _THIN == 2 else 'third'} invocation (FQGPU_TEST_THIN=1 runs them all)")
+                              f"{'second' if _THIN == 2 else 'third'} invocation (FQGPU_TEST_THIN=auto)")
+        else:
+            _THIN = max(1, int(forced)) if forced else 1
     return _THIN
 
 

@@ -20,13 +20,13 @@ def per_kernel(path, counter):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("fqg::", "")
             agg[name].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 
 def main():
     fetch, write, image_bytes = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-    fc = per_kernel(sys.argv[4], "FETCH_SIZE") if len(sys.argv) > 4 else f
+    (f, fn), (w, _) = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    fc = per_kernel(sys.argv[4], "FETCH_SIZE")[0] if len(sys.argv) > 4 else f
     calib = image_bytes / (fc["k_count_nl"] * 1024.0) if "k_count_nl" in fc else None  # (None: no calibration kernel in these runs)
     import hashlib
     import os
@@ -42,7 +42,7 @@ def main():
             continue
         rd = f.get(k, 0.0) * 1024.0 * 2.0
         wr = w.get(k, 0.0) * 1024.0
-        out["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr}
+        out["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr, "launches": fn.get(k, 0)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
