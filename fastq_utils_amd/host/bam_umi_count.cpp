@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/fqg.h"
+#include "umi_multi.h"
 
 namespace {
 
@@ -272,7 +273,55 @@ int main(int argc, char* argv[]) {
   }
   fqg_umi_result res;
   prm.strict_set = getenv("FQGPU_UMI_STRICT_SET") ? 1 : 0;  // an extra: UMI sets as src/range_list.h documents them
-  LIB(fqg_umi_count(g_ctx, stream.data(), stream.size(), FQG_MEM_HOST, offsets.data(), n_rec, &prm, &res));
+  // FQGPU_DEVICES=0,1,..: a file that is read cell by cell goes over several GPUs by cell range (umi_multi.h).
+  // Whatever that path does not take - a finding, a file that is not grouped by cell, a limit - runs on one device as
+  // before: its words are the reference's.
+  fqhost::UmiMultiResult multi;
+  {
+    std::vector<int> devs;
+    if (const char* e = getenv("FQGPU_DEVICES"))
+      for (const char* p = e; *p;) {
+        char* q = nullptr;
+        const long v = strtol(p, &q, 10);
+        if (q == p) break;
+        devs.push_back((int)v);
+        p = *q == ',' ? q + 1 : q;
+      }
+    if (devs.size() > 1 && bam_sorted_by_cell && n_rec) {
+      std::vector<fqg_ctx*> ctxs{g_ctx};
+      for (size_t i = 1; i < devs.size(); ++i) {
+        fqg_ctx* c = nullptr;
+        if (fqg_open(devs[i], &c) != 0) {
+          PRINT_ERROR("FQGPU_DEVICES: device %d is not a usable MI355X GPU", devs[i]);
+          leave(2);
+        }
+        ctxs.push_back(c);
+      }
+      multi = fqhost::umi_count_multi(ctxs, stream, offsets, n_rec, used, prm);
+      if (getenv("FQGPU_UMI_MULTI_DEBUG"))
+        fprintf(stderr, "[umi multi] %s%s\n", multi.ok ? "counted over the devices" : "one device: ", multi.ok ? "" : multi.why.c_str());
+      for (size_t i = 1; i < ctxs.size(); ++i) fqg_close(ctxs[i]);
+    }
+  }
+  if (multi.ok) {
+    memset(&res, 0, sizeof(res));
+    res.n_alignments = multi.n_alignments;
+    res.n_tags_found = multi.n_tags_found;
+    res.n_umis_discarded = multi.n_umis_discarded;
+    res.n_cells_discarded = multi.n_cells_discarded;
+    res.n_features = multi.features.size();
+    res.n_cells = multi.cells.size();
+    for (int w = 0; w < 2; ++w) {
+      res.n_entries[w] = multi.entries[w].size();
+      res.total[w] = multi.total[w];
+    }
+    res.tot_reads = multi.tot_reads;
+    res.tot_umi = multi.tot_umi;
+    res.rl_replayed = multi.rl_replayed;
+    res.rl_changed = multi.rl_changed;
+    res.rl_undefined = multi.rl_undefined;
+  } else
+    LIB(fqg_umi_count(g_ctx, stream.data(), stream.size(), FQG_MEM_HOST, offsets.data(), n_rec, &prm, &res));
   if (res.rl_unresolved) {  // never silently different from the reference
     fprintf(stderr, "\nERROR: bam_umi_count: a UMI set could not be replayed within this build's limits\n");
     leave(2);
@@ -354,12 +403,19 @@ int main(int argc, char* argv[]) {
 
   std::vector<char> names(res.n_features * 25 + 25);
   std::vector<uint64_t> cells(res.n_cells);
-  LIB(fqg_umi_features(g_ctx, names.data(), res.n_features));
-  LIB(fqg_umi_cells(g_ctx, cells.data(), res.n_cells));
   std::vector<fqg_umi_entry> ent[2];
-  for (int w = 0; w < 2; ++w) {
-    ent[w].resize(res.n_entries[w]);
-    LIB(fqg_umi_entries(g_ctx, w, ent[w].data(), ent[w].size()));
+  if (multi.ok) {
+    for (size_t i = 0; i < multi.features.size(); ++i) strncpy(&names[i * 25], multi.features[i].c_str(), 24);
+    cells = multi.cells;
+    ent[0] = multi.entries[0];
+    ent[1] = multi.entries[1];
+  } else {
+    LIB(fqg_umi_features(g_ctx, names.data(), res.n_features));
+    LIB(fqg_umi_cells(g_ctx, cells.data(), res.n_cells));
+    for (int w = 0; w < 2; ++w) {
+      ent[w].resize(res.n_entries[w]);
+      LIB(fqg_umi_entries(g_ctx, w, ent[w].data(), ent[w].size()));
+    }
   }
   auto put_lines = [](FILE* fd, const std::vector<fqg_umi_entry>& v) {
     for (const auto& e : v) fprintf(fd, "%u %u %u\n", e.row, e.col, e.value);

@@ -22,6 +22,23 @@
 #include "fq_multi.h"
 #include "fq_parallel.h"
 
+// SURVEY 5 "metrics", as bin/fastq_info has it: FQGPU_JSON_METRICS=<file> writes the machine-readable twin of the
+// "Reads processed / discarded" lines - the command line and both output streams stay the reference's
+static const std::chrono::steady_clock::time_point g_pb_start = std::chrono::steady_clock::now();
+static void pb_json_metrics(long processed, long discarded, size_t devices) {
+  const char* jm = getenv("FQGPU_JSON_METRICS");
+  if (!jm) return;
+  FILE* jf = fopen(jm, "w");
+  if (!jf) return;
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_pb_start).count();
+  const unsigned long long bytes = fqhost::bytes_handed_out().load();
+  fprintf(jf, "{\"program\": \"fastq_pre_barcodes\", \"reads\": %ld, \"discarded\": %ld, \"input_bytes\": %llu, \"seconds\": %.6f, "
+              "\"Mreads_per_s\": %.3f, \"GB_per_s\": %.3f, \"devices\": %zu}\n",
+          processed, discarded, bytes, secs, secs > 0 ? (double)processed / secs / 1e6 : 0.0, secs > 0 ? (double)bytes / secs / 1e9 : 0.0,
+          devices ? devices : (size_t)1);
+  fclose(jf);
+}
+
 using namespace fqhost;
 
 namespace {
@@ -482,6 +499,7 @@ struct BlockRun {
         fqhost::leave(kExitSys);
       }
   fflush(stdout);
+  pb_json_metrics((long)processed, (long)discarded, nd);
   fqhost::leave(0);
 }
 
@@ -938,5 +956,6 @@ int main(int argc, char** argv) {
         fqhost::leave(kExitSys);
       }
   fflush(stdout);
+  pb_json_metrics((long)processed, (long)discarded, 1);
   fqhost::leave(0);
 }

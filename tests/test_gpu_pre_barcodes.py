@@ -525,3 +525,23 @@ def test_fast_gzip_output_inflates_to_the_same_text():
             sizes[tag] = os.path.getsize(os.path.join(tmp, out))
         assert texts["fast"] == texts["zlib"] and len(texts["zlib"]) > 1000000
         assert sizes["fast"] != sizes["zlib"] and sizes["fast"] < 1.3 * sizes["zlib"]
+
+
+def test_json_metrics_twin_of_the_summary():
+    """FQGPU_JSON_METRICS (an extra): the machine-readable twin of "Reads processed / discarded" in a file of
+    its own - stdout and stderr stay the reference's (compared with the oracle here)"""
+    rng = np.random.default_rng(9)
+    r1, r2 = make_10x(rng, 4000)
+    with tempfile.TemporaryDirectory() as d:
+        files = {"r1.fastq": r1, "r2.fastq": r2}
+        for name, img in files.items():
+            with open(os.path.join(d, name), "wb") as f:
+                f.write(img)
+        args = V2 + ["--sam", "--outfile1", "-"]
+        jm = os.path.join(d, "m.json")
+        rc, out, err = run(BIN, args, d, {"FQGPU_JSON_METRICS": jm})
+        want = pbo.run_pre_barcodes(args, lambda n: files[n])
+        assert rc == want["exit"] == 0 and out == want["stdout"] and strip_progress(err) == strip_progress(want["stderr"])
+        m = json.load(open(jm))
+        assert m["program"] == "fastq_pre_barcodes" and m["reads"] == 4000 and m["devices"] == 1
+        assert "INFO:Reads discarded: %d" % m["discarded"] in err and m["seconds"] > 0 and m["input_bytes"] >= len(r1) + len(r2)

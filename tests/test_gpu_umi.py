@@ -476,3 +476,92 @@ def test_record_index_resident_on_the_device(ctx):
     assert a["code"] == b["code"] == c["code"] == 0
     for k in ("entries", "features", "cells", "n_counted", "n_new", "rl_replayed"):
         assert a[k] == b[k] == c[k], k
+
+
+# ---- bin/bam_umi_count over several contexts (FQGPU_DEVICES; host/umi_multi.h: the cell-range protocol of
+# dist.umi_count_sharded inside the drop-in program) ---------------------------------------------------------------
+def multi_case_run(i):
+    case = CLI_CASES[i]
+    with tempfile.TemporaryDirectory(dir=GOLD) as tmp:
+        rel = os.path.relpath(tmp, GOLD)
+        real = [a.replace("OUTU", rel + "/u.mtx").replace("OUTR", rel + "/r.mtx") for a in case["args"]]
+        p = subprocess.run(["bam_umi_count"] + real, executable=BIN, cwd=GOLD, capture_output=True, timeout=300,
+                           env=dict(os.environ, FQGPU_DEVICES="0,0,0"))
+        got = {}
+        for base in ("u.mtx", "r.mtx"):
+            for ext in ("", "_rows", "_cols"):
+                path = os.path.join(tmp, base + ext)
+                if os.path.exists(path):
+                    got["SCRATCH/" + base + ext] = open(path, "rb").read().decode("latin-1")
+    return p.returncode, p.stderr.decode("latin-1").replace(rel + "/", "SCRATCH/"), got
+
+
+MULTI_RUNS = SideBySide(multi_case_run, range(len(CLI_CASES)))
+
+
+@pytest.mark.parametrize("i", range(len(CLI_CASES)), ids=[" ".join(c["args"])[:80] for c in CLI_CASES])
+def test_cli_over_three_contexts_matches_reference_binary(i):
+    """every golden invocation once more with FQGPU_DEVICES=0,0,0: the files of the reference binary, byte for byte -
+    whether the cells went over the contexts or the program fell back to one (findings, unsorted input, one cell)"""
+    case = CLI_CASES[i]
+    rc, err, got = MULTI_RUNS.get(i)
+    assert (rc if rc >= 0 else 128 - rc) == want_exit(case), err[-400:]
+    if case["exit"] == -6:
+        assert "Assertion `len1+1 < FEAT_ID_MAX_LEN' failed" in err
+        return
+    assert err == case["stderr"]
+    if case["exit"] == 0:
+        assert got == golden_files(case)
+
+
+@pytest.mark.parametrize("variant", ["plain", "nh", "multi", "noise", "whitelist", "thresholds", "dense"])
+def test_program_over_contexts_against_the_oracle(variant):
+    """seeded CR-sorted BAMs with re-used UMIs (the RL_Tree's defects: rounds 2 and 3 of the protocol), NH weights and
+    several genes per alignment (the float32 chain of totals, shard after shard): the program with 2 and 3 contexts
+    writes the oracle's files and says the oracle's stderr - and it did go over the contexts"""
+    rng = np.random.default_rng(abs(hash("m" + variant)) % 9999)
+    for trial in range(2):
+        kw = dict(n_cells=int(rng.integers(8, 80)), genes=int(rng.integers(5, 300)), umi_len=int(rng.integers(2, 9)),
+                  reads_per_cell=(1, int(rng.integers(2, 300))))
+        if variant == "dense":   # few genes, few UMIs, many reads: nearly every set is replayed as the tree behaves
+            kw = dict(n_cells=int(rng.integers(20, 60)), genes=3, umi_len=3, reads_per_cell=(100, 400))
+        if variant in ("nh", "multi", "noise"):
+            kw["nh"] = True
+        if variant in ("multi", "noise"):
+            kw["multi_gx"] = True
+        if variant == "noise":
+            kw["noise"] = True
+        bam, stream = bamgen.tagged_bam(rng, **kw)
+        extra = []
+        files = {"in.bam": bam}
+        if variant == "thresholds":
+            extra += ["--min_reads", "2", "--min_umis", "2"]
+        if variant == "whitelist":
+            cells = []
+            for tid, flag, aux in uo.bam_records(stream):
+                c = uo.get_tag(aux, b"CR")
+                if c and c not in cells:
+                    cells.append(c)
+            files["wl.txt"] = b"".join(c + b"\n" for c in cells[::2])
+            extra += ["--known_cells", "wl.txt"]
+        want = uo.run_bam_umi_count(["--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"] + extra, files.get)
+        for devs in ("0,0", "0,0,0"):
+            with tempfile.TemporaryDirectory() as tmp:
+                for name, data in files.items():
+                    with open(os.path.join(tmp, name), "wb") as f:
+                        f.write(data)
+                p = subprocess.run(["bam_umi_count", "--bam", "in.bam", "--ucounts", "u", "--rcounts", "r"] + extra, executable=BIN,
+                                   cwd=tmp, capture_output=True, timeout=300,
+                                   env=dict(os.environ, FQGPU_DEVICES=devs, FQGPU_UMI_MULTI_DEBUG="1"))
+                err = p.stderr.decode("latin-1")
+                went = "[umi multi] counted over the devices" in err
+                err = "".join(ln for ln in err.splitlines(True) if not ln.startswith("[umi multi]"))
+                assert p.returncode == want["exit"], err[-500:]
+                assert err == want["stderr"], (variant, devs)
+                if want["exit"] == 0:
+                    assert went, (variant, devs, p.stderr.decode("latin-1")[-300:])
+                    for name, text in want["files"].items():
+                        if name in files:   # (the inputs)
+                            continue
+                        have = open(os.path.join(tmp, name), "rb").read()
+                        assert (have if isinstance(text, bytes) else have.decode("latin-1")) == text, (variant, devs, name)
