@@ -1843,6 +1843,7 @@ def main():
             extra("read_shapes_extra", lambda: shapes_extra(ctx, fq, torch, dev))
             torch.cuda.empty_cache()
         if world == 1 and not a.no_barcodes_extra:
+            ctx.release_scratch()  # (the 200 M-pair leg needs nearly all of the 288 GB: what earlier legs left in the context goes)
             extra("pre_barcodes_extra", lambda: barcodes_extra(ctx, fq, torch, dev, a.barcode_pairs, programs=not a.no_e2e))
             torch.cuda.empty_cache()
         if world == 1 and not a.no_umi_extra:

@@ -27,7 +27,7 @@ CODE_NAMES = {
 # every symbol include/fqg.h declares (checked by tests/test_abi_symbols.py against the header)
 EXPORTS = [
     "fqg_open", "fqg_close", "fqg_last_error", "fqg_abi_version", "fqg_set_stream",
-    "fqg_synchronize", "fqg_host_alloc", "fqg_host_free", "fqg_probe_readname_format",
+    "fqg_synchronize", "fqg_release_scratch", "fqg_host_alloc", "fqg_host_free", "fqg_probe_readname_format",
     "fqg_probe_space", "fqg_probe_first_record", "fqg_acc_create", "fqg_acc_destroy",
     "fqg_acc_reset", "fqg_acc_read", "fqg_acc_hist_nonzero", "fqg_acc_median", "fqg_acc_export",
     "fqg_acc_merge", "fqg_validate", "fqg_frame_records", "fqg_profile_enable",
@@ -609,6 +609,10 @@ class Context:
                                      flags, C.byref(res))
         self._check(rc)
         return res.as_dict()
+
+    def release_scratch(self):
+        """give the device buffers the context keeps between calls back (the current frame goes with them)"""
+        self._check(load().fqg_release_scratch(self.h))
 
     def retain_frame(self):
         return Frame(self)

@@ -459,6 +459,37 @@ void fqg_host_free(fqg_ctx* c, void* p) {
   if (p) (void)hipHostFree(p);
 }
 
+// Everything the context keeps between calls only so that the next call does not allocate again - the framing buffers
+// of the largest image seen, capture records, the tile kernels' plan and output text - given back to the device.
+// The current frame goes with them (retained frames own their buffers and stay).
+int fqg_release_scratch(fqg_ctx* c) {
+  if (!c) return FQG_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->out_pending) {
+    const int rcw = fqg_barcodes_output_wait(c);
+    if (rcw) return rcw;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (DevBuf* b : {&c->image, &c->tile_counts, &c->tile_local, &c->span_sums, &c->line_end, &c->records, &c->suspect, &c->list,
+                    &c->stage, &c->cinfo, &c->queue, &c->redo, &c->lines_slow, &c->build_keys[0], &c->build_keys[1],
+                    &c->build_cursor, &c->build_spill, &c->name_recs, &c->name_hcount, &c->name_redo, &c->name_redo_chunks,
+                    &c->bc_status, &c->bc_tile_big})
+    release(*b);
+  for (int i = 0; i < 3; ++i) {
+    release(c->bc_len[i]);
+    release(c->bc_off[i]);
+    release(c->bc_sum[i]);
+    release(c->bc_out[i]);
+    c->bc_out_bytes[i] = 0;
+  }
+  c->frame_valid = false;
+  c->frame_borrowed = false;
+  c->lazy.pending = false;
+  c->names_img = nullptr;
+  c->bc_status_valid = 0;
+  return 0;
+}
+
 // ---- accumulator --------------------------------------------------------------------------
 int fqg_acc_reset(fqg_acc* a) {
   if (!a) return FQG_ERR_ARG;
@@ -1546,7 +1577,8 @@ void launch_names_pass(fqg_ctx* c, bool match, const FrameView& fv, const IndexV
 constexpr unsigned long long kBuildSpillCap = 1ull << 20;
 int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_state* st, uint64_t record_base) {
   const int mode = env_int("FQGPU_NAMES_BUILD", -1);  // 0: never, 1: whenever the table allows it (tests), -1: by size
-  if (mode == 0 || !c->names.digests) return 1;
+  if (mode == 0) return 1;
+  const bool from_records = !c->names.digests;  // (an index that keeps name records: keys and names[] from the capture records)
   uint32_t k = 0;
   while ((1ull << k) < ix->capacity) ++k;
   if (k < kPartLogMin + 1) return 1;
@@ -1582,8 +1614,13 @@ int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_s
   {
     ProfScope ps(c, "k_names_build_scatter0");
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_slots + kBuildTile - 1) / kBuildTile, (uint64_t)c->cu_count * 8));
-    hipLaunchKernelGGL(k_build_scatter<0>, dim3(grid), dim3(kBuildThreads), 0, c->stream, fv, c->names, record_base, mask, L0,
-                       (const BuildKey*)nullptr, (const unsigned int*)nullptr, 0ull, c->d_icall);
+    if (from_records)
+      hipLaunchKernelGGL(k_build_scatter<2>, dim3(grid), dim3(kBuildThreads), 0, c->stream, fv, c->names, record_base, mask, L0,
+                         (const BuildKey*)nullptr, (const unsigned int*)nullptr, 0ull, c->d_icall,
+                         ix->keep_names ? (NameRec*)ix->names.p : (NameRec*)nullptr, st->readname_format, st->is_pe);
+    else
+      hipLaunchKernelGGL(k_build_scatter<0>, dim3(grid), dim3(kBuildThreads), 0, c->stream, fv, c->names, record_base, mask, L0,
+                         (const BuildKey*)nullptr, (const unsigned int*)nullptr, 0ull, c->d_icall, (NameRec*)nullptr, 0, 0);
   }
   const BuildKey* part_keys = L0.out;
   const unsigned int* part_count = cur0;
@@ -1593,7 +1630,7 @@ int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_s
     ProfScope ps(c, "k_names_build_scatter1");
     const unsigned tiles = (unsigned)((cap0 + kBuildTile - 1) / kBuildTile);
     hipLaunchKernelGGL(k_build_scatter<1>, dim3(tiles, 1u << bits0), dim3(kBuildThreads), 0, c->stream, fv, c->names, record_base, mask, L1,
-                       (const BuildKey*)L0.out, (const unsigned int*)cur0, cap0, c->d_icall);
+                       (const BuildKey*)L0.out, (const unsigned int*)cur0, cap0, c->d_icall, (NameRec*)nullptr, 0, 0);
     part_keys = L1.out;
     part_count = cur1;
     part_cap = cap1;
@@ -1613,8 +1650,11 @@ int names_build(fqg_ctx* c, fqg_index* ix, const FrameView& fv, const fqg_file_s
                        (const BuildKey*)c->build_spill.p, kBuildSpillCap, c->d_icall);
   }
   if ((rc = index_fetch_call(c))) return rc;
+  // (gigabytes that only this call needs: a context that keeps them is what the next large allocation of the process
+  // fails on - the bench's 200 M-pair leg did, with 4 GB free of 288)
+  release(c->build_keys[0]);
+  release(c->build_keys[1]);
   if (c->h_icall->build_overflow) return 1;
-  (void)st;
   return 0;
 }
 

@@ -151,17 +151,21 @@ __device__ __forceinline__ void build_scatter_tile(const BuildKey (&key)[PER], c
 
 constexpr int kBuildPer = kBuildTile / kBuildThreads;  // 8
 
-// LEVEL 0: from the digests of the streaming pass (the logic of k_names_pass<insert, DIGEST>); LEVEL 1: from the buckets
-// level 0 wrote (in: n_in buckets of `in_cap`, in_count[] keys each; blockIdx.y = input bucket)
+// LEVEL 0: from the digests of the streaming pass (the logic of k_names_pass<insert, DIGEST>); LEVEL 2: the same from its
+// 64-byte capture RECORDS - an index that keeps name records (file 1 of a pair): the name is decoded here
+// (name_from_record) and its record written to names[g] as insert_name writes it; LEVEL 1: from the buckets level 0 / 2
+// wrote (in: n_in buckets of `in_cap`, in_count[] keys each; blockIdx.y = input bucket)
 template <int LEVEL>
 __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_build_scatter(FrameView f, NamesView nv, uint64_t base, uint64_t mask, BuildLevel L,
                                                           const BuildKey* __restrict__ in, const unsigned int* __restrict__ in_count,
-                                                          unsigned long long in_cap, IndexCall* __restrict__ call) {
+                                                          unsigned long long in_cap, IndexCall* __restrict__ call,
+                                                          NameRec* __restrict__ names_out = nullptr, int fmt = 0, int is_pe = 0) {
   __shared__ BuildKey s_stage[kBuildTile];
   __shared__ uint8_t s_bkt[kBuildTile];  // (at most kBuildMaxBuckets = 256 buckets per level)
   __shared__ uint32_t s_cnt[kBuildMaxBuckets], s_ofs[kBuildMaxBuckets], s_gbase[kBuildMaxBuckets], s_wave[kBuildThreads / kWave];
   IndexTally t;
-  if (LEVEL == 0) {
+  if (LEVEL == 0 || LEVEL == 2) {
+    constexpr bool RECORDS = LEVEL == 2;
     // what a slot's digest is worth depends on its CHUNK (was the speculated line type the true one, how many headers
     // did it see, its first rank): a tile's chunks - 4096 / K of them - are looked up once, into LDS, and the tile's 16
     // digest loads per thread are requested together, without a condition (slots nobody wrote hold whatever the
@@ -174,10 +178,12 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t chunks_per_tile = kBuildTile >> nv.k_shift;  // (K >= 8)
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       u64x2_t dg[kBuildPer];
+      if (!RECORDS) {
 #pragma unroll
-      for (int i = 0; i < kBuildPer; ++i) {
-        const uint64_t s = tile * kBuildTile + (uint64_t)i * kBuildThreads + threadIdx.x;
-        dg[i] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(nv.recs + (s < n_slots ? s : n_slots - 1) * kDigestWords));
+        for (int i = 0; i < kBuildPer; ++i) {
+          const uint64_t s = tile * kBuildTile + (uint64_t)i * kBuildThreads + threadIdx.x;
+          dg[i] = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(nv.recs + (s < n_slots ? s : n_slots - 1) * kDigestWords));
+        }
       }
       for (uint32_t ci = threadIdx.x; ci < chunks_per_tile; ci += kBuildThreads) {
         const uint64_t c64 = tile * chunks_per_tile + ci;
@@ -206,7 +212,51 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(4
         const uint32_t hc = s_hc[ci];
         bool lv = s < n_slots && hc != kNoCapture && j < hc, redo = false;
         key[i].h = key[i].g = 0;
-        if (lv) {
+        if (lv && RECORDS) {
+          unsigned long long w[kNameRecWords];
+          const u64x2_t* src = reinterpret_cast<const u64x2_t*>(nv.recs + s * kNameRecWords);
+#pragma unroll
+          for (uint32_t q = 0; q < kNameRecWords / 2; ++q) {
+            const u64x2_t x = __builtin_nontemporal_load(src + q);
+            w[2 * q] = x.x;
+            w[2 * q + 1] = x.y;
+          }
+          NameKey k;
+          bool at_sign;
+          uint32_t v;
+          const bool ok = name_from_record(w, fmt, is_pe, k, &at_sign, &v);
+          const uint64_t r = (s_rank0[ci] + v) >> 2;
+          if (r >= f.n_records) lv = false;  // a header of the incomplete tail
+          else if (!ok) {
+            redo = true;
+            lv = false;
+          } else {
+            ++t.captured;
+            ++t.seen;
+            if (names_out) {  // (a record without '@' or with a repeated name gets one too: nothing will ever point at it)
+              u64x2_t* dst = reinterpret_cast<u64x2_t*>(names_out + (base + r));
+              u64x2_t x;
+              x.x = k.n;
+              x.y = k.nm[0];
+              __builtin_nontemporal_store(x, dst);
+#pragma unroll
+              for (uint32_t q = 1; q < 4; ++q) {
+                x.x = k.nm[2 * q - 1];
+                x.y = k.nm[2 * q];
+                __builtin_nontemporal_store(x, dst + q);
+              }
+            }
+            if (!at_sign) {  // fastq_get_readname refuses it (src/fastq.c:448)
+              t.first_wrong = r < t.first_wrong ? r : t.first_wrong;
+              lv = false;
+            } else {
+              key[i].h = k.h;
+              key[i].g = base + r;
+              ++t.inserted;
+              t.name_bytes += k.acct;
+            }
+          }
+        } else if (lv) {
           const uint32_t meta = (uint32_t)dg[i].y;
           const uint64_t r = (s_rank0[ci] + ((meta >> 20) & 511u)) >> 2;
           if (r >= f.n_records) lv = false;  // a header of the incomplete tail

@@ -86,6 +86,18 @@ inline std::string aux_z(const uint8_t* rec, const uint8_t* end, const char tag[
   return "";
 }
 
+// does the alignment loop get as far as the cell with this record?  (src/bam_umi_count.c:946-960: mapped, a feature tag,
+// a UMI tag - the filters that come before the cell is looked at; whitelists come after and only drop cells)
+inline bool reaches_the_cell(const uint8_t* rec, const uint8_t* end, const fqg_umi_params& prm) {
+  if (rec + 36 > end) return false;
+  int32_t tid;
+  uint16_t flag;
+  memcpy(&tid, rec + 4, 4);
+  memcpy(&flag, rec + 4 + 14, 2);
+  if (tid < 0 || (flag & 4u)) return false;
+  return !aux_z(rec, end, prm.feat_tag).empty() && !aux_z(rec, end, prm.umi_tag).empty();
+}
+
 struct Shard {
   fqg_ctx* ctx = nullptr;
   uint64_t lo = 0, hi = 0;               // records [lo, hi) of the file
@@ -155,16 +167,27 @@ inline UmiMultiResult umi_count_multi(const std::vector<fqg_ctx*>& ctxs, const s
   // ---- the cuts: where the CR value changes, at or behind the even split ----
   std::vector<uint64_t> cut{0};
   for (size_t d = 1; d < ctxs.size(); ++d) {
-    // (records without the tag - unmapped reads, whatever the aligner left untagged - belong to no cell: the value in
-    // front of a cut is that of the nearest record before it that has one)
+    // (only records the alignment loop takes as far as the cell say where a cell begins: an unmapped read, a read
+    // without a feature or a UMI, carries whatever CR it carries; the value in front of a cut is that of the nearest
+    // such record before it)
     uint64_t i = std::max<uint64_t>(n_rec * d / ctxs.size(), cut.back() + 1);
     std::string before;
-    for (uint64_t b = i; b-- > cut.back() && before.empty();) before = aux_z(base + offsets[b], end, prm0.cell_tag);
+    bool have_before = false;
+    // (a record whose CR this walk does not find - aux fields libbam reads differently than this parser, no tag at all -
+    // is no place for a cut and says nothing about the cell in front of one: the merge of the shards' cell lists is
+    // what vouches for the cuts, whatever they were made from)
+    for (uint64_t b = i; b-- > cut.back() && !have_before;)
+      if (reaches_the_cell(base + offsets[b], end, prm0)) {
+        before = aux_z(base + offsets[b], end, prm0.cell_tag);
+        have_before = !before.empty();
+      }
     for (; i < n_rec; ++i) {
+      if (!reaches_the_cell(base + offsets[i], end, prm0)) continue;
       const std::string here = aux_z(base + offsets[i], end, prm0.cell_tag);
       if (here.empty()) continue;
-      if (!before.empty() && here != before) break;
+      if (have_before && here != before) break;
       before = here;
+      have_before = true;
     }
     if (i >= n_rec) break;
     cut.push_back(i);

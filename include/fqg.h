@@ -104,6 +104,12 @@ int fqg_acc_median(fqg_acc *a, fqg_acc *b, uint64_t *median);
 int fqg_acc_export(fqg_acc *acc, void *buf, size_t cap, size_t *used);
 int fqg_acc_merge(fqg_acc *acc, const void *buf, size_t used);
 
+/* A context keeps the device buffers of its calls (framing tables of the largest image seen, capture records, the plan
+ * and the output text of the tile kernels ...) so that the next call does not allocate again.  fqg_release_scratch gives
+ * them back - between phases of a program that needs the memory for something else (the next phase allocates what it
+ * needs again).  The context's current frame goes with them; retained frames, indexes, accumulators and censuses stay. */
+int fqg_release_scratch(fqg_ctx *ctx);
+
 /* ---- framing + validation ---------------------------------------------------------------
  * Replaces the read/validate loop: fastq_read_entry() (src/fastq.c:245-261) for every record
  * of the image followed by fastq_validate_entry() (src/fastq.c:300-392), as driven by

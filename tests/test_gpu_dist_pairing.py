@@ -202,6 +202,6 @@ def test_names_decide_where_fingerprints_collide():
     from tests.util import REPO
 
     p = subprocess.run([sys.executable, "-m", "tests.weak_fp_pairing"], cwd=REPO, capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, FQGPU_FP_WEAK_BITS="10"))
+                       env=dict(os.environ, FQGPU_FP_WEAK_BITS="10", FQGPU_FP_WEAK_UNNAMED="1"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "names_travel: as the serial loop" in p.stdout and "fingerprints_alone: NOT as the serial loop" in p.stdout, p.stdout

@@ -250,7 +250,7 @@ def test_digests_give_what_records_and_the_line_index_give(style, build):
                 st = fq.abi.probe_first_record(image, False)
                 got = []
                 for flags, lookups in ((fq.abi.VALIDATE_NAME_DIGESTS, False), (fq.abi.VALIDATE_NAMES, False), (0, False),
-                                       (fq.abi.VALIDATE_NAME_DIGESTS, True)):
+                                       (fq.abi.VALIDATE_NAME_DIGESTS, True), (fq.abi.VALIDATE_NAMES, True)):
                     r = ctx.validate(image, None, st, flags=fq.abi.VALIDATE_NO_STATS | flags)
                     idx = ctx.name_index(expect)
                     if not lookups:
@@ -259,11 +259,17 @@ def test_digests_give_what_records_and_the_line_index_give(style, build):
                     cap = idx.names_captured()
                     if r["path"] == 3 and flags == fq.abi.VALIDATE_NAME_DIGESTS and not lookups:
                         assert cap > 0.5 * n, (cap, n)  # the digests are what ran
-                    if flags == 0 or lookups:
+                    if flags == 0 or (lookups and flags == fq.abi.VALIDATE_NAME_DIGESTS):
                         assert cap == 0, cap  # (digests hold no bytes: an index that keeps names reads the lines)
                     got.append((ir["code"], ir["record"], ir["n_entries"], ir["index_mem"]))
+                    if lookups and flags == fq.abi.VALIDATE_NAMES and image is clean:
+                        # the table a build from the capture RECORDS left (keys + name records) answers a second file:
+                        # every name found, on its bytes, nothing left
+                        ctx.validate(image, None, st, flags=fq.abi.VALIDATE_NO_STATS | flags)
+                        mr = idx.match_delete(st)
+                        assert mr["code"] == 0 and mr["n_entries"] == 0, mr
                     idx.close()
-                assert got[0] == got[1] == got[2] == got[3], (style, got)
+                assert got[0] == got[1] == got[2] == got[3] == got[4], (style, got)
             # two frames into one index: the second one's parts are merged with what the table holds; a name of the
             # first frame again in the second is the second frame's finding
             half = b"".join(recs[:n // 2])

@@ -190,3 +190,28 @@ def test_name_modes_in_parts(mode):
                     assert got[0][8] == (0, 0)
             else:
                 assert got[0][4] != 0 or got[0][0] != 0
+
+
+def test_the_program_on_pieces_that_are_cut_into_parts():
+    """bin/fastq_info on a 140 MB file in pieces of 64 MiB, every piece through the parted pass (four spans each with
+    FQGPU_STREAM_PARTS_MIN_SPANS=3): -r, the default mode (name digests + the parted pass storing the line index) and a
+    pair, clean and with a finding late in the file - stdout, stderr and status of the oracle's serial loops"""
+    import tempfile
+
+    from tests.test_gpu_cli import compare_all
+    n = 400_000
+    recs = image(31, n, 150, 150, name=b"SYN:1:FC:%d:%d 1:N:0:ACGT")
+    mates = [r.replace(b" 1:N:0:", b" 2:N:0:", 1) for r in recs]
+    k = int(n * 0.9)
+    p = recs[k].index(b"\n")
+    files = {"a.fastq": b"".join(recs), "b.fastq": b"".join(mates),
+             "bad.fastq": b"".join(recs[:k] + [recs[k][:p + 9] + b"X" + recs[k][p + 10:]] + recs[k + 1:]),
+             "dup.fastq": b"".join(recs[:k] + [recs[5]] + recs[k:]),
+             "m.fastq": b"".join(mates[:k] + mates[k + 1:])}
+    env = {"FQGPU_STREAM_PARTS_MIN_SPANS": "3", "FQGPU_CHUNK_MB": "64", "FQGPU_STREAM_PARTS": "4"}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, img in files.items():
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(img)
+        compare_all([(tmp, args, files, env) for args in (["-r", "a.fastq"], ["a.fastq"], ["-r", "bad.fastq"], ["bad.fastq"],
+                                                           ["dup.fastq"], ["a.fastq", "b.fastq"], ["a.fastq", "m.fastq"])])

@@ -519,7 +519,8 @@ def test_program_over_contexts_against_the_oracle(variant):
     """seeded CR-sorted BAMs with re-used UMIs (the RL_Tree's defects: rounds 2 and 3 of the protocol), NH weights and
     several genes per alignment (the float32 chain of totals, shard after shard): the program with 2 and 3 contexts
     writes the oracle's files and says the oracle's stderr - and it did go over the contexts"""
-    rng = np.random.default_rng(abs(hash("m" + variant)) % 9999)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("m" + variant).encode()) % 9999)  # (the same files in every run: not hash())
     for trial in range(2):
         kw = dict(n_cells=int(rng.integers(8, 80)), genes=int(rng.integers(5, 300)), umi_len=int(rng.integers(2, 9)),
                   reads_per_cell=(1, int(rng.integers(2, 300))))
