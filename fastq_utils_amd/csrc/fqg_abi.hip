@@ -2276,7 +2276,8 @@ int fqg_barcodes_census(fqg_ctx* c, fqg_census* z, const fqg_frame* const frames
   HIP_TRY(c, hipMemsetAsync(z->d_count, 0, 8, c->stream));
   {
     ProfScope ps(c, "k_bc_census");
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + kBlock - 1) / kBlock, (uint64_t)c->cu_count * 16));
+    const uint64_t tile = (uint64_t)kBlock * kCensusPer;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_done + tile - 1) / tile, (uint64_t)c->cu_count * 16));
     hipLaunchKernelGGL(k_bc_census, dim3(grid), dim3(kBlock), 0, c->stream, P, n_done, (const uint8_t*)c->bc_status.p,
                        (unsigned long long*)z->cells.p, (unsigned long long*)z->umis.p, (unsigned long long)z->n_pairs,
                        (unsigned long long)(z->cells.cap / 8), z->d_count);
