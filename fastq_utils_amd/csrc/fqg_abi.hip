@@ -1432,6 +1432,7 @@ struct fqg_index {
   uint64_t inserted = 0, matched = 0, name_bytes = 0;
   int fmt = FQG_NAME_UNDEF, is_pe = 0;
   uint32_t flags = 0;
+  bool names_once = true;        // no insert has reported a repeated name or a header without '@' (IndexView::n_positional)
 };
 
 namespace {
@@ -1451,6 +1452,8 @@ IndexView index_view(fqg_index* ix) {
   v.names = ix->keep_names ? (NameRec*)ix->names.p : nullptr;
   v.claims = (unsigned long long*)ix->claims.p;
   v.mask = ix->capacity - 1;
+  static const bool no_positional = getenv("FQGPU_NO_POSITIONAL_MATCH") != nullptr;  // (measurement, tests)
+  v.n_positional = ix->keep_names && ix->names.p && ix->names_once && !no_positional ? ix->n_records_total : 0;
   v.segs = (const IndexSeg*)ix->segs_dev.p;
   v.n_segs = (int)ix->segs.size();
   v.fmt = ix->fmt;
@@ -1796,6 +1799,7 @@ int fqg_index_insert_unique(fqg_ctx* c, fqg_index* ix, const fqg_file_state* st,
     out->code = FQG_E_DUP_NAME;
     out->record = d;
   }
+  if (w != kNoRecord || d != kNoRecord) ix->names_once = false;
   out->n_entries = ix->inserted;
   // sizeof(hashtable) + per entry sizeof(INDEX_ENTRY) + len + 1 + sizeof(hashnode)
   out->index_mem = 8 + ix->inserted * (16 + 1 + 24) + ix->name_bytes;
@@ -2112,8 +2116,11 @@ int fqg_barcodes_transform(fqg_ctx* c, const fqg_frame* const frames[6], const f
   const uint64_t nb_done = (n_done + kScan64Span - 1) / kScan64Span;
   {
     ProfScope ps(c, "k_bc_scan");
-    hipLaunchKernelGGL(k_bc_count, dim3((unsigned)std::min<uint64_t>((n_done + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0,
-                       c->stream, (const uint8_t*)c->bc_status.p, n_done, c->d_bcall);
+    if (n_done != n_iter) {  // (the plan counted the discards of all n_iter iterations)
+      HIP_TRY(c, hipMemsetAsync(&c->d_bcall->discarded, 0, 2 * sizeof(unsigned long long), c->stream));
+      hipLaunchKernelGGL(k_bc_count, dim3((unsigned)std::min<uint64_t>((n_done + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0,
+                         c->stream, (const uint8_t*)c->bc_status.p, n_done, c->d_bcall);
+    }
     HIP_TRY(c, hipMemsetAsync(d_tot, 0, 3 * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < 3; ++i) {
       if (P.out_sam ? i != 0 : !P.emit[i]) continue;  // outputs that are not produced have no lengths

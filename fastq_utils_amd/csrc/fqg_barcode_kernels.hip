@@ -587,7 +587,12 @@ __device__ __forceinline__ bc_u32x4 bc_span_unit(const SpanPlan& sp, uint32_t u)
   u = u < sp.units ? u : (sp.units ? sp.units - 1 : 0u);  // (no unit at all: unit 0 of READ1's image, never stored)
   const uint8_t* base = sp.gbase[1];  // (the staged file that comes first has first_unit 0: READ1, or the loop finds it)
 #pragma unroll
-  for (int x = 2; x < kBcFiles; ++x) base = u >= sp.first_unit[x] ? sp.gbase[x] : base;
+  for (int x = 2; x < kBcFiles; ++x) {
+    // (a VALUE on either side: "c ? sp.gbase[x] : base" is an lvalue - the compiler selects between the two ADDRESSES and
+    // loads once, the plan stays in scratch memory, and every unit of the any-set-of-files kernels waited for that load)
+    const uint8_t* const gx = sp.gbase[x];
+    base = u >= sp.first_unit[x] ? static_cast<const uint8_t*>(gx) : static_cast<const uint8_t*>(base);
+  }
   return __builtin_nontemporal_load(reinterpret_cast<const bc_u32x4*>(base + 16ull * u));
 }
 // units from_unit .. of the tile -> s_in, 8 loads in flight per lane
@@ -688,8 +693,11 @@ __device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLi
 // holds little, so many wavefronts are resident.  The name checks, which need the header bytes of every file, are made
 // by the emit kernels on the records they stage anyway (bc_check_names).  What the plan decides per emit tile - does
 // the tile fit the emit kernel's LDS areas - is worked out per group of T lanes.  MASK: see bc_has.
+// (MASK 0, any set of files: five files' lines and index entries are 233 registers - two wavefronts per SIMD, and no
+// index of a second tile in flight; 3 wavefronts: 244 bytes of scratch memory per lane and 4.7 ms instead of 3.6 on 50 M
+// iterations of four files)
 template <int MASK>
-__global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
+__global__ __launch_bounds__(kWave, MASK == 0 ? 2 : 1) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
                                                         uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
                                                         uint32_t* __restrict__ len2, uint8_t* __restrict__ tile_big,
                                                         BcCall* __restrict__ call) {
@@ -711,14 +719,19 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
   // (Many wavefronts are resident here - little LDS, ~100 registers - and hide each other's round trips: the three-tile
   // scheme of the emit kernel, which costs 70 registers, made this kernel slower, 7.7 -> 11.2 ms.)
   TileGeo cur, nxt;
-  if (blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
+  uint32_t n_dropped = 0, n_short = 0;  // of this wavefront's tiles: added to the call's totals once, at the end
+  // (The kernel for any set of files has no registers for the index of a second tile - five files' worth: it asks for a
+  // tile's index when it gets there.)
+  constexpr bool kAhead = MASK != 0;
+  if (kAhead && blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t k0 = tile * Tp;
     const uint32_t Tn = tile_size(tile);
     const bool valid = (uint32_t)lane < Tn;
     const uint64_t k = k0 + (valid ? (uint32_t)lane : Tn - 1);
     BcLine L[kBcFiles][4];
-    geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);  // the next tile's index (requested without a branch)
+    if (kAhead) geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);  // the next tile's index (requested without a branch)
+    else geo_of(tile, cur);
     // (an image with NUL bytes: lines are C strings, found by scanning them where they lie - bc_lines)
     const bool fit = !P.has_nul && bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -746,8 +759,10 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
       a = b = c = 0;
     }
     const unsigned long long none = ~0ull;
-    const unsigned long long dsc =
-        wave_min64(valid && (st == kBcDiscardShort || st == kBcDiscardQual) ? (unsigned long long)k : none);
+    const bool dropped = valid && (st == kBcDiscardShort || st == kBcDiscardQual);
+    n_dropped += dropped ? 1u : 0u;
+    n_short += valid && st == kBcDiscardShort ? 1u : 0u;
+    const unsigned long long dsc = wave_min64(dropped ? (unsigned long long)k : none);
     // the emit tiles inside this plan tile
     for (uint32_t j = 0; j * tc.T < Tn; ++j) {
       const uint32_t first = j * tc.T, last = (first + tc.T < Tn ? first + tc.T : Tn) - 1;
@@ -764,7 +779,14 @@ __global__ __launch_bounds__(kWave) void k_bc_plan_tile(BcParams P, BcTile tc, u
     if (lane == 0 && dsc != none && dsc < __atomic_load_n(&call->first_discard, __ATOMIC_RELAXED))
       atomicMin(&call->first_discard, dsc);
     __builtin_amdgcn_wave_barrier();
-    cur = nxt;
+    if (kAhead) cur = nxt;
+  }
+  // the discarded iterations of all n_iter (k_bc_count counts again when the batch ends earlier: interleaved input)
+  n_dropped = wave_sum32(n_dropped);
+  n_short = wave_sum32(n_short);
+  if (lane == 0) {
+    if (n_dropped) atomicAdd(&call->discarded, (unsigned long long)n_dropped);
+    if (n_short) atomicAdd(&call->short_warnings, (unsigned long long)n_short);
   }
 }
 
@@ -809,16 +831,27 @@ __global__ __launch_bounds__(kBlock) void k_bc_count(const uint8_t* __restrict__
 
 // ---- 64-bit exclusive scan of u32 lengths: 2048 per workgroup ---------------------------------
 constexpr int kScan64Span = kBlock * 8;
+typedef unsigned long long bc_u64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void scan64_a_body(const uint32_t* __restrict__ in, uint64_t n,
                                               unsigned long long* __restrict__ local,
                                               unsigned long long* __restrict__ sums) {
   __shared__ unsigned long long s_w[kBlock / kWave];
   const uint64_t first = (uint64_t)blockIdx.x * kScan64Span + threadIdx.x * 8;
+  // a span that lies inside the array (all but the last one), arrays on 16-byte addresses: the lane's eight lengths in two
+  // loads, its eight offsets in four stores
+  const bool whole = ((uint64_t)blockIdx.x + 1) * kScan64Span <= n && (((uintptr_t)in | (uintptr_t)local) & 15u) == 0;
   unsigned long long v[8], sum = 0;
+  if (whole) {
+    const bc_u32x4 a = *reinterpret_cast<const bc_u32x4*>(in + first), b = *reinterpret_cast<const bc_u32x4*>(in + first + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i] = first + i < n ? in[first + i] : 0u;
-    sum += v[i];
+    for (int i = 0; i < 8; ++i) sum += v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = first + i < n ? in[first + i] : 0u;
+      sum += v[i];
+    }
   }
   unsigned long long incl = sum;
 #pragma unroll
@@ -835,10 +868,21 @@ __device__ __forceinline__ void scan64_a_body(const uint32_t* __restrict__ in, u
     all += s_w[w];
   }
   unsigned long long run = before + incl - sum;
+  if (whole) {
+    unsigned long long o[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (first + i < n) local[first + i] = run;
-    run += v[i];
+    for (int i = 0; i < 8; ++i) {
+      o[i] = run;
+      run += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) *reinterpret_cast<bc_u64x2*>(local + first + i) = bc_u64x2{o[i], o[i + 1]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (first + i < n) local[first + i] = run;
+      run += v[i];
+    }
   }
   if (threadIdx.x == 0) sums[blockIdx.x] = all;
 }
@@ -849,30 +893,44 @@ __global__ __launch_bounds__(kBlock) void k_scan64_a(const uint32_t* __restrict_
   scan64_a_body(in, n, local, sums);
 }
 
+// (2048 sums per round - eight per thread, a wavefront scan by shuffles, one exchange through LDS: the scan of the
+// 97 656 span sums of 200 M lengths took 0.49 ms as 382 rounds of a 256-wide scan with sixteen barriers each)
 __device__ __forceinline__ void scan64_b_body(unsigned long long* __restrict__ sums, uint64_t nb,
                                               unsigned long long* __restrict__ total) {
-  __shared__ unsigned long long s_part[kBlock];
-  __shared__ unsigned long long s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (uint64_t base = 0; base < nb; base += kBlock) {
-    const uint64_t i = base + threadIdx.x;
-    const unsigned long long v = i < nb ? sums[i] : 0ull;
-    s_part[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < kBlock; d <<= 1) {
-      const unsigned long long o = threadIdx.x >= (unsigned)d ? s_part[threadIdx.x - d] : 0ull;
-      __syncthreads();
-      s_part[threadIdx.x] += o;
-      __syncthreads();
+  __shared__ unsigned long long s_w[kBlock / kWave];
+  unsigned long long carry = 0;  // (the same in every thread)
+  for (uint64_t base = 0; base < nb; base += kScan64Span) {
+    const uint64_t first = base + threadIdx.x * 8;
+    unsigned long long v[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = first + i < nb ? sums[first + i] : 0ull;
+      sum += v[i];
     }
-    const unsigned long long carry = s_carry;
-    if (i < nb) sums[i] = carry + s_part[threadIdx.x] - v;
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = __shfl_up(incl, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
     __syncthreads();
-    if (threadIdx.x == kBlock - 1) s_carry = carry + s_part[kBlock - 1];
-    __syncthreads();
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      if (w < (int)(threadIdx.x >> 6)) before += s_w[w];
+      all += s_w[w];
+    }
+    unsigned long long run = carry + before + incl - sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (first + i < nb) sums[first + i] = run;
+      run += v[i];
+    }
+    carry += all;
+    __syncthreads();  // (s_w is written again in the next round)
   }
-  if (threadIdx.x == 0) *total = s_carry;
+  if (threadIdx.x == 0) *total = carry;
 }
 __global__ __launch_bounds__(kBlock) void k_scan64_b(unsigned long long* __restrict__ sums, uint64_t nb,
                                                      unsigned long long* __restrict__ total) {

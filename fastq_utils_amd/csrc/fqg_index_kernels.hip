@@ -55,6 +55,9 @@ struct IndexView {
   NameRec* names;              // per inserted record (global index); null: not kept (an index nobody will ask)
   unsigned long long* claims;  // per inserted record, match-and-delete only (may be null)
   uint64_t mask;               // capacity - 1 (capacity is a power of two)
+  uint64_t n_positional;       // match-and-delete: records 0 .. n_positional - 1 have name records and every name in the
+                               // table is there once (no insert has reported a repeat or a header without '@'), so a
+                               // record whose name is the asker's IS the asker's entry - see match_name; 0: always probe
   const IndexSeg* segs;
   int n_segs;
   int fmt, is_pe;  // read-name format / is_pe of the file the index was built from
@@ -437,23 +440,15 @@ __device__ __forceinline__ void match_name(const IndexView& ix, const NameKey& k
     return;
   }
   const unsigned long long g2 = asker_base + r;
-  uint64_t at = k.h & ix.mask;
-  for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
-    const unsigned long long cur = ix.slots[at];
-    if (cur == kSlotEmpty) break;
-    if ((cur >> 40) != (k.h >> 40)) continue;
-    const unsigned long long g = cur & kIdxMask;
-    bool same;
-    if (ix.names) {
-      const u64x2_t* src = reinterpret_cast<const u64x2_t*>(ix.names + g);
-      const u64x2_t a = src[0], b = src[1], c = src[2], d = src[3];
-      same = a.x == k.n && !((a.y ^ k.nm[0]) | (b.x ^ k.nm[1]) | (b.y ^ k.nm[2]) | (c.x ^ k.nm[3]) | (c.y ^ k.nm[4]) |
-                             (d.x ^ k.nm[5]) | (d.y ^ k.nm[6]));
-      if (same && k.n > kNameInline) same = stored_name_is(ix, g, NameAt{f, r}(), k.n);
-    } else {
-      same = stored_name_is(ix, g, NameAt{f, r}(), k.n);
-    }
-    if (!same) continue;
+  auto record_has_name = [&](unsigned long long g) {
+    const u64x2_t* src = reinterpret_cast<const u64x2_t*>(ix.names + g);
+    const u64x2_t a = src[0], b = src[1], c = src[2], d = src[3];
+    bool same = a.x == k.n && !((a.y ^ k.nm[0]) | (b.x ^ k.nm[1]) | (b.y ^ k.nm[2]) | (c.x ^ k.nm[3]) | (c.y ^ k.nm[4]) |
+                                (d.x ^ k.nm[5]) | (d.y ^ k.nm[6]));
+    if (same && k.n > kNameInline) same = stored_name_is(ix, g, NameAt{f, r}(), k.n);
+    return same;
+  };
+  auto take = [&](unsigned long long g) {
     // the smallest asker gets the entry; every other asker is what the serial loop would have found missing
     // after the delete.  An asker of an EARLIER piece is smaller than every record of this one, so `late`
     // always lies in this piece.
@@ -464,6 +459,24 @@ __device__ __forceinline__ void match_name(const IndexView& ix, const NameKey& k
       t.first_missing = late < t.first_missing ? late : t.first_missing;
     }
     if (found) found[r] = g;
+  };
+  // The mate files of a sequencing run hold their reads in the same order: the partner of record i is record i.  Its
+  // name record lies next to the ones the neighbouring lanes ask for - a sequential read - where the way through the
+  // table is a load from a random slot first.  The bytes decide here as they do there, and while every name of the
+  // table is in it once (n_positional), the record that has the asker's name is the entry the table would have led
+  // to; an asker whose name is not at its own place goes through the table.
+  if (g2 < ix.n_positional && record_has_name(g2)) {
+    take(g2);
+    return;
+  }
+  uint64_t at = k.h & ix.mask;
+  for (uint64_t probes = 0; probes <= ix.mask; ++probes, at = (at + 1) & ix.mask) {
+    const unsigned long long cur = ix.slots[at];
+    if (cur == kSlotEmpty) break;
+    if ((cur >> 40) != (k.h >> 40)) continue;
+    const unsigned long long g = cur & kIdxMask;
+    if (!(ix.names ? record_has_name(g) : stored_name_is(ix, g, NameAt{f, r}(), k.n))) continue;
+    take(g);
     return;
   }
   t.first_missing = r < t.first_missing ? r : t.first_missing;

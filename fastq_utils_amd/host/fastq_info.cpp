@@ -109,6 +109,7 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
   std::vector<Dev> D(devs.size());
   D[0].ctx = g_ctx;  // (opened on devs[0])
   D[0].acc = S.acc1;
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: opening %zu more contexts %.3f s after the program started\n", devs.size() - 1, since_start());
   for (size_t i = 1; i < devs.size(); ++i) {
     const int rc = fqg_open(devs[i], &D[i].ctx);
     if (rc != 0) {
@@ -134,10 +135,25 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
   bool rerun_serial = false, probe_printed = false;
   {
     AlignedPieces src(g_ctx, path, piece, (int)(2 * devs.size() + 2));
+    const bool timing = getenv("FQGPU_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto work = [&](size_t di) {
+      double t_wait = 0, t_gpu = 0;
+      uint64_t n = 0;
+      struct Report {
+        bool on;
+        size_t di;
+        const double &w, &g;
+        const uint64_t& n;
+        ~Report() {
+          if (on) fprintf(fqhost::diag(), "fqgpu timing: context %zu: %llu pieces; waiting for a piece %.3f s, copy + validate %.3f s; %.3f s since the program started\n",
+                          di, (unsigned long long)n, w, g, since_start());
+        }
+      } report{timing, di, t_wait, t_gpu, n};
       for (;;) {
         Done d;
         fqg_file_state st;
+        const double t0 = timing ? now() : 0;
         {
           std::lock_guard<std::mutex> lk(fetch_mu);
           if (exhausted || stop || !src.next(&d.p)) {
@@ -148,7 +164,9 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
           probe_piece(pr, d.p.data, d.p.size, 1);  // piece 0 is handed out first: the state is the first record's
           st = pr.st;
         }
+        const double t1 = timing ? now() : 0;
         d.rc = fqg_validate(D[di].ctx, D[di].acc, d.p.data, d.p.size, FQG_MEM_HOST, d.p.final ? 1 : 0, &st, 0, &d.r);
+        if (timing) t_wait += t1 - t0, t_gpu += now() - t1, ++n;
         if (d.rc) d.err = fqg_last_error(D[di].ctx);
         else if (!d.p.final && d.r.code == FQG_OK && !d.r.stopped && d.r.consumed != d.p.size) {
           d.rc = FQG_ERR_ARG;

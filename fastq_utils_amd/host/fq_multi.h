@@ -67,6 +67,9 @@ class AlignedPieces {
     }
     cv_.notify_all();
     if (producer_.joinable()) producer_.join();
+    if (getenv("FQGPU_TIMING"))
+      fprintf(fqhost::diag(), "fqgpu timing: piece cutter: %llu slots filled; waiting for a free slot %.3f s, pinning %.3f s, reading + counting lines %.3f s, cutting %.3f s\n",
+              (unsigned long long)t_slots_, t_wait_, t_pin_, t_read_, t_cut_);
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     pgzip_report(pgz_.get(), path_);
@@ -121,17 +124,20 @@ class AlignedPieces {
       std::atomic<bool> bad{false};
       auto part = [&](unsigned t) {
         const size_t a = (len * t / T) & ~(size_t)4095, b = t + 1 == T ? len : (len * (t + 1) / T) & ~(size_t)4095;
+        // (256 KiB at a time: the lines are counted while the bytes are still in this core's cache - counting the part
+        // after reading all of it is a second pass over memory)
         size_t done = a;
+        uint64_t c = 0;
         while (done < b) {
-          const ssize_t got = pread(plain_fd_, dst + done, b - done, (off_t)(plain_off_ + done));
+          const ssize_t got = pread(plain_fd_, dst + done, std::min<size_t>(b - done, 256u << 10), (off_t)(plain_off_ + done));
           if (got <= 0) {
             bad = true;
             return;
           }
+          const char* const end = dst + done + (size_t)got;
+          for (const char* p = dst + done; (p = (const char*)memchr(p, '\n', (size_t)(end - p))) != nullptr; ++p) ++c;
           done += (size_t)got;
         }
-        uint64_t c = 0;
-        for (const char* p = dst + a; (p = (const char*)memchr(p, '\n', (size_t)(dst + b - p))) != nullptr; ++p) ++c;
         cnt[t] = c;
       };
       if (T <= 1) part(0);
@@ -211,9 +217,12 @@ class AlignedPieces {
     bool at_end = false;
     uint64_t seq = 0;
     uint64_t raw_before = 0;    // bytes of the file before the raw bytes being read
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (!at_end) {
+      const double t0 = now();
       const int si = free_slot();
       if (si < 0) return;
+      const double t1 = now();
       Slot& s = slots_[(size_t)si];
       if (!s.buf) {
         s.buf = slot_alloc(ctx_, cap_ + kTail + 1);
@@ -222,9 +231,18 @@ class AlignedPieces {
           return;
         }
       }
+      const double t2 = now();
       uint64_t nl = 0;
       const size_t len = read_some(s.buf, cap_, &at_end, &nl);
       if (failed_) return;
+      const double t3 = now();
+      t_wait_ += t1 - t0, t_pin_ += t2 - t1, t_read_ += t3 - t2, ++t_slots_;
+      struct Cut {
+        double& acc;
+        double from;
+        std::function<double()> clock;
+        ~Cut() { acc += clock() - from; }
+      } cut_timer{t_cut_, t3, now};
       // where the first record of these bytes starts: at the first line whose number is a multiple of four
       uint64_t skip_lines = (4 - lines_before % 4) % 4;
       if (mid_line && skip_lines == 0) skip_lines = 4;
@@ -311,6 +329,8 @@ class AlignedPieces {
   std::unique_ptr<ReaderPool> pool_;
   bool quit_ = false, failed_ = false, done_ = false;
   std::string fail_msg_;
+  double t_wait_ = 0, t_pin_ = 0, t_read_ = 0, t_cut_ = 0;  // FQGPU_TIMING (written by the producer, read after its join)
+  uint64_t t_slots_ = 0;
 };
 
 inline std::vector<int> devices_from_env() {

@@ -33,6 +33,10 @@ for devs in "" "0,0" "0,0,0"; do
     echo "devices='$devs' rep $rep: $(python3 -c "print(round($N/($e-$s),1))") Mreads/s"
   done
 done
+for devs in "" "0,0" "0,0,0"; do
+  echo "--- FQGPU_TIMING, devices='$devs'"
+  if [ -z "$devs" ]; then FQGPU_TIMING=1 bin/fastq_info -r $F 2>&1 >/dev/null | grep "fqgpu timing"; else FQGPU_TIMING=1 FQGPU_DEVICES=$devs bin/fastq_info -r $F 2>&1 >/dev/null | grep "fqgpu timing"; fi
+done
 FQGPU_DEVICES=0,0 bin/fastq_info -r $F 2>&1 | tail -6
 bin/fastq_info -r $F 2>&1 | tail -6
 rm -f $F
