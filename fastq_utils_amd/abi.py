@@ -43,7 +43,7 @@ EXPORTS = [
     "fqg_pack_barcode", "fqg_unpack_barcode", "fqg_bam_index_records", "fqg_bam_add_tags", "fqg_bam_add_tags_output",
     "fqg_umi_count", "fqg_umi_features", "fqg_umi_record_features", "fqg_umi_replayed_features", "fqg_umi_umis",
     "fqg_umi_cells", "fqg_umi_entries", "fqg_umi_emit",
-    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_names_fingerprints_acct", "fqg_names_fingerprints_named", "fqg_device_alloc", "fqg_device_free",
+    "fqg_fp_owner", "fqg_names_fingerprints", "fqg_names_fingerprints_acct", "fqg_names_fingerprints_named", "fqg_frame_name_records", "fqg_frame_names_equal", "fqg_device_alloc", "fqg_device_free",
     "fqg_device_copy", "fqg_fpset_create", "fqg_fpset_destroy", "fqg_fpset_insert", "fqg_fpset_insert_named",
     "fqg_fpset_candidates", "fqg_fpset_pair_runs", "fqg_frame_name",
 ]
@@ -271,6 +271,8 @@ def load():
     L.fqg_fpset_insert.argtypes = [vp, vp, vp, u64]
     L.fqg_fpset_insert_named.argtypes = [vp, vp, vp, vp, u64]
     L.fqg_names_fingerprints_named.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_uint32, vp, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.fqg_frame_name_records.argtypes = [vp, vp, C.POINTER(FileState), u64, u64, vp]
+    L.fqg_frame_names_equal.argtypes = [vp, vp, C.POINTER(FileState), u64, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.fqg_fpset_candidates.argtypes = [vp, vp, C.POINTER(u64), u64, C.POINTER(u64)]
     L.fqg_fpset_pair_runs.argtypes = [vp, vp, C.POINTER(PairSummary), C.POINTER(u64), u64]
     L.fqg_frame_name.argtypes = [vp, vp, C.POINTER(FileState), u64, C.c_char_p, u64]

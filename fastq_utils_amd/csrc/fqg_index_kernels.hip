@@ -542,6 +542,65 @@ __global__ __launch_bounds__(kBlock) void k_index_match_delete(FrameView f, Inde
   tally_flush(t, call);
 }
 
+// ---- names by POSITION --------------------------------------------------------------------------------------------
+// The mate files of a run hold their reads in one order.  Before the names of a pair of files that lie spread over
+// several contexts are sent to their owners by hash (fqg_fp kernels, host/fq_names_multi.h), the contexts look whether
+// record i of file 2 simply has the name of record i of file 1: the name records of a range of file 1 are written out
+// (k_names_records), copied to the context that holds the same range of file 2 - a contiguous copy - and compared
+// there (k_names_equal).  When every record of file 2 has its partner at its own place, file 1 holds as many records,
+// and no name of file 1 occurs twice (the duplicate test of file 1 has passed), the serial loop of the reference
+// (src/fastq_info.c:333-356) would have found and deleted every entry: nothing is left to exchange.
+constexpr unsigned long long kNameRecNoAt = 1ull << 63;  // in NameRec::n: the header does not start with '@'
+__global__ __launch_bounds__(kBlock) void k_names_records(FrameView f, int fmt, int is_pe, int may_have_nul, uint64_t first,
+                                                          uint64_t n, NameRec* __restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    NameKey k;
+    bool at_sign;
+    name_from_image(f, first + i, fmt, is_pe, may_have_nul, k, &at_sign);
+    u64x2_t* dst = reinterpret_cast<u64x2_t*>(out + i);
+    u64x2_t x;
+    x.x = (unsigned long long)k.n | (at_sign ? 0ull : kNameRecNoAt);
+    x.y = k.nm[0];
+    dst[0] = x;
+#pragma unroll
+    for (uint32_t j = 1; j < 4; ++j) {
+      x.x = k.nm[2 * j - 1];
+      x.y = k.nm[2 * j];
+      dst[j] = x;
+    }
+  }
+}
+// counts[0] += records whose name is the record's at the same place; counts[1] += records that agree in length and in
+// their first 56 bytes but are longer than that (the caller decides them the long way)
+__global__ __launch_bounds__(kBlock) void k_names_equal(FrameView f, int fmt, int is_pe, int may_have_nul, uint64_t first,
+                                                        uint64_t n, const NameRec* __restrict__ recs,
+                                                        unsigned long long* __restrict__ counts) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  unsigned long long same = 0, open = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    NameKey k;
+    bool at_sign;
+    name_from_image(f, first + i, fmt, is_pe, may_have_nul, k, &at_sign);
+    const u64x2_t* src = reinterpret_cast<const u64x2_t*>(recs + i);
+    const u64x2_t a = src[0], b = src[1], c = src[2], d = src[3];
+    const bool eq = at_sign && a.x == (unsigned long long)k.n &&
+                    !((a.y ^ k.nm[0]) | (b.x ^ k.nm[1]) | (b.y ^ k.nm[2]) | (c.x ^ k.nm[3]) | (c.y ^ k.nm[4]) | (d.x ^ k.nm[5]) |
+                      (d.y ^ k.nm[6]));
+    if (eq && k.n <= kNameInline) ++same;
+    else if (eq) ++open;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    same += __shfl_down(same, o, 64);
+    open += __shfl_down(open, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (same) atomicAdd(&counts[0], same);
+    if (open) atomicAdd(&counts[1], open);
+  }
+}
+
 // ---- from the capture records of the streaming pass ----------------------------------------------
 // One thread per record SLOT (chunk c, ordinal j < K).  A chunk whose speculated line type was the true one and that
 // saw at most K headers is taken from its records; the headers of every other chunk are enumerated by rank - the

@@ -97,6 +97,13 @@ void run_single_noindex(const char* path, Stats& S) {
   S.num_reads1 = fs.num_rds;
 }
 
+// Pieces and slots of the loops over several contexts.  Pinned memory is what such a run pays for at both ends - 23 ms per
+// 128 MiB when a slot is made, and again when the process leaves - so the pieces are half the one-context loop's and the
+// slots as many as can be in use at once: two with the cutter (the piece whose last record is still open, the one being
+// read), one with every context, one on its way back.
+size_t multi_piece_bytes() { return getenv("FQGPU_CHUNK_MB") ? piece_bytes() : (size_t)64 << 20; }
+int multi_slots(size_t n_contexts) { return (int)n_contexts + 3; }
+
 // ---- -r, one file, several GPUs (FQGPU_DEVICES=0,1,..): the same loop over record-aligned pieces that have no
 // order among them (fq_multi.h).  One thread + context + accumulator per device; this thread takes the results in
 // file order, so the ticker, the first finding and its text are the serial loop's; the statistics of a clean file
@@ -109,6 +116,8 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
   std::vector<Dev> D(devs.size());
   D[0].ctx = g_ctx;  // (opened on devs[0])
   D[0].acc = S.acc1;
+  // (before the piece cutter starts to pin its slots: an allocation of the runtime waits for the one in front of it, and
+  // the seven small ones of a context behind slots of tens of MiB took 0.19 s)
   if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: opening %zu more contexts %.3f s after the program started\n", devs.size() - 1, since_start());
   for (size_t i = 1; i < devs.size(); ++i) {
     const int rc = fqg_open(devs[i], &D[i].ctx);
@@ -118,7 +127,8 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
     }
     if (fqg_acc_create(D[i].ctx, &D[i].acc) != 0) die_lib("fqg_acc_create", -1);
   }
-  const size_t piece = getenv("FQGPU_CHUNK_MB") ? piece_bytes() : (size_t)128 << 20;
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: ... opened %.3f s after the program started\n", since_start());
+  const size_t piece = multi_piece_bytes();
   struct Done {
     Piece p;
     fqg_validate_result r{};
@@ -134,8 +144,9 @@ void run_single_noindex_multi(const char* path, Stats& S, const std::vector<int>
   Probe pr;
   bool rerun_serial = false, probe_printed = false;
   {
-    AlignedPieces src(g_ctx, path, piece, (int)(2 * devs.size() + 2));
+    AlignedPieces src(g_ctx, path, piece, multi_slots(devs.size()));
     const bool timing = getenv("FQGPU_TIMING") != nullptr;
+
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto work = [&](size_t di) {
       double t_wait = 0, t_gpu = 0;
@@ -296,7 +307,7 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
   MultiPass out;
   out.shards.resize(D.size());
   for (size_t i = 0; i < D.size(); ++i) out.shards[i].ctx = D[i].ctx;
-  const size_t piece = getenv("FQGPU_CHUNK_MB") ? piece_bytes() : (size_t)128 << 20;
+  const size_t piece = multi_piece_bytes();
   struct Done {
     Piece p;
     fqg_validate_result r{};
@@ -309,11 +320,26 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
   std::atomic<bool> stop{false};
   bool exhausted = false;        // (under fetch_mu)
   uint64_t n_pieces = ~0ull;     // known once the final piece was handed out (under mu)
-  AlignedPieces src(g_ctx, path, piece, (int)(2 * D.size() + 2), limit);
+  AlignedPieces src(g_ctx, path, piece, multi_slots(D.size()), limit);
+  const bool timing = getenv("FQGPU_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto work = [&](size_t di) {
+    double t_wait = 0, t_gpu = 0, t_keep = 0;
+    uint64_t n = 0;
+    struct Report {
+      bool on;
+      size_t di;
+      const double &w, &g, &k;
+      const uint64_t& n;
+      ~Report() {
+        if (on) fprintf(fqhost::diag(), "fqgpu timing: context %zu: %llu pieces; waiting for a piece %.3f s, copy + validate %.3f s, keeping the frame %.3f s\n",
+                        di, (unsigned long long)n, w, g, k);
+      }
+    } report{timing, di, t_wait, t_gpu, t_keep, n};
     for (;;) {
       Done d;
       fqg_file_state st;
+      const double t0 = timing ? now() : 0;
       {
         std::lock_guard<std::mutex> lk(fetch_mu);
         if (exhausted || stop || !src.next(&d.p)) {
@@ -324,7 +350,9 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
         probe_piece(out.pr, d.p.data, d.p.size, is_pe);  // piece 0 is handed out first: the state is the first record's
         st = validate_as ? *validate_as : out.pr.st;
       }
+      const double t1 = timing ? now() : 0;
       d.rc = fqg_validate(D[di].ctx, D[di].acc, d.p.data, d.p.size, FQG_MEM_HOST, d.p.final ? 1 : 0, &st, flags, &d.r);
+      const double t2 = timing ? now() : 0;
       if (d.rc) d.err = fqg_last_error(D[di].ctx);
       else if (!d.p.final && d.r.code == FQG_OK && !d.r.stopped && d.r.consumed != d.p.size) {
         d.rc = FQG_ERR_ARG;
@@ -338,6 +366,7 @@ MultiPass multi_pass(const char* path, std::vector<MultiDev>& D, int is_pe, uint
           out.shards[di].pieces.push_back(fqhost::NameShard::Piece{fr, d.p.first_record, d.r.n_records});
         }
       }
+      if (timing) t_wait += t1 - t0, t_gpu += t2 - t1, t_keep += now() - t2, ++n;
       std::lock_guard<std::mutex> lk(mu);
       if (d.p.final) n_pieces = d.p.seq + 1;
       done.emplace(d.p.seq, std::move(d));
@@ -465,7 +494,10 @@ bool run_index_multi(const char* path, int is_pe, Stats& S, IndexedFile& F, Mult
   bool dup = false;
   uint64_t dup_rec = 0, name_bytes = 0;
   std::string dup_name;
-  if (!ex.first_duplicate(M.f1, &dup, &dup_rec, &dup_name, &name_bytes)) {
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: file 1 passed %.3f s after the program started\n", since_start());
+  const bool exchanged = ex.first_duplicate(M.f1, &dup, &dup_rec, &dup_name, &name_bytes);
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: names of file 1 exchanged %.3f s after the program started\n", since_start());
+  if (!exchanged) {
     FQ_PRINT_ERROR("GPU library failure in the read-name exchange: %s", ex.error.c_str());
     fqhost::leave(kExitSys);
   }
@@ -538,7 +570,15 @@ void run_pair_second_file_multi(const char* path1, const char* path2, Stats& S, 
   f2.flag = FQG_FP_FILE2;
   fqhost::NamesExchange ex;
   fqhost::PairingOutcome po;
-  if (!ex.pairing(M.f1, f2, &po)) {
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: file 2 passed %.3f s after the program started\n", since_start());
+  // (mates in one order, every name at its place: nothing to exchange.  FQGPU_NO_POSITIONAL_MATCH=1: always exchange)
+  bool by_position = false;
+  bool paired_ok = getenv("FQGPU_NO_POSITIONAL_MATCH") ? true : ex.paired_by_position(M.f1, f2, &by_position);
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: names compared by position (%s) %.3f s after the program started\n", ex.why.c_str(), since_start());
+  if (paired_ok && by_position) po.matched = pass.n_records;
+  else if (paired_ok) paired_ok = ex.pairing(M.f1, f2, &po);
+  if (getenv("FQGPU_TIMING")) fprintf(fqhost::diag(), "fqgpu timing: names of the two files paired %.3f s after the program started\n", since_start());
+  if (!paired_ok) {
     FQ_PRINT_ERROR("GPU library failure in the read-name exchange: %s", ex.error.c_str());
     fqhost::leave(kExitSys);
   }

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <set>
 #include <functional>
 #include <string>
 #include <vector>
@@ -499,7 +500,7 @@ struct BlockRun {
         fqhost::leave(kExitSys);
       }
   fflush(stdout);
-  pb_json_metrics((long)processed, (long)discarded, nd);
+  pb_json_metrics((long)processed, (long)discarded, std::set<int>(devs.begin(), devs.end()).size());
   fqhost::leave(0);
 }
 
@@ -632,6 +633,11 @@ int main(int argc, char** argv) {
   const char* dev = getenv("FQGPU_DEVICE");
   std::vector<int> devices = devices_from_env();  // FQGPU_DEVICES=0,1,..: record blocks over several GPUs
   if (has_interleaved) devices.clear();
+  // One GPU, nothing said: the loop over record blocks all the same, with two contexts on that GPU - every input has a
+  // reader of its own there (the serial loop below reads them one after the other: 1.4 s against 1.0 s for 40 M reads and
+  // their index reads from tmpfs, profiles/r06_multi_dev_legs.txt), and one block's copy runs beside another's kernels.
+  // FQGPU_SERIAL_LOOP=1 keeps the serial loop (it is also what --interleaved input runs through).
+  if (devices.empty() && !has_interleaved && !getenv("FQGPU_SERIAL_LOOP")) devices.assign(2, dev ? atoi(dev) : 0);
   const bool multi = devices.size() > 1;
   int rc = fqg_open(multi ? devices[0] : (dev ? atoi(dev) : 0), &g_ctx);
   if (rc != 0) {

@@ -68,6 +68,7 @@ class RecordBlocks {
   ~RecordBlocks() {
     abort();
     if (producer_.joinable()) producer_.join();
+    if (pinner_.joinable()) pinner_.join();
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     pgzip_report(pgz_.get(), path_);
@@ -88,7 +89,9 @@ class RecordBlocks {
     per_block_ = std::max<uint64_t>(records, 1);
     // (bytes per line so far; a file without a newline in its first bytes is one long line)
     bytes_per_line_ = carry_lines_ ? (double)carry_.size() / (double)carry_lines_ : (double)std::max<size_t>(carry_.size(), 64);
+    pin_cap_ = block_bytes_estimate();
     producer_ = std::thread([this] { produce(); });
+    pinner_ = std::thread([this] { pin_slots(); });
   }
   // next block in file order; false when the input is used up.  Thread-safe.
   bool next(Block* out) {
@@ -102,6 +105,7 @@ class RecordBlocks {
     if (ready_.empty()) return false;
     *out = ready_.front();
     ready_.pop_front();
+    bytes_handed_out() += out->size;
     return true;
   }
   void release(const Block& b) {
@@ -156,16 +160,19 @@ class RecordBlocks {
       auto part = [&](unsigned t) {
         size_t a, b;
         bounds(t, &a, &b);
+        // (256 KiB at a time: the lines are counted while the bytes are still in this core's cache)
         size_t done = a;
+        uint64_t c = 0;
         while (done < b) {
-          const ssize_t got = pread(plain_fd_, dst + done, b - done, (off_t)(plain_off_ + done));
+          const ssize_t got = pread(plain_fd_, dst + done, std::min<size_t>(b - done, 256u << 10), (off_t)(plain_off_ + done));
           if (got <= 0) {
             bad = true;
             return;
           }
+          c += count_lines(dst + done, dst + done + (size_t)got);
           done += (size_t)got;
         }
-        cnt[t] = count_lines(dst + a, dst + b);
+        cnt[t] = c;
       };
       if (T <= 1) part(0);
       else {
@@ -220,9 +227,9 @@ class RecordBlocks {
     std::unique_lock<std::mutex> lk(mu_);
     int s = -1;
     cv_.wait(lk, [&] {
-      if (quit_) return true;
+      if (quit_ || failed_) return true;
       for (size_t i = 0; i < slots_.size(); ++i)
-        if (!slots_[i].busy) {
+        if (slots_[i].buf && !slots_[i].busy) {
           s = (int)i;
           return true;
         }
@@ -230,6 +237,34 @@ class RecordBlocks {
     });
     if (s >= 0) slots_[(size_t)s].busy = true;
     return s;
+  }
+  size_t block_bytes_estimate() const { return (size_t)((double)(4 * per_block_) * bytes_per_line_ * 1.06) + (1u << 20); }
+  // The slots are pinned by a thread of their own, at the size a block is expected to have, while the cutter fills - and
+  // fills again - the ones it has been given (pinning 128 MiB takes six times as long as reading them from tmpfs; see
+  // fq_multi.h).  A block that turns out larger grows its slot where it is (reserve).
+  void pin_slots() {
+    size_t want = slots_.size();
+    if (plain_fd_ >= 0) want = (size_t)std::min<uint64_t>(want, plain_size_ / std::max<size_t>(pin_cap_, 1) + 2);
+    for (size_t i = 0; i < want; ++i) {
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (quit_ || failed_ || done_) break;
+      }
+      const size_t cap = pin_cap_;
+      char* buf = slot_alloc(ctx_, cap + 1);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!buf) {
+        if (i == 0) {
+          fail_msg_ = "unable to allocate pinned memory";
+          failed_ = true;
+        }
+        cv_.notify_all();
+        break;
+      }
+      slots_[i].buf = buf;
+      slots_[i].cap = cap;
+      cv_.notify_all();
+    }
   }
   bool reserve(Slot& s, size_t keep, size_t want) {
     if (want <= s.cap) return true;
@@ -337,7 +372,8 @@ class RecordBlocks {
   uint64_t per_block_ = 1;
   double bytes_per_line_ = 64;
   uint64_t total_bytes_ = 0, total_lines_ = 0;
-  std::thread producer_;
+  std::thread producer_, pinner_;
+  size_t pin_cap_ = 0;  // what the pinner gives every slot (from the first bytes' line lengths; set before it starts)
   std::mutex mu_;
   std::condition_variable cv_;
   std::unique_ptr<ReaderPool> pool_;

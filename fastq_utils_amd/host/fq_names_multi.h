@@ -124,11 +124,98 @@ class NamesExchange {
   }
 
   // the file-2 loop: every name of f2 (flag FQG_FP_FILE2) looks for its holder in f1
+  // Mate files in one order (the usual case): is the name of EVERY record of f2 the name of the record of f1 with the
+  // same number?  (fqg_frame_name_records / fqg_frame_names_equal, include/fqg.h: a contiguous copy of name records
+  // per piece instead of the exchange by hash of pairing() below.)  *all = true: yes, and the files hold the same
+  // number of records - with f1 free of repeated names (first_duplicate has said so) that is every read paired.
+  // Anything else - a file that is shorter, one record out of place, a name beyond the 56 bytes a record holds - is
+  // *all = false and left to pairing().  One thread drives every context here: the pieces are at rest, the work per
+  // piece is two small kernels and one copy.
+  bool paired_by_position(const NamesOfFile& f1, const NamesOfFile& f2, bool* all) {
+    *all = false;
+    struct Held {
+      fqg_ctx* ctx;
+      NameShard::Piece p;
+    };
+    std::vector<Held> one, two;
+    uint64_t n1 = 0, n2 = 0, longest = 0;
+    for (auto& sh : f1.shards)
+      for (auto& p : sh.pieces) one.push_back(Held{sh.ctx, p}), n1 += p.n_records, longest = std::max(longest, p.n_records);
+    for (auto& sh : f2.shards)
+      for (auto& p : sh.pieces) two.push_back(Held{sh.ctx, p}), n2 += p.n_records, longest = std::max(longest, p.n_records);
+    if (n1 != n2 || !n1) {
+      why = "the files hold " + std::to_string(n1) + " and " + std::to_string(n2) + " records";
+      return true;
+    }
+    auto by_first = [](const Held& a, const Held& b) { return a.p.first_record < b.p.first_record; };
+    std::sort(one.begin(), one.end(), by_first);
+    std::sort(two.begin(), two.end(), by_first);
+    std::map<fqg_ctx*, void*> scratch;  // per context: room for the name records of the longest piece
+    auto room = [&](fqg_ctx* c) -> void* {
+      auto it = scratch.find(c);
+      if (it != scratch.end()) return it->second;
+      void* p = fqg_device_alloc(c, longest * FQG_NAME_REC_BYTES);
+      scratch[c] = p;
+      return p;
+    };
+    bool ok = true, same = true;
+    size_t q = 0;
+    for (size_t t = 0; t < two.size() && ok && same; ++t) {
+      const Held& b = two[t];
+      const uint64_t b_lo = b.p.first_record, b_hi = b_lo + b.p.n_records;
+      while (q < one.size() && one[q].p.first_record + one[q].p.n_records <= b_lo) ++q;
+      for (size_t k = q; k < one.size() && one[k].p.first_record < b_hi && ok && same; ++k) {
+        const Held& a = one[k];
+        const uint64_t lo = std::max(a.p.first_record, b_lo), hi = std::min(a.p.first_record + a.p.n_records, b_hi);
+        if (lo >= hi) continue;
+        void* at_a = room(a.ctx);
+        void* at_b = a.ctx == b.ctx ? at_a : room(b.ctx);
+        if (!at_a || !at_b) {
+          ok = fail("device allocation failed");
+          break;
+        }
+        if (fqg_frame_name_records(a.ctx, a.p.frame, &f1.st, lo - a.p.first_record, hi - lo, at_a) != 0) {
+          ok = fail(fqg_last_error(a.ctx));
+          break;
+        }
+        if (a.ctx != b.ctx && fqg_device_copy(b.ctx, at_b, a.ctx, at_a, (hi - lo) * FQG_NAME_REC_BYTES) != 0) {
+          ok = fail(fqg_last_error(b.ctx));
+          break;
+        }
+        uint64_t eq = 0, undecided = 0;
+        if (fqg_frame_names_equal(b.ctx, b.p.frame, &f2.st, lo - b_lo, hi - lo, at_b, &eq, &undecided) != 0) {
+          ok = fail(fqg_last_error(b.ctx));
+          break;
+        }
+        if (eq != hi - lo) {
+          same = false;
+          why = "records " + std::to_string(lo) + " .. " + std::to_string(hi - 1) + ": " + std::to_string(eq) + " names at their place, " +
+                std::to_string(undecided) + " beyond what a name record holds";
+        }
+      }
+    }
+    for (auto& kv : scratch)
+      if (kv.second) fqg_device_free(kv.first, kv.second);
+    if (ok && same) {
+      *all = true;
+      why = "every name at its place";
+    }
+    return ok;
+  }
+  std::string why;  // what paired_by_position found (FQGPU_TIMING prints it)
+
+  static double t_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  static void t_say(const char* what, double since) {
+    if (getenv("FQGPU_TIMING")) fprintf(diag(), "fqgpu timing: name exchange: %s %.3f s\n", what, t_now() - since);
+  }
   bool pairing(const NamesOfFile& f1, const NamesOfFile& f2, PairingOutcome* out) {
     *out = PairingOutcome();
     std::vector<const NamesOfFile*> files{&f1, &f2};
     Exchanged x;
+    double t0 = t_now();
     if (!exchange(files, x, true)) return false;
+    t_say("fingerprints + name records made and sent to their owners", t0);
+    t0 = t_now();
     struct Part {
       fqg_pair_summary s{};
       std::vector<uint64_t> entries;  // (run, index) pairs
@@ -157,7 +244,10 @@ class NamesExchange {
       else parts[o].entries.resize(2 * parts[o].s.n_complex);
       fqg_fpset_destroy(set);
     });
+    t_say("owners: set built, runs paired", t0);
+    t0 = t_now();
     release(x);
+    t_say("buffers freed", t0);
     bool have = false;
     uint64_t first = 0;
     auto offer_first = [&](uint64_t idx) {
@@ -315,12 +405,14 @@ class NamesExchange {
           }
         }
     };
+    const double t_made = t_now();
     {
       std::vector<std::thread> th;
       for (size_t d = 1; d < D; ++d) th.emplace_back(produce, d);
       produce(0);
       for (auto& t : th) t.join();
     }
+    t_say("... fingerprints of every piece", t_made);
     bool ok = true;
     for (auto& L : loc)
       if (!L.err.empty()) ok = fail(L.err);

@@ -305,6 +305,17 @@ int fqg_names_fingerprints_named(fqg_ctx *ctx, const fqg_frame *frame, const fqg
                                  uint32_t n_owners, void *out_device, void *names_device, uint64_t *counts,
                                  uint64_t *name_bytes);
 int fqg_fpset_insert_named(fqg_ctx *ctx, fqg_fpset *set, const void *fps_device, const void *names_device, uint64_t n);
+/* Names by POSITION, tried before the exchange above (the file-2 loop of fastq_info, src/fastq_info.c:333-356, on mate
+ * files that hold their reads in one order - the usual case - finds the partner of record i in the entry of record i):
+ * fqg_frame_name_records writes the FQG_NAME_REC_BYTES records of records first .. first + n - 1 of a retained frame
+ * (canonical names under `state`) to out_device; the caller copies them to the context that holds the same records of
+ * the other file (fqg_device_copy) and fqg_frame_names_equal counts there the records whose name is the record's at
+ * the same place (*n_equal) and those that agree in all a record holds but are longer than its 56 bytes
+ * (*n_undecided).  n_equal == the records of both files (and file 1 without a repeated name): every read is paired. */
+int fqg_frame_name_records(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t first, uint64_t n,
+                           void *out_device);
+int fqg_frame_names_equal(fqg_ctx *ctx, const fqg_frame *frame, const fqg_file_state *state, uint64_t first, uint64_t n,
+                          const void *recs_device, uint64_t *n_equal, uint64_t *n_undecided);
 /* After every insert: pairs[2k], pairs[2k+1] (host) = (earliest holder, another holder) for every
  * fingerprint value held by more than one of the inserted records; *n_found may exceed cap. */
 int fqg_fpset_candidates(fqg_ctx *ctx, fqg_fpset *set, uint64_t *pairs, uint64_t cap, uint64_t *n_found);

@@ -38,13 +38,19 @@ def arrangements():
     return [x for x in a], out
 
 
+@pytest.mark.parametrize("contexts", ["one", "0,0", "0,0,0"])
 @pytest.mark.parametrize("shortcut", ["on", "off"])
-def test_the_shortcut_gives_the_tables_answer(shortcut):
+def test_the_shortcut_gives_the_tables_answer(shortcut, contexts):
+    """contexts "0,0" / "0,0,0": the files spread over several contexts (FQGPU_DEVICES, host/fq_names_multi.h) - there
+    the shortcut compares the name records of the two files range by range (fqg_frame_name_records /
+    fqg_frame_names_equal) and the exchange by hash runs only when a name is not at its place"""
     a, files2 = arrangements()
     files = {"a_1.fastq": b"".join(a)}
     for k, v in files2.items():
         files[k + "_2.fastq"] = b"".join(v)
     env = {"FQGPU_CHUNK_MB": "1"}
+    if contexts != "one":
+        env["FQGPU_DEVICES"] = contexts
     if shortcut == "off":
         env["FQGPU_NO_POSITIONAL_MATCH"] = "1"
     with tempfile.TemporaryDirectory() as tmp:
@@ -76,3 +82,41 @@ def test_a_file_1_with_a_repeated_name_turns_the_shortcut_off():
         # asker 10 takes the entry, asker 2000 finds it gone (with the shortcut on it would have found "its" record 2000)
         assert m["code"] != 0 and m["record"] == 2000, m
         idx.close()
+
+
+def test_name_records_and_their_comparison():
+    """the two calls of the comparison by position on ranges of two frames: counts against a recount on the host"""
+    import ctypes as C
+
+    import fastq_utils_amd as fq
+    A = fq.abi
+    L = A.load()
+    rng = np.random.default_rng(3)
+    a, b = mates(rng, 5000)
+    b[1234] = rec(*casava(4321, 2), rng)                                  # another read's name
+    b[2000] = rec(b"SRX:7:FC9:1:1:1:" + b"9" * 70, b" 2:N:0:ACGTAC", rng)   # 86 bytes: beyond what a record holds ...
+    a[2000] = rec(b"SRX:7:FC9:1:1:1:" + b"9" * 70, b" 1:N:0:ACGTAC", rng)   # ... and equal: undecided
+    b[3000] = b"X" + b[3000][1:]                                          # no '@'
+    img1, img2 = b"".join(a), b"".join(b)
+    with fq.Context(0) as ctx:
+        frames, states = [], []
+        for img in (img1, img2):
+            st = A.probe_first_record(img, True)
+            ctx.validate(img, None, st, flags=A.VALIDATE_FRAME_ONLY)
+            frames.append(ctx.retain_frame())
+            states.append(st)
+        for first, n in ((0, 5000), (1000, 500), (1234, 1), (1990, 20), (2999, 3), (4999, 1), (17, 0)):
+            buf = L.fqg_device_alloc(ctx.h, max(n, 1) * 64)
+            assert buf
+            ctx._check(L.fqg_frame_name_records(ctx.h, frames[0].h, C.byref(states[0]), first, n, buf))
+            eq, und = C.c_uint64(0), C.c_uint64(0)
+            ctx._check(L.fqg_frame_names_equal(ctx.h, frames[1].h, C.byref(states[1]), first, n, buf, C.byref(eq), C.byref(und)))
+            L.fqg_device_free(ctx.h, buf)
+            bad = sum(1 for x in (1234, 2000, 3000) if first <= x < first + n)
+            assert (eq.value, und.value) == (n - bad, 1 if first <= 2000 < first + n else 0), (first, n, eq.value, und.value)
+        # beyond the frame: refused
+        buf = L.fqg_device_alloc(ctx.h, 64)
+        assert L.fqg_frame_name_records(ctx.h, frames[0].h, C.byref(states[0]), 4999, 2, buf) != 0
+        L.fqg_device_free(ctx.h, buf)
+        for f in frames:
+            f.release()
