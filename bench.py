@@ -1802,7 +1802,11 @@ def main():
                     d["pair_first_file"] = {k: d1[k] for k in ("insert_ms", "all_kernels_ms", "ms_over_validate_only")}
                     ctx.profile(True)
                     ctx.profile_reset()
-                    ctx.validate(image.data_ptr(), None, st, final=True, flags=fq.abi.VALIDATE_NO_STATS | extra_flags, nbytes=n * R)
+                    # (as the program's file-2 loop calls it, host/fastq_info.cpp run_pair_second_file: file 1's accumulator
+                    # goes on counting - with statistics wanted the image takes the pass in parts)
+                    acc2 = ctx.accumulator()
+                    ctx.validate(image.data_ptr(), acc2, st, final=True, flags=extra_flags, nbytes=n * R)
+                    acc2.close()
                     mr = idx.match_delete(st)
                     ctx.synchronize()
                     p3 = ctx.profile_read()

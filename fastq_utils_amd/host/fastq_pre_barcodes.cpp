@@ -637,7 +637,8 @@ int main(int argc, char** argv) {
   // reader of its own there (the serial loop below reads them one after the other: 1.4 s against 1.0 s for 40 M reads and
   // their index reads from tmpfs, profiles/r06_multi_dev_legs.txt), and one block's copy runs beside another's kernels.
   // FQGPU_SERIAL_LOOP=1 keeps the serial loop (it is also what --interleaved input runs through).
-  if (devices.empty() && !has_interleaved && !getenv("FQGPU_SERIAL_LOOP")) devices.assign(2, dev ? atoi(dev) : 0);
+  // (... and what a run that was started over on input cut at the gzgets limits goes through: fq_respawn.h)
+  if (devices.empty() && !has_interleaved && !fqhost::reframing() && !getenv("FQGPU_SERIAL_LOOP")) devices.assign(2, dev ? atoi(dev) : 0);
   const bool multi = devices.size() > 1;
   int rc = fqg_open(multi ? devices[0] : (dev ? atoi(dev) : 0), &g_ctx);
   if (rc != 0) {

@@ -90,6 +90,9 @@ class RecordBlocks {
     // (bytes per line so far; a file without a newline in its first bytes is one long line)
     bytes_per_line_ = carry_lines_ ? (double)carry_.size() / (double)carry_lines_ : (double)std::max<size_t>(carry_.size(), 64);
     pin_cap_ = block_bytes_estimate();
+    // (no block is longer than its file: a small plain file gets small slots; a gzip file may inflate to 24 times its size
+    // and more - a block that outgrows its slot grows it, reserve())
+    if (plain_fd_ >= 0) pin_cap_ = (size_t)std::min<uint64_t>(pin_cap_, plain_size_ + (64u << 10));
     producer_ = std::thread([this] { produce(); });
     pinner_ = std::thread([this] { pin_slots(); });
   }
@@ -243,8 +246,9 @@ class RecordBlocks {
   // fills again - the ones it has been given (pinning 128 MiB takes six times as long as reading them from tmpfs; see
   // fq_multi.h).  A block that turns out larger grows its slot where it is (reserve).
   void pin_slots() {
-    size_t want = slots_.size();
-    if (plain_fd_ >= 0) want = (size_t)std::min<uint64_t>(want, plain_size_ / std::max<size_t>(pin_cap_, 1) + 2);
+    // (every slot the caller asked for, while the cutter still runs: consumers may each hold one while another waits for
+    // the next block with a lock of the caller's held - fewer slots than consumers + 2 is a deadlock of their making)
+    const size_t want = slots_.size();
     for (size_t i = 0; i < want; ++i) {
       {
         std::lock_guard<std::mutex> lk(mu_);
@@ -292,7 +296,9 @@ class RecordBlocks {
       std::vector<Seg> segs;
       size_t len = carry_.size();
       uint64_t lines = carry_lines_;
-      if (!reserve(s, 0, std::max<size_t>((size_t)((double)need * bytes_per_line_ * 1.06) + (1u << 20), len))) return;
+      size_t room = (size_t)((double)need * bytes_per_line_ * 1.06) + (1u << 20);
+      if (plain_fd_ >= 0) room = (size_t)std::min<uint64_t>(room, plain_size_ + (64u << 10));  // (as the pinner sizes them)
+      if (!reserve(s, 0, std::max<size_t>(room, len))) return;
       if (len) {
         memcpy(s.buf, carry_.data(), len);
         segs.push_back(Seg{0, len, lines});
@@ -301,7 +307,8 @@ class RecordBlocks {
       carry_lines_ = 0;
       while (lines < need && !at_end_) {
         // what the missing lines should take, a little more than that: the surplus is carried, a shortfall reads again
-        const size_t est = (size_t)((double)(need - lines) * bytes_per_line_ * 1.03) + (64u << 10);
+        size_t est = (size_t)((double)(need - lines) * bytes_per_line_ * 1.03) + (64u << 10);
+        if (plain_fd_ >= 0) est = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(est, plain_size_ - plain_off_));  // (what the file still has)
         if (!reserve(s, len, len + est)) return;
         uint64_t nl = 0;
         const size_t got = read_some(s.buf + len, est, &at_end_, &nl, len, &segs);

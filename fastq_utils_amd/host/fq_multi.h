@@ -58,9 +58,7 @@ class AlignedPieces {
       fqhost::leave(kExitParams);
     }
     if (gz_) gzbuffer(gz_, 1 << 20);
-    // slots a file of this size can use at all (a plain file says its size; a stream may need every one)
-    want_slots_ = slots_.size();
-    if (plain_fd_ >= 0) want_slots_ = (size_t)std::min<uint64_t>(slots_.size(), plain_size_ / std::max<size_t>(cap_, 1) + 2);
+    want_slots_ = slots_.size();  // (all of them, while the cutter still runs: a file of one piece is done before the second is pinned)
     producer_ = std::thread([this] { produce(); });
     pinner_ = std::thread([this] { pin_slots(); });
   }
