@@ -566,6 +566,10 @@ def barcodes_programs(ctx, fq, torch, img1, img2, R1, R2, n_pairs, qual_rows, ke
     if m < 1_000_000:
         return {"skipped": f"/dev/shm has {free >> 30} GiB free, the host {avail >> 30} GiB available"}
     d = tempfile.mkdtemp(prefix="fqg_bench_bc_", dir=shm)
+    # (the programs are processes of their own on the same GPU: what this process's context still holds of the 200 M-pair
+    # call above - 120 GB of SAM text among it - is given back first)
+    ctx.release_scratch()
+    torch.cuda.empty_cache()
     res = {"pairs": m, "baseline_pairs": 200_000_000, "input_GB": m * per_pair_in / 1e9,
            "host_cores_usable": len(os.sched_getaffinity(0)), "host_cores": os.cpu_count(),
            "kernels_only_ms_for_all_pairs_of_the_extra": kernels_ms}

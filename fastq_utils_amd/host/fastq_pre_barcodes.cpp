@@ -272,9 +272,77 @@ struct BlockRun {
     bool ends = false;                            // an input ends inside this unit although its block is not the last
     int long_line_file = 0;                       // an input of this unit has a line beyond the gzgets limits ...
     uint64_t long_line_record = 0;                // ... in this record of the file
-    std::vector<char> out[3];
+    char* out[3] = {nullptr, nullptr, nullptr};   // the text of every output: pinned buffers that go round (OutPool)
+    size_t out_cap[3] = {0, 0, 0};
     std::string wrong_header;                     // the text of the header line of a FQG_E_WRONG_HEADER finding
   };
+  // The text a unit brings back from the GPU: pinned buffers that go round between the contexts' threads and the thread
+  // that writes.  Into fresh pageable memory the copy ran at 7.5 GB/s per context (page faults, a bounce buffer) and the
+  // copies of the next blocks TO the GPU waited behind it: 28 s for the 200 M pairs of the bench where the serial loop,
+  // whose text has always travelled in pinned buffers, takes 6.7.  As many buffers as the units that may be under way
+  // have outputs (`window` below); take() makes them as they are first asked for.
+  struct OutPool {
+    fqg_ctx* ctx;
+    size_t limit, n_made = 0;
+    std::vector<std::pair<char*, size_t>> free_;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool quit = false;
+    char* take(size_t bytes, size_t* cap) {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        size_t best = free_.size();  // a free one that is large enough: the smallest such
+        for (size_t i = 0; i < free_.size(); ++i)
+          if (free_[i].second >= bytes && (best == free_.size() || free_[i].second < free_[best].second)) best = i;
+        if (best != free_.size()) {
+          char* p = free_[best].first;
+          *cap = free_[best].second;
+          free_.erase(free_.begin() + (long)best);
+          return p;
+        }
+        if (n_made < limit) {
+          ++n_made;
+          lk.unlock();
+          const size_t want = bytes + bytes / 8 + 4096;
+          char* p = static_cast<char*>(fqg_host_alloc(ctx, want));
+          *cap = p ? want : 0;
+          if (!p) {
+            lk.lock();
+            --n_made;
+          }
+          return p;
+        }
+        if (!free_.empty()) {  // every buffer made, none of the free ones large enough: one of them makes room
+          char* small = free_.back().first;
+          free_.pop_back();
+          --n_made;
+          lk.unlock();
+          fqg_host_free(ctx, small);
+          lk.lock();
+          continue;
+        }
+        if (quit) return nullptr;
+        cv.wait(lk);
+      }
+    }
+    void give(char* p, size_t cap) {
+      if (!p) return;
+      std::lock_guard<std::mutex> lk(mu);
+      free_.emplace_back(p, cap);
+      cv.notify_all();
+    }
+    void stop() {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv.notify_all();
+    }
+  };
+  // units under way or waiting for the writer: one per context and one more; none is begun beyond that (a context that
+  // ran ahead would hold every buffer with units the writer cannot take yet, and the unit it waits for would find none)
+  const uint64_t window = nd + 1;
+  const size_t outs_per_unit = A.out_sam ? 1 : (size_t)((A.P->emit[1] ? 1 : 0) + (A.P->emit[2] ? 1 : 0));
+  OutPool out_pool{g_ctx, (size_t)window * std::max<size_t>(outs_per_unit, 1)};
+  uint64_t n_written = 0;  // units the writer is done with (under mu)
   std::map<uint64_t, Unit> done;
   std::mutex mu, fetch_mu;
   std::condition_variable cv;
@@ -283,13 +351,32 @@ struct BlockRun {
   uint64_t next_seq = 0;      // (under fetch_mu)
   uint64_t n_units = ~0ull;   // known once a unit with the end of an input was handed out (under mu)
 
+  const bool timing = getenv("FQGPU_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto work = [&](size_t di) {
     fqg_ctx* c = ctx[di];
+    double t_wait = 0, t_frame = 0, t_transform = 0, t_out = 0, t_hand = 0;
+    uint64_t n_units_done = 0;
+    struct Report {
+      bool on;
+      size_t di;
+      const double &w, &f, &t, &o, &h;
+      const uint64_t& n;
+      ~Report() {
+        if (on) fprintf(fqhost::diag(), "fqgpu timing: context %zu: %llu units; waiting for blocks %.3f s, copy + framing %.3f s, transform %.3f s, output D2H %.3f s, handing over %.3f s\n",
+                        di, (unsigned long long)n, w, f, t, o, h);
+      }
+    } report{timing, di, t_wait, t_frame, t_transform, t_out, t_hand, n_units_done};
     for (;;) {
       Unit u;
       Block b[6];
+      const double t0 = timing ? now() : 0;
       {
         std::lock_guard<std::mutex> lk(fetch_mu);
+        {
+          std::unique_lock<std::mutex> lk2(mu);
+          cv.wait(lk2, [&] { return stop.load() || next_seq < n_written + window; });
+        }
         if (exhausted || stop) return;
         bool all = true;
         for (int x = READ1; x <= INDEX3 && all; ++x)
@@ -306,6 +393,8 @@ struct BlockRun {
           n_units = u.seq + 1;
         }
       }
+      const double t1 = timing ? now() : 0;
+      t_wait += t1 - t0;
       const fqg_frame* frames[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       fqg_frame* held[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       fqg_file_state states[6];
@@ -366,14 +455,24 @@ struct BlockRun {
             frames[x] = held[x];
           }
         }
+      const double t2 = timing ? now() : 0;
+      t_frame += t2 - t1;
+      double t3 = t2;
       if (!u.rc && u.n > 0) {
         fqg_barcode_params Pb = *A.P;
         const int rc = fqg_barcodes_transform(c, frames, states, first, &Pb, u.n, u.seq * B, &u.r);
         if (rc) lib_fail("fqg_barcodes_transform", rc);
+        t3 = timing ? now() : 0;
+        t_transform += t3 - t2;
         for (int which = 0; which < 3 && !u.rc; ++which)
           if (u.r.out_bytes[which]) {
-            u.out[which].resize(u.r.out_bytes[which]);
-            const int rc2 = fqg_barcodes_output(c, which, u.out[which].data(), u.r.out_bytes[which]);
+            u.out[which] = out_pool.take(u.r.out_bytes[which], &u.out_cap[which]);
+            if (!u.out[which]) {
+              u.rc = FQG_ERR_NOMEM;
+              u.err = "no pinned memory for the output text";
+              break;
+            }
+            const int rc2 = fqg_barcodes_output(c, which, u.out[which], u.r.out_bytes[which]);
             if (rc2) lib_fail("fqg_barcodes_output", rc2);
           }
         if (!u.rc && u.r.code == FQG_E_WRONG_HEADER) {
@@ -387,21 +486,31 @@ struct BlockRun {
           u.wrong_header.assign(p, nl ? nl + 1 : end);
         }
       } else if (!u.rc) u.n = 0;
+      const double t4 = timing ? now() : 0;
+      t_out += t4 - t3;
       for (int x = READ1; x <= INDEX3; ++x)
         if (cut[x]) {
           if (held[x]) fqg_frame_release(held[x]);
           cut[x]->release(b[x]);
         }
-      std::lock_guard<std::mutex> lk(mu);
-      const uint64_t seq = u.seq;
-      done.emplace(seq, std::move(u));
-      cv.notify_all();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        const uint64_t seq = u.seq;
+        done.emplace(seq, std::move(u));
+        cv.notify_all();
+      }
+      if (timing) t_hand += now() - t4, ++n_units_done;
     }
   };
   std::vector<std::thread> th;
   for (size_t i = 0; i < nd; ++i) th.emplace_back(work, i);
   auto join_all = [&] {
     stop = true;
+    out_pool.stop();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      cv.notify_all();
+    }
     for (int x = READ1; x <= INDEX3; ++x)
       if (cut[x]) cut[x]->abort();
     for (auto& t : th)
@@ -412,11 +521,15 @@ struct BlockRun {
   bool first_batch = true;
   Unit last;
   bool have_last = false;
+  double t_main_wait = 0;
+  const double t_loop = now();
   for (uint64_t k = 0;; ++k) {
     Unit u;
     {
+      const double tw = timing ? now() : 0;
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return done.count(k) || k >= n_units; });
+      if (timing) t_main_wait += now() - tw;
       if (!done.count(k)) break;
       u = std::move(done[k]);
       done.erase(k);
@@ -440,9 +553,9 @@ struct BlockRun {
       }
       first_batch = false;
       for (uint64_t w = 0; w < r.n_short; ++w) fputs("Warning: Read too short - barcode not found\n", stderr);
-      if (r.out_bytes[0]) fwrite(u.out[0].data(), 1, r.out_bytes[0], stdout);
+      if (r.out_bytes[0]) fwrite(u.out[0], 1, r.out_bytes[0], stdout);
       for (int which = 1; which < 3; ++which)
-        if (r.out_bytes[which] && !A.outgz[which].write(u.out[which].data(), r.out_bytes[which])) {
+        if (r.out_bytes[which] && !A.outgz[which].write(u.out[which], r.out_bytes[which])) {
           join_all();
           FQ_PRINT_ERROR("%s.\n", A.outgz[which].error().c_str());  // GZ_WRITE's gzerror() text, src/fastq.c:211-235
           fqhost::leave(kExitSys);
@@ -466,12 +579,22 @@ struct BlockRun {
         fqhost::leave(kExitFormat);
       }
     }
+    for (int which = 0; which < 3; ++which) {
+      out_pool.give(u.out[which], u.out_cap[which]);
+      u.out[which] = nullptr;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ++n_written;
+      cv.notify_all();
+    }
     const bool ends = u.ends;
     last = std::move(u);
     have_last = true;
     if (ends) break;  // (later units, if any were handed out, are dropped)
   }
   join_all();
+  if (timing) fprintf(fqhost::diag(), "fqgpu timing: the thread that writes: %.3f s in the loop, %.3f s of them waiting for the next unit\n", now() - t_loop, t_main_wait);
   // an incomplete record where the next read would have happened is a truncated file (src/fastq.c:254-257); a clean
   // end of any input just ends the loop.  The first input, in file order, that has nothing left decides - unless the
   // loop's own condition ends it first (fastq_files_eof, src/fastq_pre_barcodes.c:288-297, :594): an input whose last

@@ -69,6 +69,9 @@ class RecordBlocks {
     abort();
     if (producer_.joinable()) producer_.join();
     if (pinner_.joinable()) pinner_.join();
+    if (getenv("FQGPU_TIMING"))
+      fprintf(diag(), "fqgpu timing: block cutter of %s: %llu blocks; waiting for a free (pinned) slot %.3f s, reading + counting lines %.3f s, cutting + carrying %.3f s\n",
+              path_.c_str(), (unsigned long long)t_blocks_, t_wait_, t_read_, t_cut_);
     if (gz_) gzclose(gz_);
     if (plain_fd_ >= 0) close(plain_fd_);
     pgzip_report(pgz_.get(), path_);
@@ -290,8 +293,12 @@ class RecordBlocks {
     uint64_t seq = 0;
     for (;;) {
       if (at_end_ && carry_.empty() && seq > 0) break;
+      const double t0 = t_clock();
       const int si = free_slot();
       if (si < 0) return;
+      const double t1 = t_clock();
+      t_wait_ += t1 - t0;
+      double t_reading = 0;
       Slot& s = slots_[(size_t)si];
       std::vector<Seg> segs;
       size_t len = carry_.size();
@@ -311,7 +318,9 @@ class RecordBlocks {
         if (plain_fd_ >= 0) est = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(est, plain_size_ - plain_off_));  // (what the file still has)
         if (!reserve(s, len, len + est)) return;
         uint64_t nl = 0;
+        const double tr = t_clock();
         const size_t got = read_some(s.buf + len, est, &at_end_, &nl, len, &segs);
+        t_reading += t_clock() - tr;
         if (failed_) return;
         len += got;
         lines += nl;
@@ -357,6 +366,9 @@ class RecordBlocks {
         ready_.push_back(b);
         cv_.notify_all();
       }
+      t_read_ += t_reading;
+      t_cut_ += t_clock() - t1 - t_reading;
+      ++t_blocks_;
       if (b.final) break;
     }
     std::lock_guard<std::mutex> lk(mu_);
@@ -380,6 +392,9 @@ class RecordBlocks {
   double bytes_per_line_ = 64;
   uint64_t total_bytes_ = 0, total_lines_ = 0;
   std::thread producer_, pinner_;
+  static double t_clock() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  double t_wait_ = 0, t_read_ = 0, t_cut_ = 0;  // FQGPU_TIMING (the producer's; read after its join)
+  uint64_t t_blocks_ = 0;
   size_t pin_cap_ = 0;  // what the pinner gives every slot (from the first bytes' line lengths; set before it starts)
   std::mutex mu_;
   std::condition_variable cv_;
