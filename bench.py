@@ -1707,6 +1707,17 @@ def main():
                                            other * n, device=dev)
             barrier()
             dt_pair = time.perf_counter() - t2
+            # ... and what the usual placement costs - every rank holding the SAME records of both files, file 1 known to
+            # be free of repeats (fastq_info knows by then): names compared by position, no exchange (one rank only: the
+            # shards above are deliberately the next rank's)
+            by_position = None
+            if world == 1:
+                t3 = time.perf_counter()
+                pp = fdist.global_pairing(ctx, [(frame, rv["n_records"])], st, 0, [(frame2, rv2["n_records"])], st2, 0,
+                                          device=dev, file1_unique=True)
+                ctx.synchronize()
+                by_position = {"wall_ms": (time.perf_counter() - t3) * 1e3, "by_position": bool(pp.get("by_position")),
+                               "ok": pp["matched"] == n and pp["first_unpaired"] is None}
             ctx.profile(False)
             frame.release()
             frame2.release()
@@ -1729,7 +1740,8 @@ def main():
                             "matched": pairing["matched"], "leftover": pairing["leftover"], "unpaired": pairing["unpaired"],
                             "ok": pairing["matched"] == n * world and pairing["first_unpaired"] is None,
                             "wall_ms_max_over_ranks": dt_pair * 1e3,
-                            "Mpairs_per_s_whole_job": n * world / dt_pair / 1e6},
+                            "Mpairs_per_s_whole_job": n * world / dt_pair / 1e6,
+                            "same_shards_by_position": by_position},
             }
             if own_group:
                 dist.destroy_process_group()

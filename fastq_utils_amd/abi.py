@@ -720,6 +720,19 @@ class Context:
                                                             C.c_void_p(int(names_device_ptr)), counts, None))
         return [int(x) for x in counts]
 
+    def frame_name_records(self, frame, state, first, n, out_device_ptr):
+        """the NAME_REC_BYTES-byte name records of records first .. first + n - 1 of a retained frame into device memory
+        (fqg_frame_name_records: names by position, include/fqg.h)"""
+        self._check(load().fqg_frame_name_records(self.h, frame.h, C.byref(state), first, n, C.c_void_p(int(out_device_ptr))))
+
+    def frame_names_equal(self, frame, state, first, n, recs_device_ptr):
+        """(records of the frame whose name is the name record at the same place, records that agree in the 56 bytes a
+        record holds but are longer) - fqg_frame_names_equal"""
+        eq, und = C.c_uint64(0), C.c_uint64(0)
+        self._check(load().fqg_frame_names_equal(self.h, frame.h, C.byref(state), first, n, C.c_void_p(int(recs_device_ptr)),
+                                                 C.byref(eq), C.byref(und)))
+        return int(eq.value), int(und.value)
+
     def fingerprint_set(self, expected):
         return FingerprintSet(self, expected)
 

@@ -326,7 +326,44 @@ def _export_fingerprints(ctx, frames, state, base, world, dev, torch, named=Fals
     return (parts, totals, nparts) if named else (parts, totals)
 
 
-def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=None, device=None):
+def paired_by_position(ctx, frames1, state1, base1, frames2, state2, base2, group=None, device=None):
+    """Mate files hold their reads in one order.  When every rank holds the SAME records of both files (base1 == base2,
+    as many records of each - the shards of a pair cut at the same record numbers) the question "is the name of record i
+    of file 2 the name of record i of file 1, for every i" needs no exchange at all: each rank compares its own ranges
+    (fqg_frame_name_records / fqg_frame_names_equal, include/fqg.h) and one all-reduce says whether every rank said yes.
+    True on every rank, or False on every rank (shards that differ, one name out of place, a name beyond the 56 bytes of
+    a name record: the caller exchanges by hash).  With file 1 free of repeated names, True is "every read paired"."""
+    import torch
+    import torch.distributed as dist
+
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    n1 = sum(n for _, n in frames1)
+    n2 = sum(n for _, n in frames2)
+    ok = base1 == base2 and n1 == n2
+    if ok and n1:
+        longest = max(n for _, n in list(frames1) + list(frames2))
+        buf = torch.empty(longest * NAME_BYTES, dtype=torch.uint8, device=dev)
+        a0 = 0
+        spans1 = []
+        for fr, n in frames1:
+            spans1.append((a0, n, fr))
+            a0 += n
+        b0 = 0
+        for fr2, m in frames2:
+            for a, n, fr1 in spans1:
+                lo, hi = max(a, b0), min(a + n, b0 + m)
+                if lo >= hi or not ok:
+                    continue
+                ctx.frame_name_records(fr1, state1, lo - a, hi - lo, buf.data_ptr())
+                eq, _ = ctx.frame_names_equal(fr2, state2, lo - b0, hi - lo, buf.data_ptr())
+                ok = ok and eq == hi - lo
+            b0 += m
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=None, device=None, file1_unique=False):
     """The file-2 loop of fastq_info over ranks that hold ARBITRARY shards of the two files:
     frames1 / frames2 = this rank's retained frames [(frame, n_records)] of file 1 / file 2, whose records are
     base1 / base2, +1, ... in their file.  Every name travels as a 16-byte (fingerprint, index) pair to the
@@ -334,12 +371,22 @@ def global_pairing(ctx, frames1, state1, base1, frames2, state2, base2, group=No
     of equal fingerprints on the device; what a fingerprint cannot decide is resolved on the name bytes.
     Returns, identically on every rank: dict(matched, leftover, unpaired, first_unpaired = (file-2 record
     index, its name) or None) - first_unpaired is where the serial loop prints "unpaired read", leftover what
-    it reports as "found N unpaired reads" when it gets to the end."""
+    it reports as "found N unpaired reads" when it gets to the end.
+    file1_unique: the caller has established that no name of file 1 occurs twice (fastq_info has, by the time it reads
+    file 2) - then mates that lie at the same place on every rank are paired without any exchange (paired_by_position;
+    FQGPU_NO_POSITIONAL_MATCH=1 leaves that out)."""
+    import os
+
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if file1_unique and not os.environ.get("FQGPU_NO_POSITIONAL_MATCH"):
+        if paired_by_position(ctx, frames1, state1, base1, frames2, state2, base2, group, dev):
+            total = torch.tensor([sum(n for _, n in frames2)], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(total, group=group)
+            return {"matched": int(total.item()), "leftover": 0, "unpaired": 0, "first_unpaired": None, "by_position": True}
     p1, c1, n1 = _export_fingerprints(ctx, frames1, state1, base1, world, dev, torch, named=True)
     p2, c2, n2 = _export_fingerprints(ctx, frames2, state2, base2 | FP_FILE2, world, dev, torch, named=True)
     pieces = [t for o in range(world) for t in (p1[o] + p2[o])]

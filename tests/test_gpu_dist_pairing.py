@@ -163,6 +163,48 @@ def test_protocol_through_a_one_rank_rccl_group(ctx):
         dist.destroy_process_group()
 
 
+def test_mates_in_one_order_are_paired_without_an_exchange(ctx):
+    """global_pairing(file1_unique=True): shards cut at the same record numbers, every name at its place -> by position
+    (dist.paired_by_position), no all-to-all; one read out of place, a shorter file 2, shards that differ -> the exchange,
+    with the oracle's outcome"""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(78)
+        img1 = fuzz.make_fastq(rng, 3000, 30, 50, "casava")
+        recs2 = records_of(mates(img1))
+        swapped = list(recs2)
+        swapped[100], swapped[2000] = swapped[2000], swapped[100]
+        for label, second, base2 in (("ordered", recs2, 0), ("swapped", swapped, 0), ("short", recs2[:2500], 0), ("other_base", recs2, 5)):
+            img2 = b"".join(second)
+            st1, st2 = fq.abi.probe_first_record(img1, True), fq.abi.probe_first_record(img2, True)
+            frames = {}
+            for key, img, st, at in ((1, img1, st1, 1100), (2, img2, st2, 700)):   # (the two files cut at different records)
+                cut = len(b"".join(records_of(img)[:at]))
+                frames[key] = []
+                for piece in (img[:cut], img[cut:]):
+                    r = ctx.validate(piece, None, st, flags=fq.abi.VALIDATE_NO_STATS)
+                    frames[key].append((ctx.retain_frame(), r["n_records"]))
+            got = fdist.global_pairing(ctx, frames[1], st1, 0, frames[2], st2, base2, file1_unique=True)
+            plain = fdist.global_pairing(ctx, frames[1], st1, 0, frames[2], st2, base2)
+            assert bool(got.get("by_position")) == (label == "ordered"), (label, got)
+            assert not plain.get("by_position")
+            for k in ("matched", "leftover", "unpaired", "first_unpaired"):
+                assert got[k] == plain[k], (label, k, got, plain)
+            if base2 == 0:
+                want = oracle_pairing(img1, img2)
+                assert (got["first_unpaired"][0] if got["first_unpaired"] else None) == want[0], (label, got, want)
+            for key in frames:
+                for fr, _ in frames[key]:
+                    fr.release()
+    finally:
+        dist.destroy_process_group()
+
+
 def orphans_on_both_sides(seed, n=3000, long_names=False):
     """two files of which every seventh read of file 1 and every eleventh of file 2 has no mate, file 2 in another order
     (long_names: names of 60 - 90 bytes - beyond the 56 a name record holds)"""
