@@ -2221,8 +2221,21 @@ struct fqg_census {
   DevBuf cells2, umis2, tmp, flag, local, sums, lines;
   unsigned long long* d_count = nullptr;
   uint64_t n_pairs = 0, n_cells = 0;
+  unsigned umi_bits = 1, cell_bits = 1;  // bits the packed values of the batches so far can need (census_bits)
   bool finished = false;
 };
+
+// char2uint_64 of at most `size` characters is below 10^size: the sorts of fqg_census_finish need not look at more bits
+// (a UMI of 10 bases: 34 of 64, a cell barcode of 16: 54).  A size that is not known (< 0), or beyond 19 digits: all 64.
+static unsigned census_bits(long size) {
+  if (size <= 0) return size == 0 ? 1u : 64u;
+  if (size > 19) return 64u;
+  unsigned long long lim = 1;
+  for (long i = 0; i < size; ++i) lim *= 10ull;
+  unsigned bits = 1;
+  while (bits < 64 && (1ull << bits) < lim) ++bits;
+  return bits;
+}
 
 int fqg_census_create(fqg_ctx* c, fqg_census** out) {
   if (!c || !out) return FQG_ERR_ARG;
@@ -2280,6 +2293,8 @@ int fqg_barcodes_census(fqg_ctx* c, fqg_census* z, const fqg_frame* const frames
   int rc;
   if ((rc = bc_make_params(c, frames, states, first_record, bp, n_done, 0, P, inter))) return rc;
   if ((rc = census_reserve(c, z, z->n_pairs + n_done))) return rc;
+  z->umi_bits = std::max(z->umi_bits, census_bits((long)P.umi_size));
+  z->cell_bits = std::max(z->cell_bits, P.cell_read > 0 ? census_bits((long)P.cell_size) : 1u);
   HIP_TRY(c, hipMemsetAsync(z->d_count, 0, 8, c->stream));
   {
     ProfScope ps(c, "k_bc_census");
@@ -2310,12 +2325,13 @@ int fqg_census_finish(fqg_ctx* c, fqg_census* z, uint64_t* n_pairs, uint64_t* n_
     unsigned long long *ce = (unsigned long long*)z->cells.p, *um = (unsigned long long*)z->umis.p;
     unsigned long long *ce2 = (unsigned long long*)z->cells2.p, *um2 = (unsigned long long*)z->umis2.p;
     size_t tmp_bytes = 0;
+    const unsigned ub = z->umi_bits, cb = z->cell_bits;
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, um, um2, ce, ce2, n, 0, 64, c->stream) != hipSuccess)
       return fail(c, FQG_ERR_HIP, "fqg_census_finish: sort");
     if ((rc = ensure(c, z->tmp, tmp_bytes + 16))) return rc;
     ProfScope ps(c, "k_census_finish");
-    if (rocprim::radix_sort_pairs(z->tmp.p, tmp_bytes, um, um2, ce, ce2, n, 0, 64, c->stream) != hipSuccess ||
-        rocprim::radix_sort_pairs(z->tmp.p, tmp_bytes, ce2, ce, um2, um, n, 0, 64, c->stream) != hipSuccess)
+    if (rocprim::radix_sort_pairs(z->tmp.p, tmp_bytes, um, um2, ce, ce2, n, 0, ub, c->stream) != hipSuccess ||
+        rocprim::radix_sort_pairs(z->tmp.p, tmp_bytes, ce2, ce, um2, um, n, 0, cb, c->stream) != hipSuccess)
       return fail(c, FQG_ERR_HIP, "fqg_census_finish: sort");
     const uint64_t nb = (n + kScan64Span - 1) / kScan64Span;
     if ((rc = ensure(c, z->flag, n * 4)) || (rc = ensure(c, z->local, n * 8)) || (rc = ensure(c, z->sums, nb * 8 + 8))) return rc;
@@ -2501,21 +2517,21 @@ int fqg_records_filter(fqg_ctx* c, const fqg_frame* frame, uint64_t first_record
     if (P.mode == FQG_FILTER_N) {
       const unsigned grid_n = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rec + 31) / 32, (uint64_t)c->cu_count * 32));
       hipLaunchKernelGGL(k_rf_plan_n, dim3(grid_n), dim3(kBlock), 0, c->stream, F, P, n_rec, (uint8_t*)c->bc_status.p,
-                         (uint32_t*)c->bc_len[1].p);
+                         (uint32_t*)c->bc_len[1].p, c->d_bcall);
     } else {
       hipLaunchKernelGGL(k_rf_plan_records, dim3(grid), dim3(kBlock), 0, c->stream, F, P, n_rec, (uint8_t*)c->bc_status.p,
-                         (uint32_t*)c->bc_len[1].p);
+                         (uint32_t*)c->bc_len[1].p, c->d_bcall);
     }
-    hipLaunchKernelGGL(k_rf_tile_flags, dim3((unsigned)((n_tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, F, tc, n_rec,
-                       (const uint32_t*)c->bc_len[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
   }
   {
+    // (the plan kernels count what they drop and trim; the tile flags come behind the scan, whose offsets they use)
     ProfScope ps(c, "k_rf_scan");
-    hipLaunchKernelGGL(k_rf_count, dim3((unsigned)std::min<uint64_t>((n_rec + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0,
-                       c->stream, (const uint8_t*)c->bc_status.p, n_rec, c->d_bcall);
     hipLaunchKernelGGL(k_scan64_a, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, (const uint32_t*)c->bc_len[1].p, n_rec,
                        (unsigned long long*)c->bc_off[1].p, (unsigned long long*)c->bc_sum[1].p);
     hipLaunchKernelGGL(k_scan64_b, dim3(1), dim3(kBlock), 0, c->stream, (unsigned long long*)c->bc_sum[1].p, nb, d_tot + 1);
+    hipLaunchKernelGGL(k_rf_tile_flags, dim3((unsigned)((n_tiles + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, F, tc, n_rec,
+                       (const uint32_t*)c->bc_len[1].p, (const unsigned long long*)c->bc_off[1].p,
+                       (const unsigned long long*)c->bc_sum[1].p, (uint8_t*)c->bc_tile_big.p, c->d_bcall);
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_bcall, c->d_bcall, sizeof(BcCall) + 64, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

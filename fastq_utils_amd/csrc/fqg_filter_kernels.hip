@@ -147,15 +147,28 @@ __device__ __forceinline__ void rf_emit(const BcLine (&ln)[4], const RfCut& c, W
 // first character that is no A / T / N: one or two bytes per record on ordinary reads).  The first form of this kernel
 // staged whole tiles in LDS the way the emit kernel does and read every record twice (39 GB for the 35 GB image of
 // the bench, 8.2 ms of 22.5); a record's header and quality bytes are nothing the decision looks at.
+// the discarded / trimmed records of a plan kernel's thread -> the call's totals: one add per wavefront, at its end
+__device__ __forceinline__ void rf_count_flush(uint32_t d, uint32_t t, BcCall* __restrict__ call) {
+  d = wave_sum32(d);
+  t = wave_sum32(t);
+  if ((threadIdx.x & 63) == 0) {
+    if (d) atomicAdd(&call->discarded, (unsigned long long)d);
+    if (t) atomicAdd(&call->short_warnings, (unsigned long long)t);  // (the field holds the trimmed count here)
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_rf_plan_records(BcParams F, RfParams P, uint64_t n_rec, uint8_t* __restrict__ status,
-                                                            uint32_t* __restrict__ len1) {
+                                                            uint32_t* __restrict__ len1, BcCall* __restrict__ call) {
+  uint32_t n_d = 0, n_t = 0;
   for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_rec; k += (uint64_t)gridDim.x * kBlock) {
     BcLine G[4];
     bc_lines(F.f[1], k, G);
     const RfCut c = rf_decide<false>(P, G);
     status[k] = c.flags;
     len1[k] = (c.flags & kRfDiscard) ? 0u : rf_out_len(G, c);
+    n_d += (c.flags & kRfDiscard) ? 1u : 0u;
+    n_t += (c.flags & kRfTrimmed) ? 1u : 0u;
   }
+  rf_count_flush(n_d, n_t, call);
 }
 
 // fastq_filter_n looks at every character of the sequence line: EIGHT LANES PER RECORD read it where it lies, 32 bytes
@@ -163,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_rf_plan_records(BcParams F, RfParams
 // records' sequence lines, a handful of cache lines, where one lane per record asked for 64 lines at once (10.2 ms for
 // the 100 M reads of the bench, more than the tile-staging plan it replaced).  The counts meet in the group's first lane.
 __global__ __launch_bounds__(kBlock) void k_rf_plan_n(BcParams F, RfParams P, uint64_t n_rec, uint8_t* __restrict__ status,
-                                                      uint32_t* __restrict__ len1) {
+                                                      uint32_t* __restrict__ len1, BcCall* __restrict__ call) {
+  uint32_t n_d = 0;
   const int lane = (int)(threadIdx.x & 63), sub = lane & 7;
   const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
@@ -209,13 +223,19 @@ __global__ __launch_bounds__(kBlock) void k_rf_plan_n(BcParams F, RfParams P, ui
       const bool drop = cnt > max_num_n;
       status[k] = drop ? kRfDiscard : 0;
       len1[k] = drop ? 0u : G[0].len + G[0].nl + L + G[2].len + G[2].nl + Lq;
+      n_d += drop ? 1u : 0u;
     }
   }
+  rf_count_flush(n_d, 0u, call);
 }
 
 // ... and what it decides per EMIT tile - do the tile's input span and its output fit the emit kernel's LDS areas
 // (bc_emit_tile_fits for the one input file): one thread per tile
+// (behind the scan of the lengths: a tile's output bytes are the difference of two offsets - the sum over its T lengths,
+// read one by one at a stride of T words from lane to lane, was most of this kernel's millisecond per 100 M records)
 __global__ __launch_bounds__(kBlock) void k_rf_tile_flags(BcParams F, BcTile tc, uint64_t n_rec, const uint32_t* __restrict__ len1,
+                                                          const unsigned long long* __restrict__ off,
+                                                          const unsigned long long* __restrict__ span_excl,
                                                           uint8_t* __restrict__ tile_big, BcCall* __restrict__ call) {
   const uint64_t n_tiles = (n_rec + tc.T - 1) / tc.T;
   const BcFile& f = F.f[1];
@@ -223,8 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_rf_tile_flags(BcParams F, BcTile tc,
   const uint64_t tile = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (tile < n_tiles) {
     const uint64_t k0 = tile * tc.T, k1 = (k0 + tc.T < n_rec ? k0 + tc.T : n_rec) - 1;
-    uint64_t sum = 0;
-    for (uint64_t k = k0; k <= k1; ++k) sum += len1[k];
+    const uint64_t sum = (off[k1] + span_excl[k1 / kScan64Span] + len1[k1]) - (off[k0] + span_excl[k0 / kScan64Span]);
     const uint64_t r0 = f.first + k0 * f.step + f.add, r1 = f.first + k1 * f.step + f.add;
     const uint64_t s0 = r0 == 0 ? 0 : f.fv.line_end[4 * r0 - 1] + 1, e3l = f.fv.line_end[4 * r1 + 3];
     const uint64_t n = (e3l < f.fv.nbytes ? e3l + 1 : e3l) - s0;
@@ -236,37 +255,6 @@ __global__ __launch_bounds__(kBlock) void k_rf_tile_flags(BcParams F, BcTile tc,
   }
   const unsigned long long m = __ballot(big);
   if (m && (threadIdx.x & 63) == 0) atomicAdd(&call->big, (unsigned long long)__builtin_popcountll(m));
-}
-
-// discarded / trimmed records: one atomic per workgroup
-__global__ __launch_bounds__(kBlock) void k_rf_count(const uint8_t* __restrict__ status, uint64_t n,
-                                                     BcCall* __restrict__ call) {
-  __shared__ unsigned long long s_d[kBlock / kWave], s_t[kBlock / kWave];
-  unsigned long long d = 0, t = 0;
-  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (uint64_t)gridDim.x * kBlock) {
-    const uint8_t st = status[k];
-    d += (st & kRfDiscard) ? 1u : 0u;
-    t += (st & kRfTrimmed) ? 1u : 0u;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    d += __shfl_xor(d, o, 64);
-    t += __shfl_xor(t, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_d[threadIdx.x >> 6] = d;
-    s_t[threadIdx.x >> 6] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long td = 0, tt = 0;
-    for (int w = 0; w < kBlock / kWave; ++w) {
-      td += s_d[w];
-      tt += s_t[w];
-    }
-    if (td) atomicAdd(&call->discarded, td);
-    if (tt) atomicAdd(&call->short_warnings, tt);  // (the field holds the trimmed count here)
-  }
 }
 
 __global__ __launch_bounds__(kWave, 2) void k_rf_emit_tile(BcParams F, RfParams P, BcTile tc, uint64_t n_rec,
