@@ -1100,13 +1100,15 @@ def filterpair_extra(ctx, fq, torch, dev, n, read_len):
         ctx.profile_reset()
         ctx.synchronize()
         t0 = time.perf_counter()
-        v1 = ctx.validate(img[0].data_ptr(), None, st[0], final=True, flags=A.VALIDATE_NO_STATS, nbytes=m * R)
+        # (framed as the program frames them, host/fastq_filterpair.cpp: FQG_VALIDATE_NAMES - the header lines come to the
+        # index calls as capture records of the streaming pass)
+        v1 = ctx.validate(img[0].data_ptr(), None, st[0], final=True, flags=A.VALIDATE_NO_STATS | A.VALIDATE_NAMES, nbytes=m * R)
         idx = ctx.name_index(m)
         ir = idx.insert_unique(st[0])
-        v2 = ctx.validate(img[1].data_ptr(), None, st[1], final=True, flags=A.VALIDATE_NO_STATS, nbytes=m * R)
+        v2 = ctx.validate(img[1].data_ptr(), None, st[1], final=True, flags=A.VALIDATE_NO_STATS | A.VALIDATE_NAMES, nbytes=m * R)
+        pr, match = idx.probe_delete_np(st[1], m)
         f2 = ctx.retain_frame()
         ctx.frame_make_current(f2)
-        pr, match = idx.probe_delete_np(st[1], m)
         alive = idx.alive_np(m)
         found = match < np.uint64(0xFFFFFFFFFFFFFFFE)
         # file 1's leftovers are read on from behind the LAST record that was copied (src/fastq_filterpair.c:196-216)
@@ -1117,7 +1119,7 @@ def filterpair_extra(ctx, fq, torch, dev, n, read_len):
         outs = [ctx.records_gather(fr, rec, want_output=want_text) for fr, rec in lists]
         ctx.synchronize()
         wall = time.perf_counter() - t0
-        prof = {k: v[1] for k, v in ctx.profile_read().items() if v[0] > 0 and k.startswith(("k_index", "k_gather", "k_scan64"))}
+        prof = {k: v[1] for k, v in ctx.profile_read().items() if v[0] > 0 and k.startswith(("k_index", "k_names", "k_gather", "k_scan64"))}
         ctx.profile(False)
         res = {"codes": [v1["code"], ir["code"], v2["code"], pr["code"]], "matched": int(found.sum()), "alive": int(alive.sum()),
                "bytes": [o[0] for o in outs], "wall": wall, "prof": prof, "text": [o[1] for o in outs],
