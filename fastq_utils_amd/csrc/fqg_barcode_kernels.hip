@@ -475,6 +475,50 @@ __device__ __forceinline__ void bc_out_lens(const BcParams& P, uint64_t k, const
   }
 }
 
+// bc_decide_lines and bc_out_lens for the kernels for any set of files: the lines of a file are asked for (lines_of(x, ln))
+// only inside the branch that looks at them - files that carry no barcode are never asked for
+template <bool WIDE, int MASK, class LinesOf>
+__device__ __forceinline__ uint8_t bc_decide_with(const BcParams& P, LinesOf lines_of, BcTags* tags) {
+  tags->n[0] = tags->n[1] = tags->n[2] = 0;
+  tags->qn[0] = tags->qn[1] = tags->qn[2] = 0;
+#pragma unroll
+  for (int x = 1; x < kBcFiles; ++x)
+    if (bc_has<MASK>(P, x) && (P.umi_read == x || P.sample_read == x || P.cell_read == x)) {
+      BcLine ln[4];
+      lines_of(x, ln);
+      int rc = 0;
+      if (P.umi_read == x) rc = bc_get<WIDE>(ln, P.umi_off, P.umi_size, P.phred, P.min_qual, &tags->n[0], &tags->qn[0], &tags->s[0], &tags->q[0]);
+      if (!rc && P.sample_read == x)
+        rc = bc_get<WIDE>(ln, P.sample_off, P.sample_size, P.phred, P.min_qual, &tags->n[2], &tags->qn[2], &tags->s[2], &tags->q[2]);
+      if (!rc && P.cell_read == x)
+        rc = bc_get<WIDE>(ln, P.cell_off, P.cell_size, P.phred, P.min_qual, &tags->n[1], &tags->qn[1], &tags->s[1], &tags->q[1]);
+      if (rc) return rc == 1 ? kBcDiscardShort : kBcDiscardQual;
+    }
+  return kBcKeep;
+}
+template <int MASK, class LinesOf>
+__device__ __forceinline__ void bc_out_lens_with(const BcParams& P, uint64_t k, LinesOf lines_of, const BcTags& t, uint32_t* a,
+                                                 uint32_t* b, uint32_t* c) {
+  *a = *b = *c = 0;
+  const bool se = !bc_has<MASK>(P, 2);
+  if (P.out_sam || P.emit[1]) {
+    BcLine ln[4];
+    lines_of(1, ln);
+    if (P.out_sam)
+      *a = bc_sam_line_len(P.first_read_number + k + 1, bc_sam_flag(se, true),
+                           bc_sam_geom(bc_slices(P, 1), P.read_off[1], P.read_size[1], true, ln), t);
+    else *b = bc_fastq_len(bc_slices(P, 1), P.read_off[1], P.read_size[1], ln, t);
+  }
+  if (!se && (P.out_sam || P.emit[2])) {
+    BcLine ln[4];
+    lines_of(2, ln);
+    if (P.out_sam)
+      *a += bc_sam_line_len(P.first_read_number + k + 1, bc_sam_flag(se, false),
+                            bc_sam_geom(bc_slices(P, 2), P.read_off[2], P.read_size[2], false, ln), t);
+    else *c = bc_fastq_len(bc_slices(P, 2), P.read_off[2], P.read_size[2], ln, t);
+  }
+}
+
 // ---- wavefront helpers --------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t rfl64(uint64_t v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -610,21 +654,28 @@ __device__ __forceinline__ void bc_span_copy(const SpanPlan& sp, uint32_t from_u
 }
 // the lane's lines: pointers into the staged spans (a file that is not staged: the lengths of its lines, no bytes -
 // pointers that are never followed)
+// (one file's lines: the kernels for any set of files ask for them where they use them - five files' lines at once are 80
+// registers)
+template <bool PLAN, int MASK>
+__device__ __forceinline__ void bc_file_lines(const BcParams& P, const TileGeo& tg, const SpanPlan& sp, uint8_t* s_in, int x,
+                                              BcLine (&ln)[4]) {
+  const BcGeo& g = tg.f[x];
+  const uint64_t nb = P.f[x].fv.nbytes;
+  const bool st = bc_staged<PLAN, MASK>(P, x);
+  uint8_t* b = st ? s_in + 16u * sp.first_unit[x] + sp.skew[x] : s_in;
+  const uint64_t s0 = st ? sp.s0[x] : g.start();
+  ln[0] = BcLine{b + (uint32_t)(g.start() - s0), (uint32_t)(g.e[0] - g.start()), g.e[0] < nb ? 1u : 0u};
+  ln[1] = BcLine{b + (uint32_t)(g.e[0] + 1 - s0), (uint32_t)(g.e[1] - g.e[0] - 1), g.e[1] < nb ? 1u : 0u};
+  ln[2] = BcLine{b + (uint32_t)(g.e[1] + 1 - s0), (uint32_t)(g.e[2] - g.e[1] - 1), g.e[2] < nb ? 1u : 0u};
+  ln[3] = BcLine{b + (uint32_t)(g.e[2] + 1 - s0), (uint32_t)(g.e[3] - g.e[2] - 1), g.e[3] < nb ? 1u : 0u};
+}
 template <bool PLAN, int MASK>
 __device__ __forceinline__ void bc_span_lines(const BcParams& P, const TileGeo& tg, const SpanPlan& sp, uint8_t* s_in,
                                               BcLine (&L)[kBcFiles][4]) {
 #pragma unroll
   for (int x = 1; x < kBcFiles; ++x) {
     if (!bc_has<MASK>(P, x)) continue;
-    const BcGeo& g = tg.f[x];
-    const uint64_t nb = P.f[x].fv.nbytes;
-    const bool st = bc_staged<PLAN, MASK>(P, x);
-    uint8_t* b = st ? s_in + 16u * sp.first_unit[x] + sp.skew[x] : s_in;
-    const uint64_t s0 = st ? sp.s0[x] : g.start();
-    L[x][0] = BcLine{b + (uint32_t)(g.start() - s0), (uint32_t)(g.e[0] - g.start()), g.e[0] < nb ? 1u : 0u};
-    L[x][1] = BcLine{b + (uint32_t)(g.e[0] + 1 - s0), (uint32_t)(g.e[1] - g.e[0] - 1), g.e[1] < nb ? 1u : 0u};
-    L[x][2] = BcLine{b + (uint32_t)(g.e[1] + 1 - s0), (uint32_t)(g.e[2] - g.e[1] - 1), g.e[2] < nb ? 1u : 0u};
-    L[x][3] = BcLine{b + (uint32_t)(g.e[2] + 1 - s0), (uint32_t)(g.e[3] - g.e[2] - 1), g.e[3] < nb ? 1u : 0u};
+    bc_file_lines<PLAN, MASK>(P, tg, sp, s_in, x, L[x]);
   }
 }
 
@@ -693,11 +744,23 @@ __device__ __forceinline__ void bc_lines_all(const BcParams& P, uint64_t k, BcLi
 // holds little, so many wavefronts are resident.  The name checks, which need the header bytes of every file, are made
 // by the emit kernels on the records they stage anyway (bc_check_names).  What the plan decides per emit tile - does
 // the tile fit the emit kernel's LDS areas - is worked out per group of T lanes.  MASK: see bc_has.
-// (MASK 0, any set of files: five files' lines and index entries are 233 registers - two wavefronts per SIMD, and no
-// index of a second tile in flight; 3 wavefronts: 244 bytes of scratch memory per lane and 4.7 ms instead of 3.6 on 50 M
-// iterations of four files)
+//
+// How each instantiation hides its round trips to memory (measured on 200 M pairs of READ1 + INDEX1 and 50 M iterations of
+// four files; the other sets of files keep what they had):
+//   any set of files (MASK 0): no index of a second tile in flight, a file's lines made where they are looked at
+//     (bc_decide_with) - 128 registers, FOUR wavefronts per SIMD: 2.0 ms where five files' lines at once (233 registers,
+//     two wavefronts) took 3.6;
+//   READ1 + INDEX1: no second tile in flight either, 96 registers, FIVE wavefronts: 7.8 ms against 8.4 with the next
+//     tile's index requested ahead and four wavefronts;
+//   the other specialised sets: the next tile's index requested ahead (many wavefronts are resident here - little LDS -
+//     and hide each other's round trips: the three-tile scheme of the emit kernel made this kernel slower, 7.7 -> 11.2 ms).
 template <int MASK>
-__global__ __launch_bounds__(kWave, MASK == 0 ? 2 : 1) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
+struct PlanShape {
+  static constexpr bool ahead = MASK != 0 && MASK != 0x0A;
+  static constexpr int waves = MASK == 0 ? 4 : (MASK == 0x0A ? 5 : 1);
+};
+template <int MASK>
+__global__ __launch_bounds__(kWave, PlanShape<MASK>::waves) void k_bc_plan_tile(BcParams P, BcTile tc, uint64_t n_iter, uint8_t* __restrict__ status,
                                                         uint32_t* __restrict__ len0, uint32_t* __restrict__ len1,
                                                         uint32_t* __restrict__ len2, uint8_t* __restrict__ tile_big,
                                                         BcCall* __restrict__ call) {
@@ -716,13 +779,9 @@ __global__ __launch_bounds__(kWave, MASK == 0 ? 2 : 1) void k_bc_plan_tile(BcPar
     for (int x = 1; x < kBcFiles; ++x)
       if (bc_has<MASK>(P, x)) bc_geo_load(P.f[x], k, tg.f[x]);
   };
-  // (Many wavefronts are resident here - little LDS, ~100 registers - and hide each other's round trips: the three-tile
-  // scheme of the emit kernel, which costs 70 registers, made this kernel slower, 7.7 -> 11.2 ms.)
   TileGeo cur, nxt;
   uint32_t n_dropped = 0, n_short = 0;  // of this wavefront's tiles: added to the call's totals once, at the end
-  // (The kernel for any set of files has no registers for the index of a second tile - five files' worth: it asks for a
-  // tile's index when it gets there.)
-  constexpr bool kAhead = MASK != 0;
+  constexpr bool kAhead = PlanShape<MASK>::ahead;  // (false: a tile's index is asked for when the wavefront gets there)
   if (kAhead && blockIdx.x < n_tiles) geo_of(blockIdx.x, cur);
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t k0 = tile * Tp;
@@ -733,20 +792,39 @@ __global__ __launch_bounds__(kWave, MASK == 0 ? 2 : 1) void k_bc_plan_tile(BcPar
     if (kAhead) geo_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : n_tiles - 1, nxt);  // the next tile's index (requested without a branch)
     else geo_of(tile, cur);
     // (an image with NUL bytes: lines are C strings, found by scanning them where they lie - bc_lines)
-    const bool fit = !P.has_nul && bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     BcTags t;
     uint32_t a = 0, b = 0, c = 0;
     uint8_t st;
-    if (fit) {
-      st = bc_decide_lines<true, MASK>(P, L, &t);
-      if (st == kBcKeep) bc_out_lens(P, k, L, t, &a, &b, &c);
-    } else {  // long reads: from the images
-      BcLine G[kBcFiles][4];
-      bc_lines_all<MASK>(P, k, G);
-      st = bc_decide_lines<false, MASK>(P, G, &t);
-      if (st == kBcKeep) bc_out_lens(P, k, G, t, &a, &b, &c);
+    if constexpr (MASK == 0) {
+      // any set of files: a file's lines are made where they are looked at (bc_decide_with) - never all five at once
+      SpanPlan sp;
+      bc_span_plan<true, MASK>(P, cur, (int)Tn - 1, plan_cap, sp);
+      const bool fit = !P.has_nul && sp.fit;
+      if (fit) bc_span_copy(sp, 0, lane, s_lds);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (fit) {
+        auto staged = [&](int x, BcLine(&ln)[4]) { bc_file_lines<true, MASK>(P, cur, sp, s_lds, x, ln); };
+        st = bc_decide_with<true, MASK>(P, staged, &t);
+        if (st == kBcKeep) bc_out_lens_with<MASK>(P, k, staged, t, &a, &b, &c);
+      } else {  // long reads: from the images
+        auto from_image = [&](int x, BcLine(&ln)[4]) { bc_lines(P.f[x], k, ln); };
+        st = bc_decide_with<false, MASK>(P, from_image, &t);
+        if (st == kBcKeep) bc_out_lens_with<MASK>(P, k, from_image, t, &a, &b, &c);
+      }
+    } else {
+      const bool fit = !P.has_nul && bc_stage_tile<true, MASK>(P, cur, (int)Tn - 1, lane, s_lds, plan_cap, L);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (fit) {
+        st = bc_decide_lines<true, MASK>(P, L, &t);
+        if (st == kBcKeep) bc_out_lens(P, k, L, t, &a, &b, &c);
+      } else {  // long reads: from the images
+        BcLine G[kBcFiles][4];
+        bc_lines_all<MASK>(P, k, G);
+        st = bc_decide_lines<false, MASK>(P, G, &t);
+        if (st == kBcKeep) bc_out_lens(P, k, G, t, &a, &b, &c);
+      }
     }
     if (valid) {
       status[k] = st;
