@@ -160,8 +160,10 @@ def extra_line(name, block):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (the first passes over a fresh 35 GB image run 2 % slower than the ones behind them - 8.11 - 8.18 ms against 7.98 - 8.03
+    # with five warm-up steps, whatever the number of timed steps: the defaults leave that behind)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
