@@ -94,6 +94,8 @@ def extras_summary(extras):
         "pre_barcodes_GBps": _get(e, "pre_barcodes_extra", "achieved_GBps_kernels"),
         "pre_barcodes_generic_50M_ms": _get(e, "pre_barcodes_extra", "generic_file_set", "kernels_ms"),
         "census_200M_ms": _get(e, "pre_barcodes_extra", "census_stage", "census_kernel_ms"),
+        "pre_barcodes_program_200M_sam_s": (lambda v: min(v) if v else None)(_get(e, "pre_barcodes_extra", "programs", "legs", "sam_to_stdout", "seconds")),
+        "fastq_info_r_two_contexts_Mreads_per_s": _get(e, "e2e", "cli_fastq_info_r_tmpfs_file", "variants", "two_contexts_one_gpu", "Mreads_per_s"),
         "filter_n_ms": _get(e, "filters_extra", "filter_n", "kernels_ms"),
         "trim_poly_at_ms": _get(e, "filters_extra", "trim_poly_at", "kernels_ms"),
         "umi_count_kernels_ms": _get(e, "umi_count_extra", "kernels_ms"),

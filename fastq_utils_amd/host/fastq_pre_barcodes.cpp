@@ -285,6 +285,7 @@ struct BlockRun {
     fqg_ctx* ctx;
     size_t limit, n_made = 0;
     std::vector<std::pair<char*, size_t>> free_;
+    std::set<char*> pageable;  // buffers that are not pinned (the pinned allocation failed)
     std::mutex mu;
     std::condition_variable cv;
     bool quit = false;
@@ -305,10 +306,16 @@ struct BlockRun {
           lk.unlock();
           const size_t want = bytes + bytes / 8 + 4096;
           char* p = static_cast<char*>(fqg_host_alloc(ctx, want));
+          bool plain = false;
+          if (!p) {  // (no pinned memory to be had: pageable memory does it, slower)
+            p = static_cast<char*>(malloc(want));
+            plain = p != nullptr;
+          }
           *cap = p ? want : 0;
-          if (!p) {
+          if (!p || plain) {
             lk.lock();
-            --n_made;
+            if (!p) --n_made;
+            else pageable.insert(p);
           }
           return p;
         }
@@ -316,8 +323,10 @@ struct BlockRun {
           char* small = free_.back().first;
           free_.pop_back();
           --n_made;
+          const bool plain = pageable.erase(small) != 0;
           lk.unlock();
-          fqg_host_free(ctx, small);
+          if (plain) free(small);
+          else fqg_host_free(ctx, small);
           lk.lock();
           continue;
         }
