@@ -95,7 +95,7 @@ def extras_summary(extras):
         "pre_barcodes_generic_50M_ms": _get(e, "pre_barcodes_extra", "generic_file_set", "kernels_ms"),
         "census_200M_ms": _get(e, "pre_barcodes_extra", "census_stage", "census_kernel_ms"),
         "pre_barcodes_program_200M_sam_s": (lambda v: min(v) if v else None)(_get(e, "pre_barcodes_extra", "programs", "legs", "sam_to_stdout", "seconds")),
-        "fastq_info_r_two_contexts_Mreads_per_s": _get(e, "e2e", "cli_fastq_info_r_tmpfs_file", "variants", "two_contexts_one_gpu", "Mreads_per_s"),
+        "fastq_info_r_one_context_Mreads_per_s": _get(e, "e2e", "cli_fastq_info_r_tmpfs_file", "variants", "one_context", "Mreads_per_s"),
         "filter_n_ms": _get(e, "filters_extra", "filter_n", "kernels_ms"),
         "trim_poly_at_ms": _get(e, "filters_extra", "trim_poly_at", "kernels_ms"),
         "umi_count_kernels_ms": _get(e, "umi_count_extra", "kernels_ms"),
@@ -806,7 +806,10 @@ def e2e_block(ctx, fq, torch, dev, image, n, R, st):
             variants = {}
             for label, env in (("timing", {"FQGPU_TIMING": "1"}), ("32_threads", {"FQGPU_HOST_THREADS": "32", "FQGPU_TIMING": "1"}),
                                ("256MiB_slots", {"FQGPU_CHUNK_MB": "256", "FQGPU_TIMING": "1"}),
-                               ("two_contexts_one_gpu", {"FQGPU_DEVICES": "0,0"})):
+                               ("two_contexts_one_gpu", {"FQGPU_DEVICES": "0,0"}),
+                               # (what the program does by itself on a file of this size since round 6; and the loop of one
+                               # context it ran before)
+                               ("one_context", {"FQGPU_ONE_CONTEXT": "1", "FQGPU_TIMING": "1"})):
                 t0 = time.perf_counter()
                 p = subprocess.run([exe, "-r", path], capture_output=True, env=dict(os.environ, **env))
                 dt = time.perf_counter() - t0

@@ -958,7 +958,22 @@ int main(int argc, char** argv) {
     S.acc2 = nullptr;  // the summary only looks at file 1 (src/fastq_info.c:316-319)
   } else if (!is_paired_data && skip_readname_check) {
     fprintf(stderr, "Skipping check for duplicated read names\n");
-    if (devices.size() > 1) run_single_noindex_multi(file1, S, devices);
+    // One GPU, nothing said, a large regular file: the loop over record-aligned pieces with TWO contexts on that GPU - one
+    // piece's copy runs beside another's kernels (the 100 M-read file of the bench from tmpfs: 94 Mreads/s against 87,
+    // 78 against 73 on a slower box; small files would only pay for the second context).  FQGPU_ONE_CONTEXT=1: the loop of
+    // one context, which is also what the index modes, streams and re-framed input (fq_respawn.h) run through.
+    std::vector<int> r_devs = devices;
+    if (r_devs.empty() && !getenv("FQGPU_ONE_CONTEXT") && !fqhost::reframing()) {
+      struct stat sb;
+      if (strcmp(file1, "-") != 0 && stat(file1, &sb) == 0 && S_ISREG(sb.st_mode)) {
+        unsigned char magic[2] = {0, 0};
+        const int fd = open(file1, O_RDONLY);
+        const bool gz = fd >= 0 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (fd >= 0) close(fd);
+        if ((uint64_t)sb.st_size >= (gz ? 512ull << 20 : 2048ull << 20)) r_devs.assign(2, dev ? atoi(dev) : 0);
+      }
+    }
+    if (r_devs.size() > 1) run_single_noindex_multi(file1, S, r_devs);
     else run_single_noindex(file1, S);
   } else {
     fprintf(stderr, "DEFAULT_HASHSIZE=%lu\n", 39000001ul);
