@@ -958,7 +958,7 @@ int main(int argc, char** argv) {
     S.acc2 = nullptr;  // the summary only looks at file 1 (src/fastq_info.c:316-319)
   } else if (!is_paired_data && skip_readname_check) {
     fprintf(stderr, "Skipping check for duplicated read names\n");
-    // One GPU, nothing said, a large regular file: the loop over record-aligned pieces with TWO contexts on that GPU - one
+    // One GPU, nothing said, a LARGE regular file: the loop over record-aligned pieces with TWO contexts on that GPU - one
     // piece's copy runs beside another's kernels (the 100 M-read file of the bench from tmpfs: 94 Mreads/s against 87,
     // 78 against 73 on a slower box; small files would only pay for the second context).  FQGPU_ONE_CONTEXT=1: the loop of
     // one context, which is also what the index modes, streams and re-framed input (fq_respawn.h) run through.
@@ -970,7 +970,9 @@ int main(int argc, char** argv) {
         const int fd = open(file1, O_RDONLY);
         const bool gz = fd >= 0 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
         if (fd >= 0) close(fd);
-        if ((uint64_t)sb.st_size >= (gz ? 512ull << 20 : 2048ull << 20)) r_devs.assign(2, dev ? atoi(dev) : 0);
+        // (16 GiB plain, 4 GiB gzip'd: on a file of 3.8 GB the second context - 30 ms to open, its slots to pin, both to take
+        // down - cost more than it brought, 0.45 - 0.48 s against 0.38 - 0.41; on 12.7 GB it is even, above that it wins)
+        if ((uint64_t)sb.st_size >= (gz ? 4ull << 30 : 16ull << 30)) r_devs.assign(2, dev ? atoi(dev) : 0);
       }
     }
     if (r_devs.size() > 1) run_single_noindex_multi(file1, S, r_devs);
