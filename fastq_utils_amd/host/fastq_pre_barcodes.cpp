@@ -765,13 +765,15 @@ int main(int argc, char** argv) {
   const char* dev = getenv("FQGPU_DEVICE");
   std::vector<int> devices = devices_from_env();  // FQGPU_DEVICES=0,1,..: record blocks over several GPUs
   if (has_interleaved) devices.clear();
-  // One GPU, nothing said: the loop over record blocks all the same, with two contexts on that GPU - every input has a
-  // reader of its own there (the serial loop below reads them one after the other: 1.4 s against 1.0 s for 40 M reads and
-  // their index reads from tmpfs, profiles/r06_multi_dev_legs.txt), and one block's copy runs beside another's kernels.
-  // FQGPU_SERIAL_LOOP=1 keeps the serial loop (it is also what --interleaved input runs through).
-  // (... and what a run that was started over on input cut at the gzgets limits goes through: fq_respawn.h)
-  if (devices.empty() && !has_interleaved && !fqhost::reframing() && !getenv("FQGPU_SERIAL_LOOP")) devices.assign(2, dev ? atoi(dev) : 0);
-  const bool multi = devices.size() > 1;
+  // One GPU, nothing said: the loop over record blocks all the same - every input has a reader of its own there (the serial
+  // loop below reads them one after the other: 1.4 s against 0.9 - 1.0 s for 40 M reads and their index reads from tmpfs,
+  // profiles/r07_multi_dev_legs.txt).  FQGPU_SERIAL_LOOP=1 keeps the serial loop, which is also what --interleaved input
+  // runs through and a run that was started over on input cut at the gzgets limits (fq_respawn.h).
+  const bool block_loop = !has_interleaved && !fqhost::reframing() && !getenv("FQGPU_SERIAL_LOOP");
+  // (one context: a second one on the same GPU brought nothing that could be told from the noise - 200 M pairs to SAM 5.0 -
+  // 6.1 s with one, 5.4 - 5.5 with two; 40 M reads 1.01 against 1.10 - and costs 30 ms to open; FQGPU_DEVICES=0,0 asks for it)
+  if (devices.empty() && block_loop) devices.assign(1, dev ? atoi(dev) : 0);
+  const bool multi = block_loop ? !devices.empty() : devices.size() > 1;
   int rc = fqg_open(multi ? devices[0] : (dev ? atoi(dev) : 0), &g_ctx);
   if (rc != 0) {
     FQ_PRINT_ERROR("no usable MI355X GPU (fqg_open: %d); this build has no CPU path", rc);

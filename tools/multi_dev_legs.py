@@ -57,7 +57,7 @@ for label, cmd in LEGS:
         continue
     exe = os.path.join(REPO, "bin", cmd[0])
     base = None
-    for devs in ("", "0,0", "0,0,0"):
+    for devs in ("", "0", "0,0", "0,0,0") if "pre_barcodes" in label else ("", "0,0", "0,0,0"):
         env = dict(os.environ)
         env.pop("FQGPU_DEVICES", None)
         if devs:
