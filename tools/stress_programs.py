@@ -53,7 +53,7 @@ def main():
         ("fastq_pre_barcodes, three contexts", ["fastq_pre_barcodes", "--read1", "a.fastq.gz", "--read2", "b.fastq.gz", "--umi_read", "read1",
                                                   "--umi_offset", "0", "--umi_size", "8", "--read1_offset", "8", "--outfile1", "o1.fastq.gz",
                                                   "--outfile2", "o2.fastq.gz"], blocks, ["o1.fastq.gz", "o2.fastq.gz"]),
-        ("fastq_pre_barcodes --sam, nothing said (the record-block loop with two contexts on the GPU, pinned output buffers)",
+        ("fastq_pre_barcodes --sam, nothing said (the record-block loop with one context, pinned output buffers)",
          ["fastq_pre_barcodes", "--read1", "a.fastq.gz", "--read2", "b.fastq.gz", "--umi_read", "read1", "--umi_offset", "0", "--umi_size", "8",
           "--sam", "--outfile1", "-"], {"FQGPU_BLOCK_RECORDS": "2000"}, []),
         ("fastq_filterpair (one context; many at a time)", ["fastq_filterpair", "a.fastq.gz", "b.fastq.gz", "p1.fastq.gz", "p2.fastq.gz", "up.fastq.gz"],
