@@ -864,8 +864,21 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
     PA.index_only = 0u;
     PA.keep_from = ~0ull;
   }
+  // The LAST part is the small one: its line work has no pass-1 launch behind it to hide in - it is what runs alone
+  // at the end of the call - while the line work of the parts before it runs inside the next part's launch at next to no
+  // cost.  FQGPU_STREAM_LAST_PART_PCT (default 16: parts of 28 / 28 / 28 / 16 % of the image; 25: equal parts, as this was
+  // first built).  The line workers are not quite free - what the tail loses the launches gain back in part: one box, two
+  // runs each, ms per step: 25 % 7.89 / 7.96, 16 % 7.88 / 7.87, 12 % 7.96 / 7.90, 8 % 7.96 / 7.98, 5 % 8.19 / 8.20 (there
+  // pass 1 of the last part no longer outlasts the line workers of the part before).
+  const int last_pct = std::min(std::max(env_int_early("FQGPU_STREAM_LAST_PART_PCT", 16), 1), 100);
+  auto part_begin = [&](uint32_t part) -> uint32_t {
+    if (part == 0 || n_parts <= 1) return part == 0 ? 0u : n_spans;
+    if (part >= n_parts) return n_spans;
+    const uint32_t last = std::min<uint32_t>(n_spans - (n_parts - 1), std::max<uint32_t>(1u, (uint32_t)((uint64_t)n_spans * (uint32_t)last_pct / 100u)));
+    return (uint32_t)((uint64_t)(n_spans - last) * part / (n_parts - 1));
+  };
   for (uint32_t part = 0; part < n_parts; ++part) {
-    const uint32_t span_lo = (uint32_t)((uint64_t)n_spans * part / n_parts), span_hi = (uint32_t)((uint64_t)n_spans * (part + 1) / n_parts);
+    const uint32_t span_lo = part_begin(part), span_hi = part_begin(part + 1);
     const uint32_t chunk_lo = span_lo * kScanSpan, chunk_hi = std::min<uint32_t>(n_chunks, span_hi * kScanSpan);
     {
       ProfScope ps(c, want_names == 2 ? (part ? "k_stream_pass1_lines(digests)" : "k_stream_pass1(digests)")
