@@ -86,6 +86,14 @@ def test_parts_give_the_one_launch_result(shape):
             got = run(ctx, img, parts)
             assert got[0]["path"] == 3
             same(got, one)
+        # the last part's share of the image (FQGPU_STREAM_LAST_PART_PCT: where the cuts lie, nothing else)
+        for pct in ("1", "5", "40", "90"):
+            os.environ["FQGPU_STREAM_LAST_PART_PCT"] = pct
+            try:
+                same(run(ctx, img, 4), one)
+                same(run(ctx, img, 2), one)
+            finally:
+                os.environ.pop("FQGPU_STREAM_LAST_PART_PCT", None)
         against_oracle(run(ctx, img, 3), img)
         twice = run(ctx, img, 3, flags=A.VALIDATE_COUNT_TWICE)
         assert twice[1]["num_rds"] == 2 * one[1]["num_rds"] and twice[2] == one[2]
