@@ -870,6 +870,8 @@ int frame_stream(fqg_ctx* c, const uint8_t* d_img, uint64_t nbytes, uint32_t n_c
   // first built).  The line workers are not quite free - what the tail loses the launches gain back in part: one box, two
   // runs each, ms per step: 25 % 7.89 / 7.96, 16 % 7.88 / 7.87, 12 % 7.96 / 7.90, 8 % 7.96 / 7.98, 5 % 8.19 / 8.20 (there
   // pass 1 of the last part no longer outlasts the line workers of the part before).
+  // (The name modes, whose line workers store the line index as they go, like it too - the pass with digests, one box, two
+  // runs each: 25 % 10.10 / 10.12 ms + 0.34 behind it, 16 % 10.01 / 10.06 + 0.26.  Boxes differ by more than that.)
   const int last_pct = std::min(std::max(env_int_early("FQGPU_STREAM_LAST_PART_PCT", 16), 1), 100);
   auto part_begin = [&](uint32_t part) -> uint32_t {
     if (part == 0 || n_parts <= 1) return part == 0 ? 0u : n_spans;
